@@ -1,0 +1,46 @@
+#!/opt/conda/bin/python3.9
+"""Fixture extraction (runs ONLY in the build container, with /opt/conda/bin/python3.9 + h5py 3.3).
+
+Converts the two HDF5 data files the reference ships into .npz so that neither the oracle nor the
+tests need h5py (absent from the default interpreter and from the GPU box):
+
+  /root/reference/trackertraincode/facemodel/shapeparams_gmm.h5  -> tests/golden/shapeparams_gmm.npz
+      (10-component diagonal GMM over the 50 3DMM shape parameters; read by
+       trackertraincode/neuralnets/losses.py:100-104 through modelcomponents.py:246-257)
+  /root/reference/aflw2kmini.h5                                  -> tests/golden/aflw2kmini.npz
+      (16 AFLW2000-3D samples: JPEG byte blobs + coords/quats/rois/pt3d_68/shapeparams;
+       used by test/test_landmarks.py:26-29)
+
+These are DATA files (inputs), not reference source.
+"""
+import sys
+import numpy as np
+import h5py
+
+ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+out = sys.argv[2] if len(sys.argv) > 2 else "/root/repo/tests/golden"
+
+with h5py.File(f"{ref}/trackertraincode/facemodel/shapeparams_gmm.h5", "r") as f:
+    assert f.attrs["covariance_type"] == "diag"
+    np.savez(
+        f"{out}/shapeparams_gmm.npz",
+        weights=f["weights"][...],
+        means=f["means"][...],
+        cov=f["cov"][...],
+    )
+    print("gmm", f["weights"].shape, f["means"].shape, f["cov"].shape, f["weights"].dtype)
+
+with h5py.File(f"{ref}/aflw2kmini.h5", "r") as f:
+    def show(name, obj):
+        if isinstance(obj, h5py.Dataset):
+            print(name, obj.shape, obj.dtype, dict(obj.attrs))
+    f.visititems(show)
+    d = {}
+    imgs = f["images"]
+    blobs = [np.asarray(imgs[i]).astype(np.uint8) for i in range(imgs.shape[0])]
+    d["image_lengths"] = np.array([len(b) for b in blobs], dtype=np.int64)
+    d["image_bytes"] = np.concatenate(blobs)
+    for k in ["coords", "quats", "rois", "pt3d_68", "shapeparams"]:
+        d[k] = f[k][...]
+    np.savez(f"{out}/aflw2kmini.npz", **d)
+    print({k: (v.shape, v.dtype) for k, v in d.items()})
