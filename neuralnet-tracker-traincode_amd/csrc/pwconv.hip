@@ -1,0 +1,404 @@
+// Pointwise 1x1 convolutions as GEMMs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32,
+// bit-for-bit an fmaf chain, 64 cycles per issue per SIMD).  Reference: DepthWiseBlock.conv_sep +
+// bn_sep, backbones/mobilenet_v1.py:67-68,82-84; 95.7 % of the network's MACs.
+//
+//   forward    Y[M][N]  = relu(scale*Ydw + shift)[M][K] . W[N][K]^T          (+ sum(y), sum(y^2) per column)
+//   data grad  Gdw[M][K] = (dY[M][N] . W[N][K]) * [bn_dw(Ydw) > 0]            (+ sum(g), sum(g*ydw) per column)
+//   weight grad dW[N][K] += dY[M][N]^T . relu(scale*Ydw + shift)[M][K]
+// with dY = cA*G + cB*Y + cC formed while loading (BatchNorm backward folded into three
+// per-channel coefficients).  M = B*H*W rows of channels-last activations, so both operands of
+// forward/data-grad are row-major with the contraction index contiguous: 16-byte global loads,
+// ds_write_b128 into a +4-float padded LDS image, conflict-free ds_read_b128 fragments
+// (row stride 36 floats: 16 consecutive rows hit 16 distinct 4-bank groups).
+//
+// A ds_read_b128 hands each lane 4 consecutive k of its row; lanes 0-31 hold k=8s..8s+3 and lanes
+// 32-63 hold k=8s+4..8s+7, so the j-th register of both operands forms the k-pair {8s+j, 8s+4+j} of
+// one 32x32x2 MFMA - the sum over k is order-free, so no shuffling is needed.
+#include "ttk_common.h"
+
+namespace ttk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = TTK_GEMM_BLOCK_M;  // 128 rows of M per workgroup
+constexpr int BKT = 32;               // contraction slice per LDS stage
+constexpr int LDP = BKT + 4;          // padded LDS row (floats)
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+template <int BN, int WM, int WN, int MODE>
+__global__ void __launch_bounds__(kBlock) pw_gemm_k(const float* __restrict__ A0, const float* __restrict__ A1,
+                                                     const float* __restrict__ c0, const float* __restrict__ c1,
+                                                     const float* __restrict__ c2, const float* __restrict__ Bm,
+                                                     float* __restrict__ out, const float* __restrict__ E0,
+                                                     const float* __restrict__ e0, const float* __restrict__ e1,
+                                                     float* __restrict__ part, int64_t M, int K, int Nout) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_PASSES = BM * BKT / 4 / kBlock;  // 4
+  constexpr int B_PASSES = (BN * BKT / 4 + kBlock - 1) / kBlock;
+  __shared__ __attribute__((aligned(16))) float As[2][BM][LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDP];
+  __shared__ float stat[2][BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int64_t m0 = (int64_t)blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+  const int lrow = tid >> 3, kq = (tid & 7) * 4;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra0[A_PASSES], ra1[MODE == MODE_DGRAD ? A_PASSES : 1], rb[B_PASSES];
+  const int nk = K / BKT;
+
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BKT + kq;
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+      const int64_t row = m0 + p * 32 + lrow;
+      ra0[p] = (row < M) ? ld4(A0 + row * K + k0) : f4(0.f);
+      if constexpr (MODE == MODE_DGRAD) ra1[p] = (row < M) ? ld4(A1 + row * K + k0) : f4(0.f);
+    }
+#pragma unroll
+    for (int p = 0; p < B_PASSES; ++p) {
+      const int row = p * 32 + lrow;
+      if (row < BN) rb[p] = ld4(Bm + (size_t)(n0 + row) * K + k0);
+    }
+  };
+  auto store_tile = [&](int kt, int buf) {
+    const int k0 = kt * BKT + kq;
+    const float4 q0 = ld4(c0 + k0), q1 = ld4(c1 + k0);
+    float4 q2 = f4(0.f);
+    if constexpr (MODE == MODE_DGRAD) q2 = ld4(c2 + k0);
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+      const int64_t row = m0 + p * 32 + lrow;
+      float4 v;
+      if constexpr (MODE == MODE_FWD) v = relu4(fma4(q0, ra0[p], q1));
+      else v = fma4(q0, ra0[p], fma4(q1, ra1[p], q2));
+      if (row >= M) v = f4(0.f);
+      st4(&As[buf][p * 32 + lrow][kq], v);
+    }
+#pragma unroll
+    for (int p = 0; p < B_PASSES; ++p) {
+      const int row = p * 32 + lrow;
+      if (row < BN) st4(&Bs[buf][row][kq], rb[p]);
+    }
+  };
+
+  load_tile(0);
+  store_tile(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const int fr = lane & 31, fk = 4 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < BKT / 8; ++ks) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = ld4(&As[buf][wm * (BM / WM) + i * 32 + fr][8 * ks + fk]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = ld4(&Bs[buf][wn * (BN / WN) + j * 32 + fr][8 * ks + fk]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) store_tile(kt + 1, buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    s1[j] = 0.f;
+    s2[j] = 0.f;
+    const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+    float esc = 0.f, esh = 0.f;
+    if constexpr (MODE == MODE_DGRAD) { esc = e0[col]; esh = e1[col]; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M) {
+          float v = acc[i][j][r];
+          const size_t o = (size_t)row * Nout + col;
+          if constexpr (MODE == MODE_FWD) {
+            out[o] = v;
+            s1[j] += v;
+            s2[j] = fmaf(v, v, s2[j]);
+          } else {
+            const float yo = E0[o];
+            v = (fmaf(esc, yo, esh) > 0.f) ? v : 0.f;
+            out[o] = v;
+            s1[j] += v;
+            s2[j] = fmaf(v, yo, s2[j]);
+          }
+        }
+      }
+    }
+    s1[j] += __shfl_xor(s1[j], 32);  // the two lane halves hold different rows of the same column
+    s2[j] += __shfl_xor(s2[j], 32);
+  }
+  if (part) {
+    for (int i = tid; i < 2 * BN; i += kBlock) (&stat[0][0])[i] = 0.f;
+    __syncthreads();
+    for (int w = 0; w < WM; ++w) {  // fixed order over the waves that share columns: reproducible
+      if (wm == w && lane < 32) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int cl = wn * (BN / WN) + j * 32 + lane;
+          stat[0][cl] += s1[j];
+          stat[1][cl] += s2[j];
+        }
+      }
+      __syncthreads();
+    }
+    float* prow = part + (size_t)blockIdx.y * 2 * Nout;
+    for (int i = tid; i < BN; i += kBlock) {
+      prow[n0 + i] = stat[0][i];
+      prow[Nout + n0 + i] = stat[1][i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient: contraction over M.  Both operand tiles stay in their NATURAL layout
+// ([32 rows of M][channels], channels contiguous): the MFMA wants, for A, lane (i=l&31, k=l>>5) =
+// dY[m=2s+k][n=i] and for B lane (k, j) = a[m=2s+k][c=j], i.e. 32 consecutive floats of one row per
+// half-wave: conflict-free ds_read_b32 with no transpose anywhere.
+// Work split: grid.x = output tiles of dW, grid.y = slices of M; each wave may additionally own a
+// slice of the 32-row stage (WS) when the dW tile is too small to feed 4 waves.
+// ---------------------------------------------------------------------------------------------
+template <int BN, int BK, int WR, int WC, int WS>
+__global__ void __launch_bounds__(kBlock) pw_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y,
+                                                      const float* __restrict__ cA, const float* __restrict__ cB,
+                                                      const float* __restrict__ cC, const float* __restrict__ Ydw,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      float* __restrict__ dW, int64_t M, int Cin, int Cout,
+                                                      int64_t rows_per_slice) {
+  static_assert(WR * WC * WS == 4, "4 waves");
+  constexpr int TR = BN / WR / 32, TC = BK / WC / 32;
+  constexpr int MS = 32;  // rows of M per stage
+  constexpr int D_PASSES = (MS * BN / 4 + kBlock - 1) / kBlock;
+  constexpr int A_PASSES = (MS * BK / 4 + kBlock - 1) / kBlock;
+  __shared__ __attribute__((aligned(16))) float Ds[2][MS][BN + 4];
+  __shared__ __attribute__((aligned(16))) float As[2][MS][BK + 4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ws = wave % WS, wc = (wave / WS) % WC, wr = wave / (WS * WC);
+  const int tiles_k = Cin / BK;
+  const int n0 = (blockIdx.x / tiles_k) * BN, k0 = (blockIdx.x % tiles_k) * BK;
+  const int64_t m_begin = (int64_t)blockIdx.y * rows_per_slice;
+  const int64_t m_end = (m_begin + rows_per_slice < M) ? m_begin + rows_per_slice : M;
+  if (m_begin >= m_end) return;
+
+  f32x16 acc[TR][TC];
+#pragma unroll
+  for (int i = 0; i < TR; ++i)
+#pragma unroll
+    for (int j = 0; j < TC; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 rg[D_PASSES], ry[D_PASSES], ra[A_PASSES];
+  auto load_stage = [&](int64_t ms) {
+#pragma unroll
+    for (int p = 0; p < D_PASSES; ++p) {
+      const int f = p * kBlock + tid;
+      const int row = f / (BN / 4), q = f % (BN / 4);
+      const int64_t m = ms + row;
+      if (row < MS && m < m_end) {
+        rg[p] = ld4(G + m * Cout + n0 + 4 * q);
+        ry[p] = ld4(Y + m * Cout + n0 + 4 * q);
+      } else {
+        rg[p] = f4(0.f);
+        ry[p] = f4(0.f);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+      const int f = p * kBlock + tid;
+      const int row = f / (BK / 4), q = f % (BK / 4);
+      const int64_t m = ms + row;
+      ra[p] = (row < MS && m < m_end) ? ld4(Ydw + m * Cin + k0 + 4 * q) : f4(0.f);
+    }
+  };
+  auto store_stage = [&](int64_t ms, int buf) {
+#pragma unroll
+    for (int p = 0; p < D_PASSES; ++p) {
+      const int f = p * kBlock + tid;
+      const int row = f / (BN / 4), q = f % (BN / 4);
+      if (row < MS) {
+        const int c = n0 + 4 * q;
+        float4 v = fma4(ld4(cA + c), rg[p], fma4(ld4(cB + c), ry[p], ld4(cC + c)));
+        if (ms + row >= m_end) v = f4(0.f);
+        st4(&Ds[buf][row][4 * q], v);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+      const int f = p * kBlock + tid;
+      const int row = f / (BK / 4), q = f % (BK / 4);
+      if (row < MS) {
+        const int c = k0 + 4 * q;
+        float4 v = relu4(fma4(ld4(scale + c), ra[p], ld4(shift + c)));
+        if (ms + row >= m_end) v = f4(0.f);
+        st4(&As[buf][row][4 * q], v);
+      }
+    }
+  };
+
+  load_stage(m_begin);
+  store_stage(m_begin, 0);
+  __syncthreads();
+  int it = 0;
+  for (int64_t ms = m_begin; ms < m_end; ms += MS, ++it) {
+    const int buf = it & 1;
+    const bool more = ms + MS < m_end;
+    if (more) load_stage(ms + MS);
+    constexpr int PAIRS = MS / 2 / WS;  // m-pairs this wave multiplies per stage
+#pragma unroll
+    for (int s = 0; s < PAIRS; ++s) {
+      const int mrow = 2 * (ws * PAIRS + s) + (lane >> 5);
+      float a_op[TR], b_op[TC];
+#pragma unroll
+      for (int i = 0; i < TR; ++i) a_op[i] = Ds[buf][mrow][wr * (BN / WR) + i * 32 + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < TC; ++j) b_op[j] = As[buf][mrow][wc * (BK / WC) + j * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_op[i], b_op[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_stage(ms + MS, buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < TR; ++i)
+#pragma unroll
+    for (int j = 0; j < TC; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wr * (BN / WR) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int k = k0 + wc * (BK / WC) + j * 32 + (lane & 31);
+        atomicAdd(dW + (size_t)n * Cin + k, acc[i][j][r]);
+      }
+}
+
+__global__ void __launch_bounds__(kBlock) transpose_k(const float* __restrict__ in, float* __restrict__ out, int rows,
+                                                       int cols) {
+  __shared__ float t[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < rows && c0 + tx < cols) t[i][tx] = in[(size_t)(r0 + i) * cols + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < cols && r0 + tx < rows) out[(size_t)(c0 + i) * rows + r0 + tx] = t[tx][i];
+}
+
+static bool pw_shape_ok(int64_t M, int Cin, int Cout) {
+  auto p2 = [](int v) { return v >= 32 && v <= 1024 && (v & (v - 1)) == 0; };
+  return M > 0 && p2(Cin) && p2(Cout);
+}
+
+template <int MODE>
+static void launch_gemm(const float* A0, const float* A1, const float* c0, const float* c1, const float* c2, const float* Bm,
+                        float* out, const float* E0, const float* e0, const float* e1, float* part, int64_t M, int K,
+                        int Nout, hipStream_t st) {
+  const dim3 blk(kBlock);
+  const unsigned gm = (unsigned)ceil_div(M, BM);
+  if (Nout >= 128)
+    hipLaunchKernelGGL((pw_gemm_k<128, 2, 2, MODE>), dim3(Nout / 128, gm), blk, 0, st, A0, A1, c0, c1, c2, Bm, out, E0, e0, e1,
+                       part, M, K, Nout);
+  else if (Nout == 64)
+    hipLaunchKernelGGL((pw_gemm_k<64, 2, 2, MODE>), dim3(1, gm), blk, 0, st, A0, A1, c0, c1, c2, Bm, out, E0, e0, e1, part, M,
+                       K, Nout);
+  else
+    hipLaunchKernelGGL((pw_gemm_k<32, 4, 1, MODE>), dim3(1, gm), blk, 0, st, A0, A1, c0, c1, c2, Bm, out, E0, e0, e1, part, M,
+                       K, Nout);
+}
+
+}  // namespace ttk
+
+using namespace ttk;
+
+extern "C" {
+
+int ttk_pwconv1x1_fwd(const float* ydw, const float* scale, const float* shift, const float* w, float* y, float* part,
+                      int64_t M, int Cin, int Cout, ttk_stream_t stream) {
+  TTK_REQUIRE(ydw && scale && shift && w && y, "pwconv1x1_fwd: null pointer");
+  TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_fwd: unsupported shape M=%lld Cin=%d Cout=%d (channels: powers of two in 32..1024)", (long long)M, Cin, Cout);
+  TTK_REQUIRE(ceil_div(M, BM) <= 65535, "pwconv1x1_fwd: M=%lld too large for one launch", (long long)M);
+  launch_gemm<MODE_FWD>(ydw, nullptr, scale, shift, nullptr, w, y, nullptr, nullptr, nullptr, part, M, Cin, Cout,
+                        (hipStream_t)stream);
+  TTK_LAUNCH_CHECK("pwconv1x1_fwd");
+}
+
+int ttk_pwconv1x1_bwd_data(const float* g, const float* y, const float* cA, const float* cB, const float* cC, const float* wt,
+                           const float* ydw, const float* scale_dw, const float* shift_dw, float* g_dw, float* part, int64_t M,
+                           int Cin, int Cout, ttk_stream_t stream) {
+  TTK_REQUIRE(g && y && cA && cB && cC && wt && ydw && scale_dw && shift_dw && g_dw, "pwconv1x1_bwd_data: null pointer");
+  TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_bwd_data: unsupported shape");
+  TTK_REQUIRE(ceil_div(M, BM) <= 65535, "pwconv1x1_bwd_data: M too large for one launch");
+  // contraction over Cout, output columns = Cin, B operand = wt[Cin][Cout]
+  launch_gemm<MODE_DGRAD>(g, y, cA, cB, cC, wt, g_dw, ydw, scale_dw, shift_dw, part, M, Cout, Cin, (hipStream_t)stream);
+  TTK_LAUNCH_CHECK("pwconv1x1_bwd_data");
+}
+
+int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* cA, const float* cB, const float* cC,
+                             const float* ydw, const float* scale_dw, const float* shift_dw, float* dw, int64_t M, int Cin,
+                             int Cout, ttk_stream_t stream) {
+  TTK_REQUIRE(g && y && cA && cB && cC && ydw && scale_dw && shift_dw && dw, "pwconv1x1_bwd_weight: null pointer");
+  TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_bwd_weight: unsupported shape");
+  const int bn = Cout >= 128 ? 128 : Cout, bk = Cin >= 128 ? 128 : Cin;
+  const int tiles = (Cout / bn) * (Cin / bk);
+  int64_t slices = 1024 / tiles;
+  const int64_t max_slices = ceil_div(M, 256);
+  if (slices > max_slices) slices = max_slices;
+  if (slices < 1) slices = 1;
+  int64_t rows = ceil_div(ceil_div(M, slices), 32) * 32;
+  slices = ceil_div(M, rows);
+  const dim3 grid(tiles, (unsigned)slices), blk(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+#define TTK_WG(BN_, BK_, WR_, WC_, WS_)                                                                               \
+  hipLaunchKernelGGL((pw_wgrad_k<BN_, BK_, WR_, WC_, WS_>), grid, blk, 0, st, g, y, cA, cB, cC, ydw, scale_dw, shift_dw, dw, \
+                     M, Cin, Cout, rows)
+  if (bn == 128 && bk == 128) TTK_WG(128, 128, 2, 2, 1);
+  else if (bn == 128 && bk == 64) TTK_WG(128, 64, 2, 2, 1);
+  else if (bn == 128 && bk == 32) TTK_WG(128, 32, 4, 1, 1);
+  else if (bn == 64 && bk == 128) TTK_WG(64, 128, 2, 2, 1);
+  else if (bn == 64 && bk == 64) TTK_WG(64, 64, 2, 2, 1);
+  else if (bn == 64 && bk == 32) TTK_WG(64, 32, 2, 1, 2);
+  else if (bn == 32 && bk == 128) TTK_WG(32, 128, 1, 4, 1);
+  else if (bn == 32 && bk == 64) TTK_WG(32, 64, 1, 2, 2);
+  else TTK_WG(32, 32, 1, 1, 4);
+#undef TTK_WG
+  TTK_LAUNCH_CHECK("pwconv1x1_bwd_weight");
+}
+
+int ttk_transpose(const float* in, float* out, int rows, int cols, ttk_stream_t stream) {
+  TTK_REQUIRE(in && out && rows > 0 && cols > 0, "transpose: bad arguments");
+  hipLaunchKernelGGL(transpose_k, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(kBlock), 0, (hipStream_t)stream, in, out, rows,
+                     cols);
+  TTK_LAUNCH_CHECK("transpose");
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// Shared device/host helpers for libttk_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ttk.h"
+
+namespace ttk {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;  // 4 waves: one per SIMD of a CU
+
+void set_error(const char* fmt, ...);
+
+// Host-side argument check: records the message and returns a negative code from the entry point.
+#define TTK_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      ::ttk::set_error(__VA_ARGS__);    \
+      return -1;                        \
+    }                                   \
+  } while (0)
+
+// After a launch: report the HIP error of this thread, if any (no synchronisation).
+#define TTK_LAUNCH_CHECK(name)                                              \
+  do {                                                                      \
+    hipError_t e_ = hipGetLastError();                                      \
+    if (e_ != hipSuccess) {                                                 \
+      ::ttk::set_error("%s: %s", name, hipGetErrorString(e_));              \
+      return (int)e_;                                                       \
+    }                                                                       \
+    return 0;                                                               \
+  } while (0)
+
+__host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+inline int elementwise_grid(int64_t items) {
+  int64_t g = ceil_div(items, kBlock);
+  if (g > TTK_MAX_PARTIAL_ROWS_ELEMENTWISE) g = TTK_MAX_PARTIAL_ROWS_ELEMENTWISE;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---- float4 helpers -------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+  return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) {
+  return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+__device__ __forceinline__ float4 relu4(float4 a) {
+  return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
+}
+// g * [a > 0]
+__device__ __forceinline__ float4 mask4(float4 g, float4 a) {
+  return make_float4(a.x > 0.f ? g.x : 0.f, a.y > 0.f ? g.y : 0.f, a.z > 0.f ? g.z : 0.f, a.w > 0.f ? g.w : 0.f);
+}
+
+// The "apply on load" forms of BatchNorm (see ttk.h):
+//   forward : a  = max(scale*y + shift (+skip), 0)
+//   backward: dy = cA*g + cB*y + cC
+struct BnApply4 {
+  float4 scale, shift;
+  __device__ __forceinline__ float4 pre(float4 y) const { return fma4(scale, y, shift); }
+  __device__ __forceinline__ float4 act(float4 y) const { return relu4(pre(y)); }
+  __device__ __forceinline__ float4 act(float4 y, float4 skip) const { return relu4(add4(pre(y), skip)); }
+};
+struct BnGrad4 {
+  float4 a, b, c;
+  __device__ __forceinline__ float4 dy(float4 g, float4 y) const { return fma4(a, g, fma4(b, y, c)); }
+};
+
+// ---- per-channel partial sums of a workgroup -------------------------------------------------
+// Every thread of the block owns channel quad `c4` (4 consecutive channels starting at 4*c4) and
+// has accumulated s1/s2 over its items.  Lanes that own the same quad are folded with wave
+// shuffles (they sit `lanes_per_item` apart), then the waves meet in LDS; the block writes ONE row
+// part[row][2][C].  Deterministic: no global atomics.
+template <int MAXC>
+__device__ __forceinline__ void block_channel_partials(float4 s1, float4 s2, int c4, int C, float* part_row,
+                                                        float* smem /* [2*MAXC] */) {
+  const int tid = threadIdx.x;
+  const int quads = C >> 2;  // threads per item (power of two, 8..256)
+  // fold lanes of one wave that own the same quad: strides quads, 2*quads, ... < 64
+  for (int off = quads; off < kWave; off <<= 1) {
+    s1.x += __shfl_xor(s1.x, off); s1.y += __shfl_xor(s1.y, off);
+    s1.z += __shfl_xor(s1.z, off); s1.w += __shfl_xor(s1.w, off);
+    s2.x += __shfl_xor(s2.x, off); s2.y += __shfl_xor(s2.y, off);
+    s2.z += __shfl_xor(s2.z, off); s2.w += __shfl_xor(s2.w, off);
+  }
+  for (int i = tid; i < 2 * C; i += kBlock) smem[i] = 0.f;
+  __syncthreads();
+  const int lane = tid & (kWave - 1);
+  const bool owner = (quads >= kWave) || (lane < quads);
+  // fixed-order accumulation (wave 0, then 1, ...): bitwise reproducible, no LDS atomics
+  for (int w = 0; w < kBlock / kWave; ++w) {
+    if ((tid >> 6) == w && owner) {
+      float* d = smem + 4 * c4;
+      d[0] += s1.x; d[1] += s1.y; d[2] += s1.z; d[3] += s1.w;
+      d += C;
+      d[0] += s2.x; d[1] += s2.y; d[2] += s2.z; d[3] += s2.w;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < 2 * C; i += kBlock) part_row[i] = smem[i];
+}
+
+}  // namespace ttk

@@ -1,0 +1,102 @@
+"""ctypes binding of libttk_hip.so (C-ABI: include/ttk.h).
+
+There is NO fallback: if the shared object is missing or a symbol is absent, importing the kernels
+raises; an entry point that returns non-zero raises RuntimeError(ttk_last_error_string()).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libttk_hip.so")
+
+_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+
+# name -> argument types (the trailing stream pointer is added automatically)
+_SIGNATURES = {
+    "ttk_bn_fwd_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P],
+    "ttk_bn_eval_prepare": [_P, _P, _P, _P, _F, _I, _P, _P],
+    "ttk_bn_bwd_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I],
+    "ttk_stem_fwd": [_P, _P, _P, _P, _I, _I, _I],
+    "ttk_stem_bwd_weight": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "ttk_dwconv3x3_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
+    "ttk_dwconv3x3_bwd_data": [_P] * 14 + [_I] * 5,
+    "ttk_dwconv3x3_bwd_weight": [_P] * 11 + [_I] * 6,
+    "ttk_pwconv1x1_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I],
+    "ttk_pwconv1x1_bwd_data": [_P] * 11 + [_L, _I, _I],
+    "ttk_pwconv1x1_bwd_weight": [_P] * 9 + [_L, _I, _I],
+    "ttk_transpose": [_P, _P, _I, _I],
+    "ttk_avgpool_fwd": [_P, _P, _P, _P, _P, _I, _I, _I],
+    "ttk_avgpool_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I],
+    "ttk_bn_act": [_P, _P, _P, _P, _P, _L, _I],
+}
+
+ABI_VERSION = 1
+
+
+class _Library:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP kernels are not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
+                "neuralnet-tracker-traincode_amd/csrc`). There is no CPU/PyTorch fallback for the training path."
+            )
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.cdll.ttk_last_error_string.restype = c_char_p
+        self.cdll.ttk_abi_version.restype = c_int
+        v = self.cdll.ttk_abi_version()
+        if v != ABI_VERSION:
+            raise RuntimeError(f"libttk_hip.so ABI version {v}, host expects {ABI_VERSION}: rebuild")
+        for name in ("ttk_partial_rows_elementwise", "ttk_partial_rows_gemm"):
+            fn = getattr(self.cdll, name)
+            fn.argtypes, fn.restype = [c_int64], c_int
+        self._fns = {}
+        for name, sig in _SIGNATURES.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the symbol is missing: loud by design
+            fn.argtypes = list(sig) + [c_void_p]
+            fn.restype = c_int
+            self._fns[name] = fn
+
+    def call(self, name: str, *args):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = self._fns[name](*args, stream)
+        if rc != 0:
+            msg = self.cdll.ttk_last_error_string().decode(errors="replace")
+            raise RuntimeError(f"{name} failed (code {rc}): {msg}")
+
+    def partial_rows_elementwise(self, items: int) -> int:
+        return self.cdll.ttk_partial_rows_elementwise(items)
+
+    def partial_rows_gemm(self, m: int) -> int:
+        return self.cdll.ttk_partial_rows_gemm(m)
+
+
+_lib: _Library | None = None
+
+
+def lib() -> _Library:
+    global _lib
+    if _lib is None:
+        _lib = _Library()
+    return _lib
+
+
+def ptr(t: torch.Tensor | None):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("HIP entry point received a non-CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError("HIP entry point received a non-contiguous tensor")
+    return t.data_ptr()
+
+
+def exported_symbols() -> list[str]:
+    return ["ttk_abi_version", "ttk_last_error_string", "ttk_partial_rows_elementwise",
+            "ttk_partial_rows_gemm"] + list(_SIGNATURES)

@@ -1,0 +1,381 @@
+"""MobileNetV1-style backbone of the pose estimator on MI355X.
+
+Drop-in for the reference's `trackertraincode/backbones/mobilenet_v1.py` (`MobileNet` :95-189,
+`DepthWiseBlock` :36-92): same constructor signature, attribute / state-dict names and return
+convention `(features[B,F], [z65, z33, z17, z9, z5])`, but the arithmetic is one autograd node whose
+forward and backward launch the HIP kernels of ../../csrc through the C-ABI (include/ttk.h):
+
+    stem 5x5 s2 -> 13 x (depthwise 3x3 -> pointwise 1x1 on fp32 MFMA) -> global average pool
+
+Data layout in HBM: activations are fp32 channels-last (`[B, H, W, C]`; exposed to PyTorch as NCHW
+tensors with channels_last strides).  Every conv writes its RAW output once, BatchNorm statistics
+come out of the conv's epilogue, and BN + ReLU (+ residual) are applied by the consumer while
+loading (forward) - backward mirrors this with three per-channel coefficients (see include/ttk.h).
+
+There is no PyTorch fallback for training: on CUDA tensors the HIP path runs or raises.
+CPU tensors are accepted in eval mode only (the ONNX-export / checkpoint-inspection surface of
+scripts/export_model.py), through plain torch ops.
+"""
+from __future__ import annotations
+
+import math
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _hip
+
+__all__ = ["MobileNet", "DepthWiseBlock"]
+
+NormalizationLayer = nn.BatchNorm2d
+ActivationFunc = nn.ReLU
+
+# (name, in, out, stride) of the 13 depthwise-separable blocks - reference mobilenet_v1.py:128-140
+_BLOCKS = (
+    ("dw2_1", 32, 64, 1), ("dw2_2", 64, 128, 2), ("dw3_1", 128, 128, 1), ("dw3_2", 128, 256, 2),
+    ("dw4_1", 256, 256, 1), ("dw4_2", 256, 512, 2), ("dw5_1", 512, 512, 1), ("dw5_2", 512, 512, 1),
+    ("dw5_3", 512, 512, 1), ("dw5_4", 512, 512, 1), ("dw5_5", 512, 512, 1), ("dw5_6", 512, 1024, 2),
+    ("dw6", 1024, 1024, 1),
+)
+_INTERMEDIATES = ("dw2_1", "dw3_1", "dw4_1", "dw5_5", "dw6")
+
+
+class DepthWiseBlock(nn.Module):
+    """Parameter container with the reference's names (conv_dw, bn_dw, conv_sep, bn_sep); the
+    arithmetic of `forward` lives in the fused backbone function below.  Reference :36-92."""
+
+    def __init__(self, inplanes, planes, stride=1, momentum=0.1, stochastic_depth=None, use_blurpool=True):
+        super().__init__()
+        assert stride in (1, 2)
+        self.inplanes, self.planes = inplanes, planes = int(inplanes), int(planes)
+        self.stride = stride
+        if stride == 2 and use_blurpool:
+            raise NotImplementedError(
+                "use_blurpool=True (kornia BlurPool2D before strided depthwise convs) is not built: "
+                "off in every BASELINE config, parity unpinned (SURVEY.md §8c)"
+            )
+        if stochastic_depth:
+            raise NotImplementedError("stochastic_depth is never enabled by the reference's pose estimator")
+        self.conv_dw = nn.Conv2d(inplanes, inplanes, kernel_size=3, padding=1, stride=stride, groups=inplanes, bias=False)
+        self.bn_dw = NormalizationLayer(inplanes, momentum=momentum)
+        self.conv_sep = nn.Conv2d(inplanes, planes, kernel_size=1, stride=1, padding=0, bias=False)
+        self.bn_sep = NormalizationLayer(planes, momentum=momentum)
+        self.relu = nn.ReLU(inplace=True)
+        self.skip_connection = not (stride != 1 or inplanes != planes)
+        self.stochastic_depth = None
+
+    def forward(self, x):  # eval/export path in plain torch ops (CPU); training goes through MobileNet
+        out = self.relu(self.bn_dw(self.conv_dw(x)))
+        out = self.bn_sep(self.conv_sep(out))
+        if self.skip_connection:
+            out = out + x
+        return self.relu(out)
+
+
+class _Bn(NamedTuple):
+    """Per-layer BatchNorm constants on the device: rows of one [7, C] tensor."""
+    scale: torch.Tensor
+    shift: torch.Tensor
+    mean: torch.Tensor
+    rstd: torch.Tensor
+    cA: torch.Tensor
+    cB: torch.Tensor
+    cC: torch.Tensor
+
+
+def _bn_work(C, device) -> _Bn:
+    t = torch.empty((7, C), dtype=torch.float32, device=device)
+    return _Bn(*t.unbind(0))
+
+
+class _Stage(NamedTuple):
+    y: torch.Tensor            # raw conv output [B,H,W,C]
+    bn: _Bn
+    skip: torch.Tensor | None  # residual input added before the ReLU of this stage's output
+
+
+def _part_buffer(B, H, W, device):
+    """One scratch buffer large enough for every layer's [rows][2][C] partial sums."""
+    L = _hip.lib()
+    need = 0
+    h = (H + 1) // 2
+    need = max(need, L.partial_rows_elementwise(B * h * h * 8) * 2 * 32)
+    for _, cin, cout, stride in _BLOCKS:
+        ho = (h - 1) // stride + 1
+        need = max(need, L.partial_rows_elementwise(B * h * h * (cin // 4)) * 2 * cin)    # dw bwd-data (input grid)
+        need = max(need, L.partial_rows_elementwise(B * ho * ho * (cin // 4)) * 2 * cin)  # dw fwd
+        need = max(need, L.partial_rows_gemm(B * ho * ho) * 2 * max(cin, cout))            # pw fwd / bwd-data
+        need = max(need, L.partial_rows_elementwise(B * ho * ho * (cout // 4)) * 2 * cout)  # pool bwd
+        h = ho
+    return torch.empty(need, dtype=torch.float32, device=device)
+
+
+class _Ctx:
+    """Everything one forward pass leaves behind for its backward."""
+    __slots__ = ("x", "stages", "a_in", "part", "dims", "pool_skip", "wparams", "HW", "B")
+
+
+def _forward_impl(x, params, buffers, momentum, eps, training):
+    """Launches the forward kernels.  `params`: flat list [conv1.w, bn1.w, bn1.b, (dw.w, bn_dw.w,
+    bn_dw.b, pw.w, bn_sep.w, bn_sep.b) x 13]; `buffers`: flat list of (running_mean, running_var,
+    num_batches_tracked) per BN in the same order."""
+    L = _hip.lib()
+    p = _hip.ptr
+    dev = x.device
+    B, _, H, W = x.shape
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    part = _part_buffer(B, H, W, dev)
+    ctx = _Ctx()
+    ctx.x, ctx.part, ctx.B = x, part, B
+    ctx.stages, ctx.a_in, ctx.dims = [], [], []
+
+    def finalize(bn: _Bn, rows, C, count, gamma, beta, bi):
+        rm, rv, nbt = buffers[3 * bi], buffers[3 * bi + 1], buffers[3 * bi + 2]
+        if training:
+            L.call("ttk_bn_fwd_finalize", p(part), rows, C, count, p(gamma), p(beta), p(rm), p(rv), p(nbt),
+                   float(momentum), float(eps), p(bn.scale), p(bn.shift), p(bn.mean), p(bn.rstd))
+        else:
+            L.call("ttk_bn_eval_prepare", p(gamma), p(beta), p(rm), p(rv), float(eps), C, p(bn.scale), p(bn.shift))
+
+    part_arg = p(part) if training else None
+    # ---- stem (reference :122-126,161-163)
+    y0 = torch.empty((B, Ho, Wo, 32), dtype=torch.float32, device=dev)
+    L.call("ttk_stem_fwd", p(x), p(params[0]), p(y0), part_arg, B, H, W)
+    bn = _bn_work(32, dev)
+    finalize(bn, L.partial_rows_elementwise(B * Ho * Wo * 8), 32, B * Ho * Wo, params[1], params[2], 0)
+    prev = _Stage(y0, bn, None)
+    ctx.stages.append(prev)
+    h, w_ = Ho, Wo
+    pi, bi = 3, 1
+    for name, cin, cout, stride in _BLOCKS:
+        w_dw, g_dw, b_dw, w_pw, g_pw, b_pw = params[pi:pi + 6]
+        pi += 6
+        has_skip = stride == 1 and cin == cout
+        ho, wo = (h - 1) // stride + 1, (w_ - 1) // stride + 1
+        a_in = torch.empty_like(prev.y) if has_skip else None
+        ydw = torch.empty((B, ho, wo, cin), dtype=torch.float32, device=dev)
+        L.call("ttk_dwconv3x3_fwd", p(prev.y), p(prev.bn.scale), p(prev.bn.shift), p(prev.skip), p(a_in), p(w_dw), p(ydw),
+               part_arg, B, h, w_, cin, stride)
+        bn_dw = _bn_work(cin, dev)
+        finalize(bn_dw, L.partial_rows_elementwise(B * ho * wo * (cin // 4)), cin, B * ho * wo, g_dw, b_dw, bi)
+        ypw = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=dev)
+        M = B * ho * wo
+        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw.scale), p(bn_dw.shift), p(w_pw), p(ypw), part_arg, M, cin, cout)
+        bn_pw = _bn_work(cout, dev)
+        finalize(bn_pw, L.partial_rows_gemm(M), cout, M, g_pw, b_pw, bi + 1)
+        bi += 2
+        ctx.stages.append(_Stage(ydw, bn_dw, None))
+        prev = _Stage(ypw, bn_pw, a_in)
+        ctx.stages.append(prev)
+        ctx.a_in.append(a_in)
+        ctx.dims.append((h, w_, ho, wo, cin, cout, stride, has_skip))
+        h, w_ = ho, wo
+    C = prev.y.shape[-1]
+    feat = torch.empty((B, C), dtype=torch.float32, device=dev)
+    L.call("ttk_avgpool_fwd", p(prev.y), p(prev.bn.scale), p(prev.bn.shift), p(prev.skip), p(feat), B, h * w_, C)
+    ctx.HW = h * w_
+    return feat, ctx
+
+
+def _backward_impl(ctx: _Ctx, gfeat, params):
+    L = _hip.lib()
+    p = _hip.ptr
+    B, part = ctx.B, ctx.part
+    grads = [None] * len(params)
+    last = ctx.stages[-1]
+    C = last.y.shape[-1]
+
+    def bwd_finalize(stage: _Stage, rows, count, gi):
+        """BatchNorm backward constants of `stage` + its dgamma/dbeta -> grads[gi], grads[gi+1]"""
+        Cc = stage.y.shape[-1]
+        dgamma = torch.empty(Cc, dtype=torch.float32, device=gfeat.device)
+        dbeta = torch.empty(Cc, dtype=torch.float32, device=gfeat.device)
+        L.call("ttk_bn_bwd_finalize", p(part), rows, Cc, count, p(params[gi]), p(stage.bn.mean), p(stage.bn.rstd),
+               p(stage.bn.cA), p(stage.bn.cB), p(stage.bn.cC), p(dgamma), p(dbeta), 0)
+        grads[gi], grads[gi + 1] = dgamma, dbeta
+
+    g = torch.empty_like(last.y)
+    L.call("ttk_avgpool_bwd", p(gfeat), p(last.y), p(last.bn.scale), p(last.bn.shift), p(last.skip), p(g), p(part), B, ctx.HW, C)
+    bwd_finalize(last, L.partial_rows_elementwise(B * ctx.HW * (C // 4)), B * ctx.HW, len(params) - 2)
+
+    for k in range(len(_BLOCKS) - 1, -1, -1):
+        h, w_, ho, wo, cin, cout, stride, has_skip = ctx.dims[k]
+        pi = 3 + 6 * k
+        w_dw, w_pw = params[pi], params[pi + 3]
+        st_prev, st_dw, st_pw = ctx.stages[2 * k], ctx.stages[2 * k + 1], ctx.stages[2 * k + 2]
+        a_in = ctx.a_in[k]
+        M = B * ho * wo
+        # -- pointwise: weight gradient, then data gradient (+ bn_dw backward sums)
+        dW = torch.zeros_like(w_pw)
+        L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn.cA), p(st_pw.bn.cB), p(st_pw.bn.cC), p(st_dw.y),
+               p(st_dw.bn.scale), p(st_dw.bn.shift), p(dW), M, cin, cout)
+        grads[pi + 3] = dW
+        wt = torch.empty((cin, cout), dtype=torch.float32, device=g.device)
+        L.call("ttk_transpose", p(w_pw), p(wt), cout, cin)
+        g_dw = torch.empty_like(st_dw.y)
+        L.call("ttk_pwconv1x1_bwd_data", p(g), p(st_pw.y), p(st_pw.bn.cA), p(st_pw.bn.cB), p(st_pw.bn.cC), p(wt), p(st_dw.y),
+               p(st_dw.bn.scale), p(st_dw.bn.shift), p(g_dw), p(part), M, cin, cout)
+        bwd_finalize(st_dw, L.partial_rows_gemm(M), M, pi + 1)
+        # -- depthwise: weight gradient, then data gradient (+ residual gradient, + producer's bn sums)
+        dWd = torch.empty_like(w_dw)
+        L.call("ttk_dwconv3x3_bwd_weight", p(g_dw), p(st_dw.y), p(st_dw.bn.cA), p(st_dw.bn.cB), p(st_dw.bn.cC), p(st_prev.y),
+               p(st_prev.bn.scale), p(st_prev.bn.shift), p(st_prev.skip), p(a_in), p(dWd), 0, B, h, w_, cin, stride)
+        grads[pi] = dWd
+        g_prev = torch.empty_like(st_prev.y)
+        L.call("ttk_dwconv3x3_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn.cA), p(st_dw.bn.cB), p(st_dw.bn.cC), p(w_dw),
+               p(g) if has_skip else None, p(st_prev.y), p(st_prev.bn.scale), p(st_prev.bn.shift), p(st_prev.skip), p(a_in),
+               p(g_prev), p(part), B, h, w_, cin, stride)
+        bwd_finalize(st_prev, L.partial_rows_elementwise(B * h * w_ * (cin // 4)), B * h * w_, pi - 2 if k > 0 else 1)
+        g = g_prev
+    st0 = ctx.stages[0]
+    dW1 = torch.empty_like(params[0])
+    _, _, H, W = ctx.x.shape
+    L.call("ttk_stem_bwd_weight", p(g), p(st0.y), p(st0.bn.cA), p(st0.bn.cB), p(st0.bn.cC), p(ctx.x), p(dW1), 0, B, H, W)
+    grads[0] = dW1
+    return grads
+
+
+class _MobileNetFn(torch.autograd.Function):
+    """One autograd node for the whole backbone: saves raw conv outputs + BN constants."""
+
+    @staticmethod
+    def forward(ctx, x, momentum, eps, buffers, *params):
+        feat, c = _forward_impl(x, params, buffers, momentum, eps, training=True)
+        ctx.c = c
+        ctx.nparams = len(params)
+        ctx.save_for_backward(*params)
+        return feat
+
+    @staticmethod
+    def backward(ctx, gfeat):
+        params = ctx.saved_tensors
+        grads = _backward_impl(ctx.c, gfeat.contiguous(), params)
+        ctx.c = None
+        return (None, None, None, None, *grads)
+
+
+class MobileNet(nn.Module):
+    """Reference :95-189.  `forward(x) -> (features, [out1..out5])`."""
+
+    def __init__(self, num_classes=1000, widen_factor=1.0, input_channel=1, momentum=0.1, dropout=0.0,
+                 use_blurpool=False, return_only_featuremap=False):
+        super().__init__()
+        if widen_factor != 1.0 or input_channel != 1:
+            raise NotImplementedError("the HIP backbone is built for widen_factor=1.0, input_channel=1 (the pose estimator's configuration, models.py:220)")
+        if return_only_featuremap:
+            raise NotImplementedError("return_only_featuremap is not used by the pose estimator")
+
+        def block(inplanes, planes, stride=1):
+            return DepthWiseBlock(inplanes, planes, stride=stride, momentum=momentum, use_blurpool=use_blurpool)
+
+        self.conv1 = nn.Conv2d(input_channel, 32, kernel_size=5, stride=2, padding=2, bias=False)
+        self.bn1 = NormalizationLayer(32, momentum=momentum)
+        self.relu = ActivationFunc(inplace=True)
+        for name, cin, cout, stride in _BLOCKS:
+            setattr(self, name, block(cin, cout, stride))
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.num_features = 1024
+        self.num_intermediate_features = [64, 128, 256, 512, 1024]
+        if num_classes:
+            self.drop = nn.Dropout(p=dropout) if dropout > 0.0 else nn.Identity()
+            self.fc = nn.Linear(1024, num_classes)
+        # reference :155-158 - N(0, sqrt(2/(k*k*Cout))) for EVERY conv, 1x1 included
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2.0 / n))
+
+    # ---- parameter plumbing -----------------------------------------------------------------
+    def _bns(self):
+        yield self.bn1
+        for name, *_ in _BLOCKS:
+            blk = getattr(self, name)
+            yield blk.bn_dw
+            yield blk.bn_sep
+
+    def _flat_params(self):
+        ps = [self.conv1.weight, self.bn1.weight, self.bn1.bias]
+        for name, *_ in _BLOCKS:
+            b = getattr(self, name)
+            ps += [b.conv_dw.weight, b.bn_dw.weight, b.bn_dw.bias, b.conv_sep.weight, b.bn_sep.weight, b.bn_sep.bias]
+        return ps
+
+    def _flat_buffers(self):
+        out = []
+        for bn in self._bns():
+            out += [bn.running_mean, bn.running_var, bn.num_batches_tracked]
+        return out
+
+    def _check(self, x):
+        if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError(f"expected float32 [B,1,H,W] input, got {tuple(x.shape)} {x.dtype}")
+        moms = {bn.momentum for bn in self._bns()}
+        epss = {bn.eps for bn in self._bns()}
+        if len(moms) != 1 or len(epss) != 1 or None in moms:
+            raise NotImplementedError("all BatchNorm layers must share one momentum/eps")
+        return moms.pop(), epss.pop()
+
+    def forward_features(self, x: torch.Tensor) -> torch.Tensor:
+        """[B,1,H,W] -> [B,1024]; the path NetworkWithPointHead uses (it discards the intermediates)."""
+        if not x.is_cuda:
+            return self._forward_torch(x)[0]
+        momentum, eps = self._check(x)
+        x = x.contiguous()
+        bn_training = [bn.training for bn in self._bns()]
+        if self.training and all(bn_training):
+            return _MobileNetFn.apply(x, momentum, eps, self._flat_buffers(), *self._flat_params())
+        if any(bn_training):
+            raise NotImplementedError("mixed train/eval BatchNorm layers are not supported by the fused backbone")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._flat_params()):
+            raise NotImplementedError("gradients through the eval-mode (frozen BatchNorm) backbone are not built; "
+                                      "wrap inference in torch.no_grad()")
+        feat, _ = _forward_impl(x, [q.detach() for q in self._flat_params()], self._flat_buffers(), momentum, eps, False)
+        return feat
+
+    def forward(self, x):
+        if not x.is_cuda:
+            return self._forward_torch(x)
+        feat = self.forward_features(x)
+        if hasattr(self, "fc"):
+            feat = self.fc(self.drop(feat))
+        return feat, self._intermediates(x)
+
+    @torch.no_grad()
+    def _intermediates(self, x):
+        """[z65, z33, z17, z9, z5] post-activation block outputs (reference :165-186), recomputed without
+        autograd on request: the pose network never reads them (models.py:343)."""
+        momentum, eps = self._check(x)
+        bufs = [b.clone() for b in self._flat_buffers()]  # do not double-update running statistics
+        training = self.training
+        _, c = _forward_impl(x.contiguous(), [q.detach() for q in self._flat_params()], bufs, momentum, eps, training)
+        L, p = _hip.lib(), _hip.ptr
+        outs = []
+        for k, (name, *_r) in enumerate(_BLOCKS):
+            if name in _INTERMEDIATES:
+                st = c.stages[2 * k + 2]
+                a = torch.empty_like(st.y)
+                L.call("ttk_bn_act", p(st.y), p(st.bn.scale), p(st.bn.shift), p(st.skip), p(a), a.numel() // a.shape[-1], a.shape[-1])
+                outs.append(a.permute(0, 3, 1, 2))  # NCHW view of the channels-last buffer
+        return outs
+
+    def _forward_torch(self, x):
+        """Plain-torch eval path for CPU tensors (ONNX export / checkpoint inspection).  Training on
+        the CPU is not a supported path of this package."""
+        if self.training:
+            raise RuntimeError("the MI355X training path needs CUDA tensors; CPU tensors are accepted in eval() mode only")
+        x = self.relu(self.bn1(self.conv1(x)))
+        outs = []
+        for name, *_ in _BLOCKS:
+            x = getattr(self, name)(x)
+            if name in _INTERMEDIATES:
+                outs.append(x)
+        x = self.avgpool(x)
+        x = x.view(x.size(0), -1)
+        if hasattr(self, "fc"):
+            x = self.fc(self.drop(x))
+        return x, outs
+
+    def prepare_finetune(self):
+        return [[*ch.parameters()] for ch in self.children()]
