@@ -56,7 +56,8 @@ int ttk_partial_rows_gemm(int64_t M);                 /* pointwise (MFMA) kernel
  * running_var receives the UNBIASED batch variance, normalisation uses the biased one;
  * num_batches_tracked (int64 scalar on the device, may be NULL) is incremented.
  * ------------------------------------------------------------------------------------------- */
-int ttk_bn_fwd_finalize(const float* part, int part_rows, int C, int64_t count,
+/* `part` is scratch: when part_rows > 1024 the finalize kernels first fold it IN PLACE to 1024 rows. */
+int ttk_bn_fwd_finalize(float* part, int part_rows, int C, int64_t count,
                         const float* gamma, const float* beta,
                         float* running_mean, float* running_var, int64_t* num_batches_tracked,
                         float momentum, float eps,
@@ -67,7 +68,7 @@ int ttk_bn_eval_prepare(const float* gamma, const float* beta, const float* runn
                         ttk_stream_t stream);
 /* part[row][0][c] = sum(g), part[row][1][c] = sum(g*y).  Writes cA,cB,cC and the parameter
  * gradients dgamma/dbeta (accumulate != 0: += instead of =). */
-int ttk_bn_bwd_finalize(const float* part, int part_rows, int C, int64_t count,
+int ttk_bn_bwd_finalize(float* part, int part_rows, int C, int64_t count,
                         const float* gamma, const float* mean, const float* rstd,
                         float* cA, float* cB, float* cC, float* dgamma, float* dbeta, int accumulate,
                         ttk_stream_t stream);
@@ -98,13 +99,16 @@ int ttk_dwconv3x3_fwd(const float* yprev, const float* scale, const float* shift
 /* Gradient w.r.t. the block input, masked by relu and handed to the producer's BatchNorm:
  *   G      = convT3x3(dy_dw) (+ skip_grad)            dy_dw = cA*g_dw + cB*y_dw + cC on load
  *   g_prev = G * [a_in > 0]                            -> written, with partials sum(g_prev), sum(g_prev*yprev)
- * a_in (nullable): materialised block input; if NULL it is recomputed from yprev/scale/shift/skip_prev. */
+ * a_in (nullable): materialised block input; if NULL it is recomputed from yprev/scale/shift/skip_prev.
+ * dw (nullable): FUSED weight gradient dW[C][9] (+)= sum dy_dw * a_in(taps) - every (dy, a_in) pair it
+ * needs is already in registers here, so the standalone kernel below is only kept for unit tests. */
 int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* cA, const float* cB,
                            const float* cC, const float* w, const float* skip_grad,
                            const float* yprev, const float* scale_prev, const float* shift_prev,
                            const float* skip_prev, const float* a_in, float* g_prev, float* part,
+                           float* dw, int dw_accumulate,
                            int B, int H, int W, int C, int stride, ttk_stream_t stream);
-/* dW[C][9] (+)= sum dy_dw * a_in(taps). */
+/* dW[C][9] (+)= sum dy_dw * a_in(taps) (standalone form). */
 int ttk_dwconv3x3_bwd_weight(const float* g_dw, const float* y_dw, const float* cA, const float* cB,
                              const float* cC, const float* yprev, const float* scale_prev,
                              const float* shift_prev, const float* skip_prev, const float* a_in,

@@ -15,19 +15,20 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-// block = 32 channels x 8 row-lanes; each thread strides over the partial rows.
-__global__ void __launch_bounds__(256) bn_fwd_finalize_k(const float* __restrict__ part, int rows, int C, double inv_count,
+// block = 32 channels x 32 row-lanes (1024 threads); each thread strides over the partial rows, 4 loads in flight.
+__global__ void __launch_bounds__(1024) bn_fwd_finalize_k(const float* __restrict__ part, int rows, int C, double inv_count,
                                                           double unbias, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ rmean,
                                                           float* __restrict__ rvar, int64_t* nbt, float momentum, float eps,
                                                           float* __restrict__ scale, float* __restrict__ shift,
                                                           float* __restrict__ mean_o, float* __restrict__ rstd_o) {
-  __shared__ double sm[2][8][32];
+  __shared__ double sm[2][32][32];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double a = 0.0, b = 0.0;
   if (c < C) {
-    for (int r = rl; r < rows; r += 8) {
+#pragma unroll 4
+    for (int r = rl; r < rows; r += 32) {
       a += (double)part[((size_t)r * 2 + 0) * C + c];
       b += (double)part[((size_t)r * 2 + 1) * C + c];
     }
@@ -36,7 +37,7 @@ __global__ void __launch_bounds__(256) bn_fwd_finalize_k(const float* __restrict
   sm[1][rl][cl] = b;
   __syncthreads();
   if (rl == 0 && c < C) {
-    for (int i = 1; i < 8; ++i) { a += sm[0][i][cl]; b += sm[1][i][cl]; }
+    for (int i = 1; i < 32; ++i) { a += sm[0][i][cl]; b += sm[1][i][cl]; }
     const double mean = a * inv_count;
     double var = b * inv_count - mean * mean;  // biased variance, used for normalisation
     if (var < 0.0) var = 0.0;
@@ -67,18 +68,19 @@ __global__ void bn_eval_prepare_k(const float* gamma, const float* beta, const f
 // dy = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)),  xhat = (y - mean)*rstd
 //    = cA*g + cB*y + cC
 // sum(g*xhat) = rstd*(sum(g*y) - mean*sum(g));  dgamma = sum(g*xhat), dbeta = sum(g)
-__global__ void __launch_bounds__(256) bn_bwd_finalize_k(const float* __restrict__ part, int rows, int C, double inv_count,
+__global__ void __launch_bounds__(1024) bn_bwd_finalize_k(const float* __restrict__ part, int rows, int C, double inv_count,
                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, float* __restrict__ cA,
                                                           float* __restrict__ cB, float* __restrict__ cC,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                           int accumulate) {
-  __shared__ double sm[2][8][32];
+  __shared__ double sm[2][32][32];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double a = 0.0, b = 0.0;
   if (c < C) {
-    for (int r = rl; r < rows; r += 8) {
+#pragma unroll 4
+    for (int r = rl; r < rows; r += 32) {
       a += (double)part[((size_t)r * 2 + 0) * C + c];
       b += (double)part[((size_t)r * 2 + 1) * C + c];
     }
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_k(const float* __restrict
   sm[1][rl][cl] = b;
   __syncthreads();
   if (rl == 0 && c < C) {
-    for (int i = 1; i < 8; ++i) { a += sm[0][i][cl]; b += sm[1][i][cl]; }
+    for (int i = 1; i < 32; ++i) { a += sm[0][i][cl]; b += sm[1][i][cl]; }
     const double m = mean[c], rs = rstd[c], ga = gamma[c];
     const double sum_g = a, sum_gx = rs * (b - m * a);
     const double mg = sum_g * inv_count, mgx = sum_gx * inv_count;
@@ -102,6 +104,30 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_k(const float* __restrict
   }
 }
 
+// rows r, r+F, r+2F, ... are summed into row r (r < F), in place: thread (r, i) owns element i of all
+// rows congruent to r, so no other thread reads or writes what it touches.
+constexpr int kFoldRows = 1024;
+__global__ void __launch_bounds__(256) bn_fold_rows_k(float* __restrict__ part, int rows, int row_floats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (i >= row_floats) return;
+  float acc = part[(size_t)r * row_floats + i];
+  float comp = 0.f;  // Kahan: the folded rows feed an fp64 reduction, keep them clean
+  for (int q = r + kFoldRows; q < rows; q += kFoldRows) {
+    const float v = part[(size_t)q * row_floats + i] - comp;
+    const float t = acc + v;
+    comp = (t - acc) - v;
+    acc = t;
+  }
+  part[(size_t)r * row_floats + i] = acc;
+}
+
+static int fold_if_needed(float* part, int rows, int C, hipStream_t st) {
+  if (rows <= kFoldRows) return rows;
+  hipLaunchKernelGGL(bn_fold_rows_k, dim3((2 * C + 255) / 256, kFoldRows), dim3(256), 0, st, part, rows, 2 * C);
+  return kFoldRows;
+}
+
 }  // namespace ttk
 
 using namespace ttk;
@@ -114,14 +140,15 @@ const char* ttk_last_error_string(void) { return ttk::g_err; }
 int ttk_partial_rows_elementwise(int64_t work_items) { return elementwise_grid(work_items); }
 int ttk_partial_rows_gemm(int64_t M) { return (int)ceil_div(M, TTK_GEMM_BLOCK_M); }
 
-int ttk_bn_fwd_finalize(const float* part, int part_rows, int C, int64_t count, const float* gamma, const float* beta,
+int ttk_bn_fwd_finalize(float* part, int part_rows, int C, int64_t count, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
                         float* scale, float* shift, float* mean, float* rstd, ttk_stream_t stream) {
   TTK_REQUIRE(part && gamma && beta && scale && shift && mean && rstd, "bn_fwd_finalize: null pointer");
   TTK_REQUIRE(C > 0 && part_rows > 0 && count > 0, "bn_fwd_finalize: bad sizes C=%d rows=%d count=%lld", C, part_rows, (long long)count);
   TTK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_fwd_finalize: running_mean/var must both be given");
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-  hipLaunchKernelGGL(bn_fwd_finalize_k, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, part_rows, C,
+  part_rows = fold_if_needed(part, part_rows, C, (hipStream_t)stream);
+  hipLaunchKernelGGL(bn_fwd_finalize_k, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, part_rows, C,
                      1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                      scale, shift, mean, rstd);
   TTK_LAUNCH_CHECK("bn_fwd_finalize");
@@ -136,13 +163,14 @@ int ttk_bn_eval_prepare(const float* gamma, const float* beta, const float* runn
   TTK_LAUNCH_CHECK("bn_eval_prepare");
 }
 
-int ttk_bn_bwd_finalize(const float* part, int part_rows, int C, int64_t count, const float* gamma, const float* mean,
+int ttk_bn_bwd_finalize(float* part, int part_rows, int C, int64_t count, const float* gamma, const float* mean,
                         const float* rstd, float* cA, float* cB, float* cC, float* dgamma, float* dbeta, int accumulate,
                         ttk_stream_t stream) {
   TTK_REQUIRE(part && gamma && mean && rstd && cA && cB && cC, "bn_bwd_finalize: null pointer");
   TTK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bn_bwd_finalize: dgamma/dbeta must both be given");
   TTK_REQUIRE(C > 0 && part_rows > 0 && count > 0, "bn_bwd_finalize: bad sizes");
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, part_rows, C,
+  part_rows = fold_if_needed(part, part_rows, C, (hipStream_t)stream);
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, part_rows, C,
                      1.0 / (double)count, gamma, mean, rstd, cA, cB, cC, dgamma, dbeta, accumulate);
   TTK_LAUNCH_CHECK("bn_bwd_finalize");
 }

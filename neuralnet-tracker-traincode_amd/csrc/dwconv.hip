@@ -9,6 +9,11 @@
 
 namespace ttk {
 
+__global__ void zero_f(float* p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 struct DwWeights {  // 3x3 filters of 4 consecutive channels: w[c][tap] as stored by the reference (C,1,3,3)
   float v[36];
   __device__ __forceinline__ void load(const float* w, int c4) {
@@ -86,9 +91,10 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_data_k(const float* __restrict_
                                                          const float* __restrict__ yprev, const float* __restrict__ scale_prev,
                                                          const float* __restrict__ shift_prev,
                                                          const float* __restrict__ skip_prev, const float* __restrict__ a_in,
-                                                         float* __restrict__ g_prev, float* __restrict__ part, int B, int H,
+                                                         float* __restrict__ g_prev, float* __restrict__ part,
+                                                         float* __restrict__ dwgrad, int B, int H,
                                                          int W, int C, int Ho, int Wo, int qshift) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2*C] partials (+ [9*C] weight grads)
   const int quads = C >> 2;
   const int c4 = threadIdx.x & (quads - 1);
   DwWeights wr;
@@ -97,6 +103,12 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_data_k(const float* __restrict_
   InputForm in{yprev, skip_prev, a_in, {ld4(scale_prev + 4 * c4), ld4(shift_prev + 4 * c4)}};
   const int64_t items = ((int64_t)B * H * W) << qshift;
   float4 s1 = f4(0.f), s2 = f4(0.f);
+  // Fused weight gradient: dW[c][tap] = sum_o dy(o) * a_in(o*S + tap - 1).  This thread sits at the
+  // input pixel q = o*S + tap - 1 and visits exactly those (o, tap) pairs below, so the products
+  // dy(o)*a_in(q) need no extra loads.
+  float4 wacc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wacc[t] = f4(0.f);
   for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * kBlock) {
     int64_t pix = idx >> qshift;
     const int wi = (int)(pix % W);
@@ -104,6 +116,8 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_data_k(const float* __restrict_
     const int hi = (int)(pix % H);
     const int n = (int)(pix / H);
     float4 G = f4(0.f);
+    const size_t off_in = (size_t)idx << 2;
+    const float4 a = in(off_in);
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int th = hi + 1 - kh;
@@ -119,17 +133,46 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_data_k(const float* __restrict_
         const size_t off = (((size_t)n * Ho + ho) * Wo + wo) * C + 4 * c4;
         const float4 dy = bg.dy(ld4(g_dw + off), ld4(y_dw + off));
         G = fma4(dy, wr.tap(kh * 3 + kw), G);
+        wacc[kh * 3 + kw] = fma4(dy, a, wacc[kh * 3 + kw]);
       }
     }
-    const size_t off_in = (size_t)idx << 2;
     if (skip_grad) G = add4(G, ld4(skip_grad + off_in));
-    const float4 a = in(off_in);
     const float4 gp = mask4(G, a);
     st4(g_prev + off_in, gp);
     s1 = add4(s1, gp);
     s2 = fma4(gp, ld4(yprev + off_in), s2);
   }
   if (part) block_channel_partials<1024>(s1, s2, c4, C, part + (size_t)blockIdx.x * 2 * C, smem);
+  if (dwgrad) {
+    float* ws = smem + 2 * C;  // [9][C]
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float4 v = wacc[t];
+      for (int off = quads; off < kWave; off <<= 1) {
+        v.x += __shfl_xor(v.x, off); v.y += __shfl_xor(v.y, off);
+        v.z += __shfl_xor(v.z, off); v.w += __shfl_xor(v.w, off);
+      }
+      wacc[t] = v;
+    }
+    for (int i = threadIdx.x; i < 9 * C; i += kBlock) ws[i] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1);
+    const bool owner = (quads >= kWave) || (lane < quads);
+    for (int wv = 0; wv < kBlock / kWave; ++wv) {
+      if ((threadIdx.x >> 6) == wv && owner) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          float* d = ws + t * C + 4 * c4;
+          d[0] += wacc[t].x; d[1] += wacc[t].y; d[2] += wacc[t].z; d[3] += wacc[t].w;
+        }
+      }
+      __syncthreads();
+    }
+    for (int i = threadIdx.x; i < 9 * C; i += kBlock) {
+      const int t = i / C, c = i - t * C;
+      atomicAdd(dwgrad + c * 9 + t, ws[i]);
+    }
+  }
 }
 
 // dW[c][tap] += sum_{n,ho,wo} dy_dw[n,ho,wo,c] * a_in[n, ho*S+kh-1, wo*S+kw-1, c]
@@ -199,11 +242,6 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_weight_k(const float* __restric
   }
 }
 
-__global__ void zero_f(float* p, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = 0.f;
-}
-
 // a = max(scale*y + shift (+skip), 0) over [rows][C]
 __global__ void __launch_bounds__(kBlock) bn_act_k(const float* __restrict__ y, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, const float* __restrict__ skip,
@@ -254,7 +292,7 @@ int ttk_dwconv3x3_fwd(const float* yprev, const float* scale, const float* shift
 int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* cA, const float* cB, const float* cC,
                            const float* w, const float* skip_grad, const float* yprev, const float* scale_prev,
                            const float* shift_prev, const float* skip_prev, const float* a_in, float* g_prev, float* part,
-                           int B, int H, int W, int C, int stride, ttk_stream_t stream) {
+                           float* dw, int dw_accumulate, int B, int H, int W, int C, int stride, ttk_stream_t stream) {
   TTK_REQUIRE(g_dw && y_dw && cA && cB && cC && w && yprev && scale_prev && shift_prev && g_prev, "dwconv3x3_bwd_data: null pointer");
   TTK_REQUIRE(dw_shape_ok(B, H, W, C, stride), "dwconv3x3_bwd_data: unsupported shape");
   TTK_REQUIRE(!(skip_grad && stride != 1), "dwconv3x3_bwd_data: residual gradient requires stride 1");
@@ -262,13 +300,15 @@ int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* cA
   const int qs = log2i(C / 4);
   const int64_t items = ((int64_t)B * H * W) << qs;
   const dim3 grid(elementwise_grid(items));
-  const size_t sm = 2 * (size_t)C * sizeof(float);
+  const size_t sm = (dw ? 11 : 2) * (size_t)C * sizeof(float);
+  if (dw && !dw_accumulate)
+    hipLaunchKernelGGL(zero_f, dim3((9 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dw, (int64_t)9 * C);
   if (stride == 1)
     hipLaunchKernelGGL(dw_bwd_data_k<1>, grid, dim3(kBlock), sm, (hipStream_t)stream, g_dw, y_dw, cA, cB, cC, w, skip_grad,
-                       yprev, scale_prev, shift_prev, skip_prev, a_in, g_prev, part, B, H, W, C, Ho, Wo, qs);
+                       yprev, scale_prev, shift_prev, skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, qs);
   else
     hipLaunchKernelGGL(dw_bwd_data_k<2>, grid, dim3(kBlock), sm, (hipStream_t)stream, g_dw, y_dw, cA, cB, cC, w, skip_grad,
-                       yprev, scale_prev, shift_prev, skip_prev, a_in, g_prev, part, B, H, W, C, Ho, Wo, qs);
+                       yprev, scale_prev, shift_prev, skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, qs);
   TTK_LAUNCH_CHECK("dwconv3x3_bwd_data");
 }
 

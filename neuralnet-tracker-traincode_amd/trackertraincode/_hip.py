@@ -24,7 +24,7 @@ _SIGNATURES = {
     "ttk_stem_fwd": [_P, _P, _P, _P, _I, _I, _I],
     "ttk_stem_bwd_weight": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
     "ttk_dwconv3x3_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
-    "ttk_dwconv3x3_bwd_data": [_P] * 14 + [_I] * 5,
+    "ttk_dwconv3x3_bwd_data": [_P] * 15 + [_I] * 6,
     "ttk_dwconv3x3_bwd_weight": [_P] * 11 + [_I] * 6,
     "ttk_pwconv1x1_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I],
     "ttk_pwconv1x1_bwd_data": [_P] * 11 + [_L, _I, _I],

@@ -219,14 +219,12 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
                p(st_dw.bn.scale), p(st_dw.bn.shift), p(g_dw), p(part), M, cin, cout)
         bwd_finalize(st_dw, L.partial_rows_gemm(M), M, pi + 1)
         # -- depthwise: weight gradient, then data gradient (+ residual gradient, + producer's bn sums)
-        dWd = torch.empty_like(w_dw)
-        L.call("ttk_dwconv3x3_bwd_weight", p(g_dw), p(st_dw.y), p(st_dw.bn.cA), p(st_dw.bn.cB), p(st_dw.bn.cC), p(st_prev.y),
-               p(st_prev.bn.scale), p(st_prev.bn.shift), p(st_prev.skip), p(a_in), p(dWd), 0, B, h, w_, cin, stride)
+        dWd = torch.empty_like(w_dw)  # filled by the fused weight-gradient path of bwd_data
         grads[pi] = dWd
         g_prev = torch.empty_like(st_prev.y)
         L.call("ttk_dwconv3x3_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn.cA), p(st_dw.bn.cB), p(st_dw.bn.cC), p(w_dw),
                p(g) if has_skip else None, p(st_prev.y), p(st_prev.bn.scale), p(st_prev.bn.shift), p(st_prev.skip), p(a_in),
-               p(g_prev), p(part), B, h, w_, cin, stride)
+               p(g_prev), p(part), p(dWd), 0, B, h, w_, cin, stride)
         bwd_finalize(st_prev, L.partial_rows_elementwise(B * h * w_ * (cin // 4)), B * h * w_, pi - 2 if k > 0 else 1)
         g = g_prev
     st0 = ctx.stages[0]
