@@ -152,6 +152,66 @@ int ttk_avgpool_bwd(const float* gfeat, const float* y, const float* scale, cons
 int ttk_bn_act(const float* y, const float* scale, const float* shift, const float* skip, float* a,
                int64_t rows, int C, ttk_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Multi-task heads - everything NetworkWithPointHead.forward does after the backbone
+ * (neuralnets/models.py:345-376): BoundingBox :177-197, PositionSizeOutput :200-215,
+ * DirectQuaternionWithNormalization :127-150 (+ rotrepr.py:36-48), FeaturesAsTriangularScale
+ * (negloglikelihood.py:187-242), two LocalToGlobalCoordinateOffset modules
+ * (modelcomponents.py:136-184) and Landmarks3dOutput (models.py:96-124, modelcomponents.py:38-82).
+ * The linear layers are passed stacked: wcat[NZ][F], bcat[NZ] with the row order
+ *   box 4 | xy 2 | size 1 | quat 4 | [coord-scale neck 7 | pose-scale neck 7] | [shape 50]
+ * NZ = ttk_heads_num_rows(enable_uncertainty, enable_point_head).  ids: int32 dataset ids (NULL = row 0,
+ * the reference's set_id=None path).  Outputs per sample: roi[4] coord[3] rot[4] (ijkw) qu[4]
+ * (= unnormalized_quat) Lc[9] Lr[9] (= coord_scales, pose_scales_tril) pts[68][3] shp[50]; z[B][NZ] is
+ * saved for backward.
+ * ------------------------------------------------------------------------------------------- */
+int ttk_heads_num_rows(int enable_uncertainty, int enable_point_head);
+int ttk_heads_fwd(const float* feat, const float* wcat, const float* bcat, const int* ids,
+                  const float* P, const float* Pk, const float* keypts, const float* keyeig, int B, int F,
+                  int NZ, int enable_uncertainty, int enable_point_head, int use_offset, float* z,
+                  float* roi, float* coord, float* rot, float* qu, float* Lc, float* Lr, float* pts,
+                  float* shp, ttk_stream_t stream);
+/* dz[B][NZ], dprow[B][8]: scratch.  Outputs dfeat[B][F], dwcat[NZ][F], dbcat[NZ], dP[8][4], dPk[8][4]
+ * (overwritten). */
+int ttk_heads_bwd(const float* feat, const float* wcat, const float* z, const int* ids, const float* P,
+                  const float* Pk, const float* keypts, const float* keyeig, int B, int F, int NZ,
+                  int enable_uncertainty, int enable_point_head, int use_offset, const float* g_roi,
+                  const float* g_coord, const float* g_rot, const float* g_qu, const float* g_Lc,
+                  const float* g_Lr, const float* g_pts, const float* g_shp, float* dz, float* dprow,
+                  float* dfeat, float* dwcat, float* dbcat, float* dP, float* dPk, ttk_stream_t stream);
+/* DiagonalScaleParameter (negloglikelihood.py:50-65): out[n] from hidden[n+1]. */
+int ttk_diag_scale_fwd(const float* hidden, float* out, int n, ttk_stream_t stream);
+int ttk_diag_scale_bwd(const float* hidden, const float* gout, float* ghidden, int n, ttk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Losses: per-sample values v[n] and gradients w.r.t. the predictions (gv[n] = upstream gradient).
+ *   rot       1-(q.t)^2                     losses.py:42-50 / torchquaternion.py:225-228
+ *   quatreg   (1-|qu|)^2                    losses.py:116-125
+ *   mse_rows  mean_d (p-t)^2                losses.py:67-97,163-173 (xy, size, box, shape params)
+ *   points    mean_p w_p sum_{d<dim}(p-t)^2 losses.py:128-160 (w: chin/eye weights, keypoints68.py)
+ *   nllrot    tangent-space MVN + uniform   negloglikelihood.py:245-274
+ *   nllcoord  correlated MVN + uniform      negloglikelihood.py:113-126
+ *   normal    -mean Normal.log_prob         negloglikelihood.py:129-177 (points != 0: [n][68][3] weighted)
+ *   gmm       shape plausibility, float64   losses.py:100-113, modelcomponents.py:278-290
+ *             ck[k] = log w_k + sum_d log sinv_kd - 25 log 2pi; post[n][K] scratch (responsibilities)
+ * ------------------------------------------------------------------------------------------- */
+int ttk_loss_rot_fwd(const float* q, const float* t, int n, float* v, ttk_stream_t stream);
+int ttk_loss_rot_bwd(const float* q, const float* t, const float* gv, int n, float* gq, ttk_stream_t stream);
+int ttk_loss_quatreg_fwd(const float* q, int n, float* v, ttk_stream_t stream);
+int ttk_loss_quatreg_bwd(const float* q, const float* gv, int n, float* gq, ttk_stream_t stream);
+int ttk_loss_mse_rows_fwd(const float* p, const float* t, int n, int D, float* v, ttk_stream_t stream);
+int ttk_loss_mse_rows_bwd(const float* p, const float* t, const float* gv, int n, int D, float* gp, ttk_stream_t stream);
+int ttk_loss_points_fwd(const float* p, const float* t, int n, int dim, float chin, float eye, float* v, ttk_stream_t stream);
+int ttk_loss_points_bwd(const float* p, const float* t, const float* gv, int n, int dim, float chin, float eye, float* gp, ttk_stream_t stream);
+int ttk_loss_nllrot_fwd(const float* q, const float* t, const float* L, int n, float* v, ttk_stream_t stream);
+int ttk_loss_nllrot_bwd(const float* q, const float* t, const float* L, const float* gv, int n, float* gq, float* gL, ttk_stream_t stream);
+int ttk_loss_nllcoord_fwd(const float* c, const float* t, const float* L, int n, float* v, ttk_stream_t stream);
+int ttk_loss_nllcoord_bwd(const float* c, const float* t, const float* L, const float* gv, int n, float* gc, float* gL, ttk_stream_t stream);
+int ttk_loss_normal_fwd(const float* mu, const float* sigma, const float* x, int n, int per, int points, int dim, float chin, float eye, float* v, ttk_stream_t stream);
+int ttk_loss_normal_bwd(const float* mu, const float* sigma, const float* x, const float* gv, int n, int per, int points, int dim, float chin, float eye, float* gmu, float* gsigma, ttk_stream_t stream);
+int ttk_loss_gmm_fwd(const float* x, const double* ck, const double* mu, const double* sinv, int K, double fudge, int n, float* v, double* post, ttk_stream_t stream);
+int ttk_loss_gmm_bwd(const float* x, const double* mu, const double* sinv, const double* post, int K, double fudge, const float* gv, int n, float* gx, ttk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,241 @@
+// Per-sample loss kernels (forward value + gradient w.r.t. the predictions), one thread per sample
+// or per element; arithmetic in loss_math.h.  Reference: neuralnets/losses.py, negloglikelihood.py.
+// All of these are a few KB per launch - they exist so that the loss path has no PyTorch fallback
+// and no per-step host synchronisation (reference trackertraincode/train.py:433-438 stalls the
+// stream every step; here values stay on the device).
+#include "loss_math.h"
+#include "ttk_common.h"
+
+namespace ttk {
+
+#define TTK_SAMPLE_INDEX(n)                                         \
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;              \
+  if (s >= (n)) return;
+
+__global__ void loss_rot_fwd_k(const float* q, const float* t, int n, float* v) {
+  TTK_SAMPLE_INDEX(n);
+  v[s] = lm::rot_loss(q + 4 * s, t + 4 * s);
+}
+__global__ void loss_rot_bwd_k(const float* q, const float* t, const float* gv, int n, float* gq) {
+  TTK_SAMPLE_INDEX(n);
+  lm::rot_loss_bwd(q + 4 * s, t + 4 * s, gv[s], gq + 4 * s);
+}
+__global__ void loss_quatreg_fwd_k(const float* q, int n, float* v) {
+  TTK_SAMPLE_INDEX(n);
+  v[s] = lm::quatreg_loss(q + 4 * s);
+}
+__global__ void loss_quatreg_bwd_k(const float* q, const float* gv, int n, float* gq) {
+  TTK_SAMPLE_INDEX(n);
+  lm::quatreg_loss_bwd(q + 4 * s, gv[s], gq + 4 * s);
+}
+// mean_d (p - t)^2
+__global__ void loss_mse_rows_fwd_k(const float* p, const float* t, int n, int D, float* v) {
+  TTK_SAMPLE_INDEX(n);
+  float acc = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float e = p[(size_t)s * D + d] - t[(size_t)s * D + d];
+    acc = fmaf(e, e, acc);
+  }
+  v[s] = acc / (float)D;
+}
+__global__ void loss_mse_rows_bwd_k(const float* p, const float* t, const float* gv, int n, int D, float* gp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * D) return;
+  gp[i] = 2.f * (p[i] - t[i]) * gv[i / D] / (float)D;
+}
+// mean_p( w_p * sum_{d<dim} (p - t)^2 )
+__global__ void loss_points_fwd_k(const float* p, const float* t, int n, int dim, float chin, float eye, float* v) {
+  TTK_SAMPLE_INDEX(n);
+  float acc = 0.f;
+  for (int k = 0; k < 68; ++k) {
+    float e2 = 0.f;
+    for (int d = 0; d < dim; ++d) {
+      const float e = p[((size_t)s * 68 + k) * 3 + d] - t[((size_t)s * 68 + k) * 3 + d];
+      e2 = fmaf(e, e, e2);
+    }
+    acc = fmaf(lm::point_weight(k, chin, eye), e2, acc);
+  }
+  v[s] = acc / 68.f;
+}
+__global__ void loss_points_bwd_k(const float* p, const float* t, const float* gv, int n, int dim, float chin, float eye,
+                                  float* gp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 204) return;
+  const int s = i / 204, r = i % 204, k = r / 3, d = r % 3;
+  gp[i] = d < dim ? 2.f * lm::point_weight(k, chin, eye) * (p[i] - t[i]) * gv[s] / 68.f : 0.f;
+}
+__global__ void loss_nllrot_fwd_k(const float* q, const float* t, const float* L, int n, float* v) {
+  TTK_SAMPLE_INDEX(n);
+  v[s] = lm::nllrot_loss(q + 4 * s, t + 4 * s, L + 9 * s);
+}
+__global__ void loss_nllrot_bwd_k(const float* q, const float* t, const float* L, const float* gv, int n, float* gq, float* gL) {
+  TTK_SAMPLE_INDEX(n);
+  lm::nllrot_loss_bwd(q + 4 * s, t + 4 * s, L + 9 * s, gv[s], gq + 4 * s, gL + 9 * s);
+}
+__global__ void loss_nllcoord_fwd_k(const float* c, const float* t, const float* L, int n, float* v) {
+  TTK_SAMPLE_INDEX(n);
+  v[s] = lm::nllcoord_loss(c + 3 * s, t + 3 * s, L + 9 * s);
+}
+__global__ void loss_nllcoord_bwd_k(const float* c, const float* t, const float* L, const float* gv, int n, float* gc, float* gL) {
+  TTK_SAMPLE_INDEX(n);
+  lm::nllcoord_loss_bwd(c + 3 * s, t + 3 * s, L + 9 * s, gv[s], gc + 3 * s, gL + 9 * s);
+}
+// -mean over `per` elements of w * Normal(mu, sigma).log_prob(x); elements laid out [n][rows][3] with
+// only the first `dim` of every 3 used when rows3 != 0 (points), else plain [n][per].
+__global__ void loss_normal_fwd_k(const float* mu, const float* sg, const float* x, int n, int per, int points, int dim,
+                                  float chin, float eye, float* v) {
+  TTK_SAMPLE_INDEX(n);
+  float acc = 0.f;
+  if (points) {
+    for (int k = 0; k < 68; ++k) {
+      float a = 0.f;
+      for (int d = 0; d < dim; ++d) {
+        const size_t o = ((size_t)s * 68 + k) * 3 + d;
+        a += lm::normal_nll(mu[o], sg[o], x[o]);
+      }
+      acc = fmaf(lm::point_weight(k, chin, eye), a, acc);
+    }
+    v[s] = acc / (68.f * (float)dim);
+  } else {
+    for (int d = 0; d < per; ++d) {
+      const size_t o = (size_t)s * per + d;
+      acc += lm::normal_nll(mu[o], sg[o], x[o]);
+    }
+    v[s] = acc / (float)per;
+  }
+}
+__global__ void loss_normal_bwd_k(const float* mu, const float* sg, const float* x, const float* gv, int n, int per,
+                                  int points, int dim, float chin, float eye, float* gmu, float* gsg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int stride = points ? 204 : per;
+  if (i >= n * stride) return;
+  const int s = i / stride, r = i % stride;
+  float w;
+  if (points) {
+    const int k = r / 3, d = r % 3;
+    w = d < dim ? lm::point_weight(k, chin, eye) / (68.f * (float)dim) : 0.f;
+  } else {
+    w = 1.f / (float)per;
+  }
+  float a = 0.f, b = 0.f;
+  if (w != 0.f) lm::normal_nll_bwd(mu[i], sg[i], x[i], w * gv[s], a, b);
+  gmu[i] = a;
+  gsg[i] = b;
+}
+__global__ void loss_gmm_fwd_k(const float* x, const double* ck, const double* mu, const double* sinv, int K, double fudge,
+                               int n, float* v, double* post) {
+  TTK_SAMPLE_INDEX(n);
+  v[s] = (float)lm::gmm_nll(x + 50 * s, ck, mu, sinv, K, fudge, post + (size_t)K * s);
+}
+// d/dx_d = fudge * sum_k post_k (x_d - mu_kd) sinv_kd^2
+__global__ void loss_gmm_bwd_k(const float* x, const double* mu, const double* sinv, const double* post, int K, double fudge,
+                               const float* gv, int n, float* gx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 50) return;
+  const int s = i / 50, d = i % 50;
+  double acc = 0.0;
+  for (int k = 0; k < K; ++k) {
+    const double si = sinv[k * 50 + d];
+    acc += post[(size_t)K * s + k] * ((double)x[i] - mu[k * 50 + d]) * si * si;
+  }
+  gx[i] = (float)(fudge * acc * (double)gv[s]);
+}
+
+}  // namespace ttk
+
+using namespace ttk;
+
+#define TTK_GRID(n) dim3(((n) + 255) / 256), dim3(256), 0, (hipStream_t)stream
+
+extern "C" {
+
+int ttk_loss_rot_fwd(const float* q, const float* t, int n, float* v, ttk_stream_t stream) {
+  TTK_REQUIRE(q && t && v && n > 0, "loss_rot_fwd: bad arguments");
+  hipLaunchKernelGGL(loss_rot_fwd_k, TTK_GRID(n), q, t, n, v);
+  TTK_LAUNCH_CHECK("loss_rot_fwd");
+}
+int ttk_loss_rot_bwd(const float* q, const float* t, const float* gv, int n, float* gq, ttk_stream_t stream) {
+  TTK_REQUIRE(q && t && gv && gq && n > 0, "loss_rot_bwd: bad arguments");
+  hipLaunchKernelGGL(loss_rot_bwd_k, TTK_GRID(n), q, t, gv, n, gq);
+  TTK_LAUNCH_CHECK("loss_rot_bwd");
+}
+int ttk_loss_quatreg_fwd(const float* q, int n, float* v, ttk_stream_t stream) {
+  TTK_REQUIRE(q && v && n > 0, "loss_quatreg_fwd: bad arguments");
+  hipLaunchKernelGGL(loss_quatreg_fwd_k, TTK_GRID(n), q, n, v);
+  TTK_LAUNCH_CHECK("loss_quatreg_fwd");
+}
+int ttk_loss_quatreg_bwd(const float* q, const float* gv, int n, float* gq, ttk_stream_t stream) {
+  TTK_REQUIRE(q && gv && gq && n > 0, "loss_quatreg_bwd: bad arguments");
+  hipLaunchKernelGGL(loss_quatreg_bwd_k, TTK_GRID(n), q, gv, n, gq);
+  TTK_LAUNCH_CHECK("loss_quatreg_bwd");
+}
+int ttk_loss_mse_rows_fwd(const float* p, const float* t, int n, int D, float* v, ttk_stream_t stream) {
+  TTK_REQUIRE(p && t && v && n > 0 && D > 0, "loss_mse_rows_fwd: bad arguments");
+  hipLaunchKernelGGL(loss_mse_rows_fwd_k, TTK_GRID(n), p, t, n, D, v);
+  TTK_LAUNCH_CHECK("loss_mse_rows_fwd");
+}
+int ttk_loss_mse_rows_bwd(const float* p, const float* t, const float* gv, int n, int D, float* gp, ttk_stream_t stream) {
+  TTK_REQUIRE(p && t && gv && gp && n > 0 && D > 0, "loss_mse_rows_bwd: bad arguments");
+  hipLaunchKernelGGL(loss_mse_rows_bwd_k, TTK_GRID(n * D), p, t, gv, n, D, gp);
+  TTK_LAUNCH_CHECK("loss_mse_rows_bwd");
+}
+int ttk_loss_points_fwd(const float* p, const float* t, int n, int dim, float chin, float eye, float* v, ttk_stream_t stream) {
+  TTK_REQUIRE(p && t && v && n > 0 && (dim == 2 || dim == 3), "loss_points_fwd: bad arguments");
+  hipLaunchKernelGGL(loss_points_fwd_k, TTK_GRID(n), p, t, n, dim, chin, eye, v);
+  TTK_LAUNCH_CHECK("loss_points_fwd");
+}
+int ttk_loss_points_bwd(const float* p, const float* t, const float* gv, int n, int dim, float chin, float eye, float* gp,
+                        ttk_stream_t stream) {
+  TTK_REQUIRE(p && t && gv && gp && n > 0 && (dim == 2 || dim == 3), "loss_points_bwd: bad arguments");
+  hipLaunchKernelGGL(loss_points_bwd_k, TTK_GRID(n * 204), p, t, gv, n, dim, chin, eye, gp);
+  TTK_LAUNCH_CHECK("loss_points_bwd");
+}
+int ttk_loss_nllrot_fwd(const float* q, const float* t, const float* L, int n, float* v, ttk_stream_t stream) {
+  TTK_REQUIRE(q && t && L && v && n > 0, "loss_nllrot_fwd: bad arguments");
+  hipLaunchKernelGGL(loss_nllrot_fwd_k, TTK_GRID(n), q, t, L, n, v);
+  TTK_LAUNCH_CHECK("loss_nllrot_fwd");
+}
+int ttk_loss_nllrot_bwd(const float* q, const float* t, const float* L, const float* gv, int n, float* gq, float* gL,
+                        ttk_stream_t stream) {
+  TTK_REQUIRE(q && t && L && gv && gq && gL && n > 0, "loss_nllrot_bwd: bad arguments");
+  hipLaunchKernelGGL(loss_nllrot_bwd_k, TTK_GRID(n), q, t, L, gv, n, gq, gL);
+  TTK_LAUNCH_CHECK("loss_nllrot_bwd");
+}
+int ttk_loss_nllcoord_fwd(const float* c, const float* t, const float* L, int n, float* v, ttk_stream_t stream) {
+  TTK_REQUIRE(c && t && L && v && n > 0, "loss_nllcoord_fwd: bad arguments");
+  hipLaunchKernelGGL(loss_nllcoord_fwd_k, TTK_GRID(n), c, t, L, n, v);
+  TTK_LAUNCH_CHECK("loss_nllcoord_fwd");
+}
+int ttk_loss_nllcoord_bwd(const float* c, const float* t, const float* L, const float* gv, int n, float* gc, float* gL,
+                          ttk_stream_t stream) {
+  TTK_REQUIRE(c && t && L && gv && gc && gL && n > 0, "loss_nllcoord_bwd: bad arguments");
+  hipLaunchKernelGGL(loss_nllcoord_bwd_k, TTK_GRID(n), c, t, L, gv, n, gc, gL);
+  TTK_LAUNCH_CHECK("loss_nllcoord_bwd");
+}
+int ttk_loss_normal_fwd(const float* mu, const float* sigma, const float* x, int n, int per, int points, int dim, float chin,
+                        float eye, float* v, ttk_stream_t stream) {
+  TTK_REQUIRE(mu && sigma && x && v && n > 0 && (points ? (dim == 2 || dim == 3) : per > 0), "loss_normal_fwd: bad arguments");
+  hipLaunchKernelGGL(loss_normal_fwd_k, TTK_GRID(n), mu, sigma, x, n, per, points, dim, chin, eye, v);
+  TTK_LAUNCH_CHECK("loss_normal_fwd");
+}
+int ttk_loss_normal_bwd(const float* mu, const float* sigma, const float* x, const float* gv, int n, int per, int points,
+                        int dim, float chin, float eye, float* gmu, float* gsigma, ttk_stream_t stream) {
+  TTK_REQUIRE(mu && sigma && x && gv && gmu && gsigma && n > 0, "loss_normal_bwd: bad arguments");
+  const int total = n * (points ? 204 : per);
+  hipLaunchKernelGGL(loss_normal_bwd_k, TTK_GRID(total), mu, sigma, x, gv, n, per, points, dim, chin, eye, gmu, gsigma);
+  TTK_LAUNCH_CHECK("loss_normal_bwd");
+}
+int ttk_loss_gmm_fwd(const float* x, const double* ck, const double* mu, const double* sinv, int K, double fudge, int n,
+                     float* v, double* post, ttk_stream_t stream) {
+  TTK_REQUIRE(x && ck && mu && sinv && v && post && n > 0 && K > 0 && K <= 16, "loss_gmm_fwd: bad arguments");
+  hipLaunchKernelGGL(loss_gmm_fwd_k, TTK_GRID(n), x, ck, mu, sinv, K, fudge, n, v, post);
+  TTK_LAUNCH_CHECK("loss_gmm_fwd");
+}
+int ttk_loss_gmm_bwd(const float* x, const double* mu, const double* sinv, const double* post, int K, double fudge,
+                     const float* gv, int n, float* gx, ttk_stream_t stream) {
+  TTK_REQUIRE(x && mu && sinv && post && gv && gx && n > 0 && K > 0, "loss_gmm_bwd: bad arguments");
+  hipLaunchKernelGGL(loss_gmm_bwd_k, TTK_GRID(n * 50), x, mu, sinv, post, K, fudge, gv, n, gx);
+  TTK_LAUNCH_CHECK("loss_gmm_bwd");
+}
+
+}  // extern "C"

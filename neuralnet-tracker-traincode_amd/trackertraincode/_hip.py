@@ -7,14 +7,14 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libttk_hip.so")
 
-_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+_P, _I, _L, _F, _D = c_void_p, c_int, c_int64, c_float, c_double
 
 # name -> argument types (the trailing stream pointer is added automatically)
 _SIGNATURES = {
@@ -33,6 +33,26 @@ _SIGNATURES = {
     "ttk_avgpool_fwd": [_P, _P, _P, _P, _P, _I, _I, _I],
     "ttk_avgpool_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I],
     "ttk_bn_act": [_P, _P, _P, _P, _P, _L, _I],
+    "ttk_heads_fwd": [_P] * 8 + [_I] * 6 + [_P] * 9,
+    "ttk_heads_bwd": [_P] * 8 + [_I] * 6 + [_P] * 15,
+    "ttk_diag_scale_fwd": [_P, _P, _I],
+    "ttk_diag_scale_bwd": [_P, _P, _P, _I],
+    "ttk_loss_rot_fwd": [_P, _P, _I, _P],
+    "ttk_loss_rot_bwd": [_P, _P, _P, _I, _P],
+    "ttk_loss_quatreg_fwd": [_P, _I, _P],
+    "ttk_loss_quatreg_bwd": [_P, _P, _I, _P],
+    "ttk_loss_mse_rows_fwd": [_P, _P, _I, _I, _P],
+    "ttk_loss_mse_rows_bwd": [_P, _P, _P, _I, _I, _P],
+    "ttk_loss_points_fwd": [_P, _P, _I, _I, _F, _F, _P],
+    "ttk_loss_points_bwd": [_P, _P, _P, _I, _I, _F, _F, _P],
+    "ttk_loss_nllrot_fwd": [_P, _P, _P, _I, _P],
+    "ttk_loss_nllrot_bwd": [_P, _P, _P, _P, _I, _P, _P],
+    "ttk_loss_nllcoord_fwd": [_P, _P, _P, _I, _P],
+    "ttk_loss_nllcoord_bwd": [_P, _P, _P, _P, _I, _P, _P],
+    "ttk_loss_normal_fwd": [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P],
+    "ttk_loss_normal_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P],
+    "ttk_loss_gmm_fwd": [_P, _P, _P, _P, _I, _D, _I, _P, _P],
+    "ttk_loss_gmm_bwd": [_P, _P, _P, _P, _I, _D, _P, _I, _P],
 }
 
 ABI_VERSION = 1
@@ -55,6 +75,7 @@ class _Library:
         for name in ("ttk_partial_rows_elementwise", "ttk_partial_rows_gemm"):
             fn = getattr(self.cdll, name)
             fn.argtypes, fn.restype = [c_int64], c_int
+        self.cdll.ttk_heads_num_rows.argtypes, self.cdll.ttk_heads_num_rows.restype = [c_int, c_int], c_int
         self._fns = {}
         for name, sig in _SIGNATURES.items():
             fn = getattr(self.cdll, name)  # AttributeError if the symbol is missing: loud by design
@@ -99,4 +120,4 @@ def ptr(t: torch.Tensor | None):
 
 def exported_symbols() -> list[str]:
     return ["ttk_abi_version", "ttk_last_error_string", "ttk_partial_rows_elementwise",
-            "ttk_partial_rows_gemm"] + list(_SIGNATURES)
+            "ttk_partial_rows_gemm", "ttk_heads_num_rows"] + list(_SIGNATURES)

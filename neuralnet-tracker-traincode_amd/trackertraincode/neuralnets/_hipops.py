@@ -1,0 +1,268 @@
+"""torch.autograd.Function wrappers around the heads / loss entry points of libttk_hip.so.
+
+Every function here requires CUDA tensors and the HIP library: there is no PyTorch fallback (the
+module API in losses.py / negloglikelihood.py / models.py raises for CPU tensors in training)."""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from .. import _hip
+
+_p = _hip.ptr
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError("this loss/head runs in HIP kernels on the MI355X: CUDA tensors required (no CPU fallback)")
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _call(name, *args):
+    _hip.lib().call(name, *args)
+
+
+# ---------------------------------------------------------------------------------------------
+# heads
+# ---------------------------------------------------------------------------------------------
+class HeadsFn(Function):
+    """feat[B,F] -> (roi, coord, rot, unnormalized_quat[, coord_scales, pose_scales_tril][, pt3d_68, shapeparam])"""
+
+    @staticmethod
+    def forward(ctx, feat, ids, unc, pt, use_offset, keypts, keyeig, P, Pk, *lin):
+        feat = _f32c(feat)
+        B, F = feat.shape
+        ws, bs = [_f32c(w) for w in lin[0::2]], [_f32c(b) for b in lin[1::2]]
+        wcat, bcat = torch.cat(ws, dim=0), torch.cat(bs, dim=0)
+        NZ = wcat.shape[0]
+        dev = feat.device
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        z, roi, coord, rot, qu = new(B, NZ), new(B, 4), new(B, 3), new(B, 4), new(B, 4)
+        Lc, Lr = (new(B, 3, 3), new(B, 3, 3)) if unc else (None, None)
+        pts, shp = (new(B, 68, 3), new(B, 50)) if pt else (None, None)
+        ids32 = None if ids is None else ids.to(device=dev, dtype=torch.int32).contiguous()
+        Pc = _f32c(P) if (use_offset and P is not None) else None
+        Pkc = _f32c(Pk) if (use_offset and pt and Pk is not None) else None
+        kp = _f32c(keypts) if pt else None
+        ke = _f32c(keyeig) if pt else None
+        _call("ttk_heads_fwd", _p(feat), _p(wcat), _p(bcat), _p(ids32), _p(Pc), _p(Pkc), _p(kp), _p(ke), B, F, NZ, int(unc),
+              int(pt), int(use_offset), _p(z), _p(roi), _p(coord), _p(rot), _p(qu), _p(Lc), _p(Lr), _p(pts), _p(shp))
+        ctx.save_for_backward(feat, wcat, z, ids32, Pc, Pkc, kp, ke)
+        ctx.cfg = (bool(unc), bool(pt), bool(use_offset), [w.shape[0] for w in ws])
+        outs = [roi, coord, rot, qu]
+        if unc:
+            outs += [Lc, Lr]
+        if pt:
+            outs += [pts, shp]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        feat, wcat, z, ids32, Pc, Pkc, kp, ke = ctx.saved_tensors
+        unc, pt, use_offset, rows = ctx.cfg
+        B, F = feat.shape
+        NZ = wcat.shape[0]
+        dev = feat.device
+        g = [_f32c(t) for t in gouts]
+        g_roi, g_coord, g_rot, g_qu = g[:4]
+        k = 4
+        g_Lc = g_Lr = g_pts = g_shp = None
+        if unc:
+            g_Lc, g_Lr = g[k], g[k + 1]
+            k += 2
+        if pt:
+            g_pts, g_shp = g[k], g[k + 1]
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        dz, dprow, dfeat, dwcat, dbcat = new(B, NZ), new(B, 8), new(B, F), new(NZ, F), new(NZ)
+        dP = new(8, 4) if Pc is not None else None
+        dPk = new(8, 4) if Pkc is not None else None
+        _call("ttk_heads_bwd", _p(feat), _p(wcat), _p(z), _p(ids32), _p(Pc), _p(Pkc), _p(kp), _p(ke), B, F, NZ, int(unc), int(pt),
+              int(use_offset), _p(g_roi), _p(g_coord), _p(g_rot), _p(g_qu), _p(g_Lc), _p(g_Lr), _p(g_pts), _p(g_shp), _p(dz),
+              _p(dprow), _p(dfeat), _p(dwcat), _p(dbcat), _p(dP), _p(dPk))
+        lin_grads = []
+        r0 = 0
+        for r in rows:
+            lin_grads += [dwcat[r0:r0 + r], dbcat[r0:r0 + r]]
+            r0 += r
+        # inputs: feat, ids, unc, pt, use_offset, keypts, keyeig, P, Pk, *lin
+        return (dfeat, None, None, None, None, None, None, dP, dPk, *lin_grads)
+
+
+class DiagScaleFn(Function):
+    """DiagonalScaleParameter: hidden[n+1] -> scales[n]"""
+
+    @staticmethod
+    def forward(ctx, hidden):
+        h = _f32c(hidden)
+        n = h.numel() - 1
+        out = torch.empty(n, dtype=torch.float32, device=h.device)
+        _call("ttk_diag_scale_fwd", _p(h), _p(out), n)
+        ctx.save_for_backward(h)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (h,) = ctx.saved_tensors
+        gh = torch.empty_like(h)
+        _call("ttk_diag_scale_bwd", _p(h), _p(_f32c(gout)), _p(gh), h.numel() - 1)
+        return gh
+
+
+# ---------------------------------------------------------------------------------------------
+# losses: each returns the per-sample vector [n]
+# ---------------------------------------------------------------------------------------------
+def _vec(n, like):
+    return torch.empty(n, dtype=torch.float32, device=like.device)
+
+
+class RotLossFn(Function):
+    @staticmethod
+    def forward(ctx, q, t):
+        q, t = _f32c(q), _f32c(t)
+        v = _vec(q.shape[0], q)
+        _call("ttk_loss_rot_fwd", _p(q), _p(t), q.shape[0], _p(v))
+        ctx.save_for_backward(q, t)
+        return v
+
+    @staticmethod
+    def backward(ctx, gv):
+        q, t = ctx.saved_tensors
+        gq = torch.empty_like(q)
+        _call("ttk_loss_rot_bwd", _p(q), _p(t), _p(_f32c(gv)), q.shape[0], _p(gq))
+        return gq, None
+
+
+class QuatRegFn(Function):
+    @staticmethod
+    def forward(ctx, q):
+        q = _f32c(q)
+        v = _vec(q.shape[0], q)
+        _call("ttk_loss_quatreg_fwd", _p(q), q.shape[0], _p(v))
+        ctx.save_for_backward(q)
+        return v
+
+    @staticmethod
+    def backward(ctx, gv):
+        (q,) = ctx.saved_tensors
+        gq = torch.empty_like(q)
+        _call("ttk_loss_quatreg_bwd", _p(q), _p(_f32c(gv)), q.shape[0], _p(gq))
+        return gq
+
+
+class MseRowsFn(Function):
+    """mean over the trailing dimension(s) of (p - t)^2; p, t: [n, D] (or [n] with D = 1)"""
+
+    @staticmethod
+    def forward(ctx, p, t):
+        shape = p.shape
+        p, t = _f32c(p).reshape(shape[0], -1), _f32c(t).reshape(shape[0], -1)
+        n, D = p.shape
+        v = _vec(n, p)
+        _call("ttk_loss_mse_rows_fwd", _p(p), _p(t), n, D, _p(v))
+        ctx.save_for_backward(p, t)
+        ctx.shape = shape
+        return v
+
+    @staticmethod
+    def backward(ctx, gv):
+        p, t = ctx.saved_tensors
+        gp = torch.empty_like(p)
+        _call("ttk_loss_mse_rows_bwd", _p(p), _p(t), _p(_f32c(gv)), p.shape[0], p.shape[1], _p(gp))
+        return gp.view(ctx.shape), None
+
+
+class PointsLossFn(Function):
+    @staticmethod
+    def forward(ctx, p, t, dim, chin, eye):
+        p, t = _f32c(p), _f32c(t)
+        n = p.shape[0]
+        v = _vec(n, p)
+        _call("ttk_loss_points_fwd", _p(p), _p(t), n, int(dim), float(chin), float(eye), _p(v))
+        ctx.save_for_backward(p, t)
+        ctx.cfg = (int(dim), float(chin), float(eye))
+        return v
+
+    @staticmethod
+    def backward(ctx, gv):
+        p, t = ctx.saved_tensors
+        gp = torch.empty_like(p)
+        _call("ttk_loss_points_bwd", _p(p), _p(t), _p(_f32c(gv)), p.shape[0], *ctx.cfg, _p(gp))
+        return gp, None, None, None, None
+
+
+class NllRotFn(Function):
+    @staticmethod
+    def forward(ctx, q, t, L):
+        q, t, L = _f32c(q), _f32c(t), _f32c(L)
+        v = _vec(q.shape[0], q)
+        _call("ttk_loss_nllrot_fwd", _p(q), _p(t), _p(L), q.shape[0], _p(v))
+        ctx.save_for_backward(q, t, L)
+        return v
+
+    @staticmethod
+    def backward(ctx, gv):
+        q, t, L = ctx.saved_tensors
+        gq, gL = torch.empty_like(q), torch.empty_like(L)
+        _call("ttk_loss_nllrot_bwd", _p(q), _p(t), _p(L), _p(_f32c(gv)), q.shape[0], _p(gq), _p(gL))
+        return gq, None, gL
+
+
+class NllCoordFn(Function):
+    @staticmethod
+    def forward(ctx, c, t, L):
+        c, t, L = _f32c(c), _f32c(t), _f32c(L)
+        v = _vec(c.shape[0], c)
+        _call("ttk_loss_nllcoord_fwd", _p(c), _p(t), _p(L), c.shape[0], _p(v))
+        ctx.save_for_backward(c, t, L)
+        return v
+
+    @staticmethod
+    def backward(ctx, gv):
+        c, t, L = ctx.saved_tensors
+        gc, gL = torch.empty_like(c), torch.empty_like(L)
+        _call("ttk_loss_nllcoord_bwd", _p(c), _p(t), _p(L), _p(_f32c(gv)), c.shape[0], _p(gc), _p(gL))
+        return gc, None, gL
+
+
+class NormalNllFn(Function):
+    """-mean Normal(mu, sigma).log_prob(x).  points=False: tensors [n, D]; points=True: [n, 68, 3] with the
+    first `dim` coordinates and the chin/eye point weights."""
+
+    @staticmethod
+    def forward(ctx, mu, sigma, x, points, dim, chin, eye):
+        mu, sigma, x = _f32c(mu), _f32c(sigma), _f32c(x)
+        n = mu.shape[0]
+        per = mu[0].numel()
+        v = _vec(n, mu)
+        cfg = (n, per, int(points), int(dim), float(chin), float(eye))
+        _call("ttk_loss_normal_fwd", _p(mu), _p(sigma), _p(x), *cfg, _p(v))
+        ctx.save_for_backward(mu, sigma, x)
+        ctx.cfg = cfg
+        return v
+
+    @staticmethod
+    def backward(ctx, gv):
+        mu, sigma, x = ctx.saved_tensors
+        gmu, gsg = torch.empty_like(mu), torch.empty_like(sigma)
+        _call("ttk_loss_normal_bwd", _p(mu), _p(sigma), _p(x), _p(_f32c(gv)), *ctx.cfg, _p(gmu), _p(gsg))
+        return gmu, gsg, None, None, None, None, None
+
+
+class GmmNllFn(Function):
+    @staticmethod
+    def forward(ctx, x, ck, mu, sinv, fudge):
+        x = _f32c(x)
+        n, K = x.shape[0], ck.shape[0]
+        v = _vec(n, x)
+        post = torch.empty((n, K), dtype=torch.float64, device=x.device)
+        _call("ttk_loss_gmm_fwd", _p(x), _p(ck), _p(mu), _p(sinv), K, float(fudge), n, _p(v), _p(post))
+        ctx.save_for_backward(x, mu, sinv, post)
+        ctx.fudge = float(fudge)
+        return v
+
+    @staticmethod
+    def backward(ctx, gv):
+        x, mu, sinv, post = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        _call("ttk_loss_gmm_bwd", _p(x), _p(mu), _p(sinv), _p(post), post.shape[1], ctx.fudge, _p(_f32c(gv)), x.shape[0], _p(gx))
+        return gx, None, None, None, None
