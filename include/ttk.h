@@ -212,6 +212,20 @@ int ttk_loss_normal_bwd(const float* mu, const float* sigma, const float* x, con
 int ttk_loss_gmm_fwd(const float* x, const double* ck, const double* mu, const double* sinv, int K, double fudge, int n, float* v, double* post, ttk_stream_t stream);
 int ttk_loss_gmm_bwd(const float* x, const double* mu, const double* sinv, const double* post, int K, double fudge, const float* gv, int n, float* gx, ttk_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Optimiser step: torch.nn.utils.clip_grad_norm_(params, max_norm) over ALL tensors followed by
+ * torch.optim.Adam (scripts/train_poseestimator.py:147-167 create_optimizer, :442-445
+ * gradient_clip_val=1.0) in two launches, no host sync.  Device tables: ptrs[ntensors][4] =
+ * {param, grad (0 = no gradient), exp_avg, exp_avg_sq} addresses; numel[ntensors]; group[ntensors]
+ * (index into the host arrays lr4/wd4); chunk_tensor/chunk_offset[nchunks] cut the tensors into
+ * chunks of chunk_size elements.  partial[nchunks]: scratch; out_norm (nullable): total grad norm.
+ * ------------------------------------------------------------------------------------------- */
+int ttk_clip_adam(const int64_t* ptrs, const int32_t* numel, const int32_t* group,
+                  const int32_t* chunk_tensor, const int32_t* chunk_offset, int nchunks, int chunk_size,
+                  const float* lr4, const float* wd4, float beta1, float beta2, float eps,
+                  float bias_correction1, float bias_correction2, float max_norm, float* partial,
+                  float* out_norm, ttk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,116 @@
+// Fused global-norm gradient clipping + Adam over all parameter tensors in two launches, with no
+// host synchronisation.  Replaces Lightning's clip_grad_norm_(max_norm=1.0, "norm") followed by
+// torch.optim.Adam.step (scripts/train_poseestimator.py:147-167,442-445): ~190 tensors, 3.2 M floats.
+//
+// Work is cut into fixed-size chunks (multi-tensor apply): chunk c covers elements
+// [chunk_offset[c], chunk_offset[c]+chunk_size) of tensor chunk_tensor[c].
+//   pass 1: partial[c] = sum g^2 over the chunk
+//   pass 2: every block re-adds the partials in a fixed order (fp64) -> total norm -> clip coefficient
+//           -> Adam update of its chunk.  Deterministic.
+#include "ttk_common.h"
+
+namespace ttk {
+
+struct AdamTables {
+  const int64_t* ptrs;          // [ntensors][4]: param, grad, exp_avg, exp_avg_sq (device addresses)
+  const int32_t* numel;         // [ntensors]
+  const int32_t* group;         // [ntensors]: index into lr[] / wd[]
+  const int32_t* chunk_tensor;  // [nchunks]
+  const int32_t* chunk_offset;  // [nchunks]
+};
+struct AdamHyper {
+  float lr[4], wd[4];
+  float beta1, beta2, eps, bc1, bc2, max_norm;
+};
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < kBlock / kWave; ++i) s += red[i];
+  __syncthreads();
+  return s;
+}
+
+__global__ void __launch_bounds__(kBlock) grad_sqnorm_k(AdamTables t, int chunk_size, float* __restrict__ partial) {
+  __shared__ float red[kBlock / kWave];
+  const int c = blockIdx.x;
+  const int ti = t.chunk_tensor[c], off = t.chunk_offset[c];
+  const float* g = reinterpret_cast<const float*>(t.ptrs[4 * ti + 1]);
+  const int n = min(chunk_size, t.numel[ti] - off);
+  float acc = 0.f;
+  if (g)
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+      const float v = g[off + i];
+      acc = fmaf(v, v, acc);
+    }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[c] = acc;
+}
+
+__global__ void __launch_bounds__(kBlock) clip_adam_k(AdamTables t, AdamHyper h, int chunk_size, int nchunks,
+                                                       const float* __restrict__ partial, float* __restrict__ out_norm) {
+  __shared__ double dred[kBlock];
+  // total gradient norm: fixed-order fp64 sum of the chunk partials (identical in every block)
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nchunks; i += kBlock) acc += (double)partial[i];
+  dred[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) dred[threadIdx.x] += dred[threadIdx.x + s];
+    __syncthreads();
+  }
+  const float total = (float)sqrt(dred[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && out_norm) *out_norm = total;
+  float coef = 1.f;
+  if (h.max_norm > 0.f) coef = fminf(h.max_norm / (total + 1.0e-6f), 1.f);  // torch.nn.utils.clip_grad_norm_
+
+  const int c = blockIdx.x;
+  const int ti = t.chunk_tensor[c], off = t.chunk_offset[c];
+  float* p = reinterpret_cast<float*>(t.ptrs[4 * ti + 0]);
+  const float* g = reinterpret_cast<const float*>(t.ptrs[4 * ti + 1]);
+  float* m = reinterpret_cast<float*>(t.ptrs[4 * ti + 2]);
+  float* v = reinterpret_cast<float*>(t.ptrs[4 * ti + 3]);
+  if (!g) return;  // parameter without gradient this step: untouched, like torch.optim.Adam
+  const int n = min(chunk_size, t.numel[ti] - off);
+  const float lr = h.lr[t.group[ti]], wd = h.wd[t.group[ti]];
+  const float step_size = lr / h.bc1, inv_sqrt_bc2 = 1.f / sqrtf(h.bc2);
+  for (int i = threadIdx.x; i < n; i += kBlock) {
+    const int k = off + i;
+    float gr = g[k] * coef;
+    float pv = p[k];
+    if (wd != 0.f) gr = fmaf(wd, pv, gr);  // Adam's L2 form of weight_decay
+    const float mv = fmaf(h.beta1, m[k], (1.f - h.beta1) * gr);
+    const float vv = fmaf(h.beta2, v[k], (1.f - h.beta2) * gr * gr);
+    m[k] = mv;
+    v[k] = vv;
+    const float denom = sqrtf(vv) * inv_sqrt_bc2 + h.eps;
+    p[k] = pv - step_size * (mv / denom);
+  }
+}
+
+}  // namespace ttk
+
+using namespace ttk;
+
+extern "C" {
+
+int ttk_clip_adam(const int64_t* ptrs, const int32_t* numel, const int32_t* group, const int32_t* chunk_tensor,
+                  const int32_t* chunk_offset, int nchunks, int chunk_size, const float* lr4, const float* wd4, float beta1,
+                  float beta2, float eps, float bias_correction1, float bias_correction2, float max_norm, float* partial,
+                  float* out_norm, ttk_stream_t stream) {
+  TTK_REQUIRE(ptrs && numel && group && chunk_tensor && chunk_offset && lr4 && wd4 && partial, "clip_adam: null pointer");
+  TTK_REQUIRE(nchunks > 0 && chunk_size > 0, "clip_adam: bad chunking");
+  AdamTables t{ptrs, numel, group, chunk_tensor, chunk_offset};
+  AdamHyper h;
+  for (int i = 0; i < 4; ++i) { h.lr[i] = lr4[i]; h.wd[i] = wd4[i]; }
+  h.beta1 = beta1; h.beta2 = beta2; h.eps = eps; h.bc1 = bias_correction1; h.bc2 = bias_correction2; h.max_norm = max_norm;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(grad_sqnorm_k, dim3(nchunks), dim3(kBlock), 0, st, t, chunk_size, partial);
+  hipLaunchKernelGGL(clip_adam_k, dim3(nchunks), dim3(kBlock), 0, st, t, h, chunk_size, nchunks, partial, out_norm);
+  TTK_LAUNCH_CHECK("clip_adam");
+}
+
+}  // extern "C"

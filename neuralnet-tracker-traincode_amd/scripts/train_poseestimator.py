@@ -1,0 +1,161 @@
+#!/usr/bin/env python
+"""Training entry point with the reference's flags (reference: scripts/train_poseestimator.py), run on
+MI355X GPUs through the HIP kernels.  `python train_poseestimator.py --ds synthetic --epochs 2`.
+
+Same functions as the reference script for the parts the hot path needs: `setup_losses` (:170-285),
+`find_variance_parameters` / `setup_lr_with_slower_variance_training` / `create_optimizer` (:114-167),
+`create_net` (:288-296).  Lightning's Trainer is replaced by trackertraincode.train.fit; plotting and
+the HDF5 datasets are not part of this package.  Added flags: --devices (data-parallel replicas, one
+process per GPU; launch with torch.distributed.run).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+from os.path import dirname, join
+
+import torch
+import torch.nn as nn
+
+sys.path.insert(0, dirname(dirname(os.path.abspath(__file__))))
+
+import trackertraincode.neuralnets.losses as losses  # noqa: E402
+import trackertraincode.neuralnets.models as models  # noqa: E402
+import trackertraincode.neuralnets.negloglikelihood as NLL  # noqa: E402
+import trackertraincode.pipelines  # noqa: E402
+import trackertraincode.train as train  # noqa: E402
+from trackertraincode.pipelines import Tag  # noqa: E402
+
+
+def find_variance_parameters(net: nn.Module):
+    """Parameters of the uncertainty heads: trained at 0.1 x lr (reference :114-122)."""
+    if isinstance(net, (NLL.FeaturesAsTriangularScale, NLL.FeaturesAsDiagonalScale, NLL.DiagonalScaleParameter)):
+        return list(net.parameters())
+    return sum((find_variance_parameters(c) for c in net.children()), start=[])
+
+
+def find_transformer_parameters(net: nn.Module):
+    if isinstance(net, (nn.TransformerEncoderLayer, nn.TransformerDecoderLayer)):
+        return list(net.parameters())
+    return sum((find_transformer_parameters(c) for c in net.children()), start=[])
+
+
+def setup_lr_with_slower_variance_training(net, base_lr):
+    variance = find_variance_parameters(net)
+    transformer = find_transformer_parameters(net)
+    special = {id(p) for p in variance + transformer}
+    other = [p for p in net.parameters() if id(p) not in special]
+    return [
+        {"params": other, "lr": base_lr},
+        {"params": variance, "lr": 0.1 * base_lr},
+        {"params": transformer, "lr": 0.01 * base_lr, "weight_decay": 0.01},
+    ]
+
+
+def create_optimizer(net, args):
+    """Fused clip(1.0)+Adam over the reference's three parameter groups and its LR schedule."""
+    groups = [g for g in setup_lr_with_slower_variance_training(net, args.lr) if g["params"]]
+    optimizer = train.ClipAdam(groups, lr=args.lr, max_norm=1.0)
+    n_epochs = args.epochs
+    scheduler = train.ExponentialUpThenSteps(optimizer, max(1, n_epochs // 10), 0.1, [n_epochs // 2])
+    return optimizer, scheduler
+
+
+def setup_losses(args, net):
+    """Tag -> CriterionGroup tables with the reference's names and weights (:170-285)."""
+    if args.enable_6drot:
+        raise NotImplementedError("--enable-6drot: the 6D rotation head is not built in this round")
+    C = train.Criterion
+    rot_loss = losses.QuatPoseLoss("approx_distance")
+    cregularize = [C("quatregularization1", losses.QuaternionNormalizationSoftConstraint(), 1.0e-6)]
+    poselosses, roilosses, pointlosses, pointlosses25d, shapeparamloss = [], [], [], [], []
+
+    if args.with_nll_loss:
+        def ramped(multiplier):
+            if not args.rampup_nll_losses:
+                return multiplier * 0.01
+            return lambda step: 0.01 * min(1.0, max(0.0, (step / args.epochs - 0.1) * 10.0)) * multiplier
+
+        poselosses += [C("nllrot", NLL.QuatPoseNLLLoss(), ramped(0.5)), C("nllcoord", NLL.CorrelatedCoordPoseNLLLoss(), ramped(0.5))]
+        if args.with_roi_train:
+            roilosses += [C("nllbox", NLL.BoxNLLLoss(distribution="gaussian"), ramped(0.01))]
+        if args.with_pointhead:
+            pointlosses += [C("nllpoints3d", NLL.Points3dNLLLoss(chin_weight=0.8, eye_weight=0.0), ramped(0.5))]
+            pointlosses25d += [C("nllpoints3d", NLL.Points3dNLLLoss(chin_weight=0.8, eye_weight=0.0, pointdimension=2), ramped(0.5))]
+    poselosses += [C("rot", rot_loss, 1.0), C("xy", losses.PoseXYLoss("l2"), 0.25), C("sz", losses.PoseSizeLoss("l2"), 0.25)]
+    if args.with_roi_train:
+        roilosses += [C("box", losses.BoxLoss("l2"), 0.01)]
+    if args.with_pointhead:
+        pointlosses += [C("points3d", losses.Points3dLoss("l2", chin_weight=0.8, eye_weights=0.0), 0.5)]
+        pointlosses25d += [C("points3d", losses.Points3dLoss("l2", pointdimension=2, chin_weight=0.8, eye_weights=0.0), 0.5)]
+        shapeparamloss += [C("shp_l2", losses.ShapeParameterLoss(), 0.1)]
+        cregularize += [C("nll_shp_gmm", losses.ShapePlausibilityLoss(), 0.1)]
+
+    G = train.CriterionGroup
+    train_criterions = {
+        Tag.ONLY_POSE: G(poselosses + cregularize + roilosses),
+        Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS: G(poselosses + cregularize + pointlosses + roilosses),
+        Tag.POSE_WITH_LANDMARKS: G(poselosses + cregularize + pointlosses + shapeparamloss + roilosses),
+        Tag.POSE_WITH_LANDMARKS_3D_AND_2D: G(poselosses + cregularize + pointlosses + shapeparamloss + roilosses),
+        Tag.ONLY_LANDMARKS: G(pointlosses + cregularize),
+        Tag.ONLY_LANDMARKS_25D: G(pointlosses25d + cregularize),
+    }
+    test_criterions = {Tag.POSE_WITH_LANDMARKS: G(poselosses + pointlosses + roilosses + shapeparamloss + cregularize)}
+    return train_criterions, test_criterions
+
+
+def create_net(args):
+    return models.NetworkWithPointHead(
+        enable_point_head=args.with_pointhead, enable_face_detector=False, config=args.backbone,
+        enable_uncertainty=args.with_nll_loss, backbone_args={"use_blurpool": args.with_blurpool}, enable_6drot=args.enable_6drot,
+    )
+
+
+def make_parser():
+    p = argparse.ArgumentParser(description="Trains the model")
+    p.add_argument("--backbone", default="mobilenetv1")
+    p.add_argument("--batchsize", type=int, default=64)
+    p.add_argument("--lr", type=float, default=1.0e-3)
+    p.add_argument("--epochs", type=int, default=200)
+    p.add_argument("--ds", type=str, default="synthetic")
+    p.add_argument("--with-swa", action="store_true", default=False, dest="swa")
+    p.add_argument("--outdir", type=str, default=join(dirname(__file__), "..", "model_files"))
+    p.add_argument("--ds-weighting", action="store_false", default=True, dest="ds_weight_are_sampling_frequencies")
+    p.add_argument("--no-pointhead", action="store_false", default=True, dest="with_pointhead")
+    p.add_argument("--with-nll-loss", default=False, action="store_true")
+    p.add_argument("--raug", default=30, type=float, dest="rotation_aug_angle")
+    p.add_argument("--no-imgaug", default=True, action="store_false", dest="with_image_aug")
+    p.add_argument("--blurpool", default=False, action="store_true", dest="with_blurpool")
+    p.add_argument("--roi-override", default="original", type=str, choices=["extent_to_forehead", "original", "landmarks"], dest="roi_override")
+    p.add_argument("--no-roi-train", default=True, action="store_false", dest="with_roi_train")
+    p.add_argument("--rampup-nll-losses", default=False, action="store_true")
+    p.add_argument("--enable-6drot", default=False, action="store_true")
+    return p
+
+
+def main():
+    args = make_parser().parse_args()
+    args.input_size = 129
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(device)
+    train_loader, _, _ = trackertraincode.pipelines.make_pose_estimation_loaders(
+        inputsize=args.input_size, batchsize=args.batchsize, datasets=args.ds, device=device)
+    net = create_net(args).to(device)
+    train_crit, _ = setup_losses(args, net)
+    optimizer, scheduler = create_optimizer(net, args)
+    callbacks = [train.SwaCallback(start_epoch=args.epochs * 2 // 3)] if args.swa else []
+
+    def report(epoch, out):
+        pass
+
+    train.fit(net, train_loader, train_crit, optimizer, scheduler, epochs=args.epochs, callbacks=callbacks, on_step=report)
+    out_dir = join(args.outdir, net.name)
+    os.makedirs(out_dir, exist_ok=True)
+    models.save_model(net.to("cpu"), join(out_dir, "last.ckpt"))
+    for cb in callbacks:
+        cb.on_train_end(out_dir)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,122 @@
+"""Task tags, dataset ids and the loader entry point (reference: trackertraincode/pipelines.py).
+
+In scope for the MI355X path: the `Tag` / `Id` vocabularies and the contract of
+`make_pose_estimation_loaders` (train loader yields `list[Batch]`, one Batch per Tag, images already
+on the device, f32 [n,1,129,129] in about [-0.5, 0.5]).  The reference's dataset constructors read
+unpublished / multi-GB HDF5 files through h5py + OpenCV in worker processes (pipelines.py:399-500) and
+are out of scope; `SyntheticPoseLoader` provides the same contract from
+seeded tensors for benchmarks and tests.
+"""
+from __future__ import annotations
+
+import enum
+from typing import Iterator, Sequence
+
+import torch
+
+from .datasets.batch import Batch, Metadata
+
+
+class Tag(enum.Enum):
+    POSE_WITH_LANDMARKS = 1
+    SELF_SUPERVISED_POSE = 2
+    FACE_DETECTION = 3
+    ONLY_LANDMARKS = 4
+    ONLY_LANDMARKS_25D = 5
+    ONLY_POSE = 7
+    POSE_WITH_LANDMARKS_3D_AND_2D = 8
+    ONLY_LANDMARKS_2D = 9
+    SEMSEG = 10
+    POSE_WITH_LMKS_NO_SHAPE_PARAMS = 11
+
+
+class Id(enum.Enum):
+    _300WLP = 2
+    SYNFACE = 5
+    WFLW_RELABEL = 6
+    AFLW2k3d = 8
+    BIWI = 9
+    WIDER = 11
+    _300VW = 12
+    LAPA = 13
+    REPO_300WLP = 15
+    WFLW_LP = 16
+    LAPA_MEGAFACE_LP = 17
+    REPO_300WLP_WO_EXTRA = 18
+    PANOPTIC_CMU = 19
+    REPLICANT_FACE = 20
+
+
+_FIELDS_BY_TAG = {
+    Tag.POSE_WITH_LANDMARKS: ("pose", "coord", "roi", "pt3d_68", "shapeparam"),
+    Tag.POSE_WITH_LANDMARKS_3D_AND_2D: ("pose", "coord", "roi", "pt3d_68", "shapeparam"),
+    Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS: ("pose", "coord", "roi", "pt3d_68"),
+    Tag.ONLY_POSE: ("pose", "coord", "roi"),
+    Tag.ONLY_LANDMARKS: ("pt3d_68",),
+    Tag.ONLY_LANDMARKS_25D: ("pt3d_68",),
+}
+
+
+def synthetic_subbatch(tag: Tag, n: int, device, generator: torch.Generator, inputsize: int = 129) -> Batch:
+    """One sub-batch with the label distributions of SURVEY.md §8(d)."""
+    g = generator
+    r = lambda *s: torch.rand(*s, generator=g, device=g.device)
+    rn = lambda *s: torch.randn(*s, generator=g, device=g.device)
+    data = {
+        "image": r(n, 1, inputsize, inputsize) - 0.5,
+        "coord_convention_id": torch.randint(0, 8, (n,), generator=g, device=g.device, dtype=torch.int32),
+    }
+    fields = _FIELDS_BY_TAG[tag]
+    if "pose" in fields:
+        data["pose"] = torch.nn.functional.normalize(rn(n, 4), dim=-1)
+    if "coord" in fields:
+        data["coord"] = torch.stack((r(n) * 0.6 - 0.3, r(n) * 0.6 - 0.3, r(n) * 0.8 + 0.8), dim=-1)
+    if "roi" in fields:
+        data["roi"] = torch.tensor([-0.85, -0.85, 0.85, 0.85], device=g.device) + (r(n, 4) * 0.2 - 0.1)
+    if "pt3d_68" in fields:
+        data["pt3d_68"] = rn(n, 68, 3) * 0.5
+    if "shapeparam" in fields:
+        data["shapeparam"] = rn(n, 50) * 0.5
+    return Batch(Metadata(inputsize, batchsize=n, tag=tag), {k: v.to(device) for k, v in data.items()})
+
+
+class SyntheticPoseLoader:
+    """Endless iterator of `list[Batch]` split by Tag in fixed proportions (the contract of the train
+    loader returned by make_pose_estimation_loaders, reference :534-554)."""
+
+    def __init__(self, batchsize: int, tags_and_weights: Sequence[tuple[Tag, float]], device="cuda", seed=1234, inputsize=129,
+                 steps_per_epoch: int | None = None):
+        total = sum(w for _, w in tags_and_weights)
+        counts = [int(batchsize * w / total) for _, w in tags_and_weights]
+        counts[0] += batchsize - sum(counts)
+        self._plan = [(t, c) for (t, _), c in zip(tags_and_weights, counts) if c > 0]
+        self._device, self._inputsize = device, inputsize
+        self._gen = torch.Generator(device="cpu")
+        self._gen.manual_seed(seed)
+        self._steps = steps_per_epoch if steps_per_epoch is not None else (10 * 1024) // batchsize
+
+    def __len__(self):
+        return self._steps
+
+    def __iter__(self) -> Iterator[list[Batch]]:
+        for _ in range(self._steps):
+            yield [synthetic_subbatch(t, c, self._device, self._gen, self._inputsize) for t, c in self._plan]
+
+
+def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights=None, use_weights_as_sampling_frequency=True,
+                                 enable_image_aug=True, rotation_aug_angle=30.0, roi_override="original", device="cuda"):
+    """Signature of the reference (pipelines.py:359-369).  `datasets` may be the string "synthetic" (or a
+    list of (Tag, weight) pairs) to obtain seeded synthetic loaders with the reference's contract; real
+    dataset ids need the HDF5 pipeline, which this package does not contain."""
+    if datasets == "synthetic":
+        datasets = [(Tag.POSE_WITH_LANDMARKS, 11.0), (Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS, 1.0)]
+    if isinstance(datasets, (list, tuple)) and datasets and isinstance(datasets[0], tuple) and isinstance(datasets[0][0], Tag):
+        train = SyntheticPoseLoader(batchsize, datasets, device=device, inputsize=inputsize)
+        test = SyntheticPoseLoader(batchsize, [(Tag.POSE_WITH_LANDMARKS, 1.0)], device=device, seed=4321, inputsize=inputsize,
+                                   steps_per_epoch=max(1, 400 // batchsize))
+        return train, test, len(train) * batchsize
+    raise NotImplementedError(
+        "make_pose_estimation_loaders: the HDF5 dataset readers of the reference (h5py/OpenCV worker "
+        "pipeline, $DATADIR) are outside the hot path this package implements; pass datasets='synthetic' "
+        "or feed list[Batch] from your own loader"
+    )

@@ -1,0 +1,284 @@
+"""Loss plumbing, optimiser, schedules and the training loop (reference: trackertraincode/train.py and
+the Lightning pieces of scripts/train_poseestimator.py).
+
+Same public names as the reference for what the hot path uses: LossVal, Criterion, CriterionGroup,
+concatenated_lossvals_by_name, default_compute_loss, ExponentialUpThenSteps, LinearUpThenSteps,
+SwaCallback.  pytorch-lightning is replaced by `fit()` below, which reproduces the step order the
+reference gets from `pl.Trainer(gradient_clip_val=1.0, gradient_clip_algorithm="norm")`:
+zero_grad -> forward -> loss -> backward -> global-norm clip -> Adam, LR scheduler stepped per epoch,
+SWA update per epoch after `start_epoch`.  The clip+Adam pair is one fused HIP entry point
+(`ClipAdam`, csrc/adam.hip).
+
+Difference on purpose: `default_compute_loss` does NOT copy the per-sample loss vectors to the host
+and does NOT synchronise the stream every step (reference :433-438); the returned LossVals hold
+detached DEVICE tensors (call .cpu() when you want them).
+"""
+from __future__ import annotations
+
+import ctypes
+import itertools
+import math
+import os
+from collections import defaultdict
+from typing import Any, Callable, List, NamedTuple, Union
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+from torch.optim.lr_scheduler import LambdaLR
+
+from . import _hip
+from .datasets.batch import Batch
+from .neuralnets.io import save_model
+
+
+class LossVal(NamedTuple):
+    val: Tensor
+    weight: Any
+    name: str
+
+
+def concatenated_lossvals_by_name(vals):
+    """{name: (values, weights)} concatenated over sub-batches, first-seen order (reference :47-62)."""
+    values, weights = defaultdict(list), defaultdict(list)
+    for v in vals:
+        values[v.name].append(v.val)
+        weights[v.name].append(v.weight)
+    return {k: (torch.concat(values[k]), torch.concat(weights[k])) for k in values}
+
+
+def _weight_at(w, step):
+    return w if isinstance(w, float) else w(step)
+
+
+class Criterion(NamedTuple):
+    name: str
+    f: Callable[[Any, Any], Tensor]
+    w: Union[float, Callable[[int], float]]
+
+    def evaluate(self, pred, batch, step) -> List[LossVal]:
+        return [LossVal(self.f(pred, batch), _weight_at(self.w, step), self.name)]
+
+
+class CriterionGroup(NamedTuple):
+    criterions: List[Union["CriterionGroup", Criterion]]
+    name: str = ""
+    w: Union[float, Callable[[int], float]] = 1.0
+
+    def evaluate(self, pred, batch, step) -> List[LossVal]:
+        w = _weight_at(self.w, step)
+        out = []
+        for c in self.criterions:
+            out += [LossVal(v.val, v.weight * w, self.name + v.name) for v in c.evaluate(pred, batch, step)]
+        return out
+
+
+def default_compute_loss(preds: dict, batch: List[Batch], current_epoch: int, loss):
+    """(loss_sum, per-sub-batch lists of LossVal) - reference :372-439.
+
+    Sub-batches are addressed by integer offsets into the concatenated predictions; weights become
+    per-sample tensors (scaled by `dataset_weight` when the sub-batch has one); the sum is divided by
+    the TOTAL batch size so that a loss a sub-batch does not have counts as zero."""
+    all_lossvals: list[list[LossVal]] = []
+    offset = 0
+    for subset in batch:
+        (n,) = subset.meta.prefixshape
+        subpreds = {k: v[offset:offset + n, ...] for k, v in preds.items()}
+        crit = loss[subset.meta.tag] if isinstance(loss, dict) else loss
+        terms = crit.evaluate(subpreds, subset, current_epoch)
+        if "dataset_weight" in subset:
+            dw = subset["dataset_weight"]
+            assert dw.size(0) == subset.meta.batchsize
+            terms = [v._replace(weight=v.weight * dw) for v in terms]
+        else:
+            terms = [v._replace(weight=v.val.new_full(v.val.shape, v.weight)) for v in terms]
+        all_lossvals.append(terms)
+        offset += n
+    batchsize = sum(subset.meta.batchsize for subset in batch)
+    by_name = concatenated_lossvals_by_name(itertools.chain.from_iterable(all_lossvals))
+    loss_sum = torch.concat([v * w for v, w in by_name.values()]).sum() / batchsize
+    all_lossvals = [[v._replace(val=v.val.detach()) for v in terms] for terms in all_lossvals]
+    return loss_sum, all_lossvals
+
+
+# ---------------------------------------------------------------------------------------------
+# learning-rate schedules (reference :577-629)
+# ---------------------------------------------------------------------------------------------
+def _step_factor(i, gamma, steps):
+    return gamma ** [j for j, s in enumerate([0] + list(steps)) if i > s][-1]
+
+
+def LinearUpThenSteps(optimizer, num_up, gamma, steps):
+    return LambdaLR(optimizer, lambda i: (i + 1) / num_up if i < num_up else _step_factor(i, gamma, steps))
+
+
+def ExponentialUpThenSteps(optimizer, num_up, gamma, steps):
+    """0.01 -> 1 exponentially over `num_up` epochs, then gamma^k after the k-th step epoch."""
+    eps = 1.0e-2
+
+    def factor(i):
+        if i < num_up:
+            return eps * math.exp(-math.log(eps) * (i + 1) / num_up)
+        return _step_factor(i, gamma, steps)
+
+    return LambdaLR(optimizer, factor)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused clip + Adam
+# ---------------------------------------------------------------------------------------------
+class ClipAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (betas, eps, L2 weight_decay, per-group lr) preceded by
+    clip_grad_norm_(all params, max_norm) - one C-ABI call, two kernel launches, no host sync.
+    State layout matches torch.optim.Adam (`step`, `exp_avg`, `exp_avg_sq`)."""
+
+    CHUNK = 16384
+
+    def __init__(self, params, lr=1.0e-3, betas=(0.9, 0.999), eps=1.0e-8, weight_decay=0.0, max_norm: float | None = 1.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.param_groups = [g for g in self.param_groups]
+        if len([g for g in self.param_groups if g["params"]]) > 4:
+            raise ValueError("ClipAdam supports at most 4 non-empty parameter groups")
+        if len({(g["betas"], g["eps"]) for g in self.param_groups}) != 1:
+            raise ValueError("all groups must share betas and eps")
+        self.max_norm = max_norm
+        self._tables = None
+        self._t = 0
+        self.last_grad_norm: Tensor | None = None
+
+    def _build_tables(self):
+        plist, groups = [], []
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    raise RuntimeError("ClipAdam needs contiguous float32 CUDA parameters")
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                plist.append(p)
+                groups.append(gi)
+        dev = plist[0].device
+        ct, co = [], []
+        for ti, p in enumerate(plist):
+            for off in range(0, p.numel(), self.CHUNK):
+                ct.append(ti)
+                co.append(off)
+        i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=dev)
+        self._tables = dict(
+            params=plist, numel=i32([p.numel() for p in plist]), group=i32(groups), chunk_tensor=i32(ct), chunk_offset=i32(co),
+            nchunks=len(ct), ptrs_host=torch.zeros((len(plist), 4), dtype=torch.int64).pin_memory(),
+            ptrs=torch.zeros((len(plist), 4), dtype=torch.int64, device=dev),
+            partial=torch.empty(len(ct), dtype=torch.float32, device=dev), norm=torch.zeros(1, dtype=torch.float32, device=dev),
+        )
+        h = self._tables["ptrs_host"]
+        for ti, p in enumerate(plist):
+            st = self.state[p]
+            h[ti, 0], h[ti, 2], h[ti, 3] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        if self._tables is None:
+            self._build_tables()
+        T = self._tables
+        h = T["ptrs_host"]
+        for ti, p in enumerate(T["params"]):
+            g = p.grad
+            if g is not None and not g.is_contiguous():
+                g = p.grad = g.contiguous()
+            h[ti, 1] = 0 if g is None else g.data_ptr()
+        T["ptrs"].copy_(h, non_blocking=True)
+        self._t += 1
+        b1, b2 = self.param_groups[0]["betas"]
+        lr4 = (ctypes.c_float * 4)(*([g["lr"] for g in self.param_groups] + [0.0] * 4)[:4])
+        wd4 = (ctypes.c_float * 4)(*([g["weight_decay"] for g in self.param_groups] + [0.0] * 4)[:4])
+        p_ = _hip.ptr
+        _hip.lib().call("ttk_clip_adam", p_(T["ptrs"]), p_(T["numel"]), p_(T["group"]), p_(T["chunk_tensor"]), p_(T["chunk_offset"]),
+                        T["nchunks"], self.CHUNK, lr4, wd4, b1, b2, self.param_groups[0]["eps"], 1.0 - b1 ** self._t,
+                        1.0 - b2 ** self._t, float(self.max_norm or 0.0), p_(T["partial"]), p_(T["norm"]))
+        for p in T["params"]:
+            self.state[p]["step"] += 1
+        self.last_grad_norm = T["norm"]
+        return None
+
+
+# ---------------------------------------------------------------------------------------------
+# stochastic weight averaging (reference SwaCallback :447-467)
+# ---------------------------------------------------------------------------------------------
+class SwaCallback:
+    """Equal-weight running average of parameters AND buffers (AveragedModel(use_buffers=True)),
+    updated once per epoch for epochs > start_epoch, kept on the CPU, saved as swa.ckpt."""
+
+    def __init__(self, start_epoch):
+        self._start_epoch = start_epoch
+        self._swa_model = None
+        self.n_averaged = 0
+
+    @property
+    def swa_model(self):
+        return self._swa_model
+
+    def on_train_start(self, model: nn.Module):
+        import copy
+
+        self._swa_model = copy.deepcopy(model).to("cpu")
+
+    @torch.no_grad()
+    def on_train_epoch_end(self, epoch: int, model: nn.Module):
+        if epoch <= self._start_epoch:
+            return
+        avg, new = self._swa_model.state_dict(), model.state_dict()
+        for k, a in avg.items():
+            b = new[k].detach().to("cpu")
+            if self.n_averaged == 0:
+                a.copy_(b)
+            elif a.is_floating_point():
+                a.add_((b - a) / (self.n_averaged + 1))
+            else:
+                a.copy_(a + torch.div(b - a, self.n_averaged + 1, rounding_mode="trunc"))
+        self.n_averaged += 1
+
+    def on_train_end(self, root_dir: str):
+        assert self._swa_model is not None
+        save_model(self._swa_model, os.path.join(root_dir, "swa.ckpt"))
+
+
+# ---------------------------------------------------------------------------------------------
+# the loop
+# ---------------------------------------------------------------------------------------------
+def training_step(model: nn.Module, batches: List[Batch], epoch: int, criterions):
+    """LitModel.training_step (scripts/train_poseestimator.py:310-330) without the logging."""
+    inputs = torch.concat([b["image"] for b in batches], dim=0)
+    ids = torch.concat([b["coord_convention_id"] for b in batches], dim=0)
+    preds = model(inputs, ids)
+    loss_sum, all_lossvals = default_compute_loss(preds, batches, epoch, criterions)
+    by_name = {k: v for k, (v, _) in concatenated_lossvals_by_name(itertools.chain.from_iterable(all_lossvals)).items()}
+    return {"loss": loss_sum, "mt_losses": by_name}
+
+
+def fit(model: nn.Module, train_loader, criterions, optimizer, scheduler=None, epochs=1, callbacks=(), on_step=None,
+        grad_sync=None):
+    """Epoch loop with Lightning's ordering.  `grad_sync(model)`, if given, runs between backward and the
+    optimiser step (data-parallel gradient all-reduce)."""
+    for cb in callbacks:
+        if hasattr(cb, "on_train_start"):
+            cb.on_train_start(model)
+    model.train()
+    for epoch in range(epochs):
+        for batches in train_loader:
+            optimizer.zero_grad(set_to_none=True)
+            out = training_step(model, batches, epoch, criterions)
+            out["loss"].backward()
+            if grad_sync is not None:
+                grad_sync(model)
+            optimizer.step()
+            if on_step is not None:
+                on_step(epoch, out)
+        if scheduler is not None:
+            scheduler.step()
+        for cb in callbacks:
+            if hasattr(cb, "on_train_epoch_end"):
+                cb.on_train_epoch_end(epoch, model)
+    return model

@@ -1,0 +1,119 @@
+"""CPU tests of the host-side surface: C-ABI exports, state-dict inventory, checkpoint io, Batch
+collation, CPU eval/export path against the reference's golden outputs, schedules."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import refmodel as R
+from oracle.synth import make_inputs, make_state
+from util import GOLDEN, PKG, REPO, build_net, load_golden
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    lib_path = os.path.join(PKG, "libttk_hip.so")
+    assert os.path.exists(lib_path), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(lib_path)
+    header = open(os.path.join(REPO, "include", "ttk.h")).read()
+    declared = sorted(set(re.findall(r"\b(ttk_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) > 40
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ttk.h but not exported"
+    import trackertraincode._hip as H
+
+    assert set(H.exported_symbols()) <= set(declared)
+    lib.ttk_abi_version.restype = ctypes.c_int
+    assert lib.ttk_abi_version() == H.ABI_VERSION
+
+
+@pytest.mark.parametrize("unc,pt", [(True, True), (False, True), (False, False)])
+def test_state_dict_inventory(unc, pt):
+    from trackertraincode.neuralnets.models import NetworkWithPointHead
+
+    net = NetworkWithPointHead(enable_point_head=pt, enable_uncertainty=unc)
+    mine = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    ref = R.state_shapes(pt, unc)  # pinned to the reference by test_oracle_golden
+    assert list(mine) == list(ref) and mine == ref
+    assert net.get_config() == {"enable_point_head": pt, "enable_face_detector": False, "config": "mobilenetv1",
+                                "enable_uncertainty": unc, "use_local_pose_offset": True, "backbone_args": {}, "enable_6drot": False}
+    assert net.name == "NetworkWithPointHead_mobilenetv1" and net.input_resolution == 129 and net.input_resolutions == (129,)
+
+
+@pytest.mark.parametrize("cfg", ["full", "posonly"])
+def test_cpu_eval_export_path_matches_reference_golden(cfg):
+    d, meta = load_golden(f"model_{cfg}.npz")
+    cal = {k[len("calib/"):]: d[k] for k in d.files if k.startswith("calib/")}
+    net = build_net(meta, "cpu", cal).eval()
+    image, ids = make_inputs(meta["B"], seed=meta["input_seed"])
+    with torch.no_grad():
+        out = net(torch.from_numpy(image), torch.from_numpy(ids))
+    for k in [k[len("eval/"):] for k in d.files if k.startswith("eval/")]:
+        v = out[k].value if hasattr(out[k], "value") else out[k]
+        np.testing.assert_allclose(v.numpy(), d["eval/" + k], rtol=2e-4, atol=2e-5, err_msg=k)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        net.train()(torch.from_numpy(image))
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    from trackertraincode.neuralnets import models
+
+    net = models.NetworkWithPointHead(enable_point_head=False, enable_uncertainty=True)
+    f = str(tmp_path / "m.ckpt")
+    models.save_model(net, f)
+    raw = torch.load(f, weights_only=True)
+    assert set(raw) == {"state_dict", "class_name", "config"} and raw["class_name"] == "NetworkWithPointHead"
+    net2 = models.load_model(f)
+    for (k1, v1), (k2, v2) in zip(net.state_dict().items(), net2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_batch_collation():
+    from trackertraincode.datasets.batch import Batch, Metadata
+
+    frames = [Batch(Metadata(129, 0, tag="a"), x=torch.full((2,), float(i))) for i in range(3)]
+    frames += [Batch(Metadata(129, 2, tag="b"), x=torch.zeros(2, 2))]
+    out = Batch.Collation(lambda b: b.meta.tag)(frames)
+    assert [b.meta.tag for b in out] == ["a", "b"] and out[0]["x"].shape == (3, 2) and out[0].meta.batchsize == 3
+    assert out[1].meta.batchsize == 2 and out[0].meta.prefixshape == (3,)
+    vids = [Batch(Metadata(129, 0, tag="v", seq=[0, 2]), x=torch.zeros(2, 1)), Batch(Metadata(129, 0, tag="v", seq=[0, 3]), x=torch.ones(3, 1))]
+    v = Batch.collate(vids)
+    assert v.meta.seq == [0, 2, 5] and v.meta.batchsize == 2 and v["x"].shape == (5, 1) and v.meta.prefixshape == (5,)
+    assert [f["x"].item() for f in v.iter_frames()] == [0, 0, 1, 1, 1]
+    assert [s["x"].shape[0] for s in v.iter_sequences()] == [2, 3]
+
+
+def test_lr_schedule_matches_reference_tables():
+    import trackertraincode.train as train
+
+    s = np.load(os.path.join(GOLDEN, "schedule.npz"))
+    for E in (200, 1500):
+        lin = torch.nn.Linear(1, 1)
+        opt = torch.optim.SGD(lin.parameters(), lr=1.0)
+        sch = train.ExponentialUpThenSteps(opt, max(1, E // 10), 0.1, [E // 2])
+        f = []
+        for _ in range(E):
+            f.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        np.testing.assert_allclose(np.array(f), s[f"E{E}"], rtol=1e-12)
+
+
+def test_swa_callback_matches_reference():
+    import trackertraincode.train as train
+
+    s = np.load(os.path.join(GOLDEN, "swa.npz"))
+    m = torch.nn.Sequential(torch.nn.Conv2d(1, 4, 3, bias=False), torch.nn.BatchNorm2d(4))
+    cb = train.SwaCallback(start_epoch=-1)
+    cb.on_train_start(m)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    for i in range(3):
+        sd = make_state({("bn." + k if k.startswith("1.") else k): v for k, v in shapes.items()}, seed=100 + i)
+        sd = {(k[3:] if k.startswith("bn.") else k): torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+        sd["1.num_batches_tracked"] = torch.tensor(i + 1)
+        m.load_state_dict(sd)
+        cb.on_train_epoch_end(i, m)
+    for k, v in cb.swa_model.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), s[k], rtol=1e-6, atol=1e-7, err_msg=k)

@@ -1,0 +1,162 @@
+"""GPU parity of the whole pose-estimator step (HIP backbone + fused heads + HIP losses + fused
+clip/Adam, all through the C-ABI) against the golden vectors produced by the reference and against
+the CPU oracle."""
+import itertools
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import refmodel as R
+from oracle.synth import digest_close, make_grads, make_inputs, make_state
+from util import GOLDEN, build_net, load_golden, make_batches, script_args, train_script
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+LOSS_TOL = 1.0e-3  # north_star: per-step losses within 1e-3 of the reference PyTorch-CPU path
+
+
+def _val(v):
+    return (v.value if hasattr(v, "value") else v).detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("cfg", ["full", "default", "posonly"])
+def test_train_step_matches_reference_golden(cfg):
+    import trackertraincode.train as train
+
+    d, meta = load_golden(f"model_{cfg}.npz")
+    S = train_script()
+    for epoch in (0, 20, 150):
+        net = build_net(meta, DEV).train()
+        crit, _ = S.setup_losses(script_args(meta["flags"]), net)
+        batches = make_batches(meta, DEV)
+        inputs = torch.concat([b["image"] for b in batches], dim=0)
+        ids = torch.concat([b["coord_convention_id"] for b in batches], dim=0)
+        preds = net(inputs, ids)
+        loss_sum, all_lossvals = train.default_compute_loss(preds, batches, epoch, crit)
+        by_name = train.concatenated_lossvals_by_name(itertools.chain.from_iterable(all_lossvals))
+        names = [k.split("/")[3] for k in d.files if k.startswith(f"train/e{epoch}/loss/") and k.endswith("/values")]
+        assert list(by_name.keys()) == names
+        for n in names:
+            np.testing.assert_allclose(_val(by_name[n][0]), d[f"train/e{epoch}/loss/{n}/values"], rtol=LOSS_TOL, atol=LOSS_TOL, err_msg=n)
+            np.testing.assert_allclose(_val(by_name[n][1]), d[f"train/e{epoch}/loss/{n}/weights"], rtol=1e-6, err_msg=n)
+        assert abs(loss_sum.item() - float(d[f"train/e{epoch}/loss_sum"])) < LOSS_TOL
+    for k in [k for k in d.files if k.startswith("train/out/")]:
+        np.testing.assert_allclose(_val(preds[k[len("train/out/"):]]), d[k], rtol=1e-3, atol=1e-4, err_msg=k)
+    loss_sum.backward()
+    torch.cuda.synchronize()
+    params = dict(net.named_parameters())
+    bad = []
+    for k in [k for k in d.files if k.startswith("train/grad/")]:
+        g = params[k[len("train/grad/"):]].grad
+        g = torch.zeros_like(params[k[len("train/grad/"):]]) if g is None else g
+        ok, msg = digest_close(d[k], g.cpu().numpy(), rtol=2e-2, atol=1e-6)  # B=8: ReLU-kink sensitivity, see test_backbone_gpu
+        if not ok:
+            bad.append((k, msg))
+    assert not bad, bad[:5]
+    sd = net.state_dict()
+    for k in [k for k in d.files if k.startswith("train/after/")]:
+        ok, msg = digest_close(d[k], sd[k[len("train/after/"):]].cpu().numpy(), rtol=2e-4, atol=1e-6)
+        assert ok, f"{k}: {msg}"
+
+
+def test_dataset_weight_and_validation_paths():
+    import trackertraincode.train as train
+
+    d, meta = load_golden("model_full.npz")
+    S = train_script()
+    net = build_net(meta, DEV).train()
+    crit, test_crit = S.setup_losses(script_args(meta["flags"]), net)
+    batches = make_batches(meta, DEV, with_dataset_weight=True)
+    out = train.training_step(net, batches, 150, crit)
+    assert abs(out["loss"].item() - float(d["train_dw/loss_sum"])) < LOSS_TOL
+    # validation criterion on calibrated running statistics, coord_convention_id=None
+    cal = {k[len("calib/"):]: d[k] for k in d.files if k.startswith("calib/")}
+    net = build_net(meta, DEV, cal).eval()
+    vb = make_batches(meta, DEV)[0]
+    with torch.no_grad():
+        pred = net(vb["image"])
+        values = test_crit[vb.meta.tag].evaluate(pred, vb, 3)
+        val_loss = torch.cat([(lv.val * lv.weight) for lv in values]).sum()
+    assert [lv.name for lv in values] == json.loads(str(d["val/names"]))
+    assert abs(val_loss.item() - float(d["val/val_loss"])) < 5e-3
+
+
+@pytest.mark.parametrize("cfg", ["full", "default", "posonly"])
+def test_eval_forward_matches_reference_golden(cfg):
+    d, meta = load_golden(f"model_{cfg}.npz")
+    cal = {k[len("calib/"):]: d[k] for k in d.files if k.startswith("calib/")}
+    net = build_net(meta, DEV, cal).eval()
+    image, ids = make_inputs(meta["B"], seed=meta["input_seed"])
+    with torch.no_grad():
+        out = net(torch.from_numpy(image).to(DEV), torch.from_numpy(ids).to(DEV))
+        out_noid = net(torch.from_numpy(image).to(DEV))
+    for prefix, o in (("eval/", out), ("eval_noid/", out_noid)):
+        keys = [k[len(prefix):] for k in d.files if k.startswith(prefix)]
+        assert set(keys) == set(o.keys())
+        for k in keys:
+            np.testing.assert_allclose(_val(o[k]), d[prefix + k], rtol=1e-3, atol=1e-4, err_msg=prefix + k)
+
+
+@pytest.mark.parametrize("cfg", ["full", "default"])
+def test_clip_adam_fixed_gradients_golden(cfg):
+    """Fused clip+Adam kernel + the reference's LR schedule against parameters produced by
+    torch.optim.Adam + clip_grad_norm_ in the reference's script (fixed synthetic gradients)."""
+    d, meta = load_golden(f"model_{cfg}.npz")
+    o = np.load(os.path.join(GOLDEN, f"optim_{cfg}.npz"))
+    S = train_script()
+    net = build_net(meta, DEV)
+    opt, sch = S.create_optimizer(net, script_args(meta["flags"], epochs=20))
+    pshapes = {k: tuple(p.shape) for k, p in net.named_parameters()}
+    for step, gscale in enumerate((1.0e-3, 1.0e-4, 1.0e-2)):
+        g = make_grads(pshapes, seed=200 + step, scale=gscale)
+        for k, p in net.named_parameters():
+            p.grad = torch.from_numpy(g[k].copy()).to(DEV)
+        opt.step()
+        np.testing.assert_allclose(opt.last_grad_norm.item(), float(o[f"fixed/step{step}/grad_norm"]), rtol=1e-5)
+        sch.step()
+    sd = net.state_dict()
+    for k in [k for k in o.files if k.startswith("fixed/final/")]:
+        ok, msg = digest_close(o[k], sd[k[len("fixed/final/"):]].cpu().numpy(), rtol=1e-5, atol=3e-7)
+        assert ok, f"{k}: {msg}"
+
+
+def test_gradients_vs_fp64_oracle():
+    """Whole-network gradients: HIP must be as close to the fp64 oracle as the fp32 CPU oracle is."""
+    import trackertraincode.train as train
+
+    d, meta = load_golden("model_full.npz")
+    S = train_script()
+    shapes = {k: tuple(v) for k, v in meta["shapes"].items()}
+    image, ids = make_inputs(meta["B"], seed=meta["input_seed"])
+    gmm = R.ShapeGmm(os.path.join(GOLDEN, "shapeparams_gmm.npz"))
+    fl = meta["flags"]
+    ocrit, _ = R.setup_losses(with_pointhead=fl["with_pointhead"], with_nll_loss=fl["with_nll_loss"],
+                              rampup_nll_losses=fl["rampup_nll_losses"], epochs=200, gmm=gmm)
+    from test_oracle_golden import _batches
+
+    def oracle(dtype):
+        st = {}
+        for k, v in make_state(shapes, 0).items():
+            t = torch.from_numpy(np.array(v))
+            t = t.to(dtype) if t.is_floating_point() else t
+            st[k] = t.requires_grad_(True) if not R.is_buffer(k) else t
+        out, _ = R.network_forward(st, torch.from_numpy(image).to(dtype), torch.from_numpy(ids), meta["config"], True)
+        bs = [{k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in b.items()} for b in _batches(meta)]
+        loss, _ = R.compute_loss(out, bs, 150, ocrit)
+        loss.backward()
+        return {k: v.grad for k, v in st.items() if not R.is_buffer(k)}
+
+    g64, g32 = oracle(torch.float64), oracle(torch.float32)
+    net = build_net(meta, DEV).train()
+    crit, _ = S.setup_losses(script_args(meta["flags"]), net)
+    train.training_step(net, make_batches(meta, DEV), 150, crit)["loss"].backward()
+    rel = lambda a, b: ((a.double().flatten() - b.double().flatten()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    bad = []
+    for k, p in net.named_parameters():
+        e_hip, e_cpu = rel(p.grad.cpu(), g64[k]), rel(g32[k], g64[k])
+        if e_hip > 3 * e_cpu + 5e-5:
+            bad.append((k, e_hip, e_cpu))
+    assert not bad, bad[:8]
