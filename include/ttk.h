@@ -21,11 +21,14 @@
  *    reference's NCHW tensor (C = 1, so the two layouts coincide).
  *  - training-mode BatchNorm is split in three: the producing conv writes its RAW output y and
  *    per-workgroup partial sums  part[row][0][c] = sum(y), part[row][1][c] = sum(y*y);
- *    ttk_bn_fwd_finalize folds them (fp64) into per-channel scale/shift (+ running statistics);
- *    the CONSUMER applies  a = max(scale*y + shift (+ skip), 0)  while loading.  Backward mirrors
- *    it: the producer of a gradient writes g = dL/d(bn output) and partials sum(g), sum(g*y);
- *    ttk_bn_bwd_finalize turns them into three per-channel coefficients such that
- *    dL/dy = cA*g + cB*y + cC, which the consumer applies while loading.
+ *    ttk_bn_fwd_finalize folds them (fp64) into the layer's constant block bn[TTK_BN_ROWS][C]
+ *    (+ running statistics); the CONSUMER applies
+ *        a = max(scale*(y - mean) + beta (+ skip), 0)
+ *    while loading.  Backward mirrors it: the producer of a gradient writes g = dL/d(bn output) and
+ *    partials sum(g), sum(g*(y - mean)); ttk_bn_bwd_finalize adds ga, gb, gmean to the block such that
+ *        dL/dy = ga*(g - gmean) + gb*(y - mean),
+ *    which the consumer applies while loading.  Both forms subtract first: the one-fma-per-tensor
+ *    variants cancel catastrophically in fp32 for channels that are nearly constant over the batch.
  */
 #ifndef TTK_H_
 #define TTK_H_
@@ -39,7 +42,19 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 1
+#define TTK_ABI_VERSION 2
+
+/* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
+enum {
+  TTK_BN_SCALE = 0, /* gamma * rstd                      (forward)  */
+  TTK_BN_BETA = 1,  /* copy of the bias parameter         (forward)  */
+  TTK_BN_MEAN = 2,  /* batch mean (eval: running_mean)    (both)     */
+  TTK_BN_RSTD = 3,  /* 1/sqrt(var + eps)                             */
+  TTK_BN_GA = 4,    /* gamma * rstd                       (backward) */
+  TTK_BN_GB = 5,    /* -ga * rstd^2 * mean(g*(y-mean))    (backward) */
+  TTK_BN_GMEAN = 6, /* mean(g)                            (backward) */
+  TTK_BN_ROWS = 8
+};
 #define TTK_MAX_PARTIAL_ROWS_ELEMENTWISE 1024
 #define TTK_GEMM_BLOCK_M 128
 
@@ -56,22 +71,19 @@ int ttk_partial_rows_gemm(int64_t M);                 /* pointwise (MFMA) kernel
  * running_var receives the UNBIASED batch variance, normalisation uses the biased one;
  * num_batches_tracked (int64 scalar on the device, may be NULL) is incremented.
  * ------------------------------------------------------------------------------------------- */
-/* `part` is scratch: when part_rows > 1024 the finalize kernels first fold it IN PLACE to 1024 rows. */
+/* `part` is scratch: when part_rows > 1024 the finalize kernels first fold it IN PLACE to 1024 rows.
+ * Writes rows SCALE, BETA, MEAN, RSTD of bn. */
 int ttk_bn_fwd_finalize(float* part, int part_rows, int C, int64_t count,
                         const float* gamma, const float* beta,
                         float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                        float momentum, float eps,
-                        float* scale, float* shift, float* mean, float* rstd, ttk_stream_t stream);
-/* eval mode: scale/shift from the running statistics. */
+                        float momentum, float eps, float* bn, ttk_stream_t stream);
+/* eval mode: SCALE, BETA, MEAN, RSTD from the running statistics. */
 int ttk_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean,
-                        const float* running_var, float eps, int C, float* scale, float* shift,
-                        ttk_stream_t stream);
-/* part[row][0][c] = sum(g), part[row][1][c] = sum(g*y).  Writes cA,cB,cC and the parameter
- * gradients dgamma/dbeta (accumulate != 0: += instead of =). */
-int ttk_bn_bwd_finalize(float* part, int part_rows, int C, int64_t count,
-                        const float* gamma, const float* mean, const float* rstd,
-                        float* cA, float* cB, float* cC, float* dgamma, float* dbeta, int accumulate,
-                        ttk_stream_t stream);
+                        const float* running_var, float eps, int C, float* bn, ttk_stream_t stream);
+/* part[row][0][c] = sum(g), part[row][1][c] = sum(g*(y-mean)).  Writes rows GA, GB, GMEAN of bn and
+ * the parameter gradients dgamma/dbeta (nullable; accumulate != 0: += instead of =). */
+int ttk_bn_bwd_finalize(float* part, int part_rows, int C, int64_t count, const float* gamma,
+                        float* bn, float* dgamma, float* dbeta, int accumulate, ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stem: nn.Conv2d(1, 32, 5, stride 2, pad 2, bias=False)  - mobilenet_v1.py:122-124,161.
@@ -80,77 +92,70 @@ int ttk_bn_bwd_finalize(float* part, int part_rows, int C, int64_t count,
  * ------------------------------------------------------------------------------------------- */
 int ttk_stem_fwd(const float* x, const float* w, float* y, float* part, int B, int H, int W,
                  ttk_stream_t stream);
-/* dW[32][25] (+)= sum dy * x, dy = cA*g + cB*y + cC applied on load. */
-int ttk_stem_bwd_weight(const float* g, const float* y, const float* cA, const float* cB,
-                        const float* cC, const float* x, float* dw, int accumulate, int B, int H,
-                        int W, ttk_stream_t stream);
+/* dW[32][25] (+)= sum dy * x, dy formed on load from (g, y, bn = the stem's BatchNorm block). */
+int ttk_stem_bwd_weight(const float* g, const float* y, const float* bn, const float* x, float* dw,
+                        int accumulate, int B, int H, int W, ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Depthwise 3x3, pad 1, stride 1|2, groups=C, bias=False - DepthWiseBlock.conv_dw,
  * mobilenet_v1.py:57-65,78.  The block input is formed on load from the previous layer's raw output:
- *   a_in = max(scale*yprev + shift (+ skip_prev), 0)        (bn + relu (+ residual) of the producer,
- *                                                            mobilenet_v1.py:79-90 / :162-163)
+ *   a_in = max(scale*(yprev - mean) + beta (+ skip_prev), 0)   with bn_prev = the producer's block
+ *                                                 (bn + relu (+ residual), mobilenet_v1.py:79-90 / :162-163)
  * a_out (nullable): materialise a_in, needed when THIS block has a residual connection
  * (mobilenet_v1.py:70,86-88).  w is the reference's weight (C,1,3,3) as is.
  * ------------------------------------------------------------------------------------------- */
-int ttk_dwconv3x3_fwd(const float* yprev, const float* scale, const float* shift,
-                      const float* skip_prev, float* a_out, const float* w, float* y, float* part,
-                      int B, int H, int W, int C, int stride, ttk_stream_t stream);
+int ttk_dwconv3x3_fwd(const float* yprev, const float* bn_prev, const float* skip_prev, float* a_out,
+                      const float* w, float* y, float* part, int B, int H, int W, int C, int stride,
+                      ttk_stream_t stream);
 /* Gradient w.r.t. the block input, masked by relu and handed to the producer's BatchNorm:
- *   G      = convT3x3(dy_dw) (+ skip_grad)            dy_dw = cA*g_dw + cB*y_dw + cC on load
- *   g_prev = G * [a_in > 0]                            -> written, with partials sum(g_prev), sum(g_prev*yprev)
- * a_in (nullable): materialised block input; if NULL it is recomputed from yprev/scale/shift/skip_prev.
+ *   G      = convT3x3(dy_dw) (+ skip_grad)        dy_dw formed on load from (g_dw, y_dw, bn_dw)
+ *   g_prev = G * [a_in > 0]                        -> written, with partials sum(g_prev), sum(g_prev*(yprev-mean))
+ * a_in (nullable): materialised block input; if NULL it is recomputed from yprev/bn_prev/skip_prev.
  * dw (nullable): FUSED weight gradient dW[C][9] (+)= sum dy_dw * a_in(taps) - every (dy, a_in) pair it
  * needs is already in registers here, so the standalone kernel below is only kept for unit tests. */
-int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* cA, const float* cB,
-                           const float* cC, const float* w, const float* skip_grad,
-                           const float* yprev, const float* scale_prev, const float* shift_prev,
+int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* bn_dw, const float* w,
+                           const float* skip_grad, const float* yprev, const float* bn_prev,
                            const float* skip_prev, const float* a_in, float* g_prev, float* part,
-                           float* dw, int dw_accumulate,
-                           int B, int H, int W, int C, int stride, ttk_stream_t stream);
+                           float* dw, int dw_accumulate, int B, int H, int W, int C, int stride,
+                           ttk_stream_t stream);
 /* dW[C][9] (+)= sum dy_dw * a_in(taps) (standalone form). */
-int ttk_dwconv3x3_bwd_weight(const float* g_dw, const float* y_dw, const float* cA, const float* cB,
-                             const float* cC, const float* yprev, const float* scale_prev,
-                             const float* shift_prev, const float* skip_prev, const float* a_in,
-                             float* dw, int accumulate, int B, int H, int W, int C, int stride,
-                             ttk_stream_t stream);
+int ttk_dwconv3x3_bwd_weight(const float* g_dw, const float* y_dw, const float* bn_dw,
+                             const float* yprev, const float* bn_prev, const float* skip_prev,
+                             const float* a_in, float* dw, int accumulate, int B, int H, int W, int C,
+                             int stride, ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pointwise 1x1 conv = GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) -
  * DepthWiseBlock.conv_sep, mobilenet_v1.py:67,82.
- *   y[M][Cout] = max(scale*ydw + shift, 0)[M][Cin] . w[Cout][Cin]^T,   M = B*Ho*Wo
+ *   y[M][Cout] = a_dw[M][Cin] . w[Cout][Cin]^T,   a_dw = max(bn_dw(ydw), 0) on load,  M = B*Ho*Wo
  * ------------------------------------------------------------------------------------------- */
-int ttk_pwconv1x1_fwd(const float* ydw, const float* scale, const float* shift, const float* w,
-                      float* y, float* part, int64_t M, int Cin, int Cout, ttk_stream_t stream);
-/* g_dw[M][Cin] = (dy[M][Cout] . w[Cout][Cin]) * [scale_dw*ydw + shift_dw > 0],
- * dy = cA*g + cB*y + cC on load; wt = w transposed ([Cin][Cout], ttk_transpose).
- * partials: sum(g_dw), sum(g_dw*ydw). */
-int ttk_pwconv1x1_bwd_data(const float* g, const float* y, const float* cA, const float* cB,
-                           const float* cC, const float* wt, const float* ydw,
-                           const float* scale_dw, const float* shift_dw, float* g_dw, float* part,
-                           int64_t M, int Cin, int Cout, ttk_stream_t stream);
-/* dw[Cout][Cin] += dy^T . max(scale_dw*ydw + shift_dw, 0).  dw must be zeroed (or hold the running
- * gradient) before the call: the M dimension is split over workgroups that add atomically. */
-int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* cA, const float* cB,
-                             const float* cC, const float* ydw, const float* scale_dw,
-                             const float* shift_dw, float* dw, int64_t M, int Cin, int Cout,
+int ttk_pwconv1x1_fwd(const float* ydw, const float* bn_dw, const float* w, float* y, float* part,
+                      int64_t M, int Cin, int Cout, ttk_stream_t stream);
+/* g_dw[M][Cin] = (dy[M][Cout] . w[Cout][Cin]) * [bn_dw(ydw) > 0],  dy formed on load from (g, y, bn_pw);
+ * wt = w transposed ([Cin][Cout], ttk_transpose).  partials: sum(g_dw), sum(g_dw*(ydw-mean)). */
+int ttk_pwconv1x1_bwd_data(const float* g, const float* y, const float* bn_pw, const float* wt,
+                           const float* ydw, const float* bn_dw, float* g_dw, float* part, int64_t M,
+                           int Cin, int Cout, ttk_stream_t stream);
+/* dw[Cout][Cin] += dy^T . a_dw.  dw must be zeroed (or hold the running gradient) before the call:
+ * the M dimension is split over workgroups that add atomically. */
+int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* bn_pw, const float* ydw,
+                             const float* bn_dw, float* dw, int64_t M, int Cin, int Cout,
                              ttk_stream_t stream);
 int ttk_transpose(const float* in, float* out, int rows, int cols, ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * AdaptiveAvgPool2d(1) + view over the last block's output - mobilenet_v1.py:143,180-181.
- *   feat[B][C] = mean_hw max(scale*y + shift (+ skip), 0)
+ *   feat[B][C] = mean_hw max(bn(y) (+ skip), 0)
  * ------------------------------------------------------------------------------------------- */
-int ttk_avgpool_fwd(const float* y, const float* scale, const float* shift, const float* skip,
-                    float* feat, int B, int HW, int C, ttk_stream_t stream);
-/* g[B][HW][C] = gfeat[B][C]/HW * [bn(y)+skip > 0]; partials sum(g), sum(g*y). */
-int ttk_avgpool_bwd(const float* gfeat, const float* y, const float* scale, const float* shift,
-                    const float* skip, float* g, float* part, int B, int HW, int C,
-                    ttk_stream_t stream);
-/* a[.][C] = max(scale*y + shift (+ skip), 0): materialises a post-activation tensor (the
- * `intermediates` list MobileNet.forward returns, mobilenet_v1.py:165-186). */
-int ttk_bn_act(const float* y, const float* scale, const float* shift, const float* skip, float* a,
-               int64_t rows, int C, ttk_stream_t stream);
+int ttk_avgpool_fwd(const float* y, const float* bn, const float* skip, float* feat, int B, int HW,
+                    int C, ttk_stream_t stream);
+/* g[B][HW][C] = gfeat[B][C]/HW * [bn(y)+skip > 0]; partials sum(g), sum(g*(y-mean)). */
+int ttk_avgpool_bwd(const float* gfeat, const float* y, const float* bn, const float* skip, float* g,
+                    float* part, int B, int HW, int C, ttk_stream_t stream);
+/* a[.][C] = max(bn(y) (+ skip), 0): materialises a post-activation tensor (the `intermediates` list
+ * MobileNet.forward returns, mobilenet_v1.py:165-186). */
+int ttk_bn_act(const float* y, const float* bn, const float* skip, float* a, int64_t rows, int C,
+               ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-task heads - everything NetworkWithPointHead.forward does after the backbone

@@ -20,8 +20,7 @@ __global__ void __launch_bounds__(1024) bn_fwd_finalize_k(const float* __restric
                                                           double unbias, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ rmean,
                                                           float* __restrict__ rvar, int64_t* nbt, float momentum, float eps,
-                                                          float* __restrict__ scale, float* __restrict__ shift,
-                                                          float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+                                                          float* __restrict__ bn) {
   __shared__ double sm[2][32][32];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
@@ -43,10 +42,10 @@ __global__ void __launch_bounds__(1024) bn_fwd_finalize_k(const float* __restric
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
     const double sc = (double)gamma[c] * rstd;
-    scale[c] = (float)sc;
-    shift[c] = (float)((double)beta[c] - mean * sc);
-    mean_o[c] = (float)mean;
-    rstd_o[c] = (float)rstd;
+    bn[TTK_BN_SCALE * C + c] = (float)sc;
+    bn[TTK_BN_BETA * C + c] = beta[c];
+    bn[TTK_BN_MEAN * C + c] = (float)mean;
+    bn[TTK_BN_RSTD * C + c] = (float)rstd;
     if (rmean) {
       rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mean);
       rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * var * unbias);
@@ -56,22 +55,21 @@ __global__ void __launch_bounds__(1024) bn_fwd_finalize_k(const float* __restric
 }
 
 __global__ void bn_eval_prepare_k(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
-                                  int C, float* scale, float* shift) {
+                                  int C, float* bn) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float rstd = 1.0f / sqrtf(rvar[c] + eps);
-  const float sc = gamma[c] * rstd;
-  scale[c] = sc;
-  shift[c] = beta[c] - rmean[c] * sc;
+  bn[TTK_BN_SCALE * C + c] = gamma[c] * rstd;
+  bn[TTK_BN_BETA * C + c] = beta[c];
+  bn[TTK_BN_MEAN * C + c] = rmean[c];
+  bn[TTK_BN_RSTD * C + c] = rstd;
 }
 
 // dy = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)),  xhat = (y - mean)*rstd
-//    = cA*g + cB*y + cC
-// sum(g*xhat) = rstd*(sum(g*y) - mean*sum(g));  dgamma = sum(g*xhat), dbeta = sum(g)
+//    = ga*(g - gmean) + gb*(y - mean)          ga = gamma*rstd, gb = -ga*rstd^2*mean(g*(y-mean))
+// partials: sum(g), sum(g*(y - mean));  dgamma = rstd*sum(g*(y-mean)), dbeta = sum(g)
 __global__ void __launch_bounds__(1024) bn_bwd_finalize_k(const float* __restrict__ part, int rows, int C, double inv_count,
-                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                          const float* __restrict__ rstd, float* __restrict__ cA,
-                                                          float* __restrict__ cB, float* __restrict__ cC,
+                                                          const float* __restrict__ gamma, float* __restrict__ bn,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                           int accumulate) {
   __shared__ double sm[2][32][32];
@@ -90,13 +88,12 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_k(const float* __restric
   __syncthreads();
   if (rl == 0 && c < C) {
     for (int i = 1; i < 32; ++i) { a += sm[0][i][cl]; b += sm[1][i][cl]; }
-    const double m = mean[c], rs = rstd[c], ga = gamma[c];
-    const double sum_g = a, sum_gx = rs * (b - m * a);
-    const double mg = sum_g * inv_count, mgx = sum_gx * inv_count;
+    const double rs = bn[TTK_BN_RSTD * C + c], ga = gamma[c];
+    const double sum_g = a, sum_gx = rs * b;
     const double A = ga * rs;
-    cA[c] = (float)A;
-    cB[c] = (float)(-A * mgx * rs);
-    cC[c] = (float)(A * (-mg + m * rs * mgx));
+    bn[TTK_BN_GA * C + c] = (float)A;
+    bn[TTK_BN_GB * C + c] = (float)(-A * rs * rs * b * inv_count);
+    bn[TTK_BN_GMEAN * C + c] = (float)(sum_g * inv_count);
     if (dgamma) {
       if (accumulate) { dgamma[c] += (float)sum_gx; dbeta[c] += (float)sum_g; }
       else            { dgamma[c] = (float)sum_gx;  dbeta[c] = (float)sum_g; }
@@ -142,36 +139,35 @@ int ttk_partial_rows_gemm(int64_t M) { return (int)ceil_div(M, TTK_GEMM_BLOCK_M)
 
 int ttk_bn_fwd_finalize(float* part, int part_rows, int C, int64_t count, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
-                        float* scale, float* shift, float* mean, float* rstd, ttk_stream_t stream) {
-  TTK_REQUIRE(part && gamma && beta && scale && shift && mean && rstd, "bn_fwd_finalize: null pointer");
+                        float* bn, ttk_stream_t stream) {
+  TTK_REQUIRE(part && gamma && beta && bn, "bn_fwd_finalize: null pointer");
   TTK_REQUIRE(C > 0 && part_rows > 0 && count > 0, "bn_fwd_finalize: bad sizes C=%d rows=%d count=%lld", C, part_rows, (long long)count);
   TTK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_fwd_finalize: running_mean/var must both be given");
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
   part_rows = fold_if_needed(part, part_rows, C, (hipStream_t)stream);
   hipLaunchKernelGGL(bn_fwd_finalize_k, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, part_rows, C,
                      1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
-                     scale, shift, mean, rstd);
+                     bn);
   TTK_LAUNCH_CHECK("bn_fwd_finalize");
 }
 
 int ttk_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
-                        int C, float* scale, float* shift, ttk_stream_t stream) {
-  TTK_REQUIRE(gamma && beta && running_mean && running_var && scale && shift, "bn_eval_prepare: null pointer");
+                        int C, float* bn, ttk_stream_t stream) {
+  TTK_REQUIRE(gamma && beta && running_mean && running_var && bn, "bn_eval_prepare: null pointer");
   TTK_REQUIRE(C > 0, "bn_eval_prepare: C=%d", C);
   hipLaunchKernelGGL(bn_eval_prepare_k, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
-                     running_var, eps, C, scale, shift);
+                     running_var, eps, C, bn);
   TTK_LAUNCH_CHECK("bn_eval_prepare");
 }
 
-int ttk_bn_bwd_finalize(float* part, int part_rows, int C, int64_t count, const float* gamma, const float* mean,
-                        const float* rstd, float* cA, float* cB, float* cC, float* dgamma, float* dbeta, int accumulate,
-                        ttk_stream_t stream) {
-  TTK_REQUIRE(part && gamma && mean && rstd && cA && cB && cC, "bn_bwd_finalize: null pointer");
+int ttk_bn_bwd_finalize(float* part, int part_rows, int C, int64_t count, const float* gamma, float* bn, float* dgamma,
+                        float* dbeta, int accumulate, ttk_stream_t stream) {
+  TTK_REQUIRE(part && gamma && bn, "bn_bwd_finalize: null pointer");
   TTK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bn_bwd_finalize: dgamma/dbeta must both be given");
   TTK_REQUIRE(C > 0 && part_rows > 0 && count > 0, "bn_bwd_finalize: bad sizes");
   part_rows = fold_if_needed(part, part_rows, C, (hipStream_t)stream);
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, part_rows, C,
-                     1.0 / (double)count, gamma, mean, rstd, cA, cB, cC, dgamma, dbeta, accumulate);
+                     1.0 / (double)count, gamma, bn, dgamma, dbeta, accumulate);
   TTK_LAUNCH_CHECK("bn_bwd_finalize");
 }
 

@@ -40,8 +40,8 @@ struct InputForm {  // how the block input is formed from the producer's raw out
 };
 
 template <int S>
-__global__ void __launch_bounds__(kBlock) dw_fwd_k(const float* __restrict__ yprev, const float* __restrict__ scale,
-                                                    const float* __restrict__ shift, const float* __restrict__ skip_prev,
+__global__ void __launch_bounds__(kBlock) dw_fwd_k(const float* __restrict__ yprev, const float* __restrict__ bn_prev,
+                                                    const float* __restrict__ skip_prev,
                                                     float* __restrict__ a_out, const float* __restrict__ w,
                                                     float* __restrict__ y, float* __restrict__ part, int B, int H, int W,
                                                     int C, int Ho, int Wo, int qshift) {
@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(kBlock) dw_fwd_k(const float* __restrict__ ypr
   const int c4 = threadIdx.x & (quads - 1);
   DwWeights wr;
   wr.load(w, c4);
-  InputForm in{yprev, skip_prev, nullptr, {ld4(scale + 4 * c4), ld4(shift + 4 * c4)}};
+  InputForm in{yprev, skip_prev, nullptr, BnApply4::load(bn_prev, C, 4 * c4)};
   const int64_t items = ((int64_t)B * Ho * Wo) << qshift;
   float4 s1 = f4(0.f), s2 = f4(0.f);
   for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * kBlock) {
@@ -85,11 +85,9 @@ __global__ void __launch_bounds__(kBlock) dw_fwd_k(const float* __restrict__ ypr
 // producer's ReLU, with the producer's BatchNorm-backward sums in the epilogue.
 template <int S>
 __global__ void __launch_bounds__(kBlock) dw_bwd_data_k(const float* __restrict__ g_dw, const float* __restrict__ y_dw,
-                                                         const float* __restrict__ cA, const float* __restrict__ cB,
-                                                         const float* __restrict__ cC, const float* __restrict__ w,
+                                                         const float* __restrict__ bn_dw, const float* __restrict__ w,
                                                          const float* __restrict__ skip_grad,
-                                                         const float* __restrict__ yprev, const float* __restrict__ scale_prev,
-                                                         const float* __restrict__ shift_prev,
+                                                         const float* __restrict__ yprev, const float* __restrict__ bn_prev,
                                                          const float* __restrict__ skip_prev, const float* __restrict__ a_in,
                                                          float* __restrict__ g_prev, float* __restrict__ part,
                                                          float* __restrict__ dwgrad, int B, int H,
@@ -99,8 +97,8 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_data_k(const float* __restrict_
   const int c4 = threadIdx.x & (quads - 1);
   DwWeights wr;
   wr.load(w, c4);
-  const BnGrad4 bg{ld4(cA + 4 * c4), ld4(cB + 4 * c4), ld4(cC + 4 * c4)};
-  InputForm in{yprev, skip_prev, a_in, {ld4(scale_prev + 4 * c4), ld4(shift_prev + 4 * c4)}};
+  const BnGrad4 bg = BnGrad4::load(bn_dw, C, 4 * c4);
+  InputForm in{yprev, skip_prev, a_in, BnApply4::load(bn_prev, C, 4 * c4)};
   const int64_t items = ((int64_t)B * H * W) << qshift;
   float4 s1 = f4(0.f), s2 = f4(0.f);
   // Fused weight gradient: dW[c][tap] = sum_o dy(o) * a_in(o*S + tap - 1).  This thread sits at the
@@ -140,7 +138,7 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_data_k(const float* __restrict_
     const float4 gp = mask4(G, a);
     st4(g_prev + off_in, gp);
     s1 = add4(s1, gp);
-    s2 = fma4(gp, ld4(yprev + off_in), s2);
+    s2 = fma4(gp, sub4(ld4(yprev + off_in), in.bn.mean), s2);
   }
   if (part) block_channel_partials<1024>(s1, s2, c4, C, part + (size_t)blockIdx.x * 2 * C, smem);
   if (dwgrad) {
@@ -178,18 +176,16 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_data_k(const float* __restrict_
 // dW[c][tap] += sum_{n,ho,wo} dy_dw[n,ho,wo,c] * a_in[n, ho*S+kh-1, wo*S+kw-1, c]
 template <int S>
 __global__ void __launch_bounds__(kBlock) dw_bwd_weight_k(const float* __restrict__ g_dw, const float* __restrict__ y_dw,
-                                                           const float* __restrict__ cA, const float* __restrict__ cB,
-                                                           const float* __restrict__ cC, const float* __restrict__ yprev,
-                                                           const float* __restrict__ scale_prev,
-                                                           const float* __restrict__ shift_prev,
+                                                           const float* __restrict__ bn_dw, const float* __restrict__ yprev,
+                                                           const float* __restrict__ bn_prev,
                                                            const float* __restrict__ skip_prev, const float* __restrict__ a_in,
                                                            float* __restrict__ dw, int B, int H, int W, int C, int Ho, int Wo,
                                                            int qshift) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [9][C]
   const int quads = C >> 2;
   const int c4 = threadIdx.x & (quads - 1);
-  const BnGrad4 bg{ld4(cA + 4 * c4), ld4(cB + 4 * c4), ld4(cC + 4 * c4)};
-  InputForm in{yprev, skip_prev, a_in, {ld4(scale_prev + 4 * c4), ld4(shift_prev + 4 * c4)}};
+  const BnGrad4 bg = BnGrad4::load(bn_dw, C, 4 * c4);
+  InputForm in{yprev, skip_prev, a_in, BnApply4::load(bn_prev, C, 4 * c4)};
   float4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = f4(0.f);
@@ -243,12 +239,12 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_weight_k(const float* __restric
 }
 
 // a = max(scale*y + shift (+skip), 0) over [rows][C]
-__global__ void __launch_bounds__(kBlock) bn_act_k(const float* __restrict__ y, const float* __restrict__ scale,
-                                                    const float* __restrict__ shift, const float* __restrict__ skip,
+__global__ void __launch_bounds__(kBlock) bn_act_k(const float* __restrict__ y, const float* __restrict__ bnp,
+                                                    const float* __restrict__ skip,
                                                     float* __restrict__ a, int64_t items, int C) {
   const int quads = C >> 2;
   const int c4 = threadIdx.x & (quads - 1);
-  const BnApply4 bn{ld4(scale + 4 * c4), ld4(shift + 4 * c4)};
+  const BnApply4 bn = BnApply4::load(bnp, C, 4 * c4);
   for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * kBlock) {
     const size_t off = (size_t)idx << 2;
     st4(a + off, skip ? bn.act(ld4(y + off), ld4(skip + off)) : bn.act(ld4(y + off)));
@@ -270,9 +266,9 @@ using namespace ttk;
 
 extern "C" {
 
-int ttk_dwconv3x3_fwd(const float* yprev, const float* scale, const float* shift, const float* skip_prev, float* a_out,
-                      const float* w, float* y, float* part, int B, int H, int W, int C, int stride, ttk_stream_t stream) {
-  TTK_REQUIRE(yprev && scale && shift && w && y, "dwconv3x3_fwd: null pointer");
+int ttk_dwconv3x3_fwd(const float* yprev, const float* bn_prev, const float* skip_prev, float* a_out, const float* w, float* y,
+                      float* part, int B, int H, int W, int C, int stride, ttk_stream_t stream) {
+  TTK_REQUIRE(yprev && bn_prev && w && y, "dwconv3x3_fwd: null pointer");
   TTK_REQUIRE(dw_shape_ok(B, H, W, C, stride), "dwconv3x3_fwd: unsupported shape B=%d H=%d W=%d C=%d stride=%d (C must be a power of two in 32..1024)", B, H, W, C, stride);
   TTK_REQUIRE(!(a_out && stride != 1), "dwconv3x3_fwd: a_out requires stride 1");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
@@ -281,19 +277,19 @@ int ttk_dwconv3x3_fwd(const float* yprev, const float* scale, const float* shift
   const dim3 grid(elementwise_grid(items));
   const size_t sm = 2 * (size_t)C * sizeof(float);
   if (stride == 1)
-    hipLaunchKernelGGL(dw_fwd_k<1>, grid, dim3(kBlock), sm, (hipStream_t)stream, yprev, scale, shift, skip_prev, a_out, w, y,
-                       part, B, H, W, C, Ho, Wo, qs);
+    hipLaunchKernelGGL(dw_fwd_k<1>, grid, dim3(kBlock), sm, (hipStream_t)stream, yprev, bn_prev, skip_prev, a_out, w, y, part, B,
+                       H, W, C, Ho, Wo, qs);
   else
-    hipLaunchKernelGGL(dw_fwd_k<2>, grid, dim3(kBlock), sm, (hipStream_t)stream, yprev, scale, shift, skip_prev, a_out, w, y,
-                       part, B, H, W, C, Ho, Wo, qs);
+    hipLaunchKernelGGL(dw_fwd_k<2>, grid, dim3(kBlock), sm, (hipStream_t)stream, yprev, bn_prev, skip_prev, a_out, w, y, part, B,
+                       H, W, C, Ho, Wo, qs);
   TTK_LAUNCH_CHECK("dwconv3x3_fwd");
 }
 
-int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* cA, const float* cB, const float* cC,
-                           const float* w, const float* skip_grad, const float* yprev, const float* scale_prev,
-                           const float* shift_prev, const float* skip_prev, const float* a_in, float* g_prev, float* part,
+int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* bn_dw, const float* w, const float* skip_grad,
+                           const float* yprev, const float* bn_prev, const float* skip_prev, const float* a_in, float* g_prev,
+                           float* part,
                            float* dw, int dw_accumulate, int B, int H, int W, int C, int stride, ttk_stream_t stream) {
-  TTK_REQUIRE(g_dw && y_dw && cA && cB && cC && w && yprev && scale_prev && shift_prev && g_prev, "dwconv3x3_bwd_data: null pointer");
+  TTK_REQUIRE(g_dw && y_dw && bn_dw && w && yprev && bn_prev && g_prev, "dwconv3x3_bwd_data: null pointer");
   TTK_REQUIRE(dw_shape_ok(B, H, W, C, stride), "dwconv3x3_bwd_data: unsupported shape");
   TTK_REQUIRE(!(skip_grad && stride != 1), "dwconv3x3_bwd_data: residual gradient requires stride 1");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
@@ -304,19 +300,18 @@ int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* cA
   if (dw && !dw_accumulate)
     hipLaunchKernelGGL(zero_f, dim3((9 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dw, (int64_t)9 * C);
   if (stride == 1)
-    hipLaunchKernelGGL(dw_bwd_data_k<1>, grid, dim3(kBlock), sm, (hipStream_t)stream, g_dw, y_dw, cA, cB, cC, w, skip_grad,
-                       yprev, scale_prev, shift_prev, skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, qs);
+    hipLaunchKernelGGL(dw_bwd_data_k<1>, grid, dim3(kBlock), sm, (hipStream_t)stream, g_dw, y_dw, bn_dw, w, skip_grad, yprev,
+                       bn_prev, skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, qs);
   else
-    hipLaunchKernelGGL(dw_bwd_data_k<2>, grid, dim3(kBlock), sm, (hipStream_t)stream, g_dw, y_dw, cA, cB, cC, w, skip_grad,
-                       yprev, scale_prev, shift_prev, skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, qs);
+    hipLaunchKernelGGL(dw_bwd_data_k<2>, grid, dim3(kBlock), sm, (hipStream_t)stream, g_dw, y_dw, bn_dw, w, skip_grad, yprev,
+                       bn_prev, skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, qs);
   TTK_LAUNCH_CHECK("dwconv3x3_bwd_data");
 }
 
-int ttk_dwconv3x3_bwd_weight(const float* g_dw, const float* y_dw, const float* cA, const float* cB, const float* cC,
-                             const float* yprev, const float* scale_prev, const float* shift_prev, const float* skip_prev,
-                             const float* a_in, float* dw, int accumulate, int B, int H, int W, int C, int stride,
-                             ttk_stream_t stream) {
-  TTK_REQUIRE(g_dw && y_dw && cA && cB && cC && yprev && scale_prev && shift_prev && dw, "dwconv3x3_bwd_weight: null pointer");
+int ttk_dwconv3x3_bwd_weight(const float* g_dw, const float* y_dw, const float* bn_dw, const float* yprev, const float* bn_prev,
+                             const float* skip_prev, const float* a_in, float* dw, int accumulate, int B, int H, int W, int C,
+                             int stride, ttk_stream_t stream) {
+  TTK_REQUIRE(g_dw && y_dw && bn_dw && yprev && bn_prev && dw, "dwconv3x3_bwd_weight: null pointer");
   TTK_REQUIRE(dw_shape_ok(B, H, W, C, stride), "dwconv3x3_bwd_weight: unsupported shape");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const int qs = log2i(C / 4);
@@ -326,22 +321,21 @@ int ttk_dwconv3x3_bwd_weight(const float* g_dw, const float* y_dw, const float* 
   if (!accumulate) hipLaunchKernelGGL(zero_f, dim3((9 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dw, (int64_t)9 * C);
   const size_t sm = 9 * (size_t)C * sizeof(float);
   if (stride == 1)
-    hipLaunchKernelGGL(dw_bwd_weight_k<1>, dim3(g), dim3(kBlock), sm, (hipStream_t)stream, g_dw, y_dw, cA, cB, cC, yprev,
-                       scale_prev, shift_prev, skip_prev, a_in, dw, B, H, W, C, Ho, Wo, qs);
+    hipLaunchKernelGGL(dw_bwd_weight_k<1>, dim3(g), dim3(kBlock), sm, (hipStream_t)stream, g_dw, y_dw, bn_dw, yprev, bn_prev,
+                       skip_prev, a_in, dw, B, H, W, C, Ho, Wo, qs);
   else
-    hipLaunchKernelGGL(dw_bwd_weight_k<2>, dim3(g), dim3(kBlock), sm, (hipStream_t)stream, g_dw, y_dw, cA, cB, cC, yprev,
-                       scale_prev, shift_prev, skip_prev, a_in, dw, B, H, W, C, Ho, Wo, qs);
+    hipLaunchKernelGGL(dw_bwd_weight_k<2>, dim3(g), dim3(kBlock), sm, (hipStream_t)stream, g_dw, y_dw, bn_dw, yprev, bn_prev,
+                       skip_prev, a_in, dw, B, H, W, C, Ho, Wo, qs);
   TTK_LAUNCH_CHECK("dwconv3x3_bwd_weight");
 }
 
-int ttk_bn_act(const float* y, const float* scale, const float* shift, const float* skip, float* a, int64_t rows, int C,
-               ttk_stream_t stream) {
-  TTK_REQUIRE(y && scale && shift && a, "bn_act: null pointer");
+int ttk_bn_act(const float* y, const float* bn, const float* skip, float* a, int64_t rows, int C, ttk_stream_t stream) {
+  TTK_REQUIRE(y && bn && a, "bn_act: null pointer");
   TTK_REQUIRE(rows > 0 && C >= 32 && C <= 1024 && (C & (C - 1)) == 0, "bn_act: unsupported shape rows=%lld C=%d", (long long)rows, C);
   const int64_t items = rows * (C / 4);
   int g = (int)ceil_div(items, kBlock);
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(bn_act_k, dim3(g), dim3(kBlock), 0, (hipStream_t)stream, y, scale, shift, skip, a, items, C);
+  hipLaunchKernelGGL(bn_act_k, dim3(g), dim3(kBlock), 0, (hipStream_t)stream, y, bn, skip, a, items, C);
   TTK_LAUNCH_CHECK("bn_act");
 }
 

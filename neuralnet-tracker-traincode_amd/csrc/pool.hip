@@ -6,8 +6,8 @@
 namespace ttk {
 
 // thread = (sample, channel quad)
-__global__ void __launch_bounds__(kBlock) avgpool_fwd_k(const float* __restrict__ y, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, const float* __restrict__ skip,
+__global__ void __launch_bounds__(kBlock) avgpool_fwd_k(const float* __restrict__ y, const float* __restrict__ bnp,
+                                                         const float* __restrict__ skip,
                                                          float* __restrict__ feat, int B, int HW, int C) {
   const int quads = C >> 2;
   const int64_t items = (int64_t)B * quads;
@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(kBlock) avgpool_fwd_k(const float* __restrict_
   for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * kBlock) {
     const int c4 = (int)(idx % quads);
     const int n = (int)(idx / quads);
-    const BnApply4 bn{ld4(scale + 4 * c4), ld4(shift + 4 * c4)};
+    const BnApply4 bn = BnApply4::load(bnp, C, 4 * c4);
     float4 s = f4(0.f);
     for (int p = 0; p < HW; ++p) {
       const size_t off = ((size_t)n * HW + p) * C + 4 * c4;
@@ -27,13 +27,12 @@ __global__ void __launch_bounds__(kBlock) avgpool_fwd_k(const float* __restrict_
 
 // thread = (sample, pixel, channel quad)
 __global__ void __launch_bounds__(kBlock) avgpool_bwd_k(const float* __restrict__ gfeat, const float* __restrict__ y,
-                                                         const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         const float* __restrict__ skip, float* __restrict__ g,
+                                                         const float* __restrict__ bnp, const float* __restrict__ skip, float* __restrict__ g,
                                                          float* __restrict__ part, int B, int HW, int C, int qshift) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int quads = C >> 2;
   const int c4 = threadIdx.x & (quads - 1);
-  const BnApply4 bn{ld4(scale + 4 * c4), ld4(shift + 4 * c4)};
+  const BnApply4 bn = BnApply4::load(bnp, C, 4 * c4);
   const float inv = 1.0f / (float)HW;
   const int64_t items = ((int64_t)B * HW) << qshift;
   float4 s1 = f4(0.f), s2 = f4(0.f);
@@ -47,7 +46,7 @@ __global__ void __launch_bounds__(kBlock) avgpool_bwd_k(const float* __restrict_
     gv = mask4(make_float4(gv.x * inv, gv.y * inv, gv.z * inv, gv.w * inv), a);
     st4(g + off, gv);
     s1 = add4(s1, gv);
-    s2 = fma4(gv, yv, s2);
+    s2 = fma4(gv, sub4(yv, bn.mean), s2);
   }
   if (part) block_channel_partials<1024>(s1, s2, c4, C, part + (size_t)blockIdx.x * 2 * C, smem);
 }
@@ -64,24 +63,24 @@ static int log2i_(int v) {
 
 extern "C" {
 
-int ttk_avgpool_fwd(const float* y, const float* scale, const float* shift, const float* skip, float* feat, int B, int HW,
+int ttk_avgpool_fwd(const float* y, const float* bn, const float* skip, float* feat, int B, int HW,
                     int C, ttk_stream_t stream) {
-  TTK_REQUIRE(y && scale && shift && feat, "avgpool_fwd: null pointer");
+  TTK_REQUIRE(y && bn && feat, "avgpool_fwd: null pointer");
   TTK_REQUIRE(B > 0 && HW > 0 && C >= 32 && C <= 1024 && (C & (C - 1)) == 0, "avgpool_fwd: unsupported shape B=%d HW=%d C=%d", B, HW, C);
   const int64_t items = (int64_t)B * (C / 4);
-  hipLaunchKernelGGL(avgpool_fwd_k, dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, y, scale, shift, skip,
-                     feat, B, HW, C);
+  hipLaunchKernelGGL(avgpool_fwd_k, dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, y, bn, skip, feat, B, HW,
+                     C);
   TTK_LAUNCH_CHECK("avgpool_fwd");
 }
 
-int ttk_avgpool_bwd(const float* gfeat, const float* y, const float* scale, const float* shift, const float* skip, float* g,
+int ttk_avgpool_bwd(const float* gfeat, const float* y, const float* bn, const float* skip, float* g,
                     float* part, int B, int HW, int C, ttk_stream_t stream) {
-  TTK_REQUIRE(gfeat && y && scale && shift && g, "avgpool_bwd: null pointer");
+  TTK_REQUIRE(gfeat && y && bn && g, "avgpool_bwd: null pointer");
   TTK_REQUIRE(B > 0 && HW > 0 && C >= 32 && C <= 1024 && (C & (C - 1)) == 0, "avgpool_bwd: unsupported shape");
   const int qs = log2i_(C / 4);
   const int64_t items = ((int64_t)B * HW) << qs;
   hipLaunchKernelGGL(avgpool_bwd_k, dim3(elementwise_grid(items)), dim3(kBlock), 2 * (size_t)C * sizeof(float),
-                     (hipStream_t)stream, gfeat, y, scale, shift, skip, g, part, B, HW, C, qs);
+                     (hipStream_t)stream, gfeat, y, bn, skip, g, part, B, HW, C, qs);
   TTK_LAUNCH_CHECK("avgpool_bwd");
 }
 

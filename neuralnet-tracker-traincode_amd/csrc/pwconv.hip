@@ -28,11 +28,12 @@ enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 
 template <int BN, int WM, int WN, int MODE>
 __global__ void __launch_bounds__(kBlock) pw_gemm_k(const float* __restrict__ A0, const float* __restrict__ A1,
-                                                     const float* __restrict__ c0, const float* __restrict__ c1,
-                                                     const float* __restrict__ c2, const float* __restrict__ Bm,
+                                                     const float* __restrict__ bnA, const float* __restrict__ Bm,
                                                      float* __restrict__ out, const float* __restrict__ E0,
-                                                     const float* __restrict__ e0, const float* __restrict__ e1,
-                                                     float* __restrict__ part, int64_t M, int K, int Nout) {
+                                                     const float* __restrict__ bnE, float* __restrict__ part, int64_t M,
+                                                     int K, int Nout) {
+  // bnA: BatchNorm block [TTK_BN_ROWS][K] of the layer that produced the A operand (contraction channels);
+  // bnE (data-gradient mode): block [TTK_BN_ROWS][Nout] of the layer whose ReLU masks the output.
   static_assert(WM * WN == 4, "4 waves");
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_PASSES = BM * BKT / 4 / kBlock;  // 4
@@ -74,15 +75,19 @@ __global__ void __launch_bounds__(kBlock) pw_gemm_k(const float* __restrict__ A0
   };
   auto store_tile = [&](int kt, int buf) {
     const int k0 = kt * BKT + kq;
-    const float4 q0 = ld4(c0 + k0), q1 = ld4(c1 + k0);
-    float4 q2 = f4(0.f);
-    if constexpr (MODE == MODE_DGRAD) q2 = ld4(c2 + k0);
+    float4 q0, q1, q2, q3 = f4(0.f);
+    if constexpr (MODE == MODE_FWD) {
+      q0 = ld4(bnA + TTK_BN_SCALE * K + k0); q1 = ld4(bnA + TTK_BN_MEAN * K + k0); q2 = ld4(bnA + TTK_BN_BETA * K + k0);
+    } else {
+      q0 = ld4(bnA + TTK_BN_GA * K + k0); q1 = ld4(bnA + TTK_BN_GMEAN * K + k0);
+      q2 = ld4(bnA + TTK_BN_GB * K + k0); q3 = ld4(bnA + TTK_BN_MEAN * K + k0);
+    }
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
       const int64_t row = m0 + p * 32 + lrow;
       float4 v;
-      if constexpr (MODE == MODE_FWD) v = relu4(fma4(q0, ra0[p], q1));
-      else v = fma4(q0, ra0[p], fma4(q1, ra1[p], q2));
+      if constexpr (MODE == MODE_FWD) v = relu4(fma4(q0, sub4(ra0[p], q1), q2));
+      else v = fma4(q0, sub4(ra0[p], q1), mul4(q2, sub4(ra1[p], q3)));
       if (row >= M) v = f4(0.f);
       st4(&As[buf][p * 32 + lrow][kq], v);
     }
@@ -128,8 +133,10 @@ __global__ void __launch_bounds__(kBlock) pw_gemm_k(const float* __restrict__ A0
     s1[j] = 0.f;
     s2[j] = 0.f;
     const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
-    float esc = 0.f, esh = 0.f;
-    if constexpr (MODE == MODE_DGRAD) { esc = e0[col]; esh = e1[col]; }
+    float esc = 0.f, emean = 0.f, ebeta = 0.f;
+    if constexpr (MODE == MODE_DGRAD) {
+      esc = bnE[TTK_BN_SCALE * Nout + col]; emean = bnE[TTK_BN_MEAN * Nout + col]; ebeta = bnE[TTK_BN_BETA * Nout + col];
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -143,11 +150,11 @@ __global__ void __launch_bounds__(kBlock) pw_gemm_k(const float* __restrict__ A0
             s1[j] += v;
             s2[j] = fmaf(v, v, s2[j]);
           } else {
-            const float yo = E0[o];
-            v = (fmaf(esc, yo, esh) > 0.f) ? v : 0.f;
+            const float yc = E0[o] - emean;
+            v = (fmaf(esc, yc, ebeta) > 0.f) ? v : 0.f;
             out[o] = v;
             s1[j] += v;
-            s2[j] = fmaf(v, yo, s2[j]);
+            s2[j] = fmaf(v, yc, s2[j]);
           }
         }
       }
@@ -187,10 +194,9 @@ __global__ void __launch_bounds__(kBlock) pw_gemm_k(const float* __restrict__ A0
 // ---------------------------------------------------------------------------------------------
 template <int BN, int BK, int WR, int WC, int WS>
 __global__ void __launch_bounds__(kBlock) pw_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y,
-                                                      const float* __restrict__ cA, const float* __restrict__ cB,
-                                                      const float* __restrict__ cC, const float* __restrict__ Ydw,
-                                                      const float* __restrict__ scale, const float* __restrict__ shift,
-                                                      float* __restrict__ dW, int64_t M, int Cin, int Cout,
+                                                      const float* __restrict__ bn_pw, const float* __restrict__ Ydw,
+                                                      const float* __restrict__ bn_dw, float* __restrict__ dW, int64_t M,
+                                                      int Cin, int Cout,
                                                       int64_t rows_per_slice) {
   static_assert(WR * WC * WS == 4, "4 waves");
   constexpr int TR = BN / WR / 32, TC = BK / WC / 32;
@@ -246,7 +252,7 @@ __global__ void __launch_bounds__(kBlock) pw_wgrad_k(const float* __restrict__ G
       const int row = f / (BN / 4), q = f % (BN / 4);
       if (row < MS) {
         const int c = n0 + 4 * q;
-        float4 v = fma4(ld4(cA + c), rg[p], fma4(ld4(cB + c), ry[p], ld4(cC + c)));
+        float4 v = BnGrad4::load(bn_pw, Cout, c).dy(rg[p], ry[p]);
         if (ms + row >= m_end) v = f4(0.f);
         st4(&Ds[buf][row][4 * q], v);
       }
@@ -257,7 +263,7 @@ __global__ void __launch_bounds__(kBlock) pw_wgrad_k(const float* __restrict__ G
       const int row = f / (BK / 4), q = f % (BK / 4);
       if (row < MS) {
         const int c = k0 + 4 * q;
-        float4 v = relu4(fma4(ld4(scale + c), ra[p], ld4(shift + c)));
+        float4 v = BnApply4::load(bn_dw, Cin, c).act(ra[p]);
         if (ms + row >= m_end) v = f4(0.f);
         st4(&As[buf][row][4 * q], v);
       }
@@ -320,20 +326,17 @@ static bool pw_shape_ok(int64_t M, int Cin, int Cout) {
 }
 
 template <int MODE>
-static void launch_gemm(const float* A0, const float* A1, const float* c0, const float* c1, const float* c2, const float* Bm,
-                        float* out, const float* E0, const float* e0, const float* e1, float* part, int64_t M, int K,
-                        int Nout, hipStream_t st) {
+static void launch_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
+                        const float* bnE, float* part, int64_t M, int K, int Nout, hipStream_t st) {
   const dim3 blk(kBlock);
   const unsigned gm = (unsigned)ceil_div(M, BM);
   if (Nout >= 128)
-    hipLaunchKernelGGL((pw_gemm_k<128, 2, 2, MODE>), dim3(Nout / 128, gm), blk, 0, st, A0, A1, c0, c1, c2, Bm, out, E0, e0, e1,
-                       part, M, K, Nout);
+    hipLaunchKernelGGL((pw_gemm_k<128, 2, 2, MODE>), dim3(Nout / 128, gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K,
+                       Nout);
   else if (Nout == 64)
-    hipLaunchKernelGGL((pw_gemm_k<64, 2, 2, MODE>), dim3(1, gm), blk, 0, st, A0, A1, c0, c1, c2, Bm, out, E0, e0, e1, part, M,
-                       K, Nout);
+    hipLaunchKernelGGL((pw_gemm_k<64, 2, 2, MODE>), dim3(1, gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
   else
-    hipLaunchKernelGGL((pw_gemm_k<32, 4, 1, MODE>), dim3(1, gm), blk, 0, st, A0, A1, c0, c1, c2, Bm, out, E0, e0, e1, part, M,
-                       K, Nout);
+    hipLaunchKernelGGL((pw_gemm_k<32, 4, 1, MODE>), dim3(1, gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
 }
 
 }  // namespace ttk
@@ -342,31 +345,28 @@ using namespace ttk;
 
 extern "C" {
 
-int ttk_pwconv1x1_fwd(const float* ydw, const float* scale, const float* shift, const float* w, float* y, float* part,
-                      int64_t M, int Cin, int Cout, ttk_stream_t stream) {
-  TTK_REQUIRE(ydw && scale && shift && w && y, "pwconv1x1_fwd: null pointer");
+int ttk_pwconv1x1_fwd(const float* ydw, const float* bn_dw, const float* w, float* y, float* part, int64_t M, int Cin, int Cout,
+                      ttk_stream_t stream) {
+  TTK_REQUIRE(ydw && bn_dw && w && y, "pwconv1x1_fwd: null pointer");
   TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_fwd: unsupported shape M=%lld Cin=%d Cout=%d (channels: powers of two in 32..1024)", (long long)M, Cin, Cout);
   TTK_REQUIRE(ceil_div(M, BM) <= 65535, "pwconv1x1_fwd: M=%lld too large for one launch", (long long)M);
-  launch_gemm<MODE_FWD>(ydw, nullptr, scale, shift, nullptr, w, y, nullptr, nullptr, nullptr, part, M, Cin, Cout,
-                        (hipStream_t)stream);
+  launch_gemm<MODE_FWD>(ydw, nullptr, bn_dw, w, y, nullptr, nullptr, part, M, Cin, Cout, (hipStream_t)stream);
   TTK_LAUNCH_CHECK("pwconv1x1_fwd");
 }
 
-int ttk_pwconv1x1_bwd_data(const float* g, const float* y, const float* cA, const float* cB, const float* cC, const float* wt,
-                           const float* ydw, const float* scale_dw, const float* shift_dw, float* g_dw, float* part, int64_t M,
-                           int Cin, int Cout, ttk_stream_t stream) {
-  TTK_REQUIRE(g && y && cA && cB && cC && wt && ydw && scale_dw && shift_dw && g_dw, "pwconv1x1_bwd_data: null pointer");
+int ttk_pwconv1x1_bwd_data(const float* g, const float* y, const float* bn_pw, const float* wt, const float* ydw,
+                           const float* bn_dw, float* g_dw, float* part, int64_t M, int Cin, int Cout, ttk_stream_t stream) {
+  TTK_REQUIRE(g && y && bn_pw && wt && ydw && bn_dw && g_dw, "pwconv1x1_bwd_data: null pointer");
   TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_bwd_data: unsupported shape");
   TTK_REQUIRE(ceil_div(M, BM) <= 65535, "pwconv1x1_bwd_data: M too large for one launch");
   // contraction over Cout, output columns = Cin, B operand = wt[Cin][Cout]
-  launch_gemm<MODE_DGRAD>(g, y, cA, cB, cC, wt, g_dw, ydw, scale_dw, shift_dw, part, M, Cout, Cin, (hipStream_t)stream);
+  launch_gemm<MODE_DGRAD>(g, y, bn_pw, wt, g_dw, ydw, bn_dw, part, M, Cout, Cin, (hipStream_t)stream);
   TTK_LAUNCH_CHECK("pwconv1x1_bwd_data");
 }
 
-int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* cA, const float* cB, const float* cC,
-                             const float* ydw, const float* scale_dw, const float* shift_dw, float* dw, int64_t M, int Cin,
-                             int Cout, ttk_stream_t stream) {
-  TTK_REQUIRE(g && y && cA && cB && cC && ydw && scale_dw && shift_dw && dw, "pwconv1x1_bwd_weight: null pointer");
+int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
+                             int64_t M, int Cin, int Cout, ttk_stream_t stream) {
+  TTK_REQUIRE(g && y && bn_pw && ydw && bn_dw && dw, "pwconv1x1_bwd_weight: null pointer");
   TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_bwd_weight: unsupported shape");
   const int bn = Cout >= 128 ? 128 : Cout, bk = Cin >= 128 ? 128 : Cin;
   const int tiles = (Cout / bn) * (Cin / bk);
@@ -379,8 +379,8 @@ int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* cA, co
   const dim3 grid(tiles, (unsigned)slices), blk(kBlock);
   hipStream_t st = (hipStream_t)stream;
 #define TTK_WG(BN_, BK_, WR_, WC_, WS_)                                                                               \
-  hipLaunchKernelGGL((pw_wgrad_k<BN_, BK_, WR_, WC_, WS_>), grid, blk, 0, st, g, y, cA, cB, cC, ydw, scale_dw, shift_dw, dw, \
-                     M, Cin, Cout, rows)
+  hipLaunchKernelGGL((pw_wgrad_k<BN_, BK_, WR_, WC_, WS_>), grid, blk, 0, st, g, y, bn_pw, ydw, bn_dw, dw, M, Cin, Cout, \
+                     rows)
   if (bn == 128 && bk == 128) TTK_WG(128, 128, 2, 2, 1);
   else if (bn == 128 && bk == 64) TTK_WG(128, 64, 2, 2, 1);
   else if (bn == 128 && bk == 32) TTK_WG(128, 32, 4, 1, 1);

@@ -50,14 +50,13 @@ __global__ void __launch_bounds__(kBlock) stem_fwd_k(const float* __restrict__ x
 // thread = (output pixel, channel quad) as in forward; 25 taps x 4 channels of partial sums per
 // thread are folded over the workgroup through LDS, then one atomic add per (block, weight).
 __global__ void __launch_bounds__(kBlock) stem_bwd_weight_k(const float* __restrict__ g, const float* __restrict__ y,
-                                                             const float* __restrict__ cA, const float* __restrict__ cB,
-                                                             const float* __restrict__ cC, const float* __restrict__ x,
+                                                             const float* __restrict__ bn, const float* __restrict__ x,
                                                              float* __restrict__ dw, int B, int H, int W, int Ho, int Wo) {
   __shared__ float acc_s[25][kStemC];
   for (int i = threadIdx.x; i < 25 * kStemC; i += kBlock) (&acc_s[0][0])[i] = 0.f;
   __syncthreads();
   const int c4 = threadIdx.x & (kStemQuads - 1);
-  BnGrad4 bg{ld4(cA + 4 * c4), ld4(cB + 4 * c4), ld4(cC + 4 * c4)};
+  const BnGrad4 bg = BnGrad4::load(bn, kStemC, 4 * c4);
   float4 acc[25];
 #pragma unroll
   for (int t = 0; t < 25; ++t) acc[t] = f4(0.f);
@@ -127,16 +126,16 @@ int ttk_stem_fwd(const float* x, const float* w, float* y, float* part, int B, i
   TTK_LAUNCH_CHECK("stem_fwd");
 }
 
-int ttk_stem_bwd_weight(const float* g, const float* y, const float* cA, const float* cB, const float* cC, const float* x,
-                        float* dw, int accumulate, int B, int H, int W, ttk_stream_t stream) {
-  TTK_REQUIRE(g && y && cA && cB && cC && x && dw, "stem_bwd_weight: null pointer");
+int ttk_stem_bwd_weight(const float* g, const float* y, const float* bn, const float* x, float* dw, int accumulate, int B,
+                        int H, int W, ttk_stream_t stream) {
+  TTK_REQUIRE(g && y && bn && x && dw, "stem_bwd_weight: null pointer");
   TTK_REQUIRE(B > 0 && H > 4 && W > 4, "stem_bwd_weight: bad shape");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int64_t items = (int64_t)B * Ho * Wo * kStemQuads;
   if (!accumulate) hipLaunchKernelGGL(zero_k, dim3(4), dim3(256), 0, (hipStream_t)stream, dw, 25 * kStemC);
   int grid = elementwise_grid(items);
   if (grid > 512) grid = 512;
-  hipLaunchKernelGGL(stem_bwd_weight_k, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, g, y, cA, cB, cC, x, dw, B, H, W,
+  hipLaunchKernelGGL(stem_bwd_weight_k, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, g, y, bn, x, dw, B, H, W,
                      Ho, Wo);
   TTK_LAUNCH_CHECK("stem_bwd_weight");
 }

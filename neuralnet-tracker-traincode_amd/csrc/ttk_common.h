@@ -63,18 +63,34 @@ __device__ __forceinline__ float4 mask4(float4 g, float4 a) {
   return make_float4(a.x > 0.f ? g.x : 0.f, a.y > 0.f ? g.y : 0.f, a.z > 0.f ? g.z : 0.f, a.w > 0.f ? g.w : 0.f);
 }
 
-// The "apply on load" forms of BatchNorm (see ttk.h):
-//   forward : a  = max(scale*y + shift (+skip), 0)
-//   backward: dy = cA*g + cB*y + cC
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) {
+  return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+}
+
+// The "apply on load" forms of BatchNorm (see ttk.h).  Every layer owns one block
+// bn[TTK_BN_ROWS][C] of per-channel constants.  Both forms SUBTRACT FIRST:
+//   forward : a  = max(scale*(y - mean) + beta (+skip), 0)
+//   backward: dy = ga*(g - gmean) + gb*(y - mean)
+// (folding them into one fma per tensor, scale*y + shift / cA*g + cB*y + cC, cancels catastrophically
+// in fp32 when a channel's values are nearly constant over the batch - which real loss gradients are).
 struct BnApply4 {
-  float4 scale, shift;
-  __device__ __forceinline__ float4 pre(float4 y) const { return fma4(scale, y, shift); }
+  float4 scale, mean, beta;
+  __device__ __forceinline__ static BnApply4 load(const float* bn, int C, int c) {
+    return BnApply4{ld4(bn + TTK_BN_SCALE * C + c), ld4(bn + TTK_BN_MEAN * C + c), ld4(bn + TTK_BN_BETA * C + c)};
+  }
+  __device__ __forceinline__ float4 pre(float4 y) const { return fma4(scale, sub4(y, mean), beta); }
   __device__ __forceinline__ float4 act(float4 y) const { return relu4(pre(y)); }
   __device__ __forceinline__ float4 act(float4 y, float4 skip) const { return relu4(add4(pre(y), skip)); }
 };
 struct BnGrad4 {
-  float4 a, b, c;
-  __device__ __forceinline__ float4 dy(float4 g, float4 y) const { return fma4(a, g, fma4(b, y, c)); }
+  float4 ga, gb, gmean, mean;
+  __device__ __forceinline__ static BnGrad4 load(const float* bn, int C, int c) {
+    return BnGrad4{ld4(bn + TTK_BN_GA * C + c), ld4(bn + TTK_BN_GB * C + c), ld4(bn + TTK_BN_GMEAN * C + c),
+                   ld4(bn + TTK_BN_MEAN * C + c)};
+  }
+  __device__ __forceinline__ float4 dy(float4 g, float4 y) const {
+    return fma4(ga, sub4(g, gmean), mul4(gb, sub4(y, mean)));
+  }
 };
 
 // ---- per-channel partial sums of a workgroup -------------------------------------------------

@@ -18,21 +18,21 @@ _P, _I, _L, _F, _D = c_void_p, c_int, c_int64, c_float, c_double
 
 # name -> argument types (the trailing stream pointer is added automatically)
 _SIGNATURES = {
-    "ttk_bn_fwd_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P],
-    "ttk_bn_eval_prepare": [_P, _P, _P, _P, _F, _I, _P, _P],
-    "ttk_bn_bwd_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I],
+    "ttk_bn_fwd_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _F, _F, _P],
+    "ttk_bn_eval_prepare": [_P, _P, _P, _P, _F, _I, _P],
+    "ttk_bn_bwd_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _I],
     "ttk_stem_fwd": [_P, _P, _P, _P, _I, _I, _I],
-    "ttk_stem_bwd_weight": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
-    "ttk_dwconv3x3_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
-    "ttk_dwconv3x3_bwd_data": [_P] * 15 + [_I] * 6,
-    "ttk_dwconv3x3_bwd_weight": [_P] * 11 + [_I] * 6,
-    "ttk_pwconv1x1_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I],
-    "ttk_pwconv1x1_bwd_data": [_P] * 11 + [_L, _I, _I],
-    "ttk_pwconv1x1_bwd_weight": [_P] * 9 + [_L, _I, _I],
+    "ttk_stem_bwd_weight": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "ttk_dwconv3x3_fwd": [_P] * 7 + [_I] * 5,
+    "ttk_dwconv3x3_bwd_data": [_P] * 12 + [_I] * 6,
+    "ttk_dwconv3x3_bwd_weight": [_P] * 8 + [_I] * 6,
+    "ttk_pwconv1x1_fwd": [_P, _P, _P, _P, _P, _L, _I, _I],
+    "ttk_pwconv1x1_bwd_data": [_P] * 8 + [_L, _I, _I],
+    "ttk_pwconv1x1_bwd_weight": [_P] * 6 + [_L, _I, _I],
     "ttk_transpose": [_P, _P, _I, _I],
-    "ttk_avgpool_fwd": [_P, _P, _P, _P, _P, _I, _I, _I],
-    "ttk_avgpool_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I],
-    "ttk_bn_act": [_P, _P, _P, _P, _P, _L, _I],
+    "ttk_avgpool_fwd": [_P, _P, _P, _P, _I, _I, _I],
+    "ttk_avgpool_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
+    "ttk_bn_act": [_P, _P, _P, _P, _L, _I],
     "ttk_heads_fwd": [_P] * 8 + [_I] * 6 + [_P] * 9,
     "ttk_heads_bwd": [_P] * 8 + [_I] * 6 + [_P] * 15,
     "ttk_diag_scale_fwd": [_P, _P, _I],
@@ -56,7 +56,7 @@ _SIGNATURES = {
     "ttk_clip_adam": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _F, _F, _F, _F, _F, _P, _P],
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class _Library:

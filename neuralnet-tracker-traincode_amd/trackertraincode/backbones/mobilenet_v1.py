@@ -74,25 +74,17 @@ class DepthWiseBlock(nn.Module):
         return self.relu(out)
 
 
-class _Bn(NamedTuple):
-    """Per-layer BatchNorm constants on the device: rows of one [7, C] tensor."""
-    scale: torch.Tensor
-    shift: torch.Tensor
-    mean: torch.Tensor
-    rstd: torch.Tensor
-    cA: torch.Tensor
-    cB: torch.Tensor
-    cC: torch.Tensor
+_BN_ROWS = 8  # TTK_BN_ROWS: scale, beta, mean, rstd, ga, gb, gmean, (pad) - see include/ttk.h
 
 
-def _bn_work(C, device) -> _Bn:
-    t = torch.empty((7, C), dtype=torch.float32, device=device)
-    return _Bn(*t.unbind(0))
+def _bn_work(C, device) -> torch.Tensor:
+    """Per-layer BatchNorm constant block bn[TTK_BN_ROWS][C] on the device."""
+    return torch.empty((_BN_ROWS, C), dtype=torch.float32, device=device)
 
 
 class _Stage(NamedTuple):
     y: torch.Tensor            # raw conv output [B,H,W,C]
-    bn: _Bn
+    bn: torch.Tensor           # BatchNorm constant block [8, C]
     skip: torch.Tensor | None  # residual input added before the ReLU of this stage's output
 
 
@@ -131,13 +123,13 @@ def _forward_impl(x, params, buffers, momentum, eps, training):
     ctx.x, ctx.part, ctx.B = x, part, B
     ctx.stages, ctx.a_in, ctx.dims = [], [], []
 
-    def finalize(bn: _Bn, rows, C, count, gamma, beta, bi):
+    def finalize(bn, rows, C, count, gamma, beta, bi):
         rm, rv, nbt = buffers[3 * bi], buffers[3 * bi + 1], buffers[3 * bi + 2]
         if training:
             L.call("ttk_bn_fwd_finalize", p(part), rows, C, count, p(gamma), p(beta), p(rm), p(rv), p(nbt),
-                   float(momentum), float(eps), p(bn.scale), p(bn.shift), p(bn.mean), p(bn.rstd))
+                   float(momentum), float(eps), p(bn))
         else:
-            L.call("ttk_bn_eval_prepare", p(gamma), p(beta), p(rm), p(rv), float(eps), C, p(bn.scale), p(bn.shift))
+            L.call("ttk_bn_eval_prepare", p(gamma), p(beta), p(rm), p(rv), float(eps), C, p(bn))
 
     part_arg = p(part) if training else None
     # ---- stem (reference :122-126,161-163)
@@ -156,13 +148,13 @@ def _forward_impl(x, params, buffers, momentum, eps, training):
         ho, wo = (h - 1) // stride + 1, (w_ - 1) // stride + 1
         a_in = torch.empty_like(prev.y) if has_skip else None
         ydw = torch.empty((B, ho, wo, cin), dtype=torch.float32, device=dev)
-        L.call("ttk_dwconv3x3_fwd", p(prev.y), p(prev.bn.scale), p(prev.bn.shift), p(prev.skip), p(a_in), p(w_dw), p(ydw),
-               part_arg, B, h, w_, cin, stride)
+        L.call("ttk_dwconv3x3_fwd", p(prev.y), p(prev.bn), p(prev.skip), p(a_in), p(w_dw), p(ydw), part_arg, B, h, w_, cin,
+               stride)
         bn_dw = _bn_work(cin, dev)
         finalize(bn_dw, L.partial_rows_elementwise(B * ho * wo * (cin // 4)), cin, B * ho * wo, g_dw, b_dw, bi)
         ypw = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=dev)
         M = B * ho * wo
-        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw.scale), p(bn_dw.shift), p(w_pw), p(ypw), part_arg, M, cin, cout)
+        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), p(w_pw), p(ypw), part_arg, M, cin, cout)
         bn_pw = _bn_work(cout, dev)
         finalize(bn_pw, L.partial_rows_gemm(M), cout, M, g_pw, b_pw, bi + 1)
         bi += 2
@@ -174,7 +166,7 @@ def _forward_impl(x, params, buffers, momentum, eps, training):
         h, w_ = ho, wo
     C = prev.y.shape[-1]
     feat = torch.empty((B, C), dtype=torch.float32, device=dev)
-    L.call("ttk_avgpool_fwd", p(prev.y), p(prev.bn.scale), p(prev.bn.shift), p(prev.skip), p(feat), B, h * w_, C)
+    L.call("ttk_avgpool_fwd", p(prev.y), p(prev.bn), p(prev.skip), p(feat), B, h * w_, C)
     ctx.HW = h * w_
     return feat, ctx
 
@@ -192,12 +184,11 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         Cc = stage.y.shape[-1]
         dgamma = torch.empty(Cc, dtype=torch.float32, device=gfeat.device)
         dbeta = torch.empty(Cc, dtype=torch.float32, device=gfeat.device)
-        L.call("ttk_bn_bwd_finalize", p(part), rows, Cc, count, p(params[gi]), p(stage.bn.mean), p(stage.bn.rstd),
-               p(stage.bn.cA), p(stage.bn.cB), p(stage.bn.cC), p(dgamma), p(dbeta), 0)
+        L.call("ttk_bn_bwd_finalize", p(part), rows, Cc, count, p(params[gi]), p(stage.bn), p(dgamma), p(dbeta), 0)
         grads[gi], grads[gi + 1] = dgamma, dbeta
 
     g = torch.empty_like(last.y)
-    L.call("ttk_avgpool_bwd", p(gfeat), p(last.y), p(last.bn.scale), p(last.bn.shift), p(last.skip), p(g), p(part), B, ctx.HW, C)
+    L.call("ttk_avgpool_bwd", p(gfeat), p(last.y), p(last.bn), p(last.skip), p(g), p(part), B, ctx.HW, C)
     bwd_finalize(last, L.partial_rows_elementwise(B * ctx.HW * (C // 4)), B * ctx.HW, len(params) - 2)
 
     for k in range(len(_BLOCKS) - 1, -1, -1):
@@ -209,28 +200,26 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         M = B * ho * wo
         # -- pointwise: weight gradient, then data gradient (+ bn_dw backward sums)
         dW = torch.zeros_like(w_pw)
-        L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn.cA), p(st_pw.bn.cB), p(st_pw.bn.cC), p(st_dw.y),
-               p(st_dw.bn.scale), p(st_dw.bn.shift), p(dW), M, cin, cout)
+        L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW), M, cin, cout)
         grads[pi + 3] = dW
         wt = torch.empty((cin, cout), dtype=torch.float32, device=g.device)
         L.call("ttk_transpose", p(w_pw), p(wt), cout, cin)
         g_dw = torch.empty_like(st_dw.y)
-        L.call("ttk_pwconv1x1_bwd_data", p(g), p(st_pw.y), p(st_pw.bn.cA), p(st_pw.bn.cB), p(st_pw.bn.cC), p(wt), p(st_dw.y),
-               p(st_dw.bn.scale), p(st_dw.bn.shift), p(g_dw), p(part), M, cin, cout)
+        L.call("ttk_pwconv1x1_bwd_data", p(g), p(st_pw.y), p(st_pw.bn), p(wt), p(st_dw.y), p(st_dw.bn), p(g_dw), p(part), M,
+               cin, cout)
         bwd_finalize(st_dw, L.partial_rows_gemm(M), M, pi + 1)
         # -- depthwise: weight gradient, then data gradient (+ residual gradient, + producer's bn sums)
         dWd = torch.empty_like(w_dw)  # filled by the fused weight-gradient path of bwd_data
         grads[pi] = dWd
         g_prev = torch.empty_like(st_prev.y)
-        L.call("ttk_dwconv3x3_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn.cA), p(st_dw.bn.cB), p(st_dw.bn.cC), p(w_dw),
-               p(g) if has_skip else None, p(st_prev.y), p(st_prev.bn.scale), p(st_prev.bn.shift), p(st_prev.skip), p(a_in),
-               p(g_prev), p(part), p(dWd), 0, B, h, w_, cin, stride)
+        L.call("ttk_dwconv3x3_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), p(g) if has_skip else None, p(st_prev.y),
+               p(st_prev.bn), p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 0, B, h, w_, cin, stride)
         bwd_finalize(st_prev, L.partial_rows_elementwise(B * h * w_ * (cin // 4)), B * h * w_, pi - 2 if k > 0 else 1)
         g = g_prev
     st0 = ctx.stages[0]
     dW1 = torch.empty_like(params[0])
     _, _, H, W = ctx.x.shape
-    L.call("ttk_stem_bwd_weight", p(g), p(st0.y), p(st0.bn.cA), p(st0.bn.cB), p(st0.bn.cC), p(ctx.x), p(dW1), 0, B, H, W)
+    L.call("ttk_stem_bwd_weight", p(g), p(st0.y), p(st0.bn), p(ctx.x), p(dW1), 0, B, H, W)
     grads[0] = dW1
     return grads
 
@@ -354,7 +343,7 @@ class MobileNet(nn.Module):
             if name in _INTERMEDIATES:
                 st = c.stages[2 * k + 2]
                 a = torch.empty_like(st.y)
-                L.call("ttk_bn_act", p(st.y), p(st.bn.scale), p(st.bn.shift), p(st.skip), p(a), a.numel() // a.shape[-1], a.shape[-1])
+                L.call("ttk_bn_act", p(st.y), p(st.bn), p(st.skip), p(a), a.numel() // a.shape[-1], a.shape[-1])
                 outs.append(a.permute(0, 3, 1, 2))  # NCHW view of the channels-last buffer
         return outs
 

@@ -156,7 +156,10 @@ def test_gradients_vs_fp64_oracle():
     rel = lambda a, b: ((a.double().flatten() - b.double().flatten()).norm() / b.double().norm().clamp_min(1e-30)).item()
     bad = []
     for k, p in net.named_parameters():
+        if g64[k] is None:  # parameter no active loss depends on (e.g. shape_distrib_scales: nllshape is disabled)
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
         e_hip, e_cpu = rel(p.grad.cpu(), g64[k]), rel(g32[k], g64[k])
         if e_hip > 3 * e_cpu + 5e-5:
             bad.append((k, e_hip, e_cpu))
-    assert not bad, bad[:8]
+    assert not bad, [(k, f"{a:.1e}", f"{b:.1e}") for k, a, b in bad]
