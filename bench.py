@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Benchmark of the pose-estimator training step on MI355X (BASELINE.json metric:
+face-crops/sec forward+backward at per-GPU batch 512).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = zero_grad + forward + multi-task loss + backward of NetworkWithPointHead("mobilenetv1")
+with the training script's default flags (landmark head on) on one synthetic batch that is already
+resident in HBM (+ the RCCL gradient all-reduce, overlapped with backward, when N > 1; weak scaling:
+512 crops per GPU).  The optimiser step is timed separately (`optimizer_ms`), as SURVEY.md §8(d) says.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "neuralnet-tracker-traincode_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0          # HBM3E spec (6.29 TB/s measured copy)
+ALGO_BYTES_PER_CROP = 55.55e6  # 13 888 321 fp32 elements
+ALGO_FLOP_PER_CROP = 1.372e9   # 686 045 536 MAC fwd+bwd
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="crops per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time budget of the CPU baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 32)")
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP-event timing of the C-ABI calls on the stream they are launched on (torch's current stream),
+    with the algorithmic flops/bytes of each call."""
+
+    def __init__(self):
+        self.records = []  # (name, start, end, flops, bytes)
+        self.enabled = False
+
+    @staticmethod
+    def work(name, a):
+        """(flops, bytes) of one call from its integer arguments; fp32 = 4 B/element."""
+        ints = [x for x in a if isinstance(x, int) and not isinstance(x, bool)]
+        if name == "ttk_pwconv1x1_fwd":
+            M, ci, co = ints[-3:]
+            return 2 * M * ci * co, 4 * (M * ci + M * co + ci * co)
+        if name == "ttk_pwconv1x1_bwd_data":
+            M, ci, co = ints[-3:]
+            return 2 * M * ci * co, 4 * (2 * M * co + 2 * M * ci + ci * co)
+        if name == "ttk_pwconv1x1_bwd_weight":
+            M, ci, co = ints[-3:]
+            return 2 * M * ci * co, 4 * (2 * M * co + M * ci + ci * co)
+        return 0, 0
+
+    def wrap(self, lib):
+        orig = lib.call
+        timer = self
+
+        def call(name, *args):
+            if not timer.enabled:
+                return orig(name, *args)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            orig(name, *args)
+            e.record()
+            fl, by = timer.work(name, args)
+            timer.records.append((name, s, e, fl, by))
+
+        lib.call = call
+
+    def summary(self, steps):
+        agg = {}
+        for name, s, e, fl, by in self.records:
+            a = agg.setdefault(name, [0.0, 0, 0, 0])
+            a[0] += s.elapsed_time(e)
+            a[1] += 1
+            a[2] += fl
+            a[3] += by
+        return {k: {"ms_per_step": v[0] / steps, "calls_per_step": v[1] / steps, "flops": v[2], "bytes": v[3], "ms": v[0]} for k, v in agg.items()}
+
+
+def build_step(args, device):
+    import numpy as np
+
+    import trackertraincode.train as train
+    from trackertraincode.neuralnets.models import NetworkWithPointHead
+    from trackertraincode.pipelines import SyntheticPoseLoader, Tag
+
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("amd_train_script", os.path.join(REPO, "neuralnet-tracker-traincode_amd", "scripts", "train_poseestimator.py"))
+    S = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(S)
+
+    def script_args(flags):
+        ns = S.make_parser().parse_args([])
+        for k, v in flags.items():
+            setattr(ns, k, v)
+        return ns
+
+    torch.manual_seed(0)
+    net = NetworkWithPointHead(enable_point_head=True, enable_uncertainty=False, config="mobilenetv1",
+                               backbone_args={"use_blurpool": False})
+    g = torch.Generator().manual_seed(7)  # synthetic 3DMM keypoint basis (the real blob is not in the reference)
+    net.landmarks.deformablekeypoints.set_basis(torch.randn(68, 3, generator=g) * 0.5, torch.randn(50, 68, 3, generator=g) * 0.05)
+    net = net.to(device).train()
+    flags = dict(with_pointhead=True, with_nll_loss=False, rampup_nll_losses=False)
+    crit, _ = S.setup_losses(script_args(flags), net)
+    opt, _ = S.create_optimizer(net, script_args(flags))
+    rank = int(os.environ.get("RANK", 0))
+    # mix of the reference's default training set (pipelines.py:399-453): landmark-labelled crops with and
+    # without shape parameters
+    loader = SyntheticPoseLoader(args.batch, [(Tag.POSE_WITH_LANDMARKS, 110.0), (Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS, 10.0)],
+                                 device=device, seed=1234 + rank)
+    batches = next(iter(loader))
+    return net, crit, opt, batches, train
+
+
+def cpu_baseline(args):
+    """The CPU oracle (port of the reference's algorithm, pinned to reference goldens) timed on this
+    box's host cores on a bounded sample of the same workload."""
+    from oracle import refmodel as R
+    from oracle.synth import make_inputs, make_labels, make_state
+
+    # torch's CPU kernels stop scaling (and thrash) far below the 256 hardware threads of the GPU box's
+    # host: use at most 32 threads and say so in `cores`.
+    n = args.cpu_threads or min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(n)
+    B = args.cpu_batch
+    shapes = R.state_shapes(True, False)
+    st = R.state_from_numpy(make_state(shapes, 0))
+    image, ids = make_inputs(B, seed=1, structured=False)
+    lab = make_labels(B, seed=1)
+    gmm = R.ShapeGmm(os.path.join(REPO, "tests", "golden", "shapeparams_gmm.npz"))
+    crit, _ = R.setup_losses(with_pointhead=True, with_nll_loss=False, gmm=gmm)
+    batch = [dict(tag="POSE_WITH_LANDMARKS", n=B, **{k: torch.from_numpy(v) for k, v in lab.items() if k != "dataset_weight"})]
+    x, idt = torch.from_numpy(image), torch.from_numpy(ids)
+    cfg = dict(enable_point_head=True, enable_uncertainty=False)
+
+    def step():
+        for v in st.values():
+            v.grad = None
+        out, _ = R.network_forward(st, x, idt, cfg, True)
+        loss, _ = R.compute_loss(out, batch, 0, crit)
+        loss.backward()
+
+    tw = time.perf_counter()
+    step()  # warm-up (also tells how long one step takes)
+    tw = time.perf_counter() - tw
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        step()
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt + tw > args.cpu_seconds or steps >= 50:
+            break
+    return {"value": B * steps / dt, "unit": "crops/s", "cores": n, "kind": "port",
+            "sample": f"{steps} fwd+bwd steps of the same network at batch {B} (fp32, torch CPU kernels, {n} threads), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    import trackertraincode._hip as H
+    import trackertraincode.backbones.mobilenet_v1 as MB
+    from trackertraincode.parallel import GradAllReduce, broadcast_module_state
+
+    net, crit, opt, batches, train = build_step(args, device)
+    broadcast_module_state(net)
+    reducer = GradAllReduce() if world > 1 else None
+    if reducer is not None:
+        MB.grad_ready_hook = reducer.on_ready
+    params = list(net.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        out = train.training_step(net, batches, 0, crit)
+        out["loss"].backward()
+        if reducer is not None:
+            reducer.finish(params)
+        return out["loss"]
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    timer = KernelTimer()
+    timer.wrap(H.lib())
+    for _ in range(args.warmup):
+        step()
+    sync()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # optimiser step, timed on its own
+    sync()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        opt.step()
+    sync()
+    opt_ms = (time.perf_counter() - t1) / 5 * 1e3
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        crops = args.batch * world * args.steps / elapsed
+        ks = timer.summary(args.steps)
+        gemm = [k for k in ks if k.startswith("ttk_pwconv1x1")]
+        dominant = max(ks, key=lambda k: ks[k]["ms"]) if ks else None
+        roof = None
+        if gemm:
+            # dominant kernel FAMILY = the fp32-MFMA pointwise GEMMs (95.7 % of the MACs); the entry with the
+            # largest share is reported, with the family totals beside it
+            top = max(gemm, key=lambda k: ks[k]["ms"])
+            tf = ks[top]["flops"] / (ks[top]["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": top + " (pw_gemm_k, v_mfma_f32_32x32x2_f32)", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                    "launch_avg_us": ks[top]["ms"] / (ks[top]["calls_per_step"] * args.steps) * 1e3,
+                    "achieved_GBs": ks[top]["bytes"] / (ks[top]["ms"] * 1e-3) / 1e9,
+                    "family_TFLOPs": sum(ks[k]["flops"] for k in gemm) / (sum(ks[k]["ms"] for k in gemm) * 1e-3) / 1e12}
+        per_gpu = crops / world
+        line = {
+            "metric": "face-crops/sec fwd+bwd @ batch 512", "value": crops, "unit": "crops/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "NetworkWithPointHead(mobilenetv1, point head on, NLL off = training-script defaults): "
+                                   "zero_grad + fwd + multi-task loss + bwd" + (" + RCCL grad all-reduce overlapped with bwd" if world > 1 else ""),
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "input": "129x129x1 f32",
+                       "parallelism": f"dp{world}"},
+            "roofline": roof,
+            "step_roofline": {"hbm_frac_of_8TBs": per_gpu * ALGO_BYTES_PER_CROP / (PEAK_HBM_GBS * 1e9),
+                              "fp32_mfma_frac_of_157TF": per_gpu * ALGO_FLOP_PER_CROP / (PEAK_FP32_MFMA_TFLOPS * 1e12)},
+            "optimizer_ms": opt_ms, "loss": float(loss.item()),
+            "kernels_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms"])},
+            "dominant_entry_point": dominant,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -171,6 +171,11 @@ def _forward_impl(x, params, buffers, momentum, eps, training):
     return feat, ctx
 
 
+# Data-parallel hook: called as hook([(param, grad), ...]) whenever a block's parameter gradients are
+# final, in reverse layer order (trackertraincode.parallel.GradAllReduce.on_ready).
+grad_ready_hook = None
+
+
 def _backward_impl(ctx: _Ctx, gfeat, params):
     L = _hip.lib()
     p = _hip.ptr
@@ -216,11 +221,15 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
                p(st_prev.bn), p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 0, B, h, w_, cin, stride)
         bwd_finalize(st_prev, L.partial_rows_elementwise(B * h * w_ * (cin // 4)), B * h * w_, pi - 2 if k > 0 else 1)
         g = g_prev
+        if grad_ready_hook is not None:  # this block's conv + bn_dw gradients and its own bn_sep gradients are final
+            grad_ready_hook([(params[i], grads[i]) for i in range(pi, pi + 6)])
     st0 = ctx.stages[0]
     dW1 = torch.empty_like(params[0])
     _, _, H, W = ctx.x.shape
     L.call("ttk_stem_bwd_weight", p(g), p(st0.y), p(st0.bn), p(ctx.x), p(dW1), 0, B, H, W)
     grads[0] = dW1
+    if grad_ready_hook is not None:
+        grad_ready_hook([(params[i], grads[i]) for i in range(3)])
     return grads
 
 
