@@ -63,6 +63,7 @@ const char* ttk_last_error_string(void);
 
 /* Number of rows of the `part` buffer ([rows][2][C] floats) that a producer writes. */
 int ttk_partial_rows_elementwise(int64_t work_items); /* stem / depthwise / pool kernels        */
+int ttk_partial_rows_dwconv(int B, int H, int W, int C, int stride, int backward); /* depthwise fwd (0) / data-grad (1) */
 int ttk_partial_rows_gemm(int64_t M);                 /* pointwise (MFMA) kernels: ceil(M/128)  */
 
 /* ---------------------------------------------------------------------------------------------

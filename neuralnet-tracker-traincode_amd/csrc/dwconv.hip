@@ -2,6 +2,8 @@
 // producer's BatchNorm+ReLU(+residual) applied while loading and this layer's BatchNorm statistics
 // reduced in the epilogue.  Reference: DepthWiseBlock.conv_dw/bn_dw, backbones/mobilenet_v1.py:57-66,78-80.
 //
+// This file: the standalone depthwise weight gradient (unit tests; the training step uses the fused one
+// in dwconv_tiled.hip) and the bn_act materialisation kernel.  Forward / data gradient: dwconv_tiled.hip.
 // Thread = (pixel, channel quad); the C/4 lanes of one pixel read/write C*4 contiguous bytes.
 // Channel counts are powers of two (32..1024) so quad ownership is fixed per thread, and the odd
 // spatial sizes (65/33/17/9/5) never touch the lane mapping.
@@ -38,140 +40,6 @@ struct InputForm {  // how the block input is formed from the producer's raw out
     return skip_prev ? bn.act(y, ld4(skip_prev + off)) : bn.act(y);
   }
 };
-
-template <int S>
-__global__ void __launch_bounds__(kBlock) dw_fwd_k(const float* __restrict__ yprev, const float* __restrict__ bn_prev,
-                                                    const float* __restrict__ skip_prev,
-                                                    float* __restrict__ a_out, const float* __restrict__ w,
-                                                    float* __restrict__ y, float* __restrict__ part, int B, int H, int W,
-                                                    int C, int Ho, int Wo, int qshift) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int quads = C >> 2;
-  const int c4 = threadIdx.x & (quads - 1);
-  DwWeights wr;
-  wr.load(w, c4);
-  InputForm in{yprev, skip_prev, nullptr, BnApply4::load(bn_prev, C, 4 * c4)};
-  const int64_t items = ((int64_t)B * Ho * Wo) << qshift;
-  float4 s1 = f4(0.f), s2 = f4(0.f);
-  for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * kBlock) {
-    int64_t pix = idx >> qshift;
-    const int wo = (int)(pix % Wo);
-    pix /= Wo;
-    const int ho = (int)(pix % Ho);
-    const int n = (int)(pix / Ho);
-    float4 acc = f4(0.f);
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int hi = ho * S + kh - 1;
-      if (hi < 0 || hi >= H) continue;
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int wi = wo * S + kw - 1;
-        if (wi < 0 || wi >= W) continue;
-        const size_t off = (((size_t)n * H + hi) * W + wi) * C + 4 * c4;
-        const float4 a = in(off);
-        if (S == 1 && kh == 1 && kw == 1 && a_out) st4(a_out + off, a);
-        acc = fma4(a, wr.tap(kh * 3 + kw), acc);
-      }
-    }
-    st4(y + (idx << 2), acc);
-    s1 = add4(s1, acc);
-    s2 = fma4(acc, acc, s2);
-  }
-  if (part) block_channel_partials<1024>(s1, s2, c4, C, part + (size_t)blockIdx.x * 2 * C, smem);
-}
-
-// Gradient w.r.t. the block input (transposed depthwise conv), + residual gradient, masked by the
-// producer's ReLU, with the producer's BatchNorm-backward sums in the epilogue.
-template <int S>
-__global__ void __launch_bounds__(kBlock) dw_bwd_data_k(const float* __restrict__ g_dw, const float* __restrict__ y_dw,
-                                                         const float* __restrict__ bn_dw, const float* __restrict__ w,
-                                                         const float* __restrict__ skip_grad,
-                                                         const float* __restrict__ yprev, const float* __restrict__ bn_prev,
-                                                         const float* __restrict__ skip_prev, const float* __restrict__ a_in,
-                                                         float* __restrict__ g_prev, float* __restrict__ part,
-                                                         float* __restrict__ dwgrad, int B, int H,
-                                                         int W, int C, int Ho, int Wo, int qshift) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2*C] partials (+ [9*C] weight grads)
-  const int quads = C >> 2;
-  const int c4 = threadIdx.x & (quads - 1);
-  DwWeights wr;
-  wr.load(w, c4);
-  const BnGrad4 bg = BnGrad4::load(bn_dw, C, 4 * c4);
-  InputForm in{yprev, skip_prev, a_in, BnApply4::load(bn_prev, C, 4 * c4)};
-  const int64_t items = ((int64_t)B * H * W) << qshift;
-  float4 s1 = f4(0.f), s2 = f4(0.f);
-  // Fused weight gradient: dW[c][tap] = sum_o dy(o) * a_in(o*S + tap - 1).  This thread sits at the
-  // input pixel q = o*S + tap - 1 and visits exactly those (o, tap) pairs below, so the products
-  // dy(o)*a_in(q) need no extra loads.
-  float4 wacc[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) wacc[t] = f4(0.f);
-  for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * kBlock) {
-    int64_t pix = idx >> qshift;
-    const int wi = (int)(pix % W);
-    pix /= W;
-    const int hi = (int)(pix % H);
-    const int n = (int)(pix / H);
-    float4 G = f4(0.f);
-    const size_t off_in = (size_t)idx << 2;
-    const float4 a = in(off_in);
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int th = hi + 1 - kh;
-      if (th < 0 || (S == 2 && (th & 1))) continue;
-      const int ho = th / S;
-      if (ho >= Ho) continue;
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int tw = wi + 1 - kw;
-        if (tw < 0 || (S == 2 && (tw & 1))) continue;
-        const int wo = tw / S;
-        if (wo >= Wo) continue;
-        const size_t off = (((size_t)n * Ho + ho) * Wo + wo) * C + 4 * c4;
-        const float4 dy = bg.dy(ld4(g_dw + off), ld4(y_dw + off));
-        G = fma4(dy, wr.tap(kh * 3 + kw), G);
-        wacc[kh * 3 + kw] = fma4(dy, a, wacc[kh * 3 + kw]);
-      }
-    }
-    if (skip_grad) G = add4(G, ld4(skip_grad + off_in));
-    const float4 gp = mask4(G, a);
-    st4(g_prev + off_in, gp);
-    s1 = add4(s1, gp);
-    s2 = fma4(gp, sub4(ld4(yprev + off_in), in.bn.mean), s2);
-  }
-  if (part) block_channel_partials<1024>(s1, s2, c4, C, part + (size_t)blockIdx.x * 2 * C, smem);
-  if (dwgrad) {
-    float* ws = smem + 2 * C;  // [9][C]
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      float4 v = wacc[t];
-      for (int off = quads; off < kWave; off <<= 1) {
-        v.x += __shfl_xor(v.x, off); v.y += __shfl_xor(v.y, off);
-        v.z += __shfl_xor(v.z, off); v.w += __shfl_xor(v.w, off);
-      }
-      wacc[t] = v;
-    }
-    for (int i = threadIdx.x; i < 9 * C; i += kBlock) ws[i] = 0.f;
-    __syncthreads();
-    const int lane = threadIdx.x & (kWave - 1);
-    const bool owner = (quads >= kWave) || (lane < quads);
-    for (int wv = 0; wv < kBlock / kWave; ++wv) {
-      if ((threadIdx.x >> 6) == wv && owner) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          float* d = ws + t * C + 4 * c4;
-          d[0] += wacc[t].x; d[1] += wacc[t].y; d[2] += wacc[t].z; d[3] += wacc[t].w;
-        }
-      }
-      __syncthreads();
-    }
-    for (int i = threadIdx.x; i < 9 * C; i += kBlock) {
-      const int t = i / C, c = i - t * C;
-      atomicAdd(dwgrad + c * 9 + t, ws[i]);
-    }
-  }
-}
 
 // dW[c][tap] += sum_{n,ho,wo} dy_dw[n,ho,wo,c] * a_in[n, ho*S+kh-1, wo*S+kw-1, c]
 template <int S>
@@ -265,48 +133,6 @@ static bool dw_shape_ok(int B, int H, int W, int C, int stride) {
 using namespace ttk;
 
 extern "C" {
-
-int ttk_dwconv3x3_fwd(const float* yprev, const float* bn_prev, const float* skip_prev, float* a_out, const float* w, float* y,
-                      float* part, int B, int H, int W, int C, int stride, ttk_stream_t stream) {
-  TTK_REQUIRE(yprev && bn_prev && w && y, "dwconv3x3_fwd: null pointer");
-  TTK_REQUIRE(dw_shape_ok(B, H, W, C, stride), "dwconv3x3_fwd: unsupported shape B=%d H=%d W=%d C=%d stride=%d (C must be a power of two in 32..1024)", B, H, W, C, stride);
-  TTK_REQUIRE(!(a_out && stride != 1), "dwconv3x3_fwd: a_out requires stride 1");
-  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-  const int qs = log2i(C / 4);
-  const int64_t items = ((int64_t)B * Ho * Wo) << qs;
-  const dim3 grid(elementwise_grid(items));
-  const size_t sm = 2 * (size_t)C * sizeof(float);
-  if (stride == 1)
-    hipLaunchKernelGGL(dw_fwd_k<1>, grid, dim3(kBlock), sm, (hipStream_t)stream, yprev, bn_prev, skip_prev, a_out, w, y, part, B,
-                       H, W, C, Ho, Wo, qs);
-  else
-    hipLaunchKernelGGL(dw_fwd_k<2>, grid, dim3(kBlock), sm, (hipStream_t)stream, yprev, bn_prev, skip_prev, a_out, w, y, part, B,
-                       H, W, C, Ho, Wo, qs);
-  TTK_LAUNCH_CHECK("dwconv3x3_fwd");
-}
-
-int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* bn_dw, const float* w, const float* skip_grad,
-                           const float* yprev, const float* bn_prev, const float* skip_prev, const float* a_in, float* g_prev,
-                           float* part,
-                           float* dw, int dw_accumulate, int B, int H, int W, int C, int stride, ttk_stream_t stream) {
-  TTK_REQUIRE(g_dw && y_dw && bn_dw && w && yprev && bn_prev && g_prev, "dwconv3x3_bwd_data: null pointer");
-  TTK_REQUIRE(dw_shape_ok(B, H, W, C, stride), "dwconv3x3_bwd_data: unsupported shape");
-  TTK_REQUIRE(!(skip_grad && stride != 1), "dwconv3x3_bwd_data: residual gradient requires stride 1");
-  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-  const int qs = log2i(C / 4);
-  const int64_t items = ((int64_t)B * H * W) << qs;
-  const dim3 grid(elementwise_grid(items));
-  const size_t sm = (dw ? 11 : 2) * (size_t)C * sizeof(float);
-  if (dw && !dw_accumulate)
-    hipLaunchKernelGGL(zero_f, dim3((9 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dw, (int64_t)9 * C);
-  if (stride == 1)
-    hipLaunchKernelGGL(dw_bwd_data_k<1>, grid, dim3(kBlock), sm, (hipStream_t)stream, g_dw, y_dw, bn_dw, w, skip_grad, yprev,
-                       bn_prev, skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, qs);
-  else
-    hipLaunchKernelGGL(dw_bwd_data_k<2>, grid, dim3(kBlock), sm, (hipStream_t)stream, g_dw, y_dw, bn_dw, w, skip_grad, yprev,
-                       bn_prev, skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, qs);
-  TTK_LAUNCH_CHECK("dwconv3x3_bwd_data");
-}
 
 int ttk_dwconv3x3_bwd_weight(const float* g_dw, const float* y_dw, const float* bn_dw, const float* yprev, const float* bn_prev,
                              const float* skip_prev, const float* a_in, float* dw, int accumulate, int B, int H, int W, int C,

@@ -1,0 +1,342 @@
+// LDS-tiled depthwise 3x3 (pad 1, stride 1|2) forward and data-gradient kernels.
+//
+// v1 of these kernels read every tap straight from global memory: 9 (forward) / 18 (backward)
+// 16-byte loads per output float4 through L1/TA plus a 9x repeated BatchNorm transform - they ran at
+// 1.5-2 TB/s, texture-addresser bound.  Here a workgroup owns a tile
+//     (one image) x (a band of R rows, full width) x (a slab of 32 channels)
+// stages the operand of the stencil ONCE in LDS - already transformed (forward: a_in = relu(bn(y_prev)
+// (+skip)); backward: dy = ga*(g-gmean)+gb*(y-mean)) - with one zero column of padding left and right,
+// and reads the 9 taps with ds_read_b128 (8 lanes x 16 B = the 128-byte channel slab of one pixel;
+// 8 consecutive pixels of a row = 1 KiB contiguous: conflict-free).
+//
+// Workgroups are persistent over tiles of ONE channel slab, so per-channel BatchNorm partial sums and
+// the fused depthwise weight gradient accumulate in registers across tiles and leave the block once
+// (one partial row + 288 float atomics per workgroup).
+#include "ttk_common.h"
+
+namespace ttk {
+
+constexpr int kSlab = 32;            // channels per tile
+constexpr int kSlabQuads = kSlab / 4;
+constexpr int kPixSlots = kBlock / kSlabQuads;  // 32 pixels in flight per pass
+constexpr int kLdsPixBudget = 368;   // (rows) x (W+2) pixels of 128 B each: <= 47 KB -> 3 workgroups per CU
+constexpr int kMaxDwBlocks = 2048;
+
+struct DwTiling {
+  int R, nbands, nslabs, grid, rows;  // rows = partial rows = grid / nslabs
+};
+
+// band height on the grid the kernel iterates (forward: output rows; backward: input rows)
+__host__ __device__ inline int dw_band_rows(int Hgrid, int Wstage, int stride, bool backward) {
+  const int stage_rows = kLdsPixBudget / (Wstage + 2);  // LDS rows we can afford
+  int R;
+  if (!backward) R = (stage_rows - 3) / stride + 1;      // needs (R-1)*S+3 input rows
+  else R = (stride == 1) ? stage_rows - 2 : 2 * (stage_rows - 2);  // needs <= R/S+2 output rows
+  if (R < 1) R = 1;
+  if (R > Hgrid) R = Hgrid;
+  return R;
+}
+
+inline DwTiling dw_tiling(int B, int H, int W, int C, int stride, bool backward) {
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  DwTiling t;
+  t.R = backward ? dw_band_rows(H, Wo, stride, true) : dw_band_rows(Ho, W, stride, false);
+  t.nbands = ((backward ? H : Ho) + t.R - 1) / t.R;
+  t.nslabs = C / kSlab;
+  int64_t tiles_per_slab = (int64_t)B * t.nbands;
+  int64_t rows = kMaxDwBlocks / t.nslabs;
+  if (rows < 1) rows = 1;
+  if (rows > tiles_per_slab) rows = tiles_per_slab;
+  t.rows = (int)rows;
+  t.grid = t.rows * t.nslabs;
+  return t;
+}
+
+struct SlabWeights {  // w[c][tap] of 4 consecutive channels
+  float v[36];
+  __device__ __forceinline__ void load(const float* w, int c) {
+    const float4* p = reinterpret_cast<const float4*>(w + 9 * c);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const float4 q = p[i];
+      v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+    }
+  }
+  __device__ __forceinline__ float4 tap(int t) const { return make_float4(v[t], v[9 + t], v[18 + t], v[27 + t]); }
+};
+
+// fold over the 32 pixel slots of the block: lanes 8 apart own the same quad
+__device__ __forceinline__ float4 slab_wave_fold(float4 v) {
+#pragma unroll
+  for (int off = kSlabQuads; off < kWave; off <<= 1) {
+    v.x += __shfl_xor(v.x, off); v.y += __shfl_xor(v.y, off);
+    v.z += __shfl_xor(v.z, off); v.w += __shfl_xor(v.w, off);
+  }
+  return v;
+}
+
+// Per-channel sums carried in fp64: a persistent workgroup adds thousands of terms per thread and
+// sum(g) cancels heavily (BatchNorm-backward makes the upstream gradient zero-mean), so fp32 running sums
+// cost 1-2 digits of d(beta).  fp64 adds are free next to the memory time of these kernels.
+struct D4 {
+  double x, y, z, w;
+  __device__ __forceinline__ void add(float4 v) { x += v.x; y += v.y; z += v.z; w += v.w; }
+  __device__ __forceinline__ void addmul(float4 a, float4 b) {
+    x += (double)a.x * b.x; y += (double)a.y * b.y; z += (double)a.z * b.z; w += (double)a.w * b.w;
+  }
+};
+__device__ __forceinline__ double shfl_xor_d(double v, int off) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, off);
+  hi = __shfl_xor(hi, off);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ D4 slab_wave_fold_d(D4 v) {
+#pragma unroll
+  for (int off = kSlabQuads; off < kWave; off <<= 1) {
+    v.x += shfl_xor_d(v.x, off); v.y += shfl_xor_d(v.y, off);
+    v.z += shfl_xor_d(v.z, off); v.w += shfl_xor_d(v.w, off);
+  }
+  return v;
+}
+
+// writes part_row[0][slab columns] = sum s1, part_row[1][slab columns] = sum s2 (fixed wave order)
+__device__ __forceinline__ void slab_partials(D4 s1, D4 s2, int q, int C, int c_slab, float* part_row, float* red_f) {
+  double* red = reinterpret_cast<double*>(red_f);  // [4 waves][2][32] doubles
+  s1 = slab_wave_fold_d(s1);
+  s2 = slab_wave_fold_d(s2);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane < kSlabQuads) {
+    double* d = red + (wv * 2 + 0) * kSlab + 4 * q;
+    d[0] = s1.x; d[1] = s1.y; d[2] = s1.z; d[3] = s1.w;
+    d = red + (wv * 2 + 1) * kSlab + 4 * q;
+    d[0] = s2.x; d[1] = s2.y; d[2] = s2.z; d[3] = s2.w;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * kSlab) {
+    const int which = threadIdx.x / kSlab, c = threadIdx.x % kSlab;
+    double a = 0.0;
+    for (int w = 0; w < kBlock / kWave; ++w) a += red[(w * 2 + which) * kSlab + c];
+    part_row[(size_t)which * C + c_slab + c] = (float)a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__global__ void __launch_bounds__(kBlock) dw_fwd_tiled_k(const float* __restrict__ yprev, const float* __restrict__ bn_prev,
+                                                          const float* __restrict__ skip_prev, float* __restrict__ a_out,
+                                                          const float* __restrict__ w, float* __restrict__ y,
+                                                          float* __restrict__ part, int B, int H, int W, int C, int Ho, int Wo,
+                                                          int R, int nbands, int nslabs) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [stage_rows][W+2][32] + reduction scratch
+  const int tid = threadIdx.x, q = tid & (kSlabQuads - 1), slot = tid >> 3;
+  const int slab = blockIdx.x % nslabs, c0 = slab * kSlab + 4 * q;
+  const int Wp = W + 2;
+  SlabWeights wr;
+  wr.load(w, c0);
+  const BnApply4 bn = BnApply4::load(bn_prev, C, c0);
+  D4 s1{0.0, 0.0, 0.0, 0.0}, s2{0.0, 0.0, 0.0, 0.0};
+  const int64_t tiles = (int64_t)B * nbands;
+  for (int64_t t = blockIdx.x / nslabs; t < tiles; t += gridDim.x / nslabs) {
+    const int n = (int)(t / nbands), band = (int)(t % nbands);
+    const int o0 = band * R, o1 = min(o0 + R, Ho);
+    const int i0 = o0 * S - 1;                     // first staged input row (may be -1)
+    const int nrows = (o1 - 1 - o0) * S + 3;
+    __syncthreads();  // previous tile's readers are done
+    // ---- stage: a_in rows i0 .. i0+nrows-1, columns -1 .. W (zero outside the image)
+    for (int e = tid; e < nrows * Wp * kSlabQuads; e += kBlock) {
+      const int qq = e & (kSlabQuads - 1), px = e >> 3;
+      const int col = px % Wp - 1, row = i0 + px / Wp;
+      float4 a = f4(0.f);
+      if (row >= 0 && row < H && col >= 0 && col < W) {
+        const size_t off = (((size_t)n * H + row) * W + col) * C + slab * kSlab + 4 * qq;
+        const float4 yv = ld4(yprev + off);  // qq == q for every e (kBlock is a multiple of 8): bn is this thread's quad
+        a = skip_prev ? bn.act(yv, ld4(skip_prev + off)) : bn.act(yv);
+        if (S == 1 && a_out && row >= o0 && row < o1) st4(a_out + off, a);  // each input pixel belongs to one band
+      }
+      st4(lds + (size_t)px * kSlab + 4 * qq, a);
+    }
+    __syncthreads();
+    // ---- stencil
+    const int npix = (o1 - o0) * Wo;
+    for (int p = slot; p < npix; p += kPixSlots) {
+      const int ho = o0 + p / Wo, wo = p % Wo;
+      const float* base = lds + ((size_t)((ho - o0) * S) * Wp + wo * S) * kSlab + 4 * q;  // tap (0,0): row ho*S-1, col wo*S-1
+      float4 acc = f4(0.f);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc = fma4(ld4(base + ((size_t)kh * Wp + kw) * kSlab), wr.tap(kh * 3 + kw), acc);
+      st4(y + (((size_t)n * Ho + ho) * Wo + wo) * C + c0, acc);
+      s1.add(acc);
+      s2.addmul(acc, acc);
+    }
+  }
+  if (part) {
+    const int stage = ((R - 1) * S + 3) * Wp * kSlab;
+    slab_partials(s1, s2, q, C, slab * kSlab, part + (size_t)(blockIdx.x / nslabs) * 2 * C, lds + stage);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// data gradient (+ fused weight gradient)
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__global__ void __launch_bounds__(kBlock) dw_bwd_tiled_k(const float* __restrict__ g_dw, const float* __restrict__ y_dw,
+                                                          const float* __restrict__ bn_dw, const float* __restrict__ w,
+                                                          const float* __restrict__ skip_grad,
+                                                          const float* __restrict__ yprev, const float* __restrict__ bn_prev,
+                                                          const float* __restrict__ skip_prev, const float* __restrict__ a_in,
+                                                          float* __restrict__ g_prev, float* __restrict__ part,
+                                                          float* __restrict__ dwgrad, int B, int H, int W, int C, int Ho, int Wo,
+                                                          int R, int nbands, int nslabs, int stage_floats) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // dy[stage_rows][Wo+2][32] + reduction scratch
+  const int tid = threadIdx.x, q = tid & (kSlabQuads - 1), slot = tid >> 3;
+  const int slab = blockIdx.x % nslabs, c0 = slab * kSlab + 4 * q;
+  const int Wp = Wo + 2;
+  SlabWeights wr;
+  wr.load(w, c0);
+  const BnApply4 bnp = BnApply4::load(bn_prev, C, c0);
+  const BnGrad4 bg = BnGrad4::load(bn_dw, C, c0);
+  D4 s1{0.0, 0.0, 0.0, 0.0}, s2{0.0, 0.0, 0.0, 0.0};
+  float4 wacc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wacc[t] = f4(0.f);
+  const int64_t tiles = (int64_t)B * nbands;
+  for (int64_t t = blockIdx.x / nslabs; t < tiles; t += gridDim.x / nslabs) {
+    const int n = (int)(t / nbands), band = (int)(t % nbands);
+    const int r0 = band * R, r1 = min(r0 + R, H);
+    // output rows ho with ho*S + kh - 1 in [r0, r1): ho in [ceil((r0-1)/S), floor(r1/S)], clipped
+    const int ho_lo = max(0, (r0 - 1 + S - 1) / S * (r0 > 0 ? 1 : 0));
+    const int ho_hi = min(Ho - 1, r1 / S);
+    const int nrows = ho_hi - ho_lo + 1;
+    __syncthreads();
+    // ---- stage dy rows ho_lo..ho_hi, columns -1..Wo (zeros outside)
+    for (int e = tid; e < nrows * Wp * kSlabQuads; e += kBlock) {
+      const int qq = e & (kSlabQuads - 1), px = e >> 3;
+      const int col = px % Wp - 1, row = ho_lo + px / Wp;
+      float4 dy = f4(0.f);
+      if (col >= 0 && col < Wo) {
+        const size_t off = (((size_t)n * Ho + row) * Wo + col) * C + slab * kSlab + 4 * qq;
+        dy = bg.dy(ld4(g_dw + off), ld4(y_dw + off));  // qq == q (see forward)
+      }
+      st4(lds + (size_t)px * kSlab + 4 * qq, dy);
+    }
+    __syncthreads();
+    const int npix = (r1 - r0) * W;
+    for (int p = slot; p < npix; p += kPixSlots) {
+      const int hi = r0 + p / W, wi = p % W;
+      const size_t off_in = (((size_t)n * H + hi) * W + wi) * C + c0;
+      const float4 yp = ld4(yprev + off_in);
+      float4 a;
+      if (a_in) a = ld4(a_in + off_in);
+      else a = skip_prev ? bnp.act(yp, ld4(skip_prev + off_in)) : bnp.act(yp);
+      float4 G = f4(0.f);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int th = hi + 1 - kh;
+        if (th < 0 || (S == 2 && (th & 1))) continue;
+        const int ho = th / S;
+        if (ho > Ho - 1) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tw = wi + 1 - kw;  // -1 .. W
+          if (S == 2 && (tw & 1)) continue;
+          const int wo = (S == 1) ? tw : (tw >> 1);  // -1 or Wo hit the zero padding columns (S=1); always inside for S=2
+          const float4 dy = ld4(lds + ((size_t)(ho - ho_lo) * Wp + wo + 1) * kSlab + 4 * q);
+          G = fma4(dy, wr.tap(kh * 3 + kw), G);
+          wacc[kh * 3 + kw] = fma4(dy, a, wacc[kh * 3 + kw]);
+        }
+      }
+      if (skip_grad) G = add4(G, ld4(skip_grad + off_in));
+      const float4 gp = mask4(G, a);
+      st4(g_prev + off_in, gp);
+      s1.add(gp);
+      s2.addmul(gp, sub4(yp, bnp.mean));
+    }
+  }
+  float* red = lds + stage_floats;
+  if (part) slab_partials(s1, s2, q, C, slab * kSlab, part + (size_t)(blockIdx.x / nslabs) * 2 * C, red);
+  if (dwgrad) {
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float4 v = slab_wave_fold(wacc[t]);
+      if (lane < kSlabQuads) st4(red + ((size_t)wv * 9 + t) * kSlab + 4 * q, v);
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * kSlab; i += kBlock) {
+      const int t = i / kSlab, c = i % kSlab;
+      float a = 0.f;
+      for (int wq = 0; wq < kBlock / kWave; ++wq) a += red[((size_t)wq * 9 + t) * kSlab + c];
+      atomicAdd(dwgrad + (size_t)(slab * kSlab + c) * 9 + t, a);
+    }
+  }
+}
+
+__global__ void zero_fill_k(float* p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
+static bool dw_shape_ok2(int B, int H, int W, int C, int stride) {
+  return B > 0 && H > 0 && W > 0 && W <= 256 && C >= 32 && C <= 1024 && (C & (C - 1)) == 0 && (stride == 1 || stride == 2);
+}
+
+}  // namespace ttk
+
+using namespace ttk;
+
+extern "C" {
+
+int ttk_partial_rows_dwconv(int B, int H, int W, int C, int stride, int backward) {
+  if (!dw_shape_ok2(B, H, W, C, stride)) return -1;
+  return dw_tiling(B, H, W, C, stride, backward != 0).rows;
+}
+
+int ttk_dwconv3x3_fwd(const float* yprev, const float* bn_prev, const float* skip_prev, float* a_out, const float* w, float* y,
+                      float* part, int B, int H, int W, int C, int stride, ttk_stream_t stream) {
+  TTK_REQUIRE(yprev && bn_prev && w && y, "dwconv3x3_fwd: null pointer");
+  TTK_REQUIRE(dw_shape_ok2(B, H, W, C, stride), "dwconv3x3_fwd: unsupported shape B=%d H=%d W=%d C=%d stride=%d (C: power of two in 32..1024, W <= 256)", B, H, W, C, stride);
+  TTK_REQUIRE(!(a_out && stride != 1), "dwconv3x3_fwd: a_out requires stride 1");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const DwTiling t = dw_tiling(B, H, W, C, stride, false);
+  const size_t stage = (size_t)((t.R - 1) * stride + 3) * (W + 2) * kSlab;
+  const size_t sm = (stage + 16 * kSlab) * sizeof(float);  // + [4][2][32] doubles of reduction scratch
+  if (stride == 1)
+    hipLaunchKernelGGL(dw_fwd_tiled_k<1>, dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, yprev, bn_prev, skip_prev, a_out,
+                       w, y, part, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs);
+  else
+    hipLaunchKernelGGL(dw_fwd_tiled_k<2>, dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, yprev, bn_prev, skip_prev, a_out,
+                       w, y, part, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs);
+  TTK_LAUNCH_CHECK("dwconv3x3_fwd");
+}
+
+int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* bn_dw, const float* w, const float* skip_grad,
+                           const float* yprev, const float* bn_prev, const float* skip_prev, const float* a_in, float* g_prev,
+                           float* part, float* dw, int dw_accumulate, int B, int H, int W, int C, int stride,
+                           ttk_stream_t stream) {
+  TTK_REQUIRE(g_dw && y_dw && bn_dw && w && yprev && bn_prev && g_prev, "dwconv3x3_bwd_data: null pointer");
+  TTK_REQUIRE(dw_shape_ok2(B, H, W, C, stride), "dwconv3x3_bwd_data: unsupported shape");
+  TTK_REQUIRE(!(skip_grad && stride != 1), "dwconv3x3_bwd_data: residual gradient requires stride 1");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const DwTiling t = dw_tiling(B, H, W, C, stride, true);
+  const int stage_rows = (stride == 1) ? t.R + 2 : t.R / 2 + 2;
+  const size_t stage = (size_t)stage_rows * (Wo + 2) * kSlab;
+  const size_t sm = (stage + 4 * 9 * kSlab) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dw && !dw_accumulate) hipLaunchKernelGGL(zero_fill_k, dim3((9 * C + 255) / 256), dim3(256), 0, st, dw, (int64_t)9 * C);
+  if (stride == 1)
+    hipLaunchKernelGGL(dw_bwd_tiled_k<1>, dim3(t.grid), dim3(kBlock), sm, st, g_dw, y_dw, bn_dw, w, skip_grad, yprev, bn_prev,
+                       skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage);
+  else
+    hipLaunchKernelGGL(dw_bwd_tiled_k<2>, dim3(t.grid), dim3(kBlock), sm, st, g_dw, y_dw, bn_dw, w, skip_grad, yprev, bn_prev,
+                       skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage);
+  TTK_LAUNCH_CHECK("dwconv3x3_bwd_data");
+}
+
+}  // extern "C"

@@ -77,6 +77,7 @@ class _Library:
             fn = getattr(self.cdll, name)
             fn.argtypes, fn.restype = [c_int64], c_int
         self.cdll.ttk_heads_num_rows.argtypes, self.cdll.ttk_heads_num_rows.restype = [c_int, c_int], c_int
+        self.cdll.ttk_partial_rows_dwconv.argtypes, self.cdll.ttk_partial_rows_dwconv.restype = [c_int] * 6, c_int
         self._fns = {}
         for name, sig in _SIGNATURES.items():
             fn = getattr(self.cdll, name)  # AttributeError if the symbol is missing: loud by design
@@ -93,6 +94,9 @@ class _Library:
 
     def partial_rows_elementwise(self, items: int) -> int:
         return self.cdll.ttk_partial_rows_elementwise(items)
+
+    def partial_rows_dwconv(self, B, H, W, C, stride, backward) -> int:
+        return self.cdll.ttk_partial_rows_dwconv(B, H, W, C, stride, int(backward))
 
     def partial_rows_gemm(self, m: int) -> int:
         return self.cdll.ttk_partial_rows_gemm(m)
@@ -121,4 +125,4 @@ def ptr(t: torch.Tensor | None):
 
 def exported_symbols() -> list[str]:
     return ["ttk_abi_version", "ttk_last_error_string", "ttk_partial_rows_elementwise",
-            "ttk_partial_rows_gemm", "ttk_heads_num_rows"] + list(_SIGNATURES)
+            "ttk_partial_rows_gemm", "ttk_partial_rows_dwconv", "ttk_heads_num_rows"] + list(_SIGNATURES)

@@ -96,8 +96,8 @@ def _part_buffer(B, H, W, device):
     need = max(need, L.partial_rows_elementwise(B * h * h * 8) * 2 * 32)
     for _, cin, cout, stride in _BLOCKS:
         ho = (h - 1) // stride + 1
-        need = max(need, L.partial_rows_elementwise(B * h * h * (cin // 4)) * 2 * cin)    # dw bwd-data (input grid)
-        need = max(need, L.partial_rows_elementwise(B * ho * ho * (cin // 4)) * 2 * cin)  # dw fwd
+        need = max(need, L.partial_rows_dwconv(B, h, h, cin, stride, True) * 2 * cin)     # dw bwd-data
+        need = max(need, L.partial_rows_dwconv(B, h, h, cin, stride, False) * 2 * cin)    # dw fwd
         need = max(need, L.partial_rows_gemm(B * ho * ho) * 2 * max(cin, cout))            # pw fwd / bwd-data
         need = max(need, L.partial_rows_elementwise(B * ho * ho * (cout // 4)) * 2 * cout)  # pool bwd
         h = ho
@@ -151,7 +151,7 @@ def _forward_impl(x, params, buffers, momentum, eps, training):
         L.call("ttk_dwconv3x3_fwd", p(prev.y), p(prev.bn), p(prev.skip), p(a_in), p(w_dw), p(ydw), part_arg, B, h, w_, cin,
                stride)
         bn_dw = _bn_work(cin, dev)
-        finalize(bn_dw, L.partial_rows_elementwise(B * ho * wo * (cin // 4)), cin, B * ho * wo, g_dw, b_dw, bi)
+        finalize(bn_dw, L.partial_rows_dwconv(B, h, w_, cin, stride, False), cin, B * ho * wo, g_dw, b_dw, bi)
         ypw = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=dev)
         M = B * ho * wo
         L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), p(w_pw), p(ypw), part_arg, M, cin, cout)
@@ -219,7 +219,7 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         g_prev = torch.empty_like(st_prev.y)
         L.call("ttk_dwconv3x3_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), p(g) if has_skip else None, p(st_prev.y),
                p(st_prev.bn), p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 0, B, h, w_, cin, stride)
-        bwd_finalize(st_prev, L.partial_rows_elementwise(B * h * w_ * (cin // 4)), B * h * w_, pi - 2 if k > 0 else 1)
+        bwd_finalize(st_prev, L.partial_rows_dwconv(B, h, w_, cin, stride, True), B * h * w_, pi - 2 if k > 0 else 1)
         g = g_prev
         if grad_ready_hook is not None:  # this block's conv + bn_dw gradients and its own bn_sep gradients are final
             grad_ready_hook([(params[i], grads[i]) for i in range(pi, pi + 6)])

@@ -153,13 +153,21 @@ def test_gradients_vs_fp64_oracle():
     net = build_net(meta, DEV).train()
     crit, _ = S.setup_losses(script_args(meta["flags"]), net)
     train.training_step(net, make_batches(meta, DEV), 150, crit)["loss"].backward()
-    rel = lambda a, b: ((a.double().flatten() - b.double().flatten()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    def rel(a, b):  # relative l2 error
+        a, b = a.double().flatten().cpu(), b.double().flatten()
+        return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+    # Criterion per parameter: l2 error vs fp64 within 3x the fp32 CPU path's, with a floor of 2.5e-4: a single
+    # ReLU whose pre-activation is ~0 may flip in one fp32 implementation and not in the other, which moves one
+    # channel of an upstream bias gradient by ~1e-4 of the vector norm (measured: dw5_5.bn_sep.bias 1.35e-4).
+    # Systematic precision loss shows up well above the floor (the pre-fix BatchNorm cancellation: 3e-4..2e-3
+    # on every late-layer parameter).
     bad = []
     for k, p in net.named_parameters():
         if g64[k] is None:  # parameter no active loss depends on (e.g. shape_distrib_scales: nllshape is disabled)
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
-        e_hip, e_cpu = rel(p.grad.cpu(), g64[k]), rel(g32[k], g64[k])
-        if e_hip > 3 * e_cpu + 5e-5:
+        e_hip, e_cpu = rel(p.grad, g64[k]), rel(g32[k], g64[k])
+        if e_hip > max(3 * e_cpu, 2.5e-4):
             bad.append((k, e_hip, e_cpu))
     assert not bad, [(k, f"{a:.1e}", f"{b:.1e}") for k, a, b in bad]
