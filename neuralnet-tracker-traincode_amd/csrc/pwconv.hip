@@ -38,9 +38,14 @@ __global__ void __launch_bounds__(kBlock) pw_gemm_k(const float* __restrict__ A0
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_PASSES = BM * BKT / 4 / kBlock;  // 4
   constexpr int B_PASSES = (BN * BKT / 4 + kBlock - 1) / kBlock;
-  __shared__ __attribute__((aligned(16))) float As[2][BM][LDP];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDP];
-  __shared__ float stat[2][BN];
+  // One LDS allocation: operand stages during the main loop, the C tile + reduction scratch afterwards.
+  constexpr int LDC = BN + 4;
+  constexpr int kStageFloats = 2 * (BM + BN) * LDP;
+  constexpr int kEpiFloats = BM * LDC + 4 * 2 * BN;
+  constexpr int kSmemFloats = kStageFloats > kEpiFloats ? kStageFloats : kEpiFloats;
+  __shared__ __attribute__((aligned(16))) float smem[kSmemFloats];
+  float (*As)[BM][LDP] = reinterpret_cast<float (*)[BM][LDP]>(smem);
+  float (*Bs)[BN][LDP] = reinterpret_cast<float (*)[BN][LDP]>(smem + 2 * BM * LDP);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -126,60 +131,68 @@ __global__ void __launch_bounds__(kBlock) pw_gemm_k(const float* __restrict__ A0
     __syncthreads();
   }
 
-  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  float s1[TN], s2[TN];
+  // ---- epilogue through LDS.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // The accumulators are parked in a [BM][BN+4] LDS image (the operand stages are dead; the loop ended
+  // with a barrier) and re-read row-wise, so that the mask operand, the BatchNorm partial sums and the
+  // output use 16-byte global accesses (32 lanes x 16 B = one 512-byte row segment) instead of 64 scalar
+  // loads + 64 scalar stores per lane with their latency exposed.
+  float* Cs = smem;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    s1[j] = 0.f;
-    s2[j] = 0.f;
-    const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
-    float esc = 0.f, emean = 0.f, ebeta = 0.f;
-    if constexpr (MODE == MODE_DGRAD) {
-      esc = bnE[TTK_BN_SCALE * Nout + col]; emean = bnE[TTK_BN_MEAN * Nout + col]; ebeta = bnE[TTK_BN_BETA * Nout + col];
-    }
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < M) {
-          float v = acc[i][j][r];
-          const size_t o = (size_t)row * Nout + col;
-          if constexpr (MODE == MODE_FWD) {
-            out[o] = v;
-            s1[j] += v;
-            s2[j] = fmaf(v, v, s2[j]);
-          } else {
-            const float yc = E0[o] - emean;
-            v = (fmaf(esc, yc, ebeta) > 0.f) ? v : 0.f;
-            out[o] = v;
-            s1[j] += v;
-            s2[j] = fmaf(v, yc, s2[j]);
-          }
-        }
+        const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int col = wn * (BN / WN) + j * 32 + (lane & 31);
+        Cs[row * LDC + col] = acc[i][j][r];
       }
+  __syncthreads();
+  constexpr int QN = BN / 4;           // column quads
+  constexpr int RG = kBlock / QN;      // row groups swept per pass
+  const int c4 = tid % QN, rg = tid / QN;
+  const int col = n0 + 4 * c4;
+  float4 esc = f4(0.f), emean = f4(0.f), ebeta = f4(0.f);
+  if constexpr (MODE == MODE_DGRAD) {
+    esc = ld4(bnE + TTK_BN_SCALE * Nout + col); emean = ld4(bnE + TTK_BN_MEAN * Nout + col); ebeta = ld4(bnE + TTK_BN_BETA * Nout + col);
+  }
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+#pragma unroll 4
+  for (int row = rg; row < BM; row += RG) {
+    const int64_t grow = m0 + row;
+    if (grow >= M) break;
+    float4 v = ld4(Cs + row * LDC + 4 * c4);
+    const size_t o = (size_t)grow * Nout + col;
+    if constexpr (MODE == MODE_FWD) {
+      st4(out + o, v);
+      s1 = add4(s1, v);
+      s2 = fma4(v, v, s2);
+    } else {
+      const float4 yc = sub4(ld4(E0 + o), emean);
+      v = mask4(v, fma4(esc, yc, ebeta));
+      st4(out + o, v);
+      s1 = add4(s1, v);
+      s2 = fma4(v, yc, s2);
     }
-    s1[j] += __shfl_xor(s1[j], 32);  // the two lane halves hold different rows of the same column
-    s2[j] += __shfl_xor(s2[j], 32);
   }
   if (part) {
-    for (int i = tid; i < 2 * BN; i += kBlock) (&stat[0][0])[i] = 0.f;
-    __syncthreads();
-    for (int w = 0; w < WM; ++w) {  // fixed order over the waves that share columns: reproducible
-      if (wm == w && lane < 32) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int cl = wn * (BN / WN) + j * 32 + lane;
-          stat[0][cl] += s1[j];
-          stat[1][cl] += s2[j];
-        }
-      }
-      __syncthreads();
+    // fold the row groups that live in one wave (lanes QN apart), then the 4 waves in fixed order
+    for (int off = QN; off < kWave; off <<= 1) {
+      s1.x += __shfl_xor(s1.x, off); s1.y += __shfl_xor(s1.y, off); s1.z += __shfl_xor(s1.z, off); s1.w += __shfl_xor(s1.w, off);
+      s2.x += __shfl_xor(s2.x, off); s2.y += __shfl_xor(s2.y, off); s2.z += __shfl_xor(s2.z, off); s2.w += __shfl_xor(s2.w, off);
     }
+    float* red = smem + BM * LDC;  // [4 waves][2][BN]
+    if (lane < QN) {  // QN <= 32
+      st4(red + (wave * 2 + 0) * BN + 4 * c4, s1);
+      st4(red + (wave * 2 + 1) * BN + 4 * c4, s2);
+    }
+    __syncthreads();
     float* prow = part + (size_t)blockIdx.y * 2 * Nout;
-    for (int i = tid; i < BN; i += kBlock) {
-      prow[n0 + i] = stat[0][i];
-      prow[Nout + n0 + i] = stat[1][i];
+    for (int i = tid; i < 2 * BN; i += kBlock) {
+      const int which = i / BN, c = i % BN;
+      float a = 0.f;
+      for (int w = 0; w < kBlock / kWave; ++w) a += red[(w * 2 + which) * BN + c];
+      prow[(size_t)which * Nout + n0 + c] = a;
     }
   }
 }
