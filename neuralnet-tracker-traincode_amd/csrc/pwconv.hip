@@ -49,8 +49,16 @@ __global__ void __launch_bounds__(kBlock) pw_gemm_k(const float* __restrict__ A0
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int64_t m0 = (int64_t)blockIdx.y * BM;
-  const int n0 = blockIdx.x * BN;
+  // XCD-aware tile order: workgroup ids are dealt round-robin over the 8 XCDs (each with its own L2), so
+  // ids b and b+8 share an L2.  Give every XCD a CONTIGUOUS range of tiles (column tiles of one M tile are
+  // adjacent), so the A rows of an M tile are fetched into one L2 once instead of once per column tile.
+  // Bijective for any grid size; placement only affects speed.
+  const unsigned G = gridDim.x, Lid = blockIdx.x, NB = Nout / BN;
+  const unsigned xq = G / 8, xr = G % 8, xcd = Lid % 8;
+  const unsigned tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + Lid / 8;
+  const unsigned bx = tile % NB, by = tile / NB;
+  const int64_t m0 = (int64_t)by * BM;
+  const int n0 = bx * BN;
   const int lrow = tid >> 3, kq = (tid & 7) * 4;
 
   f32x16 acc[TM][TN];
@@ -112,6 +120,10 @@ __global__ void __launch_bounds__(kBlock) pw_gemm_k(const float* __restrict__ A0
     const int fr = lane & 31, fk = 4 * (lane >> 5);
 #pragma unroll
     for (int ks = 0; ks < BKT / 8; ++ks) {
+      // the next tile's transform + ds_write go BETWEEN MFMA groups (after 3/4 of this tile's matrix work, so
+      // its global loads have had ~3000 cycles to land): their VALU/LDS issue hides under the running MFMAs
+      // instead of forming a matrix-idle phase in front of the barrier.
+      if (ks == BKT / 8 - 1 && kt + 1 < nk) store_tile(kt + 1, buf ^ 1);
       float4 af[TM], bf[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[i] = ld4(&As[buf][wm * (BM / WM) + i * 32 + fr][8 * ks + fk]);
@@ -127,7 +139,6 @@ __global__ void __launch_bounds__(kBlock) pw_gemm_k(const float* __restrict__ A0
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) store_tile(kt + 1, buf ^ 1);
     __syncthreads();
   }
 
@@ -187,7 +198,7 @@ __global__ void __launch_bounds__(kBlock) pw_gemm_k(const float* __restrict__ A0
       st4(red + (wave * 2 + 1) * BN + 4 * c4, s2);
     }
     __syncthreads();
-    float* prow = part + (size_t)blockIdx.y * 2 * Nout;
+    float* prow = part + (size_t)by * 2 * Nout;
     for (int i = tid; i < 2 * BN; i += kBlock) {
       const int which = i / BN, c = i % BN;
       float a = 0.f;
@@ -344,12 +355,12 @@ static void launch_gemm(const float* A0, const float* A1, const float* bnA, cons
   const dim3 blk(kBlock);
   const unsigned gm = (unsigned)ceil_div(M, BM);
   if (Nout >= 128)
-    hipLaunchKernelGGL((pw_gemm_k<128, 2, 2, MODE>), dim3(Nout / 128, gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K,
+    hipLaunchKernelGGL((pw_gemm_k<128, 2, 2, MODE>), dim3((Nout / 128) * gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K,
                        Nout);
   else if (Nout == 64)
-    hipLaunchKernelGGL((pw_gemm_k<64, 2, 2, MODE>), dim3(1, gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
+    hipLaunchKernelGGL((pw_gemm_k<64, 2, 2, MODE>), dim3(gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
   else
-    hipLaunchKernelGGL((pw_gemm_k<32, 4, 1, MODE>), dim3(1, gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
+    hipLaunchKernelGGL((pw_gemm_k<32, 4, 1, MODE>), dim3(gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
 }
 
 }  // namespace ttk
