@@ -232,6 +232,27 @@ int ttk_clip_adam(const int64_t* ptrs, const int32_t* numel, const int32_t* grou
                   float bias_correction1, float bias_correction2, float max_norm, float* partial,
                   float* out_norm, ttk_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * On-GPU affine-warp augmentation (the reference does this per sample on the CPU with OpenCV inside
+ * DataLoader workers: datatransformation/batch/geometric.py:193-231; semantic oracle for the image =
+ * tensors/image_geometric_torch.py:60-98, for the labels = tensors/affinetrafo.py:37-148).
+ *   ttk_view_roi       GeneralFocusRoi._compute_view_roi (:108-157) + torch.round().to(int32) (:205);
+ *                      view_roi[B][4] int32 is BIT-EXACT (explicitly rounded fp32 ops, round-half-even)
+ *   ttk_roi_transform  tr[B][2][3] = center_rotation(angle) @ range_remap(view_roi -> [0,N]^2) (:159-177)
+ *   ttk_affine_warp    out[B][1][N][N] = bilinear(src[B][1][Hs][Ws], tr^-1(pixel centre)) * mul + add,
+ *                      zero padding, align_corners=False; src uint8 (src_is_u8) or float32
+ *   ttk_affine_labels  in place: coord[B][3], pose[B][4] (ijkw), roi[B][4] (nullable each), pts_in ->
+ *                      pts_out [B][68][3] (68-point flip map when det < 0); with N > 0 followed by the
+ *                      pixel -> [-1,1] normalisation of normalize_batch (batch/normalization.py:20-56)
+ * ------------------------------------------------------------------------------------------- */
+int ttk_view_roi(const float* face_roi, const float* scales, const float* translations,
+                 float beyond_border_shift, int B, int* view_roi, ttk_stream_t stream);
+int ttk_roi_transform(const int* view_roi, const float* angles, int B, int N, float* tr, ttk_stream_t stream);
+int ttk_affine_warp(const void* src, int src_is_u8, int B, int Hs, int Ws, const float* tr, float* out,
+                    int N, float mul, float add, ttk_stream_t stream);
+int ttk_affine_labels(const float* tr, int B, int N, float* coord, float* pose, float* roi,
+                      const float* pts_in, float* pts_out, ttk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

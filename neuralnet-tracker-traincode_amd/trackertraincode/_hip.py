@@ -53,6 +53,10 @@ _SIGNATURES = {
     "ttk_loss_normal_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P],
     "ttk_loss_gmm_fwd": [_P, _P, _P, _P, _I, _D, _I, _P, _P],
     "ttk_loss_gmm_bwd": [_P, _P, _P, _P, _I, _D, _P, _I, _P],
+    "ttk_view_roi": [_P, _P, _P, _F, _I, _P],
+    "ttk_roi_transform": [_P, _P, _I, _I, _P],
+    "ttk_affine_warp": [_P, _I, _I, _I, _I, _P, _P, _I, _F, _F],
+    "ttk_affine_labels": [_P, _I, _I, _P, _P, _P, _P, _P],
     "ttk_clip_adam": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _F, _F, _F, _F, _F, _P, _P],
 }
 
