@@ -1,7 +1,6 @@
 """Data-parallel gradient exchange on CPU: 2 processes over gloo (the N>1 path of bench.py uses the same
 GradAllReduce over RCCL)."""
 import os
-import socket
 import sys
 
 import pytest
@@ -10,18 +9,10 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
-
-
-def _worker(rank, world, port, pkg, q):
+def _worker(rank, world, rdv_file, pkg, q):
     sys.path.insert(0, pkg)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # file rendezvous: no TCP port to race for (the container hostname may not resolve either)
+    dist.init_process_group("gloo", init_method=f"file://{rdv_file}", rank=rank, world_size=world)
     from trackertraincode.parallel import GradAllReduce, broadcast_module_state, shard_range
 
     torch.manual_seed(rank)
@@ -42,12 +33,12 @@ def _worker(rank, world, port, pkg, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_average_and_broadcast():
+def test_two_rank_gradient_average_and_broadcast(tmp_path):
     pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neuralnet-tracker-traincode_amd")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, pkg, q)) for r in range(2)]
+    rdv = str(tmp_path / "rendezvous")
+    procs = [ctx.Process(target=_worker, args=(r, 2, rdv, pkg, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
