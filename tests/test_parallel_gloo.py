@@ -29,7 +29,8 @@ def _worker(rank, world, rdv_file, pkg, q):
     for p, gr in zip(params[:2], grads[:2]):
         p.grad = gr.clone()
     red.finish(params)
-    q.put((rank, [p.detach().clone() for p in params], [p.grad.clone() for p in params], shard_range(10, rank, world)))
+    # numpy, not tensors: torch shares tensors through /dev/shm handles that die with this process
+    q.put((rank, [p.detach().numpy().copy() for p in params], [p.grad.numpy().copy() for p in params], shard_range(10, rank, world)))
     dist.destroy_process_group()
 
 
@@ -46,6 +47,7 @@ def test_two_rank_gradient_average_and_broadcast(tmp_path):
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, w0, g0, s0), (_, w1, g1, s1) = res
+    w0, w1, g0, g1 = ([torch.from_numpy(a) for a in x] for x in (w0, w1, g0, g1))
     for a, b in zip(w0, w1):
         assert torch.equal(a, b)  # broadcast from rank 0
     # expected average: regenerate both ranks' gradients in order
