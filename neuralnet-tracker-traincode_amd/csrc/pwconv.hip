@@ -27,21 +27,24 @@ constexpr int LDP = BKT + 4;          // padded LDS row (floats)
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 
 template <int BN, int WM, int WN, int MODE>
-__global__ void __launch_bounds__(kBlock) pw_gemm_k(const float* __restrict__ A0, const float* __restrict__ A1,
+__global__ void __launch_bounds__(WM * WN * 64) pw_gemm_k(const float* __restrict__ A0, const float* __restrict__ A1,
                                                      const float* __restrict__ bnA, const float* __restrict__ Bm,
                                                      float* __restrict__ out, const float* __restrict__ E0,
                                                      const float* __restrict__ bnE, float* __restrict__ part, int64_t M,
                                                      int K, int Nout) {
   // bnA: BatchNorm block [TTK_BN_ROWS][K] of the layer that produced the A operand (contraction channels);
   // bnE (data-gradient mode): block [TTK_BN_ROWS][Nout] of the layer whose ReLU masks the output.
-  static_assert(WM * WN == 4, "4 waves");
+  constexpr int NT = WM * WN * 64;  // threads: 4 or 8 waves
+  static_assert(NT == 256 || NT == 512, "4 or 8 waves");
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int A_PASSES = BM * BKT / 4 / kBlock;  // 4
-  constexpr int B_PASSES = (BN * BKT / 4 + kBlock - 1) / kBlock;
+  static_assert(TM >= 1 && TN >= 1, "wave tile");
+  constexpr int ROWS_PER_PASS = NT / 8;  // 8 lanes x 16 B cover one 32-float row of a stage
+  constexpr int A_PASSES = BM / ROWS_PER_PASS;
+  constexpr int B_PASSES = (BN + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
   // One LDS allocation: operand stages during the main loop, the C tile + reduction scratch afterwards.
   constexpr int LDC = BN + 4;
   constexpr int kStageFloats = 2 * (BM + BN) * LDP;
-  constexpr int kEpiFloats = BM * LDC + 4 * 2 * BN;
+  constexpr int kEpiFloats = BM * LDC + (NT / 64) * 2 * BN;
   constexpr int kSmemFloats = kStageFloats > kEpiFloats ? kStageFloats : kEpiFloats;
   __shared__ __attribute__((aligned(16))) float smem[kSmemFloats];
   float (*As)[BM][LDP] = reinterpret_cast<float (*)[BM][LDP]>(smem);
@@ -76,13 +79,13 @@ __global__ void __launch_bounds__(kBlock) pw_gemm_k(const float* __restrict__ A0
     const int k0 = kt * BKT + kq;
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
-      const int64_t row = m0 + p * 32 + lrow;
+      const int64_t row = m0 + p * ROWS_PER_PASS + lrow;
       ra0[p] = (row < M) ? ld4(A0 + row * K + k0) : f4(0.f);
       if constexpr (MODE == MODE_DGRAD) ra1[p] = (row < M) ? ld4(A1 + row * K + k0) : f4(0.f);
     }
 #pragma unroll
     for (int p = 0; p < B_PASSES; ++p) {
-      const int row = p * 32 + lrow;
+      const int row = p * ROWS_PER_PASS + lrow;
       if (row < BN) rb[p] = ld4(Bm + (size_t)(n0 + row) * K + k0);
     }
   };
@@ -97,16 +100,16 @@ __global__ void __launch_bounds__(kBlock) pw_gemm_k(const float* __restrict__ A0
     }
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
-      const int64_t row = m0 + p * 32 + lrow;
+      const int64_t row = m0 + p * ROWS_PER_PASS + lrow;
       float4 v;
       if constexpr (MODE == MODE_FWD) v = relu4(fma4(q0, sub4(ra0[p], q1), q2));
       else v = fma4(q0, sub4(ra0[p], q1), mul4(q2, sub4(ra1[p], q3)));
       if (row >= M) v = f4(0.f);
-      st4(&As[buf][p * 32 + lrow][kq], v);
+      st4(&As[buf][p * ROWS_PER_PASS + lrow][kq], v);
     }
 #pragma unroll
     for (int p = 0; p < B_PASSES; ++p) {
-      const int row = p * 32 + lrow;
+      const int row = p * ROWS_PER_PASS + lrow;
       if (row < BN) st4(&Bs[buf][row][kq], rb[p]);
     }
   };
@@ -160,7 +163,7 @@ __global__ void __launch_bounds__(kBlock) pw_gemm_k(const float* __restrict__ A0
       }
   __syncthreads();
   constexpr int QN = BN / 4;           // column quads
-  constexpr int RG = kBlock / QN;      // row groups swept per pass
+  constexpr int RG = NT / QN;          // row groups swept per pass
   const int c4 = tid % QN, rg = tid / QN;
   const int col = n0 + 4 * c4;
   float4 esc = f4(0.f), emean = f4(0.f), ebeta = f4(0.f);
@@ -199,10 +202,10 @@ __global__ void __launch_bounds__(kBlock) pw_gemm_k(const float* __restrict__ A0
     }
     __syncthreads();
     float* prow = part + (size_t)by * 2 * Nout;
-    for (int i = tid; i < 2 * BN; i += kBlock) {
+    for (int i = tid; i < 2 * BN; i += NT) {
       const int which = i / BN, c = i % BN;
       float a = 0.f;
-      for (int w = 0; w < kBlock / kWave; ++w) a += red[(w * 2 + which) * BN + c];
+      for (int w = 0; w < NT / kWave; ++w) a += red[(w * 2 + which) * BN + c];
       prow[(size_t)which * Nout + n0 + c] = a;
     }
   }
