@@ -8,6 +8,29 @@
 
 namespace ttk {
 
+// The reductions over a sample's elements (68x3 landmarks, 50 shape parameters, ...) run one WAVE per
+// sample: lanes stride over the elements (coalesced) and a shuffle tree folds them - a single thread looping
+// over 204 strided loads took 140 us for 512 samples.
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, off);
+    hi = __shfl_xor(hi, off);
+    v += __hiloint2double(hi, lo);
+  }
+  return v;
+}
+#define TTK_WAVE_SAMPLE(n)                                            \
+  const int lane = threadIdx.x & 63;                                  \
+  const int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  \
+  if (s >= (n)) return;
+
 #define TTK_SAMPLE_INDEX(n)                                         \
   const int s = blockIdx.x * blockDim.x + threadIdx.x;              \
   if (s >= (n)) return;
@@ -30,13 +53,14 @@ __global__ void loss_quatreg_bwd_k(const float* q, const float* gv, int n, float
 }
 // mean_d (p - t)^2
 __global__ void loss_mse_rows_fwd_k(const float* p, const float* t, int n, int D, float* v) {
-  TTK_SAMPLE_INDEX(n);
+  TTK_WAVE_SAMPLE(n);
   float acc = 0.f;
-  for (int d = 0; d < D; ++d) {
+  for (int d = lane; d < D; d += 64) {
     const float e = p[(size_t)s * D + d] - t[(size_t)s * D + d];
     acc = fmaf(e, e, acc);
   }
-  v[s] = acc / (float)D;
+  acc = wave_sum_f(acc);
+  if (lane == 0) v[s] = acc / (float)D;
 }
 __global__ void loss_mse_rows_bwd_k(const float* p, const float* t, const float* gv, int n, int D, float* gp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,9 +69,9 @@ __global__ void loss_mse_rows_bwd_k(const float* p, const float* t, const float*
 }
 // mean_p( w_p * sum_{d<dim} (p - t)^2 )
 __global__ void loss_points_fwd_k(const float* p, const float* t, int n, int dim, float chin, float eye, float* v) {
-  TTK_SAMPLE_INDEX(n);
+  TTK_WAVE_SAMPLE(n);
   float acc = 0.f;
-  for (int k = 0; k < 68; ++k) {
+  for (int k = lane; k < 68; k += 64) {
     float e2 = 0.f;
     for (int d = 0; d < dim; ++d) {
       const float e = p[((size_t)s * 68 + k) * 3 + d] - t[((size_t)s * 68 + k) * 3 + d];
@@ -55,7 +79,8 @@ __global__ void loss_points_fwd_k(const float* p, const float* t, int n, int dim
     }
     acc = fmaf(lm::point_weight(k, chin, eye), e2, acc);
   }
-  v[s] = acc / 68.f;
+  acc = wave_sum_f(acc);
+  if (lane == 0) v[s] = acc / 68.f;
 }
 __global__ void loss_points_bwd_k(const float* p, const float* t, const float* gv, int n, int dim, float chin, float eye,
                                   float* gp) {
@@ -84,10 +109,10 @@ __global__ void loss_nllcoord_bwd_k(const float* c, const float* t, const float*
 // only the first `dim` of every 3 used when rows3 != 0 (points), else plain [n][per].
 __global__ void loss_normal_fwd_k(const float* mu, const float* sg, const float* x, int n, int per, int points, int dim,
                                   float chin, float eye, float* v) {
-  TTK_SAMPLE_INDEX(n);
+  TTK_WAVE_SAMPLE(n);
   float acc = 0.f;
   if (points) {
-    for (int k = 0; k < 68; ++k) {
+    for (int k = lane; k < 68; k += 64) {
       float a = 0.f;
       for (int d = 0; d < dim; ++d) {
         const size_t o = ((size_t)s * 68 + k) * 3 + d;
@@ -95,13 +120,15 @@ __global__ void loss_normal_fwd_k(const float* mu, const float* sg, const float*
       }
       acc = fmaf(lm::point_weight(k, chin, eye), a, acc);
     }
-    v[s] = acc / (68.f * (float)dim);
+    acc = wave_sum_f(acc);
+    if (lane == 0) v[s] = acc / (68.f * (float)dim);
   } else {
-    for (int d = 0; d < per; ++d) {
+    for (int d = lane; d < per; d += 64) {
       const size_t o = (size_t)s * per + d;
       acc += lm::normal_nll(mu[o], sg[o], x[o]);
     }
-    v[s] = acc / (float)per;
+    acc = wave_sum_f(acc);
+    if (lane == 0) v[s] = acc / (float)per;
   }
 }
 __global__ void loss_normal_bwd_k(const float* mu, const float* sg, const float* x, const float* gv, int n, int per,
@@ -124,8 +151,24 @@ __global__ void loss_normal_bwd_k(const float* mu, const float* sg, const float*
 }
 __global__ void loss_gmm_fwd_k(const float* x, const double* ck, const double* mu, const double* sinv, int K, double fudge,
                                int n, float* v, double* post) {
-  TTK_SAMPLE_INDEX(n);
-  v[s] = (float)lm::gmm_nll(x + 50 * s, ck, mu, sinv, K, fudge, post + (size_t)K * s);
+  TTK_WAVE_SAMPLE(n);
+  double a[16];
+  const double xd = lane < 50 ? (double)x[50 * s + lane] : 0.0;
+  double mx = -1.0e300;
+  for (int k = 0; k < K; ++k) {
+    double z = 0.0;
+    if (lane < 50) {
+      z = (xd - mu[k * 50 + lane]) * sinv[k * 50 + lane];
+      z *= z;
+    }
+    a[k] = ck[k] - 0.5 * wave_sum_d(z);  // same value in every lane
+    mx = a[k] > mx ? a[k] : mx;
+  }
+  double sum = 0.0;
+  for (int k = 0; k < K; ++k) sum += exp(a[k] - mx);
+  for (int k = 0; k < K; ++k)  // static index: a[] stays in registers
+    if (lane == k) post[(size_t)K * s + k] = exp(a[k] - mx) / sum;
+  if (lane == 0) v[s] = (float)(-(mx + log(sum)) * fudge);
 }
 // d/dx_d = fudge * sum_k post_k (x_d - mu_kd) sinv_kd^2
 __global__ void loss_gmm_bwd_k(const float* x, const double* mu, const double* sinv, const double* post, int K, double fudge,
@@ -171,7 +214,7 @@ int ttk_loss_quatreg_bwd(const float* q, const float* gv, int n, float* gq, ttk_
 }
 int ttk_loss_mse_rows_fwd(const float* p, const float* t, int n, int D, float* v, ttk_stream_t stream) {
   TTK_REQUIRE(p && t && v && n > 0 && D > 0, "loss_mse_rows_fwd: bad arguments");
-  hipLaunchKernelGGL(loss_mse_rows_fwd_k, TTK_GRID(n), p, t, n, D, v);
+  hipLaunchKernelGGL(loss_mse_rows_fwd_k, TTK_GRID(n * 64), p, t, n, D, v);
   TTK_LAUNCH_CHECK("loss_mse_rows_fwd");
 }
 int ttk_loss_mse_rows_bwd(const float* p, const float* t, const float* gv, int n, int D, float* gp, ttk_stream_t stream) {
@@ -181,7 +224,7 @@ int ttk_loss_mse_rows_bwd(const float* p, const float* t, const float* gv, int n
 }
 int ttk_loss_points_fwd(const float* p, const float* t, int n, int dim, float chin, float eye, float* v, ttk_stream_t stream) {
   TTK_REQUIRE(p && t && v && n > 0 && (dim == 2 || dim == 3), "loss_points_fwd: bad arguments");
-  hipLaunchKernelGGL(loss_points_fwd_k, TTK_GRID(n), p, t, n, dim, chin, eye, v);
+  hipLaunchKernelGGL(loss_points_fwd_k, TTK_GRID(n * 64), p, t, n, dim, chin, eye, v);
   TTK_LAUNCH_CHECK("loss_points_fwd");
 }
 int ttk_loss_points_bwd(const float* p, const float* t, const float* gv, int n, int dim, float chin, float eye, float* gp,
@@ -215,7 +258,7 @@ int ttk_loss_nllcoord_bwd(const float* c, const float* t, const float* L, const 
 int ttk_loss_normal_fwd(const float* mu, const float* sigma, const float* x, int n, int per, int points, int dim, float chin,
                         float eye, float* v, ttk_stream_t stream) {
   TTK_REQUIRE(mu && sigma && x && v && n > 0 && (points ? (dim == 2 || dim == 3) : per > 0), "loss_normal_fwd: bad arguments");
-  hipLaunchKernelGGL(loss_normal_fwd_k, TTK_GRID(n), mu, sigma, x, n, per, points, dim, chin, eye, v);
+  hipLaunchKernelGGL(loss_normal_fwd_k, TTK_GRID(n * 64), mu, sigma, x, n, per, points, dim, chin, eye, v);
   TTK_LAUNCH_CHECK("loss_normal_fwd");
 }
 int ttk_loss_normal_bwd(const float* mu, const float* sigma, const float* x, const float* gv, int n, int per, int points,
@@ -228,7 +271,7 @@ int ttk_loss_normal_bwd(const float* mu, const float* sigma, const float* x, con
 int ttk_loss_gmm_fwd(const float* x, const double* ck, const double* mu, const double* sinv, int K, double fudge, int n,
                      float* v, double* post, ttk_stream_t stream) {
   TTK_REQUIRE(x && ck && mu && sinv && v && post && n > 0 && K > 0 && K <= 16, "loss_gmm_fwd: bad arguments");
-  hipLaunchKernelGGL(loss_gmm_fwd_k, TTK_GRID(n), x, ck, mu, sinv, K, fudge, n, v, post);
+  hipLaunchKernelGGL(loss_gmm_fwd_k, TTK_GRID(n * 64), x, ck, mu, sinv, K, fudge, n, v, post);
   TTK_LAUNCH_CHECK("loss_gmm_fwd");
 }
 int ttk_loss_gmm_bwd(const float* x, const double* mu, const double* sinv, const double* post, int K, double fudge,
