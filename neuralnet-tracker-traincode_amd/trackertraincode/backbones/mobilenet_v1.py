@@ -19,6 +19,7 @@ scripts/export_model.py), through plain torch ops.
 from __future__ import annotations
 
 import math
+import os
 from typing import NamedTuple
 
 import torch
@@ -176,6 +177,18 @@ def _forward_impl(x, params, buffers, momentum, eps, training):
 grad_ready_hook = None
 
 
+# weight-gradient GEMMs on a second stream (TTK_WGRAD_STREAM=0 serialises everything on the caller's stream)
+_USE_WGRAD_STREAM = os.environ.get("TTK_WGRAD_STREAM", "1") != "0"
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 def _backward_impl(ctx: _Ctx, gfeat, params):
     L = _hip.lib()
     p = _hip.ptr
@@ -192,6 +205,10 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         L.call("ttk_bn_bwd_finalize", p(part), rows, Cc, count, p(params[gi]), p(stage.bn), p(dgamma), p(dbeta), 0)
         grads[gi], grads[gi + 1] = dgamma, dbeta
 
+    main = torch.cuda.current_stream(gfeat.device)
+    side = _side_stream(gfeat.device) if _USE_WGRAD_STREAM else None
+    keep = []
+
     g = torch.empty_like(last.y)
     L.call("ttk_avgpool_bwd", p(gfeat), p(last.y), p(last.bn), p(last.skip), p(g), p(part), B, ctx.HW, C)
     bwd_finalize(last, L.partial_rows_elementwise(B * ctx.HW * (C // 4)), B * ctx.HW, len(params) - 2)
@@ -203,9 +220,22 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         st_prev, st_dw, st_pw = ctx.stages[2 * k], ctx.stages[2 * k + 1], ctx.stages[2 * k + 2]
         a_in = ctx.a_in[k]
         M = B * ho * wo
-        # -- pointwise: weight gradient, then data gradient (+ bn_dw backward sums)
+        # -- pointwise: weight gradient, then data gradient (+ bn_dw backward sums).  The weight gradient has no
+        # consumer inside backward, so it runs on a second HIP stream next to the data-gradient chain: its
+        # tail (too few tiles left for 256 CUs) and the HBM-bound depthwise kernels fill each other's gaps.
         dW = torch.zeros_like(w_pw)
-        L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW), M, cin, cout)
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record(main)  # g, bn_pw backward constants and the zeroed dW are ready
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW), M, cin, cout)
+                if grad_ready_hook is not None:
+                    done = torch.cuda.Event()
+                    done.record(side)
+            keep.append(g)  # main must not recycle g's memory while the side stream still reads it
+        else:
+            L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW), M, cin, cout)
         grads[pi + 3] = dW
         wt = torch.empty((cin, cout), dtype=torch.float32, device=g.device)
         L.call("ttk_transpose", p(w_pw), p(wt), cout, cin)
@@ -222,6 +252,8 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         bwd_finalize(st_prev, L.partial_rows_dwconv(B, h, w_, cin, stride, True), B * h * w_, pi - 2 if k > 0 else 1)
         g = g_prev
         if grad_ready_hook is not None:  # this block's conv + bn_dw gradients and its own bn_sep gradients are final
+            if side is not None:
+                main.wait_event(done)
             grad_ready_hook([(params[i], grads[i]) for i in range(pi, pi + 6)])
     st0 = ctx.stages[0]
     dW1 = torch.empty_like(params[0])
@@ -230,6 +262,9 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
     grads[0] = dW1
     if grad_ready_hook is not None:
         grad_ready_hook([(params[i], grads[i]) for i in range(3)])
+    if side is not None:
+        main.wait_stream(side)  # join: everything after backward (clip+Adam) sees the weight gradients
+        keep.clear()
     return grads
 
 
