@@ -15,6 +15,8 @@
 // 32-63 hold k=8s+4..8s+7, so the j-th register of both operands forms the k-pair {8s+j, 8s+4+j} of
 // one 32x32x2 MFMA - the sum over k is order-free, so no shuffling is needed.
 #include "ttk_common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace ttk {
 
@@ -352,9 +354,21 @@ static bool pw_shape_ok(int64_t M, int Cin, int Cout) {
   return M > 0 && p2(Cin) && p2(Cout);
 }
 
+// pwconv_split.hip: the compute-bound shapes on the bf16 pipe with exact 3-way operand splits
+template <int MODE>
+bool launch_split_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
+                       const float* bnE, float* part, int64_t M, int K, int Nout, hipStream_t st);
+
+static bool use_split_gemm() {
+  // TTK_GEMM=f32mfma keeps every pointwise conv on v_mfma_f32_32x32x2_f32 (A/B timing and numerics comparisons)
+  static const bool on = [] { const char* e = getenv("TTK_GEMM"); return !(e && strcmp(e, "f32mfma") == 0); }();
+  return on;
+}
+
 template <int MODE>
 static void launch_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
                         const float* bnE, float* part, int64_t M, int K, int Nout, hipStream_t st) {
+  if (use_split_gemm() && launch_split_gemm<MODE>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, st)) return;
   const dim3 blk(kBlock);
   const unsigned gm = (unsigned)ceil_div(M, BM);
   if (Nout >= 128)

@@ -1,0 +1,318 @@
+// Pointwise 1x1 convolutions of the compute-bound layers (Cin >= 128, Cout >= 256 and the mirrored data
+// gradients) as fp32 GEMMs on the bf16 matrix pipe.  Reference: DepthWiseBlock.conv_sep + bn_sep,
+// backbones/mobilenet_v1.py:67-68,82-84.
+//
+// Arithmetic.  Every fp32 operand value x is cut EXACTLY into three bf16 pieces, x = h + m + l (each piece
+// holds 8 significant bits: h = x truncated to bf16, m = (x-h) truncated, l = x-h-m, which then has at most
+// 8 significant bits left).  A product a*b is the sum of nine piece products, each exact in fp32; the six
+// of magnitude >= 2^-16 of the leading one (hl lh mm hm mh hh) are accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16, the three below 2^-24 (ml lm ll) are dropped - the same order as the rounding
+// of one fp32 fma.  Measured against an fp64 product the result is as close as an fp32 fmaf chain
+// (tests/test_backbone_gpu.py, tools/exp/split_gemm_bench.hip); the bf16 pipe runs 16x the fp32 MFMA rate,
+// so six products are 2.7x faster than v_mfma_f32_32x32x2_f32.
+//
+// Structure (one workgroup = 8 waves = one CU, block tile BM x BN = 128x256 or 256x128, k32 per step):
+//   waves 4-7  PRODUCE: 16-byte global loads of both fp32 operands (128 B per row), the BatchNorm form of the
+//              A operand (forward: relu(scale*(y-mean)+beta); data gradient: ga*(g-gmean)+gb*(y-mean)), the
+//              3-way split (4 VALU + 1.5 v_perm per element) and ds_write_b64 into the LDS ring;
+//   waves 0-3  CONSUME: ds_read_b128 fragments + MFMAs, wave tile (BM/2)x(BN/2), fragments of the streamed
+//              operand double-buffered in registers so LDS latency hides under 12 MFMAs.
+// The hardware places waves 0-3 and 4-7 of a workgroup on the four SIMDs in turn, so each SIMD runs one
+// producer next to one consumer: VALU/LDS-write work and matrix work overlap by construction instead of
+// alternating in lockstep phases.  One s_barrier per k32.
+// LDS ring: 2 super-stages x 2 k16 stages; a stage holds 3 piece planes per operand as unpadded 32-byte rows
+// (16 bf16), 16-byte chunk index XOR ((row>>3)&1): the 16 rows of a ds_read_b128 lane group fall on 16
+// distinct 4-bank groups.  Stage stride 36864+64 B so the two k16 halves of a producer wave's ds_write_b64
+// use different banks.
+#include "ttk_common.h"
+
+namespace ttk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+enum { SMODE_FWD = 0, SMODE_DGRAD = 1 };
+
+constexpr int kStageBytes = 96 * (128 + 256);   // 3 planes x 32 B x (BM + BN) rows
+constexpr int kStageStride = kStageBytes + 64;
+constexpr int kRingBytes = 4 * kStageStride;
+
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 3) & 1)) << 4); }
+
+__device__ __forceinline__ uint32_t pack_top16(float lo, float hi) {  // bf16(trunc lo) | bf16(trunc hi) << 16
+  return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+#define TTK_RESID(x) ((x) - __uint_as_float(__float_as_uint(x) & 0xffff0000u))
+// exact 3-way split of 4 consecutive-k values; writes the three 8-byte pieces at `dst` + piece*plane
+__device__ __forceinline__ void split_store(f32x4 v, unsigned char* dst, int plane) {
+  const float a1 = TTK_RESID(v.x), b1 = TTK_RESID(v.y), c1 = TTK_RESID(v.z), d1 = TTK_RESID(v.w);
+  const float a2 = TTK_RESID(a1), b2 = TTK_RESID(b1), c2 = TTK_RESID(c1), d2 = TTK_RESID(d1);
+  *reinterpret_cast<uint2*>(dst) = make_uint2(pack_top16(v.x, v.y), pack_top16(v.z, v.w));
+  *reinterpret_cast<uint2*>(dst + plane) = make_uint2(pack_top16(a1, b1), pack_top16(c1, d1));
+  *reinterpret_cast<uint2*>(dst + 2 * plane) = make_uint2(pack_top16(a2, b2), pack_top16(c2, d2));
+}
+
+template <int BM, int BN, int MODE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* __restrict__ bnA,
+           const float* __restrict__ Bm, float* __restrict__ out, const float* __restrict__ E0,
+           const float* __restrict__ bnE, float* __restrict__ part, int64_t M, int K, int Nout) {
+  static_assert(BM + BN == 384 && (BM == 128 || BM == 256), "128x256 or 256x128");
+  constexpr int APL = BM * 32, BPL = BN * 32;  // bytes of one piece plane
+  constexpr int TM = BM / 64, TN = BN / 64;    // 32x32 tiles of a consumer wave (wave tile (BM/2) x (BN/2))
+  constexpr bool HOLD_A = TM <= TN;            // hold the smaller fragment set, stream the other
+  constexpr int TH = HOLD_A ? TM : TN, TS = HOLD_A ? TN : TM;
+  constexpr int LDC = BN + 4;
+  constexpr int QN = BN / 4, RG = 512 / QN, HALVES = BM / 128, RGH = RG / HALVES;
+  constexpr int kEpiBytes = BM * LDC * 4 + RG * 2 * BN * 4;
+  constexpr int kSmemBytes = kRingBytes > kEpiBytes ? kRingBytes : kEpiBytes;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kSmemBytes];
+
+  const int tid = threadIdx.x;
+  // XCD-aware tile order (see pwconv.hip): every XCD gets a contiguous range of tiles.
+  const unsigned G = gridDim.x, Lid = blockIdx.x, NB = Nout / BN;
+  const unsigned xq = G / 8, xr = G % 8, xcd = Lid % 8;
+  const unsigned tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + Lid / 8;
+  const unsigned bx = tile % NB, by = tile / NB;
+  const int64_t m0 = (int64_t)by * BM;
+  const int n0 = bx * BN;
+  const int nks = K / 32;
+  const bool producer = __builtin_amdgcn_readfirstlane(tid) >= 256;
+
+  if (producer) {
+    // ------------------------------------------------------------------ producer waves
+    const int pt = tid - 256;
+    const int row0 = pt >> 3, kq8 = pt & 7;  // 32 rows per pass; 8 lanes x 16 B = one 128-byte row segment
+    const int sub = kq8 >> 2, chunk = (kq8 >> 1) & 1, o8 = (kq8 & 1) * 8;
+    constexpr int AP = BM / 32, BP = BN / 32;
+    f32x4 ra0[AP], ra1[MODE == SMODE_DGRAD ? AP : 1], rb[BP], q0, q1, q2, q3;
+    int64_t arow[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      int64_t row = m0 + row0 + 32 * i;
+      arow[i] = (row < M ? row : M - 1) * (int64_t)K + kq8 * 4;  // clamp: rows past M are computed but never stored
+    }
+    const float* bp = Bm + (int64_t)(n0 + row0) * K + kq8 * 4;
+    const float* cp = bnA + kq8 * 4;
+    unsigned char* wbase = lds + sub * kStageStride + o8;
+
+    auto load_a = [&](int ks) {
+      const int k0 = ks * 32;
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        ra0[i] = *reinterpret_cast<const f32x4*>(A0 + arow[i] + k0);
+        if constexpr (MODE == SMODE_DGRAD) ra1[i] = *reinterpret_cast<const f32x4*>(A1 + arow[i] + k0);
+      }
+      if constexpr (MODE == SMODE_FWD) {
+        q0 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_SCALE * K + k0);
+        q1 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * K + k0);
+        q2 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_BETA * K + k0);
+      } else {
+        q0 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GA * K + k0);
+        q1 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GMEAN * K + k0);
+        q2 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GB * K + k0);
+        q3 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * K + k0);
+      }
+    };
+    auto load_b = [&](int ks) {
+#pragma unroll
+      for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bp + (int64_t)(32 * i) * K + ks * 32);
+    };
+    auto store_a = [&](int ks) {
+      unsigned char* S = wbase + (ks & 1) * 2 * kStageStride;
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        f32x4 v;
+        if constexpr (MODE == SMODE_FWD) {
+          v = q0 * (ra0[i] - q1) + q2;
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        } else {
+          v = q0 * (ra0[i] - q1) + q2 * (ra1[i] - q3);
+        }
+        split_store(v, S + swz_off(row0 + 32 * i, chunk), APL);
+      }
+    };
+    auto store_b = [&](int ks) {
+      unsigned char* S = wbase + (ks & 1) * 2 * kStageStride + 3 * APL;
+#pragma unroll
+      for (int i = 0; i < BP; ++i) split_store(rb[i], S + swz_off(row0 + 32 * i, chunk), BPL);
+    };
+
+    load_a(0);
+    load_b(0);
+    store_a(0);
+    if (nks > 1) load_a(1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_b(0);
+    if (nks > 1) load_b(1);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // super-stage 0 is in LDS
+    for (int it = 0; it < nks; ++it) {
+      // fill super-stage it+1 while the consumers multiply super-stage it.  The A operand (HBM, long latency) is
+      // converted first and its next loads issued at once; the B operand (weights, L2-resident) follows.
+      if (it + 1 < nks) {
+        store_a(it + 1);
+        if (it + 2 < nks) load_a(it + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        store_b(it + 1);
+        if (it + 2 < nks) load_b(it + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+  } else {
+    // ------------------------------------------------------------------ consumer waves
+    const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // byte offsets of this lane's fragments inside a stage
+    int hold_off[TH], strm_off[TS];
+#pragma unroll
+    for (int x = 0; x < TH; ++x)
+      hold_off[x] = HOLD_A ? swz_off(wm * (BM / 2) + x * 32 + r, h) : 3 * APL + swz_off(wn * (BN / 2) + x * 32 + r, h);
+#pragma unroll
+    for (int x = 0; x < TS; ++x)
+      strm_off[x] = HOLD_A ? 3 * APL + swz_off(wn * (BN / 2) + x * 32 + r, h) : swz_off(wm * (BM / 2) + x * 32 + r, h);
+    constexpr int HPL = HOLD_A ? APL : BPL, SPL = HOLD_A ? BPL : APL;
+
+    bf16x8 hold[TH][3], hold_n[TH][3], strm[2][3];
+    __syncthreads();  // super-stage 0 is in LDS
+    for (int it = 0; it < nks; ++it) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const unsigned char* S = lds + ((it & 1) * 2 + sub) * kStageStride;
+        if (sub == 0) {  // first stage after the barrier: nothing could be prefetched across it
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int x = 0; x < TH; ++x) hold[x][p] = *reinterpret_cast<const bf16x8*>(S + p * HPL + hold_off[x]);
+            strm[0][p] = *reinterpret_cast<const bf16x8*>(S + p * SPL + strm_off[0]);
+          }
+        }
+#pragma unroll
+        for (int x = 0; x < TS; ++x) {
+          const int cur = (sub * TS + x) & 1;
+          // prefetch the fragments of the next 12 (or 24) MFMAs
+          if (x + 1 < TS) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) strm[cur ^ 1][p] = *reinterpret_cast<const bf16x8*>(S + p * SPL + strm_off[x + 1]);
+          } else if (sub == 0) {
+            const unsigned char* S2 = S + kStageStride;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+              for (int y = 0; y < TH; ++y) hold_n[y][p] = *reinterpret_cast<const bf16x8*>(S2 + p * HPL + hold_off[y]);
+              strm[cur ^ 1][p] = *reinterpret_cast<const bf16x8*>(S2 + p * SPL + strm_off[0]);
+            }
+          }
+          // six piece products, smallest first; (pa, pb) index the A and B pieces (0 = h, 1 = m, 2 = l)
+#define TTK_PROD(pa, pb)                                                                                         \
+  _Pragma("unroll") for (int y = 0; y < TH; ++y) {                                                               \
+    if constexpr (HOLD_A)                                                                                        \
+      acc[y][x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hold[y][pa], strm[cur][pb], acc[y][x], 0, 0, 0);       \
+    else                                                                                                         \
+      acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(strm[cur][pa], hold[y][pb], acc[x][y], 0, 0, 0);       \
+  }
+          TTK_PROD(0, 2) TTK_PROD(2, 0) TTK_PROD(1, 1) TTK_PROD(0, 1) TTK_PROD(1, 0) TTK_PROD(0, 0)
+#undef TTK_PROD
+        }
+        if (sub == 0) {
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int y = 0; y < TH; ++y) hold[y][p] = hold_n[y][p];
+        }
+      }
+      __syncthreads();
+    }
+    // ---- accumulators -> LDS image [BM][LDC] (the ring is dead: the loop ended with a barrier)
+    float* Cs = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int col = wn * (BN / 2) + j * 32 + r;
+          Cs[row * LDC + col] = acc[i][j][e];
+        }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ epilogue, all 8 waves
+  // Row-wise pass over the C image: 16-byte stores (a wave writes 1 KB row segments), the ReLU mask of the data
+  // gradient, and the BatchNorm partial sums of this tile's 128-row halves.
+  const float* Cs = reinterpret_cast<const float*>(lds);
+  float* red = reinterpret_cast<float*>(lds + BM * LDC * 4);  // [RG][2][BN]
+  const int c4 = tid % QN, rg = tid / QN, half = rg / RGH, rr = rg % RGH;
+  const int col = n0 + 4 * c4;
+  float4 esc = f4(0.f), emean = f4(0.f), ebeta = f4(0.f);
+  if constexpr (MODE == SMODE_DGRAD) {
+    esc = ld4(bnE + TTK_BN_SCALE * Nout + col); emean = ld4(bnE + TTK_BN_MEAN * Nout + col); ebeta = ld4(bnE + TTK_BN_BETA * Nout + col);
+  }
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+#pragma unroll 4
+  for (int i = 0; i < 128 / RGH; ++i) {
+    const int row = half * 128 + rr + RGH * i;
+    const int64_t grow = m0 + row;
+    if (grow >= M) break;
+    float4 v = ld4(Cs + row * LDC + 4 * c4);
+    const size_t o = (size_t)grow * Nout + col;
+    if constexpr (MODE == SMODE_FWD) {
+      st4(out + o, v);
+      s1 = add4(s1, v);
+      s2 = fma4(v, v, s2);
+    } else {
+      const float4 yc = sub4(ld4(E0 + o), emean);
+      v = mask4(v, fma4(esc, yc, ebeta));
+      st4(out + o, v);
+      s1 = add4(s1, v);
+      s2 = fma4(v, yc, s2);
+    }
+  }
+  if (part) {
+    st4(red + (rg * 2 + 0) * BN + 4 * c4, s1);
+    st4(red + (rg * 2 + 1) * BN + 4 * c4, s2);
+    __syncthreads();
+    for (int i = tid; i < HALVES * 2 * BN; i += 512) {
+      const int hf = i / (2 * BN), which = (i / BN) & 1, c = i % BN;
+      float a = 0.f;
+      for (int q = 0; q < RGH; ++q) a += red[((hf * RGH + q) * 2 + which) * BN + c];  // fixed order: reproducible
+      const int64_t prow = (int64_t)by * HALVES + hf;
+      if (prow * 128 < M) part[(size_t)prow * 2 * Nout + (size_t)which * Nout + n0 + c] = a;
+    }
+  }
+}
+
+// Returns true when the shape was handled here (and the kernel launched on `st`).
+template <int MODE>
+bool launch_split_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
+                       const float* bnE, float* part, int64_t M, int K, int Nout, hipStream_t st) {
+  if (K < 128 || K % 32 != 0) return false;
+  if (Nout >= 256 && Nout % 256 == 0) {
+    const unsigned tiles = (unsigned)(ceil_div(M, 128) * (Nout / 256));
+    hipLaunchKernelGGL((pw_split_k<128, 256, MODE>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
+    return true;
+  }
+  if (Nout == 128 && K >= 256) {
+    const unsigned tiles = (unsigned)ceil_div(M, 256);
+    hipLaunchKernelGGL((pw_split_k<256, 128, MODE>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
+    return true;
+  }
+  return false;
+}
+
+template bool launch_split_gemm<SMODE_FWD>(const float*, const float*, const float*, const float*, float*, const float*,
+                                           const float*, float*, int64_t, int, int, hipStream_t);
+template bool launch_split_gemm<SMODE_DGRAD>(const float*, const float*, const float*, const float*, float*, const float*,
+                                             const float*, float*, int64_t, int, int, hipStream_t);
+
+}  // namespace ttk

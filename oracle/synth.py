@@ -166,14 +166,16 @@ def digest(a, nsample: int = 96) -> np.ndarray:
     return np.concatenate([head, a[idx]])
 
 
-def digest_close(d_expected: np.ndarray, a, rtol: float, atol: float):
-    """Compare a tensor with a stored digest. Returns (ok, message)."""
+def digest_close(d_expected: np.ndarray, a, rtol: float, atol: float, rtol_samples: float | None = None):
+    """Compare a tensor with a stored digest. Returns (ok, message).  `rtol_samples` (default: rtol) is the
+    tolerance of the strided samples relative to max(rms, largest sample); `rtol` that of the l2 norm."""
+    rtol_s = rtol if rtol_samples is None else rtol_samples
     d = digest(a, nsample=max(len(d_expected) - 4, 1))
     if d.shape != d_expected.shape:
         return False, f"digest shape {d.shape} vs {d_expected.shape}"
     scale = max(d_expected[0] / math.sqrt(max(d_expected[3], 1.0)), 1e-30)  # rms of the tensor
     err_s = np.abs(d[4:] - d_expected[4:]).max() if len(d) > 4 else 0.0
-    ok_s = err_s <= atol + rtol * max(scale, np.abs(d_expected[4:]).max() if len(d) > 4 else 0.0)
+    ok_s = err_s <= atol + rtol_s * max(scale, np.abs(d_expected[4:]).max() if len(d) > 4 else 0.0)
     err_n = abs(d[0] - d_expected[0])
     ok_n = err_n <= atol * math.sqrt(d_expected[3]) + rtol * d_expected[0]
     return bool(ok_s and ok_n), f"sample err {err_s:.3e} (rms {scale:.3e}), norm err {err_n:.3e} of {d_expected[0]:.3e}"

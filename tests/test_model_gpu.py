@@ -52,7 +52,10 @@ def test_train_step_matches_reference_golden(cfg):
     for k in [k for k in d.files if k.startswith("train/grad/")]:
         g = params[k[len("train/grad/"):]].grad
         g = torch.zeros_like(params[k[len("train/grad/"):]]) if g is None else g
-        ok, msg = digest_close(d[k], g.cpu().numpy(), rtol=2e-2, atol=1e-6)  # B=8: ReLU-kink sensitivity, see test_backbone_gpu
+        # B=8: one ReLU decision that differs between two fp32 evaluations moves the few gradient entries behind it by
+        # several per cent (test_backbone_gpu / test_gradients_vs_fp64_oracle separate that from real error); the
+        # reference's digest therefore pins the norm to 2 % and single sampled entries to 10 % of the tensor's scale
+        ok, msg = digest_close(d[k], g.cpu().numpy(), rtol=2e-2, atol=1e-6, rtol_samples=1e-1)
         if not ok:
             bad.append((k, msg))
     assert not bad, bad[:5]

@@ -1,0 +1,99 @@
+"""GPU parity of the pointwise-conv GEMM entry points (C-ABI) against float64 numpy.
+
+The compute-bound shapes run on the bf16 matrix pipe with exact 3-way operand splits (csrc/pwconv_split.hip);
+the criterion is that they are as close to the exact product as a chain of fp32 multiply-adds over the same
+operands is (one fp32 accumulator per output, k by k) - i.e. no precision was given up for the speed."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BN_SCALE, BN_BETA, BN_MEAN, BN_RSTD, BN_GA, BN_GB, BN_GMEAN = range(7)
+
+
+def _bn_block(C, rng):
+    bn = np.zeros((8, C), np.float32)
+    bn[BN_SCALE] = rng.uniform(0.5, 1.5, C)
+    bn[BN_BETA] = rng.normal(0, 0.2, C)
+    bn[BN_MEAN] = rng.normal(0, 0.3, C)
+    bn[BN_RSTD] = rng.uniform(0.5, 2.0, C)
+    bn[BN_GA] = rng.uniform(0.5, 1.5, C)
+    bn[BN_GB] = rng.normal(0, 0.2, C)
+    bn[BN_GMEAN] = rng.normal(0, 0.05, C)
+    return bn
+
+
+def _chain32(a, b_t):
+    """a[M,K] @ b_t[K,N] accumulated k by k in float32 (what a chain of fp32 fused multiply-adds gives, up to the
+    rounding of the product): the accuracy class of any GEMM that keeps ONE fp32 accumulator per output."""
+    acc = np.zeros((a.shape[0], b_t.shape[1]), np.float32)
+    for k in range(a.shape[1]):
+        acc += a[:, k:k + 1] * b_t[k:k + 1, :]
+    return acc
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+# (M, Cin, Cout): split-kernel tiles 128x256 and 256x128, ragged M, the fp32-MFMA shapes, wide K
+SHAPES = [(648, 512, 512), (1000, 128, 256), (4100, 256, 256), (300, 1024, 1024), (777, 256, 128), (2049, 512, 128),
+          (648, 64, 128), (1234, 32, 64), (5000, 128, 128), (128, 512, 1024)]
+
+
+@pytest.mark.parametrize("M,Cin,Cout", SHAPES)
+def test_pwconv_fwd_and_bwd_data(M, Cin, Cout):
+    import trackertraincode._hip as H
+    L, p = H.lib(), H.ptr
+    rng = np.random.default_rng(M + Cin + Cout)
+    ydw = rng.normal(0, 1, (M, Cin)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cout, Cin)) * np.sqrt(2.0 / Cout)).astype(np.float32)
+    bn_dw, bn_pw = _bn_block(Cin, rng), _bn_block(Cout, rng)
+    dev = "cuda"
+    t = lambda a: torch.from_numpy(a).to(dev)
+    rows = L.partial_rows_gemm(M)
+
+    # ---- forward: y = relu(scale*(ydw-mean)+beta) @ w^T ; partial sums of y and y^2 per column
+    a32 = np.maximum(bn_dw[BN_SCALE] * (ydw - bn_dw[BN_MEAN]) + bn_dw[BN_BETA], 0).astype(np.float32)
+    y64 = a32.astype(np.float64) @ w.astype(np.float64).T
+    y32 = _chain32(a32, np.ascontiguousarray(w.T))
+    d_ydw, d_w, d_bn = t(ydw), t(w), t(bn_dw)
+    y = torch.empty(M, Cout, device=dev)
+    part = torch.full((rows, 2, Cout), float("nan"), device=dev)
+    L.call("ttk_pwconv1x1_fwd", p(d_ydw), p(d_bn), p(d_w), p(y), p(part), M, Cin, Cout)
+    torch.cuda.synchronize()
+    e_hip, e_f32 = _rel(y.cpu().numpy(), y64), _rel(y32, y64)
+    print(f"fwd   M={M} K={Cin} N={Cout}: hip {e_hip:.2e}  fp32 chain {e_f32:.2e}")
+    assert e_hip <= 1.5 * e_f32 + 1e-7, (e_hip, e_f32)
+    ps = part.cpu().numpy().astype(np.float64)
+    assert np.isfinite(ps).all()
+    np.testing.assert_allclose(ps[:, 0].sum(0), y64.sum(0), rtol=0, atol=2e-5 * np.abs(y64).sum(0).max())
+    np.testing.assert_allclose(ps[:, 1].sum(0), (y64 ** 2).sum(0), rtol=2e-5)
+
+    # ---- data gradient: g_dw = (dy @ w) * [bn_dw(ydw) > 0], dy = ga*(g-gmean) + gb*(y-mean_pw)
+    g = rng.normal(0, 1, (M, Cout)).astype(np.float32)
+    yv = y.cpu().numpy()
+    dy32 = (bn_pw[BN_GA] * (g - bn_pw[BN_GMEAN]) + bn_pw[BN_GB] * (yv - bn_pw[BN_MEAN])).astype(np.float32)
+    pre = bn_dw[BN_SCALE] * (ydw - bn_dw[BN_MEAN]) + bn_dw[BN_BETA]
+    mask = pre > 0
+    safe = np.abs(pre) > 1e-4  # entries whose mask could flip with rounding are left out of the comparison
+    gd64 = (dy32.astype(np.float64) @ w.astype(np.float64)) * mask
+    gd32 = _chain32(dy32, w) * mask
+    wt = torch.from_numpy(np.ascontiguousarray(w.T)).to(dev)
+    g_dw = torch.empty(M, Cin, device=dev)
+    part2 = torch.full((rows, 2, Cin), float("nan"), device=dev)
+    d_g, d_bnpw = t(g), t(bn_pw)  # named: a temporary would be recycled by the allocator before the kernel runs
+    L.call("ttk_pwconv1x1_bwd_data", p(d_g), p(y), p(d_bnpw), p(wt), p(d_ydw), p(d_bn), p(g_dw), p(part2), M, Cin, Cout)
+    torch.cuda.synchronize()
+    out = g_dw.cpu().numpy()
+    e_hip, e_f32 = _rel(out * safe, gd64 * safe), _rel(gd32 * safe, gd64 * safe)
+    print(f"dgrad M={M} K={Cout} N={Cin}: hip {e_hip:.2e}  fp32 chain {e_f32:.2e}")
+    assert e_hip <= 1.5 * e_f32 + 1e-7, (e_hip, e_f32)
+    ps = part2.cpu().numpy().astype(np.float64)
+    assert np.isfinite(ps).all()
+    o64 = out.astype(np.float64)
+    np.testing.assert_allclose(ps[:, 0].sum(0), o64.sum(0), rtol=0, atol=2e-5 * np.abs(o64).sum(0).max())
+    s2 = (o64 * (ydw.astype(np.float64) - bn_dw[BN_MEAN])).sum(0)
+    np.testing.assert_allclose(ps[:, 1].sum(0), s2, rtol=0, atol=2e-5 * np.abs(o64 * (ydw - bn_dw[BN_MEAN])).sum(0).max())
