@@ -359,6 +359,9 @@ template <int MODE>
 bool launch_split_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
                        const float* bnE, float* part, int64_t M, int K, int Nout, hipStream_t st);
 
+bool launch_split_wgrad(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
+                        int64_t M, int Cin, int Cout, hipStream_t st);
+
 static bool use_split_gemm() {
   // TTK_GEMM=f32mfma keeps every pointwise conv on v_mfma_f32_32x32x2_f32 (A/B timing and numerics comparisons)
   static const bool on = [] { const char* e = getenv("TTK_GEMM"); return !(e && strcmp(e, "f32mfma") == 0); }();
@@ -409,6 +412,9 @@ int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* bn_pw,
                              int64_t M, int Cin, int Cout, ttk_stream_t stream) {
   TTK_REQUIRE(g && y && bn_pw && ydw && bn_dw && dw, "pwconv1x1_bwd_weight: null pointer");
   TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_bwd_weight: unsupported shape");
+  if (use_split_gemm() && launch_split_wgrad(g, y, bn_pw, ydw, bn_dw, dw, M, Cin, Cout, (hipStream_t)stream)) {
+    TTK_LAUNCH_CHECK("pwconv1x1_bwd_weight");
+  }
   const int bn = Cout >= 128 ? 128 : Cout, bk = Cin >= 128 ? 128 : Cin;
   const int tiles = (Cout / bn) * (Cin / bk);
   int64_t slices = 1024 / tiles;

@@ -53,6 +53,77 @@ __device__ __forceinline__ void split_store(f32x4 v, unsigned char* dst, int pla
   *reinterpret_cast<uint2*>(dst + 2 * plane) = make_uint2(pack_top16(a2, b2), pack_top16(c2, d2));
 }
 
+// The consumer side of one block tile: `nks` super-stages (k32) of ds_read_b128 fragments + 6-product MFMAs into
+// acc[TM][TN].  Executes exactly 1 + nks barriers (matching the producers).
+template <int BM, int BN>
+__device__ __forceinline__ void consume_tile(const unsigned char* lds, int nks, int wm, int wn, int r, int h,
+                                             f32x16 (&acc)[BM / 64][BN / 64]) {
+  constexpr int APL = BM * 32, BPL = BN * 32;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr bool HOLD_A = TM <= TN;  // hold the smaller fragment set in registers, stream the other
+  constexpr int TH = HOLD_A ? TM : TN, TS = HOLD_A ? TN : TM;
+  // byte offsets of this lane's fragments inside a stage
+  int hold_off[TH], strm_off[TS];
+#pragma unroll
+  for (int x = 0; x < TH; ++x)
+    hold_off[x] = HOLD_A ? swz_off(wm * (BM / 2) + x * 32 + r, h) : 3 * APL + swz_off(wn * (BN / 2) + x * 32 + r, h);
+#pragma unroll
+  for (int x = 0; x < TS; ++x)
+    strm_off[x] = HOLD_A ? 3 * APL + swz_off(wn * (BN / 2) + x * 32 + r, h) : swz_off(wm * (BM / 2) + x * 32 + r, h);
+  constexpr int HPL = HOLD_A ? APL : BPL, SPL = HOLD_A ? BPL : APL;
+
+  bf16x8 hold[TH][3], hold_n[TH][3], strm[2][3];
+  __syncthreads();  // super-stage 0 is in LDS
+  for (int it = 0; it < nks; ++it) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const unsigned char* S = lds + ((it & 1) * 2 + sub) * kStageStride;
+      if (sub == 0) {  // first stage after the barrier: nothing could be prefetched across it
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int x = 0; x < TH; ++x) hold[x][p] = *reinterpret_cast<const bf16x8*>(S + p * HPL + hold_off[x]);
+          strm[0][p] = *reinterpret_cast<const bf16x8*>(S + p * SPL + strm_off[0]);
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < TS; ++x) {
+        const int cur = (sub * TS + x) & 1;
+        // prefetch the fragments of the next 12 (or 24) MFMAs
+        if (x + 1 < TS) {
+#pragma unroll
+          for (int p = 0; p < 3; ++p) strm[cur ^ 1][p] = *reinterpret_cast<const bf16x8*>(S + p * SPL + strm_off[x + 1]);
+        } else if (sub == 0) {
+          const unsigned char* S2 = S + kStageStride;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int y = 0; y < TH; ++y) hold_n[y][p] = *reinterpret_cast<const bf16x8*>(S2 + p * HPL + hold_off[y]);
+            strm[cur ^ 1][p] = *reinterpret_cast<const bf16x8*>(S2 + p * SPL + strm_off[0]);
+          }
+        }
+        // six piece products, smallest first; (pa, pb) index the A and B pieces (0 = h, 1 = m, 2 = l)
+#define TTK_PROD(pa, pb)                                                                                         \
+  _Pragma("unroll") for (int y = 0; y < TH; ++y) {                                                               \
+  if constexpr (HOLD_A)                                                                                        \
+    acc[y][x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hold[y][pa], strm[cur][pb], acc[y][x], 0, 0, 0);       \
+  else                                                                                                         \
+    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(strm[cur][pa], hold[y][pb], acc[x][y], 0, 0, 0);       \
+  }
+        TTK_PROD(0, 2) TTK_PROD(2, 0) TTK_PROD(1, 1) TTK_PROD(0, 1) TTK_PROD(1, 0) TTK_PROD(0, 0)
+#undef TTK_PROD
+      }
+      if (sub == 0) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int y = 0; y < TH; ++y) hold[y][p] = hold_n[y][p];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <int BM, int BN, int MODE>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* __restrict__ bnA,
@@ -61,8 +132,6 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
   static_assert(BM + BN == 384 && (BM == 128 || BM == 256), "128x256 or 256x128");
   constexpr int APL = BM * 32, BPL = BN * 32;  // bytes of one piece plane
   constexpr int TM = BM / 64, TN = BN / 64;    // 32x32 tiles of a consumer wave (wave tile (BM/2) x (BN/2))
-  constexpr bool HOLD_A = TM <= TN;            // hold the smaller fragment set, stream the other
-  constexpr int TH = HOLD_A ? TM : TN, TS = HOLD_A ? TN : TM;
   constexpr int LDC = BN + 4;
   constexpr int QN = BN / 4, RG = 512 / QN, HALVES = BM / 128, RGH = RG / HALVES;
   constexpr int kEpiBytes = BM * LDC * 4 + RG * 2 * BN * 4;
@@ -172,66 +241,7 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    // byte offsets of this lane's fragments inside a stage
-    int hold_off[TH], strm_off[TS];
-#pragma unroll
-    for (int x = 0; x < TH; ++x)
-      hold_off[x] = HOLD_A ? swz_off(wm * (BM / 2) + x * 32 + r, h) : 3 * APL + swz_off(wn * (BN / 2) + x * 32 + r, h);
-#pragma unroll
-    for (int x = 0; x < TS; ++x)
-      strm_off[x] = HOLD_A ? 3 * APL + swz_off(wn * (BN / 2) + x * 32 + r, h) : swz_off(wm * (BM / 2) + x * 32 + r, h);
-    constexpr int HPL = HOLD_A ? APL : BPL, SPL = HOLD_A ? BPL : APL;
-
-    bf16x8 hold[TH][3], hold_n[TH][3], strm[2][3];
-    __syncthreads();  // super-stage 0 is in LDS
-    for (int it = 0; it < nks; ++it) {
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        const unsigned char* S = lds + ((it & 1) * 2 + sub) * kStageStride;
-        if (sub == 0) {  // first stage after the barrier: nothing could be prefetched across it
-#pragma unroll
-          for (int p = 0; p < 3; ++p) {
-#pragma unroll
-            for (int x = 0; x < TH; ++x) hold[x][p] = *reinterpret_cast<const bf16x8*>(S + p * HPL + hold_off[x]);
-            strm[0][p] = *reinterpret_cast<const bf16x8*>(S + p * SPL + strm_off[0]);
-          }
-        }
-#pragma unroll
-        for (int x = 0; x < TS; ++x) {
-          const int cur = (sub * TS + x) & 1;
-          // prefetch the fragments of the next 12 (or 24) MFMAs
-          if (x + 1 < TS) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) strm[cur ^ 1][p] = *reinterpret_cast<const bf16x8*>(S + p * SPL + strm_off[x + 1]);
-          } else if (sub == 0) {
-            const unsigned char* S2 = S + kStageStride;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-#pragma unroll
-              for (int y = 0; y < TH; ++y) hold_n[y][p] = *reinterpret_cast<const bf16x8*>(S2 + p * HPL + hold_off[y]);
-              strm[cur ^ 1][p] = *reinterpret_cast<const bf16x8*>(S2 + p * SPL + strm_off[0]);
-            }
-          }
-          // six piece products, smallest first; (pa, pb) index the A and B pieces (0 = h, 1 = m, 2 = l)
-#define TTK_PROD(pa, pb)                                                                                         \
-  _Pragma("unroll") for (int y = 0; y < TH; ++y) {                                                               \
-    if constexpr (HOLD_A)                                                                                        \
-      acc[y][x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hold[y][pa], strm[cur][pb], acc[y][x], 0, 0, 0);       \
-    else                                                                                                         \
-      acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(strm[cur][pa], hold[y][pb], acc[x][y], 0, 0, 0);       \
-  }
-          TTK_PROD(0, 2) TTK_PROD(2, 0) TTK_PROD(1, 1) TTK_PROD(0, 1) TTK_PROD(1, 0) TTK_PROD(0, 0)
-#undef TTK_PROD
-        }
-        if (sub == 0) {
-#pragma unroll
-          for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int y = 0; y < TH; ++y) hold[y][p] = hold_n[y][p];
-        }
-      }
-      __syncthreads();
-    }
+    consume_tile<BM, BN>(lds, nks, wm, wn, r, h, acc);
     // ---- accumulators -> LDS image [BM][LDC] (the ring is dead: the loop ended with a barrier)
     float* Cs = reinterpret_cast<float*>(lds);
 #pragma unroll
@@ -290,6 +300,179 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
       if (prow * 128 < M) part[(size_t)prow * 2 * Nout + (size_t)which * Nout + n0 + c] = a;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient  dW[co][ci] += sum_m dy[m][co] * a[m][ci]  on the same consumer pipeline: the contraction runs
+// over the rows m, so the MFMA fragments need 8 CONSECUTIVE m of one channel.  Each producer thread loads a
+// 4 (rows) x 4 (channels) block - four 16-byte loads, lanes of a row group side by side in the channel
+// direction (128-byte segments) - and the transposition is free: register e of the four rows IS the 4
+// consecutive m of channel e, which is split and written as one 8-byte piece into the [channel][m] image.
+// grid.x = dW tiles, grid.y = slices of M (one fp32 atomicAdd per output element and slice).
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const float* __restrict__ bn_pw,
+                 const float* __restrict__ Ydw, const float* __restrict__ bn_dw, float* __restrict__ dW, int64_t M, int Cin,
+                 int Cout, int64_t rows_per_slice) {
+  static_assert(BM + BN == 384 && (BM == 128 || BM == 256), "128x256 or 256x128");
+  constexpr int APL = BM * 32, BPL = BN * 32;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kRingBytes];
+
+  const int tid = threadIdx.x;
+  const int tiles_k = Cin / BN;
+  const int n0 = (blockIdx.x / tiles_k) * BM, k0 = (blockIdx.x % tiles_k) * BN;
+  const int64_t m_begin = (int64_t)blockIdx.y * rows_per_slice;
+  const int64_t m_end = (m_begin + rows_per_slice < M) ? m_begin + rows_per_slice : M;
+  if (m_begin >= m_end) return;  // uniform over the block, before any barrier
+  const int nks = (int)((m_end - m_begin + 31) / 32);
+  const bool producer = __builtin_amdgcn_readfirstlane(tid) >= 256;
+
+  if (producer) {
+    const int pt = tid - 256;
+    const int mb = pt & 7, cq = pt >> 3;  // 8 row blocks of 4 rows x 32 channel quads per pass
+    const int sub = mb >> 2, chunk = (mb >> 1) & 1, o8 = (mb & 1) * 8;
+    constexpr int AP = BM / 128, BP = BN / 128;
+    f32x4 rg[AP][4], ry[AP][4], rx[BP][4];
+    f32x4 ga[AP], gb[AP], gmean[AP], ymean[AP], sc[BP], mu[BP], be[BP];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const int c = n0 + 4 * (cq + 32 * p);
+      ga[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GA * Cout + c);
+      gb[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GB * Cout + c);
+      gmean[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GMEAN * Cout + c);
+      ymean[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_MEAN * Cout + c);
+    }
+#pragma unroll
+    for (int p = 0; p < BP; ++p) {
+      const int c = k0 + 4 * (cq + 32 * p);
+      sc[p] = *reinterpret_cast<const f32x4*>(bn_dw + TTK_BN_SCALE * Cin + c);
+      mu[p] = *reinterpret_cast<const f32x4*>(bn_dw + TTK_BN_MEAN * Cin + c);
+      be[p] = *reinterpret_cast<const f32x4*>(bn_dw + TTK_BN_BETA * Cin + c);
+    }
+    const float* gp = G + n0 + 4 * cq;
+    const float* yp = Y + n0 + 4 * cq;
+    const float* xp = Ydw + k0 + 4 * cq;
+    unsigned char* wbase = lds + sub * kStageStride + o8;
+
+    auto load_a = [&](int ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int64_t row = m_begin + (int64_t)ks * 32 + 4 * mb + i;
+        row = row < m_end ? row : m_end - 1;
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+          rg[p][i] = *reinterpret_cast<const f32x4*>(gp + row * Cout + 128 * p);
+          ry[p][i] = *reinterpret_cast<const f32x4*>(yp + row * Cout + 128 * p);
+        }
+      }
+    };
+    auto load_b = [&](int ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int64_t row = m_begin + (int64_t)ks * 32 + 4 * mb + i;
+        row = row < m_end ? row : m_end - 1;
+#pragma unroll
+        for (int p = 0; p < BP; ++p) rx[p][i] = *reinterpret_cast<const f32x4*>(xp + row * Cin + 128 * p);
+      }
+    };
+    auto store_a = [&](int ks) {
+      unsigned char* S = wbase + (ks & 1) * 2 * kStageStride;
+      const int64_t row0 = m_begin + (int64_t)ks * 32 + 4 * mb;
+#pragma unroll
+      for (int p = 0; p < AP; ++p) {
+        f32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = ga[p] * (rg[p][i] - gmean[p]) + gb[p] * (ry[p][i] - ymean[p]);
+          if (row0 + i >= m_end) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the slice contribute nothing
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          split_store(f32x4{v[0][e], v[1][e], v[2][e], v[3][e]}, S + swz_off(4 * (cq + 32 * p) + e, chunk), APL);
+      }
+    };
+    auto store_b = [&](int ks) {
+      unsigned char* S = wbase + (ks & 1) * 2 * kStageStride + 3 * APL;
+      const int64_t row0 = m_begin + (int64_t)ks * 32 + 4 * mb;
+#pragma unroll
+      for (int p = 0; p < BP; ++p) {
+        f32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = sc[p] * (rx[p][i] - mu[p]) + be[p];
+          v[i].x = fmaxf(v[i].x, 0.f); v[i].y = fmaxf(v[i].y, 0.f); v[i].z = fmaxf(v[i].z, 0.f); v[i].w = fmaxf(v[i].w, 0.f);
+          if (row0 + i >= m_end) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          split_store(f32x4{v[0][e], v[1][e], v[2][e], v[3][e]}, S + swz_off(4 * (cq + 32 * p) + e, chunk), BPL);
+      }
+    };
+
+    load_a(0);
+    load_b(0);
+    store_a(0);
+    if (nks > 1) load_a(1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_b(0);
+    if (nks > 1) load_b(1);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    for (int it = 0; it < nks; ++it) {
+      if (it + 1 < nks) {
+        store_a(it + 1);
+        if (it + 2 < nks) load_a(it + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        store_b(it + 1);
+        if (it + 2 < nks) load_b(it + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+  } else {
+    const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    consume_tile<BM, BN>(lds, nks, wm, wn, r, h, acc);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = n0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int col = k0 + wn * (BN / 2) + j * 32 + r;
+          atomicAdd(dW + (size_t)row * Cin + col, acc[i][j][e]);
+        }
+  }
+}
+
+bool launch_split_wgrad(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
+                        int64_t M, int Cin, int Cout, hipStream_t st) {
+  if (Cin < 128 || Cout < 128 || Cin % 128 || Cout % 128 || (int64_t)Cin * Cout < 128 * 256) return false;
+  const bool wide = Cin % 256 == 0;  // 128 (Cout) x 256 (Cin) tiles, else 256 x 128
+  if (!wide && Cout % 256) return false;
+  const int tiles = wide ? (Cout / 128) * (Cin / 256) : (Cout / 256) * (Cin / 128);
+  int64_t slices = 256 / tiles;  // one workgroup per CU, all of equal length
+  if (slices < 1) slices = 1;
+  const int64_t max_slices = ceil_div(M, 128);
+  if (slices > max_slices) slices = max_slices;
+  const int64_t rows = ceil_div(ceil_div(M, slices), 32) * 32;
+  slices = ceil_div(M, rows);
+  const dim3 grid(tiles, (unsigned)slices);
+  if (wide)
+    hipLaunchKernelGGL((pw_split_wgrad_k<128, 256>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, M, Cin, Cout, rows);
+  else
+    hipLaunchKernelGGL((pw_split_wgrad_k<256, 128>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, M, Cin, Cout, rows);
+  return true;
 }
 
 // Returns true when the shape was handled here (and the kernel launched on `st`).

@@ -44,7 +44,7 @@ SHAPES = [(648, 512, 512), (1000, 128, 256), (4100, 256, 256), (300, 1024, 1024)
 
 
 @pytest.mark.parametrize("M,Cin,Cout", SHAPES)
-def test_pwconv_fwd_and_bwd_data(M, Cin, Cout):
+def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout):
     import trackertraincode._hip as H
     L, p = H.lib(), H.ptr
     rng = np.random.default_rng(M + Cin + Cout)
@@ -97,3 +97,13 @@ def test_pwconv_fwd_and_bwd_data(M, Cin, Cout):
     np.testing.assert_allclose(ps[:, 0].sum(0), o64.sum(0), rtol=0, atol=2e-5 * np.abs(o64).sum(0).max())
     s2 = (o64 * (ydw.astype(np.float64) - bn_dw[BN_MEAN])).sum(0)
     np.testing.assert_allclose(ps[:, 1].sum(0), s2, rtol=0, atol=2e-5 * np.abs(o64 * (ydw - bn_dw[BN_MEAN])).sum(0).max())
+
+    # ---- weight gradient: dW[co][ci] = sum_m dy[m][co] * a[m][ci] (accumulated onto a zeroed buffer)
+    dw64 = dy32.astype(np.float64).T @ a32.astype(np.float64)
+    dw32 = _chain32(np.ascontiguousarray(dy32.T), a32)
+    dW = torch.zeros(Cout, Cin, device=dev)
+    L.call("ttk_pwconv1x1_bwd_weight", p(d_g), p(y), p(d_bnpw), p(d_ydw), p(d_bn), p(dW), M, Cin, Cout)
+    torch.cuda.synchronize()
+    e_hip, e_f32 = _rel(dW.cpu().numpy(), dw64), _rel(dw32, dw64)
+    print(f"wgrad M={M} Cout={Cout} Cin={Cin}: hip {e_hip:.2e}  fp32 chain {e_f32:.2e}")
+    assert e_hip <= 1.5 * e_f32 + 1e-7, (e_hip, e_f32)
