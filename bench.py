@@ -61,34 +61,52 @@ class KernelTimer:
 
     @staticmethod
     def work(name, a):
-        """(flops, bytes) of one call from its integer arguments; fp32 = 4 B/element."""
+        """(kernel name as rocprofv3 prints it, flops, algorithmic bytes) of one call; fp32 = 4 B/element.
+        Mirrors the dispatch rules of csrc/pwconv.hip + pwconv_split.hip + dwconv_tiled.hip."""
         ints = [x for x in a if isinstance(x, int) and not isinstance(x, bool)]
-        if name == "ttk_pwconv1x1_fwd":
+        if name.startswith("ttk_pwconv1x1"):
             M, ci, co = ints[-3:]
-            return 2 * M * ci * co, 4 * (M * ci + M * co + ci * co)
-        if name == "ttk_pwconv1x1_bwd_data":
-            M, ci, co = ints[-3:]
-            return 2 * M * ci * co, 4 * (2 * M * co + 2 * M * ci + ci * co)
-        if name == "ttk_pwconv1x1_bwd_weight":
-            M, ci, co = ints[-3:]
-            return 2 * M * ci * co, 4 * (2 * M * co + M * ci + ci * co)
-        return 0, 0
+            fl = 2 * M * ci * co
+            if name == "ttk_pwconv1x1_fwd":
+                K, N, mode, by = ci, co, 0, 4 * (M * ci + M * co + ci * co)
+            elif name == "ttk_pwconv1x1_bwd_data":
+                K, N, mode, by = co, ci, 1, 4 * (2 * M * co + 2 * M * ci + ci * co)
+            else:
+                by = 4 * (2 * M * co + M * ci + ci * co)
+                if ci >= 128 and co >= 128 and ci * co >= 128 * 256 and (ci % 256 == 0 or co % 256 == 0):
+                    return ("pw_split_wgrad_k<128, 256>" if ci % 256 == 0 else "pw_split_wgrad_k<256, 128>"), fl, by
+                return "pw_wgrad_k", fl, by
+            if K >= 128 and N % 256 == 0:
+                return f"pw_split_k<128, 256, {mode}>", fl, by
+            if K >= 256 and N == 128:
+                return f"pw_split_k<256, 128, {mode}>", fl, by
+            return (f"pw_gemm_k<{min(N, 128)}, 2, 2, {mode}>" if N >= 64 else f"pw_gemm_k<32, 4, 1, {mode}>"), fl, by
+        if name == "ttk_dwconv3x3_fwd":
+            B, H, W, C, s_ = ints[-5:]
+            n_in, n_out = B * H * W * C, B * ((H - 1) // s_ + 1) * ((W - 1) // s_ + 1) * C
+            by = 4 * (n_in * (1 + bool(a[2]) + bool(a[3])) + n_out)
+            return f"dw_fwd_tiled_k<{s_}>", 2 * 9 * n_out, by
+        if name == "ttk_dwconv3x3_bwd_data":
+            B, H, W, C, s_ = ints[-5:]
+            n_in, n_out = B * H * W * C, B * ((H - 1) // s_ + 1) * ((W - 1) // s_ + 1) * C
+            by = 4 * (2 * n_out + n_in * (2 + bool(a[4]) + bool(a[7] or a[8])))
+            return f"dw_bwd_tiled_k<{s_}>", 2 * 2 * 9 * n_out, by
+        return name, 0, 0
 
     def wrap(self, lib):
         orig = lib.call
         timer = self
 
         def call(name, *args):
-            # only the dominant kernel family is bracketed with events: ~37 calls per step.  Bracketing all ~300
-            # calls costs ~4 ms/step of host time and distorts the number being measured.
-            if not timer.enabled or not name.startswith("ttk_pwconv1x1"):
+            # only the conv kernels (94 % of the GPU time) are bracketed, and only in the separate roofline pass
+            if not timer.enabled or not (name.startswith("ttk_pwconv1x1") or name.startswith("ttk_dwconv3x3")):
                 return orig(name, *args)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             orig(name, *args)
             e.record()
-            fl, by = timer.work(name, args)
-            timer.records.append((name, s, e, fl, by))
+            kern, fl, by = timer.work(name, args)
+            timer.records.append((kern, s, e, fl, by))
 
         lib.call = call
 
@@ -270,28 +288,39 @@ def main():
         ms = elapsed / args.steps * 1e3
         crops = args.batch * world * args.steps / elapsed
         ks = timer.summary(max(roof_steps, 1))
-        gemm = [k for k in ks if k.startswith("ttk_pwconv1x1")]
-        dominant = max(ks, key=lambda k: ks[k]["ms"]) if ks else None
-        roof = None
-        if gemm:
-            # dominant kernel FAMILY = the pointwise GEMMs (95.7 % of the MACs); the entry point with the largest
-            # share is reported, with the family totals beside it.  Forward / data gradient of the compute-bound
-            # layers run on the bf16 pipe with exact 3-way operand splits (6 MFMA products per fp32 product): their
-            # ceiling in fp32-equivalent FLOP/s is the dense bf16 peak / 6; the weight gradient is fp32 MFMA.
-            top = max(gemm, key=lambda k: ks[k]["ms"])
-            tf = ks[top]["flops"] / (ks[top]["ms"] * 1e-3) / 1e12
-            split = top != "ttk_pwconv1x1_bwd_weight"
-            peak = PEAK_BF16_MFMA_TFLOPS / 6 if split else PEAK_FP32_MFMA_TFLOPS
-            kern = ("pw_split_k: v_mfma_f32_32x32x16_bf16 x6 (exact 3-way bf16 split of fp32 operands); pw_gemm_k fp32 MFMA on the "
-                    "HBM-bound early layers") if split else "pw_wgrad_k: v_mfma_f32_32x32x2_f32"
-            roof = {"bound": "mfma", "kernel": f"{top} ({kern})", "achieved": tf, "peak": peak,
-                    "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
-                    "peak_note": ("fp32-equivalent: 2500 TF dense bf16 / 6 piece products" if split else "dense fp32 MFMA"),
-                    "frac_of_fp32_mfma_peak": tf / PEAK_FP32_MFMA_TFLOPS,
-                    "launch_avg_us": ks[top]["ms"] / (ks[top]["calls_per_step"] * roof_steps) * 1e3,
-                    "achieved_GBs": ks[top]["bytes"] / (ks[top]["ms"] * 1e-3) / 1e9,
-                    "family_TFLOPs": sum(ks[k]["flops"] for k in gemm) / (sum(ks[k]["ms"] for k in gemm) * 1e-3) / 1e12,
-                    "pass": f"{roof_steps} extra steps after the timed region, HIP events around each GEMM call, single stream"}
+        roof, top5 = None, []
+        if ks:
+            # dominant kernel = the kernel NAME (as rocprofv3 --stats lists it) with the largest total time in the
+            # roofline pass.  Depthwise kernels are HBM-bound; pw_split_k runs 6 bf16 MFMA products per fp32 product,
+            # so its fp32-equivalent ceiling is the dense bf16 peak / 6; pw_gemm_k / pw_wgrad_k (the early, HBM-bound
+            # pointwise layers) are fp32 MFMA kernels priced against HBM.
+            traffic = {}
+            tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath))["kernels"]
+
+            def roofline_of(k):
+                v = ks[k]
+                sec, launches = v["ms"] * 1e-3, v["calls_per_step"] * roof_steps
+                hbm = not k.startswith("pw_split")
+                if hbm:
+                    ach, peak, unit = v["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s"
+                else:
+                    ach, peak, unit = v["flops"] / sec / 1e12, PEAK_BF16_MFMA_TFLOPS / 6, "TFLOP/s"
+                tr = traffic.get(k)
+                return {"bound": "hbm" if hbm else "mfma", "kernel": k, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                        "traffic": tr["bytes_per_launch"] if tr else None, "algorithmic_bytes_per_launch": v["bytes"] / launches,
+                        "flops_per_launch": v["flops"] / launches, "launch_avg_us": v["ms"] / launches * 1e3,
+                        "launches_per_step": v["calls_per_step"], "ms_per_step": v["ms_per_step"]}
+
+            order = sorted(ks, key=lambda k: -ks[k]["ms"])
+            roof = roofline_of(order[0])
+            roof["peak_note"] = ("HBM3E spec 8 TB/s (6.3 TB/s achievable per the MI355X guide)" if roof["bound"] == "hbm"
+                                 else "fp32-equivalent: 2500 TF dense bf16 / 6 piece products")
+            roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; null = not collected)"
+            roof["pass"] = f"{roof_steps} extra steps after the timed region, HIP events around each conv call, single stream"
+            top5 = [roofline_of(k) for k in order[:6]]
+        dominant = roof["kernel"] if roof else None
         per_gpu = crops / world
         line = {
             "metric": "face-crops/sec fwd+bwd @ batch 512", "value": crops, "unit": "crops/s", "n_gpus": world, "steps": args.steps,
@@ -306,7 +335,9 @@ def main():
                               "fp32_mfma_frac_of_157TF": per_gpu * ALGO_FLOP_PER_CROP / (PEAK_FP32_MFMA_TFLOPS * 1e12)},
             "optimizer_ms": opt_ms, "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3, "loss": float(loss.item()),
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms"])},
-            "dominant_entry_point": dominant,
+            "gemm_family_TFLOPs": (sum(v["flops"] for k, v in ks.items() if k.startswith("pw_")) /
+                                   max(sum(v["ms"] for k, v in ks.items() if k.startswith("pw_")) * 1e-3, 1e-12) / 1e12) if ks else None,
+            "dominant_kernel": dominant, "top_kernels": top5,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)

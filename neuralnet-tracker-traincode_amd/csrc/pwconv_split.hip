@@ -102,6 +102,8 @@ __device__ __forceinline__ void consume_tile(const unsigned char* lds, int nks, 
             strm[cur ^ 1][p] = *reinterpret_cast<const bf16x8*>(S2 + p * SPL + strm_off[0]);
           }
         }
+        // (Pinning [reads of the next group][12 MFMAs] with sched_barrier was measured 5-10 % SLOWER than hipcc's own
+        // interleaving next to a producer wave on the same SIMD.)
         // six piece products, smallest first; (pa, pb) index the A and B pieces (0 = h, 1 = m, 2 = l)
 #define TTK_PROD(pa, pb)                                                                                         \
   _Pragma("unroll") for (int y = 0; y < TH; ++y) {                                                               \
@@ -321,9 +323,15 @@ pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const
   __shared__ __attribute__((aligned(16))) unsigned char lds[kRingBytes];
 
   const int tid = threadIdx.x;
+  // XCD-aware order: workgroup ids go round-robin over the 8 XCDs; give each XCD whole slices (all dW tiles of a
+  // slice run side by side on ONE L2, so the slice's operand rows are fetched from HBM once, not once per tile).
+  const unsigned T = gridDim.x, NG = T * gridDim.y, Lid = blockIdx.y * T + blockIdx.x;
+  const unsigned xq = NG / 8, xr = NG % 8, xcd = Lid % 8;
+  const unsigned logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + Lid / 8;
+  const unsigned tile = logical % T, slice = logical / T;
   const int tiles_k = Cin / BN;
-  const int n0 = (blockIdx.x / tiles_k) * BM, k0 = (blockIdx.x % tiles_k) * BN;
-  const int64_t m_begin = (int64_t)blockIdx.y * rows_per_slice;
+  const int n0 = (tile / tiles_k) * BM, k0 = (tile % tiles_k) * BN;
+  const int64_t m_begin = (int64_t)slice * rows_per_slice;
   const int64_t m_end = (m_begin + rows_per_slice < M) ? m_begin + rows_per_slice : M;
   if (m_begin >= m_end) return;  // uniform over the block, before any barrier
   const int nks = (int)((m_end - m_begin + 31) / 32);
