@@ -42,7 +42,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 2
+#define TTK_ABI_VERSION 3
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -225,12 +225,20 @@ int ttk_loss_gmm_bwd(const float* x, const double* mu, const double* sinv, const
  * {param, grad (0 = no gradient), exp_avg, exp_avg_sq} addresses; numel[ntensors]; group[ntensors]
  * (index into the host arrays lr4/wd4); chunk_tensor/chunk_offset[nchunks] cut the tensors into
  * chunks of chunk_size elements.  partial[nchunks]: scratch; out_norm (nullable): total grad norm.
+ * hyper_dev (nullable, DEVICE float[TTK_ADAM_HYPER_FLOATS]): when given, the per-group learning rates and weight
+ * decays are read from it instead of lr4/wd4, and the bias corrections are 1 - beta^t with t = the step counter
+ * stored in it, which the call increments first - nothing about the step is then baked into the launch
+ * arguments, so the call can sit inside a captured hipGraph that is replayed every step.
  * ------------------------------------------------------------------------------------------- */
+#define TTK_ADAM_HYPER_LR 0     /* [4] */
+#define TTK_ADAM_HYPER_WD 4     /* [4] */
+#define TTK_ADAM_HYPER_STEP 8   /* completed steps, as a float */
+#define TTK_ADAM_HYPER_FLOATS 12
 int ttk_clip_adam(const int64_t* ptrs, const int32_t* numel, const int32_t* group,
                   const int32_t* chunk_tensor, const int32_t* chunk_offset, int nchunks, int chunk_size,
                   const float* lr4, const float* wd4, float beta1, float beta2, float eps,
                   float bias_correction1, float bias_correction2, float max_norm, float* partial,
-                  float* out_norm, ttk_stream_t stream);
+                  float* out_norm, float* hyper_dev, ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * On-GPU affine-warp augmentation (the reference does this per sample on the CPU with OpenCV inside

@@ -34,9 +34,12 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return s;
 }
 
-__global__ void __launch_bounds__(kBlock) grad_sqnorm_k(AdamTables t, int chunk_size, float* __restrict__ partial) {
+__global__ void __launch_bounds__(kBlock) grad_sqnorm_k(AdamTables t, int chunk_size, float* __restrict__ partial,
+                                                         float* __restrict__ hyper_dev) {
   __shared__ float red[kBlock / kWave];
   const int c = blockIdx.x;
+  // device-resident step counter (hipGraph replays): bumped here, read by clip_adam_k after the kernel boundary
+  if (hyper_dev && c == 0 && threadIdx.x == 0) hyper_dev[TTK_ADAM_HYPER_STEP] += 1.f;
   const int ti = t.chunk_tensor[c], off = t.chunk_offset[c];
   const float* g = reinterpret_cast<const float*>(t.ptrs[4 * ti + 1]);
   const int n = min(chunk_size, t.numel[ti] - off);
@@ -51,8 +54,16 @@ __global__ void __launch_bounds__(kBlock) grad_sqnorm_k(AdamTables t, int chunk_
 }
 
 __global__ void __launch_bounds__(kBlock) clip_adam_k(AdamTables t, AdamHyper h, int chunk_size, int nchunks,
-                                                       const float* __restrict__ partial, float* __restrict__ out_norm) {
+                                                       const float* __restrict__ partial, float* __restrict__ out_norm,
+                                                       const float* __restrict__ hyper_dev) {
   __shared__ double dred[kBlock];
+  if (hyper_dev) {  // learning rates / weight decays / step count live in device memory (same values every replay of a graph)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { h.lr[i] = hyper_dev[TTK_ADAM_HYPER_LR + i]; h.wd[i] = hyper_dev[TTK_ADAM_HYPER_WD + i]; }
+    const float tstep = hyper_dev[TTK_ADAM_HYPER_STEP];
+    h.bc1 = 1.f - powf(h.beta1, tstep);
+    h.bc2 = 1.f - powf(h.beta2, tstep);
+  }
   // total gradient norm: fixed-order fp64 sum of the chunk partials (identical in every block)
   double acc = 0.0;
   for (int i = threadIdx.x; i < nchunks; i += kBlock) acc += (double)partial[i];
@@ -100,7 +111,7 @@ extern "C" {
 int ttk_clip_adam(const int64_t* ptrs, const int32_t* numel, const int32_t* group, const int32_t* chunk_tensor,
                   const int32_t* chunk_offset, int nchunks, int chunk_size, const float* lr4, const float* wd4, float beta1,
                   float beta2, float eps, float bias_correction1, float bias_correction2, float max_norm, float* partial,
-                  float* out_norm, ttk_stream_t stream) {
+                  float* out_norm, float* hyper_dev, ttk_stream_t stream) {
   TTK_REQUIRE(ptrs && numel && group && chunk_tensor && chunk_offset && lr4 && wd4 && partial, "clip_adam: null pointer");
   TTK_REQUIRE(nchunks > 0 && chunk_size > 0, "clip_adam: bad chunking");
   AdamTables t{ptrs, numel, group, chunk_tensor, chunk_offset};
@@ -108,8 +119,8 @@ int ttk_clip_adam(const int64_t* ptrs, const int32_t* numel, const int32_t* grou
   for (int i = 0; i < 4; ++i) { h.lr[i] = lr4[i]; h.wd[i] = wd4[i]; }
   h.beta1 = beta1; h.beta2 = beta2; h.eps = eps; h.bc1 = bias_correction1; h.bc2 = bias_correction2; h.max_norm = max_norm;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(grad_sqnorm_k, dim3(nchunks), dim3(kBlock), 0, st, t, chunk_size, partial);
-  hipLaunchKernelGGL(clip_adam_k, dim3(nchunks), dim3(kBlock), 0, st, t, h, chunk_size, nchunks, partial, out_norm);
+  hipLaunchKernelGGL(grad_sqnorm_k, dim3(nchunks), dim3(kBlock), 0, st, t, chunk_size, partial, hyper_dev);
+  hipLaunchKernelGGL(clip_adam_k, dim3(nchunks), dim3(kBlock), 0, st, t, h, chunk_size, nchunks, partial, out_norm, hyper_dev);
   TTK_LAUNCH_CHECK("clip_adam");
 }
 

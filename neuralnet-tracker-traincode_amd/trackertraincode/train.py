@@ -171,6 +171,7 @@ class ClipAdam(torch.optim.Optimizer):
             nchunks=len(ct), ptrs_host=torch.zeros((len(plist), 4), dtype=torch.int64).pin_memory(),
             ptrs=torch.zeros((len(plist), 4), dtype=torch.int64, device=dev),
             partial=torch.empty(len(ct), dtype=torch.float32, device=dev), norm=torch.zeros(1, dtype=torch.float32, device=dev),
+            hyper=torch.zeros(12, dtype=torch.float32, device=dev),  # TTK_ADAM_HYPER_* block (include/ttk.h)
         )
         h = self._tables["ptrs_host"]
         for ti, p in enumerate(plist):
@@ -190,18 +191,50 @@ class ClipAdam(torch.optim.Optimizer):
                 g = p.grad = g.contiguous()
             h[ti, 1] = 0 if g is None else g.data_ptr()
         T["ptrs"].copy_(h, non_blocking=True)
-        self._t += 1
         b1, b2 = self.param_groups[0]["betas"]
         lr4 = (ctypes.c_float * 4)(*([g["lr"] for g in self.param_groups] + [0.0] * 4)[:4])
         wd4 = (ctypes.c_float * 4)(*([g["weight_decay"] for g in self.param_groups] + [0.0] * 4)[:4])
         p_ = _hip.ptr
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            # inside a hipGraph capture nothing of the step may be baked into launch arguments: learning rates, weight
+            # decays and the step counter are read from (and the counter advanced in) the device block `hyper`
+            hyper, t = p_(T["hyper"]), 1
+        else:
+            self._t += 1
+            hyper, t = None, self._t
         _hip.lib().call("ttk_clip_adam", p_(T["ptrs"]), p_(T["numel"]), p_(T["group"]), p_(T["chunk_tensor"]), p_(T["chunk_offset"]),
-                        T["nchunks"], self.CHUNK, lr4, wd4, b1, b2, self.param_groups[0]["eps"], 1.0 - b1 ** self._t,
-                        1.0 - b2 ** self._t, float(self.max_norm or 0.0), p_(T["partial"]), p_(T["norm"]))
-        for p in T["params"]:
-            self.state[p]["step"] += 1
+                        T["nchunks"], self.CHUNK, lr4, wd4, b1, b2, self.param_groups[0]["eps"], 1.0 - b1 ** t,
+                        1.0 - b2 ** t, float(self.max_norm or 0.0), p_(T["partial"]), p_(T["norm"]), hyper)
+        if not capturing:
+            for p in T["params"]:
+                self.state[p]["step"] += 1
         self.last_grad_norm = T["norm"]
         return None
+
+    # ---- hipGraph support -----------------------------------------------------------------------
+    def sync_hyper_to_device(self):
+        """Write the groups' lr / weight_decay and the current step count into the device block a captured step
+        reads.  Called before a capture and whenever the scheduler changed a learning rate (once per epoch)."""
+        if self._tables is None:
+            self._build_tables()
+        vals = ([g["lr"] for g in self.param_groups] + [0.0] * 4)[:4] + ([g["weight_decay"] for g in self.param_groups] + [0.0] * 4)[:4]
+        vals += [float(self._t), 0.0, 0.0, 0.0]
+        self._tables["hyper"].copy_(torch.tensor(vals, dtype=torch.float32))  # synchronous, pageable: rare
+        self._hyper_sig = tuple(vals[:8])
+
+    def before_graph_replay(self):
+        """Push a changed learning rate / weight decay (scheduler step) to the device block before the replay."""
+        vals = tuple(([g["lr"] for g in self.param_groups] + [0.0] * 4)[:4] + ([g["weight_decay"] for g in self.param_groups] + [0.0] * 4)[:4])
+        if vals != getattr(self, "_hyper_sig", None):
+            torch.cuda.current_stream().synchronize()  # earlier replays still read the old values
+            self.sync_hyper_to_device()
+
+    def after_graph_replay(self):
+        """Host-side bookkeeping of one replayed step (the device counter was advanced by the graph)."""
+        self._t += 1
+        for p in self._tables["params"]:
+            self.state[p]["step"] += 1
 
 
 # ---------------------------------------------------------------------------------------------
@@ -256,6 +289,87 @@ def training_step(model: nn.Module, batches: List[Batch], epoch: int, criterions
     loss_sum, all_lossvals = default_compute_loss(preds, batches, epoch, criterions)
     by_name = {k: v for k, (v, _) in concatenated_lossvals_by_name(itertools.chain.from_iterable(all_lossvals)).items()}
     return {"loss": loss_sum, "mt_losses": by_name}
+
+
+def _criterion_weights(c, step):
+    """Flat tuple of every weight in a criterion tree at `step` (they are constants inside a captured graph)."""
+    if isinstance(c, dict):
+        return tuple((str(k), _criterion_weights(v, step)) for k, v in c.items())
+    if isinstance(c, CriterionGroup):
+        return (_weight_at(c.w, step),) + tuple(_criterion_weights(x, step) for x in c.criterions)
+    return (_weight_at(c.w, step),)
+
+
+class GraphedTrainStep:
+    """zero_grad + training_step + backward + ClipAdam.step captured ONCE as a hipGraph and replayed every step.
+
+    A pose-estimator step is ~330 kernel launches, two thirds of them small head / loss / autograd-glue kernels;
+    enqueueing them from Python costs ~11 ms per step next to ~13 ms of GPU work, and that host time is the next
+    bound once the kernels get faster.  A captured graph enqueues the same work with one call.  (The reference has
+    no counterpart: Lightning drives eager PyTorch; `train_poseestimator.py:442-454`.)
+
+    The graph stays valid while the sub-batch layout (tags, sizes, fields), the epoch-dependent loss weights and the
+    learning-rate-independent launch arguments stay the same: `run()` compares a signature and re-captures when it
+    changes (e.g. during the NLL ramp epochs).  Learning rates, weight decays and Adam's step count live in device
+    memory (ClipAdam.sync_hyper_to_device), so scheduler steps need no re-capture.  New batches are copied into the
+    graph's static input tensors.  Single-GPU: the data-parallel all-reduce is issued eagerly (train.fit)."""
+
+    def __init__(self, model: nn.Module, criterions, optimizer: "ClipAdam"):
+        if not isinstance(optimizer, ClipAdam):
+            raise TypeError("GraphedTrainStep needs the fused ClipAdam optimiser (its step is capturable)")
+        self.model, self.criterions, self.optimizer = model, criterions, optimizer
+        self.graph = None
+        self._sig = None
+        self._static: list[Batch] = []
+        self._out = None
+        self.captures = 0
+
+    def _signature(self, batches, epoch):
+        layout = tuple((str(b.meta.tag), b.meta.batchsize, tuple((k, tuple(v.shape), str(v.dtype)) for k, v in b.items()))
+                       for b in batches)
+        return layout, _criterion_weights(self.criterions, epoch), self.model.training
+
+    def _eager(self, batches, epoch):
+        self.optimizer.zero_grad(set_to_none=True)
+        out = training_step(self.model, batches, epoch, self.criterions)
+        out["loss"].backward()
+        self.optimizer.step()
+        return out
+
+    def _capture(self, batches, epoch):
+        self._static = [Batch(b.meta, ((k, v.clone()) for k, v in b.items())) for b in batches]
+        self.optimizer.sync_hyper_to_device()
+        self.graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)  # gradients are allocated from the graph's pool at fixed addresses
+        with torch.cuda.graph(self.graph):
+            out = training_step(self.model, self._static, epoch, self.criterions)
+            out["loss"].backward()
+            self.optimizer.step()
+        self._out = out
+        self.captures += 1
+
+    def run(self, batches: List[Batch], epoch: int):
+        """One training step.  Returns {"loss", "mt_losses"}; when replayed these are the graph's static output
+        tensors (overwritten by the next call)."""
+        sig = self._signature(batches, epoch)
+        if sig != self._sig:
+            # first step with this layout: run it eagerly (lazy initialisation, table building, stream creation happen
+            # here and the step counts), then capture for the following steps
+            out = self._eager(batches, epoch)
+            # hand back detached copies and drop the eager autograd graph BEFORE capturing: with it still alive,
+            # hipStreamEndCapture / graph instantiation was seen to segfault on ROCm 7.2 (tools/debug/graph_capture4.py)
+            out = {"loss": out["loss"].detach().clone(), "mt_losses": {k: v.detach().clone() for k, v in out["mt_losses"].items()}}
+            torch.cuda.synchronize()
+            self._capture(batches, epoch)
+            self._sig = sig
+            return out
+        for dst, src in zip(self._static, batches):
+            for k, v in src.items():
+                dst[k].copy_(v, non_blocking=True)
+        self.optimizer.before_graph_replay()
+        self.graph.replay()
+        self.optimizer.after_graph_replay()
+        return self._out
 
 
 def fit(model: nn.Module, train_loader, criterions, optimizer, scheduler=None, epochs=1, callbacks=(), on_step=None,
