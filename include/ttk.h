@@ -42,7 +42,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 3
+#define TTK_ABI_VERSION 4
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -166,25 +166,29 @@ int ttk_bn_act(const float* y, const float* bn, const float* skip, float* a, int
  * (modelcomponents.py:136-184) and Landmarks3dOutput (models.py:96-124, modelcomponents.py:38-82).
  * The linear layers are passed stacked: wcat[NZ][F], bcat[NZ] with the row order
  *   box 4 | xy 2 | size 1 | quat 4 | [coord-scale neck 7 | pose-scale neck 7] | [shape 50]
- * NZ = ttk_heads_num_rows(enable_uncertainty, enable_point_head).  ids: int32 dataset ids (NULL = row 0,
+ * NZ = ttk_heads_num_rows(enable_uncertainty, enable_point_head, enable_6drot).  ids: int32 dataset ids (NULL = row 0,
  * the reference's set_id=None path).  Outputs per sample: roi[4] coord[3] rot[4] (ijkw) qu[4]
  * (= unnormalized_quat) Lc[9] Lr[9] (= coord_scales, pose_scales_tril) pts[68][3] shp[50]; z[B][NZ] is
  * saved for backward.
+ * enable_6drot (RotRepr6dWithNormalization, models.py:153-174; torch6drotation.py:27-49; Mat33Repr, rotrepr.py:63-98):
+ * the rotation rows are 6 instead of 4, rot is [B][9] (row-major 3x3: Gram-Schmidt of the two 3-vectors, identity
+ * where max|R R^T - I| > 1e-3, times the dataset offset rotation), qu is [B][6] (= unnormalized_6drepr).
  * ------------------------------------------------------------------------------------------- */
-int ttk_heads_num_rows(int enable_uncertainty, int enable_point_head);
+int ttk_heads_num_rows(int enable_uncertainty, int enable_point_head, int enable_6drot);
 int ttk_heads_fwd(const float* feat, const float* wcat, const float* bcat, const int* ids,
                   const float* P, const float* Pk, const float* keypts, const float* keyeig, int B, int F,
-                  int NZ, int enable_uncertainty, int enable_point_head, int use_offset, float* z,
-                  float* roi, float* coord, float* rot, float* qu, float* Lc, float* Lr, float* pts,
+                  int NZ, int enable_uncertainty, int enable_point_head, int use_offset, int enable_6drot,
+                  float* z, float* roi, float* coord, float* rot, float* qu, float* Lc, float* Lr, float* pts,
                   float* shp, ttk_stream_t stream);
 /* dz[B][NZ], dprow[B][8]: scratch.  Outputs dfeat[B][F], dwcat[NZ][F], dbcat[NZ], dP[8][4], dPk[8][4]
  * (overwritten). */
 int ttk_heads_bwd(const float* feat, const float* wcat, const float* z, const int* ids, const float* P,
                   const float* Pk, const float* keypts, const float* keyeig, int B, int F, int NZ,
-                  int enable_uncertainty, int enable_point_head, int use_offset, const float* g_roi,
-                  const float* g_coord, const float* g_rot, const float* g_qu, const float* g_Lc,
-                  const float* g_Lr, const float* g_pts, const float* g_shp, float* dz, float* dprow,
-                  float* dfeat, float* dwcat, float* dbcat, float* dP, float* dPk, ttk_stream_t stream);
+                  int enable_uncertainty, int enable_point_head, int use_offset, int enable_6drot,
+                  const float* g_roi, const float* g_coord, const float* g_rot, const float* g_qu,
+                  const float* g_Lc, const float* g_Lr, const float* g_pts, const float* g_shp, float* dz,
+                  float* dprow, float* dfeat, float* dwcat, float* dbcat, float* dP, float* dPk,
+                  ttk_stream_t stream);
 /* DiagonalScaleParameter (negloglikelihood.py:50-65): out[n] from hidden[n+1]. */
 int ttk_diag_scale_fwd(const float* hidden, float* out, int n, ttk_stream_t stream);
 int ttk_diag_scale_bwd(const float* hidden, const float* gout, float* ghidden, int n, ttk_stream_t stream);
@@ -203,6 +207,16 @@ int ttk_diag_scale_bwd(const float* hidden, const float* gout, float* ghidden, i
  * ------------------------------------------------------------------------------------------- */
 int ttk_loss_rot_fwd(const float* q, const float* t, int n, float* v, ttk_stream_t stream);
 int ttk_loss_rot_bwd(const float* q, const float* t, const float* gv, int n, float* gq, ttk_stream_t stream);
+/* 6D-rotation variants (--enable-6drot): Rot6dReprLoss 0.75 - 0.25 tr(R T^T), T = tomatrix(target quaternion)
+ * (losses.py:53-58, torch6drotation.py:68-72); Rot6dNormalizationSoftConstraint mean((M M^T - I_2)^2) on the raw 6D
+ * features (losses.py:61-64, torch6drotation.py:20-24); Mat33Repr.as_quat = torchquaternion.from_matrix (:94-168:
+ * best-conditioned of four candidates, positivereal) - used by QuatPoseNLLLoss and the eval-mode `pose` output. */
+int ttk_loss_rot6d_fwd(const float* R, const float* t, int n, float* v, ttk_stream_t stream);
+int ttk_loss_rot6d_bwd(const float* t, const float* gv, int n, float* gR, ttk_stream_t stream);
+int ttk_loss_ortho6d_fwd(const float* z6, int n, float* v, ttk_stream_t stream);
+int ttk_loss_ortho6d_bwd(const float* z6, const float* gv, int n, float* gz6, ttk_stream_t stream);
+int ttk_mat_to_quat_fwd(const float* m, int n, float* q, ttk_stream_t stream);
+int ttk_mat_to_quat_bwd(const float* m, const float* gq, int n, float* gm, ttk_stream_t stream);
 int ttk_loss_quatreg_fwd(const float* q, int n, float* v, ttk_stream_t stream);
 int ttk_loss_quatreg_bwd(const float* q, const float* gv, int n, float* gq, ttk_stream_t stream);
 int ttk_loss_mse_rows_fwd(const float* p, const float* t, int n, int D, float* v, ttk_stream_t stream);

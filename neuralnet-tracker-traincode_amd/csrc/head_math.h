@@ -27,15 +27,16 @@ enum : int {
   Z_BOX = 0,    // 4: boxnet.linear
   Z_XY = 4,     // 2: posnet.linear_xy
   Z_SIZE = 6,   // 1: posnet.linear_size
-  Z_QUAT = 7,   // 4: quatnet.linear
-  Z_BASE = 11,  // rows present in every configuration
+  Z_QUAT = 7,   // 4: quatnet.linear (DirectQuaternionWithNormalization) or 6 (RotRepr6dWithNormalization)
+  Z_BASE = 11,  // rows present in every quaternion configuration (13 with the 6D head)
   // with uncertainty: +7 posnet.scales.neck.lin, +7 quatnet.uncertainty_net.neck.lin
   // with point head : +50 landmarks.shapenet (after the uncertainty rows)
 };
-TTK_HD int z_coord_scale(bool) { return Z_BASE; }
-TTK_HD int z_pose_scale(bool) { return Z_BASE + 7; }
-TTK_HD int z_shape(bool unc) { return Z_BASE + (unc ? 14 : 0); }
-TTK_HD int z_count(bool unc, bool pt) { return Z_BASE + (unc ? 14 : 0) + (pt ? 50 : 0); }
+TTK_HD int z_base(bool rot6d) { return rot6d ? Z_BASE + 2 : Z_BASE; }
+TTK_HD int z_coord_scale(bool, bool rot6d = false) { return z_base(rot6d); }
+TTK_HD int z_pose_scale(bool, bool rot6d = false) { return z_base(rot6d) + 7; }
+TTK_HD int z_shape(bool unc, bool rot6d = false) { return z_base(rot6d) + (unc ? 14 : 0); }
+TTK_HD int z_count(bool unc, bool pt, bool rot6d = false) { return z_base(rot6d) + (unc ? 14 : 0) + (pt ? 50 : 0); }
 
 struct Q {
   float i, j, k, w;
@@ -244,6 +245,209 @@ TTK_HD void sample_bwd_core(const float* z, bool unc, bool pt, bool use_offset, 
   if (unc) {
     tri_scale_bwd(z + z_coord_scale(unc), g.Lc, gz + z_coord_scale(unc));
     tri_scale_bwd(z + z_pose_scale(unc), g.Lr, gz + z_pose_scale(unc));
+  }
+}
+
+// =====================================================================================================
+// 6D rotation head (RotRepr6dWithNormalization, models.py:153-174): rotations are 3x3 matrices (row-major
+// float[9]) instead of quaternions.  neuralnets/torch6drotation.py:27-49 (tomatrix), rotrepr.py:63-98 (Mat33Repr).
+// =====================================================================================================
+TTK_HD void v3cross(const float a[3], const float b[3], float r[3]) {
+  r[0] = a[1] * b[2] - a[2] * b[1];
+  r[1] = a[2] * b[0] - a[0] * b[2];
+  r[2] = a[0] * b[1] - a[1] * b[0];
+}
+TTK_HD float v3dot(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+// F.normalize(v, eps=1e-6): v / max(|v|, eps)
+TTK_HD void v3normalize(const float v[3], float u[3]) {
+  const float inv = 1.f / fmaxf(sqrtf(v3dot(v, v)), 1.0e-6f);
+  u[0] = v[0] * inv; u[1] = v[1] * inv; u[2] = v[2] * inv;
+}
+TTK_HD void v3normalize_bwd(const float v[3], const float g[3], float gv[3]) {
+  const float n = sqrtf(v3dot(v, v));
+  if (n > 1.0e-6f) {
+    const float inv = 1.f / n, u[3] = {v[0] * inv, v[1] * inv, v[2] * inv};
+    const float d = v3dot(u, g);
+    for (int i = 0; i < 3; ++i) gv[i] = (g[i] - u[i] * d) * inv;
+  } else {
+    for (int i = 0; i < 3; ++i) gv[i] = g[i] * 1.0e6f;
+  }
+}
+TTK_HD void m3mul(const float a[9], const float b[9], float c[9]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+TTK_HD void m3vec(const float a[9], const float v[3], float r[3]) {
+  for (int i = 0; i < 3; ++i) r[i] = a[3 * i] * v[0] + a[3 * i + 1] * v[1] + a[3 * i + 2] * v[2];
+}
+TTK_HD void m3tvec(const float a[9], const float v[3], float r[3]) {  // a^T v
+  for (int j = 0; j < 3; ++j) r[j] = a[j] * v[0] + a[3 + j] * v[1] + a[6 + j] * v[2];
+}
+
+// z[6] -> R: rows x/|x|, ((x X y) X x)/|.|, (x X y)/|.|; identity if max|R R^T - I| > 1e-3.  Returns whether the
+// identity fallback was taken (then no gradient flows to z through R).
+TTK_HD bool rot6d_fwd(const float z[6], float R[9]) {
+  const float* x = z;
+  const float* y = z + 3;
+  float c[3], y2[3];
+  v3cross(x, y, c);
+  v3cross(c, x, y2);
+  v3normalize(x, R);
+  v3normalize(y2, R + 3);
+  v3normalize(c, R + 6);
+  float bad = 0.f;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) bad = fmaxf(bad, fabsf(v3dot(R + 3 * i, R + 3 * j) - (i == j ? 1.f : 0.f)));
+  if (bad > 1.0e-3f) {
+    for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.f : 0.f;
+    return true;
+  }
+  return false;
+}
+// gR: grad w.r.t. R; gdirect: grad w.r.t. the `unnormalized_6drepr` output (= z itself)
+TTK_HD void rot6d_bwd(const float z[6], const float gR[9], const float gdirect[6], float gz[6]) {
+  for (int i = 0; i < 6; ++i) gz[i] = gdirect[i];
+  float R[9];
+  if (rot6d_fwd(z, R)) return;
+  const float* x = z;
+  const float* y = z + 3;
+  float c[3], y2[3], gx[3], gy2[3], gc[3], t[3];
+  v3cross(x, y, c);
+  v3cross(c, x, y2);
+  v3normalize_bwd(x, gR, gx);
+  v3normalize_bwd(y2, gR + 3, gy2);
+  v3normalize_bwd(c, gR + 6, gc);
+  // y2 = c X x: d/dc = x X g, d/dx = g X c
+  v3cross(x, gy2, t);
+  for (int i = 0; i < 3; ++i) gc[i] += t[i];
+  v3cross(gy2, c, t);
+  for (int i = 0; i < 3; ++i) gx[i] += t[i];
+  // c = x X y: d/dx = y X g, d/dy = g X x
+  v3cross(y, gc, t);
+  for (int i = 0; i < 3; ++i) gx[i] += t[i];
+  v3cross(gc, x, t);
+  for (int i = 0; i < 3; ++i) { gz[i] += gx[i]; gz[3 + i] += t[i]; }
+}
+
+// LocalToGlobalCoordinateOffset with Mat33Repr (modelcomponents.py:136-184; make_rotate_x: rotrepr.py:73-85, FULL angle)
+TTK_HD void offset_fwd_m(const float p[4], const float hR[9], const float hc[3], float R[9], float c[3]) {
+  const float sn = sinf(p[1]), cs = cosf(p[1]);
+  const float Rx[9] = {1.f, 0.f, 0.f, 0.f, cs, -sn, 0.f, sn, cs};
+  const float t[3] = {0.f, p[1], p[2]};
+  const float size = hc[2] * elu1(p[3]);
+  m3mul(hR, Rx, R);
+  float r[3];
+  m3vec(hR, t, r);
+  c[0] = hc[0] + r[0] * size;
+  c[1] = hc[1] + r[1] * size;
+  c[2] = size;
+}
+// accumulates into ghR[9], ghc[3], gp[4]
+TTK_HD void offset_bwd_m(const float p[4], const float hR[9], const float hc[3], const float gR[9], const float gc[3],
+                         float ghR[9], float ghc[3], float gp[4]) {
+  const float sn = sinf(p[1]), cs = cosf(p[1]);
+  const float Rx[9] = {1.f, 0.f, 0.f, 0.f, cs, -sn, 0.f, sn, cs};
+  const float t[3] = {0.f, p[1], p[2]};
+  const float so = elu1(p[3]);
+  const float size = hc[2] * so;
+  float r[3];
+  m3vec(hR, t, r);
+  const float gsize = gc[2] + gc[0] * r[0] + gc[1] * r[1];
+  const float gr[3] = {gc[0] * size, gc[1] * size, 0.f};
+  ghc[0] += gc[0];
+  ghc[1] += gc[1];
+  ghc[2] += gsize * so;
+  gp[3] += gsize * hc[2] * elu1_d(p[3]);
+  // R = hR Rx: ghR += gR Rx^T ; gRx = hR^T gR
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float a = 0.f;
+      for (int k = 0; k < 3; ++k) a += gR[3 * i + k] * Rx[3 * j + k];
+      ghR[3 * i + j] += a;
+    }
+  float gRx[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) gRx[3 * i + j] = hR[i] * gR[j] + hR[3 + i] * gR[3 + j] + hR[6 + i] * gR[6 + j];
+  gp[1] += gRx[4] * (-sn) + gRx[5] * (-cs) + gRx[7] * cs + gRx[8] * (-sn);
+  // r = hR t
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) ghR[3 * i + j] += gr[i] * t[j];
+  float gt[3];
+  m3tvec(hR, gr, gt);
+  gp[1] += gt[1];
+  gp[2] += gt[2];
+}
+
+TTK_HD void landmark_fwd_m(const float Rk[9], const float ck[3], const float local[3], float out[3]) {
+  float r[3];
+  m3vec(Rk, local, r);
+  out[0] = r[0] * ck[2] + ck[0];
+  out[1] = r[1] * ck[2] + ck[1];
+  out[2] = r[2] * ck[2];
+}
+// accumulates gRk[9], gck[3]; writes glocal[3]
+TTK_HD void landmark_bwd_m(const float Rk[9], const float ck[3], const float local[3], const float g[3], float gRk[9],
+                           float gck[3], float glocal[3]) {
+  float r[3];
+  m3vec(Rk, local, r);
+  gck[0] += g[0];
+  gck[1] += g[1];
+  gck[2] += g[0] * r[0] + g[1] * r[1] + g[2] * r[2];
+  const float gr[3] = {g[0] * ck[2], g[1] * ck[2], g[2] * ck[2]};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) gRk[3 * i + j] += gr[i] * local[j];
+  m3tvec(Rk, gr, glocal);
+}
+
+struct HeadOutM {
+  float roi[4], coord[3], Lc[9], Lr[9], ck[3];
+  float rot[9], Rk[9];
+};
+TTK_HD void sample_fwd_core_m(const float* z, bool unc, bool pt, bool use_offset, const float* p, const float* pk,
+                              HeadOutM& o) {
+  box_fwd(z + Z_BOX, o.roi);
+  const float hc[3] = {z[Z_XY], z[Z_XY + 1], elu1(z[Z_SIZE])};
+  float hR[9];
+  rot6d_fwd(z + Z_QUAT, hR);
+  if (unc) {
+    tri_scale_fwd(z + z_coord_scale(unc, true), o.Lc);
+    tri_scale_fwd(z + z_pose_scale(unc, true), o.Lr);
+  }
+  if (use_offset) {
+    offset_fwd_m(p, hR, hc, o.rot, o.coord);
+    if (pt) offset_fwd_m(pk, hR, hc, o.Rk, o.ck);
+  } else {
+    for (int i = 0; i < 9; ++i) { o.rot[i] = hR[i]; o.Rk[i] = hR[i]; }
+    for (int i = 0; i < 3; ++i) { o.coord[i] = hc[i]; o.ck[i] = hc[i]; }
+  }
+}
+struct HeadGradM {
+  float roi[4], coord[3], Lc[9], Lr[9], ck[3];
+  float rot[9], z6[6], Rk[9];
+};
+// Writes gz[0 .. z_shape(unc, true)); accumulates gp[4], gpk[4].
+TTK_HD void sample_bwd_core_m(const float* z, bool unc, bool pt, bool use_offset, const float* p, const float* pk,
+                              const HeadGradM& g, float* gz, float gp[4], float gpk[4]) {
+  box_bwd(z + Z_BOX, g.roi, gz + Z_BOX);
+  const float hc[3] = {z[Z_XY], z[Z_XY + 1], elu1(z[Z_SIZE])};
+  float hR[9];
+  rot6d_fwd(z + Z_QUAT, hR);
+  float ghR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float ghc[3] = {0.f, 0.f, 0.f};
+  if (use_offset) {
+    offset_bwd_m(p, hR, hc, g.rot, g.coord, ghR, ghc, gp);
+    if (pt) offset_bwd_m(pk, hR, hc, g.Rk, g.ck, ghR, ghc, gpk);
+  } else {
+    for (int i = 0; i < 9; ++i) ghR[i] = g.rot[i] + g.Rk[i];
+    for (int i = 0; i < 3; ++i) ghc[i] = g.coord[i] + g.ck[i];
+  }
+  gz[Z_XY] = ghc[0];
+  gz[Z_XY + 1] = ghc[1];
+  gz[Z_SIZE] = ghc[2] * elu1_d(z[Z_SIZE]);
+  rot6d_bwd(z + Z_QUAT, ghR, g.z6, gz + Z_QUAT);
+  if (unc) {
+    tri_scale_bwd(z + z_coord_scale(unc, true), g.Lc, gz + z_coord_scale(unc, true));
+    tri_scale_bwd(z + z_pose_scale(unc, true), g.Lr, gz + z_pose_scale(unc, true));
   }
 }
 

@@ -20,8 +20,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 struct HeadsArgs {
   const float *feat, *wcat, *bcat, *P, *Pk, *kp, *eig;
   const int* ids;
-  int B, F, NZ, unc, pt, use_offset;
+  int B, F, NZ, unc, pt, use_offset, rot6d;
 };
+
+// P = keypt + sum_i eig_i * shapeparam_i of landmark p (DeformableHeadKeypoints, modelcomponents.py:59-82)
+__device__ __forceinline__ void landmark_local(const HeadsArgs& a, const float* sh, int p, float local[3]) {
+  local[0] = a.kp[p * 3]; local[1] = a.kp[p * 3 + 1]; local[2] = a.kp[p * 3 + 2];
+  for (int i = 0; i < 50; ++i) {
+    const float* e = a.eig + ((size_t)i * 68 + p) * 3;
+    const float c = sh[i];
+    local[0] = fmaf(e[0], c, local[0]); local[1] = fmaf(e[1], c, local[1]); local[2] = fmaf(e[2], c, local[2]);
+  }
+}
 
 __global__ void __launch_bounds__(kBlock) heads_fwd_k(HeadsArgs a, float* __restrict__ z, float* __restrict__ roi,
                                                        float* __restrict__ coord, float* __restrict__ rot,
@@ -50,31 +60,48 @@ __global__ void __launch_bounds__(kBlock) heads_fwd_k(HeadsArgs a, float* __rest
   __builtin_amdgcn_wave_barrier();
   const float* zz = zs[wv];
   const int id = a.ids ? a.ids[s] : 0;
-  hm::HeadOut o;
-  hm::sample_fwd_core(zz, a.unc, a.pt, a.use_offset, a.P ? a.P + 4 * id : nullptr, a.Pk ? a.Pk + 4 * id : nullptr, o);
-  if (lane == 0) {
-    for (int i = 0; i < 4; ++i) roi[4 * s + i] = o.roi[i];
-    for (int i = 0; i < 3; ++i) coord[3 * s + i] = o.coord[i];
-    rot[4 * s] = o.rot.i; rot[4 * s + 1] = o.rot.j; rot[4 * s + 2] = o.rot.k; rot[4 * s + 3] = o.rot.w;
-    qu[4 * s] = o.qu.i; qu[4 * s + 1] = o.qu.j; qu[4 * s + 2] = o.qu.k; qu[4 * s + 3] = o.qu.w;
-    if (a.unc)
-      for (int i = 0; i < 9; ++i) { Lc[9 * s + i] = o.Lc[i]; Lr[9 * s + i] = o.Lr[i]; }
-  }
-  if (a.pt) {
-    const float* sh = zz + hm::z_shape(a.unc);
-    if (lane < 50) shp[50 * s + lane] = sh[lane];
-    for (int p = lane; p < 68; p += 64) {
-      float local[3] = {a.kp[p * 3], a.kp[p * 3 + 1], a.kp[p * 3 + 2]};
-      for (int i = 0; i < 50; ++i) {
-        const float* e = a.eig + ((size_t)i * 68 + p) * 3;
-        const float c = sh[i];
-        local[0] = fmaf(e[0], c, local[0]); local[1] = fmaf(e[1], c, local[1]); local[2] = fmaf(e[2], c, local[2]);
-      }
-      float out[3];
-      hm::landmark_fwd(o.qk, o.ck, local, out);
-      float* d = pts + ((size_t)s * 68 + p) * 3;
-      d[0] = out[0]; d[1] = out[1]; d[2] = out[2];
+  const float* prow = a.P ? a.P + 4 * id : nullptr;
+  const float* pkrow = a.Pk ? a.Pk + 4 * id : nullptr;
+  const float* sh = zz + hm::z_shape(a.unc, a.rot6d);
+  if (a.pt && lane < 50) shp[50 * s + lane] = sh[lane];
+  if (!a.rot6d) {
+    hm::HeadOut o;
+    hm::sample_fwd_core(zz, a.unc, a.pt, a.use_offset, prow, pkrow, o);
+    if (lane == 0) {
+      for (int i = 0; i < 4; ++i) roi[4 * s + i] = o.roi[i];
+      for (int i = 0; i < 3; ++i) coord[3 * s + i] = o.coord[i];
+      rot[4 * s] = o.rot.i; rot[4 * s + 1] = o.rot.j; rot[4 * s + 2] = o.rot.k; rot[4 * s + 3] = o.rot.w;
+      qu[4 * s] = o.qu.i; qu[4 * s + 1] = o.qu.j; qu[4 * s + 2] = o.qu.k; qu[4 * s + 3] = o.qu.w;
+      if (a.unc)
+        for (int i = 0; i < 9; ++i) { Lc[9 * s + i] = o.Lc[i]; Lr[9 * s + i] = o.Lr[i]; }
     }
+    if (a.pt)
+      for (int p = lane; p < 68; p += 64) {
+        float local[3], out[3];
+        landmark_local(a, sh, p, local);
+        hm::landmark_fwd(o.qk, o.ck, local, out);
+        float* d = pts + ((size_t)s * 68 + p) * 3;
+        d[0] = out[0]; d[1] = out[1]; d[2] = out[2];
+      }
+  } else {  // 6D rotation head: rot[B][9] row-major matrices, qu[B][6] = the raw 6D features
+    hm::HeadOutM o;
+    hm::sample_fwd_core_m(zz, a.unc, a.pt, a.use_offset, prow, pkrow, o);
+    if (lane == 0) {
+      for (int i = 0; i < 4; ++i) roi[4 * s + i] = o.roi[i];
+      for (int i = 0; i < 3; ++i) coord[3 * s + i] = o.coord[i];
+      for (int i = 0; i < 9; ++i) rot[9 * s + i] = o.rot[i];
+      for (int i = 0; i < 6; ++i) qu[6 * s + i] = zz[hm::Z_QUAT + i];
+      if (a.unc)
+        for (int i = 0; i < 9; ++i) { Lc[9 * s + i] = o.Lc[i]; Lr[9 * s + i] = o.Lr[i]; }
+    }
+    if (a.pt)
+      for (int p = lane; p < 68; p += 64) {
+        float local[3], out[3];
+        landmark_local(a, sh, p, local);
+        hm::landmark_fwd_m(o.Rk, o.ck, local, out);
+        float* d = pts + ((size_t)s * 68 + p) * 3;
+        d[0] = out[0]; d[1] = out[1]; d[2] = out[2];
+      }
   }
 }
 
@@ -83,6 +110,21 @@ struct HeadsGradIn {
 };
 
 // per-sample backward: dz[B][NZ], dprow[B][8] (gradients w.r.t. this sample's rows of p and p_kpts)
+// shared tail of the per-sample backward: d shapeparam_i = sum_p <glocal_p, eig_i,p> + direct gradient
+__device__ __forceinline__ void shape_grad(const HeadsArgs& a, const float (*gl)[3], const float* g_shp, int s, int lane, float* dzs,
+                                           int zshape) {
+  for (int i = 0; i < 50; ++i) {
+    float acc = 0.f;
+    int q = 0;
+    for (int pnt = lane; pnt < 68; pnt += 64, ++q) {
+      const float* e = a.eig + ((size_t)i * 68 + pnt) * 3;
+      acc += gl[q][0] * e[0] + gl[q][1] * e[1] + gl[q][2] * e[2];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) dzs[zshape + i] = acc + g_shp[50 * s + i];
+  }
+}
+
 __global__ void __launch_bounds__(kBlock) heads_bwd_sample_k(HeadsArgs a, const float* __restrict__ z, HeadsGradIn g,
                                                               float* __restrict__ dz, float* __restrict__ dprow) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -92,51 +134,62 @@ __global__ void __launch_bounds__(kBlock) heads_bwd_sample_k(HeadsArgs a, const 
   const int id = a.ids ? a.ids[s] : 0;
   const float* p = a.P ? a.P + 4 * id : nullptr;
   const float* pk = a.Pk ? a.Pk + 4 * id : nullptr;
-  hm::HeadOut o;
-  hm::sample_fwd_core(zz, a.unc, a.pt, a.use_offset, p, pk, o);
-  hm::HeadGrad hg;
-  for (int i = 0; i < 4; ++i) hg.roi[i] = g.roi[4 * s + i];
-  for (int i = 0; i < 3; ++i) { hg.coord[i] = g.coord[3 * s + i]; hg.ck[i] = 0.f; }
-  hg.rot = Q{g.rot[4 * s], g.rot[4 * s + 1], g.rot[4 * s + 2], g.rot[4 * s + 3]};
-  hg.qu = Q{g.qu[4 * s], g.qu[4 * s + 1], g.qu[4 * s + 2], g.qu[4 * s + 3]};
-  hg.qk = Q{0.f, 0.f, 0.f, 0.f};
-  for (int i = 0; i < 9; ++i) { hg.Lc[i] = a.unc ? g.Lc[9 * s + i] : 0.f; hg.Lr[i] = a.unc ? g.Lr[9 * s + i] : 0.f; }
   float* dzs = dz + (size_t)s * a.NZ;
-  if (a.pt) {
-    const float* sh = zz + hm::z_shape(a.unc);
-    Q gqk{0.f, 0.f, 0.f, 0.f};
-    float gck[3] = {0.f, 0.f, 0.f};
-    float gl[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    int np = 0;
-    for (int pnt = lane; pnt < 68; pnt += 64, ++np) {
-      float local[3] = {a.kp[pnt * 3], a.kp[pnt * 3 + 1], a.kp[pnt * 3 + 2]};
-      for (int i = 0; i < 50; ++i) {
-        const float* e = a.eig + ((size_t)i * 68 + pnt) * 3;
-        const float c = sh[i];
-        local[0] = fmaf(e[0], c, local[0]); local[1] = fmaf(e[1], c, local[1]); local[2] = fmaf(e[2], c, local[2]);
+  const int zshape = hm::z_shape(a.unc, a.rot6d);
+  const float* sh = zz + zshape;
+  float gl[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  float gz[hm::Z_BASE + 2 + 14];
+  float gp[4] = {0.f, 0.f, 0.f, 0.f}, gpk[4] = {0.f, 0.f, 0.f, 0.f};
+  if (!a.rot6d) {
+    hm::HeadOut o;
+    hm::sample_fwd_core(zz, a.unc, a.pt, a.use_offset, p, pk, o);
+    hm::HeadGrad hg;
+    for (int i = 0; i < 4; ++i) hg.roi[i] = g.roi[4 * s + i];
+    for (int i = 0; i < 3; ++i) { hg.coord[i] = g.coord[3 * s + i]; hg.ck[i] = 0.f; }
+    hg.rot = Q{g.rot[4 * s], g.rot[4 * s + 1], g.rot[4 * s + 2], g.rot[4 * s + 3]};
+    hg.qu = Q{g.qu[4 * s], g.qu[4 * s + 1], g.qu[4 * s + 2], g.qu[4 * s + 3]};
+    hg.qk = Q{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 9; ++i) { hg.Lc[i] = a.unc ? g.Lc[9 * s + i] : 0.f; hg.Lr[i] = a.unc ? g.Lr[9 * s + i] : 0.f; }
+    if (a.pt) {
+      Q gqk{0.f, 0.f, 0.f, 0.f};
+      float gck[3] = {0.f, 0.f, 0.f};
+      int np = 0;
+      for (int pnt = lane; pnt < 68; pnt += 64, ++np) {
+        float local[3];
+        landmark_local(a, sh, pnt, local);
+        hm::landmark_bwd(o.qk, o.ck, local, g.pts + ((size_t)s * 68 + pnt) * 3, gqk, gck, gl[np]);
       }
-      hm::landmark_bwd(o.qk, o.ck, local, g.pts + ((size_t)s * 68 + pnt) * 3, gqk, gck, gl[np]);
+      shape_grad(a, gl, g.shp, s, lane, dzs, zshape);
+      hg.qk = Q{wave_sum(gqk.i), wave_sum(gqk.j), wave_sum(gqk.k), wave_sum(gqk.w)};
+      for (int i = 0; i < 3; ++i) hg.ck[i] = wave_sum(gck[i]);
     }
-    // d shapeparam_i = sum_p <glocal_p, eig_i,p> + direct gradient
-    for (int i = 0; i < 50; ++i) {
-      float acc = 0.f;
-      int q = 0;
-      for (int pnt = lane; pnt < 68; pnt += 64, ++q) {
-        const float* e = a.eig + ((size_t)i * 68 + pnt) * 3;
-        acc += gl[q][0] * e[0] + gl[q][1] * e[1] + gl[q][2] * e[2];
+    if (lane == 0) hm::sample_bwd_core(zz, a.unc, a.pt, a.use_offset, p, pk, hg, gz, gp, gpk);
+  } else {
+    hm::HeadOutM o;
+    hm::sample_fwd_core_m(zz, a.unc, a.pt, a.use_offset, p, pk, o);
+    hm::HeadGradM hg;
+    for (int i = 0; i < 4; ++i) hg.roi[i] = g.roi[4 * s + i];
+    for (int i = 0; i < 3; ++i) { hg.coord[i] = g.coord[3 * s + i]; hg.ck[i] = 0.f; }
+    for (int i = 0; i < 9; ++i) { hg.rot[i] = g.rot[9 * s + i]; hg.Rk[i] = 0.f; }
+    for (int i = 0; i < 6; ++i) hg.z6[i] = g.qu[6 * s + i];
+    for (int i = 0; i < 9; ++i) { hg.Lc[i] = a.unc ? g.Lc[9 * s + i] : 0.f; hg.Lr[i] = a.unc ? g.Lr[9 * s + i] : 0.f; }
+    if (a.pt) {
+      float gRk[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float gck[3] = {0.f, 0.f, 0.f};
+      int np = 0;
+      for (int pnt = lane; pnt < 68; pnt += 64, ++np) {
+        float local[3];
+        landmark_local(a, sh, pnt, local);
+        hm::landmark_bwd_m(o.Rk, o.ck, local, g.pts + ((size_t)s * 68 + pnt) * 3, gRk, gck, gl[np]);
       }
-      acc = wave_sum(acc);
-      if (lane == 0) dzs[hm::z_shape(a.unc) + i] = acc + g.shp[50 * s + i];
+      shape_grad(a, gl, g.shp, s, lane, dzs, zshape);
+      for (int i = 0; i < 9; ++i) hg.Rk[i] = wave_sum(gRk[i]);
+      for (int i = 0; i < 3; ++i) hg.ck[i] = wave_sum(gck[i]);
     }
-    hg.qk = Q{wave_sum(gqk.i), wave_sum(gqk.j), wave_sum(gqk.k), wave_sum(gqk.w)};
-    for (int i = 0; i < 3; ++i) hg.ck[i] = wave_sum(gck[i]);
+    if (lane == 0) hm::sample_bwd_core_m(zz, a.unc, a.pt, a.use_offset, p, pk, hg, gz, gp, gpk);
   }
   if (lane == 0) {
-    float gz[hm::Z_BASE + 14];
-    float gp[4] = {0.f, 0.f, 0.f, 0.f}, gpk[4] = {0.f, 0.f, 0.f, 0.f};
-    hm::sample_bwd_core(zz, a.unc, a.pt, a.use_offset, p, pk, hg, gz, gp, gpk);
-    const int nb = hm::z_shape(a.unc);
-    for (int i = 0; i < nb; ++i) dzs[i] = gz[i];
+    for (int i = 0; i < zshape; ++i) dzs[i] = gz[i];
     for (int i = 0; i < 4; ++i) { dprow[8 * s + i] = gp[i]; dprow[8 * s + 4 + i] = gpk[i]; }
   }
 }
@@ -217,9 +270,9 @@ __global__ void diag_scale_bwd_k(const float* h, const float* g, float* gh, int 
 
 using namespace ttk;
 
-static int heads_check(const char* name, int B, int F, int NZ, int unc, int pt) {
-  if (B <= 0 || F <= 0 || (F & 3) || NZ != hm::z_count(unc, pt) || NZ > kMaxZ) {
-    set_error("%s: bad sizes B=%d F=%d (NZ=%d expected %d)", name, B, F, NZ, hm::z_count(unc, pt));
+static int heads_check(const char* name, int B, int F, int NZ, int unc, int pt, int rot6d) {
+  if (B <= 0 || F <= 0 || (F & 3) || NZ != hm::z_count(unc, pt, rot6d) || NZ > kMaxZ) {
+    set_error("%s: bad sizes B=%d F=%d (NZ=%d expected %d)", name, B, F, NZ, hm::z_count(unc, pt, rot6d));
     return -1;
   }
   return 0;
@@ -227,18 +280,20 @@ static int heads_check(const char* name, int B, int F, int NZ, int unc, int pt) 
 
 extern "C" {
 
-int ttk_heads_num_rows(int enable_uncertainty, int enable_point_head) { return hm::z_count(enable_uncertainty, enable_point_head); }
+int ttk_heads_num_rows(int enable_uncertainty, int enable_point_head, int enable_6drot) {
+  return hm::z_count(enable_uncertainty, enable_point_head, enable_6drot);
+}
 
 int ttk_heads_fwd(const float* feat, const float* wcat, const float* bcat, const int* ids, const float* P, const float* Pk,
                   const float* keypts, const float* keyeig, int B, int F, int NZ, int enable_uncertainty, int enable_point_head,
-                  int use_offset, float* z, float* roi, float* coord, float* rot, float* qu, float* Lc, float* Lr, float* pts,
-                  float* shp, ttk_stream_t stream) {
-  if (heads_check("heads_fwd", B, F, NZ, enable_uncertainty, enable_point_head)) return -1;
+                  int use_offset, int enable_6drot, float* z, float* roi, float* coord, float* rot, float* qu, float* Lc, float* Lr,
+                  float* pts, float* shp, ttk_stream_t stream) {
+  if (heads_check("heads_fwd", B, F, NZ, enable_uncertainty, enable_point_head, enable_6drot)) return -1;
   TTK_REQUIRE(feat && wcat && bcat && z && roi && coord && rot && qu, "heads_fwd: null pointer");
   TTK_REQUIRE(!enable_uncertainty || (Lc && Lr), "heads_fwd: uncertainty outputs missing");
   TTK_REQUIRE(!enable_point_head || (pts && shp && keypts && keyeig), "heads_fwd: point-head buffers missing");
   TTK_REQUIRE(!use_offset || (P && (!enable_point_head || Pk)), "heads_fwd: local pose offset parameters missing");
-  HeadsArgs a{feat, wcat, bcat, P, Pk, keypts, keyeig, ids, B, F, NZ, enable_uncertainty, enable_point_head, use_offset};
+  HeadsArgs a{feat, wcat, bcat, P, Pk, keypts, keyeig, ids, B, F, NZ, enable_uncertainty, enable_point_head, use_offset, enable_6drot};
   hipLaunchKernelGGL(heads_fwd_k, dim3((B + 3) / 4), dim3(kBlock), 0, (hipStream_t)stream, a, z, roi, coord, rot, qu, Lc, Lr,
                      pts, shp);
   TTK_LAUNCH_CHECK("heads_fwd");
@@ -246,15 +301,15 @@ int ttk_heads_fwd(const float* feat, const float* wcat, const float* bcat, const
 
 int ttk_heads_bwd(const float* feat, const float* wcat, const float* z, const int* ids, const float* P, const float* Pk,
                   const float* keypts, const float* keyeig, int B, int F, int NZ, int enable_uncertainty, int enable_point_head,
-                  int use_offset, const float* g_roi, const float* g_coord, const float* g_rot, const float* g_qu,
+                  int use_offset, int enable_6drot, const float* g_roi, const float* g_coord, const float* g_rot, const float* g_qu,
                   const float* g_Lc, const float* g_Lr, const float* g_pts, const float* g_shp, float* dz, float* dprow,
                   float* dfeat, float* dwcat, float* dbcat, float* dP, float* dPk, ttk_stream_t stream) {
-  if (heads_check("heads_bwd", B, F, NZ, enable_uncertainty, enable_point_head)) return -1;
+  if (heads_check("heads_bwd", B, F, NZ, enable_uncertainty, enable_point_head, enable_6drot)) return -1;
   TTK_REQUIRE(feat && wcat && z && g_roi && g_coord && g_rot && g_qu && dz && dprow && dfeat && dwcat && dbcat, "heads_bwd: null pointer");
   TTK_REQUIRE(!enable_uncertainty || (g_Lc && g_Lr), "heads_bwd: uncertainty gradients missing");
   TTK_REQUIRE(!enable_point_head || (g_pts && g_shp && keypts && keyeig), "heads_bwd: point-head gradients missing");
   hipStream_t st = (hipStream_t)stream;
-  HeadsArgs a{feat, wcat, nullptr, P, Pk, keypts, keyeig, ids, B, F, NZ, enable_uncertainty, enable_point_head, use_offset};
+  HeadsArgs a{feat, wcat, nullptr, P, Pk, keypts, keyeig, ids, B, F, NZ, enable_uncertainty, enable_point_head, use_offset, enable_6drot};
   HeadsGradIn g{g_roi, g_coord, g_rot, g_qu, g_Lc, g_Lr, g_pts, g_shp};
   hipLaunchKernelGGL(heads_bwd_sample_k, dim3((B + 3) / 4), dim3(kBlock), 0, st, a, z, g, dz, dprow);
   const int64_t nf = (int64_t)B * (F / 4), nw = (int64_t)NZ * (F / 4);

@@ -187,5 +187,113 @@ TTK_HD double gmm_nll(const float x[50], const double* ck, const double* mu, con
   return -(mx + log(s)) * fudge;
 }
 
+// =====================================================================================================
+// 6D-rotation variants (losses.py:53-64, torch6drotation.py:20-24,68-72, torchquaternion.py:70-168)
+// =====================================================================================================
+// torchquaternion.tomatrix: unit quaternion (i,j,k,w) -> row-major R
+TTK_HD void quat_to_matrix(const float q[4], float R[9]) {
+  const float qi = q[0], qj = q[1], qk = q[2], qw = q[3];
+  R[0] = 1.f - 2.f * (qj * qj + qk * qk);
+  R[3] = 2.f * (qi * qj + qk * qw);
+  R[6] = 2.f * (qi * qk - qj * qw);
+  R[1] = 2.f * (qi * qj - qk * qw);
+  R[4] = 1.f - 2.f * (qi * qi + qk * qk);
+  R[7] = 2.f * (qj * qk + qi * qw);
+  R[2] = 2.f * (qi * qk + qj * qw);
+  R[5] = 2.f * (qj * qk - qi * qw);
+  R[8] = 1.f - 2.f * (qi * qi + qj * qj);
+}
+// Rot6dReprLoss: 0.75 - 0.25 * trace(R T^T), T = tomatrix(target quaternion)
+TTK_HD float rot6d_loss(const float R[9], const float tq[4]) {
+  float T[9], tr = 0.f;
+  quat_to_matrix(tq, T);
+  for (int i = 0; i < 9; ++i) tr += R[i] * T[i];
+  return 0.75f - 0.25f * tr;
+}
+TTK_HD void rot6d_loss_bwd(const float tq[4], float gv, float gR[9]) {
+  float T[9];
+  quat_to_matrix(tq, T);
+  for (int i = 0; i < 9; ++i) gR[i] = -0.25f * gv * T[i];
+}
+// Rot6dNormalizationSoftConstraint: mean((M M^T - I_2)^2), M = [x; y]
+TTK_HD float ortho6d_loss(const float z[6]) {
+  const float xx = hm::v3dot(z, z) - 1.f, yy = hm::v3dot(z + 3, z + 3) - 1.f, xy = hm::v3dot(z, z + 3);
+  return 0.25f * (xx * xx + yy * yy + 2.f * xy * xy);
+}
+TTK_HD void ortho6d_loss_bwd(const float z[6], float gv, float gz[6]) {
+  const float xx = hm::v3dot(z, z) - 1.f, yy = hm::v3dot(z + 3, z + 3) - 1.f, xy = hm::v3dot(z, z + 3);
+  for (int i = 0; i < 3; ++i) {
+    gz[i] = gv * (xx * z[i] + xy * z[3 + i]);
+    gz[3 + i] = gv * (yy * z[3 + i] + xy * z[i]);
+  }
+}
+
+// torchquaternion.from_matrix (Mat33Repr.as_quat): four candidate solutions, the best-conditioned one (largest
+// square-root argument; ties -> first in the order k, j, i, w) is taken, then positivereal.  Table rows: the
+// component whose square root is taken, the signs of (m00, m11, m22) in its argument, and for the other three
+// components (dst, a, b, sign): q_dst = 0.25 * (m[a] + sign * m[b]) / q_main.
+struct FromMatrixBranch {
+  int main;
+  float sd[3];
+  int dst[3], a[3], b[3];
+  float sg[3];
+};
+TTK_HD FromMatrixBranch from_matrix_branch(int pick) {
+  // m index = 3*row + col
+  switch (pick) {
+    case 0: return {2, {-1.f, -1.f, 1.f}, {3, 0, 1}, {3, 6, 5}, {1, 2, 7}, {-1.f, 1.f, 1.f}};   // from k
+    case 1: return {1, {-1.f, 1.f, -1.f}, {3, 0, 2}, {2, 3, 5}, {6, 1, 7}, {-1.f, 1.f, 1.f}};   // from j
+    case 2: return {0, {1.f, -1.f, -1.f}, {3, 1, 2}, {7, 3, 2}, {5, 1, 6}, {-1.f, 1.f, 1.f}};   // from i
+    default: return {3, {1.f, 1.f, 1.f}, {0, 1, 2}, {7, 2, 3}, {5, 6, 1}, {-1.f, -1.f, -1.f}};  // from w
+  }
+}
+TTK_HD int from_matrix_pick(const float m[9], float args[4]) {
+  const float d0 = m[0], d1 = m[4], d2 = m[8];
+  args[0] = fmaxf(-d0 - d1 + d2 + 1.f, 1.0e-6f);
+  args[1] = fmaxf(-d0 + d1 - d2 + 1.f, 1.0e-6f);
+  args[2] = fmaxf(d0 - d1 - d2 + 1.f, 1.0e-6f);
+  args[3] = fmaxf(d0 + d1 + d2 + 1.f, 1.0e-6f);
+  int pick = 0;
+  for (int i = 1; i < 4; ++i)
+    if (args[i] > args[pick]) pick = i;
+  return pick;
+}
+TTK_HD float sign0(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+TTK_HD void from_matrix(const float m[9], float q[4]) {
+  float args[4];
+  const int pick = from_matrix_pick(m, args);
+  const FromMatrixBranch br = from_matrix_branch(pick);
+  const float qm = 0.5f * sqrtf(args[pick]);
+  q[br.main] = qm;
+  for (int n = 0; n < 3; ++n) q[br.dst[n]] = 0.25f * (m[br.a[n]] + br.sg[n] * m[br.b[n]]) / qm;
+  const float s = sign0(q[3]);
+  for (int i = 0; i < 4; ++i) q[i] *= s;
+}
+TTK_HD void from_matrix_bwd(const float m[9], const float gq[4], float gm[9]) {
+  for (int i = 0; i < 9; ++i) gm[i] = 0.f;
+  float args[4], q[4];
+  const int pick = from_matrix_pick(m, args);
+  const FromMatrixBranch br = from_matrix_branch(pick);
+  const float qm = 0.5f * sqrtf(args[pick]);
+  q[br.main] = qm;
+  for (int n = 0; n < 3; ++n) q[br.dst[n]] = 0.25f * (m[br.a[n]] + br.sg[n] * m[br.b[n]]) / qm;
+  const float s = sign0(q[3]);
+  float gmain = s * gq[br.main];
+  for (int n = 0; n < 3; ++n) {
+    const float g = s * gq[br.dst[n]];
+    gmain -= g * q[br.dst[n]] / qm;
+    const float f = 0.25f * g / qm;
+    gm[br.a[n]] += f;
+    gm[br.b[n]] += br.sg[n] * f;
+  }
+  const float raw = br.sd[0] * m[0] + br.sd[1] * m[4] + br.sd[2] * m[8] + 1.f;
+  if (raw > 1.0e-6f) {  // clamp(min) passes no gradient below the bound
+    const float gS = gmain * 0.125f / qm;
+    gm[0] += br.sd[0] * gS;
+    gm[4] += br.sd[1] * gS;
+    gm[8] += br.sd[2] * gS;
+  }
+}
+
 }  // namespace lm
 }  // namespace ttk

@@ -43,6 +43,30 @@ __global__ void loss_rot_bwd_k(const float* q, const float* t, const float* gv, 
   TTK_SAMPLE_INDEX(n);
   lm::rot_loss_bwd(q + 4 * s, t + 4 * s, gv[s], gq + 4 * s);
 }
+__global__ void loss_rot6d_fwd_k(const float* R, const float* t, int n, float* v) {
+  TTK_SAMPLE_INDEX(n);
+  v[s] = lm::rot6d_loss(R + 9 * s, t + 4 * s);
+}
+__global__ void loss_rot6d_bwd_k(const float* t, const float* gv, int n, float* gR) {
+  TTK_SAMPLE_INDEX(n);
+  lm::rot6d_loss_bwd(t + 4 * s, gv[s], gR + 9 * s);
+}
+__global__ void loss_ortho6d_fwd_k(const float* z, int n, float* v) {
+  TTK_SAMPLE_INDEX(n);
+  v[s] = lm::ortho6d_loss(z + 6 * s);
+}
+__global__ void loss_ortho6d_bwd_k(const float* z, const float* gv, int n, float* gz) {
+  TTK_SAMPLE_INDEX(n);
+  lm::ortho6d_loss_bwd(z + 6 * s, gv[s], gz + 6 * s);
+}
+__global__ void mat_to_quat_fwd_k(const float* m, int n, float* q) {
+  TTK_SAMPLE_INDEX(n);
+  lm::from_matrix(m + 9 * s, q + 4 * s);
+}
+__global__ void mat_to_quat_bwd_k(const float* m, const float* gq, int n, float* gm) {
+  TTK_SAMPLE_INDEX(n);
+  lm::from_matrix_bwd(m + 9 * s, gq + 4 * s, gm + 9 * s);
+}
 __global__ void loss_quatreg_fwd_k(const float* q, int n, float* v) {
   TTK_SAMPLE_INDEX(n);
   v[s] = lm::quatreg_loss(q + 4 * s);
@@ -201,6 +225,36 @@ int ttk_loss_rot_bwd(const float* q, const float* t, const float* gv, int n, flo
   TTK_REQUIRE(q && t && gv && gq && n > 0, "loss_rot_bwd: bad arguments");
   hipLaunchKernelGGL(loss_rot_bwd_k, TTK_GRID(n), q, t, gv, n, gq);
   TTK_LAUNCH_CHECK("loss_rot_bwd");
+}
+int ttk_loss_rot6d_fwd(const float* R, const float* t, int n, float* v, ttk_stream_t stream) {
+  TTK_REQUIRE(R && t && v && n > 0, "loss_rot6d_fwd: bad arguments");
+  hipLaunchKernelGGL(loss_rot6d_fwd_k, TTK_GRID(n), R, t, n, v);
+  TTK_LAUNCH_CHECK("loss_rot6d_fwd");
+}
+int ttk_loss_rot6d_bwd(const float* t, const float* gv, int n, float* gR, ttk_stream_t stream) {
+  TTK_REQUIRE(t && gv && gR && n > 0, "loss_rot6d_bwd: bad arguments");
+  hipLaunchKernelGGL(loss_rot6d_bwd_k, TTK_GRID(n), t, gv, n, gR);
+  TTK_LAUNCH_CHECK("loss_rot6d_bwd");
+}
+int ttk_loss_ortho6d_fwd(const float* z, int n, float* v, ttk_stream_t stream) {
+  TTK_REQUIRE(z && v && n > 0, "loss_ortho6d_fwd: bad arguments");
+  hipLaunchKernelGGL(loss_ortho6d_fwd_k, TTK_GRID(n), z, n, v);
+  TTK_LAUNCH_CHECK("loss_ortho6d_fwd");
+}
+int ttk_loss_ortho6d_bwd(const float* z, const float* gv, int n, float* gz, ttk_stream_t stream) {
+  TTK_REQUIRE(z && gv && gz && n > 0, "loss_ortho6d_bwd: bad arguments");
+  hipLaunchKernelGGL(loss_ortho6d_bwd_k, TTK_GRID(n), z, gv, n, gz);
+  TTK_LAUNCH_CHECK("loss_ortho6d_bwd");
+}
+int ttk_mat_to_quat_fwd(const float* m, int n, float* q, ttk_stream_t stream) {
+  TTK_REQUIRE(m && q && n > 0, "mat_to_quat_fwd: bad arguments");
+  hipLaunchKernelGGL(mat_to_quat_fwd_k, TTK_GRID(n), m, n, q);
+  TTK_LAUNCH_CHECK("mat_to_quat_fwd");
+}
+int ttk_mat_to_quat_bwd(const float* m, const float* gq, int n, float* gm, ttk_stream_t stream) {
+  TTK_REQUIRE(m && gq && gm && n > 0, "mat_to_quat_bwd: bad arguments");
+  hipLaunchKernelGGL(mat_to_quat_bwd_k, TTK_GRID(n), m, gq, n, gm);
+  TTK_LAUNCH_CHECK("mat_to_quat_bwd");
 }
 int ttk_loss_quatreg_fwd(const float* q, int n, float* v, ttk_stream_t stream) {
   TTK_REQUIRE(q && v && n > 0, "loss_quatreg_fwd: bad arguments");

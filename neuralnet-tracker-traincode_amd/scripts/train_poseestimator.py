@@ -64,11 +64,10 @@ def create_optimizer(net, args):
 
 def setup_losses(args, net):
     """Tag -> CriterionGroup tables with the reference's names and weights (:170-285)."""
-    if args.enable_6drot:
-        raise NotImplementedError("--enable-6drot: the 6D rotation head is not built in this round")
     C = train.Criterion
-    rot_loss = losses.QuatPoseLoss("approx_distance")
-    cregularize = [C("quatregularization1", losses.QuaternionNormalizationSoftConstraint(), 1.0e-6)]
+    rot_loss = losses.Rot6dReprLoss() if args.enable_6drot else losses.QuatPoseLoss("approx_distance")
+    rot_constraint = losses.Rot6dNormalizationSoftConstraint() if args.enable_6drot else losses.QuaternionNormalizationSoftConstraint()
+    cregularize = [C("quatregularization1", rot_constraint, 1.0e-6)]
     poselosses, roilosses, pointlosses, pointlosses25d, shapeparamloss = [], [], [], [], []
 
     if args.with_nll_loss:

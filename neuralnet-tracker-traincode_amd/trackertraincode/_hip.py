@@ -33,12 +33,18 @@ _SIGNATURES = {
     "ttk_avgpool_fwd": [_P, _P, _P, _P, _I, _I, _I],
     "ttk_avgpool_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
     "ttk_bn_act": [_P, _P, _P, _P, _L, _I],
-    "ttk_heads_fwd": [_P] * 8 + [_I] * 6 + [_P] * 9,
-    "ttk_heads_bwd": [_P] * 8 + [_I] * 6 + [_P] * 15,
+    "ttk_heads_fwd": [_P] * 8 + [_I] * 7 + [_P] * 9,
+    "ttk_heads_bwd": [_P] * 8 + [_I] * 7 + [_P] * 15,
     "ttk_diag_scale_fwd": [_P, _P, _I],
     "ttk_diag_scale_bwd": [_P, _P, _P, _I],
     "ttk_loss_rot_fwd": [_P, _P, _I, _P],
     "ttk_loss_rot_bwd": [_P, _P, _P, _I, _P],
+    "ttk_loss_rot6d_fwd": [_P, _P, _I, _P],
+    "ttk_loss_rot6d_bwd": [_P, _P, _I, _P],
+    "ttk_loss_ortho6d_fwd": [_P, _I, _P],
+    "ttk_loss_ortho6d_bwd": [_P, _P, _I, _P],
+    "ttk_mat_to_quat_fwd": [_P, _I, _P],
+    "ttk_mat_to_quat_bwd": [_P, _P, _I, _P],
     "ttk_loss_quatreg_fwd": [_P, _I, _P],
     "ttk_loss_quatreg_bwd": [_P, _P, _I, _P],
     "ttk_loss_mse_rows_fwd": [_P, _P, _I, _I, _P],
@@ -60,7 +66,7 @@ _SIGNATURES = {
     "ttk_clip_adam": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _F, _F, _F, _F, _F, _P, _P, _P],
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class _Library:
@@ -80,7 +86,7 @@ class _Library:
         for name in ("ttk_partial_rows_elementwise", "ttk_partial_rows_gemm"):
             fn = getattr(self.cdll, name)
             fn.argtypes, fn.restype = [c_int64], c_int
-        self.cdll.ttk_heads_num_rows.argtypes, self.cdll.ttk_heads_num_rows.restype = [c_int, c_int], c_int
+        self.cdll.ttk_heads_num_rows.argtypes, self.cdll.ttk_heads_num_rows.restype = [c_int, c_int, c_int], c_int
         self.cdll.ttk_partial_rows_dwconv.argtypes, self.cdll.ttk_partial_rows_dwconv.restype = [c_int] * 6, c_int
         self._fns = {}
         for name, sig in _SIGNATURES.items():

@@ -29,7 +29,7 @@ class HeadsFn(Function):
     """feat[B,F] -> (roi, coord, rot, unnormalized_quat[, coord_scales, pose_scales_tril][, pt3d_68, shapeparam])"""
 
     @staticmethod
-    def forward(ctx, feat, ids, unc, pt, use_offset, keypts, keyeig, P, Pk, *lin):
+    def forward(ctx, feat, ids, unc, pt, use_offset, rot6d, keypts, keyeig, P, Pk, *lin):
         feat = _f32c(feat)
         B, F = feat.shape
         ws, bs = [_f32c(w) for w in lin[0::2]], [_f32c(b) for b in lin[1::2]]
@@ -37,7 +37,8 @@ class HeadsFn(Function):
         NZ = wcat.shape[0]
         dev = feat.device
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-        z, roi, coord, rot, qu = new(B, NZ), new(B, 4), new(B, 3), new(B, 4), new(B, 4)
+        z, roi, coord = new(B, NZ), new(B, 4), new(B, 3)
+        rot, qu = (new(B, 3, 3), new(B, 6)) if rot6d else (new(B, 4), new(B, 4))  # 6D head: matrices + raw 6D features
         Lc, Lr = (new(B, 3, 3), new(B, 3, 3)) if unc else (None, None)
         pts, shp = (new(B, 68, 3), new(B, 50)) if pt else (None, None)
         ids32 = None if ids is None else ids.to(device=dev, dtype=torch.int32).contiguous()
@@ -46,9 +47,9 @@ class HeadsFn(Function):
         kp = _f32c(keypts) if pt else None
         ke = _f32c(keyeig) if pt else None
         _call("ttk_heads_fwd", _p(feat), _p(wcat), _p(bcat), _p(ids32), _p(Pc), _p(Pkc), _p(kp), _p(ke), B, F, NZ, int(unc),
-              int(pt), int(use_offset), _p(z), _p(roi), _p(coord), _p(rot), _p(qu), _p(Lc), _p(Lr), _p(pts), _p(shp))
+              int(pt), int(use_offset), int(rot6d), _p(z), _p(roi), _p(coord), _p(rot), _p(qu), _p(Lc), _p(Lr), _p(pts), _p(shp))
         ctx.save_for_backward(feat, wcat, z, ids32, Pc, Pkc, kp, ke)
-        ctx.cfg = (bool(unc), bool(pt), bool(use_offset), [w.shape[0] for w in ws])
+        ctx.cfg = (bool(unc), bool(pt), bool(use_offset), bool(rot6d), [w.shape[0] for w in ws])
         outs = [roi, coord, rot, qu]
         if unc:
             outs += [Lc, Lr]
@@ -59,7 +60,7 @@ class HeadsFn(Function):
     @staticmethod
     def backward(ctx, *gouts):
         feat, wcat, z, ids32, Pc, Pkc, kp, ke = ctx.saved_tensors
-        unc, pt, use_offset, rows = ctx.cfg
+        unc, pt, use_offset, rot6d, rows = ctx.cfg
         B, F = feat.shape
         NZ = wcat.shape[0]
         dev = feat.device
@@ -77,15 +78,15 @@ class HeadsFn(Function):
         dP = new(8, 4) if Pc is not None else None
         dPk = new(8, 4) if Pkc is not None else None
         _call("ttk_heads_bwd", _p(feat), _p(wcat), _p(z), _p(ids32), _p(Pc), _p(Pkc), _p(kp), _p(ke), B, F, NZ, int(unc), int(pt),
-              int(use_offset), _p(g_roi), _p(g_coord), _p(g_rot), _p(g_qu), _p(g_Lc), _p(g_Lr), _p(g_pts), _p(g_shp), _p(dz),
+              int(use_offset), int(rot6d), _p(g_roi), _p(g_coord), _p(g_rot), _p(g_qu), _p(g_Lc), _p(g_Lr), _p(g_pts), _p(g_shp), _p(dz),
               _p(dprow), _p(dfeat), _p(dwcat), _p(dbcat), _p(dP), _p(dPk))
         lin_grads = []
         r0 = 0
         for r in rows:
             lin_grads += [dwcat[r0:r0 + r], dbcat[r0:r0 + r]]
             r0 += r
-        # inputs: feat, ids, unc, pt, use_offset, keypts, keyeig, P, Pk, *lin
-        return (dfeat, None, None, None, None, None, None, dP, dPk, *lin_grads)
+        # inputs: feat, ids, unc, pt, use_offset, rot6d, keypts, keyeig, P, Pk, *lin
+        return (dfeat, None, None, None, None, None, None, None, dP, dPk, *lin_grads)
 
 
 class DiagScaleFn(Function):
@@ -113,6 +114,63 @@ class DiagScaleFn(Function):
 # ---------------------------------------------------------------------------------------------
 def _vec(n, like):
     return torch.empty(n, dtype=torch.float32, device=like.device)
+
+
+class Rot6dLossFn(Function):
+    """Rot6dReprLoss: 0.75 - 0.25 tr(R tomatrix(t)^T); R [n,3,3], t [n,4] target quaternions (no gradient)"""
+
+    @staticmethod
+    def forward(ctx, R, t):
+        R, t = _f32c(R), _f32c(t)
+        v = _vec(R.shape[0], R)
+        _call("ttk_loss_rot6d_fwd", _p(R), _p(t), R.shape[0], _p(v))
+        ctx.save_for_backward(t)
+        return v
+
+    @staticmethod
+    def backward(ctx, gv):
+        (t,) = ctx.saved_tensors
+        gR = torch.empty((t.shape[0], 3, 3), dtype=torch.float32, device=t.device)
+        _call("ttk_loss_rot6d_bwd", _p(t), _p(_f32c(gv)), t.shape[0], _p(gR))
+        return gR, None
+
+
+class Ortho6dFn(Function):
+    """Rot6dNormalizationSoftConstraint on the raw 6D features [n,6]"""
+
+    @staticmethod
+    def forward(ctx, z):
+        z = _f32c(z)
+        v = _vec(z.shape[0], z)
+        _call("ttk_loss_ortho6d_fwd", _p(z), z.shape[0], _p(v))
+        ctx.save_for_backward(z)
+        return v
+
+    @staticmethod
+    def backward(ctx, gv):
+        (z,) = ctx.saved_tensors
+        gz = torch.empty_like(z)
+        _call("ttk_loss_ortho6d_bwd", _p(z), _p(_f32c(gv)), z.shape[0], _p(gz))
+        return gz
+
+
+class MatToQuatFn(Function):
+    """torchquaternion.from_matrix: [n,3,3] -> [n,4]"""
+
+    @staticmethod
+    def forward(ctx, m):
+        m = _f32c(m)
+        q = torch.empty((m.shape[0], 4), dtype=torch.float32, device=m.device)
+        _call("ttk_mat_to_quat_fwd", _p(m), m.shape[0], _p(q))
+        ctx.save_for_backward(m)
+        return q
+
+    @staticmethod
+    def backward(ctx, gq):
+        (m,) = ctx.saved_tensors
+        gm = torch.empty_like(m)
+        _call("ttk_mat_to_quat_bwd", _p(m), _p(_f32c(gq)), m.shape[0], _p(gm))
+        return gm
 
 
 class RotLossFn(Function):

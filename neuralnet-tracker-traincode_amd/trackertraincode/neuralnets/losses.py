@@ -126,10 +126,15 @@ class BoxLoss:
 
 
 class Rot6dReprLoss:
+    """0.75 - 0.25 tr(R tomatrix(target)^T) (reference :53-58, torch6drotation.py:68-72)."""
+
     def __call__(self, pred_batch, target_batch):
-        raise NotImplementedError("the 6D-rotation head (--enable-6drot) is not built in this round")
+        pred = pred_batch["rot"]
+        return _hipops.Rot6dLossFn.apply(pred.value if hasattr(pred, "value") else pred, target_batch["pose"])
 
 
 class Rot6dNormalizationSoftConstraint:
+    """mean((M M^T - I_2)^2) of the raw 6D features (reference :61-64, torch6drotation.py:20-24)."""
+
     def __call__(self, pred_batch, target_batch):
-        raise NotImplementedError("the 6D-rotation head (--enable-6drot) is not built in this round")
+        return _hipops.Ortho6dFn.apply(pred_batch["unnormalized_6drepr"])

@@ -80,7 +80,8 @@ class DirectQuaternionWithNormalization(nn.Module):
 
 
 class RotRepr6dWithNormalization(nn.Module):
-    """Reference :153-174 (optional --enable-6drot head; CPU/eval form only in this round)."""
+    """Reference :153-174 (optional --enable-6drot head).  On CUDA tensors the arithmetic runs inside the fused heads
+    kernel (csrc/heads.hip, enable_6drot); this module owns the parameters and the CPU/eval form."""
 
     def __init__(self, num_features, enable_uncertainty=False):
         super().__init__()
@@ -234,12 +235,10 @@ class NetworkWithPointHead(nn.Module):
         return flat
 
     def _heads_hip(self, feat: Tensor, coord_convention_id: Tensor | None) -> Dict[str, Tensor]:
-        if self.enable_6drot:
-            raise NotImplementedError("the 6D-rotation head has no HIP kernel in this round")
-        unc, pt, off = self.enable_uncertainty, self.enable_point_head, self.use_local_pose_offset
+        unc, pt, off, r6 = self.enable_uncertainty, self.enable_point_head, self.use_local_pose_offset, self.enable_6drot
         kp = self.landmarks.deformablekeypoints.keypts if pt else None
         ke = self.landmarks.deformablekeypoints.keyeigvecs if pt else None
-        outs = _hipops.HeadsFn.apply(feat, coord_convention_id, unc, pt, off, kp, ke, self.local_pose_offset.p,
+        outs = _hipops.HeadsFn.apply(feat, coord_convention_id, unc, pt, off, r6, kp, ke, self.local_pose_offset.p,
                                      self.local_pose_offset_kpts.p if pt else None, *self._linear_stack())
         roi, coord, rot, qu = outs[:4]
         out: Dict[str, Tensor] = {"roi": roi}
@@ -248,10 +247,10 @@ class NetworkWithPointHead(nn.Module):
             out["roi_scales"] = self.boxnet.scales()[None, :].expand_as(roi)
             out["coord_scales"] = outs[k]
             k += 2
-        out["unnormalized_quat"] = qu
+        out["unnormalized_6drepr" if r6 else "unnormalized_quat"] = qu
         if unc:
             out["pose_scales_tril"] = outs[5]
-        out["rot"] = QuatRepr(rot)
+        out["rot"] = Mat33Repr(rot) if r6 else QuatRepr(rot)
         out["coord"] = coord
         if pt:
             out["pt3d_68"], out["shapeparam"] = outs[k], outs[k + 1]

@@ -69,6 +69,10 @@ class Mat33Repr:
         return Mat33Repr(torch6drotation.tomatrix(z))
 
     def as_quat(self) -> Tensor:
+        if self.value.is_cuda:  # HIP kernel with the hand-derived backward (csrc/loss_math.h: from_matrix)
+            from . import _hipops
+
+            return _hipops.MatToQuatFn.apply(self.value.reshape(-1, 3, 3)).view(*self.value.shape[:-2], 4)
         return torchquaternion.from_matrix(self.value)
 
     @property

@@ -37,7 +37,7 @@ INTERMEDIATE_AFTER = ("dw2_1", "dw3_1", "dw4_1", "dw5_5", "dw6")  # mobilenet_v1
 # =============================================================================================
 # state handling
 # =============================================================================================
-def state_shapes(enable_point_head=True, enable_uncertainty=False, num_features=1024) -> dict:
+def state_shapes(enable_point_head=True, enable_uncertainty=False, num_features=1024, enable_6drot=False) -> dict:
     """Key -> shape inventory of NetworkWithPointHead("mobilenetv1") (SURVEY.md Appendix C;
     neuralnets/models.py:262-307, backbones/mobilenet_v1.py:122-140)."""
     s: dict[str, tuple] = {}
@@ -73,7 +73,7 @@ def state_shapes(enable_point_head=True, enable_uncertainty=False, num_features=
     lin("posnet.linear_size", 1)
     if enable_uncertainty:
         tri("posnet.scales")
-    lin("quatnet.linear", 4)
+    lin("quatnet.linear", 6 if enable_6drot else 4)
     if enable_uncertainty:
         tri("quatnet.uncertainty_net")
     s["local_pose_offset.p"] = (8, 4)
@@ -187,6 +187,54 @@ def quat_to_matrix(q: Tensor) -> Tensor:
 # =============================================================================================
 # backbone  (backbones/mobilenet_v1.py:75-92, 160-186)
 # =============================================================================================
+def rot6d_to_matrix(z: Tensor) -> Tensor:
+    """torch6drotation.tomatrix (:27-49): Gram-Schmidt by cross products, rows normalised with eps 1e-6, identity
+    where max|R R^T - I| > 1e-3 (no gradient through the replaced samples)."""
+    x, y = z[..., :3], z[..., 3:]
+    c = torch.cross(x, y, dim=-1)
+    y2 = torch.cross(c, x, dim=-1)
+    out = torch.nn.functional.normalize(torch.stack([x, y2, c], dim=-2), dim=-1, eps=1e-6)
+    eye = torch.eye(3, dtype=z.dtype)
+    bad = (out @ out.transpose(-2, -1) - eye).flatten(-2).abs().amax(-1)
+    return torch.where(bad[..., None, None] > 1.0e-3, eye, out)
+
+
+def matrix_to_quat(m: Tensor) -> Tensor:
+    """torchquaternion.from_matrix (:94-168) = Mat33Repr.as_quat: four candidate solutions, the one with the largest
+    square-root argument (ties: first of k, j, i, w) is picked without gradient, then positivereal."""
+    d0, d1, d2 = m[..., 0, 0], m[..., 1, 1], m[..., 2, 2]
+    args = torch.stack([-d0 - d1 + d2, -d0 + d1 - d2, d0 - d1 - d2, d0 + d1 + d2], dim=-1) + 1.0
+    args = torch.clamp(args, 1.0e-6, None)
+    qx = torch.sqrt(args) * 0.5
+    qk, qj, qi, qw = qx.unbind(-1)
+    mm = lambda a, b: m[..., a, b]
+    cand = torch.stack([
+        torch.stack([0.25 * (mm(2, 0) + mm(0, 2)) / qk, 0.25 * (mm(1, 2) + mm(2, 1)) / qk, qk, 0.25 * (mm(1, 0) - mm(0, 1)) / qk], -1),
+        torch.stack([0.25 * (mm(1, 0) + mm(0, 1)) / qj, qj, 0.25 * (mm(1, 2) + mm(2, 1)) / qj, 0.25 * (mm(0, 2) - mm(2, 0)) / qj], -1),
+        torch.stack([qi, 0.25 * (mm(1, 0) + mm(0, 1)) / qi, 0.25 * (mm(0, 2) + mm(2, 0)) / qi, 0.25 * (mm(2, 1) - mm(1, 2)) / qi], -1),
+        torch.stack([0.25 * (mm(2, 1) - mm(1, 2)) / qw, 0.25 * (mm(0, 2) - mm(2, 0)) / qw, 0.25 * (mm(1, 0) - mm(0, 1)) / qw, qw], -1),
+    ], dim=-2)
+    with torch.no_grad():
+        pick = torch.argmax(args, dim=-1)
+    q = torch.gather(cand, -2, pick[..., None, None].expand(*pick.shape, 1, 4)).squeeze(-2)
+    return positivereal(q)
+
+
+def local_pose_offset_m(P: Tensor, R: Tensor, coord: Tensor, set_id: Tensor | None):
+    """LocalToGlobalCoordinateOffset with Mat33Repr (modelcomponents.py:136-184; rotrepr.py:73-85: make_rotate_x
+    takes the FULL angle for matrices)."""
+    p = P[:1] if set_id is None else P[set_id.long()]
+    ang = p[:, 1]
+    sn, cs = torch.sin(ang), torch.cos(ang)
+    one, zero = torch.ones_like(ang), torch.zeros_like(ang)
+    Rx = torch.stack([one, zero, zero, zero, cs, -sn, zero, sn, cs], dim=-1).view(-1, 3, 3)
+    transl = torch.cat([torch.zeros_like(p[:, :1]), p[:, 1:3]], dim=-1)
+    scale = coord[..., 2:] * smoothclip0(p[:, 3])[..., None]
+    Rn = R @ Rx
+    pos = (R @ transl[..., :, None]).squeeze(-1)[..., :2] * scale + coord[..., :2]
+    return Rn, torch.cat([pos, scale], dim=-1)
+
+
 def _bn(y: Tensor, st, prefix: str, training: bool, momentum: float) -> Tensor:
     rm, rv = st[prefix + ".running_mean"], st[prefix + ".running_var"]
     out = F.batch_norm(y, rm, rv, st[prefix + ".weight"], st[prefix + ".bias"], training, momentum, BN_EPS)
@@ -264,8 +312,10 @@ def local_pose_offset(P: Tensor, q: Tensor, coord: Tensor, set_id: Tensor | None
 
 
 def heads_forward(st, f: Tensor, set_id: Tensor | None, *, enable_point_head: bool,
-                  enable_uncertainty: bool, use_local_pose_offset: bool = True, training: bool = True):
-    """neuralnets/models.py:340-376 after the backbone; `rot` is returned as a plain [B,4] quaternion."""
+                  enable_uncertainty: bool, use_local_pose_offset: bool = True, training: bool = True,
+                  enable_6drot: bool = False):
+    """neuralnets/models.py:340-376 after the backbone; `rot` is returned as a plain [B,4] quaternion
+    ([B,3,3] matrix with the 6D head, models.py:153-174)."""
     out = {}
     z = _linear(st, "boxnet.linear", f)  # models.py:186-197
     size = smoothclip0(z[..., 2:])
@@ -276,23 +326,30 @@ def heads_forward(st, f: Tensor, set_id: Tensor | None, *, enable_point_head: bo
     if enable_uncertainty:
         out["coord_scales"] = features_as_triangular_scale(st, "posnet.scales", f)
     zq = _linear(st, "quatnet.linear", f)  # models.py:135-150, rotrepr.py:36-48
-    qu = torch.cat([zq[..., :3], smoothclip0(zq[..., 3:])], dim=-1)
-    q = qnormalize(qu)
-    out["unnormalized_quat"] = qu
+    if enable_6drot:
+        q = rot6d_to_matrix(zq)
+        out["unnormalized_6drepr"] = zq
+        offset = local_pose_offset_m
+    else:
+        qu = torch.cat([zq[..., :3], smoothclip0(zq[..., 3:])], dim=-1)
+        q = qnormalize(qu)
+        out["unnormalized_quat"] = qu
+        offset = local_pose_offset
     if enable_uncertainty:
         out["pose_scales_tril"] = features_as_triangular_scale(st, "quatnet.uncertainty_net", f)
     hidden_q, hidden_c = q, coord
     if use_local_pose_offset:
-        q, coord = local_pose_offset(st["local_pose_offset.p"], hidden_q, hidden_c, set_id)
+        q, coord = offset(st["local_pose_offset.p"], hidden_q, hidden_c, set_id)
     out["rot"], out["coord"] = q, coord
     if enable_point_head:
         qk, ck = q, coord
         if use_local_pose_offset:
-            qk, ck = local_pose_offset(st["local_pose_offset_kpts.p"], hidden_q, hidden_c, set_id)
+            qk, ck = offset(st["local_pose_offset_kpts.p"], hidden_q, hidden_c, set_id)
         shp = _linear(st, "landmarks.shapenet", f)  # models.py:108-124
         eig = st["landmarks.deformablekeypoints.keyeigvecs"]
         local = (eig[None] * shp[:, :, None, None]).sum(dim=1) + st["landmarks.deformablekeypoints.keypts"]
-        pts = qrotate(qk[:, None, :], local) * ck[:, None, 2:]  # modelcomponents.py:38-56
+        rotated = (qk[:, None] @ local[..., None]).squeeze(-1) if enable_6drot else qrotate(qk[:, None, :], local)
+        pts = rotated * ck[:, None, 2:]  # modelcomponents.py:38-56
         pts = torch.cat([pts[..., :2] + ck[:, None, :2], pts[..., 2:]], dim=-1)
         out["pt3d_68"], out["shapeparam"] = pts, shp
         if enable_uncertainty:
@@ -301,7 +358,7 @@ def heads_forward(st, f: Tensor, set_id: Tensor | None, *, enable_point_head: bo
             out["pt3d_68_scales"] = ps[None, :, None].expand_as(pts)
             out["shapeparam_scales"] = ss[None, :].expand_as(shp)
     if not training:
-        out["pose"] = out["rot"]
+        out["pose"] = matrix_to_quat(out["rot"]) if enable_6drot else out["rot"]
     return out
 
 
@@ -312,6 +369,7 @@ def network_forward(st, x: Tensor, set_id: Tensor | None, cfg: dict, training: b
         st, f, set_id, enable_point_head=cfg["enable_point_head"],
         enable_uncertainty=cfg["enable_uncertainty"],
         use_local_pose_offset=cfg.get("use_local_pose_offset", True), training=training,
+        enable_6drot=cfg.get("enable_6drot", False),
     ), f
 
 
@@ -329,6 +387,15 @@ def point_weights(chin=0.8, eye=0.0) -> Tensor:
 
 def loss_rot(p, s):  # losses.py:42-50, torchquaternion.py:225-228
     return 1.0 - (p["rot"] * s["pose"]).sum(-1).square()
+
+
+def loss_rot6d(p, s):  # losses.py:53-58, torch6drotation.py:68-72
+    return 0.75 - 0.25 * (p["rot"] * quat_to_matrix(s["pose"])).flatten(-2).sum(-1)
+
+
+def loss_ortho6d(p, s):  # losses.py:61-64, torch6drotation.py:20-24
+    m = p["unnormalized_6drepr"].unflatten(-1, (2, 3))
+    return (m @ m.transpose(-2, -1) - torch.eye(2, dtype=m.dtype)).square().flatten(-2).mean(-1)
 
 
 def loss_xy(p, s):  # losses.py:79-88
@@ -395,8 +462,9 @@ def mix_with_uniform(lp: Tensor, volume: float) -> Tensor:
     return torch.logsumexp(torch.stack([a, b], dim=-1), dim=-1)
 
 
-def loss_nllrot(p, s):  # negloglikelihood.py:245-274
-    r = rotation_delta(p["rot"], s["pose"])
+def loss_nllrot(p, s):  # negloglikelihood.py:245-274 (rot.as_quat(): from_matrix for the 6D head)
+    q = matrix_to_quat(p["rot"]) if p["rot"].dim() == 3 else p["rot"]
+    r = rotation_delta(q, s["pose"])
     return -mix_with_uniform(mvn_tril_logprob(r, p["pose_scales_tril"]), math.pi**4 * 4.0 / 3.0)
 
 
@@ -421,7 +489,7 @@ def loss_nllpoints3d(p, s, dim=3):  # negloglikelihood.py:145-166
 # criterion tables  (scripts/train_poseestimator.py:170-285)
 # ---------------------------------------------------------------------------------------------
 def setup_losses(*, with_pointhead=True, with_nll_loss=False, rampup_nll_losses=False, epochs=200,
-                 with_roi_train=True, gmm: Callable | None = None):
+                 with_roi_train=True, gmm: Callable | None = None, enable_6drot=False):
     """Returns {tag_name: [(name, fn, weight or weight(epoch))]} for the train criterions."""
 
     def ramp(mult):
@@ -430,7 +498,8 @@ def setup_losses(*, with_pointhead=True, with_nll_loss=False, rampup_nll_losses=
         return mult * 0.01
 
     pose, roi, pts, pts25, shp = [], [], [], [], []
-    reg = [("quatregularization1", loss_quatreg, 1.0e-6)]
+    # scripts/train_poseestimator.py:170-178: the 6D head swaps the rotation loss and the soft constraint, names stay
+    reg = [("quatregularization1", loss_ortho6d if enable_6drot else loss_quatreg, 1.0e-6)]
     if with_nll_loss:
         pose += [("nllrot", loss_nllrot, ramp(0.5)), ("nllcoord", loss_nllcoord, ramp(0.5))]
         if with_roi_train:
@@ -438,7 +507,7 @@ def setup_losses(*, with_pointhead=True, with_nll_loss=False, rampup_nll_losses=
         if with_pointhead:
             pts += [("nllpoints3d", loss_nllpoints3d, ramp(0.5))]
             pts25 += [("nllpoints3d", lambda p, s: loss_nllpoints3d(p, s, 2), ramp(0.5))]
-    pose += [("rot", loss_rot, 1.0), ("xy", loss_xy, 0.25), ("sz", loss_sz, 0.25)]
+    pose += [("rot", loss_rot6d if enable_6drot else loss_rot, 1.0), ("xy", loss_xy, 0.25), ("sz", loss_sz, 0.25)]
     if with_roi_train:
         roi += [("box", loss_box, 0.01)]
     if with_pointhead:

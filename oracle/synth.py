@@ -92,6 +92,10 @@ def make_state(shapes: dict[str, tuple], seed: int = 0) -> dict[str, np.ndarray]
             v = (r.standard_normal(shape) * 0.1).astype(F32)
         elif leaf in ("bias", "hidden_scale"):
             base = np.asarray(_BIAS_BASE.get(name, 0.0), dtype=F32)
+            if name == "quatnet.linear.bias" and shape == (6,):
+                # 6D head (models.py:159 biases towards identity, x=(1,0,0), y=(0,1,0)); unit scale here so that the
+                # synthetic x and y stay well away from collinear
+                base = np.asarray([1.0, 0.0, 0.0, 0.0, 1.0, 0.0], dtype=F32)
             v = (np.broadcast_to(base, shape) + r.standard_normal(shape) * 0.05).astype(F32)
         else:
             raise KeyError(f"no synthetic rule for state entry {name} {shape}")

@@ -78,6 +78,11 @@ CONFIGS = {
              backbone_args={"use_blurpool": False}),
         dict(with_pointhead=False, with_nll_loss=False, rampup_nll_losses=False),
     ),
+    "rot6d": (  # --enable-6drot: RotRepr6dWithNormalization head, Rot6dReprLoss + orthonormality constraint, NLL via as_quat()
+        dict(enable_point_head=True, enable_uncertainty=True, config="mobilenetv1",
+             backbone_args={"use_blurpool": False}, enable_6drot=True),
+        dict(with_pointhead=True, with_nll_loss=True, rampup_nll_losses=True, enable_6drot=True),
+    ),
 }
 
 
@@ -306,7 +311,10 @@ if __name__ == "__main__":
         gen_schedule()
     if "swa" in which:
         gen_swa()
+    only = [w[4:] for w in which if w.startswith("cfg=")]
     for cfg in CONFIGS:
+        if only and cfg not in only:
+            continue
         if "model" in which:
             gen_model(cfg)
         if "optim" in which and cfg in ("full", "default"):

@@ -108,4 +108,78 @@ void lm_gmm(int n, const float* x, const double* ck, const double* mu, const dou
 void lm_point_weights(float chin, float eye, float* w) {
   for (int p = 0; p < 68; ++p) w[p] = lm::point_weight(p, chin, eye);
 }
+// ---- 6D rotation head (matrix mode).  outputs: roi[n,4] coord[n,3] rot[n,9] Lc[n,9] Lr[n,9] pts[n,68,3]
+void hm_heads6d_fwd(int n, int NZ, const float* z, const int* ids, const float* P, const float* Pk, const float* kp,
+                    const float* eig, int unc, int pt, int use_offset, float* roi, float* coord, float* rot, float* Lc,
+                    float* Lr, float* pts) {
+  for (int s = 0; s < n; ++s) {
+    const float* zs = z + (size_t)s * NZ;
+    hm::HeadOutM o;
+    const int id = ids ? ids[s] : 0;
+    hm::sample_fwd_core_m(zs, unc, pt, use_offset, P + 4 * id, Pk + 4 * id, o);
+    memcpy(roi + 4 * s, o.roi, 16);
+    memcpy(coord + 3 * s, o.coord, 12);
+    memcpy(rot + 9 * s, o.rot, 36);
+    if (unc) { memcpy(Lc + 9 * s, o.Lc, 36); memcpy(Lr + 9 * s, o.Lr, 36); }
+    if (pt) {
+      const float* shp = zs + hm::z_shape(unc, true);
+      for (int p = 0; p < 68; ++p) {
+        float local[3];
+        for (int d = 0; d < 3; ++d) {
+          float a = kp[p * 3 + d];
+          for (int i = 0; i < 50; ++i) a += eig[(i * 68 + p) * 3 + d] * shp[i];
+          local[d] = a;
+        }
+        hm::landmark_fwd_m(o.Rk, o.ck, local, pts + ((size_t)s * 68 + p) * 3);
+      }
+    }
+  }
+}
+void hm_heads6d_bwd(int n, int NZ, const float* z, const int* ids, const float* P, const float* Pk, const float* kp,
+                    const float* eig, int unc, int pt, int use_offset, const float* g_roi, const float* g_coord,
+                    const float* g_rot, const float* g_z6, const float* g_Lc, const float* g_Lr, const float* g_pts,
+                    const float* g_shp, float* gz, float* gP, float* gPk) {
+  memset(gP, 0, 32 * sizeof(float));
+  memset(gPk, 0, 32 * sizeof(float));
+  for (int s = 0; s < n; ++s) {
+    const float* zs = z + (size_t)s * NZ;
+    float* gzs = gz + (size_t)s * NZ;
+    const int id = ids ? ids[s] : 0;
+    hm::HeadOutM o;
+    hm::sample_fwd_core_m(zs, unc, pt, use_offset, P + 4 * id, Pk + 4 * id, o);
+    hm::HeadGradM g;
+    memset(&g, 0, sizeof(g));
+    memcpy(g.roi, g_roi + 4 * s, 16);
+    memcpy(g.coord, g_coord + 3 * s, 12);
+    memcpy(g.rot, g_rot + 9 * s, 36);
+    memcpy(g.z6, g_z6 + 6 * s, 24);
+    if (unc) { memcpy(g.Lc, g_Lc + 9 * s, 36); memcpy(g.Lr, g_Lr + 9 * s, 36); }
+    if (pt) {
+      const float* shp = zs + hm::z_shape(unc, true);
+      float* gshp = gzs + hm::z_shape(unc, true);
+      for (int i = 0; i < 50; ++i) gshp[i] = g_shp[s * 50 + i];
+      for (int p = 0; p < 68; ++p) {
+        float local[3], gl[3];
+        for (int d = 0; d < 3; ++d) {
+          float a = kp[p * 3 + d];
+          for (int i = 0; i < 50; ++i) a += eig[(i * 68 + p) * 3 + d] * shp[i];
+          local[d] = a;
+        }
+        hm::landmark_bwd_m(o.Rk, o.ck, local, g_pts + ((size_t)s * 68 + p) * 3, g.Rk, g.ck, gl);
+        for (int i = 0; i < 50; ++i)
+          for (int d = 0; d < 3; ++d) gshp[i] += gl[d] * eig[(i * 68 + p) * 3 + d];
+      }
+    }
+    hm::sample_bwd_core_m(zs, unc, pt, use_offset, P + 4 * id, Pk + 4 * id, g, gzs, gP + 4 * id, gPk + 4 * id);
+  }
+}
+void lm_rot6d(int n, const float* R, const float* t, const float* gv, float* v, float* gR) {
+  for (int s = 0; s < n; ++s) { v[s] = lm::rot6d_loss(R + 9 * s, t + 4 * s); lm::rot6d_loss_bwd(t + 4 * s, gv[s], gR + 9 * s); }
+}
+void lm_ortho6d(int n, const float* z, const float* gv, float* v, float* gz) {
+  for (int s = 0; s < n; ++s) { v[s] = lm::ortho6d_loss(z + 6 * s); lm::ortho6d_loss_bwd(z + 6 * s, gv[s], gz + 6 * s); }
+}
+void lm_from_matrix(int n, const float* m, const float* gq, float* q, float* gm) {
+  for (int s = 0; s < n; ++s) { lm::from_matrix(m + 9 * s, q + 4 * s); lm::from_matrix_bwd(m + 9 * s, gq + 4 * s, gm + 9 * s); }
+}
 }

@@ -192,3 +192,97 @@ def test_gmm_and_point_weights(hm, golden_dir):
     hm.lm_point_weights.argtypes = [ctypes.c_float, ctypes.c_float, ctypes.c_void_p]
     hm.lm_point_weights(0.8, 0.0, P(w))
     np.testing.assert_array_equal(w, R.point_weights(0.8, 0.0).numpy())
+
+
+# ---------------------------------------------------------------------------------------------
+# 6D rotation head (RotRepr6dWithNormalization) and its losses
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("unc,pt,use_offset", [(True, True, True), (False, True, True), (False, False, True), (True, True, False)])
+def test_heads6d_forward_backward(hm, unc, pt, use_offset):
+    rng = np.random.default_rng(5)
+    n = 6
+    NZ = 13 + (14 if unc else 0) + (50 if pt else 0)
+    z = f32(n, NZ, rng=rng, scale=0.7)
+    z[1, 10:13] = z[1, 7:10] * 1.5  # a collinear (x, y) pair: degenerate Gram-Schmidt -> identity fallback, no gradient
+    ids = rng.integers(0, 8, n).astype(np.int32)
+    st = _identity_state(unc, pt, NZ, rng)
+    eye = torch.eye(NZ)
+    # re-map the row pickers to the 6D layout (6 rotation rows, everything after shifted by 2)
+    st["quatnet.linear.weight"], st["quatnet.linear.bias"] = eye[7:13].clone(), torch.zeros(6)
+    if unc:
+        st["posnet.scales.neck.lin.weight"], st["quatnet.uncertainty_net.neck.lin.weight"] = eye[13:20].clone(), eye[20:27].clone()
+    if pt:
+        lo = 13 + (14 if unc else 0)
+        st["landmarks.shapenet.weight"] = eye[lo:lo + 50].clone()
+    zt = torch.from_numpy(z).requires_grad_(True)
+    out = R.heads_forward(st, zt, torch.from_numpy(ids), enable_point_head=pt, enable_uncertainty=unc,
+                          use_local_pose_offset=use_offset, training=True, enable_6drot=True)
+    names = ["roi", "coord", "rot", "unnormalized_6drepr"] + (["coord_scales", "pose_scales_tril"] if unc else []) + (["pt3d_68", "shapeparam"] if pt else [])
+    ups = {k: torch.from_numpy(f32(*out[k].shape, rng=rng)) for k in names}
+    sum((out[k] * ups[k]).sum() for k in names).backward()
+
+    kp, ke = synthetic_keypoint_buffers()
+    Pm, Pk = st["local_pose_offset.p"].detach().numpy().copy(), st["local_pose_offset_kpts.p"].detach().numpy().copy()
+    o = {"roi": np.zeros((n, 4), np.float32), "coord": np.zeros((n, 3), np.float32), "rot": np.zeros((n, 9), np.float32),
+         "coord_scales": np.zeros((n, 9), np.float32), "pose_scales_tril": np.zeros((n, 9), np.float32),
+         "pt3d_68": np.zeros((n, 68, 3), np.float32)}
+    hm.hm_heads6d_fwd(n, NZ, P(z), P(ids), P(Pm), P(Pk), P(kp), P(ke), int(unc), int(pt), int(use_offset), P(o["roi"]), P(o["coord"]),
+                      P(o["rot"]), P(o["coord_scales"]), P(o["pose_scales_tril"]), P(o["pt3d_68"]))
+    for k in names:
+        if k in ("shapeparam", "unnormalized_6drepr"):
+            continue
+        np.testing.assert_allclose(o[k].reshape(out[k].shape), out[k].detach().numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
+    if not use_offset:
+        np.testing.assert_array_equal(o["rot"][1].reshape(3, 3), np.eye(3, dtype=np.float32))  # the fallback sample
+
+    def up(k, shape):
+        return np.ascontiguousarray(ups[k].numpy().reshape(shape)) if k in ups else np.zeros(shape, np.float32)
+
+    gz, gP, gPk = np.zeros((n, NZ), np.float32), np.zeros((8, 4), np.float32), np.zeros((8, 4), np.float32)
+    hm.hm_heads6d_bwd(n, NZ, P(z), P(ids), P(Pm), P(Pk), P(kp), P(ke), int(unc), int(pt), int(use_offset), P(up("roi", (n, 4))),
+                      P(up("coord", (n, 3))), P(up("rot", (n, 9))), P(up("unnormalized_6drepr", (n, 6))), P(up("coord_scales", (n, 9))),
+                      P(up("pose_scales_tril", (n, 9))), P(up("pt3d_68", (n, 68, 3))), P(up("shapeparam", (n, 50))), P(gz), P(gP), P(gPk))
+    np.testing.assert_allclose(gz, zt.grad.numpy(), rtol=2e-4, atol=3e-5)
+    if use_offset:
+        np.testing.assert_allclose(gP, st["local_pose_offset.p"].grad.numpy(), rtol=2e-4, atol=3e-5)
+        if pt:
+            np.testing.assert_allclose(gPk, st["local_pose_offset_kpts.p"].grad.numpy(), rtol=2e-4, atol=3e-5)
+
+
+def test_rot6d_losses_and_from_matrix(hm):
+    rng = np.random.default_rng(13)
+    n = 256
+    z6 = f32(n, 6, rng=rng)
+    Rm = R.rot6d_to_matrix(torch.from_numpy(z6)).numpy().copy()
+    tq = _unit(f32(n, 4, rng=rng)).astype(np.float32)
+    gv = f32(n, rng=rng)
+    # Rot6dReprLoss
+    Rt = torch.from_numpy(Rm).requires_grad_(True)
+    v_ref = R.loss_rot6d({"rot": Rt}, {"pose": torch.from_numpy(tq)})
+    (v_ref * torch.from_numpy(gv)).sum().backward()
+    v, gR = np.zeros(n, np.float32), np.zeros((n, 9), np.float32)
+    hm.lm_rot6d(n, P(Rm), P(tq), P(gv), P(v), P(gR))
+    np.testing.assert_allclose(v, v_ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gR.reshape(n, 3, 3), Rt.grad.numpy(), rtol=1e-5, atol=1e-6)
+    # Rot6dNormalizationSoftConstraint
+    zt = torch.from_numpy(z6).requires_grad_(True)
+    v_ref = R.loss_ortho6d({"unnormalized_6drepr": zt}, None)
+    (v_ref * torch.from_numpy(gv)).sum().backward()
+    gz = np.zeros((n, 6), np.float32)
+    hm.lm_ortho6d(n, P(z6), P(gv), P(v), P(gz))
+    np.testing.assert_allclose(v, v_ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gz, zt.grad.numpy(), rtol=1e-5, atol=1e-6)
+    # Mat33Repr.as_quat = torchquaternion.from_matrix: all four branches occur in 256 random rotations
+    Rt = torch.from_numpy(Rm).requires_grad_(True)
+    q_ref = R.matrix_to_quat(Rt)
+    gq = f32(n, 4, rng=rng)
+    (q_ref * torch.from_numpy(gq)).sum().backward()
+    q, gm = np.zeros((n, 4), np.float32), np.zeros((n, 9), np.float32)
+    hm.lm_from_matrix(n, P(Rm), P(gq), P(q), P(gm))
+    d0, d1, d2 = Rm[:, 0, 0], Rm[:, 1, 1], Rm[:, 2, 2]
+    picks = np.argmax(np.stack([-d0 - d1 + d2, -d0 + d1 - d2, d0 - d1 - d2, d0 + d1 + d2], -1), -1)
+    assert set(picks.tolist()) == {0, 1, 2, 3}
+    np.testing.assert_allclose(q, q_ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gm.reshape(n, 3, 3), Rt.grad.numpy(), rtol=2e-4, atol=2e-5)
+    # and it inverts tomatrix
+    np.testing.assert_allclose(np.abs((q * tq).sum(-1)) <= 1.0 + 1e-5, True)

@@ -11,7 +11,7 @@ from oracle import refmodel as R
 from oracle.synth import digest_close, make_grads, make_inputs, make_labels, make_state
 
 torch.set_num_threads(min(8, os.cpu_count() or 1))
-CFGS = ["full", "default", "posonly"]
+CFGS = ["full", "default", "posonly", "rot6d"]
 
 
 def _load(golden_dir, name):
@@ -37,13 +37,15 @@ def _criterions(meta, golden_dir):
     fl = meta["flags"]
     gmm = R.ShapeGmm(os.path.join(golden_dir, "shapeparams_gmm.npz"))
     return R.setup_losses(with_pointhead=fl["with_pointhead"], with_nll_loss=fl["with_nll_loss"],
-                          rampup_nll_losses=fl["rampup_nll_losses"], epochs=200, gmm=gmm)
+                          rampup_nll_losses=fl["rampup_nll_losses"], epochs=200, gmm=gmm,
+                          enable_6drot=fl.get("enable_6drot", False))
 
 
 @pytest.mark.parametrize("cfg", CFGS)
 def test_state_inventory_matches_reference(cfg, golden_dir):
     d, meta = _load(golden_dir, f"model_{cfg}.npz")
-    mine = R.state_shapes(meta["config"]["enable_point_head"], meta["config"]["enable_uncertainty"])
+    mine = R.state_shapes(meta["config"]["enable_point_head"], meta["config"]["enable_uncertainty"],
+                          enable_6drot=meta["config"].get("enable_6drot", False))
     ref = {k: tuple(v) for k, v in meta["shapes"].items()}
     assert list(mine.keys()) == list(ref.keys())  # same names, same order (checkpoint surface)
     assert mine == ref
