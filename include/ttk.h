@@ -159,6 +159,27 @@ int ttk_bn_act(const float* y, const float* bn, const float* skip, float* a, int
                ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Dense convolutions of the ResNet18 backbone variant (backbones/resnet.py:52-104; arithmetic =
+ * torchvision.models.resnet.BasicBlock/conv3x3/conv1x1, an un-vendored dependency of the reference) as implicit
+ * GEMMs on the matrix cores.  Channels-last activations a[B][H][W][C] that are already post-BatchNorm/ReLU
+ * ("materialised"); k in {1,3}, stride in {1,2}, pad = k/2; Cin % 32 == 0, Cout % 64 == 0.
+ *   ttk_conv_weight_repack  w[Cout][Cin][KH][KW] -> w_fwd[KH*KW][Cout][Cin], w_bwd[KH*KW][Cin][Cout] (either may be NULL)
+ *   ttk_conv_fwd            y[B][Ho][Wo][Cout] raw conv output + part[ttk_partial_rows_gemm(B*Ho*Wo)][2][Cout]
+ *   ttk_conv_bwd_data       g_in[B][H][W][Cin] = conv^T(dy), dy = ga*(g-gmean)+gb*(y-mean) formed on load from the conv
+ *                           output's gradient g, raw output y and BatchNorm block bn.  With mask_y/mask_bn (the conv
+ *                           input was relu(mask_bn(mask_y))): masked, and part[ttk_partial_rows_gemm(B*H*W)][2][Cin]
+ *                           receives (sum g_in, sum g_in*(mask_y-mean)); without: raw gradient, part untouched.
+ *   ttk_conv_bwd_weight     dw[Cout][Cin][KH][KW] += sum_pixels dy (x) a_in (fp32 atomics; zero dw first)
+ * ------------------------------------------------------------------------------------------- */
+int ttk_conv_weight_repack(const float* w, float* w_fwd, float* w_bwd, int Cout, int Cin, int KH, int KW,
+                           ttk_stream_t stream);
+int ttk_conv_fwd(const float* a_in, const float* w_fwd, float* y, float* part, int B, int H, int W, int Cin,
+                 int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream);
+int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const float* w_bwd, const float* mask_y,
+                      const float* mask_bn, float* g_in, float* part, int B, int H, int W, int Cin, int Cout,
+                      int KH, int KW, int stride, int pad, ttk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Multi-task heads - everything NetworkWithPointHead.forward does after the backbone
  * (neuralnets/models.py:345-376): BoundingBox :177-197, PositionSizeOutput :200-215,
  * DirectQuaternionWithNormalization :127-150 (+ rotrepr.py:36-48), FeaturesAsTriangularScale

@@ -1,0 +1,71 @@
+// Dense convolutions of the ResNet18 backbone variant (reference: backbones/resnet.py:52-104; the arithmetic is
+// torchvision.models.resnet.BasicBlock / conv3x3 / conv1x1, un-vendored in the reference) as implicit GEMMs on the
+// split-bf16 producer/consumer kernel of pwconv_split.hip: channels-last activations [B][H][W][C], GEMM rows = pixels,
+// contraction = (tap, channel).  Activations are materialised here (post-BatchNorm/ReLU tensors) - ResNet18 is
+// matrix-bound (150 flop/B), the extra elementwise passes are ~10 % of its step.
+#include "ttk_common.h"
+#include "conv_geom.h"
+
+namespace ttk {
+
+// w[Cout][Cin][T] (torch layout, T = KH*KW) -> wf[T][Cout][Cin] (forward B operand) and wb[T][Cin][Cout] (data gradient)
+__global__ void conv_weight_repack_k(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wb, int Cout,
+                                     int Cin, int T) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)Cout * Cin * T) return;
+  const int t = (int)(i % T), ci = (int)((i / T) % Cin), co = (int)(i / ((int64_t)T * Cin));
+  const float v = w[i];
+  if (wf) wf[((size_t)t * Cout + co) * Cin + ci] = v;
+  if (wb) wb[((size_t)t * Cin + ci) * Cout + co] = v;
+}
+
+static bool conv_shape_ok(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+  return B > 0 && H > 0 && W > 0 && Cin >= 32 && Cin % 32 == 0 && Cout >= 64 && Cout % 64 == 0 && KH == KW && (KH == 1 || KH == 3) &&
+         (stride == 1 || stride == 2) && pad == KH / 2;
+}
+
+}  // namespace ttk
+
+using namespace ttk;
+
+extern "C" {
+
+int ttk_conv_weight_repack(const float* w, float* w_fwd, float* w_bwd, int Cout, int Cin, int KH, int KW, ttk_stream_t stream) {
+  TTK_REQUIRE(w && (w_fwd || w_bwd) && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "conv_weight_repack: bad arguments");
+  const int64_t n = (int64_t)Cout * Cin * KH * KW;
+  hipLaunchKernelGGL(conv_weight_repack_k, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, w, w_fwd, w_bwd,
+                     Cout, Cin, KH * KW);
+  TTK_LAUNCH_CHECK("conv_weight_repack");
+}
+
+int ttk_conv_fwd(const float* a_in, const float* w_fwd, float* y, float* part, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                 int stride, int pad, ttk_stream_t stream) {
+  TTK_REQUIRE(a_in && w_fwd && y, "conv_fwd: null pointer");
+  TTK_REQUIRE(conv_shape_ok(B, H, W, Cin, Cout, KH, KW, stride, pad), "conv_fwd: unsupported shape B=%d H=%d W=%d Cin=%d Cout=%d k=%d s=%d p=%d", B, H, W, Cin, Cout, KH, stride, pad);
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  const ConvGeom geo{H, W, Ho, Wo, stride, pad, KW, Cin, 0};
+  const bool ok = launch_conv_gemm(AMODE_PLAIN, EMODE_STATS, a_in, nullptr, nullptr, w_fwd, y, nullptr, nullptr, part,
+                                   (int64_t)B * Ho * Wo, KH * KW * Cin, Cout, geo, (hipStream_t)stream);
+  TTK_REQUIRE(ok, "conv_fwd: no kernel for this shape");
+  TTK_LAUNCH_CHECK("conv_fwd");
+}
+
+// Gradient w.r.t. the conv input.  dy = ga*(g-gmean)+gb*(y-mean) of the conv OUTPUT is formed while loading (bn = that
+// output's BatchNorm block).  mask_y/mask_bn (nullable together): the input activation was relu(bn_in(mask_y)) - the
+// result is masked with it and part gets the BatchNorm-backward sums (sum g, sum g*(mask_y-mean)) of bn_in; without
+// them the raw gradient is written and part is not touched.
+int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const float* w_bwd, const float* mask_y,
+                      const float* mask_bn, float* g_in, float* part, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                      int stride, int pad, ttk_stream_t stream) {
+  TTK_REQUIRE(g && y && bn && w_bwd && g_in, "conv_bwd_data: null pointer");
+  TTK_REQUIRE((mask_y == nullptr) == (mask_bn == nullptr), "conv_bwd_data: mask_y and mask_bn go together");
+  TTK_REQUIRE(conv_shape_ok(B, H, W, Cin, Cout, KH, KW, stride, pad) && Cin % 64 == 0, "conv_bwd_data: unsupported shape");
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  const ConvGeom geo{Ho, Wo, H, W, stride, pad, KW, Cout, 1};
+  const bool ok = launch_conv_gemm(AMODE_BNGRAD, mask_y ? EMODE_MASK : EMODE_PLAIN, g, y, bn, w_bwd, g_in, mask_y, mask_bn,
+                                   mask_y ? part : nullptr, (int64_t)B * H * W, KH * KW * Cout, Cin, geo, (hipStream_t)stream);
+  TTK_REQUIRE(ok, "conv_bwd_data: no kernel for this shape");
+  TTK_LAUNCH_CHECK("conv_bwd_data");
+}
+
+}  // extern "C"

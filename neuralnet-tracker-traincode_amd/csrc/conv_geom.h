@@ -1,0 +1,25 @@
+// Shared between pwconv_split.hip and conv.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ttk {
+
+// A-operand forms (what the producers compute from the loaded rows) and epilogue forms
+enum { AMODE_BNRELU = 0, AMODE_BNGRAD = 1, AMODE_PLAIN = 2 };
+enum { EMODE_STATS = 0, EMODE_MASK = 1, EMODE_PLAIN = 2 };
+
+// Implicit-GEMM convolution (ResNet 3x3 / strided 1x1, backbones/resnet.py): the GEMM rows enumerate the pixels of a
+// grid (Hg x Wg per image) and the contraction runs over (tap, channel): for tap (kh, kw) row (n, gh, gw) reads the
+// source pixel   forward:    (gh*stride - pad + kh, gw*stride - pad + kw)            [grid = output, source = input]
+//                transposed: ((gh + pad - kh)/stride, (gw + pad - kw)/stride) if divisible  [grid = input, source = output]
+// of a [n][Hs][Ws][Kc] tensor, or contributes zero outside it.  The B operand is [tap][Nout][Kc].
+struct ConvGeom {
+  int Hs, Ws, Hg, Wg, stride, pad, KW, Kc, transposed;
+};
+
+bool launch_conv_gemm(int amode, int emode, const float* A0, const float* A1, const float* bnA, const float* Bm, float* out,
+                      const float* E0, const float* bnE, float* part, int64_t M, int K, int Nout, const ConvGeom& geo,
+                      hipStream_t st);
+
+}  // namespace ttk

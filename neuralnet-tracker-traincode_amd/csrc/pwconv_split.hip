@@ -25,6 +25,7 @@
 // distinct 4-bank groups.  Stage stride 36864+64 B so the two k16 halves of a producer wave's ds_write_b64
 // use different banks.
 #include "ttk_common.h"
+#include "conv_geom.h"
 
 namespace ttk {
 
@@ -126,12 +127,12 @@ __device__ __forceinline__ void consume_tile(const unsigned char* lds, int nks, 
   }
 }
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int AMODE, int EMODE, bool GATHER>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* __restrict__ bnA,
            const float* __restrict__ Bm, float* __restrict__ out, const float* __restrict__ E0,
-           const float* __restrict__ bnE, float* __restrict__ part, int64_t M, int K, int Nout) {
-  static_assert(BM + BN == 384 && (BM == 128 || BM == 256), "128x256 or 256x128");
+           const float* __restrict__ bnE, float* __restrict__ part, int64_t M, int K, int Nout, ConvGeom geo) {
+  static_assert((BM == 128 && BN == 256) || (BM == 256 && BN == 128) || (BM == 256 && BN == 64), "tile shapes");
   constexpr int APL = BM * 32, BPL = BN * 32;  // bytes of one piece plane
   constexpr int TM = BM / 64, TN = BN / 64;    // 32x32 tiles of a consumer wave (wave tile (BM/2) x (BN/2))
   constexpr int LDC = BN + 4;
@@ -157,50 +158,97 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
     const int row0 = pt >> 3, kq8 = pt & 7;  // 32 rows per pass; 8 lanes x 16 B = one 128-byte row segment
     const int sub = kq8 >> 2, chunk = (kq8 >> 1) & 1, o8 = (kq8 & 1) * 8;
     constexpr int AP = BM / 32, BP = BN / 32;
-    f32x4 ra0[AP], ra1[MODE == SMODE_DGRAD ? AP : 1], rb[BP], q0, q1, q2, q3;
-    int64_t arow[AP];
+    f32x4 ra0[AP], ra1[AMODE == AMODE_BNGRAD ? AP : 1], rb[BP], q0, q1, q2, q3;
+    const int Kc = GATHER ? geo.Kc : K;   // channels per tap (= K without taps)
+    const int kpt = Kc / 32;              // k32 steps per tap
+    int64_t arow[GATHER ? 1 : AP];        // plain GEMM: element offset of each of this thread's rows
+    int gbase[GATHER ? AP : 1], gh[GATHER ? AP : 1], gw[GATHER ? AP : 1];  // gather: image base pixel, grid coordinates
+    unsigned vmask = 0xffffffffu;         // rows whose current tap falls inside the source tensor
+    if constexpr (!GATHER) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      int64_t row = m0 + row0 + 32 * i;
-      arow[i] = (row < M ? row : M - 1) * (int64_t)K + kq8 * 4;  // clamp: rows past M are computed but never stored
+      for (int i = 0; i < AP; ++i) {
+        int64_t row = m0 + row0 + 32 * i;
+        arow[i] = (row < M ? row : M - 1) * (int64_t)K + kq8 * 4;  // clamp: rows past M are computed but never stored
+      }
+    } else {
+      const int hw = geo.Hg * geo.Wg;
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        const int64_t row = m0 + row0 + 32 * i;
+        const int r = (int)(row < M ? row : M - 1);
+        const int n = r / hw, rem = r - n * hw;
+        gh[i] = rem / geo.Wg;
+        gw[i] = rem - gh[i] * geo.Wg;
+        gbase[i] = row < M ? n * geo.Hs * geo.Ws : -1;
+      }
     }
-    const float* bp = Bm + (int64_t)(n0 + row0) * K + kq8 * 4;
-    const float* cp = bnA + kq8 * 4;
+    const float* bp = Bm + (int64_t)(n0 + row0) * Kc + kq8 * 4;
+    const float* cp = bnA ? bnA + kq8 * 4 : nullptr;
     unsigned char* wbase = lds + sub * kStageStride + o8;
 
     auto load_a = [&](int ks) {
-      const int k0 = ks * 32;
+      const int tap = ks / kpt, kc0 = (ks - tap * kpt) * 32;
+      if constexpr (!GATHER) {
 #pragma unroll
-      for (int i = 0; i < AP; ++i) {
-        ra0[i] = *reinterpret_cast<const f32x4*>(A0 + arow[i] + k0);
-        if constexpr (MODE == SMODE_DGRAD) ra1[i] = *reinterpret_cast<const f32x4*>(A1 + arow[i] + k0);
-      }
-      if constexpr (MODE == SMODE_FWD) {
-        q0 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_SCALE * K + k0);
-        q1 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * K + k0);
-        q2 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_BETA * K + k0);
+        for (int i = 0; i < AP; ++i) {
+          ra0[i] = *reinterpret_cast<const f32x4*>(A0 + arow[i] + kc0);
+          if constexpr (AMODE == AMODE_BNGRAD) ra1[i] = *reinterpret_cast<const f32x4*>(A1 + arow[i] + kc0);
+        }
       } else {
-        q0 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GA * K + k0);
-        q1 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GMEAN * K + k0);
-        q2 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GB * K + k0);
-        q3 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * K + k0);
+        const int kh = tap / geo.KW, kw = tap - kh * geo.KW;
+        vmask = 0u;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+          int sh, sw;
+          bool ok = gbase[i] >= 0;
+          if (!geo.transposed) {
+            sh = gh[i] * geo.stride - geo.pad + kh;
+            sw = gw[i] * geo.stride - geo.pad + kw;
+          } else {
+            const int th = gh[i] + geo.pad - kh, tw = gw[i] + geo.pad - kw, sm = geo.stride - 1;  // stride 1 or 2
+            ok = ok && th >= 0 && tw >= 0 && ((th | tw) & sm) == 0;
+            sh = th >> sm;
+            sw = tw >> sm;
+          }
+          ok = ok && (unsigned)sh < (unsigned)geo.Hs && (unsigned)sw < (unsigned)geo.Ws;
+          const int64_t off = ok ? ((int64_t)(gbase[i] + sh * geo.Ws + sw) * Kc + kc0 + kq8 * 4) : (int64_t)(kq8 * 4);
+          vmask |= (ok ? 1u : 0u) << i;
+          ra0[i] = *reinterpret_cast<const f32x4*>(A0 + off);
+          if constexpr (AMODE == AMODE_BNGRAD) ra1[i] = *reinterpret_cast<const f32x4*>(A1 + off);
+        }
+      }
+      if constexpr (AMODE == AMODE_BNRELU) {
+        q0 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_SCALE * Kc + kc0);
+        q1 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * Kc + kc0);
+        q2 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_BETA * Kc + kc0);
+      } else if constexpr (AMODE == AMODE_BNGRAD) {
+        q0 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GA * Kc + kc0);
+        q1 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GMEAN * Kc + kc0);
+        q2 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GB * Kc + kc0);
+        q3 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * Kc + kc0);
       }
     };
     auto load_b = [&](int ks) {
+      const int tap = ks / kpt, kc0 = (ks - tap * kpt) * 32;
+      const float* b = bp + (int64_t)tap * Nout * Kc + kc0;
 #pragma unroll
-      for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bp + (int64_t)(32 * i) * K + ks * 32);
+      for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b + (int64_t)(32 * i) * Kc);
     };
     auto store_a = [&](int ks) {
       unsigned char* S = wbase + (ks & 1) * 2 * kStageStride;
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
         f32x4 v;
-        if constexpr (MODE == SMODE_FWD) {
+        if constexpr (AMODE == AMODE_BNRELU) {
           v = q0 * (ra0[i] - q1) + q2;
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        } else {
+        } else if constexpr (AMODE == AMODE_BNGRAD) {
           v = q0 * (ra0[i] - q1) + q2 * (ra1[i] - q3);
+        } else {
+          v = ra0[i];
         }
+        if constexpr (GATHER)
+          if (!((vmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};  // zero padding / taps that miss the stride grid
         split_store(v, S + swz_off(row0 + 32 * i, chunk), APL);
       }
     };
@@ -267,7 +315,7 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
   const int c4 = tid % QN, rg = tid / QN, half = rg / RGH, rr = rg % RGH;
   const int col = n0 + 4 * c4;
   float4 esc = f4(0.f), emean = f4(0.f), ebeta = f4(0.f);
-  if constexpr (MODE == SMODE_DGRAD) {
+  if constexpr (EMODE == EMODE_MASK) {
     esc = ld4(bnE + TTK_BN_SCALE * Nout + col); emean = ld4(bnE + TTK_BN_MEAN * Nout + col); ebeta = ld4(bnE + TTK_BN_BETA * Nout + col);
   }
   float4 s1 = f4(0.f), s2 = f4(0.f);
@@ -278,7 +326,9 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
     if (grow >= M) break;
     float4 v = ld4(Cs + row * LDC + 4 * c4);
     const size_t o = (size_t)grow * Nout + col;
-    if constexpr (MODE == SMODE_FWD) {
+    if constexpr (EMODE == EMODE_PLAIN) {
+      st4(out + o, v);
+    } else if constexpr (EMODE == EMODE_STATS) {
       st4(out + o, v);
       s1 = add4(s1, v);
       s2 = fma4(v, v, s2);
@@ -290,7 +340,7 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
       s2 = fma4(v, yc, s2);
     }
   }
-  if (part) {
+  if (EMODE != EMODE_PLAIN && part) {
     st4(red + (rg * 2 + 0) * BN + 4 * c4, s1);
     st4(red + (rg * 2 + 1) * BN + 4 * c4, s2);
     __syncthreads();
@@ -487,15 +537,19 @@ bool launch_split_wgrad(const float* g, const float* y, const float* bn_pw, cons
 template <int MODE>
 bool launch_split_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
                        const float* bnE, float* part, int64_t M, int K, int Nout, hipStream_t st) {
+  constexpr int AM = MODE == SMODE_FWD ? AMODE_BNRELU : AMODE_BNGRAD, EM = MODE == SMODE_FWD ? EMODE_STATS : EMODE_MASK;
   if (K < 128 || K % 32 != 0) return false;
+  const ConvGeom none{};
   if (Nout >= 256 && Nout % 256 == 0) {
     const unsigned tiles = (unsigned)(ceil_div(M, 128) * (Nout / 256));
-    hipLaunchKernelGGL((pw_split_k<128, 256, MODE>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
+    hipLaunchKernelGGL((pw_split_k<128, 256, AM, EM, false>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K,
+                       Nout, none);
     return true;
   }
   if (Nout == 128 && K >= 256) {
     const unsigned tiles = (unsigned)ceil_div(M, 256);
-    hipLaunchKernelGGL((pw_split_k<256, 128, MODE>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
+    hipLaunchKernelGGL((pw_split_k<256, 128, AM, EM, false>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K,
+                       Nout, none);
     return true;
   }
   return false;
@@ -505,5 +559,29 @@ template bool launch_split_gemm<SMODE_FWD>(const float*, const float*, const flo
                                            const float*, float*, int64_t, int, int, hipStream_t);
 template bool launch_split_gemm<SMODE_DGRAD>(const float*, const float*, const float*, const float*, float*, const float*,
                                              const float*, float*, int64_t, int, int, hipStream_t);
+
+// Implicit-GEMM convolution launches (conv.hip).  amode/emode: AMODE_* / EMODE_*.  Nout must be a multiple of 64;
+// geo.Kc a multiple of 32.  K = taps * geo.Kc.
+bool launch_conv_gemm(int amode, int emode, const float* A0, const float* A1, const float* bnA, const float* Bm, float* out,
+                      const float* E0, const float* bnE, float* part, int64_t M, int K, int Nout, const ConvGeom& geo,
+                      hipStream_t st) {
+#define TTK_CONV_LAUNCH(BM_, BN_, AM_, EM_)                                                                           \
+  hipLaunchKernelGGL((pw_split_k<BM_, BN_, AM_, EM_, true>), dim3((unsigned)(ceil_div(M, BM_) * (Nout / BN_))), dim3(512), 0, st, \
+                     A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, geo)
+#define TTK_CONV_TILES(AM_, EM_)                                  \
+  do {                                                            \
+    if (Nout % 256 == 0) TTK_CONV_LAUNCH(128, 256, AM_, EM_);     \
+    else if (Nout % 128 == 0) TTK_CONV_LAUNCH(256, 128, AM_, EM_); \
+    else TTK_CONV_LAUNCH(256, 64, AM_, EM_);                      \
+    return true;                                                  \
+  } while (0)
+  if (Nout % 64 != 0 || geo.Kc % 32 != 0) return false;
+  if (amode == AMODE_PLAIN && emode == EMODE_STATS) TTK_CONV_TILES(AMODE_PLAIN, EMODE_STATS);
+  if (amode == AMODE_BNGRAD && emode == EMODE_MASK) TTK_CONV_TILES(AMODE_BNGRAD, EMODE_MASK);
+  if (amode == AMODE_BNGRAD && emode == EMODE_PLAIN) TTK_CONV_TILES(AMODE_BNGRAD, EMODE_PLAIN);
+#undef TTK_CONV_TILES
+#undef TTK_CONV_LAUNCH
+  return false;
+}
 
 }  // namespace ttk

@@ -33,6 +33,9 @@ _SIGNATURES = {
     "ttk_avgpool_fwd": [_P, _P, _P, _P, _I, _I, _I],
     "ttk_avgpool_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
     "ttk_bn_act": [_P, _P, _P, _P, _L, _I],
+    "ttk_conv_weight_repack": [_P, _P, _P, _I, _I, _I, _I],
+    "ttk_conv_fwd": [_P, _P, _P, _P] + [_I] * 9,
+    "ttk_conv_bwd_data": [_P] * 8 + [_I] * 9,
     "ttk_heads_fwd": [_P] * 8 + [_I] * 7 + [_P] * 9,
     "ttk_heads_bwd": [_P] * 8 + [_I] * 7 + [_P] * 15,
     "ttk_diag_scale_fwd": [_P, _P, _I],

@@ -1,0 +1,98 @@
+"""GPU parity of the implicit-GEMM convolution entry points (ResNet18 variant) against float64 torch convolutions
+on the host.  Inputs are channels-last activations, exactly as the backbone stores them."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BN_SCALE, BN_BETA, BN_MEAN, BN_RSTD, BN_GA, BN_GB, BN_GMEAN = range(7)
+
+
+def _bn_block(C, rng):
+    bn = np.zeros((8, C), np.float32)
+    bn[BN_SCALE] = rng.uniform(0.5, 1.5, C)
+    bn[BN_BETA] = rng.normal(0, 0.2, C)
+    bn[BN_MEAN] = rng.normal(0, 0.3, C)
+    bn[BN_RSTD] = rng.uniform(0.5, 2.0, C)
+    bn[BN_GA] = rng.uniform(0.5, 1.5, C)
+    bn[BN_GB] = rng.normal(0, 0.2, C)
+    bn[BN_GMEAN] = rng.normal(0, 0.05, C)
+    return bn
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+# (B, H, Cin, Cout, k, stride): every conv shape class of ResNet18 at 129x129 input + ragged row counts
+SHAPES = [(3, 33, 64, 64, 3, 1), (2, 33, 64, 128, 3, 2), (2, 33, 64, 128, 1, 2), (3, 17, 128, 128, 3, 1), (2, 17, 128, 256, 3, 2),
+          (5, 9, 256, 256, 3, 1), (2, 9, 256, 512, 1, 2), (7, 5, 512, 512, 3, 1), (1, 9, 256, 512, 3, 2)]
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,stride", SHAPES)
+def test_conv_fwd_bwd_data_bwd_weight(B, H, Cin, Cout, k, stride):
+    import trackertraincode._hip as Hh
+    L, p = Hh.lib(), Hh.ptr
+    rng = np.random.default_rng(B * 1000 + H + Cin + Cout + k + stride)
+    pad, W = k // 2, H
+    Ho = (H + 2 * pad - k) // stride + 1
+    a = np.maximum(rng.normal(0, 1, (B, H, W, Cin)), 0).astype(np.float32)  # a post-ReLU activation
+    w = (rng.normal(0, 1, (Cout, Cin, k, k)) * np.sqrt(2.0 / (k * k * Cout))).astype(np.float32)
+    dev = "cuda"
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d_a, d_w = t(a), t(w)
+    w_f, w_b = torch.empty(k * k, Cout, Cin, device=dev), torch.empty(k * k, Cin, Cout, device=dev)
+    L.call("ttk_conv_weight_repack", p(d_w), p(w_f), p(w_b), Cout, Cin, k, k)
+
+    # ---- forward
+    a64 = torch.from_numpy(a).double().permute(0, 3, 1, 2).requires_grad_(True)
+    w64 = torch.from_numpy(w).double().requires_grad_(True)
+    y64 = F.conv2d(a64, w64, stride=stride, padding=pad)
+    y_ref = y64.detach().permute(0, 2, 3, 1).numpy()
+    M = B * Ho * Ho
+    rows = L.partial_rows_gemm(M)
+    y = torch.empty(B, Ho, Ho, Cout, device=dev)
+    part = torch.full((rows, 2, Cout), float("nan"), device=dev)
+    L.call("ttk_conv_fwd", p(d_a), p(w_f), p(y), p(part), B, H, W, Cin, Cout, k, k, stride, pad)
+    torch.cuda.synchronize()
+    assert _rel(y.cpu().numpy(), y_ref) < 1.5e-6
+    ps = part.cpu().numpy().astype(np.float64)
+    assert np.isfinite(ps).all()
+    flat = y_ref.reshape(-1, Cout)
+    np.testing.assert_allclose(ps[:, 0].sum(0), flat.sum(0), rtol=0, atol=3e-5 * np.abs(flat).sum(0).max())
+    np.testing.assert_allclose(ps[:, 1].sum(0), (flat ** 2).sum(0), rtol=3e-5)
+
+    # ---- data gradient, raw and masked
+    g = rng.normal(0, 1, (B, Ho, Ho, Cout)).astype(np.float32)
+    bn = _bn_block(Cout, rng)
+    yv = y.cpu().numpy()
+    dy = (bn[BN_GA] * (g - bn[BN_GMEAN]) + bn[BN_GB] * (yv - bn[BN_MEAN])).astype(np.float32)
+    dy64 = torch.from_numpy(dy).double().permute(0, 3, 1, 2)
+    ga_ref, gw_ref = torch.autograd.grad(y64, (a64, w64), dy64)
+    ga_ref = ga_ref.permute(0, 2, 3, 1).numpy()
+    d_g, d_bn = t(g), t(bn)
+    g_in = torch.empty(B, H, W, Cin, device=dev)
+    L.call("ttk_conv_bwd_data", p(d_g), p(y), p(d_bn), p(w_b), None, None, p(g_in), None, B, H, W, Cin, Cout, k, k, stride, pad)
+    torch.cuda.synchronize()
+    assert _rel(g_in.cpu().numpy(), ga_ref) < 1.5e-6
+    if Cin % 64 == 0:
+        mask_y = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+        mbn = _bn_block(Cin, rng)
+        pre = mbn[BN_SCALE] * (mask_y - mbn[BN_MEAN]) + mbn[BN_BETA]
+        safe = np.abs(pre) > 1e-4
+        ref = ga_ref * (pre > 0)
+        d_my, d_mbn = t(mask_y), t(mbn)
+        rows_in = L.partial_rows_gemm(B * H * W)
+        part2 = torch.full((rows_in, 2, Cin), float("nan"), device=dev)
+        L.call("ttk_conv_bwd_data", p(d_g), p(y), p(d_bn), p(w_b), p(d_my), p(d_mbn), p(g_in), p(part2), B, H, W, Cin, Cout, k, k,
+               stride, pad)
+        torch.cuda.synchronize()
+        out = g_in.cpu().numpy()
+        assert _rel(out * safe, ref * safe) < 1.5e-6
+        ps = part2.cpu().numpy().astype(np.float64)
+        o64 = out.astype(np.float64).reshape(-1, Cin)
+        np.testing.assert_allclose(ps[:, 0].sum(0), o64.sum(0), rtol=0, atol=3e-5 * np.abs(o64).sum(0).max())
+        yc = (mask_y.astype(np.float64) - mbn[BN_MEAN]).reshape(-1, Cin)
+        np.testing.assert_allclose(ps[:, 1].sum(0), (o64 * yc).sum(0), rtol=0, atol=3e-5 * np.abs(o64 * yc).sum(0).max())
