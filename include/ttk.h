@@ -42,7 +42,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 4
+#define TTK_ABI_VERSION 5
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -178,6 +178,32 @@ int ttk_conv_fwd(const float* a_in, const float* w_fwd, float* y, float* part, i
 int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const float* w_bwd, const float* mask_y,
                       const float* mask_bn, float* g_in, float* part, int B, int H, int W, int Cin, int Cout,
                       int KH, int KW, int stride, int pad, ttk_stream_t stream);
+int ttk_conv_bwd_weight(const float* g, const float* y, const float* bn, const float* a_in, float* dw, int B, int H,
+                        int W, int Cin, int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The non-GEMM kernels of the ResNet18 variant (backbones/resnet.py:52-104: torchvision ResNet18, 1-channel 7x7 stem).
+ *   ttk_stem7_fwd          y[B][65][65][64] = conv7x7/s2/p3(x[B][1][H][W]) + part[ttk_partial_rows_elementwise(B*Ho*Wo*16)][2][64]
+ *   ttk_stem7_bwd_weight   dw[64][1][7][7] (overwritten) from dy = ga*(g-gmean)+gb*(y-mean)
+ *   ttk_maxpool3x3s2_fwd   a[B][Ho][Wo][C] = maxpool3x3/s2/p1(relu(bn(y))), idx = window position of the first maximum
+ *   ttk_maxpool3x3s2_bwd   g[B][H][W][C] = gradient w.r.t. bn(y) (ReLU mask applied) from ga (+ gb) w.r.t. the pooled
+ *                          activation; part[ttk_partial_rows_elementwise(B*H*W*C/4)][2][C] = (sum g, sum g*(y-mean))
+ *   ttk_bn_add_act         a = relu(bn(y) + r); r = res, or res_bn(res) when res is the raw downsample-conv output
+ *                          (BasicBlock: out = relu(bn2(conv2) + identity)), or nothing
+ *   ttk_residual_bwd       gs = (ga (+ gb)) * [a > 0]; part = sums for bn(y); partd (with yd, bnd) = sums for the
+ *                          downsample BatchNorm; rows of both = ttk_partial_rows_elementwise(rows*C/4)
+ * ------------------------------------------------------------------------------------------- */
+int ttk_stem7_fwd(const float* x, const float* w, float* y, float* part, int B, int H, int W, ttk_stream_t stream);
+int ttk_stem7_bwd_weight(const float* g, const float* y, const float* bn, const float* x, float* dw, int B, int H,
+                         int W, ttk_stream_t stream);
+int ttk_maxpool3x3s2_fwd(const float* y, const float* bn, float* a, unsigned char* idx, int B, int H, int W, int C,
+                         ttk_stream_t stream);
+int ttk_maxpool3x3s2_bwd(const float* ga, const float* gb, const unsigned char* idx, const float* y, const float* bn,
+                         float* g, float* part, int B, int H, int W, int C, ttk_stream_t stream);
+int ttk_bn_add_act(const float* y, const float* bn, const float* res, const float* res_bn, float* a, int64_t rows,
+                   int C, ttk_stream_t stream);
+int ttk_residual_bwd(const float* ga, const float* gb, const float* a, const float* y, const float* bn, const float* yd,
+                     const float* bnd, float* gs, float* part, float* partd, int64_t rows, int C, ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-task heads - everything NetworkWithPointHead.forward does after the backbone

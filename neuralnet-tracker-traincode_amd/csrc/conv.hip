@@ -68,4 +68,16 @@ int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const flo
   TTK_LAUNCH_CHECK("conv_bwd_data");
 }
 
+// dw[Cout][Cin][KH][KW] += sum_{pixels} dy (x) a_in.  The caller zeroes dw (or accumulates on purpose).
+int ttk_conv_bwd_weight(const float* g, const float* y, const float* bn, const float* a_in, float* dw, int B, int H, int W,
+                        int Cin, int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream) {
+  TTK_REQUIRE(g && y && bn && a_in && dw, "conv_bwd_weight: null pointer");
+  TTK_REQUIRE(conv_shape_ok(B, H, W, Cin, Cout, KH, KW, stride, pad), "conv_bwd_weight: unsupported shape");
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  const ConvGeom geo{H, W, Ho, Wo, stride, pad, KW, Cin, 0};
+  const bool ok = launch_conv_wgrad(g, y, bn, a_in, dw, (int64_t)B * Ho * Wo, Cout, KH * KW, geo, (hipStream_t)stream);
+  TTK_REQUIRE(ok, "conv_bwd_weight: no kernel for this shape");
+  TTK_LAUNCH_CHECK("conv_bwd_weight");
+}
+
 }  // extern "C"

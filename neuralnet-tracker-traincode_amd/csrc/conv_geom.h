@@ -22,4 +22,7 @@ bool launch_conv_gemm(int amode, int emode, const float* A0, const float* A1, co
                       const float* E0, const float* bnE, float* part, int64_t M, int K, int Nout, const ConvGeom& geo,
                       hipStream_t st);
 
+bool launch_conv_wgrad(const float* g, const float* y, const float* bn, const float* a_in, float* dw, int64_t M, int Cout,
+                       int taps, const ConvGeom& geo, hipStream_t st);
+
 }  // namespace ttk

@@ -362,11 +362,15 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
 // consecutive m of channel e, which is split and written as one 8-byte piece into the [channel][m] image.
 // grid.x = dW tiles, grid.y = slices of M (one fp32 atomicAdd per output element and slice).
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN>
+template <int BM, int BN, bool CONV>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const float* __restrict__ bn_pw,
-                 const float* __restrict__ Ydw, const float* __restrict__ bn_dw, float* __restrict__ dW, int64_t M, int Cin,
-                 int Cout, int64_t rows_per_slice) {
+                 const float* __restrict__ X, const float* __restrict__ bn_x, float* __restrict__ dW, int64_t M, int Ncols,
+                 int Cout, int64_t rows_per_slice, ConvGeom geo) {
+  // Pointwise (CONV = false): columns = input channels, X = raw depthwise output (BatchNorm+ReLU applied on load).
+  // Convolution (CONV = true): columns = (tap, input channel), X = the materialised input activation [B][Hs][Ws][Kc];
+  // the rows m enumerate OUTPUT pixels (Hg x Wg per image) and column (tap, ci) reads the input pixel the tap points
+  // at (zero outside).  Partial tiles (Cout < BM, Ncols % BN != 0) are masked.
   static_assert(BM + BN == 384 && (BM == 128 || BM == 256), "128x256 or 256x128");
   constexpr int APL = BM * 32, BPL = BN * 32;
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -379,8 +383,9 @@ pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const
   const unsigned xq = NG / 8, xr = NG % 8, xcd = Lid % 8;
   const unsigned logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + Lid / 8;
   const unsigned tile = logical % T, slice = logical / T;
-  const int tiles_k = Cin / BN;
+  const int tiles_k = (Ncols + BN - 1) / BN;
   const int n0 = (tile / tiles_k) * BM, k0 = (tile % tiles_k) * BN;
+  const int Kc = CONV ? geo.Kc : Ncols;  // row length of X
   const int64_t m_begin = (int64_t)slice * rows_per_slice;
   const int64_t m_end = (m_begin + rows_per_slice < M) ? m_begin + rows_per_slice : M;
   if (m_begin >= m_end) return;  // uniform over the block, before any barrier
@@ -394,24 +399,34 @@ pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const
     constexpr int AP = BM / 128, BP = BN / 128;
     f32x4 rg[AP][4], ry[AP][4], rx[BP][4];
     f32x4 ga[AP], gb[AP], gmean[AP], ymean[AP], sc[BP], mu[BP], be[BP];
+    int ca[AP], cb[BP], kh[BP], kw[BP];  // channel of the A rows; input channel and tap of the B columns
+    bool va[AP], vb[BP];
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       const int c = n0 + 4 * (cq + 32 * p);
-      ga[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GA * Cout + c);
-      gb[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GB * Cout + c);
-      gmean[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GMEAN * Cout + c);
-      ymean[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_MEAN * Cout + c);
+      va[p] = c < Cout;
+      ca[p] = va[p] ? c : 0;
+      ga[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GA * Cout + ca[p]);
+      gb[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GB * Cout + ca[p]);
+      gmean[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GMEAN * Cout + ca[p]);
+      ymean[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_MEAN * Cout + ca[p]);
     }
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
       const int c = k0 + 4 * (cq + 32 * p);
-      sc[p] = *reinterpret_cast<const f32x4*>(bn_dw + TTK_BN_SCALE * Cin + c);
-      mu[p] = *reinterpret_cast<const f32x4*>(bn_dw + TTK_BN_MEAN * Cin + c);
-      be[p] = *reinterpret_cast<const f32x4*>(bn_dw + TTK_BN_BETA * Cin + c);
+      vb[p] = c < Ncols;
+      const int cc = vb[p] ? c : 0;
+      const int tap = CONV ? cc / Kc : 0;
+      cb[p] = cc - tap * Kc;
+      kh[p] = CONV ? tap / geo.KW : 0;
+      kw[p] = CONV ? tap - kh[p] * geo.KW : 0;
+      if constexpr (!CONV) {
+        sc[p] = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_SCALE * Kc + cb[p]);
+        mu[p] = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_MEAN * Kc + cb[p]);
+        be[p] = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_BETA * Kc + cb[p]);
+      }
     }
-    const float* gp = G + n0 + 4 * cq;
-    const float* yp = Y + n0 + 4 * cq;
-    const float* xp = Ydw + k0 + 4 * cq;
+    unsigned bmask = 0u;  // (pass, row) pairs of the in-flight B loads that hit the source tensor
     unsigned char* wbase = lds + sub * kStageStride + o8;
 
     auto load_a = [&](int ks) {
@@ -421,18 +436,43 @@ pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const
         row = row < m_end ? row : m_end - 1;
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-          rg[p][i] = *reinterpret_cast<const f32x4*>(gp + row * Cout + 128 * p);
-          ry[p][i] = *reinterpret_cast<const f32x4*>(yp + row * Cout + 128 * p);
+          rg[p][i] = *reinterpret_cast<const f32x4*>(G + row * Cout + ca[p]);
+          ry[p][i] = *reinterpret_cast<const f32x4*>(Y + row * Cout + ca[p]);
         }
       }
     };
     auto load_b = [&](int ks) {
+      const int64_t r0 = m_begin + (int64_t)ks * 32 + 4 * mb;
+      if constexpr (!CONV) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int64_t row = m_begin + (int64_t)ks * 32 + 4 * mb + i;
-        row = row < m_end ? row : m_end - 1;
+        for (int i = 0; i < 4; ++i) {
+          int64_t row = r0 + i;
+          row = row < m_end ? row : m_end - 1;
 #pragma unroll
-        for (int p = 0; p < BP; ++p) rx[p][i] = *reinterpret_cast<const f32x4*>(xp + row * Cin + 128 * p);
+          for (int p = 0; p < BP; ++p) rx[p][i] = *reinterpret_cast<const f32x4*>(X + row * Kc + cb[p]);
+        }
+      } else {
+        // (n, ho, wo) of the first of the four consecutive output pixels by division, the others by carry
+        const int hw = geo.Hg * geo.Wg;
+        const int rr = (int)(r0 < m_end ? r0 : m_end - 1);
+        int n = rr / hw, rem = rr - n * hw, ho = rem / geo.Wg, wo = rem - ho * geo.Wg;
+        bmask = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool rowok = r0 + i < m_end;
+#pragma unroll
+          for (int p = 0; p < BP; ++p) {
+            const int hi = ho * geo.stride - geo.pad + kh[p], wi = wo * geo.stride - geo.pad + kw[p];
+            const bool ok = rowok && vb[p] && (unsigned)hi < (unsigned)geo.Hs && (unsigned)wi < (unsigned)geo.Ws;
+            const int64_t off = ok ? ((int64_t)((n * geo.Hs + hi) * geo.Ws + wi) * Kc + cb[p]) : (int64_t)cb[p];
+            bmask |= (ok ? 1u : 0u) << (4 * p + i);
+            rx[p][i] = *reinterpret_cast<const f32x4*>(X + off);
+          }
+          if (++wo == geo.Wg) {
+            wo = 0;
+            if (++ho == geo.Hg) { ho = 0; ++n; }
+          }
+        }
       }
     };
     auto store_a = [&](int ks) {
@@ -444,7 +484,7 @@ pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           v[i] = ga[p] * (rg[p][i] - gmean[p]) + gb[p] * (ry[p][i] - ymean[p]);
-          if (row0 + i >= m_end) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the slice contribute nothing
+          if (row0 + i >= m_end || !va[p]) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the slice contribute nothing
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -459,9 +499,13 @@ pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const
         f32x4 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          v[i] = sc[p] * (rx[p][i] - mu[p]) + be[p];
-          v[i].x = fmaxf(v[i].x, 0.f); v[i].y = fmaxf(v[i].y, 0.f); v[i].z = fmaxf(v[i].z, 0.f); v[i].w = fmaxf(v[i].w, 0.f);
-          if (row0 + i >= m_end) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (!CONV) {
+            v[i] = sc[p] * (rx[p][i] - mu[p]) + be[p];
+            v[i].x = fmaxf(v[i].x, 0.f); v[i].y = fmaxf(v[i].y, 0.f); v[i].z = fmaxf(v[i].z, 0.f); v[i].w = fmaxf(v[i].w, 0.f);
+            if (row0 + i >= m_end || !vb[p]) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          } else {
+            v[i] = ((bmask >> (4 * p + i)) & 1u) ? rx[p][i] : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -500,16 +544,20 @@ pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     consume_tile<BM, BN>(lds, nks, wm, wn, r, h, acc);
+    const int taps = CONV ? Ncols / Kc : 1;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j) {
+      const int col = k0 + wn * (BN / 2) + j * 32 + r;
+      if (col >= Ncols) continue;
+      const int tap = CONV ? col / Kc : 0, ci = col - tap * Kc;
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = n0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const int col = k0 + wn * (BN / 2) + j * 32 + r;
-          atomicAdd(dW + (size_t)row * Cin + col, acc[i][j][e]);
+          if (row < Cout) atomicAdd(dW + ((size_t)row * Kc + ci) * taps + tap, acc[i][j][e]);  // dw[co][ci][tap]
         }
+    }
   }
 }
 
@@ -527,9 +575,26 @@ bool launch_split_wgrad(const float* g, const float* y, const float* bn_pw, cons
   slices = ceil_div(M, rows);
   const dim3 grid(tiles, (unsigned)slices);
   if (wide)
-    hipLaunchKernelGGL((pw_split_wgrad_k<128, 256>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, M, Cin, Cout, rows);
+    hipLaunchKernelGGL((pw_split_wgrad_k<128, 256, false>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, M, Cin, Cout, rows, ConvGeom{});
   else
-    hipLaunchKernelGGL((pw_split_wgrad_k<256, 128>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, M, Cin, Cout, rows);
+    hipLaunchKernelGGL((pw_split_wgrad_k<256, 128, false>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, M, Cin, Cout, rows, ConvGeom{});
+  return true;
+}
+
+// dw[Cout][Cin][taps] += sum over output pixels of dy (x) gathered input activation (conv.hip)
+bool launch_conv_wgrad(const float* g, const float* y, const float* bn, const float* a_in, float* dw, int64_t M, int Cout,
+                       int taps, const ConvGeom& geo, hipStream_t st) {
+  if (geo.Kc % 4 != 0 || Cout % 4 != 0) return false;
+  const int ncols = taps * geo.Kc;
+  const int tiles = (int)(ceil_div(Cout, 128) * ceil_div(ncols, 256));
+  int64_t slices = 256 / tiles;
+  if (slices < 1) slices = 1;
+  const int64_t max_slices = ceil_div(M, 128);
+  if (slices > max_slices) slices = max_slices;
+  const int64_t rows = ceil_div(ceil_div(M, slices), 32) * 32;
+  slices = ceil_div(M, rows);
+  hipLaunchKernelGGL((pw_split_wgrad_k<128, 256, true>), dim3(tiles, (unsigned)slices), dim3(512), 0, st, g, y, bn, a_in, nullptr, dw,
+                     M, ncols, Cout, rows, geo);
   return true;
 }
 

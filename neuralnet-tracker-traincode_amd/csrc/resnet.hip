@@ -1,0 +1,336 @@
+// The non-GEMM kernels of the ResNet18 backbone variant (reference: backbones/resnet.py:52-104 = torchvision ResNet
+// with a 1-channel 7x7 stem; BasicBlock arithmetic restated from torchvision.models.resnet, which the reference does
+// not vendor): stem convolution and its weight gradient, 3x3/s2 max-pool with BatchNorm+ReLU on load, the residual
+// add + ReLU that materialises a block's output activation, and the elementwise backward of that add.  All HBM-bound;
+// the dense 3x3 / 1x1 convolutions are in conv.hip.
+#include "ttk_common.h"
+
+namespace ttk {
+
+constexpr int kS7C = 64;      // stem output channels
+constexpr int kS7K = 7;       // 7x7, stride 2, pad 3
+constexpr int kS7Half = 32;   // channels per workgroup column (blockIdx.y)
+
+// thread = TWO horizontally adjacent output pixels x 32 channels (same scheme as stem.hip, see there): the filter
+// bank of this channel half sits in LDS as wt[tap][c] and is read with wave-uniform (broadcast) ds_read_b128.
+__global__ void __launch_bounds__(kBlock) stem7_fwd_k(const float* __restrict__ x, const float* __restrict__ w,
+                                                       float* __restrict__ y, float* __restrict__ part, int B, int H, int W,
+                                                       int Ho, int Wo) {
+  __shared__ __attribute__((aligned(16))) float wt[kS7K * kS7K][kS7Half];
+  __shared__ float red[kBlock / kWave][2 * kS7Half];
+  const int cbase = blockIdx.y * kS7Half;
+  for (int i = threadIdx.x; i < kS7K * kS7K * kS7Half; i += kBlock) {
+    const int t = i % (kS7K * kS7K), c = i / (kS7K * kS7K);
+    wt[t][c] = w[(size_t)(cbase + c) * kS7K * kS7K + t];  // w[c][tap] -> wt[tap][c]
+  }
+  __syncthreads();
+  float s1[kS7Half], s2[kS7Half];
+#pragma unroll
+  for (int c = 0; c < kS7Half; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+  const int Wpairs = (Wo + 1) / 2;
+  const int64_t npairs = (int64_t)B * Ho * Wpairs;
+  for (int64_t pr = (int64_t)blockIdx.x * kBlock + threadIdx.x; pr < npairs; pr += (int64_t)gridDim.x * kBlock) {
+    asm volatile("" ::: "memory");  // keep the LDS filter reads inside the iteration (see stem.hip)
+    const int wp = (int)(pr % Wpairs), ho = (int)((pr / Wpairs) % Ho), n = (int)(pr / ((int64_t)Wpairs * Ho));
+    const int wo = 2 * wp;
+    const bool second = wo + 1 < Wo;
+    const float* xn = x + (size_t)n * H * W;
+    float xin[kS7K][kS7K + 2];
+#pragma unroll
+    for (int kh = 0; kh < kS7K; ++kh) {
+      const int hi = 2 * ho + kh - 3;
+#pragma unroll
+      for (int k = 0; k < kS7K + 2; ++k) {
+        const int wi = 2 * wo + k - 3;
+        xin[kh][k] = (hi >= 0 && hi < H && wi >= 0 && wi < W) ? xn[(size_t)hi * W + wi] : 0.f;
+      }
+    }
+    float* y0 = y + (((size_t)n * Ho + ho) * Wo + wo) * kS7C + cbase;
+#pragma unroll
+    for (int c4 = 0; c4 < kS7Half / 4; ++c4) {
+      float4 a0 = f4(0.f), a1 = f4(0.f);
+#pragma unroll
+      for (int kh = 0; kh < kS7K; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < kS7K; ++kw) {
+          const float4 wq = ld4(&wt[kh * kS7K + kw][4 * c4]);
+          a0 = fma4(f4(xin[kh][kw]), wq, a0);
+          a1 = fma4(f4(xin[kh][kw + 2]), wq, a1);
+        }
+      st4(y0 + 4 * c4, a0);
+      if (second) st4(y0 + kS7C + 4 * c4, a1);
+      else a1 = f4(0.f);
+      s1[4 * c4 + 0] += a0.x + a1.x; s1[4 * c4 + 1] += a0.y + a1.y; s1[4 * c4 + 2] += a0.z + a1.z; s1[4 * c4 + 3] += a0.w + a1.w;
+      s2[4 * c4 + 0] = fmaf(a0.x, a0.x, fmaf(a1.x, a1.x, s2[4 * c4 + 0]));
+      s2[4 * c4 + 1] = fmaf(a0.y, a0.y, fmaf(a1.y, a1.y, s2[4 * c4 + 1]));
+      s2[4 * c4 + 2] = fmaf(a0.z, a0.z, fmaf(a1.z, a1.z, s2[4 * c4 + 2]));
+      s2[4 * c4 + 3] = fmaf(a0.w, a0.w, fmaf(a1.w, a1.w, s2[4 * c4 + 3]));
+    }
+  }
+  if (part) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < kS7Half; ++c) {
+      float a = s1[c], b = s2[c];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+      if (lane == 0) { red[wv][c] = a; red[wv][kS7Half + c] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * kS7Half) {
+      const int which = threadIdx.x / kS7Half, c = threadIdx.x % kS7Half;
+      float a = 0.f;
+      for (int i = 0; i < kBlock / kWave; ++i) a += red[i][threadIdx.x];  // fixed wave order
+      part[(size_t)blockIdx.x * 2 * kS7C + (size_t)which * kS7C + cbase + c] = a;
+    }
+  }
+}
+
+// dW[c][tap] = sum_pixels dy[pixel][c] * x[tap of pixel].  One wave = one output pixel per iteration, lane = channel:
+// the 49 input values of the pixel are wave-uniform (broadcast through L1), dy is one 256-byte row.
+__global__ void __launch_bounds__(kBlock) stem7_bwd_weight_k(const float* __restrict__ g, const float* __restrict__ y,
+                                                              const float* __restrict__ bn, const float* __restrict__ x,
+                                                              float* __restrict__ dw, int B, int H, int W, int Ho, int Wo) {
+  __shared__ float acc_s[kS7K * kS7K][kS7C];
+  for (int i = threadIdx.x; i < kS7K * kS7K * kS7C; i += kBlock) (&acc_s[0][0])[i] = 0.f;
+  __syncthreads();
+  const int c = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float ga = bn[TTK_BN_GA * kS7C + c], gb = bn[TTK_BN_GB * kS7C + c], gmean = bn[TTK_BN_GMEAN * kS7C + c],
+              mean = bn[TTK_BN_MEAN * kS7C + c];
+  float acc[kS7K * kS7K];
+#pragma unroll
+  for (int t = 0; t < kS7K * kS7K; ++t) acc[t] = 0.f;
+  const int64_t npix = (int64_t)B * Ho * Wo;
+  const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / kWave) + wv, nwaves = (int64_t)gridDim.x * (kBlock / kWave);
+  for (int64_t pix = wave0; pix < npix; pix += nwaves) {
+    const int wo = (int)(pix % Wo), ho = (int)((pix / Wo) % Ho), n = (int)(pix / ((int64_t)Wo * Ho));
+    const float* xn = x + (size_t)n * H * W;
+    const float dy = fmaf(ga, g[pix * kS7C + c] - gmean, gb * (y[pix * kS7C + c] - mean));
+#pragma unroll
+    for (int kh = 0; kh < kS7K; ++kh) {
+      const int hi = 2 * ho + kh - 3;
+#pragma unroll
+      for (int kw = 0; kw < kS7K; ++kw) {
+        const int wi = 2 * wo + kw - 3;
+        const float v = (hi >= 0 && hi < H && wi >= 0 && wi < W) ? xn[(size_t)hi * W + wi] : 0.f;
+        acc[kh * kS7K + kw] = fmaf(v, dy, acc[kh * kS7K + kw]);
+      }
+    }
+  }
+  for (int w = 0; w < kBlock / kWave; ++w) {  // waves fold into LDS in a fixed order
+    if (wv == w) {
+#pragma unroll
+      for (int t = 0; t < kS7K * kS7K; ++t) acc_s[t][c] += acc[t];
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < kS7K * kS7K * kS7C; i += kBlock) {
+    const int t = i % (kS7K * kS7K), cc = i / (kS7K * kS7K);
+    atomicAdd(dw + i, acc_s[t][cc]);  // dw[c][tap]
+  }
+}
+
+// ---- max-pool 3x3 / stride 2 / pad 1 over relu(bn(y)); idx = window position (kh*3+kw) of the FIRST maximum, which is
+// what torch's max_pool2d backward routes the gradient to.  thread = (output pixel, channel quad).
+__global__ void __launch_bounds__(kBlock) maxpool_fwd_k(const float* __restrict__ y, const float* __restrict__ bnp,
+                                                         float* __restrict__ a, unsigned char* __restrict__ idx, int B, int H,
+                                                         int W, int Ho, int Wo, int C) {
+  const int quads = C >> 2;
+  const int c4 = threadIdx.x & (quads - 1);
+  const BnApply4 bn = BnApply4::load(bnp, C, 4 * c4);
+  const int64_t items = (int64_t)B * Ho * Wo * quads;
+  for (int64_t it = (int64_t)blockIdx.x * kBlock + threadIdx.x; it < items; it += (int64_t)gridDim.x * kBlock) {
+    int64_t pix = it / quads;
+    const int wo = (int)(pix % Wo), ho = (int)((pix / Wo) % Ho), n = (int)(pix / ((int64_t)Wo * Ho));
+    float4 m = f4(-1.f);  // relu outputs are >= 0 and every window holds at least one pixel
+    uchar4 am = make_uchar4(0, 0, 0, 0);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hi = 2 * ho + kh - 1;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int wi = 2 * wo + kw - 1;
+        if (hi < 0 || hi >= H || wi < 0 || wi >= W) continue;
+        const float4 v = bn.act(ld4(y + (((size_t)n * H + hi) * W + wi) * C + 4 * c4));
+        const unsigned char t = (unsigned char)(kh * 3 + kw);
+        if (v.x > m.x) { m.x = v.x; am.x = t; }
+        if (v.y > m.y) { m.y = v.y; am.y = t; }
+        if (v.z > m.z) { m.z = v.z; am.z = t; }
+        if (v.w > m.w) { m.w = v.w; am.w = t; }
+      }
+    }
+    st4(a + (size_t)it * 4, m);
+    *reinterpret_cast<uchar4*>(idx + (size_t)it * 4) = am;
+  }
+}
+
+// gradient w.r.t. the BatchNorm output of y (already through the ReLU mask) + that BatchNorm's backward sums.
+// ga (+ gb): gradient(s) w.r.t. the pooled activation.  thread = (input pixel, channel quad).
+__global__ void __launch_bounds__(kBlock) maxpool_bwd_k(const float* __restrict__ ga, const float* __restrict__ gb,
+                                                         const unsigned char* __restrict__ idx, const float* __restrict__ y,
+                                                         const float* __restrict__ bnp, float* __restrict__ g,
+                                                         float* __restrict__ part, int B, int H, int W, int Ho, int Wo, int C) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int quads = C >> 2;
+  const int c4 = threadIdx.x & (quads - 1);
+  const BnApply4 bn = BnApply4::load(bnp, C, 4 * c4);
+  const int64_t items = (int64_t)B * H * W * quads;
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+  for (int64_t it = (int64_t)blockIdx.x * kBlock + threadIdx.x; it < items; it += (int64_t)gridDim.x * kBlock) {
+    int64_t pix = it / quads;
+    const int wi = (int)(pix % W), hi = (int)((pix / W) % H), n = (int)(pix / ((int64_t)W * H));
+    const float4 yv = ld4(y + (size_t)it * 4);
+    const float4 act = bn.act(yv);
+    float4 acc = f4(0.f);
+    // windows (ho, wo) that contain (hi, wi): 2*ho - 1 <= hi <= 2*ho + 1
+    for (int ho = (hi + 1) >> 1; ho >= (hi >> 1) && ho >= 0; --ho) {
+      if (ho >= Ho) continue;
+      const int kh = hi - 2 * ho + 1;
+      for (int wo = (wi + 1) >> 1; wo >= (wi >> 1) && wo >= 0; --wo) {
+        if (wo >= Wo) continue;
+        const unsigned char t = (unsigned char)(kh * 3 + (wi - 2 * wo + 1));
+        const size_t o = ((((size_t)n * Ho + ho) * Wo + wo) * quads + c4) * 4;
+        const uchar4 am = *reinterpret_cast<const uchar4*>(idx + o);
+        float4 gv = ld4(ga + o);
+        if (gb) gv = add4(gv, ld4(gb + o));
+        if (am.x == t) acc.x += gv.x;
+        if (am.y == t) acc.y += gv.y;
+        if (am.z == t) acc.z += gv.z;
+        if (am.w == t) acc.w += gv.w;
+      }
+    }
+    const float4 gv = mask4(acc, act);
+    st4(g + (size_t)it * 4, gv);
+    s1 = add4(s1, gv);
+    s2 = fma4(gv, sub4(yv, bn.mean), s2);
+  }
+  if (part) block_channel_partials<1024>(s1, s2, c4, C, part + (size_t)blockIdx.x * 2 * C, smem);
+}
+
+// a = relu(bn(y) + r), r = res (an activation) or res_bn(res) (a raw conv output, the downsample branch) or nothing
+__global__ void __launch_bounds__(kBlock) bn_add_act_k(const float* __restrict__ y, const float* __restrict__ bnp,
+                                                        const float* __restrict__ res, const float* __restrict__ res_bn,
+                                                        float* __restrict__ a, int64_t items, int C) {
+  const int quads = C >> 2;
+  const int c4 = threadIdx.x & (quads - 1);
+  const BnApply4 bn = BnApply4::load(bnp, C, 4 * c4);
+  BnApply4 rb = bn;
+  if (res_bn) rb = BnApply4::load(res_bn, C, 4 * c4);
+  for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * kBlock) {
+    const size_t off = (size_t)idx << 2;
+    float4 v = bn.pre(ld4(y + off));
+    if (res) v = add4(v, res_bn ? rb.pre(ld4(res + off)) : ld4(res + off));
+    st4(a + off, relu4(v));
+  }
+}
+
+// gs = (ga (+ gb)) * [a > 0]: gradient w.r.t. s = bn(y) + r of a block whose output activation is a = relu(s).
+// part: BatchNorm-backward sums of bn(y) (sum gs, sum gs*(y-mean)); partd (with yd, bnd): the same for the
+// downsample branch's BatchNorm.
+__global__ void __launch_bounds__(kBlock) residual_bwd_k(const float* __restrict__ ga, const float* __restrict__ gb,
+                                                          const float* __restrict__ a, const float* __restrict__ y,
+                                                          const float* __restrict__ bnp, const float* __restrict__ yd,
+                                                          const float* __restrict__ bnd, float* __restrict__ gs,
+                                                          float* __restrict__ part, float* __restrict__ partd, int64_t items,
+                                                          int C) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int quads = C >> 2;
+  const int c4 = threadIdx.x & (quads - 1);
+  const float4 mean = ld4(bnp + TTK_BN_MEAN * C + 4 * c4);
+  const float4 meand = yd ? ld4(bnd + TTK_BN_MEAN * C + 4 * c4) : f4(0.f);
+  float4 s1 = f4(0.f), s2 = f4(0.f), t2 = f4(0.f);
+  for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * kBlock) {
+    const size_t off = (size_t)idx << 2;
+    float4 gv = ld4(ga + off);
+    if (gb) gv = add4(gv, ld4(gb + off));
+    gv = mask4(gv, ld4(a + off));
+    st4(gs + off, gv);
+    s1 = add4(s1, gv);
+    s2 = fma4(gv, sub4(ld4(y + off), mean), s2);
+    if (yd) t2 = fma4(gv, sub4(ld4(yd + off), meand), t2);
+  }
+  block_channel_partials<1024>(s1, s2, c4, C, part + (size_t)blockIdx.x * 2 * C, smem);
+  if (yd) {
+    __syncthreads();
+    block_channel_partials<1024>(s1, t2, c4, C, partd + (size_t)blockIdx.x * 2 * C, smem);
+  }
+}
+
+static bool ew_shape_ok(int64_t rows, int C) { return rows > 0 && C >= 32 && C <= 1024 && (C & (C - 1)) == 0; }
+
+}  // namespace ttk
+
+using namespace ttk;
+
+extern "C" {
+
+int ttk_stem7_fwd(const float* x, const float* w, float* y, float* part, int B, int H, int W, ttk_stream_t stream) {
+  TTK_REQUIRE(x && w && y, "stem7_fwd: null pointer");
+  TTK_REQUIRE(B > 0 && H > 6 && W > 6, "stem7_fwd: bad shape B=%d H=%d W=%d", B, H, W);
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  const int64_t items = (int64_t)B * Ho * Wo * (kS7C / 4);  // sizes the partial rows (ttk_partial_rows_elementwise)
+  hipLaunchKernelGGL(stem7_fwd_k, dim3(elementwise_grid(items), kS7C / kS7Half), dim3(kBlock), 0, (hipStream_t)stream, x, w, y, part,
+                     B, H, W, Ho, Wo);
+  TTK_LAUNCH_CHECK("stem7_fwd");
+}
+
+int ttk_stem7_bwd_weight(const float* g, const float* y, const float* bn, const float* x, float* dw, int B, int H, int W,
+                         ttk_stream_t stream) {
+  TTK_REQUIRE(g && y && bn && x && dw, "stem7_bwd_weight: null pointer");
+  TTK_REQUIRE(B > 0 && H > 6 && W > 6, "stem7_bwd_weight: bad shape");
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  hipMemsetAsync(dw, 0, sizeof(float) * kS7C * kS7K * kS7K, (hipStream_t)stream);
+  int64_t grid = ceil_div((int64_t)B * Ho * Wo, 4 * 64);
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(stem7_bwd_weight_k, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, g, y, bn, x, dw, B, H, W, Ho,
+                     Wo);
+  TTK_LAUNCH_CHECK("stem7_bwd_weight");
+}
+
+int ttk_maxpool3x3s2_fwd(const float* y, const float* bn, float* a, unsigned char* idx, int B, int H, int W, int C,
+                         ttk_stream_t stream) {
+  TTK_REQUIRE(y && bn && a && idx, "maxpool3x3s2_fwd: null pointer");
+  TTK_REQUIRE(B > 0 && H > 1 && W > 1 && ew_shape_ok(1, C), "maxpool3x3s2_fwd: unsupported shape");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int64_t items = (int64_t)B * Ho * Wo * (C / 4);
+  int64_t grid = ceil_div(items, kBlock);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(maxpool_fwd_k, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, y, bn, a, idx, B, H, W, Ho, Wo, C);
+  TTK_LAUNCH_CHECK("maxpool3x3s2_fwd");
+}
+
+int ttk_maxpool3x3s2_bwd(const float* ga, const float* gb, const unsigned char* idx, const float* y, const float* bn, float* g,
+                         float* part, int B, int H, int W, int C, ttk_stream_t stream) {
+  TTK_REQUIRE(ga && idx && y && bn && g, "maxpool3x3s2_bwd: null pointer");
+  TTK_REQUIRE(B > 0 && H > 1 && W > 1 && ew_shape_ok(1, C), "maxpool3x3s2_bwd: unsupported shape");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int64_t items = (int64_t)B * H * W * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_k, dim3(elementwise_grid(items)), dim3(kBlock), 2 * (size_t)C * sizeof(float), (hipStream_t)stream,
+                     ga, gb, idx, y, bn, g, part, B, H, W, Ho, Wo, C);
+  TTK_LAUNCH_CHECK("maxpool3x3s2_bwd");
+}
+
+int ttk_bn_add_act(const float* y, const float* bn, const float* res, const float* res_bn, float* a, int64_t rows, int C,
+                   ttk_stream_t stream) {
+  TTK_REQUIRE(y && bn && a && (res || !res_bn), "bn_add_act: bad arguments");
+  TTK_REQUIRE(ew_shape_ok(rows, C), "bn_add_act: unsupported shape rows=%lld C=%d", (long long)rows, C);
+  const int64_t items = rows * (C / 4);
+  int64_t grid = ceil_div(items, kBlock);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(bn_add_act_k, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, y, bn, res, res_bn, a, items, C);
+  TTK_LAUNCH_CHECK("bn_add_act");
+}
+
+int ttk_residual_bwd(const float* ga, const float* gb, const float* a, const float* y, const float* bn, const float* yd,
+                     const float* bnd, float* gs, float* part, float* partd, int64_t rows, int C, ttk_stream_t stream) {
+  TTK_REQUIRE(ga && a && y && bn && gs && part, "residual_bwd: null pointer");
+  TTK_REQUIRE((yd == nullptr) == (bnd == nullptr) && (yd == nullptr) == (partd == nullptr), "residual_bwd: yd, bnd, partd go together");
+  TTK_REQUIRE(ew_shape_ok(rows, C), "residual_bwd: unsupported shape");
+  const int64_t items = rows * (C / 4);
+  hipLaunchKernelGGL(residual_bwd_k, dim3(elementwise_grid(items)), dim3(kBlock), 2 * (size_t)C * sizeof(float), (hipStream_t)stream,
+                     ga, gb, a, y, bn, yd, bnd, gs, part, partd, items, C);
+  TTK_LAUNCH_CHECK("residual_bwd");
+}
+
+}  // extern "C"

@@ -96,3 +96,9 @@ def test_conv_fwd_bwd_data_bwd_weight(B, H, Cin, Cout, k, stride):
         np.testing.assert_allclose(ps[:, 0].sum(0), o64.sum(0), rtol=0, atol=3e-5 * np.abs(o64).sum(0).max())
         yc = (mask_y.astype(np.float64) - mbn[BN_MEAN]).reshape(-1, Cin)
         np.testing.assert_allclose(ps[:, 1].sum(0), (o64 * yc).sum(0), rtol=0, atol=3e-5 * np.abs(o64 * yc).sum(0).max())
+
+    # ---- weight gradient (accumulates onto a zeroed buffer; torch layout [Cout][Cin][k][k])
+    dw = torch.zeros(Cout, Cin, k, k, device=dev)
+    L.call("ttk_conv_bwd_weight", p(d_g), p(y), p(d_bn), p(d_a), p(dw), B, H, W, Cin, Cout, k, k, stride, pad)
+    torch.cuda.synchronize()
+    assert _rel(dw.cpu().numpy(), gw_ref.numpy()) < 1.5e-6
