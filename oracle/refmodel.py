@@ -275,6 +275,57 @@ def mobilenet_forward(st, x: Tensor, training: bool, momentum: float = 0.1, pref
 # =============================================================================================
 # heads  (neuralnets/models.py:96-215, negloglikelihood.py:22-65,187-242, modelcomponents.py:136-184)
 # =============================================================================================
+# =============================================================================================
+# ResNet18 variant (backbones/resnet.py:52-104).  PARITY UNPINNED: the arithmetic lives in torchvision.models.resnet
+# (requirements.txt:3, version not pinned; absent from this image), so this restates torchvision's published
+# BasicBlock / ResNet.forward and cannot be checked against an import of the reference.  Anchors: the reference's call
+# site (resnet.py:58-73: _resnet(BasicBlock, [2,2,2,2]), conv1 := Conv2d(1,64,7,2,3), children()[:-1] + Flatten) and
+# its shape tests (test/test_backbones.py:19-40).
+# =============================================================================================
+RESNET18_PLAN = [(64, 1), (64, 1), (128, 2), (128, 1), (256, 2), (256, 1), (512, 2), (512, 1)]
+
+
+def resnet18_state_shapes(prefix="") -> dict:
+    s = {}
+
+    def bn(name, c):
+        s[name + ".weight"], s[name + ".bias"] = (c,), (c,)
+        s[name + ".running_mean"], s[name + ".running_var"], s[name + ".num_batches_tracked"] = (c,), (c,), ()
+
+    s[prefix + "layers.0.weight"] = (64, 1, 7, 7)
+    bn(prefix + "layers.1", 64)
+    cin = 64
+    for i, (planes, stride) in enumerate(RESNET18_PLAN):
+        b = f"{prefix}layers.{4 + i // 2}.{i % 2}"
+        s[b + ".conv1.weight"] = (planes, cin, 3, 3)
+        bn(b + ".bn1", planes)
+        s[b + ".conv2.weight"] = (planes, planes, 3, 3)
+        bn(b + ".bn2", planes)
+        if stride != 1 or cin != planes:
+            s[b + ".downsample.0.weight"] = (planes, cin, 1, 1)
+            bn(b + ".downsample.1", planes)
+        cin = planes
+    return s
+
+
+def resnet18_forward(st, x: Tensor, training: bool, momentum: float = 0.1, prefix=""):
+    """[B,1,H,W] -> ([B,512], None)"""
+    y = F.conv2d(x, st[prefix + "layers.0.weight"], stride=2, padding=3)
+    y = F.max_pool2d(torch.relu(_bn(y, st, prefix + "layers.1", training, momentum)), 3, 2, 1)
+    cin = 64
+    for i, (planes, stride) in enumerate(RESNET18_PLAN):
+        b = f"{prefix}layers.{4 + i // 2}.{i % 2}"
+        identity = y
+        out = F.conv2d(y, st[b + ".conv1.weight"], stride=stride, padding=1)
+        out = torch.relu(_bn(out, st, b + ".bn1", training, momentum))
+        out = _bn(F.conv2d(out, st[b + ".conv2.weight"], stride=1, padding=1), st, b + ".bn2", training, momentum)
+        if stride != 1 or cin != planes:
+            identity = _bn(F.conv2d(y, st[b + ".downsample.0.weight"], stride=stride), st, b + ".downsample.1", training, momentum)
+        y = torch.relu(out + identity)
+        cin = planes
+    return y.mean(dim=(2, 3)), None
+
+
 def _linear(st, prefix, f):
     return F.linear(f, st[prefix + ".weight"], st[prefix + ".bias"])
 

@@ -63,7 +63,8 @@ def make_state(shapes: dict[str, tuple], seed: int = 0) -> dict[str, np.ndarray]
         shape = tuple(shape)
         r = _rng(seed, name)
         leaf = name.rsplit(".", 1)[-1]
-        is_bn = ".bn" in name or name.startswith("bn") or ".downsample.1" in name
+        is_bn = (".bn" in name or name.startswith("bn") or ".downsample.1" in name
+                 or name.startswith("layers.1.") or ".layers.1." in name)  # layers.1 = the ResNet stem's BatchNorm
         if leaf == "num_batches_tracked":
             v = np.zeros(shape, dtype=np.int64)
         elif leaf == "running_mean":

@@ -117,3 +117,26 @@ def test_swa_callback_matches_reference():
         cb.on_train_epoch_end(i, m)
     for k, v in cb.swa_model.state_dict().items():
         np.testing.assert_allclose(v.numpy(), s[k], rtol=1e-6, atol=1e-7, err_msg=k)
+
+
+def test_resnet18_module_surface():
+    """State-dict inventory (torchvision naming, reference resnet.py:68-73), init laws and the CPU eval path."""
+    import torch
+    from oracle import refmodel as R
+    from trackertraincode.backbones.resnet import BasicBlock, resnet18
+
+    net = resnet18()
+    assert net.num_features == 512
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == R.resnet18_state_shapes()
+    assert list(net.state_dict().keys()) == list(R.resnet18_state_shapes().keys())
+    assert all(float(m.bn2.weight.abs().max()) == 0.0 for m in net.modules() if isinstance(m, BasicBlock))  # zero_init_residual
+    net.eval()
+    x = torch.rand(2, 1, 129, 129) - 0.5
+    with torch.no_grad():
+        feat, inter = net(x)
+        st = {k: v.clone() for k, v in net.state_dict().items()}
+        ref, _ = R.resnet18_forward(st, x, False)
+    assert inter is None and feat.shape == (2, 512)
+    torch.testing.assert_close(feat, ref, rtol=1e-5, atol=1e-6)
+    with __import__("pytest").raises(NotImplementedError):
+        resnet18(use_blurpool=True)
