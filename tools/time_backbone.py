@@ -4,12 +4,17 @@ import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "neuralnet-tracker-traincode_amd"))
 from trackertraincode.backbones.mobilenet_v1 import MobileNet
+from trackertraincode.backbones.resnet import resnet18
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+which = sys.argv[3] if len(sys.argv) > 3 else "mobilenetv1"
 torch.manual_seed(0)
-net = MobileNet(num_classes=None).cuda().train()
+net = (resnet18() if which == "resnet18" else MobileNet(num_classes=None)).cuda().train()
+if which == "resnet18":
+    for m in net.modules():  # zero_init_residual would make half the network's gradients trivially zero
+        if hasattr(m, "bn2"): torch.nn.init.constant_(m.bn2.weight, 1.0)
 x = torch.rand(B, 1, 129, 129, device="cuda") - 0.5
-G = torch.randn(B, 1024, device="cuda")
+G = torch.randn(B, net.num_features, device="cuda")
 def step():
     for p in net.parameters(): p.grad = None
     f = net.forward_features(x)
