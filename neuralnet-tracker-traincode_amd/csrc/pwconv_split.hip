@@ -158,7 +158,7 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
     const int row0 = pt >> 3, kq8 = pt & 7;  // 32 rows per pass; 8 lanes x 16 B = one 128-byte row segment
     const int sub = kq8 >> 2, chunk = (kq8 >> 1) & 1, o8 = (kq8 & 1) * 8;
     constexpr int AP = BM / 32, BP = BN / 32;
-    f32x4 ra0[AP], ra1[AMODE == AMODE_BNGRAD ? AP : 1], rb[BP], q0, q1, q2, q3;
+    f32x4 ra0[AP], ra1[AMODE == AMODE_BNGRAD ? AP : 1], rb[2][BP], q0, q1, q2, q3;  // B: two register sets (see the loop)
     const int Kc = GATHER ? geo.Kc : K;   // channels per tap (= K without taps)
     const int kpt = Kc / 32;              // k32 steps per tap
     int64_t arow[GATHER ? 1 : AP];        // plain GEMM: element offset of each of this thread's rows
@@ -228,11 +228,11 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
         q3 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * Kc + kc0);
       }
     };
-    auto load_b = [&](int ks) {
+    auto load_b = [&](int ks, int set) {
       const int tap = ks / kpt, kc0 = (ks - tap * kpt) * 32;
       const float* b = bp + (int64_t)tap * Nout * Kc + kc0;
 #pragma unroll
-      for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b + (int64_t)(32 * i) * Kc);
+      for (int i = 0; i < BP; ++i) rb[set][i] = *reinterpret_cast<const f32x4*>(b + (int64_t)(32 * i) * Kc);
     };
     auto store_a = [&](int ks) {
       unsigned char* S = wbase + (ks & 1) * 2 * kStageStride;
@@ -252,33 +252,46 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
         split_store(v, S + swz_off(row0 + 32 * i, chunk), APL);
       }
     };
-    auto store_b = [&](int ks) {
+    auto store_b = [&](int ks, int set) {
       unsigned char* S = wbase + (ks & 1) * 2 * kStageStride + 3 * APL;
 #pragma unroll
-      for (int i = 0; i < BP; ++i) split_store(rb[i], S + swz_off(row0 + 32 * i, chunk), BPL);
+      for (int i = 0; i < BP; ++i) split_store(rb[set][i], S + swz_off(row0 + 32 * i, chunk), BPL);
     };
 
-    load_a(0);
-    load_b(0);
-    store_a(0);
-    if (nks > 1) load_a(1);
-    __builtin_amdgcn_sched_barrier(0);
-    store_b(0);
-    if (nks > 1) load_b(1);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();  // super-stage 0 is in LDS
-    for (int it = 0; it < nks; ++it) {
-      // fill super-stage it+1 while the consumers multiply super-stage it.  The A operand (HBM, long latency) is
-      // converted first and its next loads issued at once; the B operand (weights, L2-resident) follows.
+    // Cycle stamps of this loop (s_memtime around each phase, 128x256 forward tile) put the PRODUCERS on the critical
+    // path: ~960 cycles for the A half, ~1150 for the B half of pure work, plus whatever part of the load latency is
+    // exposed, against ~3300 cycles of MFMA issue per k32 - and the consumers waited 900-2000 cycles per step at the
+    // barrier.  The B (weight) loads were the ones issued last and needed first, so B has two register sets: stage
+    // it+2 is loaded at the START of step it and consumed a whole step later.  (Giving A a second set too made the
+    // data-gradient producers spill and the load issue itself stall - the CU's vector-memory queue was full.)
+    auto step = [&](int it, int set_ld, int set_st) {  // fills super-stage it+1
+      if (it + 2 < nks) load_b(it + 2, set_ld);
+      __builtin_amdgcn_sched_barrier(0);
       if (it + 1 < nks) {
         store_a(it + 1);
         if (it + 2 < nks) load_a(it + 2);
         __builtin_amdgcn_sched_barrier(0);
-        store_b(it + 1);
-        if (it + 2 < nks) load_b(it + 2);
+        store_b(it + 1, set_st);
         __builtin_amdgcn_sched_barrier(0);
       }
+    };
+    load_a(0);
+    load_b(0, 0);
+    if (nks > 1) load_b(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_a(0);
+    if (nks > 1) load_a(1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_b(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // super-stage 0 is in LDS
+    for (int it = 0; it < nks; it += 2) {
+      step(it, 0, 1);
       __syncthreads();
+      if (it + 1 < nks) {
+        step(it + 1, 1, 0);
+        __syncthreads();
+      }
     }
   } else {
     // ------------------------------------------------------------------ consumer waves
