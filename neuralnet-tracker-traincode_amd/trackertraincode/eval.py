@@ -1,0 +1,223 @@
+"""Evaluation path: `Predictor` (face box -> 129x129 crop -> network -> predictions in image coordinates) and the pose /
+landmark error metrics (reference: trackertraincode/eval.py:158-252, 295-440; scripts/evaluate_pose_network.py).
+
+The crop is produced on the MI355X by the affine-warp kernels of csrc/warp.hip (the same kernels as the training
+augmentation, with the deterministic parameters of the reference's `FocusRoi`: enlargement 1.1, no shift, no rotation),
+the network runs its eval-mode HIP path, and the back-transformation to image coordinates is the inverse of the crop
+transform applied with `apply_affine2d`.  The reference crops with OpenCV (`croprescale_image_cv2`, area / linear
+filters); this build resamples bilinearly like its `affine_transform_image_torch` - predictions on real images differ
+from an OpenCV crop at the level of the resampling filter, which is why MAE parity is asserted against the CPU
+oracle running the SAME resampling (tests/test_eval_gpu.py), not against stored reference numbers.
+torchmetrics is not a dependency here: the metrics are small accumulators with the reference's names and formulas."""
+from __future__ import annotations
+
+from typing import Dict, List, NamedTuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import utils
+from .datasets.batch import Batch, Metadata
+from .datatransformation.batch.geometric import NoRoiRandomization
+from .datatransformation.gpu import GpuFocusRoiAugment
+from .datatransformation.tensors.affinetrafo import FieldCategory, apply_affine2d, position_normalization
+from .neuralnets import torchquaternion
+from .neuralnets.affine2d import Affine2d
+
+
+class Predictor:
+    """`predict_batch(images, rois)`: images = list of uint8 tensors [H,W] / [H,W,1] / [H,W,3] (grey levels or RGB,
+    any sizes) or one [B,1,H,W] tensor; rois [B,4] = (x0, y0, x1, y1) face boxes in pixels.  Returns a Batch with the
+    network outputs mapped back to image coordinates: coord [B,3] (x, y, head size in pixels), pose [B,4], roi [B,4],
+    pt3d_68 [B,68,3] (when the network has the landmark head) - reference :185-208."""
+
+    def __init__(self, net: torch.nn.Module, focus_roi_expansion_factor: float = 1.1, device: str | torch.device = "cuda"):
+        self._net = net.to(device).eval()
+        self._device = torch.device(device)
+        self._crop = GpuFocusRoiAugment(new_size=net.input_resolution, make_params=NoRoiRandomization(focus_roi_expansion_factor))
+
+    @property
+    def input_resolution(self) -> int:
+        return self._net.input_resolution
+
+    @staticmethod
+    def _grey(img: Tensor) -> Tensor:
+        if img.dim() == 3 and img.shape[-1] == 3:  # ITU-R 601 luma, as the training data is stored (grey 8 bit)
+            w = torch.tensor([0.299, 0.587, 0.114], dtype=torch.float32, device=img.device)
+            img = (img.to(torch.float32) * w).sum(-1).round().clamp(0, 255).to(torch.uint8)
+        elif img.dim() == 3:
+            img = img[..., 0]
+        return img
+
+    def crop_batch(self, images, rois: Tensor) -> Batch:
+        """Normalised crops [B,1,N,N] (whitened) + the pixel transforms image -> crop used for the back-transformation."""
+        rois = rois.to(self._device, torch.float32)
+        if torch.is_tensor(images):
+            groups = {tuple(images.shape[-2:]): list(range(images.shape[0]))}
+            get = lambda i: images[i, 0]
+        else:
+            groups: Dict[tuple, List[int]] = {}
+            for i, im in enumerate(images):
+                groups.setdefault(tuple(self._grey(im).shape), []).append(i)
+            get = lambda i: self._grey(images[i])
+        B = rois.shape[0]
+        N = self.input_resolution
+        crops = torch.empty((B, 1, N, N), dtype=torch.float32, device=self._device)
+        trs = torch.empty((B, 2, 3), dtype=torch.float32, device=self._device)
+        for _, idx in groups.items():  # images of one size are warped together
+            src = torch.stack([get(i).to(self._device) for i in idx])[:, None].contiguous()
+            sub = Batch(Metadata(tuple(src.shape[-2:][::-1]), len(idx)), image=src, roi=rois[idx])
+            out = self._crop(sub)
+            crops[idx], trs[idx] = out["image"], out.transform
+        return Batch(Metadata(N, B), image=crops, image_transform=trs)
+
+    @torch.no_grad()
+    def predict_batch(self, images, rois: Tensor) -> Batch:
+        crop = self.crop_batch(images, rois)
+        preds = self._net(crop["image"])
+        N = self.input_resolution
+        # image pixels -> crop pixels -> [-1, 1]: invert the whole chain for the predictions (reference :199-206:
+        # unnormalize_batch, then the stored image_backtransform)
+        to_norm = position_normalization(N, N).to(self._device) @ Affine2d(crop["image_transform"])
+        back = to_norm.inv()
+        cats = {"coord": FieldCategory.xys, "pose": FieldCategory.quat, "pt3d_68": FieldCategory.points, "roi": FieldCategory.roi}
+        out = {}
+        for k, c in cats.items():
+            if k in preds:
+                v = preds[k]
+                out[k] = apply_affine2d(back, k, v.value if hasattr(v, "value") else v, c)
+        for k in ("coord_scales", "pose_scales_tril", "shapeparam", "unnormalized_quat"):
+            if k in preds:
+                out[k] = preds[k]
+        meta = Metadata(N, rois.shape[0], categories=dict(cats))
+        return Batch(meta, out)
+
+    def evaluate(self, metric, samples, batchsize: int = 128):
+        """`samples`: iterable of dicts with "image", "roi" and the labels the metric reads (reference :210-222)."""
+        for chunk in utils.iter_batched(samples, batchsize):
+            images = [s["image"] for s in chunk]
+            keys = [k for k in chunk[0] if k != "image"]
+            targets = Batch(Metadata(0, len(chunk)), {k: torch.stack([torch.as_tensor(s[k]) for s in chunk]).to(self._device) for k in keys})
+            preds = self.predict_batch(images, targets["roi"])
+            metric.update(preds, targets)
+        return metric.compute()
+
+
+# ---------------------------------------------------------------------------------------------
+# metrics (reference :295-440)
+# ---------------------------------------------------------------------------------------------
+class _SimpleConcatenatingErrorMetric:
+    def __init__(self):
+        self.error: list[Tensor] = []
+
+    def update(self, preds: Batch, targets: Batch) -> None:
+        self.error.append(self.compute_on_batch(preds, targets))
+
+    def compute_on_batch(self, preds: Batch, targets: Batch) -> Tensor:
+        raise NotImplementedError()
+
+    def compute(self) -> Tensor:
+        return torch.cat(self.error)
+
+    def reset(self):
+        self.error = []
+
+
+class LabelExtractor(_SimpleConcatenatingErrorMetric):
+    def __init__(self, key):
+        super().__init__()
+        self._key = key
+
+    def compute_on_batch(self, preds, targets):
+        return targets[self._key]
+
+
+class PredExtractor(LabelExtractor):
+    def compute_on_batch(self, preds, targets):
+        return preds[self._key]
+
+
+class GeodesicError(_SimpleConcatenatingErrorMetric):
+    def compute_on_batch(self, preds, targets):
+        return torchquaternion.geodesicdistance(targets["pose"], preds["pose"])
+
+
+def _angle_errors(euler1, euler2):
+    v1 = np.stack([np.cos(euler1), np.sin(euler1)], axis=-1)
+    v2 = np.stack([np.cos(euler2), np.sin(euler2)], axis=-1)
+    return np.arccos(np.clip(np.sum(v1 * v2, axis=-1), -1.0, 1.0))
+
+
+def _quat_to_aflw3d_rotations(quats: Tensor):
+    return np.array([utils.inv_aflw_rotation_conversion(q) for q in utils.convert_to_rot(quats.detach().cpu().numpy())])
+
+
+def _aflw3d_euler_errors(quats1: Tensor, quats2: Tensor) -> Tensor:
+    return torch.from_numpy(_angle_errors(_quat_to_aflw3d_rotations(quats1), _quat_to_aflw3d_rotations(quats2))).to(quats1.device)
+
+
+class EulerAngleErrors(_SimpleConcatenatingErrorMetric):
+    """|pitch|, |yaw|, |roll| differences in the AFLW2000-3D convention, radians, [B,3]."""
+
+    def compute_on_batch(self, preds, targets):
+        return _aflw3d_euler_errors(preds["pose"], targets["pose"])
+
+
+class NormalizedXYSError(_SimpleConcatenatingErrorMetric):
+    def compute_on_batch(self, preds, targets):
+        x0, y0, x1, y1 = targets["roi"].unbind(-1)
+        return torch.abs(preds["coord"] - targets["coord"]) / (x1 - x0)[:, None]
+
+
+def _eval_keypoints(pred: Tensor, gt: Tensor, dims=3):
+    assert pred.shape == gt.shape and pred.shape[-1] == 3
+    pred, gt = pred.clone(), gt.clone()
+    pred[:, :, 2] -= torch.mean(pred[:, :, 2], dim=-1, keepdim=True)
+    gt[:, :, 2] -= torch.mean(gt[:, :, 2], dim=-1, keepdim=True)
+    dist = torch.mean(torch.norm(pred[:, :, :dims] - gt[:, :, :dims], dim=-1), dim=-1)
+    bbox = torch.sqrt((gt[:, :, 0].amax(1) - gt[:, :, 0].amin(1)) * (gt[:, :, 1].amax(1) - gt[:, :, 1].amin(1)))
+    return dist / bbox
+
+
+class UnweightedKptNME(_SimpleConcatenatingErrorMetric):
+    def __init__(self, dimensions=3):
+        super().__init__()
+        self.dims = dimensions
+
+    def compute_on_batch(self, preds, targets):
+        return _eval_keypoints(preds["pt3d_68"], targets["pt3d_68"], self.dims)
+
+
+class KptNmeResults(NamedTuple):
+    bin_30_nme: float
+    bin_60_nme: float
+    bin_90_nme: float
+    avg_nme: float
+
+
+class KptNME:
+    """Landmark NME binned by |yaw| of the label: 0-30, 30-60, 60-90 degrees (reference :407-440)."""
+
+    def __init__(self, dimensions=3):
+        self.dims, self.error, self.masks = dimensions, [], []
+
+    def update(self, preds, targets):
+        pyr = _quat_to_aflw3d_rotations(targets["pose"])
+        yaw = np.abs(pyr[:, 1]) * 180.0 / np.pi
+        self.masks.append(torch.from_numpy(np.stack([(a <= yaw) & (yaw < b) for a, b in ((0.0, 30.0), (30.0, 60.0), (60.0, 90.0))], -1)))
+        self.error.append(_eval_keypoints(preds["pt3d_68"], targets["pt3d_68"], self.dims).cpu())
+
+    def compute(self) -> KptNmeResults:
+        errors, masks = torch.cat(self.error), torch.cat(self.masks).unbind(-1)
+        bins = [torch.mean(errors[m]).item() for m in masks]
+        return KptNmeResults(*bins, float(np.average(bins)))
+
+
+def pose_error_table(euler_errors: Tensor, geodesic: Tensor) -> dict:
+    """The summary row scripts/evaluate_pose_network.py prints: MAE per angle and their mean in degrees (reference
+    scripts/evaluate_pose_network.py:205-291)."""
+    e = euler_errors.detach().cpu().numpy() * utils.rad2deg
+    mae = e.mean(0)
+    return {"pitch": float(mae[0]), "yaw": float(mae[1]), "roll": float(mae[2]), "mae": float(mae.mean()),
+            "geodesic": float(geodesic.detach().cpu().numpy().mean() * utils.rad2deg)}

@@ -140,3 +140,45 @@ def test_resnet18_module_surface():
     torch.testing.assert_close(feat, ref, rtol=1e-5, atol=1e-6)
     with __import__("pytest").raises(NotImplementedError):
         resnet18(use_blurpool=True)
+
+
+def test_eval_metrics_and_rotation_conventions():
+    """trackertraincode.utils / eval metrics against their definitions (reference utils.py:41-64, eval.py:337-440)."""
+    import numpy as np
+    import torch
+    from scipy.spatial.transform import Rotation
+
+    from trackertraincode import eval as E
+    from trackertraincode import utils
+
+    rng = np.random.default_rng(0)
+    pyr = rng.uniform(-1.2, 1.2, (32, 3))
+    rot = utils.aflw_rotation_conversion(pyr[:, 0], pyr[:, 1], pyr[:, 2])
+    back = np.array([utils.inv_aflw_rotation_conversion(r) for r in rot])
+    np.testing.assert_allclose(back, pyr, atol=1e-9)  # the two conversions invert each other
+    q = torch.from_numpy(rot.as_quat().astype(np.float32))
+    d = rng.uniform(-0.05, 0.05, (32, 3))
+    q2 = torch.from_numpy(utils.aflw_rotation_conversion(*(pyr + d).T).as_quat().astype(np.float32))
+    m = E.EulerAngleErrors()
+    m.update({"pose": q2}, {"pose": q})
+    np.testing.assert_allclose(m.compute().numpy(), np.abs(d), atol=2e-5)
+    geo = E.GeodesicError()
+    geo.update({"pose": q2}, {"pose": q})
+    ref = (Rotation.from_quat(q.numpy()).inv() * Rotation.from_quat(q2.numpy())).magnitude()
+    np.testing.assert_allclose(geo.compute().numpy(), ref, atol=2e-5)
+    tab = E.pose_error_table(m.compute(), geo.compute())
+    assert abs(tab["mae"] - np.abs(d).mean() * 180 / np.pi) < 1e-3
+    # landmark NME: a pure in-plane shift of every point by 1 % of the box size
+    gt = torch.from_numpy(rng.uniform(0, 100, (4, 68, 3)).astype(np.float32))
+    size = torch.sqrt((gt[:, :, 0].amax(1) - gt[:, :, 0].amin(1)) * (gt[:, :, 1].amax(1) - gt[:, :, 1].amin(1)))
+    pred = gt.clone()
+    pred[:, :, 0] += 0.01 * size[:, None]
+    nme = E.UnweightedKptNME()
+    nme.update({"pt3d_68": pred}, {"pt3d_68": gt})
+    np.testing.assert_allclose(nme.compute().numpy(), 0.01, rtol=1e-4)
+    k = E.KptNME()
+    yaw = np.array([10.0, 40.0, 70.0, 20.0]) * np.pi / 180
+    qq = torch.from_numpy(utils.aflw_rotation_conversion(np.zeros(4), yaw, np.zeros(4)).as_quat().astype(np.float32))
+    k.update({"pt3d_68": pred}, {"pt3d_68": gt, "pose": qq})
+    res = k.compute()
+    assert abs(res.bin_30_nme - 0.01) < 1e-5 and abs(res.bin_60_nme - 0.01) < 1e-5 and abs(res.avg_nme - 0.01) < 1e-5
