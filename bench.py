@@ -75,12 +75,12 @@ class KernelTimer:
             else:
                 by = 4 * (2 * M * co + M * ci + ci * co)
                 if ci >= 128 and co >= 128 and ci * co >= 128 * 256 and (ci % 256 == 0 or co % 256 == 0):
-                    return ("pw_split_wgrad_k<128, 256>" if ci % 256 == 0 else "pw_split_wgrad_k<256, 128>"), fl, by
+                    return ("pw_split_wgrad_k<128, 256, false>" if ci % 256 == 0 else "pw_split_wgrad_k<256, 128, false>"), fl, by
                 return "pw_wgrad_k", fl, by
             if K >= 128 and N % 256 == 0:
-                return f"pw_split_k<128, 256, {mode}>", fl, by
+                return f"pw_split_k<128, 256, {mode}, {mode}, false>", fl, by  # <BM, BN, A-operand form, epilogue form, gather>
             if K >= 256 and N == 128:
-                return f"pw_split_k<256, 128, {mode}>", fl, by
+                return f"pw_split_k<256, 128, {mode}, {mode}, false>", fl, by
             return (f"pw_gemm_k<{min(N, 128)}, 2, 2, {mode}>" if N >= 64 else f"pw_gemm_k<32, 4, 1, {mode}>"), fl, by
         if name == "ttk_dwconv3x3_fwd":
             B, H, W, C, s_ = ints[-5:]
