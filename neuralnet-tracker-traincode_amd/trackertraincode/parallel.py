@@ -21,9 +21,12 @@ import torch.distributed as dist
 
 
 class GradAllReduce:
-    def __init__(self, process_group=None, bucket_bytes: int = 4 << 20):
+    def __init__(self, process_group=None, bucket_bytes: int = 4 << 20, always_reduce: bool = False):
+        """`always_reduce`: issue the collectives even in a world of one (they are identities) - used to exercise the
+        stream / event / bucket logic on a single GPU."""
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._always = always_reduce
         self.bucket_bytes = bucket_bytes
         self._pending: list[tuple[torch.Tensor, list[torch.Tensor], object]] = []
         self._queue: list[torch.Tensor] = []
@@ -34,7 +37,7 @@ class GradAllReduce:
     # The parameter is kept because autograd may CLONE the returned gradient into param.grad (it does
     # when somebody else - like this object - still references the tensor): finish() writes to param.grad.
     def on_ready(self, pairs):
-        if self.world == 1:
+        if self.world == 1 and not self._always:
             return
         for p, g in pairs:
             if g is None:
@@ -64,7 +67,7 @@ class GradAllReduce:
     def finish(self, extra_params: Iterable[torch.nn.Parameter] = ()):
         """Reduce whatever is still queued (plus the .grad of `extra_params`, e.g. the head parameters),
         wait for all buckets and write the averaged values into the parameters' gradients."""
-        if self.world == 1:
+        if self.world == 1 and not self._always:
             return
         seen = {id(p) for _, grads, _ in self._pending for p, _ in grads} | {id(p) for p, _ in self._queue}
         self.on_ready([(p, p.grad) for p in extra_params if p.grad is not None and id(p) not in seen])
