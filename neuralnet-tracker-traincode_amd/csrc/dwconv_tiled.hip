@@ -197,8 +197,14 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_tiled_k(const float* __restrict
   const int tid = threadIdx.x, q = tid & (kSlabQuads - 1), slot = tid >> 3;
   const int slab = blockIdx.x % nslabs, c0 = slab * kSlab + 4 * q;
   const int Wp = Wo + 2;
-  SlabWeights wr;
-  wr.load(w, c0);
+  // the filter taps of this thread's channel quad live in LDS (wt[tap][32 channels], after the reduction scratch):
+  // 36 fewer VGPRs, which pays for handling two pixels per iteration below
+  float* wt = lds + stage_floats + 4 * 9 * kSlab;
+  if (slot == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+      st4(wt + t * kSlab + 4 * q, make_float4(w[(size_t)(c0 + 0) * 9 + t], w[(size_t)(c0 + 1) * 9 + t], w[(size_t)(c0 + 2) * 9 + t], w[(size_t)(c0 + 3) * 9 + t]));
+  }
   const BnApply4 bnp = BnApply4::load(bn_prev, C, c0);
   const BnGrad4 bg = BnGrad4::load(bn_dw, C, c0);
   D4 s1{0.0, 0.0, 0.0, 0.0}, s2{0.0, 0.0, 0.0, 0.0};
@@ -227,35 +233,51 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_tiled_k(const float* __restrict
     }
     __syncthreads();
     const int npix = (r1 - r0) * W;
-    for (int p = slot; p < npix; p += kPixSlots) {
-      const int hi = r0 + p / W, wi = p % W;
-      const size_t off_in = (((size_t)n * H + hi) * W + wi) * C + c0;
-      const float4 yp = ld4(yprev + off_in);
-      float4 a;
-      if (a_in) a = ld4(a_in + off_in);
-      else a = skip_prev ? bnp.act(yp, ld4(skip_prev + off_in)) : bnp.act(yp);
-      float4 G = f4(0.f);
+    // two pixels per thread and iteration: their (up to six) global loads are issued back to back before either
+    // pixel's LDS taps are read
+    for (int p = slot; p < npix; p += 2 * kPixSlots) {
+      const int pb = p + kPixSlots;
+      const bool hasb = pb < npix;
+      const int hiA = r0 + p / W, wiA = p % W;
+      const int hiB = hasb ? r0 + pb / W : hiA, wiB = hasb ? pb % W : wiA;
+      const size_t offA = (((size_t)n * H + hiA) * W + wiA) * C + c0;
+      const size_t offB = (((size_t)n * H + hiB) * W + wiB) * C + c0;
+      const float4 ypA = ld4(yprev + offA), ypB = ld4(yprev + offB);
+      float4 rawA = f4(0.f), rawB = f4(0.f), sgA = f4(0.f), sgB = f4(0.f);
+      if (a_in) { rawA = ld4(a_in + offA); rawB = ld4(a_in + offB); }
+      else if (skip_prev) { rawA = ld4(skip_prev + offA); rawB = ld4(skip_prev + offB); }
+      if (skip_grad) { sgA = ld4(skip_grad + offA); sgB = ld4(skip_grad + offB); }
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int th = hi + 1 - kh;
-        if (th < 0 || (S == 2 && (th & 1))) continue;
-        const int ho = th / S;
-        if (ho > Ho - 1) continue;
+      for (int half = 0; half < 2; ++half) {
+        if (half == 1 && !hasb) break;
+        const int hi = half ? hiB : hiA, wi = half ? wiB : wiA;
+        const float4 yp = half ? ypB : ypA, raw = half ? rawB : rawA, sg = half ? sgB : sgA;
+        float4 a;
+        if (a_in) a = raw;
+        else a = skip_prev ? bnp.act(yp, raw) : bnp.act(yp);
+        float4 G = f4(0.f);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int tw = wi + 1 - kw;  // -1 .. W
-          if (S == 2 && (tw & 1)) continue;
-          const int wo = (S == 1) ? tw : (tw >> 1);  // -1 or Wo hit the zero padding columns (S=1); always inside for S=2
-          const float4 dy = ld4(lds + ((size_t)(ho - ho_lo) * Wp + wo + 1) * kSlab + 4 * q);
-          G = fma4(dy, wr.tap(kh * 3 + kw), G);
-          wacc[kh * 3 + kw] = fma4(dy, a, wacc[kh * 3 + kw]);
+        for (int kh = 0; kh < 3; ++kh) {
+          const int th = hi + 1 - kh;
+          if (th < 0 || (S == 2 && (th & 1))) continue;
+          const int ho = th / S;
+          if (ho > Ho - 1) continue;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int tw = wi + 1 - kw;  // -1 .. W
+            if (S == 2 && (tw & 1)) continue;
+            const int wo = (S == 1) ? tw : (tw >> 1);  // -1 or Wo hit the zero padding columns (S=1); always inside for S=2
+            const float4 dy = ld4(lds + ((size_t)(ho - ho_lo) * Wp + wo + 1) * kSlab + 4 * q);
+            G = fma4(dy, ld4(wt + (kh * 3 + kw) * kSlab + 4 * q), G);
+            wacc[kh * 3 + kw] = fma4(dy, a, wacc[kh * 3 + kw]);
+          }
         }
+        if (skip_grad) G = add4(G, sg);
+        const float4 gp = mask4(G, a);
+        st4(g_prev + (half ? offB : offA), gp);
+        s1.add(gp);
+        s2.addmul(gp, sub4(yp, bnp.mean));
       }
-      if (skip_grad) G = add4(G, ld4(skip_grad + off_in));
-      const float4 gp = mask4(G, a);
-      st4(g_prev + off_in, gp);
-      s1.add(gp);
-      s2.addmul(gp, sub4(yp, bnp.mean));
     }
   }
   float* red = lds + stage_floats;
@@ -327,7 +349,7 @@ int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* bn
   const DwTiling t = dw_tiling(B, H, W, C, stride, true);
   const int stage_rows = (stride == 1) ? t.R + 2 : t.R / 2 + 2;
   const size_t stage = (size_t)stage_rows * (Wo + 2) * kSlab;
-  const size_t sm = (stage + 4 * 9 * kSlab) * sizeof(float);
+  const size_t sm = (stage + 4 * 9 * kSlab + 9 * kSlab) * sizeof(float);  // stage + reduction scratch + filter taps
   hipStream_t st = (hipStream_t)stream;
   if (dw && !dw_accumulate) hipLaunchKernelGGL(zero_fill_k, dim3((9 * C + 255) / 256), dim3(256), 0, st, dw, (int64_t)9 * C);
   if (stride == 1)
