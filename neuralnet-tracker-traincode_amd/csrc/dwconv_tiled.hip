@@ -146,18 +146,37 @@ __global__ void __launch_bounds__(kBlock) dw_fwd_tiled_k(const float* __restrict
     const int i0 = o0 * S - 1;                     // first staged input row (may be -1)
     const int nrows = (o1 - 1 - o0) * S + 3;
     __syncthreads();  // previous tile's readers are done
-    // ---- stage: a_in rows i0 .. i0+nrows-1, columns -1 .. W (zero outside the image)
-    for (int e = tid; e < nrows * Wp * kSlabQuads; e += kBlock) {
-      const int qq = e & (kSlabQuads - 1), px = e >> 3;
-      const int col = px % Wp - 1, row = i0 + px / Wp;
-      float4 a = f4(0.f);
-      if (row >= 0 && row < H && col >= 0 && col < W) {
-        const size_t off = (((size_t)n * H + row) * W + col) * C + slab * kSlab + 4 * qq;
-        const float4 yv = ld4(yprev + off);  // qq == q for every e (kBlock is a multiple of 8): bn is this thread's quad
-        a = skip_prev ? bn.act(yv, ld4(skip_prev + off)) : bn.act(yv);
-        if (S == 1 && a_out && row >= o0 && row < o1) st4(a_out + off, a);  // each input pixel belongs to one band
+    // ---- stage: a_in rows i0 .. i0+nrows-1, columns -1 .. W (zero outside the image).  Two elements per thread and
+    // iteration so that their loads are in flight together (the staging phase is where this kernel touches HBM).
+    const int nstage = nrows * Wp * kSlabQuads;
+    for (int e = tid; e < nstage; e += 2 * kBlock) {
+      float4 yv[2], sk[2];
+      size_t off[2];
+      bool in[2];
+      int pxs[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ee = e + u * kBlock;
+        const int px = ee >> 3;
+        const int col = px % Wp - 1, row = i0 + px / Wp;
+        pxs[u] = px;
+        in[u] = ee < nstage && row >= 0 && row < H && col >= 0 && col < W;
+        off[u] = in[u] ? (((size_t)n * H + row) * W + col) * C + slab * kSlab + 4 * q : 0;  // qq == q: kBlock is a multiple of 8
+        yv[u] = in[u] ? ld4(yprev + off[u]) : f4(0.f);
+        sk[u] = (in[u] && skip_prev) ? ld4(skip_prev + off[u]) : f4(0.f);
       }
-      st4(lds + (size_t)px * kSlab + 4 * qq, a);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ee = e + u * kBlock;
+        if (ee >= nstage) break;
+        float4 a = f4(0.f);
+        if (in[u]) {
+          a = skip_prev ? bn.act(yv[u], sk[u]) : bn.act(yv[u]);
+          const int row = i0 + pxs[u] / Wp;
+          if (S == 1 && a_out && row >= o0 && row < o1) st4(a_out + off[u], a);  // each input pixel belongs to one band
+        }
+        st4(lds + (size_t)pxs[u] * kSlab + 4 * q, a);
+      }
     }
     __syncthreads();
     // ---- stencil
@@ -220,16 +239,28 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_tiled_k(const float* __restrict
     const int ho_hi = min(Ho - 1, r1 / S);
     const int nrows = ho_hi - ho_lo + 1;
     __syncthreads();
-    // ---- stage dy rows ho_lo..ho_hi, columns -1..Wo (zeros outside)
-    for (int e = tid; e < nrows * Wp * kSlabQuads; e += kBlock) {
-      const int qq = e & (kSlabQuads - 1), px = e >> 3;
-      const int col = px % Wp - 1, row = ho_lo + px / Wp;
-      float4 dy = f4(0.f);
-      if (col >= 0 && col < Wo) {
-        const size_t off = (((size_t)n * Ho + row) * Wo + col) * C + slab * kSlab + 4 * qq;
-        dy = bg.dy(ld4(g_dw + off), ld4(y_dw + off));  // qq == q (see forward)
+    // ---- stage dy rows ho_lo..ho_hi, columns -1..Wo (zeros outside); two elements per thread and iteration (four
+    // loads in flight)
+    const int nstage = nrows * Wp * kSlabQuads;
+    for (int e = tid; e < nstage; e += 2 * kBlock) {
+      float4 gv[2], yv[2];
+      bool in[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ee = e + u * kBlock;
+        const int px = ee >> 3;
+        const int col = px % Wp - 1, row = ho_lo + px / Wp;
+        in[u] = ee < nstage && col >= 0 && col < Wo;
+        const size_t off = in[u] ? (((size_t)n * Ho + row) * Wo + col) * C + slab * kSlab + 4 * q : 0;  // qq == q (see forward)
+        gv[u] = in[u] ? ld4(g_dw + off) : f4(0.f);
+        yv[u] = in[u] ? ld4(y_dw + off) : f4(0.f);
       }
-      st4(lds + (size_t)px * kSlab + 4 * qq, dy);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ee = e + u * kBlock;
+        if (ee >= nstage) break;
+        st4(lds + (size_t)(ee >> 3) * kSlab + 4 * q, in[u] ? bg.dy(gv[u], yv[u]) : f4(0.f));
+      }
     }
     __syncthreads();
     const int npix = (r1 - r0) * W;
