@@ -21,6 +21,7 @@ constexpr int kSlabQuads = kSlab / 4;
 constexpr int kPixSlots = kBlock / kSlabQuads;  // 32 pixels in flight per pass
 constexpr int kLdsPixBudget = 368;   // (rows) x (W+2) pixels of 128 B each: <= 47 KB -> 3 workgroups per CU
 constexpr int kMaxDwBlocks = 2048;
+constexpr int kFwdU = 4;             // staging elements per thread and iteration (forward)
 
 struct DwTiling {
   int R, nbands, nslabs, grid, rows;  // rows = partial rows = grid / nslabs
@@ -149,13 +150,13 @@ __global__ void __launch_bounds__(kBlock) dw_fwd_tiled_k(const float* __restrict
     // ---- stage: a_in rows i0 .. i0+nrows-1, columns -1 .. W (zero outside the image).  Two elements per thread and
     // iteration so that their loads are in flight together (the staging phase is where this kernel touches HBM).
     const int nstage = nrows * Wp * kSlabQuads;
-    for (int e = tid; e < nstage; e += 2 * kBlock) {
-      float4 yv[2], sk[2];
-      size_t off[2];
-      bool in[2];
-      int pxs[2];
+    for (int e = tid; e < nstage; e += kFwdU * kBlock) {
+      float4 yv[kFwdU], sk[kFwdU];
+      size_t off[kFwdU];
+      bool in[kFwdU];
+      int pxs[kFwdU];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < kFwdU; ++u) {
         const int ee = e + u * kBlock;
         const int px = ee >> 3;
         const int col = px % Wp - 1, row = i0 + px / Wp;
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(kBlock) dw_fwd_tiled_k(const float* __restrict
         sk[u] = (in[u] && skip_prev) ? ld4(skip_prev + off[u]) : f4(0.f);
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < kFwdU; ++u) {
         const int ee = e + u * kBlock;
         if (ee >= nstage) break;
         float4 a = f4(0.f);
