@@ -79,7 +79,7 @@ class KernelTimer:
                 return "pw_wgrad_k", fl, by
             if K >= 128 and N % 256 == 0:
                 return f"pw_split_k<128, 256, {mode}, {mode}, false>", fl, by  # <BM, BN, A-operand form, epilogue form, gather>
-            if K >= 256 and N == 128:
+            if K >= 128 and N == 128:
                 return f"pw_split_k<256, 128, {mode}, {mode}, false>", fl, by
             return (f"pw_gemm_k<{min(N, 128)}, 2, 2, {mode}>" if N >= 64 else f"pw_gemm_k<32, 4, 1, {mode}>"), fl, by
         if name == "ttk_dwconv3x3_fwd":

@@ -42,7 +42,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 5
+#define TTK_ABI_VERSION 6
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -126,17 +126,19 @@ int ttk_dwconv3x3_bwd_weight(const float* g_dw, const float* y_dw, const float* 
                              int stride, ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Pointwise 1x1 conv = GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) -
- * DepthWiseBlock.conv_sep, mobilenet_v1.py:67,82.
+ * Pointwise 1x1 conv = GEMM on the matrix cores - DepthWiseBlock.conv_sep, mobilenet_v1.py:67,82.
  *   y[M][Cout] = a_dw[M][Cin] . w[Cout][Cin]^T,   a_dw = max(bn_dw(ydw), 0) on load,  M = B*Ho*Wo
+ * Compute-bound shapes run as exact-split bf16 MFMA products (fp32-chain accuracy, csrc/pwconv_split.hip), the
+ * HBM-bound early layers on v_mfma_f32_32x32x2_f32.  wsplit (forward and data gradient): scratch of
+ * 3 * 2 * Cin * Cout bytes for the pre-split weight operand; NULL selects the fp32 MFMA kernels for every shape.
  * ------------------------------------------------------------------------------------------- */
 int ttk_pwconv1x1_fwd(const float* ydw, const float* bn_dw, const float* w, float* y, float* part,
-                      int64_t M, int Cin, int Cout, ttk_stream_t stream);
+                      int64_t M, int Cin, int Cout, void* wsplit, ttk_stream_t stream);
 /* g_dw[M][Cin] = (dy[M][Cout] . w[Cout][Cin]) * [bn_dw(ydw) > 0],  dy formed on load from (g, y, bn_pw);
  * wt = w transposed ([Cin][Cout], ttk_transpose).  partials: sum(g_dw), sum(g_dw*(ydw-mean)). */
 int ttk_pwconv1x1_bwd_data(const float* g, const float* y, const float* bn_pw, const float* wt,
                            const float* ydw, const float* bn_dw, float* g_dw, float* part, int64_t M,
-                           int Cin, int Cout, ttk_stream_t stream);
+                           int Cin, int Cout, void* wsplit, ttk_stream_t stream);
 /* dw[Cout][Cin] += dy^T . a_dw.  dw must be zeroed (or hold the running gradient) before the call:
  * the M dimension is split over workgroups that add atomically. */
 int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* bn_pw, const float* ydw,
@@ -163,7 +165,9 @@ int ttk_bn_act(const float* y, const float* bn, const float* skip, float* a, int
  * torchvision.models.resnet.BasicBlock/conv3x3/conv1x1, an un-vendored dependency of the reference) as implicit
  * GEMMs on the matrix cores.  Channels-last activations a[B][H][W][C] that are already post-BatchNorm/ReLU
  * ("materialised"); k in {1,3}, stride in {1,2}, pad = k/2; Cin % 32 == 0, Cout % 64 == 0.
- *   ttk_conv_weight_repack  w[Cout][Cin][KH][KW] -> w_fwd[KH*KW][Cout][Cin], w_bwd[KH*KW][Cin][Cout] (either may be NULL)
+ *   ttk_conv_weight_repack  w[Cout][Cin][KH][KW] -> w_fwd[3][KH*KW][Cout][Cin], w_bwd[3][KH*KW][Cin][Cout] (either may be
+ *                           NULL): 16-bit piece planes (h, m, l) of the exact 3-way bf16 split of every weight, i.e.
+ *                           3 * 2 bytes per element - the form the GEMM producers move without arithmetic
  *   ttk_conv_fwd            y[B][Ho][Wo][Cout] raw conv output + part[ttk_partial_rows_gemm(B*Ho*Wo)][2][Cout]
  *   ttk_conv_bwd_data       g_in[B][H][W][Cin] = conv^T(dy), dy = ga*(g-gmean)+gb*(y-mean) formed on load from the conv
  *                           output's gradient g, raw output y and BatchNorm block bn.  With mask_y/mask_bn (the conv
@@ -171,11 +175,11 @@ int ttk_bn_act(const float* y, const float* bn, const float* skip, float* a, int
  *                           receives (sum g_in, sum g_in*(mask_y-mean)); without: raw gradient, part untouched.
  *   ttk_conv_bwd_weight     dw[Cout][Cin][KH][KW] += sum_pixels dy (x) a_in (fp32 atomics; zero dw first)
  * ------------------------------------------------------------------------------------------- */
-int ttk_conv_weight_repack(const float* w, float* w_fwd, float* w_bwd, int Cout, int Cin, int KH, int KW,
+int ttk_conv_weight_repack(const float* w, void* w_fwd, void* w_bwd, int Cout, int Cin, int KH, int KW,
                            ttk_stream_t stream);
-int ttk_conv_fwd(const float* a_in, const float* w_fwd, float* y, float* part, int B, int H, int W, int Cin,
+int ttk_conv_fwd(const float* a_in, const void* w_fwd, float* y, float* part, int B, int H, int W, int Cin,
                  int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream);
-int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const float* w_bwd, const float* mask_y,
+int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const void* w_bwd, const float* mask_y,
                       const float* mask_bn, float* g_in, float* part, int B, int H, int W, int Cin, int Cout,
                       int KH, int KW, int stride, int pad, ttk_stream_t stream);
 int ttk_conv_bwd_weight(const float* g, const float* y, const float* bn, const float* a_in, float* dw, int B, int H,

@@ -8,15 +8,27 @@
 
 namespace ttk {
 
-// w[Cout][Cin][T] (torch layout, T = KH*KW) -> wf[T][Cout][Cin] (forward B operand) and wb[T][Cin][Cout] (data gradient)
-__global__ void conv_weight_repack_k(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wb, int Cout,
+// w[Cout][Cin][T] (torch layout, T = KH*KW) -> wf[3][T][Cout][Cin] (forward B operand) and wb[3][T][Cin][Cout] (data
+// gradient): bf16 piece planes h, m, l of the exact 3-way split (pwconv_split.hip), so that the GEMM producers move the
+// weight operand without arithmetic.
+__global__ void conv_weight_repack_k(const float* __restrict__ w, uint16_t* __restrict__ wf, uint16_t* __restrict__ wb, int Cout,
                                      int Cin, int T) {
+  const int64_t n = (int64_t)Cout * Cin * T;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)Cout * Cin * T) return;
+  if (i >= n) return;
   const int t = (int)(i % T), ci = (int)((i / T) % Cin), co = (int)(i / ((int64_t)T * Cin));
-  const float v = w[i];
-  if (wf) wf[((size_t)t * Cout + co) * Cin + ci] = v;
-  if (wb) wb[((size_t)t * Cin + ci) * Cout + co] = v;
+  const float x = w[i];
+  const float r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+  const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+  const uint16_t h = (uint16_t)(__float_as_uint(x) >> 16), m = (uint16_t)(__float_as_uint(r1) >> 16), l = (uint16_t)(__float_as_uint(r2) >> 16);
+  if (wf) {
+    const size_t o = ((size_t)t * Cout + co) * Cin + ci;
+    wf[o] = h; wf[n + o] = m; wf[2 * n + o] = l;
+  }
+  if (wb) {
+    const size_t o = ((size_t)t * Cin + ci) * Cout + co;
+    wb[o] = h; wb[n + o] = m; wb[2 * n + o] = l;
+  }
 }
 
 static bool conv_shape_ok(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
@@ -30,21 +42,21 @@ using namespace ttk;
 
 extern "C" {
 
-int ttk_conv_weight_repack(const float* w, float* w_fwd, float* w_bwd, int Cout, int Cin, int KH, int KW, ttk_stream_t stream) {
+int ttk_conv_weight_repack(const float* w, void* w_fwd, void* w_bwd, int Cout, int Cin, int KH, int KW, ttk_stream_t stream) {
   TTK_REQUIRE(w && (w_fwd || w_bwd) && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "conv_weight_repack: bad arguments");
   const int64_t n = (int64_t)Cout * Cin * KH * KW;
-  hipLaunchKernelGGL(conv_weight_repack_k, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, w, w_fwd, w_bwd,
+  hipLaunchKernelGGL(conv_weight_repack_k, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_fwd, (uint16_t*)w_bwd,
                      Cout, Cin, KH * KW);
   TTK_LAUNCH_CHECK("conv_weight_repack");
 }
 
-int ttk_conv_fwd(const float* a_in, const float* w_fwd, float* y, float* part, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+int ttk_conv_fwd(const float* a_in, const void* w_fwd, float* y, float* part, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                  int stride, int pad, ttk_stream_t stream) {
   TTK_REQUIRE(a_in && w_fwd && y, "conv_fwd: null pointer");
   TTK_REQUIRE(conv_shape_ok(B, H, W, Cin, Cout, KH, KW, stride, pad), "conv_fwd: unsupported shape B=%d H=%d W=%d Cin=%d Cout=%d k=%d s=%d p=%d", B, H, W, Cin, Cout, KH, stride, pad);
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   const ConvGeom geo{H, W, Ho, Wo, stride, pad, KW, Cin, 0};
-  const bool ok = launch_conv_gemm(AMODE_PLAIN, EMODE_STATS, a_in, nullptr, nullptr, w_fwd, y, nullptr, nullptr, part,
+  const bool ok = launch_conv_gemm(AMODE_PLAIN, EMODE_STATS, a_in, nullptr, nullptr, (const uint16_t*)w_fwd, y, nullptr, nullptr, part,
                                    (int64_t)B * Ho * Wo, KH * KW * Cin, Cout, geo, (hipStream_t)stream);
   TTK_REQUIRE(ok, "conv_fwd: no kernel for this shape");
   TTK_LAUNCH_CHECK("conv_fwd");
@@ -54,7 +66,7 @@ int ttk_conv_fwd(const float* a_in, const float* w_fwd, float* y, float* part, i
 // output's BatchNorm block).  mask_y/mask_bn (nullable together): the input activation was relu(bn_in(mask_y)) - the
 // result is masked with it and part gets the BatchNorm-backward sums (sum g, sum g*(mask_y-mean)) of bn_in; without
 // them the raw gradient is written and part is not touched.
-int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const float* w_bwd, const float* mask_y,
+int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const void* w_bwd, const float* mask_y,
                       const float* mask_bn, float* g_in, float* part, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                       int stride, int pad, ttk_stream_t stream) {
   TTK_REQUIRE(g && y && bn && w_bwd && g_in, "conv_bwd_data: null pointer");
@@ -62,7 +74,7 @@ int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const flo
   TTK_REQUIRE(conv_shape_ok(B, H, W, Cin, Cout, KH, KW, stride, pad) && Cin % 64 == 0, "conv_bwd_data: unsupported shape");
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   const ConvGeom geo{Ho, Wo, H, W, stride, pad, KW, Cout, 1};
-  const bool ok = launch_conv_gemm(AMODE_BNGRAD, mask_y ? EMODE_MASK : EMODE_PLAIN, g, y, bn, w_bwd, g_in, mask_y, mask_bn,
+  const bool ok = launch_conv_gemm(AMODE_BNGRAD, mask_y ? EMODE_MASK : EMODE_PLAIN, g, y, bn, (const uint16_t*)w_bwd, g_in, mask_y, mask_bn,
                                    mask_y ? part : nullptr, (int64_t)B * H * W, KH * KW * Cout, Cin, geo, (hipStream_t)stream);
   TTK_REQUIRE(ok, "conv_bwd_data: no kernel for this shape");
   TTK_LAUNCH_CHECK("conv_bwd_data");

@@ -18,7 +18,7 @@ struct ConvGeom {
   int Hs, Ws, Hg, Wg, stride, pad, KW, Kc, transposed;
 };
 
-bool launch_conv_gemm(int amode, int emode, const float* A0, const float* A1, const float* bnA, const float* Bm, float* out,
+bool launch_conv_gemm(int amode, int emode, const float* A0, const float* A1, const float* bnA, const uint16_t* Bm, float* out,
                       const float* E0, const float* bnE, float* part, int64_t M, int K, int Nout, const ConvGeom& geo,
                       hipStream_t st);
 

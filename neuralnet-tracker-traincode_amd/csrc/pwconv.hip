@@ -357,7 +357,7 @@ static bool pw_shape_ok(int64_t M, int Cin, int Cout) {
 // pwconv_split.hip: the compute-bound shapes on the bf16 pipe with exact 3-way operand splits
 template <int MODE>
 bool launch_split_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
-                       const float* bnE, float* part, int64_t M, int K, int Nout, hipStream_t st);
+                       const float* bnE, float* part, int64_t M, int K, int Nout, void* wsplit, hipStream_t st);
 
 bool launch_split_wgrad(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
                         int64_t M, int Cin, int Cout, hipStream_t st);
@@ -370,8 +370,8 @@ static bool use_split_gemm() {
 
 template <int MODE>
 static void launch_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
-                        const float* bnE, float* part, int64_t M, int K, int Nout, hipStream_t st) {
-  if (use_split_gemm() && launch_split_gemm<MODE>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, st)) return;
+                        const float* bnE, float* part, int64_t M, int K, int Nout, void* wsplit, hipStream_t st) {
+  if (use_split_gemm() && launch_split_gemm<MODE>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, wsplit, st)) return;
   const dim3 blk(kBlock);
   const unsigned gm = (unsigned)ceil_div(M, BM);
   if (Nout >= 128)
@@ -390,21 +390,22 @@ using namespace ttk;
 extern "C" {
 
 int ttk_pwconv1x1_fwd(const float* ydw, const float* bn_dw, const float* w, float* y, float* part, int64_t M, int Cin, int Cout,
-                      ttk_stream_t stream) {
+                      void* wsplit, ttk_stream_t stream) {
   TTK_REQUIRE(ydw && bn_dw && w && y, "pwconv1x1_fwd: null pointer");
   TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_fwd: unsupported shape M=%lld Cin=%d Cout=%d (channels: powers of two in 32..1024)", (long long)M, Cin, Cout);
   TTK_REQUIRE(ceil_div(M, BM) <= 65535, "pwconv1x1_fwd: M=%lld too large for one launch", (long long)M);
-  launch_gemm<MODE_FWD>(ydw, nullptr, bn_dw, w, y, nullptr, nullptr, part, M, Cin, Cout, (hipStream_t)stream);
+  launch_gemm<MODE_FWD>(ydw, nullptr, bn_dw, w, y, nullptr, nullptr, part, M, Cin, Cout, wsplit, (hipStream_t)stream);
   TTK_LAUNCH_CHECK("pwconv1x1_fwd");
 }
 
 int ttk_pwconv1x1_bwd_data(const float* g, const float* y, const float* bn_pw, const float* wt, const float* ydw,
-                           const float* bn_dw, float* g_dw, float* part, int64_t M, int Cin, int Cout, ttk_stream_t stream) {
+                           const float* bn_dw, float* g_dw, float* part, int64_t M, int Cin, int Cout, void* wsplit,
+                           ttk_stream_t stream) {
   TTK_REQUIRE(g && y && bn_pw && wt && ydw && bn_dw && g_dw, "pwconv1x1_bwd_data: null pointer");
   TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_bwd_data: unsupported shape");
   TTK_REQUIRE(ceil_div(M, BM) <= 65535, "pwconv1x1_bwd_data: M too large for one launch");
   // contraction over Cout, output columns = Cin, B operand = wt[Cin][Cout]
-  launch_gemm<MODE_DGRAD>(g, y, bn_pw, wt, g_dw, ydw, bn_dw, part, M, Cout, Cin, (hipStream_t)stream);
+  launch_gemm<MODE_DGRAD>(g, y, bn_pw, wt, g_dw, ydw, bn_dw, part, M, Cout, Cin, wsplit, (hipStream_t)stream);
   TTK_LAUNCH_CHECK("pwconv1x1_bwd_data");
 }
 

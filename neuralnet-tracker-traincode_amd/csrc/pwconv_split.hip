@@ -32,6 +32,7 @@ namespace ttk {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 enum { SMODE_FWD = 0, SMODE_DGRAD = 1 };
 
@@ -130,7 +131,7 @@ __device__ __forceinline__ void consume_tile(const unsigned char* lds, int nks, 
 template <int BM, int BN, int AMODE, int EMODE, bool GATHER>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* __restrict__ bnA,
-           const float* __restrict__ Bm, float* __restrict__ out, const float* __restrict__ E0,
+           const uint16_t* __restrict__ Bq, float* __restrict__ out, const float* __restrict__ E0,
            const float* __restrict__ bnE, float* __restrict__ part, int64_t M, int K, int Nout, ConvGeom geo) {
   static_assert((BM == 128 && BN == 256) || (BM == 256 && BN == 128) || (BM == 256 && BN == 64), "tile shapes");
   constexpr int APL = BM * 32, BPL = BN * 32;  // bytes of one piece plane
@@ -158,7 +159,9 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
     const int row0 = pt >> 3, kq8 = pt & 7;  // 32 rows per pass; 8 lanes x 16 B = one 128-byte row segment
     const int sub = kq8 >> 2, chunk = (kq8 >> 1) & 1, o8 = (kq8 & 1) * 8;
     constexpr int AP = BM / 32, BP = BN / 32;
-    f32x4 ra0[AP], ra1[AMODE == AMODE_BNGRAD ? AP : 1], rb[2][BP], q0, q1, q2, q3;  // B: two register sets (see the loop)
+    f32x4 ra0[AP], ra1[AMODE == AMODE_BNGRAD ? AP : 1], q0, q1, q2, q3;
+    constexpr int BI = BN / 64;  // B rows per thread and piece plane: 64 rows x 4 chunks of 16 B (8 k) per pass
+    u32x4 rb[1][3][BI];
     const int Kc = GATHER ? geo.Kc : K;   // channels per tap (= K without taps)
     const int kpt = Kc / 32;              // k32 steps per tap
     int64_t arow[GATHER ? 1 : AP];        // plain GEMM: element offset of each of this thread's rows
@@ -182,7 +185,11 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
         gbase[i] = row < M ? n * geo.Hs * geo.Ws : -1;
       }
     }
-    const float* bp = Bm + (int64_t)(n0 + row0) * Kc + kq8 * 4;
+    // B arrives already split (launch_*: split_weights_k / conv_weight_repack_k): three bf16 planes [tap][Nout][Kc]
+    const int brow = pt >> 2, bc4 = pt & 3;
+    const uint16_t* bp = Bq + (int64_t)(n0 + brow) * Kc + bc4 * 8;
+    const int64_t bplane = (int64_t)(K / Kc) * Nout * Kc;
+    unsigned char* wbase_b = lds + (bc4 >> 1) * kStageStride + 3 * APL;
     const float* cp = bnA ? bnA + kq8 * 4 : nullptr;
     unsigned char* wbase = lds + sub * kStageStride + o8;
 
@@ -230,9 +237,11 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
     };
     auto load_b = [&](int ks, int set) {
       const int tap = ks / kpt, kc0 = (ks - tap * kpt) * 32;
-      const float* b = bp + (int64_t)tap * Nout * Kc + kc0;
+      const uint16_t* b = bp + (int64_t)tap * Nout * Kc + kc0;
 #pragma unroll
-      for (int i = 0; i < BP; ++i) rb[set][i] = *reinterpret_cast<const f32x4*>(b + (int64_t)(32 * i) * Kc);
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < BI; ++i) rb[set][p][i] = *reinterpret_cast<const u32x4*>(b + p * bplane + (int64_t)(64 * i) * Kc);
     };
     auto store_a = [&](int ks) {
       unsigned char* S = wbase + (ks & 1) * 2 * kStageStride;
@@ -252,46 +261,44 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
         split_store(v, S + swz_off(row0 + 32 * i, chunk), APL);
       }
     };
-    auto store_b = [&](int ks, int set) {
-      unsigned char* S = wbase + (ks & 1) * 2 * kStageStride + 3 * APL;
+    auto store_b = [&](int ks, int set) {  // no arithmetic: 16-byte chunks (8 k of one piece) straight into the ring
+      unsigned char* S = wbase_b + (ks & 1) * 2 * kStageStride;
 #pragma unroll
-      for (int i = 0; i < BP; ++i) split_store(rb[set][i], S + swz_off(row0 + 32 * i, chunk), BPL);
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<u32x4*>(S + p * BPL + swz_off(brow + 64 * i, bc4 & 1)) = rb[set][p][i];
     };
 
-    // Cycle stamps of this loop (s_memtime around each phase, 128x256 forward tile) put the PRODUCERS on the critical
-    // path: ~960 cycles for the A half, ~1150 for the B half of pure work, plus whatever part of the load latency is
-    // exposed, against ~3300 cycles of MFMA issue per k32 - and the consumers waited 900-2000 cycles per step at the
-    // barrier.  The B (weight) loads were the ones issued last and needed first, so B has two register sets: stage
-    // it+2 is loaded at the START of step it and consumed a whole step later.  (Giving A a second set too made the
-    // data-gradient producers spill and the load issue itself stall - the CU's vector-memory queue was full.)
-    auto step = [&](int it, int set_ld, int set_st) {  // fills super-stage it+1
-      if (it + 2 < nks) load_b(it + 2, set_ld);
-      __builtin_amdgcn_sched_barrier(0);
+    // Cycle stamps of this loop (s_memtime around each phase, 128x256 forward tile): ~3300 cycles of MFMA issue per k32 in
+    // the consumers, which then waited 900-2000 cycles at the barrier for the producers; the producers' time was mostly
+    // spent waiting for loads issued only ~1200 cycles before their use.
+    // One register set per operand is enough when every load is issued right after the previous contents of its
+    // registers were consumed: B is consumed first in a step and reloaded at once, then A - each load has a whole
+    // step (~4000 cycles) to land, with 16 loads in flight per thread (more - a second set per operand - overflowed
+    // the CU's vector-memory queue and stalled the load ISSUE for thousands of cycles).
+    auto step = [&](int it) {  // fills super-stage it+1
       if (it + 1 < nks) {
+        store_b(it + 1, 0);
+        if (it + 2 < nks) load_b(it + 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
         store_a(it + 1);
         if (it + 2 < nks) load_a(it + 2);
         __builtin_amdgcn_sched_barrier(0);
-        store_b(it + 1, set_st);
-        __builtin_amdgcn_sched_barrier(0);
       }
     };
-    load_a(0);
     load_b(0, 0);
-    if (nks > 1) load_b(1, 1);
+    load_a(0);
+    __builtin_amdgcn_sched_barrier(0);
+    store_b(0, 0);
+    if (nks > 1) load_b(1, 0);
     __builtin_amdgcn_sched_barrier(0);
     store_a(0);
     if (nks > 1) load_a(1);
     __builtin_amdgcn_sched_barrier(0);
-    store_b(0, 0);
-    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // super-stage 0 is in LDS
-    for (int it = 0; it < nks; it += 2) {
-      step(it, 0, 1);
+    for (int it = 0; it < nks; ++it) {
+      step(it);
       __syncthreads();
-      if (it + 1 < nks) {
-        step(it + 1, 1, 0);
-        __syncthreads();
-      }
     }
   } else {
     // ------------------------------------------------------------------ consumer waves
@@ -611,22 +618,38 @@ bool launch_conv_wgrad(const float* g, const float* y, const float* bn, const fl
   return true;
 }
 
+// w[n] fp32 -> q[3][n] bf16 pieces (same element order): the exact 3-way split of split_store, done once per call
+// for the weight operand so that the GEMM producers move it without arithmetic.
+__global__ void split_weights_k(const float* __restrict__ w, uint16_t* __restrict__ q, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = w[i];
+  const float r1 = TTK_RESID(x), r2 = TTK_RESID(r1);
+  q[i] = (uint16_t)(__float_as_uint(x) >> 16);
+  q[n + i] = (uint16_t)(__float_as_uint(r1) >> 16);
+  q[2 * n + i] = (uint16_t)(__float_as_uint(r2) >> 16);
+}
+
 // Returns true when the shape was handled here (and the kernel launched on `st`).
 template <int MODE>
 bool launch_split_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
-                       const float* bnE, float* part, int64_t M, int K, int Nout, hipStream_t st) {
+                       const float* bnE, float* part, int64_t M, int K, int Nout, void* wsplit, hipStream_t st) {
   constexpr int AM = MODE == SMODE_FWD ? AMODE_BNRELU : AMODE_BNGRAD, EM = MODE == SMODE_FWD ? EMODE_STATS : EMODE_MASK;
-  if (K < 128 || K % 32 != 0) return false;
+  if (K < 128 || K % 32 != 0 || !wsplit) return false;
+  if (!((Nout >= 256 && Nout % 256 == 0) || (Nout == 128 && K >= 128))) return false;
   const ConvGeom none{};
+  uint16_t* Bq = reinterpret_cast<uint16_t*>(wsplit);
+  const int64_t nw = (int64_t)Nout * K;
+  hipLaunchKernelGGL(split_weights_k, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, st, Bm, Bq, nw);
   if (Nout >= 256 && Nout % 256 == 0) {
     const unsigned tiles = (unsigned)(ceil_div(M, 128) * (Nout / 256));
-    hipLaunchKernelGGL((pw_split_k<128, 256, AM, EM, false>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K,
+    hipLaunchKernelGGL((pw_split_k<128, 256, AM, EM, false>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, out, E0, bnE, part, M, K,
                        Nout, none);
     return true;
   }
-  if (Nout == 128 && K >= 256) {
+  if (Nout == 128 && K >= 128) {
     const unsigned tiles = (unsigned)ceil_div(M, 256);
-    hipLaunchKernelGGL((pw_split_k<256, 128, AM, EM, false>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K,
+    hipLaunchKernelGGL((pw_split_k<256, 128, AM, EM, false>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, out, E0, bnE, part, M, K,
                        Nout, none);
     return true;
   }
@@ -634,13 +657,13 @@ bool launch_split_gemm(const float* A0, const float* A1, const float* bnA, const
 }
 
 template bool launch_split_gemm<SMODE_FWD>(const float*, const float*, const float*, const float*, float*, const float*,
-                                           const float*, float*, int64_t, int, int, hipStream_t);
+                                           const float*, float*, int64_t, int, int, void*, hipStream_t);
 template bool launch_split_gemm<SMODE_DGRAD>(const float*, const float*, const float*, const float*, float*, const float*,
-                                             const float*, float*, int64_t, int, int, hipStream_t);
+                                             const float*, float*, int64_t, int, int, void*, hipStream_t);
 
 // Implicit-GEMM convolution launches (conv.hip).  amode/emode: AMODE_* / EMODE_*.  Nout must be a multiple of 64;
 // geo.Kc a multiple of 32.  K = taps * geo.Kc.
-bool launch_conv_gemm(int amode, int emode, const float* A0, const float* A1, const float* bnA, const float* Bm, float* out,
+bool launch_conv_gemm(int amode, int emode, const float* A0, const float* A1, const float* bnA, const uint16_t* Bm, float* out,
                       const float* E0, const float* bnE, float* part, int64_t M, int K, int Nout, const ConvGeom& geo,
                       hipStream_t st) {
 #define TTK_CONV_LAUNCH(BM_, BN_, AM_, EM_)                                                                           \

@@ -26,8 +26,8 @@ _SIGNATURES = {
     "ttk_dwconv3x3_fwd": [_P] * 7 + [_I] * 5,
     "ttk_dwconv3x3_bwd_data": [_P] * 12 + [_I] * 6,
     "ttk_dwconv3x3_bwd_weight": [_P] * 8 + [_I] * 6,
-    "ttk_pwconv1x1_fwd": [_P, _P, _P, _P, _P, _L, _I, _I],
-    "ttk_pwconv1x1_bwd_data": [_P] * 8 + [_L, _I, _I],
+    "ttk_pwconv1x1_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "ttk_pwconv1x1_bwd_data": [_P] * 8 + [_L, _I, _I, _P],
     "ttk_pwconv1x1_bwd_weight": [_P] * 6 + [_L, _I, _I],
     "ttk_transpose": [_P, _P, _I, _I],
     "ttk_avgpool_fwd": [_P, _P, _P, _P, _I, _I, _I],
@@ -76,7 +76,7 @@ _SIGNATURES = {
     "ttk_clip_adam": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _F, _F, _F, _F, _F, _P, _P, _P],
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class _Library:

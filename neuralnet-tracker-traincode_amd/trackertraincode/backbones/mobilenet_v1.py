@@ -155,7 +155,8 @@ def _forward_impl(x, params, buffers, momentum, eps, training):
         finalize(bn_dw, L.partial_rows_dwconv(B, h, w_, cin, stride, False), cin, B * ho * wo, g_dw, b_dw, bi)
         ypw = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=dev)
         M = B * ho * wo
-        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), p(w_pw), p(ypw), part_arg, M, cin, cout)
+        wq = torch.empty(3 * cout * cin, dtype=torch.int16, device=dev)  # scratch: pre-split weight operand
+        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), p(w_pw), p(ypw), part_arg, M, cin, cout, p(wq))
         bn_pw = _bn_work(cout, dev)
         finalize(bn_pw, L.partial_rows_gemm(M), cout, M, g_pw, b_pw, bi + 1)
         bi += 2
@@ -240,8 +241,9 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         wt = torch.empty((cin, cout), dtype=torch.float32, device=g.device)
         L.call("ttk_transpose", p(w_pw), p(wt), cout, cin)
         g_dw = torch.empty_like(st_dw.y)
+        wq = torch.empty(3 * cout * cin, dtype=torch.int16, device=g.device)  # scratch: pre-split weight operand
         L.call("ttk_pwconv1x1_bwd_data", p(g), p(st_pw.y), p(st_pw.bn), p(wt), p(st_dw.y), p(st_dw.bn), p(g_dw), p(part), M,
-               cin, cout)
+               cin, cout, p(wq))
         bwd_finalize(st_dw, L.partial_rows_gemm(M), M, pi + 1)
         # -- depthwise: weight gradient, then data gradient (+ residual gradient, + producer's bn sums)
         dWd = torch.empty_like(w_dw)  # filled by the fused weight-gradient path of bwd_data

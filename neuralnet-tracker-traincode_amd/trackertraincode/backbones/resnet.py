@@ -81,6 +81,7 @@ def _forward_impl(x, params, buffers, momentum, eps):
     c.part, c.partd = _part_buffers(B, dev)
     part = c.part
     new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    newq = lambda *s: torch.empty((3,) + s, dtype=torch.int16, device=dev)  # pre-split (3 bf16 piece planes) weight operands
     bi = [0]
 
     def finalize(bn, rows, C, count, gamma, beta, scratch=None):
@@ -111,7 +112,7 @@ def _forward_impl(x, params, buffers, momentum, eps):
         ho = (h - 1) // stride + 1
         k.ho = ho
         M = B * ho * ho
-        w1f, k.w1b = new(9, planes, cin), new(9, cin, planes)
+        w1f, k.w1b = newq(9, planes, cin), newq(9, cin, planes)
         L.call("ttk_conv_weight_repack", p(w1), p(w1f), p(k.w1b), planes, cin, 3, 3)
         k.y1 = new(B, ho, ho, planes)
         L.call("ttk_conv_fwd", p(a_in), p(w1f), p(k.y1), p(part), B, h, h, cin, planes, 3, 3, stride, 1)
@@ -119,7 +120,7 @@ def _forward_impl(x, params, buffers, momentum, eps):
         finalize(k.bn1, L.partial_rows_gemm(M), planes, M, g1, b1)
         k.a_mid = new(B, ho, ho, planes)
         L.call("ttk_bn_add_act", p(k.y1), p(k.bn1), None, None, p(k.a_mid), M, planes)
-        w2f, k.w2b = new(9, planes, planes), new(9, planes, planes)
+        w2f, k.w2b = newq(9, planes, planes), newq(9, planes, planes)
         L.call("ttk_conv_weight_repack", p(w2), p(w2f), p(k.w2b), planes, planes, 3, 3)
         k.y2 = new(B, ho, ho, planes)
         L.call("ttk_conv_fwd", p(k.a_mid), p(w2f), p(k.y2), p(part), B, ho, ho, planes, planes, 3, 3, 1, 1)
@@ -129,7 +130,7 @@ def _forward_impl(x, params, buffers, momentum, eps):
         if has_ds:
             wd, gd, bd = params[pi:pi + 3]
             pi += 3
-            wdf = new(1, planes, cin)
+            wdf = newq(1, planes, cin)
             L.call("ttk_conv_weight_repack", p(wd), p(wdf), None, planes, cin, 1, 1)
             k.yd = new(B, ho, ho, planes)
             L.call("ttk_conv_fwd", p(a_in), p(wdf), p(k.yd), p(part), B, h, h, cin, planes, 1, 1, stride, 0)
@@ -202,7 +203,7 @@ def _backward_impl(c: _Ctx, gfeat, params):
             dWd = torch.zeros_like(params[pi + 6])
             L.call("ttk_conv_bwd_weight", p(gs), p(k.yd), p(k.bnd), p(k.a_in), p(dWd), B, k.h, k.h, k.cin, C, 1, 1, k.stride, 0)
             grads[pi + 6] = dWd
-            wdb = new(1, k.cin, C)
+            wdb = torch.empty((3, 1, k.cin, C), dtype=torch.int16, device=dev)
             L.call("ttk_conv_weight_repack", p(params[pi + 6]), None, p(wdb), C, k.cin, 1, 1)
             g_sc = new(B, k.h, k.h, k.cin)
             L.call("ttk_conv_bwd_data", p(gs), p(k.yd), p(k.bnd), p(wdb), None, None, p(g_sc), None, B, k.h, k.h, k.cin, C, 1, 1, k.stride, 0)

@@ -43,7 +43,8 @@ def test_conv_fwd_bwd_data_bwd_weight(B, H, Cin, Cout, k, stride):
     dev = "cuda"
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     d_a, d_w = t(a), t(w)
-    w_f, w_b = torch.empty(k * k, Cout, Cin, device=dev), torch.empty(k * k, Cin, Cout, device=dev)
+    w_f = torch.empty(3, k * k, Cout, Cin, dtype=torch.int16, device=dev)  # pre-split weight operands (3 bf16 piece planes)
+    w_b = torch.empty(3, k * k, Cin, Cout, dtype=torch.int16, device=dev)
     L.call("ttk_conv_weight_repack", p(d_w), p(w_f), p(w_b), Cout, Cin, k, k)
 
     # ---- forward

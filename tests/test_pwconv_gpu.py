@@ -62,7 +62,8 @@ def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout):
     d_ydw, d_w, d_bn = t(ydw), t(w), t(bn_dw)
     y = torch.empty(M, Cout, device=dev)
     part = torch.full((rows, 2, Cout), float("nan"), device=dev)
-    L.call("ttk_pwconv1x1_fwd", p(d_ydw), p(d_bn), p(d_w), p(y), p(part), M, Cin, Cout)
+    wq = torch.empty(3 * Cout * Cin, dtype=torch.int16, device=dev)  # scratch for the pre-split weight operand
+    L.call("ttk_pwconv1x1_fwd", p(d_ydw), p(d_bn), p(d_w), p(y), p(part), M, Cin, Cout, p(wq))
     torch.cuda.synchronize()
     e_hip, e_f32 = _rel(y.cpu().numpy(), y64), _rel(y32, y64)
     print(f"fwd   M={M} K={Cin} N={Cout}: hip {e_hip:.2e}  fp32 chain {e_f32:.2e}")
@@ -85,7 +86,7 @@ def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout):
     g_dw = torch.empty(M, Cin, device=dev)
     part2 = torch.full((rows, 2, Cin), float("nan"), device=dev)
     d_g, d_bnpw = t(g), t(bn_pw)  # named: a temporary would be recycled by the allocator before the kernel runs
-    L.call("ttk_pwconv1x1_bwd_data", p(d_g), p(y), p(d_bnpw), p(wt), p(d_ydw), p(d_bn), p(g_dw), p(part2), M, Cin, Cout)
+    L.call("ttk_pwconv1x1_bwd_data", p(d_g), p(y), p(d_bnpw), p(wt), p(d_ydw), p(d_bn), p(g_dw), p(part2), M, Cin, Cout, p(wq))
     torch.cuda.synchronize()
     out = g_dw.cpu().numpy()
     e_hip, e_f32 = _rel(out * safe, gd64 * safe), _rel(gd32 * safe, gd64 * safe)

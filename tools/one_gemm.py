@@ -10,9 +10,10 @@ ydw, y, g = torch.randn(M, ci, device=dev), torch.randn(M, co, device=dev), torc
 w, wt = torch.randn(co, ci, device=dev) * 0.05, torch.randn(ci, co, device=dev) * 0.05
 bn_dw, bn_pw = torch.rand(8, ci, device=dev) + 0.5, torch.rand(8, co, device=dev) + 0.5
 out, gdw, dW = torch.empty(M, co, device=dev), torch.empty(M, ci, device=dev), torch.zeros(co, ci, device=dev)
+wq = torch.empty(3 * 1024 * 1024, dtype=torch.int16, device=dev)
 part = torch.empty(L.partial_rows_gemm(M) * 2 * max(ci, co), device=dev)
 for _ in range(reps):
-    if kind == "fwd": L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), p(w), p(out), p(part), M, ci, co)
-    elif kind == "dgrad": L.call("ttk_pwconv1x1_bwd_data", p(g), p(y), p(bn_pw), p(wt), p(ydw), p(bn_dw), p(gdw), p(part), M, ci, co)
+    if kind == "fwd": L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), p(w), p(out), p(part), M, ci, co, p(wq))
+    elif kind == "dgrad": L.call("ttk_pwconv1x1_bwd_data", p(g), p(y), p(bn_pw), p(wt), p(ydw), p(bn_dw), p(gdw), p(part), M, ci, co, p(wq))
     else: L.call("ttk_pwconv1x1_bwd_weight", p(g), p(y), p(bn_pw), p(ydw), p(bn_dw), p(dW), M, ci, co)
 torch.cuda.synchronize()

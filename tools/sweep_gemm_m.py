@@ -13,9 +13,10 @@ for R in [16, 32, 64, 128, 192, 256, 288, 320, 324, 352, 384, 448, 512, 640, 768
     w = torch.randn(C, C, device=dev) * 0.05
     bn = torch.rand(8, C, device=dev) + 0.5
     out = torch.empty(M, C, device=dev)
+    wq = torch.empty(3 * 1024 * 1024, dtype=torch.int16, device=dev)
     part = torch.empty(L.partial_rows_gemm(M) * 2 * C, device=dev)
-    calls = {"fwd": lambda: L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn), p(w), p(out), p(part), M, C, C),
-             "dgrad": lambda: L.call("ttk_pwconv1x1_bwd_data", p(g), p(y), p(bn), p(w), p(ydw), p(bn), p(out), p(part), M, C, C)}
+    calls = {"fwd": lambda: L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn), p(w), p(out), p(part), M, C, C, p(wq)),
+             "dgrad": lambda: L.call("ttk_pwconv1x1_bwd_data", p(g), p(y), p(bn), p(w), p(ydw), p(bn), p(out), p(part), M, C, C, p(wq))}
     line = f"R={R:5d} tiles={R*C//128:6d} ({R*C/128/256:6.2f}/CU) "
     for k, fn in calls.items():
         for _ in range(3): fn()
