@@ -66,7 +66,8 @@ class KernelTimer:
         Mirrors the dispatch rules of csrc/pwconv.hip + pwconv_split.hip + dwconv_tiled.hip."""
         ints = [x for x in a if isinstance(x, int) and not isinstance(x, bool)]
         if name.startswith("ttk_pwconv1x1"):
-            M, ci, co = ints[-3:]
+            # forward / data gradient end with the scratch pointer of the pre-split weights (an int here)
+            M, ci, co = ints[-3:] if name == "ttk_pwconv1x1_bwd_weight" else ints[-4:-1]
             fl = 2 * M * ci * co
             if name == "ttk_pwconv1x1_fwd":
                 K, N, mode, by = ci, co, 0, 4 * (M * ci + M * co + ci * co)
