@@ -43,17 +43,28 @@ __global__ void __launch_bounds__(kBlock) heads_fwd_k(HeadsArgs a, float* __rest
   const int s = blockIdx.x * (kBlock / kWave) + wv;
   if (s >= a.B) return;  // whole wave exits together
   const float* f = a.feat + (size_t)s * a.F;
-  for (int j = 0; j < a.NZ; ++j) {
-    const float* w = a.wcat + (size_t)j * a.F;
-    float acc = 0.f;
+  // four rows of the stacked linear layer at a time: their weight loads are independent, so the wave has 4x the loads in
+  // flight of a row-by-row loop (this kernel is a chain of latencies, not of bandwidth)
+  for (int j0 = 0; j0 < a.NZ; j0 += 4) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int k = lane * 4; k < a.F; k += 256) {
-      const float4 fv = ld4(f + k), wv4 = ld4(w + k);
-      acc = fmaf(fv.x, wv4.x, fmaf(fv.y, wv4.y, fmaf(fv.z, wv4.z, fmaf(fv.w, wv4.w, acc))));
+      const float4 fv = ld4(f + k);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = min(j0 + u, a.NZ - 1);
+        const float4 wv4 = ld4(a.wcat + (size_t)j * a.F + k);
+        acc[u] = fmaf(fv.x, wv4.x, fmaf(fv.y, wv4.y, fmaf(fv.z, wv4.z, fmaf(fv.w, wv4.w, acc[u]))));
+      }
     }
-    acc = wave_sum(acc) + a.bcat[j];
-    if (lane == 0) {
-      zs[wv][j] = acc;
-      z[(size_t)s * a.NZ + j] = acc;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float v = wave_sum(acc[u]);
+      const int j = j0 + u;
+      if (lane == 0 && j < a.NZ) {
+        const float zz = v + a.bcat[j];
+        zs[wv][j] = zz;
+        z[(size_t)s * a.NZ + j] = zz;
+      }
     }
   }
   __builtin_amdgcn_s_waitcnt(0);  // LDS writes of lane 0 visible to the wave (same wave: program order)
@@ -227,16 +238,24 @@ __global__ void __launch_bounds__(kBlock) heads_bwd_weight_k(const float* __rest
   if (f == 0) atomicAdd(db + j, sb);
 }
 
-// dP[r][c] = sum_{b: id_b == r} dprow[b][c] (c<4), dPk likewise (c>=4).  64 threads.
-__global__ void heads_bwd_offset_k(const float* __restrict__ dprow, const int* __restrict__ ids, float* __restrict__ dP,
-                                   float* __restrict__ dPk, int B) {
-  const int t = threadIdx.x;  // 0..63: module (1 bit), row (3 bits), component (2 bits)
+// dP[r][c] = sum_{b: id_b == r} dprow[b][c] (c<4), dPk likewise (c>=4).  One workgroup per output element
+// (module, row, component), its threads stride over the samples; fixed-order reduction.
+__global__ void __launch_bounds__(kBlock) heads_bwd_offset_k(const float* __restrict__ dprow, const int* __restrict__ ids,
+                                                              float* __restrict__ dP, float* __restrict__ dPk, int B) {
+  __shared__ float red[kBlock];
+  const int t = blockIdx.x;  // 0..63: module (1 bit), row (3 bits), component (2 bits)
   const int mod = t >> 5, r = (t >> 2) & 7, c = t & 3;
   float acc = 0.f;
-  for (int b = 0; b < B; ++b)
+  for (int b = threadIdx.x; b < B; b += kBlock)
     if ((ids ? ids[b] : 0) == r) acc += dprow[8 * b + 4 * mod + c];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
   float* out = mod ? dPk : dP;
-  if (out) out[4 * r + c] = acc;
+  if (threadIdx.x == 0 && out) out[4 * r + c] = red[0];
 }
 
 __global__ void fill_zero_k(float* p, int64_t n) {
@@ -318,7 +337,7 @@ int ttk_heads_bwd(const float* feat, const float* wcat, const float* z, const in
   hipLaunchKernelGGL(fill_zero_k, dim3(1), dim3(256), 0, st, dbcat, (int64_t)NZ);
   hipLaunchKernelGGL(heads_bwd_weight_k, dim3((unsigned)ceil_div(nw, kBlock), (unsigned)ceil_div(B, 64)), dim3(kBlock), 0, st, dz,
                      feat, dwcat, dbcat, B, F, NZ);
-  if (use_offset && (dP || dPk)) hipLaunchKernelGGL(heads_bwd_offset_k, dim3(1), dim3(64), 0, st, dprow, ids, dP, dPk, B);
+  if (use_offset && (dP || dPk)) hipLaunchKernelGGL(heads_bwd_offset_k, dim3(64), dim3(kBlock), 0, st, dprow, ids, dP, dPk, B);
   TTK_LAUNCH_CHECK("heads_bwd");
 }
 
