@@ -4,6 +4,7 @@
 // add + ReLU that materialises a block's output activation, and the elementwise backward of that add.  All HBM-bound;
 // the dense 3x3 / 1x1 convolutions are in conv.hip.
 #include "ttk_common.h"
+#include "stem_wgrad.h"
 
 namespace ttk {
 
@@ -83,57 +84,6 @@ __global__ void __launch_bounds__(kBlock) stem7_fwd_k(const float* __restrict__ 
       for (int i = 0; i < kBlock / kWave; ++i) a += red[i][threadIdx.x];  // fixed wave order
       part[(size_t)blockIdx.x * 2 * kS7C + (size_t)which * kS7C + cbase + c] = a;
     }
-  }
-}
-
-// dW[c][tap] = sum_pixels dy[pixel][c] * x[tap of pixel].  A workgroup owns output rows (n, ho): the 7 input rows and
-// the dy row (BatchNorm-backward form applied on load) are staged in LDS once, then thread (channel c, tap group g)
-// accumulates its 13 taps over the 65 pixels of the row - the input value is a wave-uniform LDS broadcast, dy is read
-// once per pixel.  (v1 fetched the 49 input values of every pixel as broadcast GLOBAL loads: 2.5 ms at B=512, a chain
-// of latencies; this form streams dy at HBM speed.)
-constexpr int kS7Taps = kS7K * kS7K;             // 49
-constexpr int kS7TapsPerThread = (kS7Taps + 3) / 4;  // 13: taps g, g+4, ...
-__global__ void __launch_bounds__(kBlock) stem7_bwd_weight_k(const float* __restrict__ g, const float* __restrict__ y,
-                                                              const float* __restrict__ bn, const float* __restrict__ x,
-                                                              float* __restrict__ dw, int B, int H, int W, int Ho, int Wo) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int Wp = W + 6;            // input row with 3 zero columns on each side
-  float* xs = smem;                // [7][Wp]
-  float* dys = smem + kS7K * Wp;   // [Wo][64]
-  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const float ga = bn[TTK_BN_GA * kS7C + c], gb = bn[TTK_BN_GB * kS7C + c], gmean = bn[TTK_BN_GMEAN * kS7C + c],
-              mean = bn[TTK_BN_MEAN * kS7C + c];
-  float acc[kS7TapsPerThread];
-  int xoff[kS7TapsPerThread];
-#pragma unroll
-  for (int j = 0; j < kS7TapsPerThread; ++j) {
-    acc[j] = 0.f;
-    const int t = min(grp + 4 * j, kS7Taps - 1);
-    xoff[j] = (t / kS7K) * Wp + (t % kS7K);
-  }
-  const int64_t nrows = (int64_t)B * Ho;
-  for (int64_t row = blockIdx.x; row < nrows; row += gridDim.x) {
-    const int ho = (int)(row % Ho), n = (int)(row / Ho);
-    __syncthreads();  // previous row's readers are done
-    for (int i = threadIdx.x; i < kS7K * Wp; i += kBlock) {
-      const int kh = i / Wp, wi = i % Wp - 3, hi = 2 * ho + kh - 3;
-      xs[i] = (hi >= 0 && hi < H && wi >= 0 && wi < W) ? x[((size_t)n * H + hi) * W + wi] : 0.f;
-    }
-    const size_t rbase = (size_t)row * Wo * kS7C;
-    for (int i = threadIdx.x; i < Wo * kS7C; i += kBlock)  // i % 64 == c for every i: this thread's BatchNorm constants apply
-      dys[i] = fmaf(ga, g[rbase + i] - gmean, gb * (y[rbase + i] - mean));
-    __syncthreads();
-    for (int wo = 0; wo < Wo; ++wo) {
-      const float d = dys[wo * kS7C + c];
-      const float* xr = xs + 2 * wo;
-#pragma unroll
-      for (int j = 0; j < kS7TapsPerThread; ++j) acc[j] = fmaf(d, xr[xoff[j]], acc[j]);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < kS7TapsPerThread; ++j) {
-    const int t = grp + 4 * j;
-    if (t < kS7Taps) atomicAdd(dw + (size_t)c * kS7Taps + t, acc[j]);
   }
 }
 
@@ -287,11 +237,7 @@ int ttk_stem7_bwd_weight(const float* g, const float* y, const float* bn, const 
   TTK_REQUIRE(B > 0 && H > 6 && W > 6, "stem7_bwd_weight: bad shape");
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   hipMemsetAsync(dw, 0, sizeof(float) * kS7C * kS7K * kS7K, (hipStream_t)stream);
-  int64_t grid = (int64_t)B * Ho;
-  if (grid > 2048) grid = 2048;
-  const size_t sm = (size_t)(kS7K * (W + 6) + Wo * kS7C) * sizeof(float);
-  hipLaunchKernelGGL(stem7_bwd_weight_k, dim3((unsigned)grid), dim3(kBlock), sm, (hipStream_t)stream, g, y, bn, x, dw, B, H, W, Ho,
-                     Wo);
+  launch_stem_wgrad<kS7K, kS7C>(g, y, bn, x, dw, B, H, W, Ho, Wo, (hipStream_t)stream);
   TTK_LAUNCH_CHECK("stem7_bwd_weight");
 }
 
