@@ -70,7 +70,7 @@ def _part_buffers(B, device):
     return mk(), mk()
 
 
-def _forward_impl(x, params, buffers, momentum, eps):
+def _forward_impl(x, params, buffers, momentum, eps, training=True):
     """params: [conv1.w, bn1.w, bn1.b, then per block (conv1.w, bn1.w, bn1.b, conv2.w, bn2.w, bn2.b[, ds.w, dsbn.w, dsbn.b])];
     buffers: (running_mean, running_var, num_batches_tracked) per BatchNorm in the same order."""
     L, p = _hip.lib(), _hip.ptr
@@ -87,8 +87,11 @@ def _forward_impl(x, params, buffers, momentum, eps):
     def finalize(bn, rows, C, count, gamma, beta, scratch=None):
         rm, rv, nbt = buffers[3 * bi[0]: 3 * bi[0] + 3]
         bi[0] += 1
-        L.call("ttk_bn_fwd_finalize", p(scratch if scratch is not None else part), rows, C, count, p(gamma), p(beta), p(rm), p(rv),
-               p(nbt), float(momentum), float(eps), p(bn))
+        if training:
+            L.call("ttk_bn_fwd_finalize", p(scratch if scratch is not None else part), rows, C, count, p(gamma), p(beta), p(rm), p(rv),
+                   p(nbt), float(momentum), float(eps), p(bn))
+        else:  # eval: constants from the running statistics, the partial sums the kernels wrote are ignored
+            L.call("ttk_bn_eval_prepare", p(gamma), p(beta), p(rm), p(rv), float(eps), C, p(bn))
 
     # ---- stem 7x7/s2 + bn + relu + maxpool 3x3/s2 (reference resnet.py:63-66; torchvision ResNet.forward)
     Ho = (H - 1) // 2 + 1
@@ -311,14 +314,20 @@ class ResNetBackbone(nn.Module):
         if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 1:
             raise ValueError(f"expected float32 [B,1,H,W] input, got {tuple(x.shape)} {x.dtype}")
         bns = list(self._bns())
-        if not (self.training and all(b.training for b in bns)):
-            # eval / frozen-statistics mode: plain torch ops on the GPU (not the benchmarked path; the hand-written
-            # kernels cover training, where the time goes)
-            return self.layers(x)
         moms, epss = {b.momentum for b in bns}, {b.eps for b in bns}
         if len(moms) != 1 or len(epss) != 1 or None in moms:
             raise NotImplementedError("all BatchNorm layers must share one momentum/eps")
-        return _ResNetFn.apply(x.contiguous(), moms.pop(), epss.pop(), self._flat_buffers(), *self._flat_params())
+        bn_training = [b.training for b in bns]
+        if self.training and all(bn_training):
+            return _ResNetFn.apply(x.contiguous(), moms.pop(), epss.pop(), self._flat_buffers(), *self._flat_params())
+        if any(bn_training):
+            raise NotImplementedError("mixed train/eval BatchNorm layers are not supported by the fused backbone")
+        if torch.is_grad_enabled() and any(q.requires_grad for q in self._flat_params()):
+            raise NotImplementedError("gradients through the eval-mode (frozen BatchNorm) backbone are not built; "
+                                      "wrap inference in torch.no_grad()")
+        feat, _ = _forward_impl(x.contiguous(), [q.detach() for q in self._flat_params()], self._flat_buffers(), moms.pop(), epss.pop(),
+                                training=False)
+        return feat
 
     def forward(self, x):
         return self.forward_features(x), None

@@ -111,3 +111,22 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(H, "_lib", None)
     with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
         H.lib()
+
+
+def test_entry_points_reject_bad_arguments():
+    """Negative return code -> RuntimeError carrying ttk_last_error_string(); nothing is launched."""
+    import trackertraincode._hip as H
+
+    L, p = H.lib(), H.ptr
+    t = torch.zeros(64, device="cuda")
+    with pytest.raises(RuntimeError, match="pwconv1x1_fwd"):
+        L.call("ttk_pwconv1x1_fwd", p(t), p(t), p(t), p(t), p(t), 100, 48, 64, None)  # 48 channels: not a power of two
+    with pytest.raises(RuntimeError, match="null pointer"):
+        L.call("ttk_pwconv1x1_fwd", None, p(t), p(t), p(t), p(t), 100, 32, 64, None)
+    with pytest.raises(RuntimeError, match="dwconv3x3_fwd"):
+        L.call("ttk_dwconv3x3_fwd", p(t), p(t), None, None, p(t), p(t), None, 1, 8, 8, 32, 3)  # stride 3
+    with pytest.raises(RuntimeError, match="conv_fwd"):
+        L.call("ttk_conv_fwd", p(t), p(t), p(t), p(t), 1, 8, 8, 64, 64, 5, 5, 1, 2)  # 5x5 is not a ResNet18 conv
+    with pytest.raises(RuntimeError, match="heads_fwd"):
+        L.call("ttk_heads_fwd", p(t), p(t), p(t), None, None, None, None, None, 4, 1024, 7, 0, 0, 0, 0, p(t), p(t), p(t), p(t), p(t), None, None,
+               None, None)  # NZ does not match the configuration

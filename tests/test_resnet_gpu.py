@@ -84,3 +84,23 @@ def test_resnet18_pose_network_step():
     assert out["coord"].shape == (4, 3) and out["roi"].shape == (4, 4)
     (out["coord"].sum() + out["roi"].sum() + out["rot"].value.sum()).backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.convnet.parameters())
+
+
+def test_resnet18_eval_forward_matches_oracle():
+    """Eval mode (running statistics) on the HIP kernels against the oracle with calibrated statistics."""
+    from trackertraincode.backbones.resnet import resnet18
+
+    sd = make_state(R.resnet18_state_shapes(), seed=0)
+    image, _ = make_inputs(4, seed=9)
+    st = R.state_from_numpy(sd, requires_grad=False)
+    with torch.no_grad():
+        R.resnet18_forward(st, torch.from_numpy(image), True, momentum=1.0)  # calibrate running stats on this batch
+        ref, _ = R.resnet18_forward(st, torch.from_numpy(image), False)
+    net = resnet18().cuda()
+    net.load_state_dict({k: v.clone() for k, v in st.items()}, strict=True)
+    net.eval()
+    with torch.no_grad():
+        feat, _ = net(torch.from_numpy(image).cuda())
+    assert _rel(feat.cpu(), ref) < 2e-4
+    with pytest.raises(NotImplementedError):
+        net(torch.from_numpy(image).cuda())  # grad mode with trainable parameters in eval: not built
