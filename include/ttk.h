@@ -42,7 +42,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 6
+#define TTK_ABI_VERSION 7
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -144,6 +144,12 @@ int ttk_pwconv1x1_bwd_data(const float* g, const float* y, const float* bn_pw, c
 int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* bn_pw, const float* ydw,
                              const float* bn_dw, float* dw, int64_t M, int Cin, int Cout,
                              ttk_stream_t stream);
+/* Weight operands of n (<= 16) pointwise layers in ONE launch (w[i]: [Cout][Cin] fp32 device pointers; w, cin, cout and
+ * prepared are HOST arrays).  prepared[i]: device scratch of ttk_pwconv_prepared_bytes(cin[i], cout[i]); pass it as
+ * `wsplit` with w == NULL (forward) / wt == NULL (data gradient) to skip the per-call split and transpose launches. */
+size_t ttk_pwconv_prepared_bytes(int Cin, int Cout);
+int ttk_pwconv_prepare_weights(int n, const float* const* w, const int* cin, const int* cout,
+                               void* const* prepared, ttk_stream_t stream);
 int ttk_transpose(const float* in, float* out, int rows, int cols, ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -272,6 +278,22 @@ int ttk_loss_quatreg_fwd(const float* q, int n, float* v, ttk_stream_t stream);
 int ttk_loss_quatreg_bwd(const float* q, const float* gv, int n, float* gq, ttk_stream_t stream);
 int ttk_loss_mse_rows_fwd(const float* p, const float* t, int n, int D, float* v, ttk_stream_t stream);
 int ttk_loss_mse_rows_bwd(const float* p, const float* t, const float* gv, int n, int D, float* gp, ttk_stream_t stream);
+/* The same over the column window [c0, c0+Dc) of rows Dt floats apart (PoseXYLoss / PoseSizeLoss on coord[..., :2] and
+ * coord[..., 2], reference neuralnets/losses.py:66-85, without materialising the slices); gp is the gradient of the whole
+ * [n][Dt] tensor, zero outside the window. */
+int ttk_loss_mse_cols_fwd(const float* p, const float* t, int n, int Dt, int c0, int Dc, float* v, ttk_stream_t stream);
+int ttk_loss_mse_cols_bwd(const float* p, const float* t, const float* gv, int n, int Dt, int c0, int Dc, float* gp, ttk_stream_t stream);
+/* Loss bookkeeping of one step (reference train.py:372-439, default_compute_loss) in single launches; src, dst, count,
+ * val, sample_w, w, gval are HOST arrays of n <= 32 entries.
+ *   multi_copy      : dst[k][0..count[k]) = src[k] ? src[k][..] : 0      (concatenate sub-batch values / slice gradients)
+ *   weighted_sum_fwd: out = scale * sum_k w[k] * sum_i sample_w[k][i] * val[k][i]  (sample_w or sample_w[k] NULL = 1),
+ *                     one workgroup, fixed summation order, double accumulators
+ *   weighted_sum_bwd: gval[k][i] = gout[0] * scale * w[k] * sample_w[k][i] */
+int ttk_multi_copy(int n, const float* const* src, float* const* dst, const int64_t* count, ttk_stream_t stream);
+int ttk_weighted_sum_fwd(int n, const float* const* val, const float* const* sample_w, const float* w, const int* count,
+                         float scale, float* out, ttk_stream_t stream);
+int ttk_weighted_sum_bwd(int n, const float* gout, const float* const* sample_w, const float* w, const int* count,
+                         float scale, float* const* gval, ttk_stream_t stream);
 int ttk_loss_points_fwd(const float* p, const float* t, int n, int dim, float chin, float eye, float* v, ttk_stream_t stream);
 int ttk_loss_points_bwd(const float* p, const float* t, const float* gv, int n, int dim, float chin, float eye, float* gp, ttk_stream_t stream);
 int ttk_loss_nllrot_fwd(const float* q, const float* t, const float* L, int n, float* v, ttk_stream_t stream);

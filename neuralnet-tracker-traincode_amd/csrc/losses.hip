@@ -91,6 +91,79 @@ __global__ void loss_mse_rows_bwd_k(const float* p, const float* t, const float*
   if (i >= n * D) return;
   gp[i] = 2.f * (p[i] - t[i]) * gv[i / D] / (float)D;
 }
+// the same over the column window [c0, c0 + Dc) of rows that are Dt floats apart (p and t alike); the gradient is written
+// for the whole row, zero outside the window
+__global__ void loss_mse_cols_fwd_k(const float* p, const float* t, int n, int Dt, int c0, int Dc, float* v) {
+  TTK_WAVE_SAMPLE(n);
+  float acc = 0.f;
+  for (int d = lane; d < Dc; d += 64) {
+    const float e = p[(size_t)s * Dt + c0 + d] - t[(size_t)s * Dt + c0 + d];
+    acc = fmaf(e, e, acc);
+  }
+  acc = wave_sum_f(acc);
+  if (lane == 0) v[s] = acc / (float)Dc;
+}
+__global__ void loss_mse_cols_bwd_k(const float* p, const float* t, const float* gv, int n, int Dt, int c0, int Dc, float* gp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * Dt) return;
+  const int d = i % Dt - c0;
+  gp[i] = (d >= 0 && d < Dc) ? 2.f * (p[i] - t[i]) * gv[i / Dt] / (float)Dc : 0.f;
+}
+
+// ---- loss bookkeeping of one training step in single launches (train.py default_compute_loss) ---------------------
+constexpr int kMaxSeg = 32;
+struct CopySegs {
+  const float* src[kMaxSeg];  // nullptr: zeros
+  float* dst[kMaxSeg];
+  long long first[kMaxSeg + 1];  // running element offsets
+  int n;
+};
+__global__ void multi_copy_k(CopySegs a) {
+  const long long total = a.first[a.n];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int k = 0;
+    while (i >= a.first[k + 1]) ++k;
+    const long long j = i - a.first[k];
+    a.dst[k][j] = a.src[k] ? a.src[k][j] : 0.f;
+  }
+}
+struct SumTerms {
+  const float* val[kMaxSeg];   // forward: loss values; backward: unused
+  float* gval[kMaxSeg];        // backward: gradient of each term's values
+  const float* sw[kMaxSeg];    // per-sample weights or nullptr (= 1)
+  float w[kMaxSeg];
+  int first[kMaxSeg + 1];
+  int n;
+};
+// out = scale * sum_k w_k * sum_i sw_k[i] * val_k[i]; one block, fixed summation order (double accumulators)
+__global__ void __launch_bounds__(1024) weighted_sum_fwd_k(SumTerms a, float scale, float* out) {
+  __shared__ double red[1024];
+  double acc = 0.0;
+  const int total = a.first[a.n];
+  for (int i = threadIdx.x; i < total; i += 1024) {
+    int k = 0;
+    while (i >= a.first[k + 1]) ++k;
+    const int j = i - a.first[k];
+    acc += (double)(a.val[k][j] * (a.sw[k] ? a.w[k] * a.sw[k][j] : a.w[k]));
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = (float)(red[0] * (double)scale);
+}
+__global__ void weighted_sum_bwd_k(SumTerms a, float scale, const float* gout) {
+  const int total = a.first[a.n];
+  const float g = *gout * scale;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int k = 0;
+    while (i >= a.first[k + 1]) ++k;
+    const int j = i - a.first[k];
+    a.gval[k][j] = g * (a.sw[k] ? a.w[k] * a.sw[k][j] : a.w[k]);
+  }
+}
 // mean_p( w_p * sum_{d<dim} (p - t)^2 )
 __global__ void loss_points_fwd_k(const float* p, const float* t, int n, int dim, float chin, float eye, float* v) {
   TTK_WAVE_SAMPLE(n);
@@ -275,6 +348,75 @@ int ttk_loss_mse_rows_bwd(const float* p, const float* t, const float* gv, int n
   TTK_REQUIRE(p && t && gv && gp && n > 0 && D > 0, "loss_mse_rows_bwd: bad arguments");
   hipLaunchKernelGGL(loss_mse_rows_bwd_k, TTK_GRID(n * D), p, t, gv, n, D, gp);
   TTK_LAUNCH_CHECK("loss_mse_rows_bwd");
+}
+int ttk_loss_mse_cols_fwd(const float* p, const float* t, int n, int Dt, int c0, int Dc, float* v, ttk_stream_t stream) {
+  TTK_REQUIRE(p && t && v && n > 0 && Dc > 0 && c0 >= 0 && c0 + Dc <= Dt, "loss_mse_cols_fwd: bad arguments");
+  hipLaunchKernelGGL(loss_mse_cols_fwd_k, TTK_GRID(n * 64), p, t, n, Dt, c0, Dc, v);
+  TTK_LAUNCH_CHECK("loss_mse_cols_fwd");
+}
+int ttk_loss_mse_cols_bwd(const float* p, const float* t, const float* gv, int n, int Dt, int c0, int Dc, float* gp,
+                          ttk_stream_t stream) {
+  TTK_REQUIRE(p && t && gv && gp && n > 0 && Dc > 0 && c0 >= 0 && c0 + Dc <= Dt, "loss_mse_cols_bwd: bad arguments");
+  hipLaunchKernelGGL(loss_mse_cols_bwd_k, TTK_GRID(n * Dt), p, t, gv, n, Dt, c0, Dc, gp);
+  TTK_LAUNCH_CHECK("loss_mse_cols_bwd");
+}
+int ttk_multi_copy(int n, const float* const* src, float* const* dst, const int64_t* count, ttk_stream_t stream) {
+  TTK_REQUIRE(n > 0 && n <= kMaxSeg && src && dst && count, "multi_copy: 1..32 segments");
+  CopySegs a{};
+  a.n = n;
+  long long total = 0;
+  for (int k = 0; k < n; ++k) {
+    TTK_REQUIRE(count[k] >= 0 && (dst[k] || count[k] == 0), "multi_copy: segment %d: null destination or negative count", k);
+    a.src[k] = src[k];
+    a.dst[k] = dst[k];
+    a.first[k] = total;
+    total += count[k];
+  }
+  a.first[n] = total;
+  if (total == 0) return 0;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(multi_copy_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  TTK_LAUNCH_CHECK("multi_copy");
+}
+static int fill_sum_terms(SumTerms& a, int n, const float* const* sample_w, const float* w, const int* count) {
+  a.n = n;
+  int total = 0;
+  for (int k = 0; k < n; ++k) {
+    if (count[k] < 0) return -1;
+    a.sw[k] = sample_w ? sample_w[k] : nullptr;
+    a.w[k] = w[k];
+    a.first[k] = total;
+    total += count[k];
+  }
+  a.first[n] = total;
+  return total;
+}
+int ttk_weighted_sum_fwd(int n, const float* const* val, const float* const* sample_w, const float* w, const int* count,
+                         float scale, float* out, ttk_stream_t stream) {
+  TTK_REQUIRE(n > 0 && n <= kMaxSeg && val && w && count && out, "weighted_sum_fwd: 1..32 terms");
+  SumTerms a{};
+  TTK_REQUIRE(fill_sum_terms(a, n, sample_w, w, count) >= 0, "weighted_sum_fwd: negative count");
+  for (int k = 0; k < n; ++k) {
+    TTK_REQUIRE(val[k] || count[k] == 0, "weighted_sum_fwd: term %d: null values", k);
+    a.val[k] = val[k];
+  }
+  hipLaunchKernelGGL(weighted_sum_fwd_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, scale, out);
+  TTK_LAUNCH_CHECK("weighted_sum_fwd");
+}
+int ttk_weighted_sum_bwd(int n, const float* gout, const float* const* sample_w, const float* w, const int* count, float scale,
+                         float* const* gval, ttk_stream_t stream) {
+  TTK_REQUIRE(n > 0 && n <= kMaxSeg && gout && w && count && gval, "weighted_sum_bwd: 1..32 terms");
+  SumTerms a{};
+  const int total = fill_sum_terms(a, n, sample_w, w, count);
+  TTK_REQUIRE(total >= 0, "weighted_sum_bwd: negative count");
+  for (int k = 0; k < n; ++k) {
+    TTK_REQUIRE(gval[k] || count[k] == 0, "weighted_sum_bwd: term %d: null gradient buffer", k);
+    a.gval[k] = gval[k];
+  }
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(weighted_sum_bwd_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, scale, gout);
+  TTK_LAUNCH_CHECK("weighted_sum_bwd");
 }
 int ttk_loss_points_fwd(const float* p, const float* t, int n, int dim, float chin, float eye, float* v, ttk_stream_t stream) {
   TTK_REQUIRE(p && t && v && n > 0 && (dim == 2 || dim == 3), "loss_points_fwd: bad arguments");

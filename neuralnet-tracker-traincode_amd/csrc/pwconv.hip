@@ -359,6 +359,8 @@ template <int MODE>
 bool launch_split_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
                        const float* bnE, float* part, int64_t M, int K, int Nout, void* wsplit, hipStream_t st);
 
+bool split_gemm_shape(int K, int Nout);
+
 bool launch_split_wgrad(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
                         int64_t M, int Cin, int Cout, hipStream_t st);
 
@@ -372,6 +374,7 @@ template <int MODE>
 static void launch_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
                         const float* bnE, float* part, int64_t M, int K, int Nout, void* wsplit, hipStream_t st) {
   if (use_split_gemm() && launch_split_gemm<MODE>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, wsplit, st)) return;
+  if (!Bm) Bm = static_cast<const float*>(wsplit);  // prepared operand of a shape that stays on the fp32 kernels
   const dim3 blk(kBlock);
   const unsigned gm = (unsigned)ceil_div(M, BM);
   if (Nout >= 128)
@@ -383,6 +386,51 @@ static void launch_gemm(const float* A0, const float* A1, const float* bnA, cons
     hipLaunchKernelGGL((pw_gemm_k<32, 4, 1, MODE>), dim3(gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
 }
 
+// ---- all pointwise layers' weight operands in one launch (ttk_pwconv_prepare_weights) -------------------------------
+constexpr int kPrepMax = 16;
+struct PrepArgs {
+  const float* w[kPrepMax];
+  unsigned char* out[kPrepMax];
+  int cin[kPrepMax], cout[kPrepMax];
+  int first_tile[kPrepMax + 1];  // 32x32 tiles of w, layer after layer
+  int split_fwd[kPrepMax], split_bwd[kPrepMax];
+  int n;
+};
+
+__device__ __forceinline__ void prep_store(unsigned char* region, bool split, int64_t idx, int64_t n, float x) {
+  if (split) {
+    uint16_t* q = reinterpret_cast<uint16_t*>(region);
+    const float r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+    const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    q[idx] = (uint16_t)(__float_as_uint(x) >> 16);
+    q[n + idx] = (uint16_t)(__float_as_uint(r1) >> 16);
+    q[2 * n + idx] = (uint16_t)(__float_as_uint(r2) >> 16);
+  } else {
+    reinterpret_cast<float*>(region)[idx] = x;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) pw_prepare_weights_k(PrepArgs a) {
+  __shared__ float t[32][33];
+  int l = 0;
+  while (l + 1 < a.n && (int)blockIdx.x >= a.first_tile[l + 1]) ++l;
+  const int tile = blockIdx.x - a.first_tile[l];
+  const int Cin = a.cin[l], Cout = a.cout[l];
+  const int tk = Cin / 32, r0 = (tile / tk) * 32, c0 = (tile % tk) * 32;  // r: output channel, c: input channel
+  const int64_t n = (int64_t)Cin * Cout;
+  const float* w = a.w[l];
+  unsigned char* fwd = a.out[l];
+  unsigned char* bwd = a.out[l] + 6 * n;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += kBlock / 32) {
+    const float x = w[(int64_t)(r0 + i) * Cin + c0 + tx];
+    t[i][tx] = x;
+    prep_store(fwd, a.split_fwd[l], (int64_t)(r0 + i) * Cin + c0 + tx, n, x);
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += kBlock / 32) prep_store(bwd, a.split_bwd[l], (int64_t)(c0 + i) * Cout + r0 + tx, n, t[tx][i]);
+}
+
 }  // namespace ttk
 
 using namespace ttk;
@@ -391,7 +439,7 @@ extern "C" {
 
 int ttk_pwconv1x1_fwd(const float* ydw, const float* bn_dw, const float* w, float* y, float* part, int64_t M, int Cin, int Cout,
                       void* wsplit, ttk_stream_t stream) {
-  TTK_REQUIRE(ydw && bn_dw && w && y, "pwconv1x1_fwd: null pointer");
+  TTK_REQUIRE(ydw && bn_dw && y && (w || wsplit), "pwconv1x1_fwd: null pointer");
   TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_fwd: unsupported shape M=%lld Cin=%d Cout=%d (channels: powers of two in 32..1024)", (long long)M, Cin, Cout);
   TTK_REQUIRE(ceil_div(M, BM) <= 65535, "pwconv1x1_fwd: M=%lld too large for one launch", (long long)M);
   launch_gemm<MODE_FWD>(ydw, nullptr, bn_dw, w, y, nullptr, nullptr, part, M, Cin, Cout, wsplit, (hipStream_t)stream);
@@ -401,7 +449,8 @@ int ttk_pwconv1x1_fwd(const float* ydw, const float* bn_dw, const float* w, floa
 int ttk_pwconv1x1_bwd_data(const float* g, const float* y, const float* bn_pw, const float* wt, const float* ydw,
                            const float* bn_dw, float* g_dw, float* part, int64_t M, int Cin, int Cout, void* wsplit,
                            ttk_stream_t stream) {
-  TTK_REQUIRE(g && y && bn_pw && wt && ydw && bn_dw && g_dw, "pwconv1x1_bwd_data: null pointer");
+  TTK_REQUIRE(g && y && bn_pw && (wt || wsplit) && ydw && bn_dw && g_dw, "pwconv1x1_bwd_data: null pointer");
+  if (!wt) wsplit = static_cast<unsigned char*>(wsplit) + (size_t)6 * Cin * Cout;  // data-gradient half of a prepared block
   TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_bwd_data: unsupported shape");
   TTK_REQUIRE(ceil_div(M, BM) <= 65535, "pwconv1x1_bwd_data: M too large for one launch");
   // contraction over Cout, output columns = Cin, B operand = wt[Cin][Cout]
@@ -440,6 +489,30 @@ int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* bn_pw,
   else TTK_WG(32, 32, 1, 1, 4);
 #undef TTK_WG
   TTK_LAUNCH_CHECK("pwconv1x1_bwd_weight");
+}
+
+size_t ttk_pwconv_prepared_bytes(int Cin, int Cout) { return (size_t)12 * Cin * Cout; }
+
+int ttk_pwconv_prepare_weights(int n, const float* const* w, const int* cin, const int* cout, void* const* prepared,
+                               ttk_stream_t stream) {
+  TTK_REQUIRE(n > 0 && n <= kPrepMax && w && cin && cout && prepared, "pwconv_prepare_weights: bad arguments (1..16 layers)");
+  PrepArgs a{};
+  a.n = n;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    TTK_REQUIRE(w[i] && prepared[i] && pw_shape_ok(1, cin[i], cout[i]), "pwconv_prepare_weights: layer %d: null pointer or unsupported shape", i);
+    a.w[i] = w[i];
+    a.out[i] = static_cast<unsigned char*>(prepared[i]);
+    a.cin[i] = cin[i];
+    a.cout[i] = cout[i];
+    a.first_tile[i] = tiles;
+    tiles += (cin[i] / 32) * (cout[i] / 32);
+    a.split_fwd[i] = use_split_gemm() && split_gemm_shape(cin[i], cout[i]);
+    a.split_bwd[i] = use_split_gemm() && split_gemm_shape(cout[i], cin[i]);
+  }
+  a.first_tile[n] = tiles;
+  hipLaunchKernelGGL(pw_prepare_weights_k, dim3(tiles), dim3(kBlock), 0, (hipStream_t)stream, a);
+  TTK_LAUNCH_CHECK("pwconv_prepare_weights");
 }
 
 int ttk_transpose(const float* in, float* out, int rows, int cols, ttk_stream_t stream) {

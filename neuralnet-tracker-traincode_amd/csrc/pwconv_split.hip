@@ -630,17 +630,22 @@ __global__ void split_weights_k(const float* __restrict__ w, uint16_t* __restric
   q[2 * n + i] = (uint16_t)(__float_as_uint(r2) >> 16);
 }
 
-// Returns true when the shape was handled here (and the kernel launched on `st`).
+// The [M][K] x [Nout][K]^T shapes that run on the split kernels (everything else: fp32 MFMA, pwconv.hip).
+bool split_gemm_shape(int K, int Nout) {
+  return K >= 128 && K % 32 == 0 && ((Nout >= 256 && Nout % 256 == 0) || Nout == 128);
+}
+
+// Returns true when the shape was handled here (and the kernel launched on `st`).  Bm == nullptr: wsplit already holds
+// the three planes (ttk_pwconv_prepare_weights).
 template <int MODE>
 bool launch_split_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
                        const float* bnE, float* part, int64_t M, int K, int Nout, void* wsplit, hipStream_t st) {
   constexpr int AM = MODE == SMODE_FWD ? AMODE_BNRELU : AMODE_BNGRAD, EM = MODE == SMODE_FWD ? EMODE_STATS : EMODE_MASK;
-  if (K < 128 || K % 32 != 0 || !wsplit) return false;
-  if (!((Nout >= 256 && Nout % 256 == 0) || (Nout == 128 && K >= 128))) return false;
+  if (!wsplit || !split_gemm_shape(K, Nout)) return false;
   const ConvGeom none{};
   uint16_t* Bq = reinterpret_cast<uint16_t*>(wsplit);
   const int64_t nw = (int64_t)Nout * K;
-  hipLaunchKernelGGL(split_weights_k, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, st, Bm, Bq, nw);
+  if (Bm) hipLaunchKernelGGL(split_weights_k, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, st, Bm, Bq, nw);
   if (Nout >= 256 && Nout % 256 == 0) {
     const unsigned tiles = (unsigned)(ceil_div(M, 128) * (Nout / 256));
     hipLaunchKernelGGL((pw_split_k<128, 256, AM, EM, false>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, out, E0, bnE, part, M, K,

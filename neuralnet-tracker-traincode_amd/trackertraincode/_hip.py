@@ -29,6 +29,7 @@ _SIGNATURES = {
     "ttk_pwconv1x1_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
     "ttk_pwconv1x1_bwd_data": [_P] * 8 + [_L, _I, _I, _P],
     "ttk_pwconv1x1_bwd_weight": [_P] * 6 + [_L, _I, _I],
+    "ttk_pwconv_prepare_weights": [_I, _P, _P, _P, _P],
     "ttk_transpose": [_P, _P, _I, _I],
     "ttk_avgpool_fwd": [_P, _P, _P, _P, _I, _I, _I],
     "ttk_avgpool_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
@@ -59,6 +60,11 @@ _SIGNATURES = {
     "ttk_loss_quatreg_bwd": [_P, _P, _I, _P],
     "ttk_loss_mse_rows_fwd": [_P, _P, _I, _I, _P],
     "ttk_loss_mse_rows_bwd": [_P, _P, _P, _I, _I, _P],
+    "ttk_loss_mse_cols_fwd": [_P, _P, _I, _I, _I, _I, _P],
+    "ttk_loss_mse_cols_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "ttk_multi_copy": [_I, _P, _P, _P],
+    "ttk_weighted_sum_fwd": [_I, _P, _P, _P, _P, _F, _P],
+    "ttk_weighted_sum_bwd": [_I, _P, _P, _P, _P, _F, _P],
     "ttk_loss_points_fwd": [_P, _P, _I, _I, _F, _F, _P],
     "ttk_loss_points_bwd": [_P, _P, _P, _I, _I, _F, _F, _P],
     "ttk_loss_nllrot_fwd": [_P, _P, _P, _I, _P],
@@ -76,7 +82,7 @@ _SIGNATURES = {
     "ttk_clip_adam": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _F, _F, _F, _F, _F, _P, _P, _P],
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class _Library:
@@ -97,6 +103,7 @@ class _Library:
             fn = getattr(self.cdll, name)
             fn.argtypes, fn.restype = [c_int64], c_int
         self.cdll.ttk_heads_num_rows.argtypes, self.cdll.ttk_heads_num_rows.restype = [c_int, c_int, c_int], c_int
+        self.cdll.ttk_pwconv_prepared_bytes.argtypes, self.cdll.ttk_pwconv_prepared_bytes.restype = [c_int, c_int], ctypes.c_size_t
         self.cdll.ttk_partial_rows_dwconv.argtypes, self.cdll.ttk_partial_rows_dwconv.restype = [c_int] * 6, c_int
         self._fns = {}
         for name, sig in _SIGNATURES.items():
@@ -111,6 +118,30 @@ class _Library:
         if rc != 0:
             msg = self.cdll.ttk_last_error_string().decode(errors="replace")
             raise RuntimeError(f"{name} failed (code {rc}): {msg}")
+
+    def pwconv_prepared_bytes(self, cin: int, cout: int) -> int:
+        return self.cdll.ttk_pwconv_prepared_bytes(cin, cout)
+
+    def pwconv_prepare_weights(self, weights, prepared):
+        """One launch: forward and data-gradient weight operands of every pointwise layer (`weights[i]`: [Cout, Cin(,1,1)]
+        fp32, `prepared[i]`: uint8 scratch of pwconv_prepared_bytes)."""
+        n = len(weights)
+        wp = (c_void_p * n)(*[ptr(w) for w in weights])
+        pp = (c_void_p * n)(*[ptr(q) for q in prepared])
+        ci = (c_int * n)(*[int(w.shape[1]) for w in weights])
+        co = (c_int * n)(*[int(w.shape[0]) for w in weights])
+        self.call("ttk_pwconv_prepare_weights", n, wp, ci, co, pp)
+
+    def multi_copy(self, srcs, dsts):
+        """dsts[k].copy_(srcs[k]) (None: zero fill) for up to 32 contiguous float32 tensors per launch."""
+        for i in range(0, len(dsts), 32):
+            s, d = srcs[i:i + 32], dsts[i:i + 32]
+            n = len(d)
+            for a, b in zip(s, d):
+                if b.dtype != torch.float32 or not b.is_contiguous() or (a is not None and (a.dtype != torch.float32 or not a.is_contiguous() or a.numel() != b.numel())):
+                    raise RuntimeError("multi_copy: contiguous float32 tensors of matching sizes expected")
+            self.call("ttk_multi_copy", n, (c_void_p * n)(*[ptr(a) for a in s]), (c_void_p * n)(*[ptr(b) for b in d]),
+                      (c_int64 * n)(*[b.numel() for b in d]))
 
     def partial_rows_elementwise(self, items: int) -> int:
         return self.cdll.ttk_partial_rows_elementwise(items)

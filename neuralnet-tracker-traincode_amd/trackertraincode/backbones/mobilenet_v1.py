@@ -107,7 +107,7 @@ def _part_buffer(B, H, W, device):
 
 class _Ctx:
     """Everything one forward pass leaves behind for its backward."""
-    __slots__ = ("x", "stages", "a_in", "part", "dims", "pool_skip", "wparams", "HW", "B")
+    __slots__ = ("x", "stages", "a_in", "part", "dims", "pool_skip", "wparams", "HW", "B", "prep")
 
 
 def _forward_impl(x, params, buffers, momentum, eps, training):
@@ -133,6 +133,12 @@ def _forward_impl(x, params, buffers, momentum, eps, training):
             L.call("ttk_bn_eval_prepare", p(gamma), p(beta), p(rm), p(rv), float(eps), C, p(bn))
 
     part_arg = p(part) if training else None
+    # forward and data-gradient weight operands of all 13 pointwise convs, one launch
+    w_pws = [params[3 + 6 * k + 3] for k in range(len(_BLOCKS))]
+    sizes = [L.pwconv_prepared_bytes(cin, cout) for _, cin, cout, _ in _BLOCKS]
+    pool = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+    ctx.prep = list(torch.split(pool, sizes))
+    L.pwconv_prepare_weights(w_pws, ctx.prep)
     # ---- stem (reference :122-126,161-163)
     y0 = torch.empty((B, Ho, Wo, 32), dtype=torch.float32, device=dev)
     L.call("ttk_stem_fwd", p(x), p(params[0]), p(y0), part_arg, B, H, W)
@@ -155,8 +161,7 @@ def _forward_impl(x, params, buffers, momentum, eps, training):
         finalize(bn_dw, L.partial_rows_dwconv(B, h, w_, cin, stride, False), cin, B * ho * wo, g_dw, b_dw, bi)
         ypw = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=dev)
         M = B * ho * wo
-        wq = torch.empty(3 * cout * cin, dtype=torch.int16, device=dev)  # scratch: pre-split weight operand
-        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), p(w_pw), p(ypw), part_arg, M, cin, cout, p(wq))
+        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(ypw), part_arg, M, cin, cout, p(ctx.prep[len(ctx.dims)]))
         bn_pw = _bn_work(cout, dev)
         finalize(bn_pw, L.partial_rows_gemm(M), cout, M, g_pw, b_pw, bi + 1)
         bi += 2
@@ -194,17 +199,20 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
     L = _hip.lib()
     p = _hip.ptr
     B, part = ctx.B, ctx.part
-    grads = [None] * len(params)
+    # one zeroed arena for every parameter gradient (the weight-gradient kernels accumulate atomically): one fill launch
+    offs, total = [], 0
+    for q in params:
+        offs.append(total)
+        total += (q.numel() + 63) // 64 * 64
+    arena = torch.zeros(total, dtype=torch.float32, device=gfeat.device)
+    grads = [arena[o:o + q.numel()].view(q.shape) for o, q in zip(offs, params)]
     last = ctx.stages[-1]
     C = last.y.shape[-1]
 
     def bwd_finalize(stage: _Stage, rows, count, gi):
         """BatchNorm backward constants of `stage` + its dgamma/dbeta -> grads[gi], grads[gi+1]"""
         Cc = stage.y.shape[-1]
-        dgamma = torch.empty(Cc, dtype=torch.float32, device=gfeat.device)
-        dbeta = torch.empty(Cc, dtype=torch.float32, device=gfeat.device)
-        L.call("ttk_bn_bwd_finalize", p(part), rows, Cc, count, p(params[gi]), p(stage.bn), p(dgamma), p(dbeta), 0)
-        grads[gi], grads[gi + 1] = dgamma, dbeta
+        L.call("ttk_bn_bwd_finalize", p(part), rows, Cc, count, p(params[gi]), p(stage.bn), p(grads[gi]), p(grads[gi + 1]), 0)
 
     main = torch.cuda.current_stream(gfeat.device)
     side = _side_stream(gfeat.device) if _USE_WGRAD_STREAM else None
@@ -224,7 +232,7 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         # -- pointwise: weight gradient, then data gradient (+ bn_dw backward sums).  The weight gradient has no
         # consumer inside backward, so it runs on a second HIP stream next to the data-gradient chain: its
         # tail (too few tiles left for 256 CUs) and the HBM-bound depthwise kernels fill each other's gaps.
-        dW = torch.zeros_like(w_pw)
+        dW = grads[pi + 3]
         if side is not None:
             ev = torch.cuda.Event()
             ev.record(main)  # g, bn_pw backward constants and the zeroed dW are ready
@@ -237,20 +245,15 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
             keep.append(g)  # main must not recycle g's memory while the side stream still reads it
         else:
             L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW), M, cin, cout)
-        grads[pi + 3] = dW
-        wt = torch.empty((cin, cout), dtype=torch.float32, device=g.device)
-        L.call("ttk_transpose", p(w_pw), p(wt), cout, cin)
         g_dw = torch.empty_like(st_dw.y)
-        wq = torch.empty(3 * cout * cin, dtype=torch.int16, device=g.device)  # scratch: pre-split weight operand
-        L.call("ttk_pwconv1x1_bwd_data", p(g), p(st_pw.y), p(st_pw.bn), p(wt), p(st_dw.y), p(st_dw.bn), p(g_dw), p(part), M,
-               cin, cout, p(wq))
+        L.call("ttk_pwconv1x1_bwd_data", p(g), p(st_pw.y), p(st_pw.bn), None, p(st_dw.y), p(st_dw.bn), p(g_dw), p(part), M,
+               cin, cout, p(ctx.prep[k]))
         bwd_finalize(st_dw, L.partial_rows_gemm(M), M, pi + 1)
         # -- depthwise: weight gradient, then data gradient (+ residual gradient, + producer's bn sums)
-        dWd = torch.empty_like(w_dw)  # filled by the fused weight-gradient path of bwd_data
-        grads[pi] = dWd
+        dWd = grads[pi]  # accumulated by the fused weight-gradient path of bwd_data
         g_prev = torch.empty_like(st_prev.y)
         L.call("ttk_dwconv3x3_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), p(g) if has_skip else None, p(st_prev.y),
-               p(st_prev.bn), p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 0, B, h, w_, cin, stride)
+               p(st_prev.bn), p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 1, B, h, w_, cin, stride)
         bwd_finalize(st_prev, L.partial_rows_dwconv(B, h, w_, cin, stride, True), B * h * w_, pi - 2 if k > 0 else 1)
         g = g_prev
         if grad_ready_hook is not None:  # this block's conv + bn_dw gradients and its own bn_sep gradients are final
@@ -258,10 +261,8 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
                 main.wait_event(done)
             grad_ready_hook([(params[i], grads[i]) for i in range(pi, pi + 6)])
     st0 = ctx.stages[0]
-    dW1 = torch.empty_like(params[0])
     _, _, H, W = ctx.x.shape
-    L.call("ttk_stem_bwd_weight", p(g), p(st0.y), p(st0.bn), p(ctx.x), p(dW1), 0, B, H, W)
-    grads[0] = dW1
+    L.call("ttk_stem_bwd_weight", p(g), p(st0.y), p(st0.bn), p(ctx.x), p(grads[0]), 1, B, H, W)
     if grad_ready_hook is not None:
         grad_ready_hook([(params[i], grads[i]) for i in range(3)])
     if side is not None:

@@ -33,10 +33,12 @@ class HeadsFn(Function):
         feat = _f32c(feat)
         B, F = feat.shape
         ws, bs = [_f32c(w) for w in lin[0::2]], [_f32c(b) for b in lin[1::2]]
-        wcat, bcat = torch.cat(ws, dim=0), torch.cat(bs, dim=0)
-        NZ = wcat.shape[0]
         dev = feat.device
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        rows = [w.shape[0] for w in ws]
+        NZ = sum(rows)
+        wcat, bcat = new(NZ, F), new(NZ)  # all heads' weights / biases stacked, one launch
+        _hip.lib().multi_copy(ws + bs, list(torch.split(wcat, rows)) + list(torch.split(bcat, rows)))
         z, roi, coord = new(B, NZ), new(B, 4), new(B, 3)
         rot, qu = (new(B, 3, 3), new(B, 6)) if rot6d else (new(B, 4), new(B, 4))  # 6D head: matrices + raw 6D features
         Lc, Lr = (new(B, 3, 3), new(B, 3, 3)) if unc else (None, None)
@@ -227,6 +229,116 @@ class MseRowsFn(Function):
         gp = torch.empty_like(p)
         _call("ttk_loss_mse_rows_bwd", _p(p), _p(t), _p(_f32c(gv)), p.shape[0], p.shape[1], _p(gp))
         return gp.view(ctx.shape), None
+
+
+class MseColsFn(Function):
+    """MseRowsFn of p[:, c0:c0+nc] against t[:, c0:c0+nc] for p, t: [n, Dt], without materialising the column slices
+    (and their slice-backward fill/copy/accumulate kernels): the gradient comes back for the whole of p."""
+
+    @staticmethod
+    def forward(ctx, p, t, c0, nc):
+        p, t = _f32c(p), _f32c(t)
+        n, Dt = p.shape
+        v = _vec(n, p)
+        _call("ttk_loss_mse_cols_fwd", _p(p), _p(t), n, Dt, int(c0), int(nc), _p(v))
+        ctx.save_for_backward(p, t)
+        ctx.cols = (int(c0), int(nc))
+        return v
+
+    @staticmethod
+    def backward(ctx, gv):
+        p, t = ctx.saved_tensors
+        gp = torch.empty_like(p)
+        _call("ttk_loss_mse_cols_bwd", _p(p), _p(t), _p(_f32c(gv)), p.shape[0], p.shape[1], *ctx.cols, _p(gp))
+        return gp, None, None, None
+
+
+def mse_cols(p, t, c0, nc):
+    """mean((p[..., c0:c0+nc] - t[..., c0:c0+nc])**2, -1) per sample."""
+    if p.dim() == 2 and t.shape == p.shape:
+        return MseColsFn.apply(p, t, c0, nc)
+    sl = slice(c0, c0 + nc) if nc > 1 else c0
+    return MseRowsFn.apply(p[..., sl], t[..., sl])
+
+
+class SplitRowsFn(Function):
+    """Row ranges (one per sub-batch) of several prediction tensors as views; backward assembles the gradient of every
+    tensor with one launch, where autograd's slice nodes take a fill, a copy and an accumulation per slice."""
+
+    @staticmethod
+    def forward(ctx, sizes, *tensors):
+        ctx.set_materialize_grads(False)
+        ctx.sizes = tuple(int(n) for n in sizes)
+        ctx.like = [(t.shape, t.device) for t in tensors]
+        outs = []
+        for t in tensors:
+            off = 0
+            for n in ctx.sizes:
+                outs.append(t.narrow(0, off, n))
+                off += n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        k = len(ctx.sizes)
+        used = [j for j in range(len(ctx.like)) if any(g is not None for g in gs[j * k:(j + 1) * k])]
+        if not used:
+            return (None,) * (1 + len(ctx.like))
+        dev = ctx.like[used[0]][1]
+        numels = [int(torch.Size(ctx.like[j][0]).numel()) for j in used]
+        flat = torch.empty(sum(numels), dtype=torch.float32, device=dev)
+        fulls = [f.view(ctx.like[j][0]) for f, j in zip(torch.split(flat, numels), used)]
+        srcs, dsts = [], []
+        for full, j in zip(fulls, used):
+            off = 0
+            for i, n in enumerate(ctx.sizes):
+                g = gs[j * k + i]
+                srcs.append(None if g is None else _f32c(g))
+                dsts.append(full.narrow(0, off, n))
+                off += n
+        _hip.lib().multi_copy(srcs, dsts)
+        out = [None] * len(ctx.like)
+        for full, j in zip(fulls, used):
+            out[j] = full
+        return (None, *out)
+
+
+class WeightedSumFn(Function):
+    """scale * sum_k w_k * sum_i sample_w_k[i] * val_k[i] (the loss sum of train.default_compute_loss) - one launch
+    forward, one backward, instead of a fill/mul per term plus concatenations and a reduction."""
+
+    @staticmethod
+    def forward(ctx, scalars, sample_ws, scale, *vals):
+        from ctypes import c_float, c_int, c_void_p
+        vals = [_f32c(v).reshape(-1) for v in vals]
+        sws = [None if s is None else _f32c(s).reshape(-1) for s in sample_ws]
+        for v, s in zip(vals, sws):
+            if s is not None and s.numel() != v.numel():
+                raise RuntimeError("per-sample weights and loss values differ in length")
+        dev = vals[0].device
+        chunks = [(i, min(i + 32, len(vals))) for i in range(0, len(vals), 32)]
+        parts = torch.empty(len(chunks), dtype=torch.float32, device=dev)
+        for c, (a, b) in enumerate(chunks):
+            n = b - a
+            _call("ttk_weighted_sum_fwd", n, (c_void_p * n)(*[_p(v) for v in vals[a:b]]), (c_void_p * n)(*[_p(s) for s in sws[a:b]]),
+                  (c_float * n)(*[float(w) for w in scalars[a:b]]), (c_int * n)(*[v.numel() for v in vals[a:b]]), float(scale),
+                  _p(parts[c:c + 1]))
+        ctx.meta = (list(map(float, scalars)), sws, float(scale), [v.shape for v in vals], chunks)
+        return parts[0] if len(chunks) == 1 else parts.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        from ctypes import c_float, c_int, c_void_p
+        scalars, sws, scale, shapes, chunks = ctx.meta
+        g = _f32c(g).reshape(1)
+        counts = [int(s.numel()) for s in shapes]
+        flat = torch.empty(sum(counts), dtype=torch.float32, device=g.device)
+        gvals = list(torch.split(flat, counts))
+        for a, b in chunks:
+            n = b - a
+            _call("ttk_weighted_sum_bwd", n, _p(g), (c_void_p * n)(*[_p(s) for s in sws[a:b]]), (c_float * n)(*scalars[a:b]),
+                  (c_int * n)(*counts[a:b]), scale, (c_void_p * n)(*[_p(x) for x in gvals[a:b]]))
+        return (None, None, None, *gvals)
 
 
 class PointsLossFn(Function):

@@ -48,7 +48,7 @@ class PoseSizeLoss:
         self._prefix = prefix
 
     def __call__(self, pred, sample):
-        return _hipops.MseRowsFn.apply(pred[self._prefix + "coord"][..., 2], sample["coord"][..., 2])
+        return _hipops.mse_cols(pred[self._prefix + "coord"], sample["coord"], 2, 1)
 
 
 class PoseXYLoss:
@@ -57,7 +57,7 @@ class PoseXYLoss:
         self._prefix = prefix
 
     def __call__(self, pred, sample):
-        return _hipops.MseRowsFn.apply(pred[self._prefix + "coord"][..., :2], sample["coord"][..., :2])
+        return _hipops.mse_cols(pred[self._prefix + "coord"], sample["coord"], 0, 2)
 
 
 class ShapeParameterLoss:

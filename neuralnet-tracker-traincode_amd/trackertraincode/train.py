@@ -38,13 +38,91 @@ class LossVal(NamedTuple):
     name: str
 
 
+class SampleWeight:
+    """Per-sample weight of one loss term, `scalar * dataset_weight` (or the scalar broadcast over the sub-batch) -
+    what the reference stores as a tensor in `LossVal.weight` after default_compute_loss (:404-412).  The tensor is
+    only built when something reads it (`.tensor()`, or arithmetic with a tensor): the training step itself feeds
+    (scalar, per_sample) to one fused weighted-sum kernel instead of launching a fill or multiply per term."""
+
+    __slots__ = ("scalar", "per_sample", "_like", "_t")
+
+    def __init__(self, scalar: float, per_sample: Tensor | None, like: Tensor):
+        self.scalar, self.per_sample, self._like, self._t = float(scalar), per_sample, like, None
+
+    def tensor(self) -> Tensor:
+        if self._t is None:
+            like = self._like
+            self._t = like.new_full(like.shape, self.scalar) if self.per_sample is None else self.scalar * self.per_sample
+        return self._t
+
+    def __mul__(self, other):
+        return self.tensor() * other
+
+    __rmul__ = __mul__
+
+    @property
+    def shape(self):
+        return self._like.shape
+
+
+def _as_weight_tensor(w):
+    return w.tensor() if isinstance(w, SampleWeight) else w
+
+
+def _concat_groups(groups: dict):
+    """{name: [1-D tensors]} -> {name: concatenation}; on the GPU all groups land in one buffer with one launch."""
+    flat = [t for ts in groups.values() for t in ts]
+    if not flat or not all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 1 and not t.requires_grad for t in flat):
+        return {k: torch.concat(ts) for k, ts in groups.items()}
+    flat = [t.contiguous() for t in flat]
+    buf = torch.empty(sum(t.numel() for t in flat), dtype=torch.float32, device=flat[0].device)
+    _hip.lib().multi_copy(flat, list(torch.split(buf, [t.numel() for t in flat])))
+    return dict(zip(groups.keys(), torch.split(buf, [sum(t.numel() for t in ts) for ts in groups.values()])))
+
+
 def concatenated_lossvals_by_name(vals):
     """{name: (values, weights)} concatenated over sub-batches, first-seen order (reference :47-62)."""
     values, weights = defaultdict(list), defaultdict(list)
     for v in vals:
         values[v.name].append(v.val)
-        weights[v.name].append(v.weight)
-    return {k: (torch.concat(values[k]), torch.concat(weights[k])) for k in values}
+        weights[v.name].append(_as_weight_tensor(v.weight))
+    values = _concat_groups(values)
+    return {k: (values[k], torch.concat(weights[k])) for k in values}
+
+
+def concatenated_values_by_name(vals):
+    """{name: values} only - what the training step logs (no weight tensors are built)."""
+    values = defaultdict(list)
+    for v in vals:
+        values[v.name].append(v.val)
+    return _concat_groups(values)
+
+
+def _split_predictions(preds: dict, sizes):
+    """Per sub-batch {key: rows of preds[key]}.  float32 GPU tensors (and the rotation containers around them) are
+    split by ONE autograd node whose backward assembles all gradients with a single launch."""
+    from .neuralnets import _hipops
+
+    def tensor_of(v):
+        t = v if isinstance(v, Tensor) else getattr(v, "value", None)
+        ok = isinstance(t, Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() >= 1
+        return t if ok else None
+
+    fused = {k: tensor_of(v) for k, v in preds.items()}
+    fused = {k: t for k, t in fused.items() if t is not None}
+    pieces = _hipops.SplitRowsFn.apply(tuple(sizes), *fused.values()) if fused else ()
+    out, offset = [], 0
+    for i, n in enumerate(sizes):
+        sub = {}
+        for k, v in preds.items():
+            if k in fused:
+                piece = pieces[list(fused).index(k) * len(sizes) + i]
+                sub[k] = piece if isinstance(v, Tensor) else type(v)(piece)
+            else:
+                sub[k] = v[offset:offset + n, ...]
+        out.append(sub)
+        offset += n
+    return out
 
 
 def _weight_at(w, step):
@@ -79,24 +157,26 @@ def default_compute_loss(preds: dict, batch: List[Batch], current_epoch: int, lo
     Sub-batches are addressed by integer offsets into the concatenated predictions; weights become
     per-sample tensors (scaled by `dataset_weight` when the sub-batch has one); the sum is divided by
     the TOTAL batch size so that a loss a sub-batch does not have counts as zero."""
+    from .neuralnets import _hipops
+
     all_lossvals: list[list[LossVal]] = []
-    offset = 0
-    for subset in batch:
-        (n,) = subset.meta.prefixshape
-        subpreds = {k: v[offset:offset + n, ...] for k, v in preds.items()}
+    sizes = [subset.meta.prefixshape[0] for subset in batch]
+    for subset, subpreds in zip(batch, _split_predictions(preds, sizes)):
         crit = loss[subset.meta.tag] if isinstance(loss, dict) else loss
         terms = crit.evaluate(subpreds, subset, current_epoch)
+        dw = None
         if "dataset_weight" in subset:
             dw = subset["dataset_weight"]
             assert dw.size(0) == subset.meta.batchsize
-            terms = [v._replace(weight=v.weight * dw) for v in terms]
-        else:
-            terms = [v._replace(weight=v.val.new_full(v.val.shape, v.weight)) for v in terms]
-        all_lossvals.append(terms)
-        offset += n
+        all_lossvals.append([v._replace(weight=SampleWeight(v.weight, dw, v.val)) for v in terms])
     batchsize = sum(subset.meta.batchsize for subset in batch)
-    by_name = concatenated_lossvals_by_name(itertools.chain.from_iterable(all_lossvals))
-    loss_sum = torch.concat([v * w for v, w in by_name.values()]).sum() / batchsize
+    flat = list(itertools.chain.from_iterable(all_lossvals))
+    if flat and all(v.val.is_cuda and v.val.dtype == torch.float32 for v in flat):
+        loss_sum = _hipops.WeightedSumFn.apply([v.weight.scalar for v in flat], [v.weight.per_sample for v in flat], 1.0 / batchsize,
+                                               *[v.val for v in flat])
+    else:  # host-side logic on CPU tensors (tests); the reference's formula
+        by_name = concatenated_lossvals_by_name(flat)
+        loss_sum = torch.concat([v * w for v, w in by_name.values()]).sum() / batchsize
     all_lossvals = [[v._replace(val=v.val.detach()) for v in terms] for terms in all_lossvals]
     return loss_sum, all_lossvals
 
@@ -287,7 +367,7 @@ def training_step(model: nn.Module, batches: List[Batch], epoch: int, criterions
     ids = torch.concat([b["coord_convention_id"] for b in batches], dim=0)
     preds = model(inputs, ids)
     loss_sum, all_lossvals = default_compute_loss(preds, batches, epoch, criterions)
-    by_name = {k: v for k, (v, _) in concatenated_lossvals_by_name(itertools.chain.from_iterable(all_lossvals)).items()}
+    by_name = concatenated_values_by_name(itertools.chain.from_iterable(all_lossvals))
     return {"loss": loss_sum, "mt_losses": by_name}
 
 

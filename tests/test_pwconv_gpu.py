@@ -108,3 +108,36 @@ def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout):
     e_hip, e_f32 = _rel(dW.cpu().numpy(), dw64), _rel(dw32, dw64)
     print(f"wgrad M={M} Cout={Cout} Cin={Cin}: hip {e_hip:.2e}  fp32 chain {e_f32:.2e}")
     assert e_hip <= 1.5 * e_f32 + 1e-7, (e_hip, e_f32)
+
+
+def test_prepared_weights_match_per_call_split():
+    """ttk_pwconv_prepare_weights (all layers, one launch) feeds the same kernels the same operand bits as the
+    per-call split/transposition: outputs are bit-identical."""
+    import trackertraincode._hip as H
+    L, p = H.lib(), H.ptr
+    dev = "cuda"
+    shapes = [(648, 512, 512), (1234, 32, 64), (777, 256, 128), (300, 1024, 1024), (5000, 128, 128), (900, 64, 128)]
+    rng = np.random.default_rng(5)
+    ws = [torch.from_numpy((rng.normal(0, 1, (co, ci, 1, 1)) * np.sqrt(2.0 / co)).astype(np.float32)).to(dev) for _, ci, co in shapes]
+    prep = [torch.empty(L.pwconv_prepared_bytes(ci, co), dtype=torch.uint8, device=dev) for _, ci, co in shapes]
+    L.pwconv_prepare_weights(ws, prep)
+    for (M, Cin, Cout), w, q in zip(shapes, ws, prep):
+        ydw = torch.from_numpy(rng.normal(0, 1, (M, Cin)).astype(np.float32)).to(dev)
+        g = torch.from_numpy(rng.normal(0, 1, (M, Cout)).astype(np.float32)).to(dev)
+        bn_dw, bn_pw = torch.from_numpy(_bn_block(Cin, rng)).to(dev), torch.from_numpy(_bn_block(Cout, rng)).to(dev)
+        rows = L.partial_rows_gemm(M)
+        wq = torch.empty(3 * Cout * Cin, dtype=torch.int16, device=dev)
+        wt = w.reshape(Cout, Cin).t().contiguous()
+        out = []
+        for prepared in (False, True):
+            y, part = torch.empty(M, Cout, device=dev), torch.zeros(rows, 2, Cout, device=dev)
+            L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None if prepared else p(w), p(y), p(part), M, Cin, Cout, p(q if prepared else wq))
+            gd, part2 = torch.empty(M, Cin, device=dev), torch.zeros(rows, 2, Cin, device=dev)
+            L.call("ttk_pwconv1x1_bwd_data", p(g), p(y), p(bn_pw), None if prepared else p(wt), p(ydw), p(bn_dw), p(gd), p(part2), M, Cin, Cout,
+                   p(q if prepared else wq))
+            torch.cuda.synchronize()
+            out.append((y, part, gd, part2))
+        for a, b in zip(*out):
+            assert torch.equal(a, b), (M, Cin, Cout)
+    with pytest.raises(RuntimeError, match="null pointer"):
+        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(y), None, M, Cin, Cout, None)
