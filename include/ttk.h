@@ -171,7 +171,7 @@ int ttk_bn_act(const float* y, const float* bn, const float* skip, float* a, int
  * torchvision.models.resnet.BasicBlock/conv3x3/conv1x1, an un-vendored dependency of the reference) as implicit
  * GEMMs on the matrix cores.  Channels-last activations a[B][H][W][C] that are already post-BatchNorm/ReLU
  * ("materialised"); k in {1,3}, stride in {1,2}, pad = k/2; Cin % 32 == 0, Cout % 64 == 0.
- *   ttk_conv_weight_repack  w[Cout][Cin][KH][KW] -> w_fwd[3][KH*KW][Cout][Cin], w_bwd[3][KH*KW][Cin][Cout] (either may be
+ *   ttk_conv_weight_repack  w[Cout][Cin][KH][KW] -> w_fwd[3][KH*KW*Cin/32][Cout][32], w_bwd[3][KH*KW*Cout/32][Cin][32] (either may be
  *                           NULL): 16-bit piece planes (h, m, l) of the exact 3-way bf16 split of every weight, i.e.
  *                           3 * 2 bytes per element - the form the GEMM producers move without arithmetic
  *   ttk_conv_fwd            y[B][Ho][Wo][Cout] raw conv output + part[ttk_partial_rows_gemm(B*Ho*Wo)][2][Cout]

@@ -21,12 +21,13 @@ __global__ void conv_weight_repack_k(const float* __restrict__ w, uint16_t* __re
   const float r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
   const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
   const uint16_t h = (uint16_t)(__float_as_uint(x) >> 16), m = (uint16_t)(__float_as_uint(r1) >> 16), l = (uint16_t)(__float_as_uint(r2) >> 16);
-  if (wf) {
-    const size_t o = ((size_t)t * Cout + co) * Cin + ci;
+  // planes [K/32][N][32] (pw_split_k's B layout), K = (tap, channel) with the channel fastest
+  if (wf) {  // forward: N = Cout, K = (t, ci)
+    const size_t o = ((size_t)(t * (Cin >> 5) + (ci >> 5)) * Cout + co) * 32 + (ci & 31);
     wf[o] = h; wf[n + o] = m; wf[2 * n + o] = l;
   }
-  if (wb) {
-    const size_t o = ((size_t)t * Cin + ci) * Cout + co;
+  if (wb) {  // data gradient: N = Cin, K = (t, co)
+    const size_t o = ((size_t)(t * (Cout >> 5) + (co >> 5)) * Cin + ci) * 32 + (co & 31);
     wb[o] = h; wb[n + o] = m; wb[2 * n + o] = l;
   }
 }

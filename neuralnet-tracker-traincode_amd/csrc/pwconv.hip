@@ -397,16 +397,19 @@ struct PrepArgs {
   int n;
 };
 
-__device__ __forceinline__ void prep_store(unsigned char* region, bool split, int64_t idx, int64_t n, float x) {
+// element (row, k) of a [rows][K] operand: fp32 in place, or the three bf16 planes in pw_split_k's [K/32][rows][32] order
+__device__ __forceinline__ void prep_store(unsigned char* region, bool split, int row, int k, int rows, int K, float x) {
+  const int64_t n = (int64_t)rows * K;
   if (split) {
     uint16_t* q = reinterpret_cast<uint16_t*>(region);
+    const int64_t idx = ((int64_t)(k >> 5) * rows + row) * 32 + (k & 31);
     const float r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
     const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
     q[idx] = (uint16_t)(__float_as_uint(x) >> 16);
     q[n + idx] = (uint16_t)(__float_as_uint(r1) >> 16);
     q[2 * n + idx] = (uint16_t)(__float_as_uint(r2) >> 16);
   } else {
-    reinterpret_cast<float*>(region)[idx] = x;
+    reinterpret_cast<float*>(region)[(int64_t)row * K + k] = x;
   }
 }
 
@@ -425,10 +428,10 @@ __global__ void __launch_bounds__(kBlock) pw_prepare_weights_k(PrepArgs a) {
   for (int i = ty; i < 32; i += kBlock / 32) {
     const float x = w[(int64_t)(r0 + i) * Cin + c0 + tx];
     t[i][tx] = x;
-    prep_store(fwd, a.split_fwd[l], (int64_t)(r0 + i) * Cin + c0 + tx, n, x);
+    prep_store(fwd, a.split_fwd[l], r0 + i, c0 + tx, Cout, Cin, x);
   }
   __syncthreads();
-  for (int i = ty; i < 32; i += kBlock / 32) prep_store(bwd, a.split_bwd[l], (int64_t)(c0 + i) * Cout + r0 + tx, n, t[tx][i]);
+  for (int i = ty; i < 32; i += kBlock / 32) prep_store(bwd, a.split_bwd[l], c0 + i, r0 + tx, Cin, Cout, t[tx][i]);
 }
 
 }  // namespace ttk

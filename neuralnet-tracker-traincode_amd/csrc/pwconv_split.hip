@@ -185,10 +185,13 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
         gbase[i] = row < M ? n * geo.Hs * geo.Ws : -1;
       }
     }
-    // B arrives already split (launch_*: split_weights_k / conv_weight_repack_k): three bf16 planes [tap][Nout][Kc]
+    // B arrives already split (launch_*: split_weights_k / conv_weight_repack_k / pw_prepare_weights_k): three bf16
+    // planes [K/32][Nout][32] - the 64 bytes a row contributes to one k32 step are contiguous and rows follow each
+    // other, so every wave-wide 16-byte load reads ONE contiguous KB (whole cache lines; a [Nout][K] plane gave each
+    // load sixteen half-used lines whose other halves had left the L1 by the next step).
     const int brow = pt >> 2, bc4 = pt & 3;
-    const uint16_t* bp = Bq + (int64_t)(n0 + brow) * Kc + bc4 * 8;
-    const int64_t bplane = (int64_t)(K / Kc) * Nout * Kc;
+    const uint16_t* bp = Bq + (int64_t)(n0 + brow) * 32 + bc4 * 8;
+    const int64_t bplane = (int64_t)K * Nout;
     unsigned char* wbase_b = lds + (bc4 >> 1) * kStageStride + 3 * APL;
     const float* cp = bnA ? bnA + kq8 * 4 : nullptr;
     unsigned char* wbase = lds + sub * kStageStride + o8;
@@ -236,12 +239,11 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
       }
     };
     auto load_b = [&](int ks, int set) {
-      const int tap = ks / kpt, kc0 = (ks - tap * kpt) * 32;
-      const uint16_t* b = bp + (int64_t)tap * Nout * Kc + kc0;
+      const uint16_t* b = bp + (int64_t)ks * Nout * 32;
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int i = 0; i < BI; ++i) rb[set][p][i] = *reinterpret_cast<const u32x4*>(b + p * bplane + (int64_t)(64 * i) * Kc);
+        for (int i = 0; i < BI; ++i) rb[set][p][i] = *reinterpret_cast<const u32x4*>(b + p * bplane + 64 * 32 * i);
     };
     auto store_a = [&](int ks) {
       unsigned char* S = wbase + (ks & 1) * 2 * kStageStride;
@@ -620,14 +622,18 @@ bool launch_conv_wgrad(const float* g, const float* y, const float* bn, const fl
 
 // w[n] fp32 -> q[3][n] bf16 pieces (same element order): the exact 3-way split of split_store, done once per call
 // for the weight operand so that the GEMM producers move it without arithmetic.
-__global__ void split_weights_k(const float* __restrict__ w, uint16_t* __restrict__ q, int64_t n) {
+// w[Nout][K] fp32 -> three bf16 planes [K/32][Nout][32] (the layout pw_split_k's producers read)
+__global__ void split_weights_k(const float* __restrict__ w, uint16_t* __restrict__ q, int Nout, int K) {
+  const int64_t n = (int64_t)Nout * K;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const int row = (int)(i / K), k = (int)(i - (int64_t)row * K);
+  const int64_t o = ((int64_t)(k >> 5) * Nout + row) * 32 + (k & 31);
   const float x = w[i];
   const float r1 = TTK_RESID(x), r2 = TTK_RESID(r1);
-  q[i] = (uint16_t)(__float_as_uint(x) >> 16);
-  q[n + i] = (uint16_t)(__float_as_uint(r1) >> 16);
-  q[2 * n + i] = (uint16_t)(__float_as_uint(r2) >> 16);
+  q[o] = (uint16_t)(__float_as_uint(x) >> 16);
+  q[n + o] = (uint16_t)(__float_as_uint(r1) >> 16);
+  q[2 * n + o] = (uint16_t)(__float_as_uint(r2) >> 16);
 }
 
 // The [M][K] x [Nout][K]^T shapes that run on the split kernels (everything else: fp32 MFMA, pwconv.hip).
@@ -645,7 +651,7 @@ bool launch_split_gemm(const float* A0, const float* A1, const float* bnA, const
   const ConvGeom none{};
   uint16_t* Bq = reinterpret_cast<uint16_t*>(wsplit);
   const int64_t nw = (int64_t)Nout * K;
-  if (Bm) hipLaunchKernelGGL(split_weights_k, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, st, Bm, Bq, nw);
+  if (Bm) hipLaunchKernelGGL(split_weights_k, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, st, Bm, Bq, Nout, K);
   if (Nout >= 256 && Nout % 256 == 0) {
     const unsigned tiles = (unsigned)(ceil_div(M, 128) * (Nout / 256));
     hipLaunchKernelGGL((pw_split_k<128, 256, AM, EM, false>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, out, E0, bnE, part, M, K,
