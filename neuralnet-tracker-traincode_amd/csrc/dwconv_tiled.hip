@@ -25,6 +25,8 @@ constexpr int kFwdU = 4;             // staging elements per thread and iteratio
 
 struct DwTiling {
   int R, nbands, nslabs, grid, rows;  // rows = partial rows = grid / nslabs
+  int NI;                             // images per tile (> 1 only when one band covers the image: the 9x9 and 5x5 layers)
+  int stage_rows;                     // LDS rows of one image's stage
 };
 
 // band height on the grid the kernel iterates (forward: output rows; backward: input rows)
@@ -44,7 +46,18 @@ inline DwTiling dw_tiling(int B, int H, int W, int C, int stride, bool backward)
   t.R = backward ? dw_band_rows(H, Wo, stride, true) : dw_band_rows(Ho, W, stride, false);
   t.nbands = ((backward ? H : Ho) + t.R - 1) / t.R;
   t.nslabs = C / kSlab;
-  int64_t tiles_per_slab = (int64_t)B * t.nbands;
+  t.stage_rows = backward ? (stride == 1 ? t.R + 2 : t.R / 2 + 2) : (t.R - 1) * stride + 3;
+  // Small images: one tile = several whole images side by side in LDS (each with its own zero border).  A 5x5 image
+  // is 49 staged pixels - a fraction of one pass of the 256 threads between two barriers; seven of them fill the
+  // stage buffer, the lanes and the memory pipeline.
+  t.NI = 1;
+  if (t.nbands == 1) {
+    const int per_image = t.stage_rows * ((backward ? Wo : W) + 2);
+    t.NI = kLdsPixBudget / per_image;
+    if (t.NI > B) t.NI = B;
+    if (t.NI < 1) t.NI = 1;
+  }
+  int64_t tiles_per_slab = (int64_t)((B + t.NI - 1) / t.NI) * t.nbands;
   int64_t rows = kMaxDwBlocks / t.nslabs;
   if (rows < 1) rows = 1;
   if (rows > tiles_per_slab) rows = tiles_per_slab;
@@ -131,8 +144,8 @@ __global__ void __launch_bounds__(kBlock) dw_fwd_tiled_k(const float* __restrict
                                                           const float* __restrict__ skip_prev, float* __restrict__ a_out,
                                                           const float* __restrict__ w, float* __restrict__ y,
                                                           float* __restrict__ part, int B, int H, int W, int C, int Ho, int Wo,
-                                                          int R, int nbands, int nslabs) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [stage_rows][W+2][32] + reduction scratch
+                                                          int R, int nbands, int nslabs, int NI) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [NI][stage_rows][W+2][32] + reduction scratch
   const int tid = threadIdx.x, q = tid & (kSlabQuads - 1), slot = tid >> 3;
   const int slab = blockIdx.x % nslabs, c0 = slab * kSlab + 4 * q;
   const int Wp = W + 2;
@@ -140,29 +153,34 @@ __global__ void __launch_bounds__(kBlock) dw_fwd_tiled_k(const float* __restrict
   wr.load(w, c0);
   const BnApply4 bn = BnApply4::load(bn_prev, C, c0);
   D4 s1{0.0, 0.0, 0.0, 0.0}, s2{0.0, 0.0, 0.0, 0.0};
-  const int64_t tiles = (int64_t)B * nbands;
+  const int64_t tiles = (int64_t)((B + NI - 1) / NI) * nbands;
   for (int64_t t = blockIdx.x / nslabs; t < tiles; t += gridDim.x / nslabs) {
-    const int n = (int)(t / nbands), band = (int)(t % nbands);
+    const int n0 = (int)(t / nbands) * NI, band = (int)(t % nbands);  // NI > 1 implies nbands == 1
+    const int nimg = min(NI, B - n0);
     const int o0 = band * R, o1 = min(o0 + R, Ho);
     const int i0 = o0 * S - 1;                     // first staged input row (may be -1)
     const int nrows = (o1 - 1 - o0) * S + 3;
+    const unsigned PI = (unsigned)(nrows * Wp);    // staged pixels per image
     __syncthreads();  // previous tile's readers are done
-    // ---- stage: a_in rows i0 .. i0+nrows-1, columns -1 .. W (zero outside the image).  Two elements per thread and
-    // iteration so that their loads are in flight together (the staging phase is where this kernel touches HBM).
-    const int nstage = nrows * Wp * kSlabQuads;
+    // ---- stage: a_in rows i0 .. i0+nrows-1, columns -1 .. W (zero outside the image) of nimg images.  Several
+    // elements per thread and iteration so that their loads are in flight together (the staging phase is where this
+    // kernel touches HBM).
+    const int nstage = nimg * (int)PI * kSlabQuads;
     for (int e = tid; e < nstage; e += kFwdU * kBlock) {
       float4 yv[kFwdU], sk[kFwdU];
       size_t off[kFwdU];
       bool in[kFwdU];
-      int pxs[kFwdU];
+      int pxs[kFwdU], rows[kFwdU];
 #pragma unroll
       for (int u = 0; u < kFwdU; ++u) {
         const int ee = e + u * kBlock;
-        const int px = ee >> 3;
-        const int col = px % Wp - 1, row = i0 + px / Wp;
-        pxs[u] = px;
+        const unsigned pxa = (unsigned)ee >> 3;              // pixel slot in LDS over all images of the tile
+        const unsigned img = NI > 1 ? pxa / PI : 0u, px = NI > 1 ? pxa - img * PI : pxa;
+        const int col = (int)(px % (unsigned)Wp) - 1, row = i0 + (int)(px / (unsigned)Wp);
+        pxs[u] = (int)pxa;
+        rows[u] = row;
         in[u] = ee < nstage && row >= 0 && row < H && col >= 0 && col < W;
-        off[u] = in[u] ? (((size_t)n * H + row) * W + col) * C + slab * kSlab + 4 * q : 0;  // qq == q: kBlock is a multiple of 8
+        off[u] = in[u] ? (((size_t)(n0 + img) * H + row) * W + col) * C + slab * kSlab + 4 * q : 0;  // qq == q: kBlock is a multiple of 8
         yv[u] = in[u] ? ld4(yprev + off[u]) : f4(0.f);
         sk[u] = (in[u] && skip_prev) ? ld4(skip_prev + off[u]) : f4(0.f);
       }
@@ -173,18 +191,20 @@ __global__ void __launch_bounds__(kBlock) dw_fwd_tiled_k(const float* __restrict
         float4 a = f4(0.f);
         if (in[u]) {
           a = skip_prev ? bn.act(yv[u], sk[u]) : bn.act(yv[u]);
-          const int row = i0 + pxs[u] / Wp;
-          if (S == 1 && a_out && row >= o0 && row < o1) st4(a_out + off[u], a);  // each input pixel belongs to one band
+          if (S == 1 && a_out && rows[u] >= o0 && rows[u] < o1) st4(a_out + off[u], a);  // each input pixel belongs to one band
         }
         st4(lds + (size_t)pxs[u] * kSlab + 4 * q, a);
       }
     }
     __syncthreads();
     // ---- stencil
-    const int npix = (o1 - o0) * Wo;
+    const unsigned npix1 = (unsigned)((o1 - o0) * Wo);  // output pixels per image
+    const int npix = nimg * (int)npix1;
     for (int p = slot; p < npix; p += kPixSlots) {
-      const int ho = o0 + p / Wo, wo = p % Wo;
-      const float* base = lds + ((size_t)((ho - o0) * S) * Wp + wo * S) * kSlab + 4 * q;  // tap (0,0): row ho*S-1, col wo*S-1
+      const unsigned img = NI > 1 ? (unsigned)p / npix1 : 0u, pp = NI > 1 ? (unsigned)p - img * npix1 : (unsigned)p;
+      const int n = n0 + (int)img;
+      const int ho = o0 + (int)(pp / (unsigned)Wo), wo = (int)(pp % (unsigned)Wo);
+      const float* base = lds + ((size_t)img * PI + (size_t)((ho - o0) * S) * Wp + wo * S) * kSlab + 4 * q;  // tap (0,0): row ho*S-1, col wo*S-1
       float4 acc = f4(0.f);
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
@@ -196,7 +216,7 @@ __global__ void __launch_bounds__(kBlock) dw_fwd_tiled_k(const float* __restrict
     }
   }
   if (part) {
-    const int stage = ((R - 1) * S + 3) * Wp * kSlab;
+    const int stage = NI * ((R - 1) * S + 3) * Wp * kSlab;
     slab_partials(s1, s2, q, C, slab * kSlab, part + (size_t)(blockIdx.x / nslabs) * 2 * C, lds + stage);
   }
 }
@@ -212,8 +232,8 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_tiled_k(const float* __restrict
                                                           const float* __restrict__ skip_prev, const float* __restrict__ a_in,
                                                           float* __restrict__ g_prev, float* __restrict__ part,
                                                           float* __restrict__ dwgrad, int B, int H, int W, int C, int Ho, int Wo,
-                                                          int R, int nbands, int nslabs, int stage_floats) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // dy[stage_rows][Wo+2][32] + reduction scratch
+                                                          int R, int nbands, int nslabs, int stage_floats, int NI) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // dy[NI][stage_rows][Wo+2][32] + reduction scratch
   const int tid = threadIdx.x, q = tid & (kSlabQuads - 1), slot = tid >> 3;
   const int slab = blockIdx.x % nslabs, c0 = slab * kSlab + 4 * q;
   const int Wp = Wo + 2;
@@ -231,28 +251,31 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_tiled_k(const float* __restrict
   float4 wacc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wacc[t] = f4(0.f);
-  const int64_t tiles = (int64_t)B * nbands;
+  const int64_t tiles = (int64_t)((B + NI - 1) / NI) * nbands;
   for (int64_t t = blockIdx.x / nslabs; t < tiles; t += gridDim.x / nslabs) {
-    const int n = (int)(t / nbands), band = (int)(t % nbands);
+    const int n0 = (int)(t / nbands) * NI, band = (int)(t % nbands);  // NI > 1 implies nbands == 1
+    const int nimg = min(NI, B - n0);
     const int r0 = band * R, r1 = min(r0 + R, H);
     // output rows ho with ho*S + kh - 1 in [r0, r1): ho in [ceil((r0-1)/S), floor(r1/S)], clipped
     const int ho_lo = max(0, (r0 - 1 + S - 1) / S * (r0 > 0 ? 1 : 0));
     const int ho_hi = min(Ho - 1, r1 / S);
     const int nrows = ho_hi - ho_lo + 1;
+    const unsigned PI = (unsigned)(nrows * Wp);  // staged pixels per image
     __syncthreads();
-    // ---- stage dy rows ho_lo..ho_hi, columns -1..Wo (zeros outside); two elements per thread and iteration (four
-    // loads in flight)
-    const int nstage = nrows * Wp * kSlabQuads;
+    // ---- stage dy rows ho_lo..ho_hi, columns -1..Wo (zeros outside) of nimg images; two elements per thread and
+    // iteration (four loads in flight)
+    const int nstage = nimg * (int)PI * kSlabQuads;
     for (int e = tid; e < nstage; e += 2 * kBlock) {
       float4 gv[2], yv[2];
       bool in[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int ee = e + u * kBlock;
-        const int px = ee >> 3;
-        const int col = px % Wp - 1, row = ho_lo + px / Wp;
+        const unsigned pxa = (unsigned)ee >> 3;
+        const unsigned img = NI > 1 ? pxa / PI : 0u, px = NI > 1 ? pxa - img * PI : pxa;
+        const int col = (int)(px % (unsigned)Wp) - 1, row = ho_lo + (int)(px / (unsigned)Wp);
         in[u] = ee < nstage && col >= 0 && col < Wo;
-        const size_t off = in[u] ? (((size_t)n * Ho + row) * Wo + col) * C + slab * kSlab + 4 * q : 0;  // qq == q (see forward)
+        const size_t off = in[u] ? (((size_t)(n0 + img) * Ho + row) * Wo + col) * C + slab * kSlab + 4 * q : 0;  // qq == q (see forward)
         gv[u] = in[u] ? ld4(g_dw + off) : f4(0.f);
         yv[u] = in[u] ? ld4(y_dw + off) : f4(0.f);
       }
@@ -264,16 +287,20 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_tiled_k(const float* __restrict
       }
     }
     __syncthreads();
-    const int npix = (r1 - r0) * W;
+    const unsigned npix1 = (unsigned)((r1 - r0) * W);  // input pixels per image
+    const int npix = nimg * (int)npix1;
     // two pixels per thread and iteration: their (up to six) global loads are issued back to back before either
     // pixel's LDS taps are read
     for (int p = slot; p < npix; p += 2 * kPixSlots) {
       const int pb = p + kPixSlots;
       const bool hasb = pb < npix;
-      const int hiA = r0 + p / W, wiA = p % W;
-      const int hiB = hasb ? r0 + pb / W : hiA, wiB = hasb ? pb % W : wiA;
-      const size_t offA = (((size_t)n * H + hiA) * W + wiA) * C + c0;
-      const size_t offB = (((size_t)n * H + hiB) * W + wiB) * C + c0;
+      const unsigned imgA = NI > 1 ? (unsigned)p / npix1 : 0u, ppA = NI > 1 ? (unsigned)p - imgA * npix1 : (unsigned)p;
+      const unsigned imgB = (NI > 1 && hasb) ? (unsigned)pb / npix1 : imgA;
+      const unsigned ppB = hasb ? ((NI > 1) ? (unsigned)pb - imgB * npix1 : (unsigned)pb) : ppA;
+      const int hiA = r0 + (int)(ppA / (unsigned)W), wiA = (int)(ppA % (unsigned)W);
+      const int hiB = r0 + (int)(ppB / (unsigned)W), wiB = (int)(ppB % (unsigned)W);
+      const size_t offA = (((size_t)(n0 + imgA) * H + hiA) * W + wiA) * C + c0;
+      const size_t offB = (((size_t)(n0 + imgB) * H + hiB) * W + wiB) * C + c0;
       const float4 ypA = ld4(yprev + offA), ypB = ld4(yprev + offB);
       float4 rawA = f4(0.f), rawB = f4(0.f), sgA = f4(0.f), sgB = f4(0.f);
       if (a_in) { rawA = ld4(a_in + offA); rawB = ld4(a_in + offB); }
@@ -283,6 +310,7 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_tiled_k(const float* __restrict
       for (int half = 0; half < 2; ++half) {
         if (half == 1 && !hasb) break;
         const int hi = half ? hiB : hiA, wi = half ? wiB : wiA;
+        const float* dyimg = lds + (size_t)(half ? imgB : imgA) * PI * kSlab;
         const float4 yp = half ? ypB : ypA, raw = half ? rawB : rawA, sg = half ? sgB : sgA;
         float4 a;
         if (a_in) a = raw;
@@ -299,7 +327,7 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_tiled_k(const float* __restrict
             const int tw = wi + 1 - kw;  // -1 .. W
             if (S == 2 && (tw & 1)) continue;
             const int wo = (S == 1) ? tw : (tw >> 1);  // -1 or Wo hit the zero padding columns (S=1); always inside for S=2
-            const float4 dy = ld4(lds + ((size_t)(ho - ho_lo) * Wp + wo + 1) * kSlab + 4 * q);
+            const float4 dy = ld4(dyimg + ((size_t)(ho - ho_lo) * Wp + wo + 1) * kSlab + 4 * q);
             G = fma4(dy, ld4(wt + (kh * 3 + kw) * kSlab + 4 * q), G);
             wacc[kh * 3 + kw] = fma4(dy, a, wacc[kh * 3 + kw]);
           }
@@ -359,14 +387,14 @@ int ttk_dwconv3x3_fwd(const float* yprev, const float* bn_prev, const float* ski
   TTK_REQUIRE(!(a_out && stride != 1), "dwconv3x3_fwd: a_out requires stride 1");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const DwTiling t = dw_tiling(B, H, W, C, stride, false);
-  const size_t stage = (size_t)((t.R - 1) * stride + 3) * (W + 2) * kSlab;
+  const size_t stage = (size_t)t.NI * t.stage_rows * (W + 2) * kSlab;
   const size_t sm = (stage + 16 * kSlab) * sizeof(float);  // + [4][2][32] doubles of reduction scratch
   if (stride == 1)
     hipLaunchKernelGGL(dw_fwd_tiled_k<1>, dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, yprev, bn_prev, skip_prev, a_out,
-                       w, y, part, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs);
+                       w, y, part, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI);
   else
     hipLaunchKernelGGL(dw_fwd_tiled_k<2>, dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, yprev, bn_prev, skip_prev, a_out,
-                       w, y, part, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs);
+                       w, y, part, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI);
   TTK_LAUNCH_CHECK("dwconv3x3_fwd");
 }
 
@@ -379,17 +407,16 @@ int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* bn
   TTK_REQUIRE(!(skip_grad && stride != 1), "dwconv3x3_bwd_data: residual gradient requires stride 1");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const DwTiling t = dw_tiling(B, H, W, C, stride, true);
-  const int stage_rows = (stride == 1) ? t.R + 2 : t.R / 2 + 2;
-  const size_t stage = (size_t)stage_rows * (Wo + 2) * kSlab;
+  const size_t stage = (size_t)t.NI * t.stage_rows * (Wo + 2) * kSlab;
   const size_t sm = (stage + 4 * 9 * kSlab + 9 * kSlab) * sizeof(float);  // stage + reduction scratch + filter taps
   hipStream_t st = (hipStream_t)stream;
   if (dw && !dw_accumulate) hipLaunchKernelGGL(zero_fill_k, dim3((9 * C + 255) / 256), dim3(256), 0, st, dw, (int64_t)9 * C);
   if (stride == 1)
     hipLaunchKernelGGL(dw_bwd_tiled_k<1>, dim3(t.grid), dim3(kBlock), sm, st, g_dw, y_dw, bn_dw, w, skip_grad, yprev, bn_prev,
-                       skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage);
+                       skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage, t.NI);
   else
     hipLaunchKernelGGL(dw_bwd_tiled_k<2>, dim3(t.grid), dim3(kBlock), sm, st, g_dw, y_dw, bn_dw, w, skip_grad, yprev, bn_prev,
-                       skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage);
+                       skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage, t.NI);
   TTK_LAUNCH_CHECK("dwconv3x3_bwd_data");
 }
 
