@@ -42,7 +42,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 7
+#define TTK_ABI_VERSION 8
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -304,6 +304,27 @@ int ttk_loss_normal_fwd(const float* mu, const float* sigma, const float* x, int
 int ttk_loss_normal_bwd(const float* mu, const float* sigma, const float* x, const float* gv, int n, int per, int points, int dim, float chin, float eye, float* gmu, float* gsigma, ttk_stream_t stream);
 int ttk_loss_gmm_fwd(const float* x, const double* ck, const double* mu, const double* sinv, int K, double fudge, int n, float* v, double* post, ttk_stream_t stream);
 int ttk_loss_gmm_bwd(const float* x, const double* mu, const double* sinv, const double* post, int K, double fudge, const float* gv, int n, float* gx, ttk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * On-GPU intensity augmentation - the kornia chain of trackertraincode/pipelines.py:508-532
+ * (container: datatransformation/batch/intensity.py:30-41) in one pass: one workgroup per image, the image stays in
+ * LDS from its single read to its single write.  x, y: [B][H][W] grey levels in [0,1] (y may alias x);
+ * params[B][TTK_INTENSITY_PARAMS]: which operations fire for each sample and their sampled magnitudes (0 / negative =
+ * off), applied in the reference's order equalize -> posterize -> gamma -> contrast -> brightness -> 5x5 Gaussian
+ * blur (sigma 1.5, reflect border) -> + noise_std * noise -> clip to [0,1] -> + out_shift (whitening, -0.5).
+ * noise: standard normal draws [B][H][W] or NULL.  2*H*W*4 + 2 KB of LDS per image (129x129: 132 KB).
+ * kornia is not available to this build: parity unpinned, checker oracle/intensity.py.
+ * ------------------------------------------------------------------------------------------- */
+#define TTK_INTENSITY_EQUALIZE 0        /* > 0: histogram equalisation */
+#define TTK_INTENSITY_POSTERIZE_BITS 1  /* 1..7: bits kept; 0 or 8: off */
+#define TTK_INTENSITY_GAMMA 2           /* > 0: v^gamma */
+#define TTK_INTENSITY_CONTRAST 3        /* > 0: v * factor */
+#define TTK_INTENSITY_BRIGHTNESS 4      /* > 0: v + (factor - 1) */
+#define TTK_INTENSITY_BLUR 5            /* > 0: blur */
+#define TTK_INTENSITY_NOISE_STD 6       /* > 0: additive Gaussian noise */
+#define TTK_INTENSITY_PARAMS 8
+int ttk_intensity_augment(const float* x, float* y, const float* params, const float* noise, int B, int H, int W,
+                          float out_shift, ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimiser step: torch.nn.utils.clip_grad_norm_(params, max_norm) over ALL tensors followed by

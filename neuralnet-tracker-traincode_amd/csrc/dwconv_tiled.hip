@@ -19,7 +19,7 @@ namespace ttk {
 constexpr int kSlab = 32;            // channels per tile
 constexpr int kSlabQuads = kSlab / 4;
 constexpr int kPixSlots = kBlock / kSlabQuads;  // 32 pixels in flight per pass
-constexpr int kLdsPixBudget = 368;   // (rows) x (W+2) pixels of 128 B each: <= 47 KB -> 3 workgroups per CU
+constexpr int kLdsPixBudget = 368;   // (rows) x (W+2) pixels of 128 B each: <= 47 KB -> 3 workgroups per CU (560 -> 2 per CU measured slower)
 constexpr int kMaxDwBlocks = 2048;
 constexpr int kFwdU = 4;             // staging elements per thread and iteration (forward)
 

@@ -79,10 +79,11 @@ _SIGNATURES = {
     "ttk_roi_transform": [_P, _P, _I, _I, _P],
     "ttk_affine_warp": [_P, _I, _I, _I, _I, _P, _P, _I, _F, _F],
     "ttk_affine_labels": [_P, _I, _I, _P, _P, _P, _P, _P],
+    "ttk_intensity_augment": [_P, _P, _P, _P, _I, _I, _I, _F],
     "ttk_clip_adam": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _F, _F, _F, _F, _F, _P, _P, _P],
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class _Library:

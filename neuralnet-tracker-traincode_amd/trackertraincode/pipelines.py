@@ -80,12 +80,32 @@ def synthetic_subbatch(tag: Tag, n: int, device, generator: torch.Generator, inp
     return Batch(Metadata(inputsize, batchsize=n, tag=tag), {k: v.to(device) for k, v in data.items()})
 
 
+def make_image_augmentations(generator: torch.Generator | None = None, whiten: bool = True):
+    """The reference's two intensity-augmentation containers (pipelines.py:508-528) on the fused HIP kernel
+    (datatransformation/batch/intensity.py); the second one also applies the whitening that follows (:530, -0.5).
+    Input images are in [0,1]."""
+    from .datatransformation import batch as B
+
+    return [
+        B.KorniaImageDistortions(
+            B.RandomEqualize(p=0.2), B.RandomPosterize((4.0, 6.0), p=0.01), B.RandomGamma((0.5, 2.0), p=0.2),
+            B.RandomContrast((0.7, 1.5), p=0.2), B.RandomBrightness((0.7, 1.5), p=0.2),
+            B.RandomGaussianBlur(p=0.1, kernel_size=(5, 5), sigma=(1.5, 1.5), silence_instantiation_warning=True),
+            random_apply=4, generator=generator),
+        B.KorniaImageDistortions(
+            B.RandomGaussianNoise(std=4.0 / 255.0, p=0.25), B.RandomGaussianNoise(std=16.0 / 255.0, p=0.25 ** 2),
+            B.RandomGaussianNoise(std=32.0 / 255.0, p=0.25 ** 3), B.RandomGaussianNoise(std=64.0 / 255.0, p=0.25 ** 4),
+            B.OnlyClip(p=1.0), out_shift=-0.5 if whiten else 0.0, generator=generator),
+    ]
+
+
 class SyntheticPoseLoader:
     """Endless iterator of `list[Batch]` split by Tag in fixed proportions (the contract of the train
     loader returned by make_pose_estimation_loaders, reference :534-554)."""
 
     def __init__(self, batchsize: int, tags_and_weights: Sequence[tuple[Tag, float]], device="cuda", seed=1234, inputsize=129,
-                 steps_per_epoch: int | None = None):
+                 steps_per_epoch: int | None = None, image_augmentations=None):
+        self._augs = image_augmentations  # containers from make_image_augmentations (images are un-whitened for them)
         total = sum(w for _, w in tags_and_weights)
         counts = [int(batchsize * w / total) for _, w in tags_and_weights]
         counts[0] += batchsize - sum(counts)
@@ -100,7 +120,14 @@ class SyntheticPoseLoader:
 
     def __iter__(self) -> Iterator[list[Batch]]:
         for _ in range(self._steps):
-            yield [synthetic_subbatch(t, c, self._device, self._gen, self._inputsize) for t, c in self._plan]
+            batches = [synthetic_subbatch(t, c, self._device, self._gen, self._inputsize) for t, c in self._plan]
+            if self._augs:
+                for b in batches:
+                    img = b["image"] + 0.5  # synthetic crops are stored whitened
+                    for aug in self._augs:
+                        img = aug.apply(img, aug.sample_params(img.shape[0]))
+                    b["image"] = img
+            yield batches
 
 
 def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights=None, use_weights_as_sampling_frequency=True,
@@ -111,7 +138,8 @@ def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights
     if datasets == "synthetic":
         datasets = [(Tag.POSE_WITH_LANDMARKS, 11.0), (Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS, 1.0)]
     if isinstance(datasets, (list, tuple)) and datasets and isinstance(datasets[0], tuple) and isinstance(datasets[0][0], Tag):
-        train = SyntheticPoseLoader(batchsize, datasets, device=device, inputsize=inputsize)
+        augs = make_image_augmentations(torch.Generator().manual_seed(99)) if enable_image_aug and str(device).startswith("cuda") else None
+        train = SyntheticPoseLoader(batchsize, datasets, device=device, inputsize=inputsize, image_augmentations=augs)
         test = SyntheticPoseLoader(batchsize, [(Tag.POSE_WITH_LANDMARKS, 1.0)], device=device, seed=4321, inputsize=inputsize,
                                    steps_per_epoch=max(1, 400 // batchsize))
         return train, test, len(train) * batchsize
