@@ -39,8 +39,10 @@ class GpuFocusRoiAugment:
         tr = torch.empty((B, 2, 3), dtype=torch.float32, device=dev)
         out_img = torch.empty((B, 1, self.new_size, self.new_size), dtype=torch.float32, device=dev)
         L = _hip.lib()
-        L.call("ttk_view_roi", _p(roi), _p(f32(params.scales)), _p(f32(params.translations)), self.beyond_border_shift, B, _p(view))
-        L.call("ttk_roi_transform", _p(view), _p(f32(params.angles)), B, self.new_size, _p(tr))
+        # named: a temporary's memory would be handed to the next allocation before the kernel has read it
+        scales, translations, angles = f32(params.scales), f32(params.translations), f32(params.angles)
+        L.call("ttk_view_roi", _p(roi), _p(scales), _p(translations), self.beyond_border_shift, B, _p(view))
+        L.call("ttk_roi_transform", _p(view), _p(angles), B, self.new_size, _p(tr))
         src = img.contiguous()
         if src.dtype not in (torch.uint8, torch.float32):
             src = src.float()

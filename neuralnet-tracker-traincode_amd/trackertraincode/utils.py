@@ -38,3 +38,21 @@ def iter_batched(iterable, batchsize):
         if not ret:
             break
         yield ret
+
+
+def cycle(iterable):
+    """Endless iteration that re-creates the iterator instead of caching its items (reference :92-100)."""
+    while True:
+        empty = True
+        for x in iterable:
+            empty = False
+            yield x
+        if empty:
+            return
+
+
+def num_workers() -> int:
+    """Worker processes for CPU-side loading (reference :107-114: NUM_WORKERS env or the core count)."""
+    import os
+
+    return int(os.environ.get("NUM_WORKERS", os.cpu_count() or 1))

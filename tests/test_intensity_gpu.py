@@ -159,3 +159,53 @@ def test_pipeline_loader_applies_augmentations():
     assert ia.shape == ib.shape and ia.min() >= -0.5 and ia.max() <= 0.5
     changed = ((ia - ib).abs().flatten(1).max(dim=1).values > 1e-6).float().mean().item()
     assert 0.2 < changed < 0.95  # most samples get at least one operation, some none
+
+
+@pytest.mark.gpu
+def test_resident_loader_feeds_training_step():
+    """HBM-resident uint8 frames -> weighted draw -> HIP crop/warp + intensity augmentation -> list[Batch] -> one step."""
+    import importlib.util, os
+    import trackertraincode.train as train
+    from trackertraincode import pipelines
+    from trackertraincode.datasets.resident import ResidentFrames, ResidentLoader
+    from trackertraincode.neuralnets.models import NetworkWithPointHead
+    from trackertraincode.pipelines import Tag
+
+    g = torch.Generator().manual_seed(0)
+    dev = "cuda"
+
+    def frames(n, tag, with_shape):
+        f = {"image": torch.randint(0, 256, (n, 1, 96, 96), generator=g, dtype=torch.uint8),
+             "roi": torch.tensor([20.0, 20.0, 76.0, 76.0]) + torch.rand(n, 4, generator=g) * 4,
+             "coord": torch.cat((48 + torch.randn(n, 2, generator=g), 25 + torch.rand(n, 1, generator=g)), -1),
+             "pose": torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=-1),
+             "pt3d_68": 48 + 10 * torch.randn(n, 68, 3, generator=g),
+             "coord_convention_id": torch.zeros(n, dtype=torch.int32)}
+        if with_shape:
+            f["shapeparam"] = torch.randn(n, 50, generator=g) * 0.5
+        return ResidentFrames(tag, {k: v.to(dev) for k, v in f.items()})
+
+    loader = ResidentLoader([frames(300, Tag.POSE_WITH_LANDMARKS, True), frames(40, Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS, False)],
+                            [11.0, 1.0], batchsize=64, steps_per_epoch=2, seed=1,
+                            image_augmentations=pipelines.make_image_augmentations(torch.Generator().manual_seed(3)))
+    steps = list(loader)
+    assert len(steps) == 2
+    for batches in steps:
+        assert sum(b.meta.batchsize for b in batches) == 64
+        for b in batches:
+            n = b.meta.batchsize
+            assert b["image"].shape == (n, 1, 129, 129) and b["image"].dtype == torch.float32
+            assert b["image"].min() >= -0.5 and b["image"].max() <= 0.5
+            assert b["pt3d_68"].shape == (n, 68, 3) and b["coord"].abs().max() < 3 and ("shapeparam" in b) == (b.meta.tag == Tag.POSE_WITH_LANDMARKS)
+            assert torch.allclose(b["pose"].norm(dim=-1), torch.ones(n, device=dev), atol=1e-5)
+    spec = importlib.util.spec_from_file_location("amd_train_script", os.path.join(os.path.dirname(__file__), "..", "neuralnet-tracker-traincode_amd", "scripts", "train_poseestimator.py"))
+    S = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(S)
+    args = S.make_parser().parse_args([])
+    args.with_pointhead, args.with_nll_loss, args.rampup_nll_losses = True, False, False
+    torch.manual_seed(0)
+    net = NetworkWithPointHead(enable_point_head=True, enable_uncertainty=False, config="mobilenetv1", backbone_args={"use_blurpool": False}).to(dev).train()
+    crit, _ = S.setup_losses(args, net)
+    out = train.training_step(net, steps[0], 0, crit)
+    out["loss"].backward()
+    assert torch.isfinite(out["loss"]) and all(torch.isfinite(q.grad).all() for q in net.parameters() if q.grad is not None)
