@@ -182,3 +182,31 @@ def test_eval_metrics_and_rotation_conventions():
     k.update({"pt3d_68": pred}, {"pt3d_68": gt, "pose": qq})
     res = k.compute()
     assert abs(res.bin_30_nme - 0.01) < 1e-5 and abs(res.bin_60_nme - 0.01) < 1e-5 and abs(res.avg_nme - 0.01) < 1e-5
+
+
+def test_conv_bn_fusion_keeps_the_eval_output():
+    """neuralnets/bnfusion.fuse_convbn on the backbone's plain-torch eval path (reference bnfusion.py:24-63)."""
+    import torch.fx as fx
+    import torch.nn as nn
+    from trackertraincode.backbones.mobilenet_v1 import MobileNet
+    from trackertraincode.neuralnets.bnfusion import fuse_convbn, torch_eval_module
+
+    torch.manual_seed(0)
+    net = MobileNet(num_classes=None) if "num_classes" in MobileNet.__init__.__code__.co_varnames else MobileNet()
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+    net.eval()
+    with pytest.raises(RuntimeError):
+        torch_eval_module(MobileNet().train())
+    gm = fx.symbolic_trace(torch_eval_module(net))
+    fused = fuse_convbn(gm)
+    assert sum(isinstance(m, nn.BatchNorm2d) for m in fused.modules()) == 0
+    assert sum(isinstance(m, nn.BatchNorm2d) for m in gm.modules()) == 27  # the input graph is left alone
+    x = torch.rand(2, 1, 129, 129) - 0.5
+    with torch.no_grad():
+        a, b = gm(x), fused(x)
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
