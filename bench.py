@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-call HIP-event instrumentation (roofline = null)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel from Python instead of replaying one captured hipGraph")
+    ap.add_argument("--force-graph", action="store_true", help="always replay the captured hipGraph (default at N=1: whichever of graph replay "
+                    "and eager enqueue the warm-up measures faster)")
     ap.add_argument("--serial-streams", action="store_true",
                     help="keep every kernel on one stream (for rocprofv3 runs: per-kernel durations are then those of the kernel alone)")
     ap.add_argument("--cpu-batch", type=int, default=64)
@@ -240,11 +242,13 @@ def main():
         opt.step()  # fused global-norm clip + Adam (2 launches, no host sync)
         return out["loss"]
 
+    use_graph = [graphed is not None]
+
     def step():
-        # single GPU: the whole step (zero_grad, forward, losses, backward, clip+Adam) is one captured hipGraph that
-        # is replayed - same kernels, one enqueue call instead of ~330; data-parallel runs stay eager (RCCL calls
+        # single GPU: the whole step (zero_grad, forward, losses, backward, clip+Adam) can be one captured hipGraph that
+        # is replayed - same kernels, one enqueue call instead of ~200; data-parallel runs stay eager (RCCL calls
         # are issued from Python between backward and the optimiser)
-        if graphed is not None and not timer.enabled:
+        if use_graph[0] and not timer.enabled:
             return graphed.run(batches, 0)["loss"]
         return eager_step()
 
@@ -258,8 +262,38 @@ def main():
         MB._USE_WGRAD_STREAM = False
     timer = KernelTimer()
     timer.wrap(H.lib())
-    for _ in range(args.warmup):
-        step()
+    enqueue_note = ""
+    if graphed is not None and not args.force_graph:
+        # Both enqueue modes run the same kernels.  Replay removes the host from the loop; eager enqueue lets the
+        # launch-ahead queue hide the gaps between the ~200 small dependent kernels.  Which one wins depends on the host:
+        # measure both during warm-up (untimed, runs as long as the timed region) and use the faster.
+        probe = {}
+        for mode in (False, True):  # eager first: it then runs exactly as it would without any capture in the process
+            use_graph[0] = mode
+            for _ in range(max(args.warmup, 2)):
+                step()
+            sync()
+            tp = time.perf_counter()
+            for _ in range(max(args.steps, 4)):
+                step()
+            sync()
+            probe[mode] = (time.perf_counter() - tp) / max(args.steps, 4) * 1e3
+        use_graph[0] = probe[True] <= probe[False]
+        enqueue_note = f"; warm-up probe: graph replay {probe[True]:.2f} ms/step, eager {probe[False]:.2f} ms/step"
+        if not use_graph[0]:
+            # a live capture slows later eager steps by ~1 ms (its private memory pool): drop it
+            import gc
+            graphed.graph = graphed._out = None
+            graphed._static = []
+            for p in params:
+                p.grad = None
+            gc.collect()
+            torch.cuda.empty_cache()
+        for _ in range(2):
+            step()
+    else:
+        for _ in range(args.warmup):
+            step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -345,7 +379,7 @@ def main():
             "roofline": roof,
             "step_roofline": {"hbm_frac_of_8TBs": per_gpu * ALGO_BYTES_PER_CROP / (PEAK_HBM_GBS * 1e9),
                               "fp32_mfma_frac_of_157TF": per_gpu * ALGO_FLOP_PER_CROP / (PEAK_FP32_MFMA_TFLOPS * 1e12)},
-            "enqueue": ("hipGraph replay (1 capture)" if graphed is not None else "eager Python launches"),
+            "enqueue": ("hipGraph replay (1 capture)" if use_graph[0] else "eager Python launches") + enqueue_note,
             "optimizer_ms": opt_ms, "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3, "loss": float(loss.item()),
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms"])},
             "gemm_family_TFLOPs": (sum(v["flops"] for k, v in ks.items() if k.startswith("pw_")) /
