@@ -181,8 +181,8 @@ __global__ void __launch_bounds__(kBlock) dw_fwd_tiled_k(const float* __restrict
         rows[u] = row;
         in[u] = ee < nstage && row >= 0 && row < H && col >= 0 && col < W;
         off[u] = in[u] ? (((size_t)(n0 + img) * H + row) * W + col) * C + slab * kSlab + 4 * q : 0;  // qq == q: kBlock is a multiple of 8
-        yv[u] = in[u] ? ld4(yprev + off[u]) : f4(0.f);
-        sk[u] = (in[u] && skip_prev) ? ld4(skip_prev + off[u]) : f4(0.f);
+        yv[u] = in[u] ? ld4nt(yprev + off[u]) : f4(0.f);
+        sk[u] = (in[u] && skip_prev) ? ld4nt(skip_prev + off[u]) : f4(0.f);
       }
 #pragma unroll
       for (int u = 0; u < kFwdU; ++u) {
@@ -276,8 +276,8 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_tiled_k(const float* __restrict
         const int col = (int)(px % (unsigned)Wp) - 1, row = ho_lo + (int)(px / (unsigned)Wp);
         in[u] = ee < nstage && col >= 0 && col < Wo;
         const size_t off = in[u] ? (((size_t)(n0 + img) * Ho + row) * Wo + col) * C + slab * kSlab + 4 * q : 0;  // qq == q (see forward)
-        gv[u] = in[u] ? ld4(g_dw + off) : f4(0.f);
-        yv[u] = in[u] ? ld4(y_dw + off) : f4(0.f);
+        gv[u] = in[u] ? ld4nt(g_dw + off) : f4(0.f);
+        yv[u] = in[u] ? ld4nt(y_dw + off) : f4(0.f);
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -301,11 +301,11 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_tiled_k(const float* __restrict
       const int hiB = r0 + (int)(ppB / (unsigned)W), wiB = (int)(ppB % (unsigned)W);
       const size_t offA = (((size_t)(n0 + imgA) * H + hiA) * W + wiA) * C + c0;
       const size_t offB = (((size_t)(n0 + imgB) * H + hiB) * W + wiB) * C + c0;
-      const float4 ypA = ld4(yprev + offA), ypB = ld4(yprev + offB);
+      const float4 ypA = ld4nt(yprev + offA), ypB = ld4nt(yprev + offB);
       float4 rawA = f4(0.f), rawB = f4(0.f), sgA = f4(0.f), sgB = f4(0.f);
-      if (a_in) { rawA = ld4(a_in + offA); rawB = ld4(a_in + offB); }
-      else if (skip_prev) { rawA = ld4(skip_prev + offA); rawB = ld4(skip_prev + offB); }
-      if (skip_grad) { sgA = ld4(skip_grad + offA); sgB = ld4(skip_grad + offB); }
+      if (a_in) { rawA = ld4nt(a_in + offA); rawB = ld4nt(a_in + offB); }
+      else if (skip_prev) { rawA = ld4nt(skip_prev + offA); rawB = ld4nt(skip_prev + offB); }
+      if (skip_grad) { sgA = ld4nt(skip_grad + offA); sgB = ld4nt(skip_grad + offB); }
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         if (half == 1 && !hasb) break;

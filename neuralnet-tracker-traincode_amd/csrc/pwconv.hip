@@ -82,8 +82,8 @@ __global__ void __launch_bounds__(WM * WN * 64) pw_gemm_k(const float* __restric
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
       const int64_t row = m0 + p * ROWS_PER_PASS + lrow;
-      ra0[p] = (row < M) ? ld4(A0 + row * K + k0) : f4(0.f);
-      if constexpr (MODE == MODE_DGRAD) ra1[p] = (row < M) ? ld4(A1 + row * K + k0) : f4(0.f);
+      ra0[p] = (row < M) ? ld4nt(A0 + row * K + k0) : f4(0.f);
+      if constexpr (MODE == MODE_DGRAD) ra1[p] = (row < M) ? ld4nt(A1 + row * K + k0) : f4(0.f);
     }
 #pragma unroll
     for (int p = 0; p < B_PASSES; ++p) {
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(WM * WN * 64) pw_gemm_k(const float* __restric
       s1 = add4(s1, v);
       s2 = fma4(v, v, s2);
     } else {
-      const float4 yc = sub4(ld4(E0 + o), emean);
+      const float4 yc = sub4(ld4nt(E0 + o), emean);
       v = mask4(v, fma4(esc, yc, ebeta));
       st4(out + o, v);
       s1 = add4(s1, v);
@@ -259,8 +259,8 @@ __global__ void __launch_bounds__(kBlock) pw_wgrad_k(const float* __restrict__ G
       const int row = f / (BN / 4), q = f % (BN / 4);
       const int64_t m = ms + row;
       if (row < MS && m < m_end) {
-        rg[p] = ld4(G + m * Cout + n0 + 4 * q);
-        ry[p] = ld4(Y + m * Cout + n0 + 4 * q);
+        rg[p] = ld4nt(G + m * Cout + n0 + 4 * q);
+        ry[p] = ld4nt(Y + m * Cout + n0 + 4 * q);
       } else {
         rg[p] = f4(0.f);
         ry[p] = f4(0.f);
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(kBlock) pw_wgrad_k(const float* __restrict__ G
       const int f = p * kBlock + tid;
       const int row = f / (BK / 4), q = f % (BK / 4);
       const int64_t m = ms + row;
-      ra[p] = (row < MS && m < m_end) ? ld4(Ydw + m * Cin + k0 + 4 * q) : f4(0.f);
+      ra[p] = (row < MS && m < m_end) ? ld4nt(Ydw + m * Cin + k0 + 4 * q) : f4(0.f);
     }
   };
   auto store_stage = [&](int64_t ms, int buf) {

@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(kBlock) stem_bwd_weight_k(const float* __restr
     const int ho = (int)(pix % Ho);
     const int n = (int)(pix / Ho);
     const float* xn = x + (size_t)n * H * W;
-    const float4 dy = bg.dy(ld4(g + (idx << 2)), ld4(y + (idx << 2)));
+    const float4 dy = bg.dy(ld4nt(g + (idx << 2)), ld4nt(y + (idx << 2)));
 #pragma unroll
     for (int kh = 0; kh < 5; ++kh) {
       const int hi = 2 * ho + kh - 2;
