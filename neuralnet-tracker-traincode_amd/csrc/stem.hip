@@ -2,6 +2,8 @@
 // and its weight gradient.  HBM-bound: the output (B*65*65*32 floats) dominates; the 129x129 input
 // plane is read through L1/L2 (each pixel is touched by <= 9 outputs x 8 lanes).
 #include "ttk_common.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace ttk {
 
@@ -144,6 +146,161 @@ __global__ void __launch_bounds__(kBlock) stem_bwd_weight_k(const float* __restr
   for (int i = threadIdx.x; i < 25 * kStemC; i += kBlock) atomicAdd(dw + i, acc_s[i % 25][i / 25]);  // dw[c][tap]
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same two operations on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: true fp32 products and accumulation, the
+// instruction the early pointwise layers use).  The scalar kernels above spend 1600 FMAs + 200 LDS broadcasts per
+// thread-iteration and run at 1.6 TB/s (forward) / 2.3 TB/s (weight gradient); as GEMMs the arithmetic is ~25 us and
+// the kernels become what the header says they are, HBM streams.
+//
+// forward:  y[px][c] = sum_t patch[px][t] * w[c][t]            M = 32 pixels, N = 32 channels, K = 25 taps (13 k-pairs)
+// wgrad:    dW[c][t] = sum_px dy[px][c] * patch[px][t]         M = 32 channels, N = 32 (25 taps + 7 idle), K = pixels
+// A fragment: lane l supplies A[row = l % 32][k = l / 32]; B fragment: B[k = l / 32][col = l % 32]; the accumulator of
+// lane l holds column l % 32, rows (e & 3) + 8 * (e >> 2) + 4 * (l / 32), e = 0..15.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float stem_patch(const float* __restrict__ x, int n, int ho, int wo, int tap, int H, int W, bool ok) {
+  const int kh = tap / 5, kw = tap - 5 * kh;
+  const int hi = 2 * ho + kh - 2, wi = 2 * wo + kw - 2;
+  return (ok && tap < 25 && hi >= 0 && hi < H && wi >= 0 && wi < W) ? x[((size_t)n * H + hi) * W + wi] : 0.f;
+}
+
+__global__ void __launch_bounds__(kBlock) stem_fwd_mfma_k(const float* __restrict__ x, const float* __restrict__ w,
+                                                           float* __restrict__ y, float* __restrict__ part, int B, int H,
+                                                           int W, int Ho, int Wo) {
+  __shared__ float red[kBlock / kWave][2 * kStemC];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, hk = lane >> 5;
+  float bw[13];  // B fragments: w[c = r][tap = 2j + hk]
+#pragma unroll
+  for (int j = 0; j < 13; ++j) bw[j] = (2 * j + hk < 25) ? w[r * 25 + 2 * j + hk] : 0.f;
+  float s1 = 0.f, s2 = 0.f;  // column r, rows of this lane's half
+  const int64_t P = (int64_t)B * Ho * Wo, tiles = (P + 31) / 32;
+  const int HoWo = Ho * Wo;
+  for (int64_t t = (int64_t)blockIdx.x * (kBlock / kWave) + wv; t < tiles; t += (int64_t)gridDim.x * (kBlock / kWave)) {
+    const int64_t px = t * 32 + r;
+    const bool ok = px < P;
+    const int n = (int)(px / HoWo), rem = (int)(px - (int64_t)n * HoWo), ho = rem / Wo, wo = rem - ho * Wo;
+    float a[13];
+#pragma unroll
+    for (int j = 0; j < 13; ++j) a[j] = stem_patch(x, n, ho, wo, 2 * j + hk, H, W, ok);
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 13; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bw[j], acc, 0, 0, 0);
+    float* yt = y + (size_t)t * 32 * kStemC + r;  // column r of the tile's 32 pixels
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * hk;
+      if (t * 32 + row < P) {
+        yt[(size_t)row * kStemC] = acc[e];  // 32 lanes = the 128 bytes of one pixel
+        s1 += acc[e];
+        s2 = fmaf(acc[e], acc[e], s2);
+      }
+    }
+  }
+  if (part) {
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (lane < 32) { red[wv][r] = s1; red[wv][kStemC + r] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 2 * kStemC) {
+      float a = 0.f;
+      for (int i = 0; i < kBlock / kWave; ++i) a += red[i][threadIdx.x];  // fixed wave order
+      part[(size_t)blockIdx.x * 2 * kStemC + threadIdx.x] = a;
+    }
+  }
+}
+
+// Weight gradient.  A workgroup owns a band of kWgBand output rows of one image: the input rows the band touches sit in
+// LDS (zero outside the image), so the patch fragments are LDS reads; dy is loaded with 16-byte loads (512 B per
+// wave-load instead of the fragment layout's 4 bytes per lane - the dword version was texture-addresser bound at
+// 255 us), formed in registers and turned into fragment order through a wave-private LDS tile.
+constexpr int kWgBand = 13;   // 65 = 5 x 13 output rows
+constexpr int kWgChunk = 32;  // pixels per wave iteration = 16 MFMA k-pairs (four 16-byte loads per lane and tensor in flight)
+
+__global__ void __launch_bounds__(kBlock) stem_wgrad_mfma_k(const float* __restrict__ g, const float* __restrict__ y,
+                                                             const float* __restrict__ bn, const float* __restrict__ x,
+                                                             float* __restrict__ dw, int B, int H, int W, int Ho, int Wo,
+                                                             int nbands) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int xrows = 2 * kWgBand + 3;
+  float* xs = sm;                                         // [xrows][W]
+  float* dys = sm + xrows * W;                            // [4 waves][kWgChunk][32]
+  float* red = dys + (kBlock / kWave) * kWgChunk * kStemC;  // [4 waves][32][25]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, hk = lane >> 5;
+  const int c4 = lane & 7, pl = lane >> 3;  // staging role: channel quad, pixel 0..7 (+8)
+  const float4 ga = ld4(bn + TTK_BN_GA * kStemC + 4 * c4), gb = ld4(bn + TTK_BN_GB * kStemC + 4 * c4),
+               gmean = ld4(bn + TTK_BN_GMEAN * kStemC + 4 * c4), mean = ld4(bn + TTK_BN_MEAN * kStemC + 4 * c4);
+  const int kh = r / 5, kw = r - 5 * kh;  // this lane's tap (r < 25)
+  float* dyw = dys + wv * kWgChunk * kStemC;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int t = blockIdx.x; t < B * nbands; t += gridDim.x) {
+    const int n = t / nbands, band = t - n * nbands;
+    const int ho0 = band * kWgBand, ho1 = min(ho0 + kWgBand, Ho);
+    const int hi0 = 2 * ho0 - 2;
+    __syncthreads();  // previous band's readers are done with xs
+    for (int i = threadIdx.x; i < xrows * W; i += kBlock) {
+      const int rr = i / W, cc = i - rr * W, hi = hi0 + rr;
+      xs[i] = (hi >= 0 && hi < H) ? x[((size_t)n * H + hi) * W + cc] : 0.f;
+    }
+    __syncthreads();
+    const int npix = (ho1 - ho0) * Wo;
+    const size_t pix0 = ((size_t)n * Ho + ho0) * Wo;  // the band's pixels are contiguous in g / y
+    for (int p0 = wv * kWgChunk; p0 < npix; p0 += (kBlock / kWave) * kWgChunk) {
+      // ---- dy of 16 pixels x 32 channels: two 16-byte loads per lane and tensor
+      float4 gvs[kWgChunk / 8], yvs[kWgChunk / 8];
+#pragma unroll
+      for (int u = 0; u < kWgChunk / 8; ++u) {
+        const int pp = p0 + pl + 8 * u;
+        const size_t o = (pix0 + (pp < npix ? pp : 0)) * kStemC + 4 * c4;
+        gvs[u] = ld4nt(g + o);
+        yvs[u] = ld4nt(y + o);
+      }
+#pragma unroll
+      for (int u = 0; u < kWgChunk / 8; ++u) {
+        const int pp = p0 + pl + 8 * u;
+        float4 d = f4(0.f);
+        if (pp < npix) {
+          const float4 gv = gvs[u], yv = yvs[u];
+          d = make_float4(fmaf(ga.x, gv.x - gmean.x, gb.x * (yv.x - mean.x)), fmaf(ga.y, gv.y - gmean.y, gb.y * (yv.y - mean.y)),
+                          fmaf(ga.z, gv.z - gmean.z, gb.z * (yv.z - mean.z)), fmaf(ga.w, gv.w - gmean.w, gb.w * (yv.w - mean.w)));
+        }
+        st4(dyw + (pl + 8 * u) * kStemC + 4 * c4, d);
+      }
+      __builtin_amdgcn_wave_barrier();  // the tile is wave-private; LDS executes a wave's accesses in order
+      // pixel of this lane's k index: p0 + 2j + hk; its (row, column) inside the band advance without divisions
+      int ho = (p0 + hk) / Wo, wo = (p0 + hk) - ho * Wo;
+      const float* xrow = xs + (2 * ho + kh) * W + kw - 2;
+#pragma unroll
+      for (int j = 0; j < kWgChunk / 2; ++j) {
+        const int q = 2 * j + hk;
+        const float a = dyw[q * kStemC + r];
+        const int wi = 2 * wo + kw - 2;
+        const float b = (r < 25 && p0 + q < npix && wi >= 0 && wi < W) ? xrow[2 * wo] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        wo += 2;
+        if (wo >= Wo) { wo -= Wo; xrow += 2 * W; }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // lane holds dW[c = row(e, hk)][tap = r]; fold the waves of the block, then one atomic per weight and block
+  if (r < 25) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(wv * kStemC + (e & 3) + 8 * (e >> 2) + 4 * hk) * 25 + r] = acc[e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kStemC * 25; i += kBlock) {
+    float v = 0.f;
+    for (int q = 0; q < kBlock / kWave; ++q) v += red[q * kStemC * 25 + i];
+    atomicAdd(dw + i, v);  // dw[c][tap]
+  }
+}
+
 __global__ void zero_k(float* p, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0.f;
@@ -160,8 +317,11 @@ int ttk_stem_fwd(const float* x, const float* w, float* y, float* part, int B, i
   TTK_REQUIRE(B > 0 && H > 4 && W > 4, "stem_fwd: bad shape B=%d H=%d W=%d", B, H, W);
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int64_t items = (int64_t)B * Ho * Wo * kStemQuads;  // sizes the partial rows (ttk_partial_rows_elementwise)
-  hipLaunchKernelGGL(stem_fwd_k, dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, x, w, y, part, B, H,
-                     W, Ho, Wo);
+  static const bool scalar = [] { const char* e = getenv("TTK_STEM"); return e && strcmp(e, "scalar") == 0; }();
+  if (scalar)  // TTK_STEM=scalar: the VALU kernels (A/B timing)
+    hipLaunchKernelGGL(stem_fwd_k, dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, x, w, y, part, B, H, W, Ho, Wo);
+  else
+    hipLaunchKernelGGL(stem_fwd_mfma_k, dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, x, w, y, part, B, H, W, Ho, Wo);
   TTK_LAUNCH_CHECK("stem_fwd");
 }
 
@@ -173,9 +333,17 @@ int ttk_stem_bwd_weight(const float* g, const float* y, const float* bn, const f
   const int64_t items = (int64_t)B * Ho * Wo * kStemQuads;
   if (!accumulate) hipLaunchKernelGGL(zero_k, dim3(4), dim3(256), 0, (hipStream_t)stream, dw, 25 * kStemC);
   int grid = elementwise_grid(items);
-  if (grid > 512) grid = 512;
-  hipLaunchKernelGGL(stem_bwd_weight_k, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, g, y, bn, x, dw, B, H, W,
-                     Ho, Wo);
+  static const bool scalar = [] { const char* e = getenv("TTK_STEM"); return e && strcmp(e, "scalar") == 0; }();
+  if (scalar) {
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(stem_bwd_weight_k, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, g, y, bn, x, dw, B, H, W, Ho, Wo);
+  } else {
+    const int nbands = (Ho + kWgBand - 1) / kWgBand;
+    grid = B * nbands < 1024 ? B * nbands : 1024;
+    const size_t sm = ((size_t)(2 * kWgBand + 3) * W + (kBlock / kWave) * (kWgChunk * kStemC + kStemC * 25)) * sizeof(float);
+    TTK_REQUIRE(sm <= 64 * 1024, "stem_bwd_weight: image too wide for the LDS band (W=%d)", W);
+    hipLaunchKernelGGL(stem_wgrad_mfma_k, dim3(grid), dim3(kBlock), sm, (hipStream_t)stream, g, y, bn, x, dw, B, H, W, Ho, Wo, nbands);
+  }
   TTK_LAUNCH_CHECK("stem_bwd_weight");
 }
 
