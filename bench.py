@@ -48,6 +48,7 @@ def parse():
                     "and eager enqueue the warm-up measures faster)")
     ap.add_argument("--serial-streams", action="store_true",
                     help="keep every kernel on one stream (for rocprofv3 runs: per-kernel durations are then those of the kernel alone)")
+    ap.add_argument("--per-call", action="store_true", help="print the roofline pass call by call (kernel, shape, us, GB/s, TFLOP/s) on stderr")
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 32)")
@@ -100,6 +101,7 @@ class KernelTimer:
     def wrap(self, lib):
         orig = lib.call
         timer = self
+        timer.shapes = []
 
         def call(name, *args):
             # only the conv kernels (94 % of the GPU time) are bracketed, and only in the separate roofline pass
@@ -110,9 +112,22 @@ class KernelTimer:
             orig(name, *args)
             e.record()
             kern, fl, by = timer.work(name, args)
+            ints = [x for x in args if isinstance(x, int) and not isinstance(x, bool)]
             timer.records.append((kern, s, e, fl, by))
+            timer.shapes.append(tuple(ints[-4:-1]) if name in ("ttk_pwconv1x1_fwd", "ttk_pwconv1x1_bwd_data") else tuple(ints[-3:]) if name == "ttk_pwconv1x1_bwd_weight" else tuple(ints[-5:]))
 
         lib.call = call
+
+    def per_call(self, steps):
+        """Average over the steps of the pass, one line per call position inside a step."""
+        n = len(self.records) // steps
+        lines = []
+        for i in range(n):
+            recs = [self.records[i + k * n] for k in range(steps)]
+            us = sum(s.elapsed_time(e) for _, s, e, _, _ in recs) / steps * 1e3
+            kern, _, _, fl, by = recs[0]
+            lines.append(f"{kern:38s} {str(self.shapes[i]):28s} {us:8.1f} us {by / us / 1e3:7.0f} GB/s {fl / us / 1e6:7.1f} TFLOP/s")
+        return lines
 
     def summary(self, steps):
         agg = {}
@@ -334,6 +349,8 @@ def main():
         ms = elapsed / args.steps * 1e3
         crops = args.batch * world * args.steps / elapsed
         ks = timer.summary(max(roof_steps, 1))
+        if args.per_call and roof_steps:
+            print("\n".join(timer.per_call(roof_steps)), file=sys.stderr)
         roof, top5 = None, []
         if ks:
             # dominant kernel = the kernel NAME (as rocprofv3 --stats lists it) with the largest total time in the

@@ -20,14 +20,18 @@ constexpr int kSlab = 32;            // channels per tile
 constexpr int kSlabQuads = kSlab / 4;
 constexpr int kPixSlots = kBlock / kSlabQuads;  // 32 pixels in flight per pass
 constexpr int kLdsPixBudget = 368;   // (rows) x (W+2) pixels of 128 B each: <= 47 KB -> 3 workgroups per CU (560 -> 2 per CU measured slower)
-constexpr int kMaxDwBlocks = 2048;
+constexpr int kMaxDwBlocks = 768;   // 3 workgroups per CU x 256 CUs: one resident wave of persistent workgroups
 constexpr int kFwdU = 4;             // staging elements per thread and iteration (forward)
 
 struct DwTiling {
   int R, nbands, nslabs, grid, rows;  // rows = partial rows = grid / nslabs
   int NI;                             // images per tile (> 1 only when one band covers the image: the 9x9 and 5x5 layers)
   int stage_rows;                     // LDS rows of one image's stage
+  int NCT, TW;                        // column tiles per band and their width (stride 1, wide images); else 1, full width
 };
+
+constexpr int kColTileMinW = 48;  // images at least this wide (the 65x65 layer) are tiled in columns too
+constexpr int kColTile = 17;      // 19 x 19 staged pixels for 17 x 17 results: halo 1.25x instead of 1.7x for 3-row bands
 
 // band height on the grid the kernel iterates (forward: output rows; backward: input rows)
 __host__ __device__ inline int dw_band_rows(int Hgrid, int Wstage, int stride, bool backward) {
@@ -43,7 +47,14 @@ __host__ __device__ inline int dw_band_rows(int Hgrid, int Wstage, int stride, b
 inline DwTiling dw_tiling(int B, int H, int W, int C, int stride, bool backward) {
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   DwTiling t;
-  t.R = backward ? dw_band_rows(H, Wo, stride, true) : dw_band_rows(Ho, W, stride, false);
+  t.NCT = 1;
+  t.TW = Wo;
+  if (stride == 1 && W >= kColTileMinW) {
+    t.NCT = (W + kColTile - 1) / kColTile;
+    t.TW = (W + t.NCT - 1) / t.NCT;
+  }
+  const int Wtile = t.NCT > 1 ? t.TW : (backward ? Wo : W);
+  t.R = backward ? dw_band_rows(H, Wtile, stride, true) : dw_band_rows(Ho, Wtile, stride, false);
   t.nbands = ((backward ? H : Ho) + t.R - 1) / t.R;
   t.nslabs = C / kSlab;
   t.stage_rows = backward ? (stride == 1 ? t.R + 2 : t.R / 2 + 2) : (t.R - 1) * stride + 3;
@@ -51,13 +62,13 @@ inline DwTiling dw_tiling(int B, int H, int W, int C, int stride, bool backward)
   // is 49 staged pixels - a fraction of one pass of the 256 threads between two barriers; seven of them fill the
   // stage buffer, the lanes and the memory pipeline.
   t.NI = 1;
-  if (t.nbands == 1) {
+  if (t.nbands == 1 && t.NCT == 1) {
     const int per_image = t.stage_rows * ((backward ? Wo : W) + 2);
     t.NI = kLdsPixBudget / per_image;
     if (t.NI > B) t.NI = B;
     if (t.NI < 1) t.NI = 1;
   }
-  int64_t tiles_per_slab = (int64_t)((B + t.NI - 1) / t.NI) * t.nbands;
+  int64_t tiles_per_slab = (int64_t)((B + t.NI - 1) / t.NI) * t.nbands * t.NCT;
   int64_t rows = kMaxDwBlocks / t.nslabs;
   if (rows < 1) rows = 1;
   if (rows > tiles_per_slab) rows = tiles_per_slab;
@@ -140,23 +151,25 @@ __device__ __forceinline__ void slab_partials(D4 s1, D4 s2, int q, int C, int c_
 // forward
 // ---------------------------------------------------------------------------------------------
 template <int S>
-__global__ void __launch_bounds__(kBlock) dw_fwd_tiled_k(const float* __restrict__ yprev, const float* __restrict__ bn_prev,
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3)))
+dw_fwd_tiled_k(const float* __restrict__ yprev, const float* __restrict__ bn_prev,
                                                           const float* __restrict__ skip_prev, float* __restrict__ a_out,
                                                           const float* __restrict__ w, float* __restrict__ y,
                                                           float* __restrict__ part, int B, int H, int W, int C, int Ho, int Wo,
-                                                          int R, int nbands, int nslabs, int NI) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [NI][stage_rows][W+2][32] + reduction scratch
+                                                          int R, int nbands, int nslabs, int NI, int NCT, int TW) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [NI][stage_rows][tile width + 2][32] + reduction scratch
   const int tid = threadIdx.x, q = tid & (kSlabQuads - 1), slot = tid >> 3;
   const int slab = blockIdx.x % nslabs, c0 = slab * kSlab + 4 * q;
-  const int Wp = W + 2;
   SlabWeights wr;
   wr.load(w, c0);
   const BnApply4 bn = BnApply4::load(bn_prev, C, c0);
   D4 s1{0.0, 0.0, 0.0, 0.0}, s2{0.0, 0.0, 0.0, 0.0};
-  const int64_t tiles = (int64_t)((B + NI - 1) / NI) * nbands;
+  const int64_t tiles = (int64_t)((B + NI - 1) / NI) * nbands * NCT;
   for (int64_t t = blockIdx.x / nslabs; t < tiles; t += gridDim.x / nslabs) {
-    const int n0 = (int)(t / nbands) * NI, band = (int)(t % nbands);  // NI > 1 implies nbands == 1
+    const int ct = (int)(t % NCT), band = (int)((t / NCT) % nbands), n0 = (int)(t / ((int64_t)NCT * nbands)) * NI;  // NI > 1 implies one tile per image
     const int nimg = min(NI, B - n0);
+    const int cx0 = ct * TW, tw = NCT > 1 ? min(TW, Wo - cx0) : Wo;  // output columns [cx0, cx0 + tw) (column tiles: stride 1)
+    const int Wp = NCT > 1 ? tw + 2 : W + 2;                          // staged input columns cx0-1 .. cx0+tw (or -1 .. W)
     const int o0 = band * R, o1 = min(o0 + R, Ho);
     const int i0 = o0 * S - 1;                     // first staged input row (may be -1)
     const int nrows = (o1 - 1 - o0) * S + 3;
@@ -176,9 +189,9 @@ __global__ void __launch_bounds__(kBlock) dw_fwd_tiled_k(const float* __restrict
         const int ee = e + u * kBlock;
         const unsigned pxa = (unsigned)ee >> 3;              // pixel slot in LDS over all images of the tile
         const unsigned img = NI > 1 ? pxa / PI : 0u, px = NI > 1 ? pxa - img * PI : pxa;
-        const int col = (int)(px % (unsigned)Wp) - 1, row = i0 + (int)(px / (unsigned)Wp);
+        const int col = (int)(px % (unsigned)Wp) - 1 + cx0, row = i0 + (int)(px / (unsigned)Wp);
         pxs[u] = (int)pxa;
-        rows[u] = row;
+        rows[u] = (row >= o0 && row < o1 && col >= cx0 && col < cx0 + tw) ? 1 : 0;  // the one tile this input pixel belongs to
         in[u] = ee < nstage && row >= 0 && row < H && col >= 0 && col < W;
         off[u] = in[u] ? (((size_t)(n0 + img) * H + row) * W + col) * C + slab * kSlab + 4 * q : 0;  // qq == q: kBlock is a multiple of 8
         yv[u] = in[u] ? ld4nt(yprev + off[u]) : f4(0.f);
@@ -191,20 +204,20 @@ __global__ void __launch_bounds__(kBlock) dw_fwd_tiled_k(const float* __restrict
         float4 a = f4(0.f);
         if (in[u]) {
           a = skip_prev ? bn.act(yv[u], sk[u]) : bn.act(yv[u]);
-          if (S == 1 && a_out && rows[u] >= o0 && rows[u] < o1) st4(a_out + off[u], a);  // each input pixel belongs to one band
+          if (S == 1 && a_out && rows[u]) st4(a_out + off[u], a);
         }
         st4(lds + (size_t)pxs[u] * kSlab + 4 * q, a);
       }
     }
     __syncthreads();
     // ---- stencil
-    const unsigned npix1 = (unsigned)((o1 - o0) * Wo);  // output pixels per image
+    const unsigned npix1 = (unsigned)((o1 - o0) * tw);  // output pixels per image
     const int npix = nimg * (int)npix1;
     for (int p = slot; p < npix; p += kPixSlots) {
       const unsigned img = NI > 1 ? (unsigned)p / npix1 : 0u, pp = NI > 1 ? (unsigned)p - img * npix1 : (unsigned)p;
       const int n = n0 + (int)img;
-      const int ho = o0 + (int)(pp / (unsigned)Wo), wo = (int)(pp % (unsigned)Wo);
-      const float* base = lds + ((size_t)img * PI + (size_t)((ho - o0) * S) * Wp + wo * S) * kSlab + 4 * q;  // tap (0,0): row ho*S-1, col wo*S-1
+      const int ho = o0 + (int)(pp / (unsigned)tw), wl = (int)(pp % (unsigned)tw), wo = cx0 + wl;
+      const float* base = lds + ((size_t)img * PI + (size_t)((ho - o0) * S) * Wp + wl * S) * kSlab + 4 * q;  // tap (0,0): row ho*S-1, col wo*S-1
       float4 acc = f4(0.f);
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
@@ -216,7 +229,7 @@ __global__ void __launch_bounds__(kBlock) dw_fwd_tiled_k(const float* __restrict
     }
   }
   if (part) {
-    const int stage = NI * ((R - 1) * S + 3) * Wp * kSlab;
+    const int stage = NI * ((R - 1) * S + 3) * (NCT > 1 ? TW + 2 : W + 2) * kSlab;
     slab_partials(s1, s2, q, C, slab * kSlab, part + (size_t)(blockIdx.x / nslabs) * 2 * C, lds + stage);
   }
 }
@@ -225,18 +238,18 @@ __global__ void __launch_bounds__(kBlock) dw_fwd_tiled_k(const float* __restrict
 // data gradient (+ fused weight gradient)
 // ---------------------------------------------------------------------------------------------
 template <int S>
-__global__ void __launch_bounds__(kBlock) dw_bwd_tiled_k(const float* __restrict__ g_dw, const float* __restrict__ y_dw,
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3)))  // <= 168 VGPRs: 3 workgroups per CU, as the LDS tile allows
+dw_bwd_tiled_k(const float* __restrict__ g_dw, const float* __restrict__ y_dw,
                                                           const float* __restrict__ bn_dw, const float* __restrict__ w,
                                                           const float* __restrict__ skip_grad,
                                                           const float* __restrict__ yprev, const float* __restrict__ bn_prev,
                                                           const float* __restrict__ skip_prev, const float* __restrict__ a_in,
                                                           float* __restrict__ g_prev, float* __restrict__ part,
                                                           float* __restrict__ dwgrad, int B, int H, int W, int C, int Ho, int Wo,
-                                                          int R, int nbands, int nslabs, int stage_floats, int NI) {
+                                                          int R, int nbands, int nslabs, int stage_floats, int NI, int NCT, int TW) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // dy[NI][stage_rows][Wo+2][32] + reduction scratch
   const int tid = threadIdx.x, q = tid & (kSlabQuads - 1), slot = tid >> 3;
   const int slab = blockIdx.x % nslabs, c0 = slab * kSlab + 4 * q;
-  const int Wp = Wo + 2;
   // the filter taps of this thread's channel quad live in LDS (wt[tap][32 channels], after the reduction scratch):
   // 36 fewer VGPRs, which pays for handling two pixels per iteration below
   float* wt = lds + stage_floats + 4 * 9 * kSlab;
@@ -251,10 +264,12 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_tiled_k(const float* __restrict
   float4 wacc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wacc[t] = f4(0.f);
-  const int64_t tiles = (int64_t)((B + NI - 1) / NI) * nbands;
+  const int64_t tiles = (int64_t)((B + NI - 1) / NI) * nbands * NCT;
   for (int64_t t = blockIdx.x / nslabs; t < tiles; t += gridDim.x / nslabs) {
-    const int n0 = (int)(t / nbands) * NI, band = (int)(t % nbands);  // NI > 1 implies nbands == 1
+    const int ct = (int)(t % NCT), band = (int)((t / NCT) % nbands), n0 = (int)(t / ((int64_t)NCT * nbands)) * NI;  // NI > 1 implies one tile per image
     const int nimg = min(NI, B - n0);
+    const int cx0 = ct * TW, tw = NCT > 1 ? min(TW, W - cx0) : W;  // input columns [cx0, cx0 + tw) (column tiles: stride 1)
+    const int Wp = NCT > 1 ? tw + 2 : Wo + 2;                       // staged dy columns cx0-1 .. cx0+tw (or -1 .. Wo)
     const int r0 = band * R, r1 = min(r0 + R, H);
     // output rows ho with ho*S + kh - 1 in [r0, r1): ho in [ceil((r0-1)/S), floor(r1/S)], clipped
     const int ho_lo = max(0, (r0 - 1 + S - 1) / S * (r0 > 0 ? 1 : 0));
@@ -273,7 +288,7 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_tiled_k(const float* __restrict
         const int ee = e + u * kBlock;
         const unsigned pxa = (unsigned)ee >> 3;
         const unsigned img = NI > 1 ? pxa / PI : 0u, px = NI > 1 ? pxa - img * PI : pxa;
-        const int col = (int)(px % (unsigned)Wp) - 1, row = ho_lo + (int)(px / (unsigned)Wp);
+        const int col = (int)(px % (unsigned)Wp) - 1 + cx0, row = ho_lo + (int)(px / (unsigned)Wp);
         in[u] = ee < nstage && col >= 0 && col < Wo;
         const size_t off = in[u] ? (((size_t)(n0 + img) * Ho + row) * Wo + col) * C + slab * kSlab + 4 * q : 0;  // qq == q (see forward)
         gv[u] = in[u] ? ld4nt(g_dw + off) : f4(0.f);
@@ -287,7 +302,7 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_tiled_k(const float* __restrict
       }
     }
     __syncthreads();
-    const unsigned npix1 = (unsigned)((r1 - r0) * W);  // input pixels per image
+    const unsigned npix1 = (unsigned)((r1 - r0) * tw);  // input pixels per image
     const int npix = nimg * (int)npix1;
     // two pixels per thread and iteration: their (up to six) global loads are issued back to back before either
     // pixel's LDS taps are read
@@ -297,8 +312,8 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_tiled_k(const float* __restrict
       const unsigned imgA = NI > 1 ? (unsigned)p / npix1 : 0u, ppA = NI > 1 ? (unsigned)p - imgA * npix1 : (unsigned)p;
       const unsigned imgB = (NI > 1 && hasb) ? (unsigned)pb / npix1 : imgA;
       const unsigned ppB = hasb ? ((NI > 1) ? (unsigned)pb - imgB * npix1 : (unsigned)pb) : ppA;
-      const int hiA = r0 + (int)(ppA / (unsigned)W), wiA = (int)(ppA % (unsigned)W);
-      const int hiB = r0 + (int)(ppB / (unsigned)W), wiB = (int)(ppB % (unsigned)W);
+      const int hiA = r0 + (int)(ppA / (unsigned)tw), wiA = cx0 + (int)(ppA % (unsigned)tw);
+      const int hiB = r0 + (int)(ppB / (unsigned)tw), wiB = cx0 + (int)(ppB % (unsigned)tw);
       const size_t offA = (((size_t)(n0 + imgA) * H + hiA) * W + wiA) * C + c0;
       const size_t offB = (((size_t)(n0 + imgB) * H + hiB) * W + wiB) * C + c0;
       const float4 ypA = ld4nt(yprev + offA), ypB = ld4nt(yprev + offB);
@@ -327,7 +342,7 @@ __global__ void __launch_bounds__(kBlock) dw_bwd_tiled_k(const float* __restrict
             const int tw = wi + 1 - kw;  // -1 .. W
             if (S == 2 && (tw & 1)) continue;
             const int wo = (S == 1) ? tw : (tw >> 1);  // -1 or Wo hit the zero padding columns (S=1); always inside for S=2
-            const float4 dy = ld4(dyimg + ((size_t)(ho - ho_lo) * Wp + wo + 1) * kSlab + 4 * q);
+            const float4 dy = ld4(dyimg + ((size_t)(ho - ho_lo) * Wp + wo - cx0 + 1) * kSlab + 4 * q);
             G = fma4(dy, ld4(wt + (kh * 3 + kw) * kSlab + 4 * q), G);
             wacc[kh * 3 + kw] = fma4(dy, a, wacc[kh * 3 + kw]);
           }
@@ -387,14 +402,14 @@ int ttk_dwconv3x3_fwd(const float* yprev, const float* bn_prev, const float* ski
   TTK_REQUIRE(!(a_out && stride != 1), "dwconv3x3_fwd: a_out requires stride 1");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const DwTiling t = dw_tiling(B, H, W, C, stride, false);
-  const size_t stage = (size_t)t.NI * t.stage_rows * (W + 2) * kSlab;
+  const size_t stage = (size_t)t.NI * t.stage_rows * ((t.NCT > 1 ? t.TW : W) + 2) * kSlab;
   const size_t sm = (stage + 16 * kSlab) * sizeof(float);  // + [4][2][32] doubles of reduction scratch
   if (stride == 1)
     hipLaunchKernelGGL(dw_fwd_tiled_k<1>, dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, yprev, bn_prev, skip_prev, a_out,
-                       w, y, part, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI);
+                       w, y, part, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI, t.NCT, t.TW);
   else
     hipLaunchKernelGGL(dw_fwd_tiled_k<2>, dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, yprev, bn_prev, skip_prev, a_out,
-                       w, y, part, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI);
+                       w, y, part, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI, t.NCT, t.TW);
   TTK_LAUNCH_CHECK("dwconv3x3_fwd");
 }
 
@@ -407,16 +422,16 @@ int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* bn
   TTK_REQUIRE(!(skip_grad && stride != 1), "dwconv3x3_bwd_data: residual gradient requires stride 1");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const DwTiling t = dw_tiling(B, H, W, C, stride, true);
-  const size_t stage = (size_t)t.NI * t.stage_rows * (Wo + 2) * kSlab;
+  const size_t stage = (size_t)t.NI * t.stage_rows * ((t.NCT > 1 ? t.TW : Wo) + 2) * kSlab;
   const size_t sm = (stage + 4 * 9 * kSlab + 9 * kSlab) * sizeof(float);  // stage + reduction scratch + filter taps
   hipStream_t st = (hipStream_t)stream;
   if (dw && !dw_accumulate) hipLaunchKernelGGL(zero_fill_k, dim3((9 * C + 255) / 256), dim3(256), 0, st, dw, (int64_t)9 * C);
   if (stride == 1)
     hipLaunchKernelGGL(dw_bwd_tiled_k<1>, dim3(t.grid), dim3(kBlock), sm, st, g_dw, y_dw, bn_dw, w, skip_grad, yprev, bn_prev,
-                       skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage, t.NI);
+                       skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage, t.NI, t.NCT, t.TW);
   else
     hipLaunchKernelGGL(dw_bwd_tiled_k<2>, dim3(t.grid), dim3(kBlock), sm, st, g_dw, y_dw, bn_dw, w, skip_grad, yprev, bn_prev,
-                       skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage, t.NI);
+                       skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage, t.NI, t.NCT, t.TW);
   TTK_LAUNCH_CHECK("dwconv3x3_bwd_data");
 }
 
