@@ -85,7 +85,9 @@ class KernelTimer:
                 return f"pw_split_k<128, 256, {mode}, {mode}, false>", fl, by  # <BM, BN, A-operand form, epilogue form, gather>
             if K >= 128 and N == 128:
                 return f"pw_split_k<256, 128, {mode}, {mode}, false>", fl, by
-            return (f"pw_gemm_k<{min(N, 128)}, 2, 2, {mode}>" if N >= 64 else f"pw_gemm_k<32, 4, 1, {mode}>"), fl, by
+            if N == 64 and K == 32:
+                return f"pw_gemm_k<64, 2, 2, {mode}, 1>", fl, by  # single LDS stage
+            return (f"pw_gemm_k<{min(N, 128)}, 2, 2, {mode}, 2>" if N >= 64 else f"pw_gemm_k<32, 4, 1, {mode}, 2>"), fl, by
         if name == "ttk_dwconv3x3_fwd":
             B, H, W, C, s_ = ints[-5:]
             n_in, n_out = B * H * W * C, B * ((H - 1) // s_ + 1) * ((W - 1) // s_ + 1) * C

@@ -28,8 +28,11 @@ constexpr int LDP = BKT + 4;          // padded LDS row (floats)
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 
-template <int BN, int WM, int WN, int MODE>
-__global__ void __launch_bounds__(WM * WN * 64) pw_gemm_k(const float* __restrict__ A0, const float* __restrict__ A1,
+// STAGES = 1: the whole contraction is one LDS stage (K = 32, the first pointwise layer): half the LDS, and with the
+// 168-VGPR cap three workgroups per CU instead of two for this HBM-bound layer.
+template <int BN, int WM, int WN, int MODE, int STAGES = 2>
+__global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(STAGES == 1 ? 3 : 1, STAGES == 1 ? 3 : 8)))
+pw_gemm_k(const float* __restrict__ A0, const float* __restrict__ A1,
                                                      const float* __restrict__ bnA, const float* __restrict__ Bm,
                                                      float* __restrict__ out, const float* __restrict__ E0,
                                                      const float* __restrict__ bnE, float* __restrict__ part, int64_t M,
@@ -45,12 +48,12 @@ __global__ void __launch_bounds__(WM * WN * 64) pw_gemm_k(const float* __restric
   constexpr int B_PASSES = (BN + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
   // One LDS allocation: operand stages during the main loop, the C tile + reduction scratch afterwards.
   constexpr int LDC = BN + 4;
-  constexpr int kStageFloats = 2 * (BM + BN) * LDP;
+  constexpr int kStageFloats = STAGES * (BM + BN) * LDP;
   constexpr int kEpiFloats = BM * LDC + (NT / 64) * 2 * BN;
   constexpr int kSmemFloats = kStageFloats > kEpiFloats ? kStageFloats : kEpiFloats;
   __shared__ __attribute__((aligned(16))) float smem[kSmemFloats];
   float (*As)[BM][LDP] = reinterpret_cast<float (*)[BM][LDP]>(smem);
-  float (*Bs)[BN][LDP] = reinterpret_cast<float (*)[BN][LDP]>(smem + 2 * BM * LDP);
+  float (*Bs)[BN][LDP] = reinterpret_cast<float (*)[BN][LDP]>(smem + STAGES * BM * LDP);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -120,7 +123,7 @@ __global__ void __launch_bounds__(WM * WN * 64) pw_gemm_k(const float* __restric
   store_tile(0, 0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+    const int buf = kt & (STAGES - 1);
     if (kt + 1 < nk) load_tile(kt + 1);
     const int fr = lane & 31, fk = 4 * (lane >> 5);
 #pragma unroll
@@ -128,7 +131,7 @@ __global__ void __launch_bounds__(WM * WN * 64) pw_gemm_k(const float* __restric
       // the next tile's transform + ds_write go BETWEEN MFMA groups (after 3/4 of this tile's matrix work, so
       // its global loads have had ~3000 cycles to land): their VALU/LDS issue hides under the running MFMAs
       // instead of forming a matrix-idle phase in front of the barrier.
-      if (ks == BKT / 8 - 1 && kt + 1 < nk) store_tile(kt + 1, buf ^ 1);
+      if (STAGES > 1 && ks == BKT / 8 - 1 && kt + 1 < nk) store_tile(kt + 1, buf ^ 1);
       float4 af[TM], bf[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[i] = ld4(&As[buf][wm * (BM / WM) + i * 32 + fr][8 * ks + fk]);
@@ -380,6 +383,8 @@ static void launch_gemm(const float* A0, const float* A1, const float* bnA, cons
   if (Nout >= 128)
     hipLaunchKernelGGL((pw_gemm_k<128, 2, 2, MODE>), dim3((Nout / 128) * gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K,
                        Nout);
+  else if (Nout == 64 && K == BKT)
+    hipLaunchKernelGGL((pw_gemm_k<64, 2, 2, MODE, 1>), dim3(gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
   else if (Nout == 64)
     hipLaunchKernelGGL((pw_gemm_k<64, 2, 2, MODE>), dim3(gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
   else
