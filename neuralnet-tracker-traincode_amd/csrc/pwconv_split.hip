@@ -451,7 +451,33 @@ pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const
     unsigned bmask = 0u;  // (pass, row) pairs of the in-flight B loads that hit the source tensor
     unsigned char* wbase = lds + sub * kStageStride + o8;
 
+    // Steps whose 32 rows all lie inside the slice (all but possibly the last one) take a path without row clamps and
+    // zero fills, and the pointwise kernel's tiles are always full (launch_split_wgrad): the producers are the critical
+    // path of this kernel (VALU issue, ~850 instructions per step before this split), so every select counts.
+    const int nfull = (int)((m_end - m_begin) / 32);
+    const float* gp[AP];
+    const float* yp[AP];
+    const float* xp[BP];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      gp[p] = G + (m_begin + 4 * mb) * Cout + ca[p];
+      yp[p] = Y + (m_begin + 4 * mb) * Cout + ca[p];
+    }
+#pragma unroll
+    for (int p = 0; p < BP; ++p) xp[p] = X + (m_begin + 4 * mb) * Kc + cb[p];
+
     auto load_a = [&](int ks) {
+      if (ks < nfull) {
+        const int64_t base = (int64_t)ks * 32 * Cout;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int p = 0; p < AP; ++p) {
+            rg[p][i] = *reinterpret_cast<const f32x4*>(gp[p] + base + (int64_t)i * Cout);
+            ry[p][i] = *reinterpret_cast<const f32x4*>(yp[p] + base + (int64_t)i * Cout);
+          }
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         int64_t row = m_begin + (int64_t)ks * 32 + 4 * mb + i;
@@ -466,6 +492,14 @@ pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const
     auto load_b = [&](int ks) {
       const int64_t r0 = m_begin + (int64_t)ks * 32 + 4 * mb;
       if constexpr (!CONV) {
+        if (ks < nfull) {
+          const int64_t base = (int64_t)ks * 32 * Kc;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int p = 0; p < BP; ++p) rx[p][i] = *reinterpret_cast<const f32x4*>(xp[p] + base + (int64_t)i * Kc);
+          return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           int64_t row = r0 + i;
@@ -500,13 +534,16 @@ pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const
     auto store_a = [&](int ks) {
       unsigned char* S = wbase + (ks & 1) * 2 * kStageStride;
       const int64_t row0 = m_begin + (int64_t)ks * 32 + 4 * mb;
+      const bool masked = CONV || ks >= nfull;  // uniform
 #pragma unroll
       for (int p = 0; p < AP; ++p) {
         f32x4 v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[i] = ga[p] * (rg[p][i] - gmean[p]) + gb[p] * (ry[p][i] - ymean[p]);
-          if (row0 + i >= m_end || !va[p]) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the slice contribute nothing
+        for (int i = 0; i < 4; ++i) v[i] = ga[p] * (rg[p][i] - gmean[p]) + gb[p] * (ry[p][i] - ymean[p]);
+        if (masked) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (row0 + i >= m_end || !va[p]) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the slice contribute nothing
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -516,6 +553,7 @@ pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const
     auto store_b = [&](int ks) {
       unsigned char* S = wbase + (ks & 1) * 2 * kStageStride + 3 * APL;
       const int64_t row0 = m_begin + (int64_t)ks * 32 + 4 * mb;
+      const bool masked = ks >= nfull;  // uniform (pointwise)
 #pragma unroll
       for (int p = 0; p < BP; ++p) {
         f32x4 v[4];
@@ -524,9 +562,15 @@ pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const
           if constexpr (!CONV) {
             v[i] = sc[p] * (rx[p][i] - mu[p]) + be[p];
             v[i].x = fmaxf(v[i].x, 0.f); v[i].y = fmaxf(v[i].y, 0.f); v[i].z = fmaxf(v[i].z, 0.f); v[i].w = fmaxf(v[i].w, 0.f);
-            if (row0 + i >= m_end || !vb[p]) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
           } else {
             v[i] = ((bmask >> (4 * p + i)) & 1u) ? rx[p][i] : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+        if constexpr (!CONV) {
+          if (masked) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (row0 + i >= m_end || !vb[p]) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
           }
         }
 #pragma unroll
