@@ -44,11 +44,18 @@ __global__ void __launch_bounds__(kBlock) grad_sqnorm_k(AdamTables t, int chunk_
   const float* g = reinterpret_cast<const float*>(t.ptrs[4 * ti + 1]);
   const int n = min(chunk_size, t.numel[ti] - off);
   float acc = 0.f;
-  if (g)
-    for (int i = threadIdx.x; i < n; i += kBlock) {
-      const float v = g[off + i];
+  if (g) {
+    const float* gc = g + off;
+    const int n4 = ((reinterpret_cast<uintptr_t>(gc) & 15) == 0) ? n / 4 : 0;  // 16-byte body, scalar tail
+    for (int i = threadIdx.x; i < n4; i += kBlock) {
+      const float4 v = ld4(gc + 4 * i);
+      acc = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, acc))));
+    }
+    for (int i = 4 * n4 + threadIdx.x; i < n; i += kBlock) {
+      const float v = gc[i];
       acc = fmaf(v, v, acc);
     }
+  }
   acc = block_sum(acc, red);
   if (threadIdx.x == 0) partial[c] = acc;
 }
@@ -88,17 +95,35 @@ __global__ void __launch_bounds__(kBlock) clip_adam_k(AdamTables t, AdamHyper h,
   const int n = min(chunk_size, t.numel[ti] - off);
   const float lr = h.lr[t.group[ti]], wd = h.wd[t.group[ti]];
   const float step_size = lr / h.bc1, inv_sqrt_bc2 = 1.f / sqrtf(h.bc2);
-  for (int i = threadIdx.x; i < n; i += kBlock) {
-    const int k = off + i;
-    float gr = g[k] * coef;
-    float pv = p[k];
+  auto update = [&](float gr, float& pv, float& mv, float& vv) {
+    gr *= coef;
     if (wd != 0.f) gr = fmaf(wd, pv, gr);  // Adam's L2 form of weight_decay
-    const float mv = fmaf(h.beta1, m[k], (1.f - h.beta1) * gr);
-    const float vv = fmaf(h.beta2, v[k], (1.f - h.beta2) * gr * gr);
+    mv = fmaf(h.beta1, mv, (1.f - h.beta1) * gr);
+    vv = fmaf(h.beta2, vv, (1.f - h.beta2) * gr * gr);
+    const float denom = sqrtf(vv) * inv_sqrt_bc2 + h.eps;
+    pv = pv - step_size * (mv / denom);
+  };
+  p += off; g += off; m += off; v += off;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                         reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+  const int n4 = aligned ? n / 4 : 0;  // 16-byte body (7 streams of 16 B per lane), scalar tail
+  for (int i = threadIdx.x; i < n4; i += kBlock) {
+    const float4 g4 = ld4(g + 4 * i);
+    float4 p4 = ld4(p + 4 * i), m4 = ld4(m + 4 * i), v4 = ld4(v + 4 * i);
+    update(g4.x, p4.x, m4.x, v4.x);
+    update(g4.y, p4.y, m4.y, v4.y);
+    update(g4.z, p4.z, m4.z, v4.z);
+    update(g4.w, p4.w, m4.w, v4.w);
+    st4(m + 4 * i, m4);
+    st4(v + 4 * i, v4);
+    st4(p + 4 * i, p4);
+  }
+  for (int k = 4 * n4 + threadIdx.x; k < n; k += kBlock) {
+    float pv = p[k], mv = m[k], vv = v[k];
+    update(g[k], pv, mv, vv);
     m[k] = mv;
     v[k] = vv;
-    const float denom = sqrtf(vv) * inv_sqrt_bc2 + h.eps;
-    p[k] = pv - step_size * (mv / denom);
+    p[k] = pv;
   }
 }
 

@@ -212,7 +212,7 @@ class ClipAdam(torch.optim.Optimizer):
     clip_grad_norm_(all params, max_norm) - one C-ABI call, two kernel launches, no host sync.
     State layout matches torch.optim.Adam (`step`, `exp_avg`, `exp_avg_sq`)."""
 
-    CHUNK = 16384
+    CHUNK = 4096  # elements per workgroup: ~800 workgroups for the 3.2 M parameters (16384 left most of the 256 CUs idle)
 
     def __init__(self, params, lr=1.0e-3, betas=(0.9, 0.999), eps=1.0e-8, weight_decay=0.0, max_norm: float | None = 1.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
