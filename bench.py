@@ -287,14 +287,20 @@ def main():
         probe = {}
         for mode in (False, True):  # eager first: it then runs exactly as it would without any capture in the process
             use_graph[0] = mode
-            for _ in range(max(args.warmup, 2)):
-                step()
-            sync()
-            tp = time.perf_counter()
-            for _ in range(max(args.steps, 4)):
-                step()
-            sync()
-            probe[mode] = (time.perf_counter() - tp) / max(args.steps, 4) * 1e3
+            try:
+                for _ in range(max(args.warmup, 2)):
+                    step()
+                sync()
+                tp = time.perf_counter()
+                for _ in range(max(args.steps, 4)):
+                    step()
+                sync()
+                probe[mode] = (time.perf_counter() - tp) / max(args.steps, 4) * 1e3
+            except Exception as exc:  # a failed capture must not cost the measurement: eager enqueue always works
+                if not mode:
+                    raise
+                probe[mode] = float("inf")
+                print(f"bench.py: hipGraph capture failed ({type(exc).__name__}: {exc}); using eager enqueue", file=sys.stderr)
         use_graph[0] = probe[True] <= probe[False]
         enqueue_note = f"; warm-up probe: graph replay {probe[True]:.2f} ms/step, eager {probe[False]:.2f} ms/step"
         if not use_graph[0]:
