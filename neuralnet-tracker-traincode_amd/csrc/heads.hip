@@ -38,14 +38,14 @@ __global__ void __launch_bounds__(kBlock) heads_fwd_k(HeadsArgs a, float* __rest
                                                        float* __restrict__ qu, float* __restrict__ Lc,
                                                        float* __restrict__ Lr, float* __restrict__ pts,
                                                        float* __restrict__ shp) {
-  __shared__ float zs[kBlock / kWave][kMaxZ];
+  // One workgroup per sample: its four waves share the rows of the stacked linear layer (the kernel is a chain of
+  // load latencies - a wave per sample left half the CUs idle and took 56 us at B = 512), then wave 0 finishes the sample.
+  __shared__ float zs1[kMaxZ];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int s = blockIdx.x * (kBlock / kWave) + wv;
-  if (s >= a.B) return;  // whole wave exits together
+  const int s = blockIdx.x;
   const float* f = a.feat + (size_t)s * a.F;
-  // four rows of the stacked linear layer at a time: their weight loads are independent, so the wave has 4x the loads in
-  // flight of a row-by-row loop (this kernel is a chain of latencies, not of bandwidth)
-  for (int j0 = 0; j0 < a.NZ; j0 += 4) {
+  // four rows at a time: their weight loads are independent, so a wave has 4x the loads in flight of a row-by-row loop
+  for (int j0 = 4 * wv; j0 < a.NZ; j0 += 4 * (kBlock / kWave)) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int k = lane * 4; k < a.F; k += 256) {
       const float4 fv = ld4(f + k);
@@ -62,14 +62,14 @@ __global__ void __launch_bounds__(kBlock) heads_fwd_k(HeadsArgs a, float* __rest
       const int j = j0 + u;
       if (lane == 0 && j < a.NZ) {
         const float zz = v + a.bcat[j];
-        zs[wv][j] = zz;
+        zs1[j] = zz;
         z[(size_t)s * a.NZ + j] = zz;
       }
     }
   }
-  __builtin_amdgcn_s_waitcnt(0);  // LDS writes of lane 0 visible to the wave (same wave: program order)
-  __builtin_amdgcn_wave_barrier();
-  const float* zz = zs[wv];
+  __syncthreads();
+  if (wv != 0) return;
+  const float* zz = zs1;
   const int id = a.ids ? a.ids[s] : 0;
   const float* prow = a.P ? a.P + 4 * id : nullptr;
   const float* pkrow = a.Pk ? a.Pk + 4 * id : nullptr;
@@ -124,15 +124,25 @@ struct HeadsGradIn {
 // shared tail of the per-sample backward: d shapeparam_i = sum_p <glocal_p, eig_i,p> + direct gradient
 __device__ __forceinline__ void shape_grad(const HeadsArgs& a, const float (*gl)[3], const float* g_shp, int s, int lane, float* dzs,
                                            int zshape) {
-  for (int i = 0; i < 50; ++i) {
+  // lane i owns shape parameter i: the landmark gradients go through a wave-private LDS tile and every lane runs its own
+  // 204-term dot product with 16-byte loads (50 wave-wide reductions in a row made this kernel a 40 us latency chain)
+  __shared__ __attribute__((aligned(16))) float gls[kBlock / kWave][68 * 3];
+  float* mine = gls[threadIdx.x >> 6];
+  int q = 0;
+  for (int pnt = lane; pnt < 68; pnt += 64, ++q) {
+    mine[3 * pnt] = gl[q][0]; mine[3 * pnt + 1] = gl[q][1]; mine[3 * pnt + 2] = gl[q][2];
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 50) {
+    const float* e = a.eig + (size_t)lane * 204;
     float acc = 0.f;
-    int q = 0;
-    for (int pnt = lane; pnt < 68; pnt += 64, ++q) {
-      const float* e = a.eig + ((size_t)i * 68 + pnt) * 3;
-      acc += gl[q][0] * e[0] + gl[q][1] * e[1] + gl[q][2] * e[2];
+#pragma unroll 17
+    for (int k = 0; k < 204; k += 4) {
+      const float4 ev = ld4(e + k), gv = ld4(mine + k);
+      acc = fmaf(ev.x, gv.x, fmaf(ev.y, gv.y, fmaf(ev.z, gv.z, fmaf(ev.w, gv.w, acc))));
     }
-    acc = wave_sum(acc);
-    if (lane == 0) dzs[zshape + i] = acc + g_shp[50 * s + i];
+    dzs[zshape + lane] = acc + g_shp[50 * s + lane];
   }
 }
 
@@ -313,7 +323,7 @@ int ttk_heads_fwd(const float* feat, const float* wcat, const float* bcat, const
   TTK_REQUIRE(!enable_point_head || (pts && shp && keypts && keyeig), "heads_fwd: point-head buffers missing");
   TTK_REQUIRE(!use_offset || (P && (!enable_point_head || Pk)), "heads_fwd: local pose offset parameters missing");
   HeadsArgs a{feat, wcat, bcat, P, Pk, keypts, keyeig, ids, B, F, NZ, enable_uncertainty, enable_point_head, use_offset, enable_6drot};
-  hipLaunchKernelGGL(heads_fwd_k, dim3((B + 3) / 4), dim3(kBlock), 0, (hipStream_t)stream, a, z, roi, coord, rot, qu, Lc, Lr,
+  hipLaunchKernelGGL(heads_fwd_k, dim3(B), dim3(kBlock), 0, (hipStream_t)stream, a, z, roi, coord, rot, qu, Lc, Lr,
                      pts, shp);
   TTK_LAUNCH_CHECK("heads_fwd");
 }
