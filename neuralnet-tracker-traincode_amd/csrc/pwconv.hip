@@ -363,6 +363,8 @@ bool launch_split_gemm(const float* A0, const float* A1, const float* bnA, const
                        const float* bnE, float* part, int64_t M, int K, int Nout, void* wsplit, hipStream_t st);
 
 bool split_gemm_shape(int K, int Nout);
+bool launch_big_fwd(const float* A0, const float* bnA, const void* prepared, float* out, float* part, int64_t M, int K, int Nout,
+                    hipStream_t st);
 
 bool launch_split_wgrad(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
                         int64_t M, int Cin, int Cout, hipStream_t st);
@@ -434,6 +436,16 @@ __global__ void __launch_bounds__(kBlock) pw_prepare_weights_k(PrepArgs a) {
     const float x = w[(int64_t)(r0 + i) * Cin + c0 + tx];
     t[i][tx] = x;
     prep_store(fwd, a.split_fwd[l], r0 + i, c0 + tx, Cout, Cin, x);
+    if (a.split_fwd[l]) {  // third region: the same planes in k16-block order [K/16][Cout][16] (pw_big_k's B layout)
+      uint16_t* q = reinterpret_cast<uint16_t*>(a.out[l] + 12 * n);
+      const int k = c0 + tx, row = r0 + i;
+      const int64_t idx = ((int64_t)(k >> 4) * Cout + row) * 16 + (k & 15);
+      const float r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+      const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+      q[idx] = (uint16_t)(__float_as_uint(x) >> 16);
+      q[n + idx] = (uint16_t)(__float_as_uint(r1) >> 16);
+      q[2 * n + idx] = (uint16_t)(__float_as_uint(r2) >> 16);
+    }
   }
   __syncthreads();
   for (int i = ty; i < 32; i += kBlock / 32) prep_store(bwd, a.split_bwd[l], c0 + i, r0 + tx, Cin, Cout, t[tx][i]);
@@ -450,6 +462,8 @@ int ttk_pwconv1x1_fwd(const float* ydw, const float* bn_dw, const float* w, floa
   TTK_REQUIRE(ydw && bn_dw && y && (w || wsplit), "pwconv1x1_fwd: null pointer");
   TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_fwd: unsupported shape M=%lld Cin=%d Cout=%d (channels: powers of two in 32..1024)", (long long)M, Cin, Cout);
   TTK_REQUIRE(ceil_div(M, BM) <= 65535, "pwconv1x1_fwd: M=%lld too large for one launch", (long long)M);
+  static const bool big = [] { const char* e = getenv("TTK_GEMM"); return e && strcmp(e, "big") == 0; }();
+  if (big && !w && launch_big_fwd(ydw, bn_dw, wsplit, y, part, M, Cin, Cout, (hipStream_t)stream)) { TTK_LAUNCH_CHECK("pwconv1x1_fwd"); }
   launch_gemm<MODE_FWD>(ydw, nullptr, bn_dw, w, y, nullptr, nullptr, part, M, Cin, Cout, wsplit, (hipStream_t)stream);
   TTK_LAUNCH_CHECK("pwconv1x1_fwd");
 }
@@ -499,7 +513,7 @@ int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* bn_pw,
   TTK_LAUNCH_CHECK("pwconv1x1_bwd_weight");
 }
 
-size_t ttk_pwconv_prepared_bytes(int Cin, int Cout) { return (size_t)12 * Cin * Cout; }
+size_t ttk_pwconv_prepared_bytes(int Cin, int Cout) { return (size_t)18 * Cin * Cout; }
 
 int ttk_pwconv_prepare_weights(int n, const float* const* w, const int* cin, const int* cout, void* const* prepared,
                                ttk_stream_t stream) {
