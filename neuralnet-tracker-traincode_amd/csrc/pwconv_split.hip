@@ -821,7 +821,7 @@ pw_big_fwd_k(const float* __restrict__ A0, const float* __restrict__ bnA, const 
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   auto consume = [&](int slot) {
     const unsigned char* S = lds + slot * kBigStride;
-    bf16x8 fa[2][3], fb[3];
+    bf16x8 fa[2][3], fb[3];  // (double-buffering the B fragments was measured slower)
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -867,6 +867,19 @@ pw_big_fwd_k(const float* __restrict__ A0, const float* __restrict__ bnA, const 
 #endif
 #if !(defined(TTK_EXP) && TTK_EXP == 31)
     if (st < nk16) conv_a(blk, set, hf, wslot);
+#endif
+#ifndef TTK_BIG_INTERLEAVE
+#define TTK_BIG_INTERLEAVE 2
+#endif
+#if TTK_BIG_INTERLEAVE > 0
+    // ask the scheduler to thread the conversion's VALU / LDS work through the MFMA stream: an MFMA occupies the matrix
+    // pipe for 32 cycles, during which the wave can issue ~7 independent VALU instructions
+#pragma unroll
+    for (int q = 0; q < 48; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, TTK_BIG_INTERLEAVE, 0);  // VALU
+      __builtin_amdgcn_sched_group_barrier(0x300, 1, 0);  // one LDS access
+    }
 #endif
     int newer = 0;
 #if !(defined(TTK_EXP) && TTK_EXP == 34)

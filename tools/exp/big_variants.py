@@ -6,8 +6,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "neuralne
 import trackertraincode._hip as H
 HERE = os.path.dirname(os.path.abspath(__file__))
 os.environ["TTK_GEMM"] = "big"
-names = {0: "product lib", 31: "no A conversion", 32: "no MFMA phase", 33: "no B transfers", 34: "no A loads"}
-for v in [0, 31, 32, 33, 34]:
+names = {0: "product lib", 31: "no A conversion", 32: "no MFMA phase", 33: "no B transfers", 34: "no A loads", 42: "interleave 2 VALU/MFMA", 44: "interleave 4 VALU/MFMA"}
+for v in [int(a) for a in sys.argv[1:]] or [0, 31, 32, 33, 34]:
     H.LIB_PATH = os.path.join(HERE, "_build", f"libttk_exp{v}.so") if v else H.LIB_PATH
     if v: H._lib = None
     L, p = H.lib(), H.ptr
