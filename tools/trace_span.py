@@ -9,7 +9,7 @@ lo,hi=pairs[-1]
 seq=rows[lo:hi]
 def find(s): return [i for i,r in enumerate(seq) if s in r[2]]
 t0=seq[0][0]
-marks=[("stem_fwd",find("stem_fwd_k")[0]),("avgpool_fwd",find("avgpool_fwd_k")[0]),("heads_fwd",find("heads_fwd_k")[0]),("heads_bwd_sample",find("heads_bwd_sample_k")[0]),("avgpool_bwd",find("avgpool_bwd_k")[0]),("stem_bwd",find("stem_bwd_weight")[0])]
+marks=[("stem_fwd",(find("stem_fwd_mfma_k") or find("stem_fwd_k"))[0]),("avgpool_fwd",find("avgpool_fwd_k")[0]),("heads_fwd",find("heads_fwd_k")[0]),("heads_bwd_sample",find("heads_bwd_sample_k")[0]),("avgpool_bwd",find("avgpool_bwd_k")[0]),("stem_bwd",(find("stem_wgrad_mfma_k") or find("stem_bwd_weight"))[0])]
 for n,i in marks: print(f"{n:18s} start {(seq[i][0]-t0)/1e3:9.1f} us  end {(seq[i][1]-t0)/1e3:9.1f}")
 print("step span", (seq[-1][1]-t0)/1e3, "launches", len(seq), "prev step end->this start gap", (t0-rows[lo-1][1])/1e3)
 busy=0; cur_s,cur_e=seq[0][0],seq[0][1]
