@@ -242,3 +242,33 @@ def test_graphed_train_step_matches_eager():
             assert int(a) == int(b), k
     # an epoch whose loss weights differ forces a re-capture: the signature covers the criterion weights
     assert g._signature(batches, 0)[1] != g._signature(batches, 150)[1]
+
+
+@pytest.mark.parametrize("B", [1, 3, 33])
+def test_training_step_runs_at_ragged_batch_sizes(B):
+    """Every kernel masks its ragged last tile: a full step (fwd, losses, bwd, clip+Adam) at batch sizes that are not
+    multiples of any tile dimension stays finite, and its loss matches the same samples inside a larger batch's eval
+    forward where that is defined (B = 1 has no batch statistics to compare: finiteness only)."""
+    import trackertraincode.train as train
+    from trackertraincode.neuralnets.models import NetworkWithPointHead
+    from trackertraincode.pipelines import SyntheticPoseLoader, Tag
+
+    S = train_script()
+    torch.manual_seed(0)
+    net = NetworkWithPointHead(enable_point_head=True, enable_uncertainty=False, config="mobilenetv1", backbone_args={"use_blurpool": False})
+    g = torch.Generator().manual_seed(7)
+    net.landmarks.deformablekeypoints.set_basis(torch.randn(68, 3, generator=g) * 0.5, torch.randn(50, 68, 3, generator=g) * 0.05)
+    net = net.to(DEV).train()
+    flags = dict(with_pointhead=True, with_nll_loss=False, rampup_nll_losses=False)
+    crit, _ = S.setup_losses(script_args(flags), net)
+    opt, _ = S.create_optimizer(net, script_args(flags))
+    batches = next(iter(SyntheticPoseLoader(B, [(Tag.POSE_WITH_LANDMARKS, 2.0), (Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS, 1.0)], device=DEV, seed=5)))
+    assert sum(b.meta.batchsize for b in batches) == B
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        out = train.training_step(net, batches, 0, crit)
+        out["loss"].backward()
+        opt.step()
+        assert torch.isfinite(out["loss"])
+    assert all(torch.isfinite(q).all() for q in net.parameters())
+    assert all(torch.isfinite(q.grad).all() for q in net.parameters() if q.grad is not None)
