@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libttk_hip.so")
+LIB_PATH = os.environ.get("TTK_LIB") or os.path.join(os.path.dirname(_HERE), "libttk_hip.so")  # TTK_LIB: A/B builds
 
 _P, _I, _L, _F, _D = c_void_p, c_int, c_int64, c_float, c_double
 
