@@ -154,6 +154,7 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
   const bool producer = __builtin_amdgcn_readfirstlane(tid) >= 256;
 
   if (producer) {
+    __builtin_amdgcn_s_setprio(3);  // the producers are the critical path: let them issue ahead of the MFMA waves (-0.35 % step time)
     // ------------------------------------------------------------------ producer waves
     const int pt = tid - 256;
     const int row0 = pt >> 3, kq8 = pt & 7;  // 32 rows per pass; 8 lanes x 16 B = one 128-byte row segment
@@ -415,6 +416,7 @@ pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const
   const bool producer = __builtin_amdgcn_readfirstlane(tid) >= 256;
 
   if (producer) {
+    __builtin_amdgcn_s_setprio(3);
     const int pt = tid - 256;
     const int mb = pt & 7, cq = pt >> 3;  // 8 row blocks of 4 rows x 32 channel quads per pass
     const int sub = mb >> 2, chunk = (mb >> 1) & 1, o8 = (mb & 1) * 8;
