@@ -6,11 +6,12 @@ face-crops/sec forward+backward at per-GPU batch 512).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = zero_grad + forward + multi-task loss + backward of NetworkWithPointHead("mobilenetv1")
-with the training script's default flags (landmark head on) on one synthetic batch that is already
-resident in HBM (+ the RCCL gradient all-reduce, overlapped with backward, when N > 1; weak scaling:
-512 crops per GPU).  The optimiser step is timed separately (`optimizer_ms`), as SURVEY.md §8(d) says.
-Prints ONE JSON line on rank 0.
+One step = zero_grad + forward + multi-task loss + backward + fused clip/Adam step of
+NetworkWithPointHead("mobilenetv1") with the training script's default flags (landmark head on) on one
+synthetic batch that is already resident in HBM (+ the RCCL gradient all-reduce, overlapped with
+backward, when N > 1; weak scaling: 512 crops per GPU).  The optimiser step is INSIDE `value`;
+`optimizer_ms` reports it alone for reference.  `--backbone resnet18` / `--batch 256` time BASELINE
+configs 3 and 2 the same way.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -28,7 +29,7 @@ for p in (REPO, os.path.join(REPO, "neuralnet-tracker-traincode_amd")):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, 32 cycles per issue)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 / fp16 MFMA peak (v_mfma_f32_32x32x16_{bf16,f16}, 32 cycles per issue)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0          # HBM3E spec (6.29 TB/s measured copy)
 ALGO_BYTES_PER_CROP = 55.55e6  # 13 888 321 fp32 elements
@@ -41,6 +42,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="crops per GPU")
+    ap.add_argument("--backbone", default="mobilenetv1", choices=["mobilenetv1", "resnet18"])
+    ap.add_argument("--traffic-json", default=None, help="rocprofv3 PMC summary (tools/pmc_summary.py) taken with THIS build; "
+                    "fills roofline.traffic (null without it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-call HIP-event instrumentation (roofline = null)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel from Python instead of replaying one captured hipGraph")
@@ -79,12 +83,12 @@ class KernelTimer:
             else:
                 by = 4 * (2 * M * co + M * ci + ci * co)
                 if ci >= 128 and co >= 128 and ci * co >= 128 * 256 and (ci % 256 == 0 or co % 256 == 0):
-                    return ("pw_split_wgrad_k<128, 256, false>" if ci % 256 == 0 else "pw_split_wgrad_k<256, 128, false>"), fl, by
+                    return ("pw16_wgrad_k<128, 256>" if ci % 256 == 0 else "pw16_wgrad_k<256, 128>"), fl, by
                 return "pw_wgrad_k", fl, by
             if K >= 128 and N % 256 == 0:
-                return f"pw_split_k<128, 256, {mode}, {mode}, false>", fl, by  # <BM, BN, A-operand form, epilogue form, gather>
+                return f"pw16_k<128, 256, {mode}, {mode}>", fl, by  # <BM, BN, A-operand form, epilogue form>
             if K >= 128 and N == 128:
-                return f"pw_split_k<256, 128, {mode}, {mode}, false>", fl, by
+                return f"pw16_k<256, 128, {mode}, {mode}>", fl, by
             if N == 64 and K == 32:
                 return f"pw_gemm_k<64, 2, 2, {mode}, 1>", fl, by  # single LDS stage
             return (f"pw_gemm_k<{min(N, 128)}, 2, 2, {mode}, 2>" if N >= 64 else f"pw_gemm_k<32, 4, 1, {mode}, 2>"), fl, by
@@ -98,6 +102,13 @@ class KernelTimer:
             n_in, n_out = B * H * W * C, B * ((H - 1) // s_ + 1) * ((W - 1) // s_ + 1) * C
             by = 4 * (2 * n_out + n_in * (2 + bool(a[4]) + bool(a[7] or a[8])))
             return f"dw_bwd_tiled_k<{s_}>", 2 * 2 * 9 * n_out, by
+        if name in ("ttk_conv_fwd", "ttk_conv_bwd_data", "ttk_conv_bwd_weight"):  # ResNet18 implicit GEMMs (split-bf16, 6 products)
+            B, H, W, ci, co, kh, kw, s_, _pad = ints[-9:]
+            Ho, Wo = (H - 1) // s_ + 1, (W - 1) // s_ + 1
+            fl = 2 * B * Ho * Wo * ci * co * kh * kw
+            n_in, n_out = B * H * W * ci, B * Ho * Wo * co
+            by = 4 * {"ttk_conv_fwd": n_in + n_out, "ttk_conv_bwd_data": 2 * n_out + 2 * n_in, "ttk_conv_bwd_weight": 2 * n_out + n_in}[name]
+            return name.replace("ttk_", "") + " (pw_split_k implicit GEMM)", fl, by
         return name, 0, 0
 
     def wrap(self, lib):
@@ -107,7 +118,7 @@ class KernelTimer:
 
         def call(name, *args):
             # only the conv kernels (94 % of the GPU time) are bracketed, and only in the separate roofline pass
-            if not timer.enabled or not (name.startswith("ttk_pwconv1x1") or name.startswith("ttk_dwconv3x3")):
+            if not timer.enabled or not (name.startswith("ttk_pwconv1x1") or name.startswith("ttk_dwconv3x3") or name.startswith("ttk_conv_")):
                 return orig(name, *args)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -116,7 +127,8 @@ class KernelTimer:
             kern, fl, by = timer.work(name, args)
             ints = [x for x in args if isinstance(x, int) and not isinstance(x, bool)]
             timer.records.append((kern, s, e, fl, by))
-            timer.shapes.append(tuple(ints[-4:-1]) if name in ("ttk_pwconv1x1_fwd", "ttk_pwconv1x1_bwd_data") else tuple(ints[-3:]) if name == "ttk_pwconv1x1_bwd_weight" else tuple(ints[-5:]))
+            timer.shapes.append(tuple(ints[-4:-1]) if name in ("ttk_pwconv1x1_fwd", "ttk_pwconv1x1_bwd_data") else tuple(ints[-3:]) if name == "ttk_pwconv1x1_bwd_weight"
+                                else tuple(ints[-9:]) if name.startswith("ttk_conv_") else tuple(ints[-5:]))
 
         lib.call = call
 
@@ -162,7 +174,7 @@ def build_step(args, device):
         return ns
 
     torch.manual_seed(0)
-    net = NetworkWithPointHead(enable_point_head=True, enable_uncertainty=False, config="mobilenetv1",
+    net = NetworkWithPointHead(enable_point_head=True, enable_uncertainty=False, config=args.backbone,
                                backbone_args={"use_blurpool": False})
     g = torch.Generator().manual_seed(7)  # synthetic 3DMM keypoint basis (the real blob is not in the reference)
     net.landmarks.deformablekeypoints.set_basis(torch.randn(68, 3, generator=g) * 0.5, torch.randn(50, 68, 3, generator=g) * 0.05)
@@ -365,19 +377,17 @@ def main():
             # roofline pass.  Depthwise kernels are HBM-bound; pw_split_k runs 6 bf16 MFMA products per fp32 product,
             # so its fp32-equivalent ceiling is the dense bf16 peak / 6; pw_gemm_k / pw_wgrad_k (the early, HBM-bound
             # pointwise layers) are fp32 MFMA kernels priced against HBM.
-            traffic = {}
-            tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath))["kernels"]
+            traffic = json.load(open(args.traffic_json))["kernels"] if args.traffic_json else {}
 
             def roofline_of(k):
                 v = ks[k]
                 sec, launches = v["ms"] * 1e-3, v["calls_per_step"] * roof_steps
-                hbm = not k.startswith("pw_split")
+                products = 3 if k.startswith("pw16") else 6 if "pw_split" in k else 0  # 16-bit MFMA products per fp32 product
+                hbm = products == 0
                 if hbm:
                     ach, peak, unit = v["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s"
                 else:
-                    ach, peak, unit = v["flops"] / sec / 1e12, PEAK_BF16_MFMA_TFLOPS / 6, "TFLOP/s"
+                    ach, peak, unit = v["flops"] / sec / 1e12, PEAK_BF16_MFMA_TFLOPS / products, "TFLOP/s"
                 tr = traffic.get(k)
                 return {"bound": "hbm" if hbm else "mfma", "kernel": k, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                         "traffic": tr["bytes_per_launch"] if tr else None, "algorithmic_bytes_per_launch": v["bytes"] / launches,
@@ -387,28 +397,29 @@ def main():
             order = sorted(ks, key=lambda k: -ks[k]["ms"])
             roof = roofline_of(order[0])
             roof["peak_note"] = ("HBM3E spec 8 TB/s (6.3 TB/s achievable per the MI355X guide)" if roof["bound"] == "hbm"
-                                 else "fp32-equivalent: 2500 TF dense bf16 / 6 piece products")
-            roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; null = not collected)"
+                                 else "fp32-equivalent: 2500 TF dense 16-bit MFMA / piece products per fp32 product (3: fp16 x 2 split, 6: bf16 x 3 split)")
+            roof["traffic_source"] = (args.traffic_json + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build)") if args.traffic_json else None
             roof["pass"] = f"{roof_steps} extra steps after the timed region, HIP events around each conv call, single stream"
             top5 = [roofline_of(k) for k in order[:6]]
         dominant = roof["kernel"] if roof else None
         per_gpu = crops / world
         line = {
-            "metric": "face-crops/sec fwd+bwd @ batch 512", "value": crops, "unit": "crops/s", "n_gpus": world, "steps": args.steps,
+            "metric": f"face-crops/sec fwd+bwd @ batch {args.batch}", "value": crops, "unit": "crops/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "NetworkWithPointHead(mobilenetv1, point head on, NLL off = training-script defaults): "
+            "config": {"workload": f"NetworkWithPointHead({args.backbone}, point head on, NLL off = training-script defaults): "
                                    "zero_grad + fwd + multi-task loss + bwd" + (" + RCCL grad all-reduce overlapped with bwd" if world > 1 else "") + " + fused clip/Adam step",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "input": "129x129x1 f32",
                        "parallelism": f"dp{world}"},
             "roofline": roof,
-            "step_roofline": {"hbm_frac_of_8TBs": per_gpu * ALGO_BYTES_PER_CROP / (PEAK_HBM_GBS * 1e9),
-                              "fp32_mfma_frac_of_157TF": per_gpu * ALGO_FLOP_PER_CROP / (PEAK_FP32_MFMA_TFLOPS * 1e12)},
+            "step_roofline": ({"hbm_frac_of_8TBs": per_gpu * ALGO_BYTES_PER_CROP / (PEAK_HBM_GBS * 1e9),
+                               "fp32_mfma_frac_of_157TF": per_gpu * ALGO_FLOP_PER_CROP / (PEAK_FP32_MFMA_TFLOPS * 1e12)} if args.backbone == "mobilenetv1"
+                              else {"fp32_mfma_frac_of_157TF": per_gpu * 4.203e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12)}),  # 4.203 GFLOP/crop
             "enqueue": ("hipGraph replay (1 capture)" if use_graph[0] else "eager Python launches") + enqueue_note,
             "optimizer_ms": opt_ms, "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3, "loss": float(loss.item()),
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms"])},
-            "gemm_family_TFLOPs": (sum(v["flops"] for k, v in ks.items() if k.startswith("pw_")) /
-                                   max(sum(v["ms"] for k, v in ks.items() if k.startswith("pw_")) * 1e-3, 1e-12) / 1e12) if ks else None,
+            "gemm_family_TFLOPs": (sum(v["flops"] for k, v in ks.items() if k.startswith("pw")) /
+                                   max(sum(v["ms"] for k, v in ks.items() if k.startswith("pw")) * 1e-3, 1e-12) / 1e12) if ks else None,
             "dominant_kernel": dominant, "top_kernels": top5,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -42,7 +42,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 8
+#define TTK_ABI_VERSION 9
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -53,8 +53,19 @@ enum {
   TTK_BN_GA = 4,    /* gamma * rstd                       (backward) */
   TTK_BN_GB = 5,    /* -ga * rstd^2 * mean(g*(y-mean))    (backward) */
   TTK_BN_GMEAN = 6, /* mean(g)                            (backward) */
+  TTK_BN_AUX = 7,   /* magnitude bounds of the tensors this layer forms (TTK_AUX_*), for the fp16-split GEMMs */
   TTK_BN_ROWS = 8
 };
+/* Row TTK_BN_AUX.  The pointwise GEMMs on the fp16 matrix pipe (csrc/pwconv_f16.hip) scale each operand tensor by a
+ * power of two taken from an upper bound of its magnitude; the bounds live here.  They are NON-NEGATIVE floats that
+ * several workgroups raise with an integer atomicMax on the bit pattern, so the row must be ZERO before the forward
+ * pass of a step (the shipped host allocates all blocks of a step from one zeroed arena).  0 = unknown: scale 1.
+ *   ACT_BOUND >= max |max(scale*(y-mean)+beta, 0)|        written by ttk_bn_fwd_finalize (Cauchy-Schwarz on the batch
+ *                                                         variance: |y-mean| <= sqrt(count*var)); eval: stays 0
+ *   GMAX      =  max |g|  of the gradient w.r.t. this layer's output, raised by the kernel that produces g
+ *                                                         (ttk_avgpool_bwd, ttk_dwconv3x3_bwd_data)
+ *   DY_BOUND  >= max |ga*(g-gmean) + gb*(y-mean)|         written by ttk_bn_bwd_finalize from GMAX and the variance */
+enum { TTK_AUX_ACT_BOUND = 0, TTK_AUX_DY_BOUND = 1, TTK_AUX_GMAX = 2 };
 #define TTK_MAX_PARTIAL_ROWS_ELEMENTWISE 1024
 #define TTK_GEMM_BLOCK_M 128
 
@@ -73,7 +84,7 @@ int ttk_partial_rows_gemm(int64_t M);                 /* pointwise (MFMA) kernel
  * num_batches_tracked (int64 scalar on the device, may be NULL) is incremented.
  * ------------------------------------------------------------------------------------------- */
 /* `part` is scratch: when part_rows > 1024 the finalize kernels first fold it IN PLACE to 1024 rows.
- * Writes rows SCALE, BETA, MEAN, RSTD of bn. */
+ * Writes rows SCALE, BETA, MEAN, RSTD of bn and raises bn[TTK_BN_AUX][TTK_AUX_ACT_BOUND]. */
 int ttk_bn_fwd_finalize(float* part, int part_rows, int C, int64_t count,
                         const float* gamma, const float* beta,
                         float* running_mean, float* running_var, int64_t* num_batches_tracked,
@@ -81,7 +92,8 @@ int ttk_bn_fwd_finalize(float* part, int part_rows, int C, int64_t count,
 /* eval mode: SCALE, BETA, MEAN, RSTD from the running statistics. */
 int ttk_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, int C, float* bn, ttk_stream_t stream);
-/* part[row][0][c] = sum(g), part[row][1][c] = sum(g*(y-mean)).  Writes rows GA, GB, GMEAN of bn and
+/* part[row][0][c] = sum(g), part[row][1][c] = sum(g*(y-mean)).  Writes rows GA, GB, GMEAN of bn, raises
+ * bn[TTK_BN_AUX][TTK_AUX_DY_BOUND] (when the producer of g left its maximum in TTK_AUX_GMAX) and writes
  * the parameter gradients dgamma/dbeta (nullable; accumulate != 0: += instead of =). */
 int ttk_bn_bwd_finalize(float* part, int part_rows, int C, int64_t count, const float* gamma,
                         float* bn, float* dgamma, float* dbeta, int accumulate, ttk_stream_t stream);
@@ -113,9 +125,10 @@ int ttk_dwconv3x3_fwd(const float* yprev, const float* bn_prev, const float* ski
  *   g_prev = G * [a_in > 0]                        -> written, with partials sum(g_prev), sum(g_prev*(yprev-mean))
  * a_in (nullable): materialised block input; if NULL it is recomputed from yprev/bn_prev/skip_prev.
  * dw (nullable): FUSED weight gradient dW[C][9] (+)= sum dy_dw * a_in(taps) - every (dy, a_in) pair it
- * needs is already in registers here, so the standalone kernel below is only kept for unit tests. */
+ * needs is already in registers here, so the standalone kernel below is only kept for unit tests.
+ * Raises bn_prev[TTK_BN_AUX][TTK_AUX_GMAX] to max |g_prev| (the bound the previous block's GEMMs scale by). */
 int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* bn_dw, const float* w,
-                           const float* skip_grad, const float* yprev, const float* bn_prev,
+                           const float* skip_grad, const float* yprev, float* bn_prev,
                            const float* skip_prev, const float* a_in, float* g_prev, float* part,
                            float* dw, int dw_accumulate, int B, int H, int W, int C, int stride,
                            ttk_stream_t stream);
@@ -128,9 +141,13 @@ int ttk_dwconv3x3_bwd_weight(const float* g_dw, const float* y_dw, const float* 
 /* ---------------------------------------------------------------------------------------------
  * Pointwise 1x1 conv = GEMM on the matrix cores - DepthWiseBlock.conv_sep, mobilenet_v1.py:67,82.
  *   y[M][Cout] = a_dw[M][Cin] . w[Cout][Cin]^T,   a_dw = max(bn_dw(ydw), 0) on load,  M = B*Ho*Wo
- * Compute-bound shapes run as exact-split bf16 MFMA products (fp32-chain accuracy, csrc/pwconv_split.hip), the
- * HBM-bound early layers on v_mfma_f32_32x32x2_f32.  wsplit (forward and data gradient): scratch of
- * 3 * 2 * Cin * Cout bytes for the pre-split weight operand; NULL selects the fp32 MFMA kernels for every shape.
+ * Compute-bound shapes run as split-operand products on the 16-bit matrix pipe with fp32-chain accuracy: two fp16
+ * pieces per operand and three products (csrc/pwconv_f16.hip; the default), or TTK_GEMM=bf16x3: three bf16 pieces and
+ * six products (csrc/pwconv_split.hip).  The HBM-bound early layers run on v_mfma_f32_32x32x2_f32 (TTK_GEMM=f32mfma:
+ * every layer).  The fp16 form needs the operand bounds of row TTK_BN_AUX: bn_dw[AUX][ACT_BOUND] (forward, weight
+ * gradient), bn_pw[AUX][DY_BOUND] (both gradients).
+ * wsplit (forward and data gradient): scratch of ttk_pwconv_prepared_bytes(Cin, Cout) for the split weight operand,
+ * or a block that ttk_pwconv_prepare_weights filled (then w / wt == NULL); NULL selects the fp32 MFMA kernels.
  * ------------------------------------------------------------------------------------------- */
 int ttk_pwconv1x1_fwd(const float* ydw, const float* bn_dw, const float* w, float* y, float* part,
                       int64_t M, int Cin, int Cout, void* wsplit, ttk_stream_t stream);
@@ -139,14 +156,19 @@ int ttk_pwconv1x1_fwd(const float* ydw, const float* bn_dw, const float* w, floa
 int ttk_pwconv1x1_bwd_data(const float* g, const float* y, const float* bn_pw, const float* wt,
                            const float* ydw, const float* bn_dw, float* g_dw, float* part, int64_t M,
                            int Cin, int Cout, void* wsplit, ttk_stream_t stream);
-/* dw[Cout][Cin] += dy^T . a_dw.  dw must be zeroed (or hold the running gradient) before the call:
- * the M dimension is split over workgroups that add atomically. */
+/* dw[Cout][Cin] += dy^T . a_dw.  dw must be zeroed (or hold the running gradient) before the call.
+ * partial == NULL: the M dimension is split over workgroups that add atomically (fp32 atomics: the result depends on
+ * the order the hardware commits them).  partial = scratch of ttk_pwconv_wgrad_partial_bytes(M, Cin, Cout) (> 0 for
+ * the shapes on the 16-bit pipe): every slice of M stores its tile and a second kernel adds the slices to dw in a
+ * fixed order - bitwise reproducible. */
+size_t ttk_pwconv_wgrad_partial_bytes(int64_t M, int Cin, int Cout);
 int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* bn_pw, const float* ydw,
-                             const float* bn_dw, float* dw, int64_t M, int Cin, int Cout,
+                             const float* bn_dw, float* dw, float* partial, int64_t M, int Cin, int Cout,
                              ttk_stream_t stream);
-/* Weight operands of n (<= 16) pointwise layers in ONE launch (w[i]: [Cout][Cin] fp32 device pointers; w, cin, cout and
- * prepared are HOST arrays).  prepared[i]: device scratch of ttk_pwconv_prepared_bytes(cin[i], cout[i]); pass it as
- * `wsplit` with w == NULL (forward) / wt == NULL (data gradient) to skip the per-call split and transpose launches. */
+/* Weight operands of n (<= 16) pointwise layers (w[i]: [Cout][Cin] fp32 device pointers; w, cin, cout and
+ * prepared are HOST arrays): three launches for all layers (|w| maxima, planes).  prepared[i]: device scratch of
+ * ttk_pwconv_prepared_bytes(cin[i], cout[i]); pass it as `wsplit` with w == NULL (forward) / wt == NULL (data gradient)
+ * to skip the per-call split and transpose launches. */
 size_t ttk_pwconv_prepared_bytes(int Cin, int Cout);
 int ttk_pwconv_prepare_weights(int n, const float* const* w, const int* cin, const int* cout,
                                void* const* prepared, ttk_stream_t stream);
@@ -158,8 +180,9 @@ int ttk_transpose(const float* in, float* out, int rows, int cols, ttk_stream_t 
  * ------------------------------------------------------------------------------------------- */
 int ttk_avgpool_fwd(const float* y, const float* bn, const float* skip, float* feat, int B, int HW,
                     int C, ttk_stream_t stream);
-/* g[B][HW][C] = gfeat[B][C]/HW * [bn(y)+skip > 0]; partials sum(g), sum(g*(y-mean)). */
-int ttk_avgpool_bwd(const float* gfeat, const float* y, const float* bn, const float* skip, float* g,
+/* g[B][HW][C] = gfeat[B][C]/HW * [bn(y)+skip > 0]; partials sum(g), sum(g*(y-mean)); raises
+ * bn[TTK_BN_AUX][TTK_AUX_GMAX] to max |g|. */
+int ttk_avgpool_bwd(const float* gfeat, const float* y, float* bn, const float* skip, float* g,
                     float* part, int B, int HW, int C, ttk_stream_t stream);
 /* a[.][C] = max(bn(y) (+ skip), 0): materialises a post-activation tensor (the `intermediates` list
  * MobileNet.forward returns, mobilenet_v1.py:165-186). */

@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(1024) bn_fwd_finalize_k(const float* __restric
   sm[0][rl][cl] = a;
   sm[1][rl][cl] = b;
   __syncthreads();
+  float bound = 0.f;
   if (rl == 0 && c < C) {
     for (int i = 1; i < 32; ++i) { a += sm[0][i][cl]; b += sm[1][i][cl]; }
     const double mean = a * inv_count;
@@ -50,6 +51,15 @@ __global__ void __launch_bounds__(1024) bn_fwd_finalize_k(const float* __restric
       rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mean);
       rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * var * unbias);
     }
+    // bound of |max(scale*(y-mean)+beta, 0)| over the batch (Cauchy-Schwarz: |y-mean| <= sqrt(sum (y-mean)^2)); the
+    // variance comes from fp32 partial sums through E[y^2]-mean^2, so it is padded by its possible cancellation error
+    const double dev = sqrt((var + 1.0e-6 * (b * inv_count)) / inv_count);
+    bound = (float)(fabs(sc) * dev + fabs((double)beta[c])) * 1.0001f;
+  }
+  if (rl == 0) {  // lanes 0..31 of wave 0
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) bound = fmaxf(bound, __shfl_xor(bound, off));
+    if (cl == 0) atomicMax(reinterpret_cast<unsigned*>(bn + (size_t)TTK_BN_AUX * C + TTK_AUX_ACT_BOUND), __float_as_uint(bound));
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
 }
@@ -86,6 +96,7 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_k(const float* __restric
   sm[0][rl][cl] = a;
   sm[1][rl][cl] = b;
   __syncthreads();
+  float bound = 0.f;
   if (rl == 0 && c < C) {
     for (int i = 1; i < 32; ++i) { a += sm[0][i][cl]; b += sm[1][i][cl]; }
     const double rs = bn[TTK_BN_RSTD * C + c], ga = gamma[c];
@@ -98,6 +109,15 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_k(const float* __restric
       if (accumulate) { dgamma[c] += (float)sum_gx; dbeta[c] += (float)sum_g; }
       else            { dgamma[c] = (float)sum_gx;  dbeta[c] = (float)sum_g; }
     }
+    // bound of |ga*(g-gmean) + gb*(y-mean)|: max|g| from the producer of g, |y-mean| <= sqrt(count*var) <= sqrt(count)/rstd
+    const double gmax = (double)bn[(size_t)TTK_BN_AUX * C + TTK_AUX_GMAX];
+    if (gmax > 0.0)
+      bound = (float)(fabs(A) * (gmax + fabs(sum_g * inv_count)) + fabs(A * rs * rs * b * inv_count) * sqrt(1.0 / inv_count) / rs) * 1.0001f;
+  }
+  if (rl == 0) {
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) bound = fmaxf(bound, __shfl_xor(bound, off));
+    if (cl == 0 && bound > 0.f) atomicMax(reinterpret_cast<unsigned*>(bn + (size_t)TTK_BN_AUX * C + TTK_AUX_DY_BOUND), __float_as_uint(bound));
   }
 }
 

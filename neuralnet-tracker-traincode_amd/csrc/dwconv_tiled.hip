@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 
 dw_bwd_tiled_k(const float* __restrict__ g_dw, const float* __restrict__ y_dw,
                                                           const float* __restrict__ bn_dw, const float* __restrict__ w,
                                                           const float* __restrict__ skip_grad,
-                                                          const float* __restrict__ yprev, const float* __restrict__ bn_prev,
+                                                          const float* __restrict__ yprev, float* __restrict__ bn_prev,
                                                           const float* __restrict__ skip_prev, const float* __restrict__ a_in,
                                                           float* __restrict__ g_prev, float* __restrict__ part,
                                                           float* __restrict__ dwgrad, int B, int H, int W, int C, int Ho, int Wo,
@@ -261,6 +261,7 @@ dw_bwd_tiled_k(const float* __restrict__ g_dw, const float* __restrict__ y_dw,
   const BnApply4 bnp = BnApply4::load(bn_prev, C, c0);
   const BnGrad4 bg = BnGrad4::load(bn_dw, C, c0);
   D4 s1{0.0, 0.0, 0.0, 0.0}, s2{0.0, 0.0, 0.0, 0.0};
+  float gmx = 0.f;  // max |g_prev|: the magnitude bound the previous block's fp16-split GEMMs scale by (ttk.h, TTK_AUX_GMAX)
   float4 wacc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wacc[t] = f4(0.f);
@@ -350,12 +351,16 @@ dw_bwd_tiled_k(const float* __restrict__ g_dw, const float* __restrict__ y_dw,
         if (skip_grad) G = add4(G, sg);
         const float4 gp = mask4(G, a);
         st4(g_prev + (half ? offB : offA), gp);
+        gmx = fmaxf(fmaxf(gmx, fmaxf(fabsf(gp.x), fabsf(gp.y))), fmaxf(fabsf(gp.z), fabsf(gp.w)));
         s1.add(gp);
         s2.addmul(gp, sub4(yp, bnp.mean));
       }
     }
   }
   float* red = lds + stage_floats;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) gmx = fmaxf(gmx, __shfl_xor(gmx, off));
+  if ((tid & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(bn_prev + (size_t)TTK_BN_AUX * C + TTK_AUX_GMAX), __float_as_uint(gmx));
   if (part) slab_partials(s1, s2, q, C, slab * kSlab, part + (size_t)(blockIdx.x / nslabs) * 2 * C, red);
   if (dwgrad) {
     __syncthreads();
@@ -414,7 +419,7 @@ int ttk_dwconv3x3_fwd(const float* yprev, const float* bn_prev, const float* ski
 }
 
 int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* bn_dw, const float* w, const float* skip_grad,
-                           const float* yprev, const float* bn_prev, const float* skip_prev, const float* a_in, float* g_prev,
+                           const float* yprev, float* bn_prev, const float* skip_prev, const float* a_in, float* g_prev,
                            float* part, float* dw, int dw_accumulate, int B, int H, int W, int C, int stride,
                            ttk_stream_t stream) {
   TTK_REQUIRE(g_dw && y_dw && bn_dw && w && yprev && bn_prev && g_prev, "dwconv3x3_bwd_data: null pointer");

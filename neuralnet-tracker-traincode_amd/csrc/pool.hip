@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(kBlock) avgpool_fwd_k(const float* __restrict_
 
 // thread = (sample, pixel, channel quad)
 __global__ void __launch_bounds__(kBlock) avgpool_bwd_k(const float* __restrict__ gfeat, const float* __restrict__ y,
-                                                         const float* __restrict__ bnp, const float* __restrict__ skip, float* __restrict__ g,
+                                                         float* __restrict__ bnp, const float* __restrict__ skip, float* __restrict__ g,
                                                          float* __restrict__ part, int B, int HW, int C, int qshift) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int quads = C >> 2;
@@ -36,6 +36,7 @@ __global__ void __launch_bounds__(kBlock) avgpool_bwd_k(const float* __restrict_
   const float inv = 1.0f / (float)HW;
   const int64_t items = ((int64_t)B * HW) << qshift;
   float4 s1 = f4(0.f), s2 = f4(0.f);
+  float gmx = 0.f;  // max |g| (ttk.h, TTK_AUX_GMAX)
   for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * kBlock) {
     const int64_t pix = idx >> qshift;
     const int n = (int)(pix / HW);
@@ -45,9 +46,13 @@ __global__ void __launch_bounds__(kBlock) avgpool_bwd_k(const float* __restrict_
     float4 gv = ld4(gfeat + (size_t)n * C + 4 * c4);
     gv = mask4(make_float4(gv.x * inv, gv.y * inv, gv.z * inv, gv.w * inv), a);
     st4(g + off, gv);
+    gmx = fmaxf(fmaxf(gmx, fmaxf(fabsf(gv.x), fabsf(gv.y))), fmaxf(fabsf(gv.z), fabsf(gv.w)));
     s1 = add4(s1, gv);
     s2 = fma4(gv, sub4(yv, bn.mean), s2);
   }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) gmx = fmaxf(gmx, __shfl_xor(gmx, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(bnp + (size_t)TTK_BN_AUX * C + TTK_AUX_GMAX), __float_as_uint(gmx));
   if (part) block_channel_partials<1024>(s1, s2, c4, C, part + (size_t)blockIdx.x * 2 * C, smem);
 }
 
@@ -73,7 +78,7 @@ int ttk_avgpool_fwd(const float* y, const float* bn, const float* skip, float* f
   TTK_LAUNCH_CHECK("avgpool_fwd");
 }
 
-int ttk_avgpool_bwd(const float* gfeat, const float* y, const float* bn, const float* skip, float* g,
+int ttk_avgpool_bwd(const float* gfeat, const float* y, float* bn, const float* skip, float* g,
                     float* part, int B, int HW, int C, ttk_stream_t stream) {
   TTK_REQUIRE(gfeat && y && bn && g, "avgpool_bwd: null pointer");
   TTK_REQUIRE(B > 0 && HW > 0 && C >= 32 && C <= 1024 && (C & (C - 1)) == 0, "avgpool_bwd: unsupported shape");

@@ -357,29 +357,51 @@ static bool pw_shape_ok(int64_t M, int Cin, int Cout) {
   return M > 0 && p2(Cin) && p2(Cout);
 }
 
-// pwconv_split.hip: the compute-bound shapes on the bf16 pipe with exact 3-way operand splits
+// pwconv_f16.hip: the compute-bound shapes on the fp16 pipe with 2-piece operand splits (three products) - the default
+template <int MODE>
+bool launch_f16_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
+                     const float* bnE, float* part, int64_t M, int K, int Nout, void* planes, float* wmax, hipStream_t st);
+bool f16_gemm_shape(int K, int Nout);
+bool launch_f16_wgrad(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
+                      float* partial, int64_t M, int Cin, int Cout, hipStream_t st);
+size_t f16_wgrad_partial_bytes(int64_t M, int Cin, int Cout);
+
+// pwconv_split.hip: the same shapes on the bf16 pipe with exact 3-piece splits (six products; TTK_GEMM=bf16x3, and the
+// implicit-GEMM convolutions of the ResNet18 variant)
 template <int MODE>
 bool launch_split_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
                        const float* bnE, float* part, int64_t M, int K, int Nout, void* wsplit, hipStream_t st);
 
 bool split_gemm_shape(int K, int Nout);
-bool launch_big_fwd(const float* A0, const float* bnA, const void* prepared, float* out, float* part, int64_t M, int K, int Nout,
-                    hipStream_t st);
 
 bool launch_split_wgrad(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
                         int64_t M, int Cin, int Cout, hipStream_t st);
 
-static bool use_split_gemm() {
-  // TTK_GEMM=f32mfma keeps every pointwise conv on v_mfma_f32_32x32x2_f32 (A/B timing and numerics comparisons)
-  static const bool on = [] { const char* e = getenv("TTK_GEMM"); return !(e && strcmp(e, "f32mfma") == 0); }();
-  return on;
+enum { GEMM_F16X2 = 0, GEMM_BF16X3 = 1, GEMM_F32 = 2 };
+static int gemm_mode() {
+  // TTK_GEMM=f32mfma keeps every pointwise conv on v_mfma_f32_32x32x2_f32, bf16x3 selects the 3-piece bf16 split
+  // (A/B timing and numerics comparisons)
+  static const int mode = [] {
+    const char* e = getenv("TTK_GEMM");
+    if (e && strcmp(e, "f32mfma") == 0) return (int)GEMM_F32;
+    if (e && strcmp(e, "bf16x3") == 0) return (int)GEMM_BF16X3;
+    return (int)GEMM_F16X2;
+  }();
+  return mode;
 }
+// Layout of a prepared weight block of n = Cin*Cout elements.  fp16 / fp32 modes: [forward operand 4n][data-gradient
+// operand 4n][header: |w| maximum] - an operand is two fp16 planes or, for the shapes that stay on the fp32 kernels,
+// the fp32 rows; bf16 mode: [forward 6n][data gradient 6n].
+static size_t prep_bwd_offset(size_t n) { return gemm_mode() == GEMM_BF16X3 ? 6 * n : 4 * n; }
+static size_t prep_hdr_offset(size_t n) { return gemm_mode() == GEMM_BF16X3 ? 12 * n : 8 * n; }
 
 template <int MODE>
 static void launch_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
-                        const float* bnE, float* part, int64_t M, int K, int Nout, void* wsplit, hipStream_t st) {
-  if (use_split_gemm() && launch_split_gemm<MODE>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, wsplit, st)) return;
-  if (!Bm) Bm = static_cast<const float*>(wsplit);  // prepared operand of a shape that stays on the fp32 kernels
+                        const float* bnE, float* part, int64_t M, int K, int Nout, void* region, float* hdr, hipStream_t st) {
+  const int mode = gemm_mode();
+  if (mode == GEMM_F16X2 && launch_f16_gemm<MODE>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, region, hdr, st)) return;
+  if (mode == GEMM_BF16X3 && launch_split_gemm<MODE>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, region, st)) return;
+  if (!Bm) Bm = static_cast<const float*>(region);  // prepared operand of a shape that stays on the fp32 kernels
   const dim3 blk(kBlock);
   const unsigned gm = (unsigned)ceil_div(M, BM);
   if (Nout >= 128)
@@ -393,7 +415,7 @@ static void launch_gemm(const float* A0, const float* A1, const float* bnA, cons
     hipLaunchKernelGGL((pw_gemm_k<32, 4, 1, MODE>), dim3(gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
 }
 
-// ---- all pointwise layers' weight operands in one launch (ttk_pwconv_prepare_weights) -------------------------------
+// ---- all pointwise layers' weight operands (ttk_pwconv_prepare_weights) -----------------------------------------------
 constexpr int kPrepMax = 16;
 struct PrepArgs {
   const float* w[kPrepMax];
@@ -401,54 +423,78 @@ struct PrepArgs {
   int cin[kPrepMax], cout[kPrepMax];
   int first_tile[kPrepMax + 1];  // 32x32 tiles of w, layer after layer
   int split_fwd[kPrepMax], split_bwd[kPrepMax];
-  int n;
+  int n, mode;
 };
 
-// element (row, k) of a [rows][K] operand: fp32 in place, or the three bf16 planes in pw_split_k's [K/32][rows][32] order
-__device__ __forceinline__ void prep_store(unsigned char* region, bool split, int row, int k, int rows, int K, float x) {
+// element (row, k) of a [rows][K] operand: fp32 in place, or its piece planes in the split kernels' [K/32][rows][32] order
+// (bf16 mode: three exact pieces; fp16 mode: two round-to-nearest pieces of x * s)
+__device__ __forceinline__ void prep_store(unsigned char* region, bool split, int mode, float s, int row, int k, int rows, int K, float x) {
   const int64_t n = (int64_t)rows * K;
-  if (split) {
-    uint16_t* q = reinterpret_cast<uint16_t*>(region);
-    const int64_t idx = ((int64_t)(k >> 5) * rows + row) * 32 + (k & 31);
+  if (!split) {
+    reinterpret_cast<float*>(region)[(int64_t)row * K + k] = x;
+    return;
+  }
+  uint16_t* q = reinterpret_cast<uint16_t*>(region);
+  const int64_t idx = ((int64_t)(k >> 5) * rows + row) * 32 + (k & 31);
+  if (mode == GEMM_BF16X3) {
     const float r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
     const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
     q[idx] = (uint16_t)(__float_as_uint(x) >> 16);
     q[n + idx] = (uint16_t)(__float_as_uint(r1) >> 16);
     q[2 * n + idx] = (uint16_t)(__float_as_uint(r2) >> 16);
   } else {
-    reinterpret_cast<float*>(region)[(int64_t)row * K + k] = x;
+    const float xs = x * s;
+    const _Float16 hh = (_Float16)xs;
+    const _Float16 ll = (_Float16)(xs - (float)hh);
+    q[idx] = __builtin_bit_cast(uint16_t, hh);
+    q[n + idx] = __builtin_bit_cast(uint16_t, ll);
   }
+}
+
+__device__ __forceinline__ int prep_layer(const PrepArgs& a) {
+  int l = 0;
+  while (l + 1 < a.n && (int)blockIdx.x >= a.first_tile[l + 1]) ++l;
+  return l;
+}
+
+__global__ void pw_prepare_zero_k(PrepArgs a) {
+  const int l = threadIdx.x;
+  if (l < a.n) *reinterpret_cast<unsigned*>(a.out[l] + 8 * (int64_t)a.cin[l] * a.cout[l]) = 0u;
+}
+
+// |w| maximum of every layer (non-negative floats order like their bit patterns: integer atomicMax)
+__global__ void __launch_bounds__(kBlock) pw_prepare_absmax_k(PrepArgs a) {
+  const int l = prep_layer(a);
+  const int tile = blockIdx.x - a.first_tile[l];
+  const int Cin = a.cin[l], Cout = a.cout[l];
+  const int tk = Cin / 32, r0 = (tile / tk) * 32, c0 = (tile % tk) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  float m = 0.f;
+  for (int i = ty; i < 32; i += kBlock / 32) m = fmaxf(m, fabsf(a.w[l][(int64_t)(r0 + i) * Cin + c0 + tx]));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(a.out[l] + 8 * (int64_t)Cin * Cout), __float_as_uint(m));
 }
 
 __global__ void __launch_bounds__(kBlock) pw_prepare_weights_k(PrepArgs a) {
   __shared__ float t[32][33];
-  int l = 0;
-  while (l + 1 < a.n && (int)blockIdx.x >= a.first_tile[l + 1]) ++l;
+  const int l = prep_layer(a);
   const int tile = blockIdx.x - a.first_tile[l];
   const int Cin = a.cin[l], Cout = a.cout[l];
   const int tk = Cin / 32, r0 = (tile / tk) * 32, c0 = (tile % tk) * 32;  // r: output channel, c: input channel
   const int64_t n = (int64_t)Cin * Cout;
   const float* w = a.w[l];
   unsigned char* fwd = a.out[l];
-  unsigned char* bwd = a.out[l] + 6 * n;
+  unsigned char* bwd = a.out[l] + (a.mode == GEMM_BF16X3 ? 6 : 4) * n;
+  const float s = a.mode == GEMM_F16X2 ? pow2_scale(*reinterpret_cast<const float*>(a.out[l] + 8 * n)) : 1.f;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int i = ty; i < 32; i += kBlock / 32) {
     const float x = w[(int64_t)(r0 + i) * Cin + c0 + tx];
     t[i][tx] = x;
-    prep_store(fwd, a.split_fwd[l], r0 + i, c0 + tx, Cout, Cin, x);
-    if (a.split_fwd[l]) {  // third region: the same planes in k16-block order [K/16][Cout][16] (pw_big_k's B layout)
-      uint16_t* q = reinterpret_cast<uint16_t*>(a.out[l] + 12 * n);
-      const int k = c0 + tx, row = r0 + i;
-      const int64_t idx = ((int64_t)(k >> 4) * Cout + row) * 16 + (k & 15);
-      const float r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
-      const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-      q[idx] = (uint16_t)(__float_as_uint(x) >> 16);
-      q[n + idx] = (uint16_t)(__float_as_uint(r1) >> 16);
-      q[2 * n + idx] = (uint16_t)(__float_as_uint(r2) >> 16);
-    }
+    prep_store(fwd, a.split_fwd[l], a.mode, s, r0 + i, c0 + tx, Cout, Cin, x);
   }
   __syncthreads();
-  for (int i = ty; i < 32; i += kBlock / 32) prep_store(bwd, a.split_bwd[l], c0 + i, r0 + tx, Cin, Cout, t[tx][i]);
+  for (int i = ty; i < 32; i += kBlock / 32) prep_store(bwd, a.split_bwd[l], a.mode, s, c0 + i, r0 + tx, Cin, Cout, t[tx][i]);
 }
 
 }  // namespace ttk
@@ -462,9 +508,10 @@ int ttk_pwconv1x1_fwd(const float* ydw, const float* bn_dw, const float* w, floa
   TTK_REQUIRE(ydw && bn_dw && y && (w || wsplit), "pwconv1x1_fwd: null pointer");
   TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_fwd: unsupported shape M=%lld Cin=%d Cout=%d (channels: powers of two in 32..1024)", (long long)M, Cin, Cout);
   TTK_REQUIRE(ceil_div(M, BM) <= 65535, "pwconv1x1_fwd: M=%lld too large for one launch", (long long)M);
-  static const bool big = [] { const char* e = getenv("TTK_GEMM"); return e && strcmp(e, "big") == 0; }();
-  if (big && !w && launch_big_fwd(ydw, bn_dw, wsplit, y, part, M, Cin, Cout, (hipStream_t)stream)) { TTK_LAUNCH_CHECK("pwconv1x1_fwd"); }
-  launch_gemm<MODE_FWD>(ydw, nullptr, bn_dw, w, y, nullptr, nullptr, part, M, Cin, Cout, wsplit, (hipStream_t)stream);
+  unsigned char* ws = static_cast<unsigned char*>(wsplit);
+  const size_t n = (size_t)Cin * Cout;
+  launch_gemm<MODE_FWD>(ydw, nullptr, bn_dw, w, y, nullptr, nullptr, part, M, Cin, Cout, ws, ws ? reinterpret_cast<float*>(ws + prep_hdr_offset(n)) : nullptr,
+                        (hipStream_t)stream);
   TTK_LAUNCH_CHECK("pwconv1x1_fwd");
 }
 
@@ -472,19 +519,29 @@ int ttk_pwconv1x1_bwd_data(const float* g, const float* y, const float* bn_pw, c
                            const float* bn_dw, float* g_dw, float* part, int64_t M, int Cin, int Cout, void* wsplit,
                            ttk_stream_t stream) {
   TTK_REQUIRE(g && y && bn_pw && (wt || wsplit) && ydw && bn_dw && g_dw, "pwconv1x1_bwd_data: null pointer");
-  if (!wt) wsplit = static_cast<unsigned char*>(wsplit) + (size_t)6 * Cin * Cout;  // data-gradient half of a prepared block
   TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_bwd_data: unsupported shape");
   TTK_REQUIRE(ceil_div(M, BM) <= 65535, "pwconv1x1_bwd_data: M too large for one launch");
+  unsigned char* ws = static_cast<unsigned char*>(wsplit);
+  const size_t n = (size_t)Cin * Cout;
+  unsigned char* region = (ws && !wt) ? ws + prep_bwd_offset(n) : ws;  // data-gradient half of a prepared block
   // contraction over Cout, output columns = Cin, B operand = wt[Cin][Cout]
-  launch_gemm<MODE_DGRAD>(g, y, bn_pw, wt, g_dw, ydw, bn_dw, part, M, Cout, Cin, wsplit, (hipStream_t)stream);
+  launch_gemm<MODE_DGRAD>(g, y, bn_pw, wt, g_dw, ydw, bn_dw, part, M, Cout, Cin, region, ws ? reinterpret_cast<float*>(ws + prep_hdr_offset(n)) : nullptr,
+                          (hipStream_t)stream);
   TTK_LAUNCH_CHECK("pwconv1x1_bwd_data");
 }
 
+size_t ttk_pwconv_wgrad_partial_bytes(int64_t M, int Cin, int Cout) {
+  return (gemm_mode() == GEMM_F16X2 && pw_shape_ok(M, Cin, Cout)) ? f16_wgrad_partial_bytes(M, Cin, Cout) : 0;
+}
+
 int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
-                             int64_t M, int Cin, int Cout, ttk_stream_t stream) {
+                             float* partial, int64_t M, int Cin, int Cout, ttk_stream_t stream) {
   TTK_REQUIRE(g && y && bn_pw && ydw && bn_dw && dw, "pwconv1x1_bwd_weight: null pointer");
   TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_bwd_weight: unsupported shape");
-  if (use_split_gemm() && launch_split_wgrad(g, y, bn_pw, ydw, bn_dw, dw, M, Cin, Cout, (hipStream_t)stream)) {
+  if (gemm_mode() == GEMM_F16X2 && launch_f16_wgrad(g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, (hipStream_t)stream)) {
+    TTK_LAUNCH_CHECK("pwconv1x1_bwd_weight");
+  }
+  if (gemm_mode() == GEMM_BF16X3 && launch_split_wgrad(g, y, bn_pw, ydw, bn_dw, dw, M, Cin, Cout, (hipStream_t)stream)) {
     TTK_LAUNCH_CHECK("pwconv1x1_bwd_weight");
   }
   const int bn = Cout >= 128 ? 128 : Cout, bk = Cin >= 128 ? 128 : Cin;
@@ -513,13 +570,17 @@ int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* bn_pw,
   TTK_LAUNCH_CHECK("pwconv1x1_bwd_weight");
 }
 
-size_t ttk_pwconv_prepared_bytes(int Cin, int Cout) { return (size_t)18 * Cin * Cout; }
+size_t ttk_pwconv_prepared_bytes(int Cin, int Cout) {
+  const size_t n = (size_t)Cin * Cout;
+  return prep_hdr_offset(n) + 64;
+}
 
 int ttk_pwconv_prepare_weights(int n, const float* const* w, const int* cin, const int* cout, void* const* prepared,
                                ttk_stream_t stream) {
   TTK_REQUIRE(n > 0 && n <= kPrepMax && w && cin && cout && prepared, "pwconv_prepare_weights: bad arguments (1..16 layers)");
   PrepArgs a{};
   a.n = n;
+  a.mode = gemm_mode();
   int tiles = 0;
   for (int i = 0; i < n; ++i) {
     TTK_REQUIRE(w[i] && prepared[i] && pw_shape_ok(1, cin[i], cout[i]), "pwconv_prepare_weights: layer %d: null pointer or unsupported shape", i);
@@ -529,11 +590,16 @@ int ttk_pwconv_prepare_weights(int n, const float* const* w, const int* cin, con
     a.cout[i] = cout[i];
     a.first_tile[i] = tiles;
     tiles += (cin[i] / 32) * (cout[i] / 32);
-    a.split_fwd[i] = use_split_gemm() && split_gemm_shape(cin[i], cout[i]);
-    a.split_bwd[i] = use_split_gemm() && split_gemm_shape(cout[i], cin[i]);
+    a.split_fwd[i] = a.mode == GEMM_F16X2 ? f16_gemm_shape(cin[i], cout[i]) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cin[i], cout[i]));
+    a.split_bwd[i] = a.mode == GEMM_F16X2 ? f16_gemm_shape(cout[i], cin[i]) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cout[i], cin[i]));
   }
   a.first_tile[n] = tiles;
-  hipLaunchKernelGGL(pw_prepare_weights_k, dim3(tiles), dim3(kBlock), 0, (hipStream_t)stream, a);
+  hipStream_t st = (hipStream_t)stream;
+  if (a.mode == GEMM_F16X2) {
+    hipLaunchKernelGGL(pw_prepare_zero_k, dim3(1), dim3(kPrepMax), 0, st, a);
+    hipLaunchKernelGGL(pw_prepare_absmax_k, dim3(tiles), dim3(kBlock), 0, st, a);
+  }
+  hipLaunchKernelGGL(pw_prepare_weights_k, dim3(tiles), dim3(kBlock), 0, st, a);
   TTK_LAUNCH_CHECK("pwconv_prepare_weights");
 }
 

@@ -1,0 +1,636 @@
+// Pointwise 1x1 convolutions of the compute-bound layers as fp32 GEMMs on the fp16 matrix pipe with a 2-piece
+// round-to-nearest operand split.  Reference: DepthWiseBlock.conv_sep + bn_sep, backbones/mobilenet_v1.py:67-68,82-84.
+//
+// Arithmetic.  Every fp32 operand value x of a tensor with a known magnitude bound is scaled by a power of two S (exact)
+// so that |x S| < 2^15 and cut into two fp16 pieces,
+//     h = fp16(x S)  (round to nearest, 11 significant bits),   l = fp16(x S - h)   (the next 11 bits; x S - h is exact),
+// so x S = h + l up to 2^-23 |x S|.  A product a*b is accumulated in fp32 as  h_a l_b + l_a h_b + h_a h_b  (three
+// v_mfma_f32_32x32x16_f16, each piece product exact in fp32; the dropped l_a l_b is below 2^-24 |a b|) and the tile is
+// multiplied by 1/(S_a S_b) on its way out.  Measured against an fp64 product this is as close as a chain of fp32 fmas
+// (tests/test_pwconv_gpu.py holds every shape to that criterion; tools/exp/split16.py is the numpy model) - the same
+// accuracy class as the 3-piece bf16 split of pwconv_split.hip (six products) at HALF the matrix work, two thirds of
+// the LDS and L2 bytes and a cheaper conversion (v_cvt_pk_f16_f32 instead of mask/subtract chains).
+//
+// Range.  fp16 has 5 exponent bits: pieces below 2^-14 lose bits and anything above 65504 overflows, so each operand
+// tensor carries an upper bound of its magnitude (row TTK_BN_AUX of the BatchNorm block that forms it, include/ttk.h):
+// S = 2^(14 - floor(log2 bound)).  Elements down to 2^-17 of the bound keep all 22 bits; smaller ones keep an ABSOLUTE
+// error of 2^-40 of the bound, far below the fp32 rounding of the elements that dominate a sum.  Bounds come from the
+// statistics the step has anyway (bn.hip: Cauchy-Schwarz on the batch variance forward, the producer's max|g| backward).
+//
+// Structure: as pwconv_split.hip (one workgroup = 8 waves = one CU; waves 4-7 produce - global loads, BatchNorm form,
+// split, ds_write into a ring of 2 x 2 k16 stages; waves 0-3 consume - ds_read_b128 fragments + MFMAs on (BM/2)x(BN/2)
+// wave tiles; one s_barrier per k32), with two piece planes per operand.
+#include "ttk_common.h"
+#include "conv_geom.h"
+
+namespace ttk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+enum { SMODE_FWD = 0, SMODE_DGRAD = 1 };
+
+constexpr int kStage16 = 64 * (128 + 256);  // 2 planes x 32 B x (BM + BN) rows of one k16 stage
+constexpr int kStride16 = kStage16 + 64;    // the two k16 halves of a producer wave's ds_write_b64 use different banks
+constexpr int kRing16 = 4 * kStride16;      // 2 super-stages (k32) x 2 k16 stages
+
+__device__ __forceinline__ int swz16(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 3) & 1)) << 4); }
+
+// 2-piece split of 4 consecutive-k values (already scaled); writes the two 8-byte pieces at dst and dst + plane
+__device__ __forceinline__ void split_store16(f32x4 v, unsigned char* dst, int plane) {
+  const f16x2 h01 = __builtin_convertvector(f32x2{v.x, v.y}, f16x2), h23 = __builtin_convertvector(f32x2{v.z, v.w}, f16x2);
+  const f32x2 f01 = __builtin_convertvector(h01, f32x2), f23 = __builtin_convertvector(h23, f32x2);
+  const f16x2 l01 = __builtin_convertvector(f32x2{v.x - f01.x, v.y - f01.y}, f16x2);
+  const f16x2 l23 = __builtin_convertvector(f32x2{v.z - f23.x, v.w - f23.y}, f16x2);
+  *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+  *reinterpret_cast<uint2*>(dst + plane) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+}
+
+// The consumer side of one block tile: `nks` super-stages (k32) of ds_read_b128 fragments + 3-product MFMAs into
+// acc[TM][TN].  Executes exactly 1 + nks barriers (matching the producers).
+template <int BM, int BN>
+__device__ __forceinline__ void consume_tile16(const unsigned char* lds, int nks, int wm, int wn, int r, int h,
+                                               f32x16 (&acc)[BM / 64][BN / 64]) {
+  constexpr int APL = BM * 32, BPL = BN * 32;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr bool HOLD_A = TM <= TN;  // hold the smaller fragment set in registers, stream the other
+  constexpr int TH = HOLD_A ? TM : TN, TS = HOLD_A ? TN : TM;
+  int hold_off[TH], strm_off[TS];
+#pragma unroll
+  for (int x = 0; x < TH; ++x)
+    hold_off[x] = HOLD_A ? swz16(wm * (BM / 2) + x * 32 + r, h) : 2 * APL + swz16(wn * (BN / 2) + x * 32 + r, h);
+#pragma unroll
+  for (int x = 0; x < TS; ++x)
+    strm_off[x] = HOLD_A ? 2 * APL + swz16(wn * (BN / 2) + x * 32 + r, h) : swz16(wm * (BM / 2) + x * 32 + r, h);
+  constexpr int HPL = HOLD_A ? APL : BPL, SPL = HOLD_A ? BPL : APL;
+
+  f16x8 hold[TH][2], hold_n[TH][2], strm[2][2];
+  __syncthreads();  // super-stage 0 is in LDS
+  for (int it = 0; it < nks; ++it) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const unsigned char* S = lds + ((it & 1) * 2 + sub) * kStride16;
+      if (sub == 0) {  // first stage after the barrier: nothing could be prefetched across it
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+          for (int x = 0; x < TH; ++x) hold[x][p] = *reinterpret_cast<const f16x8*>(S + p * HPL + hold_off[x]);
+          strm[0][p] = *reinterpret_cast<const f16x8*>(S + p * SPL + strm_off[0]);
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < TS; ++x) {
+        const int cur = (sub * TS + x) & 1;
+        if (x + 1 < TS) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) strm[cur ^ 1][p] = *reinterpret_cast<const f16x8*>(S + p * SPL + strm_off[x + 1]);
+        } else if (sub == 0) {
+          const unsigned char* S2 = S + kStride16;
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int y = 0; y < TH; ++y) hold_n[y][p] = *reinterpret_cast<const f16x8*>(S2 + p * HPL + hold_off[y]);
+            strm[cur ^ 1][p] = *reinterpret_cast<const f16x8*>(S2 + p * SPL + strm_off[0]);
+          }
+        }
+        // three piece products, smallest first; (pa, pb) index the A and B pieces (0 = h, 1 = l)
+#define TTK_PROD16(pa, pb)                                                                                      \
+  _Pragma("unroll") for (int y = 0; y < TH; ++y) {                                                              \
+  if constexpr (HOLD_A)                                                                                       \
+    acc[y][x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hold[y][pa], strm[cur][pb], acc[y][x], 0, 0, 0);       \
+  else                                                                                                        \
+    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(strm[cur][pa], hold[y][pb], acc[x][y], 0, 0, 0);       \
+  }
+        TTK_PROD16(0, 1) TTK_PROD16(1, 0) TTK_PROD16(0, 0)
+#undef TTK_PROD16
+      }
+      if (sub == 0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int y = 0; y < TH; ++y) hold[y][p] = hold_n[y][p];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// A: fp32 rows [M][K] (formed on load: forward relu(bn(y)), data gradient ga*(g-gmean)+gb*(y-mean)), bound in
+// bnA[TTK_BN_AUX][AMODE == BNRELU ? TTK_AUX_ACT_BOUND : TTK_AUX_DY_BOUND]; Bq: two fp16 planes [K/32][Nout][32] of the
+// weights scaled by pow2_scale(*wmax).
+template <int BM, int BN, int AMODE, int EMODE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+pw16_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* __restrict__ bnA,
+       const uint16_t* __restrict__ Bq, const float* __restrict__ wmax, float* __restrict__ out, const float* __restrict__ E0,
+       const float* __restrict__ bnE, float* __restrict__ part, int64_t M, int K, int Nout) {
+  static_assert((BM == 128 && BN == 256) || (BM == 256 && BN == 128), "tile shapes");
+  constexpr int APL = BM * 32, BPL = BN * 32;  // bytes of one piece plane of a k16 stage
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int LDC = BN + 4;
+  constexpr int QN = BN / 4, RG = 512 / QN, HALVES = BM / 128, RGH = RG / HALVES;
+  constexpr int kEpiBytes = BM * LDC * 4 + RG * 2 * BN * 4;
+  constexpr int kSmemBytes = kRing16 > kEpiBytes ? kRing16 : kEpiBytes;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kSmemBytes];
+
+  const int tid = threadIdx.x;
+  // XCD-aware tile order (see pwconv.hip): every XCD gets a contiguous range of tiles.
+  const unsigned G = gridDim.x, Lid = blockIdx.x, NB = Nout / BN;
+  const unsigned xq = G / 8, xr = G % 8, xcd = Lid % 8;
+  const unsigned tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + Lid / 8;
+  const unsigned bx = tile % NB, by = tile / NB;
+  const int64_t m0 = (int64_t)by * BM;
+  const int n0 = bx * BN;
+  const int nks = K / 32;
+  const bool producer = __builtin_amdgcn_readfirstlane(tid) >= 256;
+  const float sa = pow2_scale(bnA[(size_t)TTK_BN_AUX * K + (AMODE == AMODE_BNRELU ? TTK_AUX_ACT_BOUND : TTK_AUX_DY_BOUND)]);
+  const float sb = pow2_scale(*wmax);
+
+  if (producer) {
+    __builtin_amdgcn_s_setprio(3);
+    const int pt = tid - 256;
+    const int row0 = pt >> 3, kq8 = pt & 7;  // 32 rows per pass; 8 lanes x 16 B = one 128-byte row segment
+    const int sub = kq8 >> 2, chunk = (kq8 >> 1) & 1, o8 = (kq8 & 1) * 8;
+    constexpr int AP = BM / 32;
+    f32x4 ra0[AP], ra1[AMODE == AMODE_BNGRAD ? AP : 1], q0, q1, q2, q3;
+    constexpr int BI = BN / 64;  // B rows per thread and piece plane: 64 rows x 4 chunks of 16 B (8 k) per pass
+    u32x4 rb[2][BI];
+    int64_t arow[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      int64_t row = m0 + row0 + 32 * i;
+      arow[i] = (row < M ? row : M - 1) * (int64_t)K + kq8 * 4;  // clamp: rows past M are computed but never stored
+    }
+    const int brow = pt >> 2, bc4 = pt & 3;
+    const uint16_t* bp = Bq + (int64_t)(n0 + brow) * 32 + bc4 * 8;
+    const int64_t bplane = (int64_t)K * Nout;
+    unsigned char* wbase_b = lds + (bc4 >> 1) * kStride16 + 2 * APL;
+    const float* cp = bnA + kq8 * 4;
+    unsigned char* wbase = lds + sub * kStride16 + o8;
+
+    auto load_a = [&](int ks) {
+      const int kc0 = ks * 32;
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        ra0[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A0 + arow[i] + kc0));
+        if constexpr (AMODE == AMODE_BNGRAD) ra1[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A1 + arow[i] + kc0));
+      }
+      // the scale S_a rides on the per-channel constants (exact: a power of two)
+      if constexpr (AMODE == AMODE_BNRELU) {
+        q0 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_SCALE * K + kc0) * sa;
+        q1 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * K + kc0);
+        q2 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_BETA * K + kc0) * sa;
+      } else {
+        q0 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GA * K + kc0) * sa;
+        q1 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GMEAN * K + kc0);
+        q2 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GB * K + kc0) * sa;
+        q3 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * K + kc0);
+      }
+    };
+    auto load_b = [&](int ks) {
+      const uint16_t* b = bp + (int64_t)ks * Nout * 32;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < BI; ++i) rb[p][i] = *reinterpret_cast<const u32x4*>(b + p * bplane + 64 * 32 * i);
+    };
+    auto store_a = [&](int ks) {
+      unsigned char* S = wbase + (ks & 1) * 2 * kStride16;
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        f32x4 v;
+        if constexpr (AMODE == AMODE_BNRELU) {
+          v = q0 * (ra0[i] - q1) + q2;
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        } else {
+          v = q0 * (ra0[i] - q1) + q2 * (ra1[i] - q3);
+        }
+        split_store16(v, S + swz16(row0 + 32 * i, chunk), APL);
+      }
+    };
+    auto store_b = [&](int ks) {  // no arithmetic: 16-byte chunks (8 k of one piece) straight into the ring
+      unsigned char* S = wbase_b + (ks & 1) * 2 * kStride16;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<u32x4*>(S + p * BPL + swz16(brow + 64 * i, bc4 & 1)) = rb[p][i];
+    };
+
+    // B is consumed first in a step and reloaded at once, then A: every load has a whole step to land
+    load_b(0);
+    load_a(0);
+    __builtin_amdgcn_sched_barrier(0);
+    store_b(0);
+    if (nks > 1) load_b(1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_a(0);
+    if (nks > 1) load_a(1);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // super-stage 0 is in LDS
+    for (int it = 0; it < nks; ++it) {
+      if (it + 1 < nks) {
+        store_b(it + 1);
+        if (it + 2 < nks) load_b(it + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        store_a(it + 1);
+        if (it + 2 < nks) load_a(it + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+  } else {
+    const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    consume_tile16<BM, BN>(lds, nks, wm, wn, r, h, acc);
+    // ---- accumulators -> LDS image [BM][LDC] (the ring is dead: the loop ended with a barrier)
+    float* Cs = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int col = wn * (BN / 2) + j * 32 + r;
+          Cs[row * LDC + col] = acc[i][j][e];
+        }
+  }
+  __syncthreads();
+
+  // ---- epilogue, all 8 waves: row-wise pass over the C image - un-scale, 16-byte stores (a wave writes 1 KB row
+  // segments), the ReLU mask of the data gradient, and the BatchNorm partial sums of this tile's 128-row halves.
+  const float inv = 1.f / (sa * sb);  // exact: a power of two
+  const float* Cs = reinterpret_cast<const float*>(lds);
+  float* red = reinterpret_cast<float*>(lds + BM * LDC * 4);  // [RG][2][BN]
+  const int c4 = tid % QN, rg = tid / QN, half = rg / RGH, rr = rg % RGH;
+  const int col = n0 + 4 * c4;
+  float4 esc = f4(0.f), emean = f4(0.f), ebeta = f4(0.f);
+  if constexpr (EMODE == EMODE_MASK) {
+    esc = ld4(bnE + TTK_BN_SCALE * Nout + col); emean = ld4(bnE + TTK_BN_MEAN * Nout + col); ebeta = ld4(bnE + TTK_BN_BETA * Nout + col);
+  }
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+#pragma unroll 4
+  for (int i = 0; i < 128 / RGH; ++i) {
+    const int row = half * 128 + rr + RGH * i;
+    const int64_t grow = m0 + row;
+    if (grow >= M) break;
+    float4 v = ld4(Cs + row * LDC + 4 * c4);
+    v = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+    const size_t o = (size_t)grow * Nout + col;
+    if constexpr (EMODE == EMODE_STATS) {
+      st4(out + o, v);
+      s1 = add4(s1, v);
+      s2 = fma4(v, v, s2);
+    } else {
+      const float4 yc = sub4(ld4(E0 + o), emean);
+      v = mask4(v, fma4(esc, yc, ebeta));
+      st4(out + o, v);
+      s1 = add4(s1, v);
+      s2 = fma4(v, yc, s2);
+    }
+  }
+  if (part) {
+    st4(red + (rg * 2 + 0) * BN + 4 * c4, s1);
+    st4(red + (rg * 2 + 1) * BN + 4 * c4, s2);
+    __syncthreads();
+    for (int i = tid; i < HALVES * 2 * BN; i += 512) {
+      const int hf = i / (2 * BN), which = (i / BN) & 1, c = i % BN;
+      float a = 0.f;
+      for (int q = 0; q < RGH; ++q) a += red[((hf * RGH + q) * 2 + which) * BN + c];  // fixed order: reproducible
+      const int64_t prow = (int64_t)by * HALVES + hf;
+      if (prow * 128 < M) part[(size_t)prow * 2 * Nout + (size_t)which * Nout + n0 + c] = a;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient  dW[co][ci] += sum_m dy[m][co] * a[m][ci]: the contraction runs over the rows m, so the MFMA
+// fragments need 8 CONSECUTIVE m of one channel.  Each producer thread loads a 4 (rows) x 4 (channels) block - four
+// 16-byte loads, lanes of a row group side by side in the channel direction (128-byte segments) - and the
+// transposition is register naming: register e of the four rows IS the 4 consecutive m of channel e.
+// grid.x = dW tiles, grid.y = slices of M.  partial == nullptr: one fp32 atomicAdd per output element and slice;
+// otherwise (deterministic mode) slice s stores its tile to partial[s][Cout][Cin] and wgrad_reduce_k folds the slices
+// in a fixed order.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const float* __restrict__ bn_pw,
+             const float* __restrict__ X, const float* __restrict__ bn_x, float* __restrict__ dW, float* __restrict__ partial,
+             int64_t M, int Cin, int Cout, int64_t rows_per_slice) {
+  static_assert(BM + BN == 384 && (BM == 128 || BM == 256), "128x256 or 256x128");
+  constexpr int APL = BM * 32, BPL = BN * 32;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kRing16];
+
+  const int tid = threadIdx.x;
+  // XCD-aware order: give each XCD whole slices (all dW tiles of a slice run side by side on ONE L2, so the slice's
+  // operand rows are fetched from HBM once, not once per tile).
+  const unsigned T = gridDim.x, NG = T * gridDim.y, Lid = blockIdx.y * T + blockIdx.x;
+  const unsigned xq = NG / 8, xr = NG % 8, xcd = Lid % 8;
+  const unsigned logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + Lid / 8;
+  const unsigned tile = logical % T, slice = logical / T;
+  const int tiles_k = Cin / BN;
+  const int n0 = (tile / tiles_k) * BM, k0 = (tile % tiles_k) * BN;
+  const int64_t m_begin = (int64_t)slice * rows_per_slice;
+  const int64_t m_end = (m_begin + rows_per_slice < M) ? m_begin + rows_per_slice : M;
+  if (m_begin >= m_end) return;  // uniform over the block, before any barrier (deterministic mode: the host sizes the slices so that none is empty)
+  const int nks = (int)((m_end - m_begin + 31) / 32);
+  const bool producer = __builtin_amdgcn_readfirstlane(tid) >= 256;
+  const float sa = pow2_scale(bn_pw[(size_t)TTK_BN_AUX * Cout + TTK_AUX_DY_BOUND]);
+  const float sb = pow2_scale(bn_x[(size_t)TTK_BN_AUX * Cin + TTK_AUX_ACT_BOUND]);
+
+  if (producer) {
+    __builtin_amdgcn_s_setprio(3);
+    const int pt = tid - 256;
+    const int mb = pt & 7, cq = pt >> 3;  // 8 row blocks of 4 rows x 32 channel quads per pass
+    const int sub = mb >> 2, chunk = (mb >> 1) & 1, o8 = (mb & 1) * 8;
+    constexpr int AP = BM / 128, BP = BN / 128;
+    f32x4 rg[AP][4], ry[AP][4], rx[BP][4];
+    f32x4 ga[AP], gb[AP], gmean[AP], ymean[AP], sc[BP], mu[BP], be[BP];
+    int ca[AP], cb[BP];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      ca[p] = n0 + 4 * (cq + 32 * p);
+      ga[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GA * Cout + ca[p]) * sa;
+      gb[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GB * Cout + ca[p]) * sa;
+      gmean[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GMEAN * Cout + ca[p]);
+      ymean[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_MEAN * Cout + ca[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < BP; ++p) {
+      cb[p] = k0 + 4 * (cq + 32 * p);
+      sc[p] = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_SCALE * Cin + cb[p]) * sb;
+      mu[p] = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_MEAN * Cin + cb[p]);
+      be[p] = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_BETA * Cin + cb[p]) * sb;
+    }
+    unsigned char* wbase = lds + sub * kStride16 + o8;
+
+    // Steps whose 32 rows all lie inside the slice (all but possibly the last one) take a path without row clamps and
+    // zero fills.
+    const int nfull = (int)((m_end - m_begin) / 32);
+    const float* gp[AP];
+    const float* yp[AP];
+    const float* xp[BP];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      gp[p] = G + (m_begin + 4 * mb) * Cout + ca[p];
+      yp[p] = Y + (m_begin + 4 * mb) * Cout + ca[p];
+    }
+#pragma unroll
+    for (int p = 0; p < BP; ++p) xp[p] = X + (m_begin + 4 * mb) * Cin + cb[p];
+
+    auto load_a = [&](int ks) {
+      if (ks < nfull) {
+        const int64_t base = (int64_t)ks * 32 * Cout;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int p = 0; p < AP; ++p) {
+            rg[p][i] = *reinterpret_cast<const f32x4*>(gp[p] + base + (int64_t)i * Cout);
+            ry[p][i] = *reinterpret_cast<const f32x4*>(yp[p] + base + (int64_t)i * Cout);
+          }
+        return;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int64_t row = m_begin + (int64_t)ks * 32 + 4 * mb + i;
+        row = row < m_end ? row : m_end - 1;
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+          rg[p][i] = *reinterpret_cast<const f32x4*>(G + row * Cout + ca[p]);
+          ry[p][i] = *reinterpret_cast<const f32x4*>(Y + row * Cout + ca[p]);
+        }
+      }
+    };
+    auto load_b = [&](int ks) {
+      if (ks < nfull) {
+        const int64_t base = (int64_t)ks * 32 * Cin;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int p = 0; p < BP; ++p) rx[p][i] = *reinterpret_cast<const f32x4*>(xp[p] + base + (int64_t)i * Cin);
+        return;
+      }
+      const int64_t r0 = m_begin + (int64_t)ks * 32 + 4 * mb;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int64_t row = r0 + i;
+        row = row < m_end ? row : m_end - 1;
+#pragma unroll
+        for (int p = 0; p < BP; ++p) rx[p][i] = *reinterpret_cast<const f32x4*>(X + row * Cin + cb[p]);
+      }
+    };
+    auto store_a = [&](int ks) {
+      unsigned char* S = wbase + (ks & 1) * 2 * kStride16;
+      const int64_t row0 = m_begin + (int64_t)ks * 32 + 4 * mb;
+      const bool masked = ks >= nfull;  // uniform
+#pragma unroll
+      for (int p = 0; p < AP; ++p) {
+        f32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = ga[p] * (rg[p][i] - gmean[p]) + gb[p] * (ry[p][i] - ymean[p]);
+        if (masked) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (row0 + i >= m_end) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the slice contribute nothing
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          split_store16(f32x4{v[0][e], v[1][e], v[2][e], v[3][e]}, S + swz16(4 * (cq + 32 * p) + e, chunk), APL);
+      }
+    };
+    auto store_b = [&](int ks) {
+      unsigned char* S = wbase + (ks & 1) * 2 * kStride16 + 2 * APL;
+      const int64_t row0 = m_begin + (int64_t)ks * 32 + 4 * mb;
+      const bool masked = ks >= nfull;  // uniform
+#pragma unroll
+      for (int p = 0; p < BP; ++p) {
+        f32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = sc[p] * (rx[p][i] - mu[p]) + be[p];
+          v[i].x = fmaxf(v[i].x, 0.f); v[i].y = fmaxf(v[i].y, 0.f); v[i].z = fmaxf(v[i].z, 0.f); v[i].w = fmaxf(v[i].w, 0.f);
+        }
+        if (masked) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (row0 + i >= m_end) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          split_store16(f32x4{v[0][e], v[1][e], v[2][e], v[3][e]}, S + swz16(4 * (cq + 32 * p) + e, chunk), BPL);
+      }
+    };
+
+    load_a(0);
+    load_b(0);
+    store_a(0);
+    if (nks > 1) load_a(1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_b(0);
+    if (nks > 1) load_b(1);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    for (int it = 0; it < nks; ++it) {
+      if (it + 1 < nks) {
+        store_a(it + 1);
+        if (it + 2 < nks) load_a(it + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        store_b(it + 1);
+        if (it + 2 < nks) load_b(it + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+  } else {
+    const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    consume_tile16<BM, BN>(lds, nks, wm, wn, r, h, acc);
+    const float inv = 1.f / (sa * sb);
+    float* dst = partial ? partial + (size_t)slice * Cout * Cin : dW;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = k0 + wn * (BN / 2) + j * 32 + r;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = n0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (partial) dst[(size_t)row * Cin + col] = acc[i][j][e] * inv;
+          else atomicAdd(dst + (size_t)row * Cin + col, acc[i][j][e] * inv);
+        }
+    }
+  }
+}
+
+// dW[i] += partial[0][i] + partial[1][i] + ... (fixed order: bitwise reproducible)
+__global__ void __launch_bounds__(256) wgrad_reduce_k(const float* __restrict__ partial, float* __restrict__ dW, int64_t n, int slices) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 a = ld4(dW + i);
+  for (int s = 0; s < slices; ++s) a = add4(a, ld4(partial + (size_t)s * n + i));
+  st4(dW + i, a);
+}
+
+// The [M][K] x [Nout][K]^T shapes that run on these kernels (everything else: fp32 MFMA, pwconv.hip).
+bool f16_gemm_shape(int K, int Nout) {
+  return K >= 128 && K % 32 == 0 && ((Nout >= 256 && Nout % 256 == 0) || Nout == 128);
+}
+bool f16_wgrad_shape(int Cin, int Cout) {
+  if (Cin < 128 || Cout < 128 || Cin % 128 || Cout % 128 || (int64_t)Cin * Cout < 128 * 256) return false;
+  return Cin % 256 == 0 || Cout % 256 == 0;
+}
+
+// slices of M for the weight gradient: one workgroup per CU, all of equal length
+static void wgrad_slices(int64_t M, int tiles, int64_t& slices, int64_t& rows) {
+  slices = 256 / tiles;
+  if (slices < 1) slices = 1;
+  const int64_t max_slices = ceil_div(M, 128);
+  if (slices > max_slices) slices = max_slices;
+  rows = ceil_div(ceil_div(M, slices), 32) * 32;
+  slices = ceil_div(M, rows);
+}
+
+size_t f16_wgrad_partial_bytes(int64_t M, int Cin, int Cout) {
+  if (!f16_wgrad_shape(Cin, Cout)) return 0;
+  const int tiles = (Cout / 128) * (Cin / 128) / 2;
+  int64_t slices, rows;
+  wgrad_slices(M, tiles, slices, rows);
+  return (size_t)slices * Cin * Cout * sizeof(float);
+}
+
+bool launch_f16_wgrad(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
+                      float* partial, int64_t M, int Cin, int Cout, hipStream_t st) {
+  if (!f16_wgrad_shape(Cin, Cout)) return false;
+  const bool wide = Cin % 256 == 0;  // 128 (Cout) x 256 (Cin) tiles, else 256 x 128
+  const int tiles = wide ? (Cout / 128) * (Cin / 256) : (Cout / 256) * (Cin / 128);
+  int64_t slices, rows;
+  wgrad_slices(M, tiles, slices, rows);
+  const dim3 grid(tiles, (unsigned)slices);
+  if (wide)
+    hipLaunchKernelGGL((pw16_wgrad_k<128, 256>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
+  else
+    hipLaunchKernelGGL((pw16_wgrad_k<256, 128>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
+  if (partial) {
+    const int64_t n = (int64_t)Cin * Cout;
+    hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, st, partial, dw, n, (int)slices);
+  }
+  return true;
+}
+
+// ---- weight operand: |w| maximum of the layer (as ordered uint bits), then the two fp16 planes [K/32][rows][32] ----
+__global__ void __launch_bounds__(256) w16_absmax_k(const float* __restrict__ w, int64_t n, unsigned* __restrict__ wmax) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(wmax, __float_as_uint(m));  // non-negative floats order like their bit patterns
+}
+
+// w[rows][K] fp32 -> two fp16 planes [K/32][rows][32] of w * pow2_scale(*wmax)
+__global__ void w16_split_k(const float* __restrict__ w, uint16_t* __restrict__ q, const float* __restrict__ wmax, int rows, int K) {
+  const int64_t n = (int64_t)rows * K;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float s = pow2_scale(*wmax);
+  const int row = (int)(i / K), k = (int)(i - (int64_t)row * K);
+  const int64_t o = ((int64_t)(k >> 5) * rows + row) * 32 + (k & 31);
+  const float x = w[i] * s;
+  const _Float16 hh = (_Float16)x;
+  const _Float16 ll = (_Float16)(x - (float)hh);
+  q[o] = __builtin_bit_cast(uint16_t, hh);
+  q[n + o] = __builtin_bit_cast(uint16_t, ll);
+}
+
+// Returns true when the shape was handled here (and the kernels launched on `st`).  Bm != nullptr: raw weight rows
+// [Nout][K] that are split into `planes` first (per-call form, unit tests); wmax: the layer's |w| maximum (a device
+// float that the per-call form computes itself).
+template <int MODE>
+bool launch_f16_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
+                     const float* bnE, float* part, int64_t M, int K, int Nout, void* planes, float* wmax, hipStream_t st) {
+  constexpr int AM = MODE == SMODE_FWD ? AMODE_BNRELU : AMODE_BNGRAD, EM = MODE == SMODE_FWD ? EMODE_STATS : EMODE_MASK;
+  if (!planes || !wmax || !f16_gemm_shape(K, Nout)) return false;
+  uint16_t* Bq = reinterpret_cast<uint16_t*>(planes);
+  const int64_t nw = (int64_t)Nout * K;
+  if (Bm) {
+    (void)hipMemsetAsync(wmax, 0, sizeof(float), st);
+    hipLaunchKernelGGL(w16_absmax_k, dim3((unsigned)(nw / 1024 < 1 ? 1 : (nw / 1024 > 256 ? 256 : nw / 1024))), dim3(256), 0, st, Bm, nw,
+                       reinterpret_cast<unsigned*>(wmax));
+    hipLaunchKernelGGL(w16_split_k, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, st, Bm, Bq, wmax, Nout, K);
+  }
+  if (Nout >= 256 && Nout % 256 == 0) {
+    const unsigned tiles = (unsigned)(ceil_div(M, 128) * (Nout / 256));
+    hipLaunchKernelGGL((pw16_k<128, 256, AM, EM>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout);
+    return true;
+  }
+  if (Nout == 128) {
+    const unsigned tiles = (unsigned)ceil_div(M, 256);
+    hipLaunchKernelGGL((pw16_k<256, 128, AM, EM>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout);
+    return true;
+  }
+  return false;
+}
+
+template bool launch_f16_gemm<SMODE_FWD>(const float*, const float*, const float*, const float*, float*, const float*,
+                                         const float*, float*, int64_t, int, int, void*, float*, hipStream_t);
+template bool launch_f16_gemm<SMODE_DGRAD>(const float*, const float*, const float*, const float*, float*, const float*,
+                                           const float*, float*, int64_t, int, int, void*, float*, hipStream_t);
+
+}  // namespace ttk

@@ -723,235 +723,6 @@ __global__ void split_weights_k(const float* __restrict__ w, uint16_t* __restric
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// EXPERIMENT (TTK_GEMM=big): forward GEMM with a 256 x 256 tile per CU.  pw_split_k's 128 x 256 tile pulls 64 KB through
-// the CU's L1 per 2.1 MFLOP (16 KB of fp32 A + 48 KB of B planes) and is bound by that fill rate; a
-// 256 x 256 tile needs 40 KB for the same work.  Its 256 KB of accumulators take all 8 waves (128 AccVGPRs each), so
-// there are no producer waves: every wave issues its share of the loads, consumes a k16 stage (48 MFMAs on its 64 x 128
-// wave tile) and converts its share of A for the stage two ahead, between two barriers.
-//   LDS: ring of 3 k16 stages (A planes 24 KB + B planes 24 KB each) + the BatchNorm constants of A [3][K].
-//   B: three bf16 planes in k16-block order [K/16][Nout][16] (third region of ttk_pwconv_prepare_weights), moved with
-//      global_load_lds_dwordx4 - no registers; the transfer for stage it+2 is issued at the top of iteration it.
-//   A: fp32 rows, loaded as whole 128-byte row pieces (one k32 block = two stages) three iterations ahead into one of
-//      two register sets, converted half a block per iteration.
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lds_dma16(const void* g, uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_addr) : "memory", "m0");
-}
-#define TTK_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))
-
-constexpr int kBigStage = 6 * 256 * 32;       // 49152 bytes: 3 A planes + 3 B planes of 256 rows x 32 B
-constexpr int kBigStride = kBigStage + 64;
-constexpr int kBigRing = 3 * kBigStride;
-
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-pw_big_fwd_k(const float* __restrict__ A0, const float* __restrict__ bnA, const uint16_t* __restrict__ Bq,
-             float* __restrict__ out, float* __restrict__ part, int64_t M, int K, int Nout) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  constexpr int PL = 256 * 32;  // bytes of one piece plane (A or B)
-  float* bnS = reinterpret_cast<float*>(lds + kBigRing);  // [3][K]: scale, mean, beta
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int r = lane & 31, h = lane >> 5;
-  const int ww = __builtin_amdgcn_readfirstlane(wave);
-  // XCD-aware tile order (see pw_split_k)
-  const unsigned G = gridDim.x, Lid = blockIdx.x, NB = Nout / 256;
-  const unsigned xq = G / 8, xr = G % 8, xcd = Lid % 8;
-  const unsigned tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + Lid / 8;
-  const unsigned bx = tile % NB, by = tile / NB;
-  const int64_t m0 = (int64_t)by * 256;
-  const int n0 = bx * 256;
-  const int nk16 = K / 16;
-  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-
-  for (int i = tid; i < K; i += 512) {
-    bnS[i] = bnA[TTK_BN_SCALE * K + i];
-    bnS[K + i] = bnA[TTK_BN_MEAN * K + i];
-    bnS[2 * K + i] = bnA[TTK_BN_BETA * K + i];
-  }
-
-  // ---- B transfers: 24 (plane, 32-row group) pairs per stage, three per wave
-  const uint16_t* bp = Bq + (int64_t)(n0 + (lane >> 1)) * 16 + (((lane & 1) ^ ((lane >> 4) & 1)) << 3);
-  const int64_t bplane = (int64_t)K * Nout;
-  auto dma_b = [&](int st, int slot) {
-    const uint16_t* b = bp + (int64_t)st * Nout * 16;
-    const uint32_t S = lds_base + slot * kBigStride + 3 * PL;
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int pair = ww + 8 * u, p = pair >> 3, rg = pair & 7;
-      lds_dma16(b + p * bplane + rg * 32 * 16, S + p * PL + rg * 1024);
-    }
-  };
-  // ---- A: thread = rows (ra, ra + 128) x k quad kq4 of both halves of a k32 block
-  const int ra = tid >> 2, kq4 = tid & 3;
-  const float* ap[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int64_t row = m0 + ra + 128 * i;
-    ap[i] = A0 + (row < M ? row : M - 1) * (int64_t)K + 4 * kq4;  // rows past M are computed but never stored
-  }
-  f32x4 raw[2][2][2];  // [set][row][half]
-  auto load_a = [&](int blk, const int set) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) raw[set][i][hf] = *reinterpret_cast<const f32x4*>(ap[i] + 32 * blk + 16 * hf);
-  };
-  auto conv_a = [&](int blk, const int set, const int hf, int slot) {  // half hf of block blk -> stage 2*blk + hf
-    const int k = 32 * blk + 16 * hf + 4 * kq4;
-    const f32x4 q0 = *reinterpret_cast<const f32x4*>(bnS + k), q1 = *reinterpret_cast<const f32x4*>(bnS + K + k),
-                q2 = *reinterpret_cast<const f32x4*>(bnS + 2 * K + k);
-    unsigned char* S = lds + slot * kBigStride + (kq4 & 1) * 8;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      f32x4 v = q0 * (raw[set][i][hf] - q1) + q2;
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      split_store(v, S + swz_off(ra + 128 * i, kq4 >> 1), PL);
-    }
-  };
-  // ---- consumer side of one k16 stage: wave tile 64 x 128 = 2 x 4 MFMA tiles, A fragments held, B streamed
-  int a_off[2], b_off[4];
-#pragma unroll
-  for (int x = 0; x < 2; ++x) a_off[x] = swz_off(wm * 64 + x * 32 + r, h);
-#pragma unroll
-  for (int x = 0; x < 4; ++x) b_off[x] = 3 * PL + swz_off(wn * 128 + x * 32 + r, h);
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  auto consume = [&](int slot) {
-    const unsigned char* S = lds + slot * kBigStride;
-    bf16x8 fa[2][3], fb[3];  // (double-buffering the B fragments was measured slower)
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int x = 0; x < 2; ++x) fa[x][p] = *reinterpret_cast<const bf16x8*>(S + p * PL + a_off[x]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int p = 0; p < 3; ++p) fb[p] = *reinterpret_cast<const bf16x8*>(S + p * PL + b_off[j]);
-#define TTK_PROD(pa, pb) \
-  _Pragma("unroll") for (int y = 0; y < 2; ++y) acc[y][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[y][pa], fb[pb], acc[y][j], 0, 0, 0);
-      TTK_PROD(0, 2) TTK_PROD(2, 0) TTK_PROD(1, 1) TTK_PROD(0, 1) TTK_PROD(1, 0) TTK_PROD(0, 0)
-#undef TTK_PROD
-    }
-  };
-
-  // ---- prologue: stages 0 and 1 (block 0), blocks 1 and 2 in flight
-  const int nblk = K / 32;
-  __syncthreads();  // bnS
-  dma_b(0, 0);
-  if (nk16 > 1) dma_b(1, 1);
-  load_a(0, 0);
-  if (nblk > 1) load_a(1, 1);
-  __builtin_amdgcn_sched_barrier(0);
-  conv_a(0, 0, 0, 0);
-  conv_a(0, 0, 1, 1);
-  __builtin_amdgcn_sched_barrier(0);
-  if (nblk > 2) load_a(2, 0);
-  __builtin_amdgcn_sched_barrier(0);
-  if (nblk > 2) TTK_WAIT_VM(4); else TTK_WAIT_VM(0);  // the B transfers are older than block 2's loads
-  __syncthreads();
-
-  // iteration it: transfers for stage it+2, MFMAs on stage it, conversion of A for stage it+2 (block (it+2)/2, half it&1,
-  // register set ((it+2)/2)&1), and after an odd iteration the loads of block (it+2)/2 + 2 into the set just emptied
-  auto iter = [&](int it, const int set, const int hf) {
-    const int slot = it % 3, wslot = (it + 2) % 3;
-    const int st = it + 2, blk = st >> 1;
-#if !(defined(TTK_EXP) && TTK_EXP == 33)
-    if (st < nk16) dma_b(st, wslot);
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-#if !(defined(TTK_EXP) && TTK_EXP == 32)
-    consume(slot);
-#endif
-#if !(defined(TTK_EXP) && TTK_EXP == 31)
-    if (st < nk16) conv_a(blk, set, hf, wslot);
-#endif
-#ifndef TTK_BIG_INTERLEAVE
-#define TTK_BIG_INTERLEAVE 2
-#endif
-#if TTK_BIG_INTERLEAVE > 0
-    // ask the scheduler to thread the conversion's VALU / LDS work through the MFMA stream: an MFMA occupies the matrix
-    // pipe for 32 cycles, during which the wave can issue ~7 independent VALU instructions
-#pragma unroll
-    for (int q = 0; q < 48; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, TTK_BIG_INTERLEAVE, 0);  // VALU
-      __builtin_amdgcn_sched_group_barrier(0x300, 1, 0);  // one LDS access
-    }
-#endif
-    int newer = 0;
-#if !(defined(TTK_EXP) && TTK_EXP == 34)
-    if (hf == 1 && blk + 2 < nblk) {
-      __builtin_amdgcn_sched_barrier(0);
-      load_a(blk + 2, set);
-      newer = 4;
-    }
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-    if (newer) TTK_WAIT_VM(4); else TTK_WAIT_VM(0);
-    __syncthreads();
-  };
-  for (int it = 0; it < nk16; it += 4) {
-    iter(it, 1, 0);
-    if (it + 1 < nk16) iter(it + 1, 1, 1);
-    if (it + 2 < nk16) iter(it + 2, 0, 0);
-    if (it + 3 < nk16) iter(it + 3, 0, 1);
-  }
-
-  // ---- epilogue from registers: 128-byte row segments per half wave; column sums of this wave's 64 rows, then the two
-  // waves of a 128-row half through LDS (the ring is dead: the loop ended with a barrier)
-  float* red = reinterpret_cast<float*>(lds);  // [4 wm][2][256]
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int col = wn * 128 + j * 32 + r;
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row < M) {
-          const float v = acc[i][j][e];
-          out[(size_t)row * Nout + n0 + col] = v;
-          s1 += v;
-          s2 = fmaf(v, v, s2);
-        }
-      }
-    s1 += __shfl_xor(s1, 32);
-    s2 += __shfl_xor(s2, 32);
-    if (h == 0) { red[(wm * 2 + 0) * 256 + col] = s1; red[(wm * 2 + 1) * 256 + col] = s2; }
-  }
-  if (part) {
-    __syncthreads();
-    for (int i = tid; i < 2 * 2 * 256; i += 512) {
-      const int hf = i >> 9, which = (i >> 8) & 1, c = i & 255;
-      const int64_t prow = (int64_t)by * 2 + hf;
-      if (prow * 128 < M)
-        part[(size_t)prow * 2 * Nout + (size_t)which * Nout + n0 + c] = red[((2 * hf) * 2 + which) * 256 + c] + red[((2 * hf + 1) * 2 + which) * 256 + c];
-    }
-  }
-}
-
-bool launch_big_fwd(const float* A0, const float* bnA, const void* prepared, float* out, float* part, int64_t M, int K, int Nout,
-                    hipStream_t st) {
-  if (K < 128 || K % 32 != 0 || K > 1024 || Nout % 256 != 0 || !prepared) return false;
-  const size_t sm = (size_t)kBigRing + (size_t)3 * K * sizeof(float);
-  if (sm > 160 * 1024) return false;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pw_big_fwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
-    attr_set = true;
-  }
-  const uint16_t* Bq16 = reinterpret_cast<const uint16_t*>(static_cast<const unsigned char*>(prepared) + (size_t)12 * K * Nout);
-  const unsigned tiles = (unsigned)(ceil_div(M, 256) * (Nout / 256));
-  hipLaunchKernelGGL(pw_big_fwd_k, dim3(tiles), dim3(512), sm, st, A0, bnA, Bq16, out, part, M, K, Nout);
-  return true;
-}
-
 // The [M][K] x [Nout][K]^T shapes that run on the split kernels (everything else: fp32 MFMA, pwconv.hip).
 bool split_gemm_shape(int K, int Nout) {
   return K >= 128 && K % 32 == 0 && ((Nout >= 256 && Nout % 256 == 0) || Nout == 128);

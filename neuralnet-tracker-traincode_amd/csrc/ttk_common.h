@@ -42,6 +42,19 @@ inline int elementwise_grid(int64_t items) {
   return (int)g;
 }
 
+// Power-of-two scale S of an fp16-split GEMM operand (pwconv_f16.hip): bound * S lies in [2^14, 2^15), so every scaled
+// value is below the fp16 maximum; 1 when the bound is unknown (<= 0, inf, nan).  |log2 S| <= 60: products of two scales
+// and their reciprocals stay inside the fp32 exponent range.
+__host__ __device__ inline float pow2_scale(float bound) {
+  if (!(bound > 0.f) || bound > 3.0e38f) return 1.f;
+  union { float f; unsigned u; } b;
+  b.f = bound;
+  int s = 14 - ((int)((b.u >> 23) & 0xffu) - 127);
+  s = s > 60 ? 60 : (s < -60 ? -60 : s);
+  b.u = (unsigned)(s + 127) << 23;
+  return b.f;
+}
+
 // ---- float4 helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

@@ -28,7 +28,7 @@ _SIGNATURES = {
     "ttk_dwconv3x3_bwd_weight": [_P] * 8 + [_I] * 6,
     "ttk_pwconv1x1_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
     "ttk_pwconv1x1_bwd_data": [_P] * 8 + [_L, _I, _I, _P],
-    "ttk_pwconv1x1_bwd_weight": [_P] * 6 + [_L, _I, _I],
+    "ttk_pwconv1x1_bwd_weight": [_P] * 7 + [_L, _I, _I],
     "ttk_pwconv_prepare_weights": [_I, _P, _P, _P, _P],
     "ttk_transpose": [_P, _P, _I, _I],
     "ttk_avgpool_fwd": [_P, _P, _P, _P, _I, _I, _I],
@@ -83,7 +83,7 @@ _SIGNATURES = {
     "ttk_clip_adam": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _F, _F, _F, _F, _F, _P, _P, _P],
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class _Library:
@@ -106,6 +106,7 @@ class _Library:
         self.cdll.ttk_heads_num_rows.argtypes, self.cdll.ttk_heads_num_rows.restype = [c_int, c_int, c_int], c_int
         self.cdll.ttk_pwconv_prepared_bytes.argtypes, self.cdll.ttk_pwconv_prepared_bytes.restype = [c_int, c_int], ctypes.c_size_t
         self.cdll.ttk_partial_rows_dwconv.argtypes, self.cdll.ttk_partial_rows_dwconv.restype = [c_int] * 6, c_int
+        self.cdll.ttk_pwconv_wgrad_partial_bytes.argtypes, self.cdll.ttk_pwconv_wgrad_partial_bytes.restype = [c_int64, c_int, c_int], ctypes.c_size_t
         self._fns = {}
         for name, sig in _SIGNATURES.items():
             fn = getattr(self.cdll, name)  # AttributeError if the symbol is missing: loud by design
@@ -122,6 +123,10 @@ class _Library:
 
     def pwconv_prepared_bytes(self, cin: int, cout: int) -> int:
         return self.cdll.ttk_pwconv_prepared_bytes(cin, cout)
+
+    def pwconv_wgrad_partial_bytes(self, m: int, cin: int, cout: int) -> int:
+        """Scratch bytes of the deterministic (fixed-order) weight-gradient reduction; 0 = this shape has none."""
+        return self.cdll.ttk_pwconv_wgrad_partial_bytes(m, cin, cout)
 
     def pwconv_prepare_weights(self, weights, prepared):
         """One launch: forward and data-gradient weight operands of every pointwise layer (`weights[i]`: [Cout, Cin(,1,1)]
@@ -177,4 +182,5 @@ def ptr(t: torch.Tensor | None):
 
 def exported_symbols() -> list[str]:
     return ["ttk_abi_version", "ttk_last_error_string", "ttk_partial_rows_elementwise",
-            "ttk_partial_rows_gemm", "ttk_partial_rows_dwconv", "ttk_heads_num_rows"] + list(_SIGNATURES)
+            "ttk_partial_rows_gemm", "ttk_partial_rows_dwconv", "ttk_heads_num_rows", "ttk_pwconv_prepared_bytes",
+            "ttk_pwconv_wgrad_partial_bytes"] + list(_SIGNATURES)

@@ -78,9 +78,20 @@ class DepthWiseBlock(nn.Module):
 _BN_ROWS = 8  # TTK_BN_ROWS: scale, beta, mean, rstd, ga, gb, gmean, (pad) - see include/ttk.h
 
 
-def _bn_work(C, device) -> torch.Tensor:
-    """Per-layer BatchNorm constant block bn[TTK_BN_ROWS][C] on the device."""
-    return torch.empty((_BN_ROWS, C), dtype=torch.float32, device=device)
+class _BnArena:
+    """The BatchNorm constant blocks bn[TTK_BN_ROWS][C] of all layers of one step, cut from ONE zeroed allocation:
+    row TTK_BN_AUX (the operand magnitude bounds of the fp16-split GEMMs, include/ttk.h) must start at zero because
+    the kernels raise it with atomicMax - one fill launch per step instead of one per layer."""
+
+    def __init__(self, channels, device):
+        self._buf = torch.zeros(sum(_BN_ROWS * c for c in channels), dtype=torch.float32, device=device)
+        self._off = 0
+
+    def take(self, C) -> torch.Tensor:
+        n = _BN_ROWS * C
+        blk = self._buf[self._off:self._off + n].view(_BN_ROWS, C)
+        self._off += n
+        return blk
 
 
 class _Stage(NamedTuple):
@@ -123,6 +134,7 @@ def _forward_impl(x, params, buffers, momentum, eps, training):
     ctx = _Ctx()
     ctx.x, ctx.part, ctx.B = x, part, B
     ctx.stages, ctx.a_in, ctx.dims = [], [], []
+    bns = _BnArena([32] + [c for _, cin, cout, _ in _BLOCKS for c in (cin, cout)], dev)
 
     def finalize(bn, rows, C, count, gamma, beta, bi):
         rm, rv, nbt = buffers[3 * bi], buffers[3 * bi + 1], buffers[3 * bi + 2]
@@ -142,7 +154,7 @@ def _forward_impl(x, params, buffers, momentum, eps, training):
     # ---- stem (reference :122-126,161-163)
     y0 = torch.empty((B, Ho, Wo, 32), dtype=torch.float32, device=dev)
     L.call("ttk_stem_fwd", p(x), p(params[0]), p(y0), part_arg, B, H, W)
-    bn = _bn_work(32, dev)
+    bn = bns.take(32)
     finalize(bn, L.partial_rows_elementwise(B * Ho * Wo * 8), 32, B * Ho * Wo, params[1], params[2], 0)
     prev = _Stage(y0, bn, None)
     ctx.stages.append(prev)
@@ -157,12 +169,12 @@ def _forward_impl(x, params, buffers, momentum, eps, training):
         ydw = torch.empty((B, ho, wo, cin), dtype=torch.float32, device=dev)
         L.call("ttk_dwconv3x3_fwd", p(prev.y), p(prev.bn), p(prev.skip), p(a_in), p(w_dw), p(ydw), part_arg, B, h, w_, cin,
                stride)
-        bn_dw = _bn_work(cin, dev)
+        bn_dw = bns.take(cin)
         finalize(bn_dw, L.partial_rows_dwconv(B, h, w_, cin, stride, False), cin, B * ho * wo, g_dw, b_dw, bi)
         ypw = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=dev)
         M = B * ho * wo
         L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(ypw), part_arg, M, cin, cout, p(ctx.prep[len(ctx.dims)]))
-        bn_pw = _bn_work(cout, dev)
+        bn_pw = bns.take(cout)
         finalize(bn_pw, L.partial_rows_gemm(M), cout, M, g_pw, b_pw, bi + 1)
         bi += 2
         ctx.stages.append(_Stage(ydw, bn_dw, None))
@@ -187,6 +199,9 @@ grad_ready_hook = None
 # 0.3-0.4 ms/step while the kernels left the GPU half empty at their tails; with today's kernels the serial order is 0.3 %
 # faster (same box, alternating runs: 9.94 vs 9.98 ms), so it is off by default.
 _USE_WGRAD_STREAM = os.environ.get("TTK_WGRAD_STREAM", "0") != "0"
+# TTK_DETERMINISTIC=1: every weight-gradient reduction runs in a fixed order (slices of M stored to scratch and folded
+# by a second kernel instead of fp32 atomics): two runs of a step give bitwise equal gradients.
+_DETERMINISTIC = os.environ.get("TTK_DETERMINISTIC", "0") != "0"
 _SIDE_STREAMS: dict = {}
 
 
@@ -217,7 +232,11 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         L.call("ttk_bn_bwd_finalize", p(part), rows, Cc, count, p(params[gi]), p(stage.bn), p(grads[gi]), p(grads[gi + 1]), 0)
 
     main = torch.cuda.current_stream(gfeat.device)
-    side = _side_stream(gfeat.device) if _USE_WGRAD_STREAM else None
+    side = _side_stream(gfeat.device) if (_USE_WGRAD_STREAM and not _DETERMINISTIC) else None
+    wg_scratch = None
+    if _DETERMINISTIC:
+        need = max(L.pwconv_wgrad_partial_bytes(B * d[2] * d[3], d[4], d[5]) for d in ctx.dims)
+        wg_scratch = torch.empty(max(need, 4) // 4, dtype=torch.float32, device=gfeat.device)
     keep = []
 
     g = torch.empty_like(last.y)
@@ -240,13 +259,13 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
             ev.record(main)  # g, bn_pw backward constants and the zeroed dW are ready
             side.wait_event(ev)
             with torch.cuda.stream(side):
-                L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW), M, cin, cout)
+                L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW), None, M, cin, cout)
                 if grad_ready_hook is not None:
                     done = torch.cuda.Event()
                     done.record(side)
             keep.append(g)  # main must not recycle g's memory while the side stream still reads it
         else:
-            L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW), M, cin, cout)
+            L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW), p(wg_scratch), M, cin, cout)
         g_dw = torch.empty_like(st_dw.y)
         L.call("ttk_pwconv1x1_bwd_data", p(g), p(st_pw.y), p(st_pw.bn), None, p(st_dw.y), p(st_dw.bn), p(g_dw), p(part), M,
                cin, cout, p(ctx.prep[k]))
