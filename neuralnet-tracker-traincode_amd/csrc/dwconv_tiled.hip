@@ -360,7 +360,10 @@ dw_bwd_tiled_k(const float* __restrict__ g_dw, const float* __restrict__ y_dw,
   float* red = lds + stage_floats;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) gmx = fmaxf(gmx, __shfl_xor(gmx, off));
-  if ((tid & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(bn_prev + (size_t)TTK_BN_AUX * C + TTK_AUX_GMAX), __float_as_uint(gmx));
+  if ((tid & 63) == 0) {  // most waves find the slot already at or above their maximum: one relaxed read instead of ~3000 atomics on one address
+    unsigned* slot = reinterpret_cast<unsigned*>(bn_prev + (size_t)TTK_BN_AUX * C + TTK_AUX_GMAX);
+    if (__float_as_uint(gmx) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, __float_as_uint(gmx));
+  }
   if (part) slab_partials(s1, s2, q, C, slab * kSlab, part + (size_t)(blockIdx.x / nslabs) * 2 * C, red);
   if (dwgrad) {
     __syncthreads();

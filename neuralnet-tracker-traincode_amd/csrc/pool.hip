@@ -52,7 +52,10 @@ __global__ void __launch_bounds__(kBlock) avgpool_bwd_k(const float* __restrict_
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) gmx = fmaxf(gmx, __shfl_xor(gmx, off));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(bnp + (size_t)TTK_BN_AUX * C + TTK_AUX_GMAX), __float_as_uint(gmx));
+  if ((threadIdx.x & 63) == 0) {  // most waves find the slot already at or above their maximum: one relaxed read instead of ~3000 atomics on one address
+    unsigned* slot = reinterpret_cast<unsigned*>(bnp + (size_t)TTK_BN_AUX * C + TTK_AUX_GMAX);
+    if (__float_as_uint(gmx) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, __float_as_uint(gmx));
+  }
   if (part) block_channel_partials<1024>(s1, s2, c4, C, part + (size_t)blockIdx.x * 2 * C, smem);
 }
 

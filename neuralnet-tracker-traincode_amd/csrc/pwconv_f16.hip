@@ -22,6 +22,7 @@
 // wave tiles; one s_barrier per k32), with two piece planes per operand.
 #include "ttk_common.h"
 #include "conv_geom.h"
+#include <type_traits>
 
 namespace ttk {
 
@@ -36,7 +37,21 @@ enum { SMODE_FWD = 0, SMODE_DGRAD = 1 };
 
 constexpr int kStage16 = 64 * (128 + 256);  // 2 planes x 32 B x (BM + BN) rows of one k16 stage
 constexpr int kStride16 = kStage16 + 64;    // the two k16 halves of a producer wave's ds_write_b64 use different banks
-constexpr int kRing16 = 4 * kStride16;      // 2 super-stages (k32) x 2 k16 stages
+// The LDS ring holds RS super-stages (k32) of 2 k16 stages.  RS = 3 (148 KB): a super-stage is complete one barrier
+// BEFORE the consumers start on it, so they fetch its first fragments under the previous stage's last MFMAs instead of
+// right after the barrier, and the producers' LDS writes of a step may trail into the next one's barrier wait.
+#ifndef TTK_RS
+#define TTK_RS 2
+#endif
+// Register sets per producer operand = steps of global loads in flight (each load has D steps to land; cycle stamps and
+// the timing variants of tools/exp/variants.sh showed the producers WAITING for loads that had one step).
+#ifndef TTK_D
+#define TTK_D 1
+#endif
+#ifndef TTK_DW
+#define TTK_DW 1
+#endif
+constexpr int ring_bytes(int rs) { return rs * 2 * kStride16; }
 
 __device__ __forceinline__ int swz16(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 3) & 1)) << 4); }
 
@@ -52,9 +67,9 @@ __device__ __forceinline__ void split_store16(f32x4 v, unsigned char* dst, int p
 
 // The consumer side of one block tile: `nks` super-stages (k32) of ds_read_b128 fragments + 3-product MFMAs into
 // acc[TM][TN].  Executes exactly 1 + nks barriers (matching the producers).
-template <int BM, int BN>
+template <int BM, int BN, int RS>
 __device__ __forceinline__ void consume_tile16(const unsigned char* lds, int nks, int wm, int wn, int r, int h,
-                                               f32x16 (&acc)[BM / 64][BN / 64]) {
+                                               f32x16 (&acc)[BM / 64][BN / 64], long long* barrier_wait = nullptr) {
   constexpr int APL = BM * 32, BPL = BN * 32;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr bool HOLD_A = TM <= TN;  // hold the smaller fragment set in registers, stream the other
@@ -69,19 +84,23 @@ __device__ __forceinline__ void consume_tile16(const unsigned char* lds, int nks
   constexpr int HPL = HOLD_A ? APL : BPL, SPL = HOLD_A ? BPL : APL;
 
   f16x8 hold[TH][2], hold_n[TH][2], strm[2][2];
-  __syncthreads();  // super-stage 0 is in LDS
+  auto fetch_first = [&](const unsigned char* S, f16x8 (&hd)[TH][2], f16x8 (&st)[2]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int x = 0; x < TH; ++x) hd[x][p] = *reinterpret_cast<const f16x8*>(S + p * HPL + hold_off[x]);
+      st[p] = *reinterpret_cast<const f16x8*>(S + p * SPL + strm_off[0]);
+    }
+  };
+  __syncthreads();  // super-stage 0 (RS = 3: and 1) is in LDS
+  if constexpr (RS == 3) fetch_first(lds, hold, strm[0]);
+  int slot = 0;  // it % RS
   for (int it = 0; it < nks; ++it) {
+    const int slot_n = slot + 1 == RS ? 0 : slot + 1;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
-      const unsigned char* S = lds + ((it & 1) * 2 + sub) * kStride16;
-      if (sub == 0) {  // first stage after the barrier: nothing could be prefetched across it
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-#pragma unroll
-          for (int x = 0; x < TH; ++x) hold[x][p] = *reinterpret_cast<const f16x8*>(S + p * HPL + hold_off[x]);
-          strm[0][p] = *reinterpret_cast<const f16x8*>(S + p * SPL + strm_off[0]);
-        }
-      }
+      const unsigned char* S = lds + (slot * 2 + sub) * kStride16;
+      if (RS == 2 && sub == 0) fetch_first(S, hold, strm[0]);  // first stage after the barrier: nothing could be prefetched across it
 #pragma unroll
       for (int x = 0; x < TS; ++x) {
         const int cur = (sub * TS + x) & 1;
@@ -89,13 +108,9 @@ __device__ __forceinline__ void consume_tile16(const unsigned char* lds, int nks
 #pragma unroll
           for (int p = 0; p < 2; ++p) strm[cur ^ 1][p] = *reinterpret_cast<const f16x8*>(S + p * SPL + strm_off[x + 1]);
         } else if (sub == 0) {
-          const unsigned char* S2 = S + kStride16;
-#pragma unroll
-          for (int p = 0; p < 2; ++p) {
-#pragma unroll
-            for (int y = 0; y < TH; ++y) hold_n[y][p] = *reinterpret_cast<const f16x8*>(S2 + p * HPL + hold_off[y]);
-            strm[cur ^ 1][p] = *reinterpret_cast<const f16x8*>(S2 + p * SPL + strm_off[0]);
-          }
+          fetch_first(S + kStride16, hold_n, strm[cur ^ 1]);
+        } else if (RS == 3) {
+          if (it + 1 < nks) fetch_first(lds + slot_n * 2 * kStride16, hold_n, strm[cur ^ 1]);  // complete since the previous barrier
         }
         // three piece products, smallest first; (pa, pb) index the A and B pieces (0 = h, 1 = l)
 #define TTK_PROD16(pa, pb)                                                                                      \
@@ -105,35 +120,72 @@ __device__ __forceinline__ void consume_tile16(const unsigned char* lds, int nks
   else                                                                                                        \
     acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(strm[cur][pa], hold[y][pb], acc[x][y], 0, 0, 0);       \
   }
+#if defined(TTK_EXP) && TTK_EXP == 4
+        asm volatile("" ::"v"(strm[cur][0]), "v"(strm[cur][1]), "v"(hold[0][0]), "v"(hold[0][1]));  // timing experiment: fragments read, no MFMAs
+#else
         TTK_PROD16(0, 1) TTK_PROD16(1, 0) TTK_PROD16(0, 0)
+#endif
 #undef TTK_PROD16
       }
-      if (sub == 0) {
+      if (sub == 0 || RS == 3) {
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
           for (int y = 0; y < TH; ++y) hold[y][p] = hold_n[y][p];
       }
     }
+#if defined(TTK_EXP) && TTK_EXP == 9
+    const long long b0 = __builtin_readcyclecounter();
     __syncthreads();
+    if (barrier_wait) *barrier_wait += __builtin_readcyclecounter() - b0;
+#else
+    __syncthreads();
+#endif
+    slot = slot_n;
+  }
+}
+
+// The producers' schedule, shared by the three kernels: stage s is written to LDS slot s % RS from register set s % D
+// (its global loads were issued D stages earlier); the consumers work on stage `it` between barrier `it` and `it + 1`
+// while the producers write stage it + RS - 1.  produce(s, set) must store stage s from `set` and re-load the set for
+// stage s + D; prefetch(s, set) issues the loads of the first D stages.
+template <int D, int RS, typename Prefetch, typename Produce>
+__device__ __forceinline__ void producer_schedule(int nks, Prefetch&& prefetch, Produce&& produce) {
+  static_assert(D >= 1 && D <= 3, "register sets");
+  if (0 < nks) prefetch(0, std::integral_constant<int, 0>{});
+  if (D > 1 && 1 < nks) prefetch(1, std::integral_constant<int, 1 % D>{});
+  if (D > 2 && 2 < nks) prefetch(2, std::integral_constant<int, 2 % D>{});
+  const int total = nks + RS - 1;  // one barrier after each of s = RS-2 .. nks+RS-2: 1 + nks barriers
+  for (int base = 0; base < total; base += D) {
+#define TTK_SCHED_STEP(d)                                                   \
+  if (D > d && base + d < total) {                                          \
+    const int s_ = base + d;                                                \
+    if (s_ < nks) produce(s_, std::integral_constant<int, (d) % D>{});      \
+    if (s_ >= RS - 2) __syncthreads();                                      \
+  }
+    TTK_SCHED_STEP(0)
+    TTK_SCHED_STEP(1)
+    TTK_SCHED_STEP(2)
+#undef TTK_SCHED_STEP
   }
 }
 
 // A: fp32 rows [M][K] (formed on load: forward relu(bn(y)), data gradient ga*(g-gmean)+gb*(y-mean)), bound in
 // bnA[TTK_BN_AUX][AMODE == BNRELU ? TTK_AUX_ACT_BOUND : TTK_AUX_DY_BOUND]; Bq: two fp16 planes [K/32][Nout][32] of the
 // weights scaled by pow2_scale(*wmax).
-template <int BM, int BN, int AMODE, int EMODE>
+template <int BM, int BN, int AMODE, int EMODE, int D>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 pw16_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* __restrict__ bnA,
        const uint16_t* __restrict__ Bq, const float* __restrict__ wmax, float* __restrict__ out, const float* __restrict__ E0,
        const float* __restrict__ bnE, float* __restrict__ part, int64_t M, int K, int Nout) {
   static_assert((BM == 128 && BN == 256) || (BM == 256 && BN == 128), "tile shapes");
+  constexpr int RS = TTK_RS;
   constexpr int APL = BM * 32, BPL = BN * 32;  // bytes of one piece plane of a k16 stage
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int LDC = BN + 4;
-  constexpr int QN = BN / 4, RG = 512 / QN, HALVES = BM / 128, RGH = RG / HALVES;
+  constexpr int QN = BN / 4, RG = 512 / QN, HALVES = BM / 128, RGH = RG / HALVES, EI = 128 / RGH;
   constexpr int kEpiBytes = BM * LDC * 4 + RG * 2 * BN * 4;
-  constexpr int kSmemBytes = kRing16 > kEpiBytes ? kRing16 : kEpiBytes;
+  constexpr int kSmemBytes = ring_bytes(RS) > kEpiBytes ? ring_bytes(RS) : kEpiBytes;
   __shared__ __attribute__((aligned(16))) unsigned char lds[kSmemBytes];
 
   const int tid = threadIdx.x;
@@ -155,9 +207,10 @@ pw16_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* 
     const int row0 = pt >> 3, kq8 = pt & 7;  // 32 rows per pass; 8 lanes x 16 B = one 128-byte row segment
     const int sub = kq8 >> 2, chunk = (kq8 >> 1) & 1, o8 = (kq8 & 1) * 8;
     constexpr int AP = BM / 32;
-    f32x4 ra0[AP], ra1[AMODE == AMODE_BNGRAD ? AP : 1], q0, q1, q2, q3;
+    constexpr int NQ = AMODE == AMODE_BNGRAD ? 4 : 3;
+    f32x4 ra0[D][AP], ra1[D][AMODE == AMODE_BNGRAD ? AP : 1], q[D][NQ];
     constexpr int BI = BN / 64;  // B rows per thread and piece plane: 64 rows x 4 chunks of 16 B (8 k) per pass
-    u32x4 rb[2][BI];
+    u32x4 rb[D][2][BI];
     int64_t arow[AP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
@@ -171,76 +224,106 @@ pw16_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* 
     const float* cp = bnA + kq8 * 4;
     unsigned char* wbase = lds + sub * kStride16 + o8;
 
-    auto load_a = [&](int ks) {
+    auto load_a = [&](int ks, auto setc) {
+      constexpr int set = decltype(setc)::value;
+#if defined(TTK_EXP) && (TTK_EXP == 2 || TTK_EXP == 6)
+      if (ks >= D) return;  // timing experiment: A is loaded for the first steps only
+#endif
       const int kc0 = ks * 32;
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
-        ra0[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A0 + arow[i] + kc0));
-        if constexpr (AMODE == AMODE_BNGRAD) ra1[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A1 + arow[i] + kc0));
+        ra0[set][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A0 + arow[i] + kc0));
+        if constexpr (AMODE == AMODE_BNGRAD) ra1[set][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A1 + arow[i] + kc0));
       }
-      // the scale S_a rides on the per-channel constants (exact: a power of two)
       if constexpr (AMODE == AMODE_BNRELU) {
-        q0 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_SCALE * K + kc0) * sa;
-        q1 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * K + kc0);
-        q2 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_BETA * K + kc0) * sa;
+        q[set][0] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_SCALE * K + kc0);
+        q[set][1] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * K + kc0);
+        q[set][2] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_BETA * K + kc0);
       } else {
-        q0 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GA * K + kc0) * sa;
-        q1 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GMEAN * K + kc0);
-        q2 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GB * K + kc0) * sa;
-        q3 = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * K + kc0);
+        q[set][0] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GA * K + kc0);
+        q[set][1] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GMEAN * K + kc0);
+        q[set][2] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GB * K + kc0);
+        q[set][3] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * K + kc0);
       }
     };
-    auto load_b = [&](int ks) {
+    auto load_b = [&](int ks, auto setc) {
+      constexpr int set = decltype(setc)::value;
+#if defined(TTK_EXP) && (TTK_EXP == 3 || TTK_EXP == 6)
+      if (ks >= D) return;  // timing experiment
+#endif
       const uint16_t* b = bp + (int64_t)ks * Nout * 32;
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int i = 0; i < BI; ++i) rb[p][i] = *reinterpret_cast<const u32x4*>(b + p * bplane + 64 * 32 * i);
+        for (int i = 0; i < BI; ++i) rb[set][p][i] = *reinterpret_cast<const u32x4*>(b + p * bplane + 64 * 32 * i);
     };
-    auto store_a = [&](int ks) {
-      unsigned char* S = wbase + (ks & 1) * 2 * kStride16;
+    auto store_a = [&](int ks, auto setc) {
+      constexpr int set = decltype(setc)::value;
+#if defined(TTK_EXP) && (TTK_EXP == 6 || TTK_EXP == 7)
+      if (ks >= D) return;  // timing experiment: no conversion / LDS writes
+#endif
+      unsigned char* S = wbase + (ks % RS) * 2 * kStride16;
+      // the scale S_a rides on the per-channel constants (exact: a power of two)
+      const f32x4 c0 = q[set][0] * sa, c2 = q[set][2] * sa;
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
         f32x4 v;
         if constexpr (AMODE == AMODE_BNRELU) {
-          v = q0 * (ra0[i] - q1) + q2;
+          v = c0 * (ra0[set][i] - q[set][1]) + c2;
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         } else {
-          v = q0 * (ra0[i] - q1) + q2 * (ra1[i] - q3);
+          v = c0 * (ra0[set][i] - q[set][1]) + c2 * (ra1[set][i] - q[set][NQ - 1]);
         }
         split_store16(v, S + swz16(row0 + 32 * i, chunk), APL);
       }
     };
-    auto store_b = [&](int ks) {  // no arithmetic: 16-byte chunks (8 k of one piece) straight into the ring
-      unsigned char* S = wbase_b + (ks & 1) * 2 * kStride16;
+    auto store_b = [&](int ks, auto setc) {  // no arithmetic: 16-byte chunks (8 k of one piece) straight into the ring
+      constexpr int set = decltype(setc)::value;
+#if defined(TTK_EXP) && (TTK_EXP == 6 || TTK_EXP == 8)
+      if (ks >= D) return;  // timing experiment
+#endif
+      unsigned char* S = wbase_b + (ks % RS) * 2 * kStride16;
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int i = 0; i < BI; ++i) *reinterpret_cast<u32x4*>(S + p * BPL + swz16(brow + 64 * i, bc4 & 1)) = rb[p][i];
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<u32x4*>(S + p * BPL + swz16(brow + 64 * i, bc4 & 1)) = rb[set][p][i];
     };
-
-    // B is consumed first in a step and reloaded at once, then A: every load has a whole step to land
-    load_b(0);
-    load_a(0);
-    __builtin_amdgcn_sched_barrier(0);
-    store_b(0);
-    if (nks > 1) load_b(1);
-    __builtin_amdgcn_sched_barrier(0);
-    store_a(0);
-    if (nks > 1) load_a(1);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();  // super-stage 0 is in LDS
-    for (int it = 0; it < nks; ++it) {
-      if (it + 1 < nks) {
-        store_b(it + 1);
-        if (it + 2 < nks) load_b(it + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        store_a(it + 1);
-        if (it + 2 < nks) load_a(it + 2);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      __syncthreads();
+    // B is consumed first in a step and reloaded at once, then A
+#if defined(TTK_EXP) && TTK_EXP == 9
+    long long tb = 0, ta = 0;  // cycles in the B part / the A part of produce() (the rest of the loop is barrier wait)
+    const long long p0 = __builtin_readcyclecounter();
+#endif
+    producer_schedule<D, RS>(
+        nks,
+        [&](int s, auto setc) { load_b(s, setc); load_a(s, setc); __builtin_amdgcn_sched_barrier(0); },
+        [&](int s, auto setc) {
+#if defined(TTK_EXP) && TTK_EXP == 9
+          const long long q0 = __builtin_readcyclecounter();
+#endif
+          store_b(s, setc);
+          if (s + D < nks) load_b(s + D, setc);
+          __builtin_amdgcn_sched_barrier(0);
+#if defined(TTK_EXP) && TTK_EXP == 9
+          __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the LDS writes are done
+          const long long q1 = __builtin_readcyclecounter();
+          tb += q1 - q0;
+#endif
+          store_a(s, setc);
+          if (s + D < nks) load_a(s + D, setc);
+          __builtin_amdgcn_sched_barrier(0);
+#if defined(TTK_EXP) && TTK_EXP == 9
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          ta += __builtin_readcyclecounter() - q1;
+#endif
+        });
+#if defined(TTK_EXP) && TTK_EXP == 9
+    if (tile == 0 && tid == 256 && part) {
+      float* dbg = part + (size_t)ceil_div(M, 128) * 2 * Nout;
+      dbg[4] = (float)(__builtin_readcyclecounter() - p0);
+      dbg[5] = (float)tb;
+      dbg[6] = (float)ta;
     }
+#endif
   } else {
     const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
@@ -251,7 +334,22 @@ pw16_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* 
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    consume_tile16<BM, BN>(lds, nks, wm, wn, r, h, acc);
+#if defined(TTK_EXP) && TTK_EXP == 9
+    // clock diagnostic: shader cycles and 100 MHz real-time ticks around the main loop of tile 0 -> behind the partial rows
+    const long long c0 = __builtin_readcyclecounter();
+    const long long t0 = __builtin_amdgcn_s_memrealtime();
+    long long bwait = 0;
+    consume_tile16<BM, BN, RS>(lds, nks, wm, wn, r, h, acc, &bwait);
+    if (tile == 0 && tid == 0 && part) {
+      float* dbg = part + (size_t)ceil_div(M, 128) * 2 * Nout;
+      dbg[0] = (float)(__builtin_readcyclecounter() - c0);
+      dbg[1] = (float)(__builtin_amdgcn_s_memrealtime() - t0);
+      dbg[2] = (float)nks;
+      dbg[3] = (float)bwait;
+    }
+#else
+    consume_tile16<BM, BN, RS>(lds, nks, wm, wn, r, h, acc);
+#endif
     // ---- accumulators -> LDS image [BM][LDC] (the ring is dead: the loop ended with a barrier)
     float* Cs = reinterpret_cast<float*>(lds);
 #pragma unroll
@@ -265,22 +363,34 @@ pw16_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* 
           Cs[row * LDC + col] = acc[i][j][e];
         }
   }
-  __syncthreads();
-
   // ---- epilogue, all 8 waves: row-wise pass over the C image - un-scale, 16-byte stores (a wave writes 1 KB row
   // segments), the ReLU mask of the data gradient, and the BatchNorm partial sums of this tile's 128-row halves.
+  const int c4 = tid % QN, rg = tid / QN, half = rg / RGH, rr = rg % RGH;
+  const int col = n0 + 4 * c4;
+  // the mask operand of the data gradient is requested before the barrier: its latency hides behind the accumulator
+  // writes of the consumer waves (it was 16 dependent round trips to memory inside the loop below)
+  float4 e0[EMODE == EMODE_MASK ? EI : 1];
+  if constexpr (EMODE == EMODE_MASK) {
+#pragma unroll
+    for (int i = 0; i < EI; ++i) {
+      const int64_t grow = m0 + half * 128 + rr + RGH * i;
+      e0[i] = grow < M ? ld4(E0 + (size_t)grow * Nout + col) : f4(0.f);
+    }
+  }
+  __syncthreads();
+#if defined(TTK_EXP) && TTK_EXP == 5
+  if (M > 0) return;  // timing experiment: no epilogue
+#endif
   const float inv = 1.f / (sa * sb);  // exact: a power of two
   const float* Cs = reinterpret_cast<const float*>(lds);
   float* red = reinterpret_cast<float*>(lds + BM * LDC * 4);  // [RG][2][BN]
-  const int c4 = tid % QN, rg = tid / QN, half = rg / RGH, rr = rg % RGH;
-  const int col = n0 + 4 * c4;
   float4 esc = f4(0.f), emean = f4(0.f), ebeta = f4(0.f);
   if constexpr (EMODE == EMODE_MASK) {
     esc = ld4(bnE + TTK_BN_SCALE * Nout + col); emean = ld4(bnE + TTK_BN_MEAN * Nout + col); ebeta = ld4(bnE + TTK_BN_BETA * Nout + col);
   }
   float4 s1 = f4(0.f), s2 = f4(0.f);
-#pragma unroll 4
-  for (int i = 0; i < 128 / RGH; ++i) {
+#pragma unroll
+  for (int i = 0; i < EI; ++i) {
     const int row = half * 128 + rr + RGH * i;
     const int64_t grow = m0 + row;
     if (grow >= M) break;
@@ -288,11 +398,13 @@ pw16_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* 
     v = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
     const size_t o = (size_t)grow * Nout + col;
     if constexpr (EMODE == EMODE_STATS) {
+#if !(defined(TTK_EXP) && TTK_EXP == 1)
       st4(out + o, v);
+#endif
       s1 = add4(s1, v);
       s2 = fma4(v, v, s2);
     } else {
-      const float4 yc = sub4(ld4(E0 + o), emean);
+      const float4 yc = sub4(e0[i], emean);
       v = mask4(v, fma4(esc, yc, ebeta));
       st4(out + o, v);
       s1 = add4(s1, v);
@@ -306,7 +418,7 @@ pw16_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* 
     for (int i = tid; i < HALVES * 2 * BN; i += 512) {
       const int hf = i / (2 * BN), which = (i / BN) & 1, c = i % BN;
       float a = 0.f;
-      for (int q = 0; q < RGH; ++q) a += red[((hf * RGH + q) * 2 + which) * BN + c];  // fixed order: reproducible
+      for (int qq = 0; qq < RGH; ++qq) a += red[((hf * RGH + qq) * 2 + which) * BN + c];  // fixed order: reproducible
       const int64_t prow = (int64_t)by * HALVES + hf;
       if (prow * 128 < M) part[(size_t)prow * 2 * Nout + (size_t)which * Nout + n0 + c] = a;
     }
@@ -322,15 +434,16 @@ pw16_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* 
 // otherwise (deterministic mode) slice s stores its tile to partial[s][Cout][Cin] and wgrad_reduce_k folds the slices
 // in a fixed order.
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN>
+template <int BM, int BN, int D>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const float* __restrict__ bn_pw,
              const float* __restrict__ X, const float* __restrict__ bn_x, float* __restrict__ dW, float* __restrict__ partial,
              int64_t M, int Cin, int Cout, int64_t rows_per_slice) {
   static_assert(BM + BN == 384 && (BM == 128 || BM == 256), "128x256 or 256x128");
+  constexpr int RS = TTK_RS;
   constexpr int APL = BM * 32, BPL = BN * 32;
   constexpr int TM = BM / 64, TN = BN / 64;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[kRing16];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[ring_bytes(RS)];
 
   const int tid = threadIdx.x;
   // XCD-aware order: give each XCD whole slices (all dW tiles of a slice run side by side on ONE L2, so the slice's
@@ -343,7 +456,7 @@ pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const flo
   const int n0 = (tile / tiles_k) * BM, k0 = (tile % tiles_k) * BN;
   const int64_t m_begin = (int64_t)slice * rows_per_slice;
   const int64_t m_end = (m_begin + rows_per_slice < M) ? m_begin + rows_per_slice : M;
-  if (m_begin >= m_end) return;  // uniform over the block, before any barrier (deterministic mode: the host sizes the slices so that none is empty)
+  if (m_begin >= m_end) return;  // uniform over the block, before any barrier (the host sizes the slices so that none is empty)
   const int nks = (int)((m_end - m_begin + 31) / 32);
   const bool producer = __builtin_amdgcn_readfirstlane(tid) >= 256;
   const float sa = pow2_scale(bn_pw[(size_t)TTK_BN_AUX * Cout + TTK_AUX_DY_BOUND]);
@@ -355,7 +468,7 @@ pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const flo
     const int mb = pt & 7, cq = pt >> 3;  // 8 row blocks of 4 rows x 32 channel quads per pass
     const int sub = mb >> 2, chunk = (mb >> 1) & 1, o8 = (mb & 1) * 8;
     constexpr int AP = BM / 128, BP = BN / 128;
-    f32x4 rg[AP][4], ry[AP][4], rx[BP][4];
+    f32x4 rg[D][AP][4], ry[D][AP][4], rx[D][BP][4];
     f32x4 ga[AP], gb[AP], gmean[AP], ymean[AP], sc[BP], mu[BP], be[BP];
     int ca[AP], cb[BP];
 #pragma unroll
@@ -389,15 +502,16 @@ pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const flo
 #pragma unroll
     for (int p = 0; p < BP; ++p) xp[p] = X + (m_begin + 4 * mb) * Cin + cb[p];
 
-    auto load_a = [&](int ks) {
+    auto load_a = [&](int ks, auto setc) {
+      constexpr int set = decltype(setc)::value;
       if (ks < nfull) {
         const int64_t base = (int64_t)ks * 32 * Cout;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int p = 0; p < AP; ++p) {
-            rg[p][i] = *reinterpret_cast<const f32x4*>(gp[p] + base + (int64_t)i * Cout);
-            ry[p][i] = *reinterpret_cast<const f32x4*>(yp[p] + base + (int64_t)i * Cout);
+            rg[set][p][i] = *reinterpret_cast<const f32x4*>(gp[p] + base + (int64_t)i * Cout);
+            ry[set][p][i] = *reinterpret_cast<const f32x4*>(yp[p] + base + (int64_t)i * Cout);
           }
         return;
       }
@@ -407,18 +521,19 @@ pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const flo
         row = row < m_end ? row : m_end - 1;
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-          rg[p][i] = *reinterpret_cast<const f32x4*>(G + row * Cout + ca[p]);
-          ry[p][i] = *reinterpret_cast<const f32x4*>(Y + row * Cout + ca[p]);
+          rg[set][p][i] = *reinterpret_cast<const f32x4*>(G + row * Cout + ca[p]);
+          ry[set][p][i] = *reinterpret_cast<const f32x4*>(Y + row * Cout + ca[p]);
         }
       }
     };
-    auto load_b = [&](int ks) {
+    auto load_b = [&](int ks, auto setc) {
+      constexpr int set = decltype(setc)::value;
       if (ks < nfull) {
         const int64_t base = (int64_t)ks * 32 * Cin;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int p = 0; p < BP; ++p) rx[p][i] = *reinterpret_cast<const f32x4*>(xp[p] + base + (int64_t)i * Cin);
+          for (int p = 0; p < BP; ++p) rx[set][p][i] = *reinterpret_cast<const f32x4*>(xp[p] + base + (int64_t)i * Cin);
         return;
       }
       const int64_t r0 = m_begin + (int64_t)ks * 32 + 4 * mb;
@@ -427,18 +542,19 @@ pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const flo
         int64_t row = r0 + i;
         row = row < m_end ? row : m_end - 1;
 #pragma unroll
-        for (int p = 0; p < BP; ++p) rx[p][i] = *reinterpret_cast<const f32x4*>(X + row * Cin + cb[p]);
+        for (int p = 0; p < BP; ++p) rx[set][p][i] = *reinterpret_cast<const f32x4*>(X + row * Cin + cb[p]);
       }
     };
-    auto store_a = [&](int ks) {
-      unsigned char* S = wbase + (ks & 1) * 2 * kStride16;
+    auto store_a = [&](int ks, auto setc) {
+      constexpr int set = decltype(setc)::value;
+      unsigned char* S = wbase + (ks % RS) * 2 * kStride16;
       const int64_t row0 = m_begin + (int64_t)ks * 32 + 4 * mb;
       const bool masked = ks >= nfull;  // uniform
 #pragma unroll
       for (int p = 0; p < AP; ++p) {
         f32x4 v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = ga[p] * (rg[p][i] - gmean[p]) + gb[p] * (ry[p][i] - ymean[p]);
+        for (int i = 0; i < 4; ++i) v[i] = ga[p] * (rg[set][p][i] - gmean[p]) + gb[p] * (ry[set][p][i] - ymean[p]);
         if (masked) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
@@ -449,8 +565,9 @@ pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const flo
           split_store16(f32x4{v[0][e], v[1][e], v[2][e], v[3][e]}, S + swz16(4 * (cq + 32 * p) + e, chunk), APL);
       }
     };
-    auto store_b = [&](int ks) {
-      unsigned char* S = wbase + (ks & 1) * 2 * kStride16 + 2 * APL;
+    auto store_b = [&](int ks, auto setc) {
+      constexpr int set = decltype(setc)::value;
+      unsigned char* S = wbase + (ks % RS) * 2 * kStride16 + 2 * APL;
       const int64_t row0 = m_begin + (int64_t)ks * 32 + 4 * mb;
       const bool masked = ks >= nfull;  // uniform
 #pragma unroll
@@ -458,7 +575,7 @@ pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const flo
         f32x4 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          v[i] = sc[p] * (rx[p][i] - mu[p]) + be[p];
+          v[i] = sc[p] * (rx[set][p][i] - mu[p]) + be[p];
           v[i].x = fmaxf(v[i].x, 0.f); v[i].y = fmaxf(v[i].y, 0.f); v[i].z = fmaxf(v[i].z, 0.f); v[i].w = fmaxf(v[i].w, 0.f);
         }
         if (masked) {
@@ -471,27 +588,17 @@ pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const flo
           split_store16(f32x4{v[0][e], v[1][e], v[2][e], v[3][e]}, S + swz16(4 * (cq + 32 * p) + e, chunk), BPL);
       }
     };
-
-    load_a(0);
-    load_b(0);
-    store_a(0);
-    if (nks > 1) load_a(1);
-    __builtin_amdgcn_sched_barrier(0);
-    store_b(0);
-    if (nks > 1) load_b(1);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    for (int it = 0; it < nks; ++it) {
-      if (it + 1 < nks) {
-        store_a(it + 1);
-        if (it + 2 < nks) load_a(it + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        store_b(it + 1);
-        if (it + 2 < nks) load_b(it + 2);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      __syncthreads();
-    }
+    producer_schedule<D, RS>(
+        nks,
+        [&](int s, auto setc) { load_a(s, setc); load_b(s, setc); __builtin_amdgcn_sched_barrier(0); },
+        [&](int s, auto setc) {
+          store_a(s, setc);
+          if (s + D < nks) load_a(s + D, setc);
+          __builtin_amdgcn_sched_barrier(0);
+          store_b(s, setc);
+          if (s + D < nks) load_b(s + D, setc);
+          __builtin_amdgcn_sched_barrier(0);
+        });
   } else {
     const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
@@ -502,7 +609,7 @@ pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const flo
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    consume_tile16<BM, BN>(lds, nks, wm, wn, r, h, acc);
+    consume_tile16<BM, BN, RS>(lds, nks, wm, wn, r, h, acc);
     const float inv = 1.f / (sa * sb);
     float* dst = partial ? partial + (size_t)slice * Cout * Cin : dW;
 #pragma unroll
@@ -565,9 +672,9 @@ bool launch_f16_wgrad(const float* g, const float* y, const float* bn_pw, const 
   wgrad_slices(M, tiles, slices, rows);
   const dim3 grid(tiles, (unsigned)slices);
   if (wide)
-    hipLaunchKernelGGL((pw16_wgrad_k<128, 256>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
-  else
-    hipLaunchKernelGGL((pw16_wgrad_k<256, 128>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
+    hipLaunchKernelGGL((pw16_wgrad_k<128, 256, TTK_DW>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
+  else  // (one register set: two spill)
+    hipLaunchKernelGGL((pw16_wgrad_k<256, 128, 1>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
   if (partial) {
     const int64_t n = (int64_t)Cin * Cout;
     hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, st, partial, dw, n, (int)slices);
@@ -617,12 +724,13 @@ bool launch_f16_gemm(const float* A0, const float* A1, const float* bnA, const f
   }
   if (Nout >= 256 && Nout % 256 == 0) {
     const unsigned tiles = (unsigned)(ceil_div(M, 128) * (Nout / 256));
-    hipLaunchKernelGGL((pw16_k<128, 256, AM, EM>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout);
+    hipLaunchKernelGGL((pw16_k<128, 256, AM, EM, TTK_D>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout);
     return true;
   }
   if (Nout == 128) {
     const unsigned tiles = (unsigned)ceil_div(M, 256);
-    hipLaunchKernelGGL((pw16_k<256, 128, AM, EM>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout);
+    constexpr int D = (MODE == SMODE_DGRAD || TTK_D > 2) ? 1 : TTK_D;  // eight A rows per thread: more sets spill
+    hipLaunchKernelGGL((pw16_k<256, 128, AM, EM, D>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout);
     return true;
   }
   return false;
