@@ -98,7 +98,7 @@ class KernelTimer:
             by = 4 * (n_in * (1 + bool(a[2]) + bool(a[3])) + n_out)
             return f"dw_fwd_tiled_k<{s_}>", 2 * 9 * n_out, by
         if name == "ttk_dwconv3x3_bwd_data":
-            B, H, W, C, s_ = ints[-5:]
+            B, H, W, C, s_ = a[-5:]
             n_in, n_out = B * H * W * C, B * ((H - 1) // s_ + 1) * ((W - 1) // s_ + 1) * C
             by = 4 * (2 * n_out + n_in * (2 + bool(a[4]) + bool(a[7] or a[8])))
             return f"dw_bwd_tiled_k<{s_}>", 2 * 2 * 9 * n_out, by
@@ -250,13 +250,15 @@ def main():
 
     import trackertraincode._hip as H
     import trackertraincode.backbones.mobilenet_v1 as MB
+    from trackertraincode import parallel
     from trackertraincode.parallel import GradAllReduce, broadcast_module_state
 
     net, crit, opt, batches, train = build_step(args, device)
     broadcast_module_state(net)
     reducer = GradAllReduce() if world > 1 else None
     if reducer is not None:
-        MB.grad_ready_hook = reducer.on_ready
+        parallel.install(reducer)            # gradient arenas are all-reduced in place while backward continues
+        opt.grad_scale = reducer.grad_scale  # 1/world, applied inside the fused clip+Adam kernel
     params = list(net.parameters())
 
     graphed = train.GraphedTrainStep(net, crit, opt) if (world == 1 and not args.no_graph) else None

@@ -106,8 +106,11 @@ int ttk_bn_bwd_finalize(float* part, int part_rows, int C, int64_t count, const 
 int ttk_stem_fwd(const float* x, const float* w, float* y, float* part, int B, int H, int W,
                  ttk_stream_t stream);
 /* dW[32][25] (+)= sum dy * x, dy formed on load from (g, y, bn = the stem's BatchNorm block). */
+/* partial (nullable): scratch of ttk_stem_wgrad_partial_bytes() - the workgroups store their partial sums there and a
+ * second kernel folds them in a fixed order (bitwise reproducible) instead of fp32 atomics. */
+size_t ttk_stem_wgrad_partial_bytes(void);
 int ttk_stem_bwd_weight(const float* g, const float* y, const float* bn, const float* x, float* dw,
-                        int accumulate, int B, int H, int W, ttk_stream_t stream);
+                        int accumulate, float* partial, int B, int H, int W, ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Depthwise 3x3, pad 1, stride 1|2, groups=C, bias=False - DepthWiseBlock.conv_dw,
@@ -126,12 +129,14 @@ int ttk_dwconv3x3_fwd(const float* yprev, const float* bn_prev, const float* ski
  * a_in (nullable): materialised block input; if NULL it is recomputed from yprev/bn_prev/skip_prev.
  * dw (nullable): FUSED weight gradient dW[C][9] (+)= sum dy_dw * a_in(taps) - every (dy, a_in) pair it
  * needs is already in registers here, so the standalone kernel below is only kept for unit tests.
- * Raises bn_prev[TTK_BN_AUX][TTK_AUX_GMAX] to max |g_prev| (the bound the previous block's GEMMs scale by). */
+ * Raises bn_prev[TTK_BN_AUX][TTK_AUX_GMAX] to max |g_prev| (the bound the previous block's GEMMs scale by).
+ * dw_partial (nullable): scratch of ttk_partial_rows_dwconv(.., 1) * 9 * C floats - the fused weight gradient is then
+ * folded from per-workgroup rows in a fixed order (bitwise reproducible) instead of fp32 atomics. */
 int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* bn_dw, const float* w,
                            const float* skip_grad, const float* yprev, float* bn_prev,
                            const float* skip_prev, const float* a_in, float* g_prev, float* part,
-                           float* dw, int dw_accumulate, int B, int H, int W, int C, int stride,
-                           ttk_stream_t stream);
+                           float* dw, int dw_accumulate, float* dw_partial, int B, int H, int W, int C,
+                           int stride, ttk_stream_t stream);
 /* dW[C][9] (+)= sum dy_dw * a_in(taps) (standalone form). */
 int ttk_dwconv3x3_bwd_weight(const float* g_dw, const float* y_dw, const float* bn_dw,
                              const float* yprev, const float* bn_prev, const float* skip_prev,
@@ -158,8 +163,8 @@ int ttk_pwconv1x1_bwd_data(const float* g, const float* y, const float* bn_pw, c
                            int Cin, int Cout, void* wsplit, ttk_stream_t stream);
 /* dw[Cout][Cin] += dy^T . a_dw.  dw must be zeroed (or hold the running gradient) before the call.
  * partial == NULL: the M dimension is split over workgroups that add atomically (fp32 atomics: the result depends on
- * the order the hardware commits them).  partial = scratch of ttk_pwconv_wgrad_partial_bytes(M, Cin, Cout) (> 0 for
- * the shapes on the 16-bit pipe): every slice of M stores its tile and a second kernel adds the slices to dw in a
+ * the order the hardware commits them).  partial = scratch of ttk_pwconv_wgrad_partial_bytes(M, Cin, Cout) (0 = this
+ * shape / GEMM mode has no such form): every slice of M stores its tile and a second kernel adds the slices to dw in a
  * fixed order - bitwise reproducible. */
 size_t ttk_pwconv_wgrad_partial_bytes(int64_t M, int Cin, int Cout);
 int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* bn_pw, const float* ydw,
@@ -355,21 +360,23 @@ int ttk_intensity_augment(const float* x, float* y, const float* params, const f
  * gradient_clip_val=1.0) in two launches, no host sync.  Device tables: ptrs[ntensors][4] =
  * {param, grad (0 = no gradient), exp_avg, exp_avg_sq} addresses; numel[ntensors]; group[ntensors]
  * (index into the host arrays lr4/wd4); chunk_tensor/chunk_offset[nchunks] cut the tensors into
- * chunks of chunk_size elements.  partial[nchunks]: scratch; out_norm (nullable): total grad norm.
- * hyper_dev (nullable, DEVICE float[TTK_ADAM_HYPER_FLOATS]): when given, the per-group learning rates and weight
- * decays are read from it instead of lr4/wd4, and the bias corrections are 1 - beta^t with t = the step counter
- * stored in it, which the call increments first - nothing about the step is then baked into the launch
- * arguments, so the call can sit inside a captured hipGraph that is replayed every step.
+ * chunks of chunk_size elements.  steps[ntensors] (DEVICE floats): torch.optim.Adam's per-parameter `step`, kept on
+ * the device - the call adds 1 for every tensor that has a gradient and derives the bias corrections
+ * 1 - beta^step from it (fp64), so nothing about the step count is a launch argument and the call can sit inside a
+ * captured hipGraph.  grad_scale: the gradients in memory are read as grad_scale * g everywhere (norm, clip, update) -
+ * 1/world for data-parallel replicas whose all-reduce left SUMS in place.  partial[nchunks]: scratch; out_norm
+ * (nullable): total gradient norm (of the scaled gradients).  hyper_dev (nullable, DEVICE
+ * float[TTK_ADAM_HYPER_FLOATS]): when given, the per-group learning rates and weight decays are read from it instead
+ * of lr4/wd4 (a captured graph then follows a scheduler without re-capture).
  * ------------------------------------------------------------------------------------------- */
 #define TTK_ADAM_HYPER_LR 0     /* [4] */
 #define TTK_ADAM_HYPER_WD 4     /* [4] */
-#define TTK_ADAM_HYPER_STEP 8   /* completed steps, as a float */
-#define TTK_ADAM_HYPER_FLOATS 12
+#define TTK_ADAM_HYPER_FLOATS 8
 int ttk_clip_adam(const int64_t* ptrs, const int32_t* numel, const int32_t* group,
                   const int32_t* chunk_tensor, const int32_t* chunk_offset, int nchunks, int chunk_size,
-                  const float* lr4, const float* wd4, float beta1, float beta2, float eps,
-                  float bias_correction1, float bias_correction2, float max_norm, float* partial,
-                  float* out_norm, float* hyper_dev, ttk_stream_t stream);
+                  const float* lr4, const float* wd4, float beta1, float beta2, float eps, float max_norm,
+                  float grad_scale, float* steps, float* partial, float* out_norm, const float* hyper_dev,
+                  ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * On-GPU affine-warp augmentation (the reference does this per sample on the CPU with OpenCV inside

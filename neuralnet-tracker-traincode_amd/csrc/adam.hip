@@ -17,10 +17,11 @@ struct AdamTables {
   const int32_t* group;         // [ntensors]: index into lr[] / wd[]
   const int32_t* chunk_tensor;  // [nchunks]
   const int32_t* chunk_offset;  // [nchunks]
+  float* steps;                 // [ntensors]: updates applied to each tensor so far (torch.optim.Adam's per-parameter `step`)
 };
 struct AdamHyper {
   float lr[4], wd[4];
-  float beta1, beta2, eps, bc1, bc2, max_norm;
+  float beta1, beta2, eps, max_norm, grad_scale;
 };
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
@@ -34,14 +35,15 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return s;
 }
 
-__global__ void __launch_bounds__(kBlock) grad_sqnorm_k(AdamTables t, int chunk_size, float* __restrict__ partial,
-                                                         float* __restrict__ hyper_dev) {
+__global__ void __launch_bounds__(kBlock) grad_sqnorm_k(AdamTables t, int chunk_size, float* __restrict__ partial) {
   __shared__ float red[kBlock / kWave];
   const int c = blockIdx.x;
-  // device-resident step counter (hipGraph replays): bumped here, read by clip_adam_k after the kernel boundary
-  if (hyper_dev && c == 0 && threadIdx.x == 0) hyper_dev[TTK_ADAM_HYPER_STEP] += 1.f;
   const int ti = t.chunk_tensor[c], off = t.chunk_offset[c];
   const float* g = reinterpret_cast<const float*>(t.ptrs[4 * ti + 1]);
+  // device-resident per-tensor step counters (nothing about the step count is a launch argument: the call can sit in a
+  // captured hipGraph): bumped here by the tensor's first chunk, read by clip_adam_k after the kernel boundary; a
+  // tensor without a gradient this step is not counted, like torch.optim.Adam
+  if (g && off == 0 && threadIdx.x == 0) t.steps[ti] += 1.f;
   const int n = min(chunk_size, t.numel[ti] - off);
   float acc = 0.f;
   if (g) {
@@ -64,12 +66,9 @@ __global__ void __launch_bounds__(kBlock) clip_adam_k(AdamTables t, AdamHyper h,
                                                        const float* __restrict__ partial, float* __restrict__ out_norm,
                                                        const float* __restrict__ hyper_dev) {
   __shared__ double dred[kBlock];
-  if (hyper_dev) {  // learning rates / weight decays / step count live in device memory (same values every replay of a graph)
+  if (hyper_dev) {  // learning rates / weight decays live in device memory (same launch arguments every replay of a graph)
 #pragma unroll
     for (int i = 0; i < 4; ++i) { h.lr[i] = hyper_dev[TTK_ADAM_HYPER_LR + i]; h.wd[i] = hyper_dev[TTK_ADAM_HYPER_WD + i]; }
-    const float tstep = hyper_dev[TTK_ADAM_HYPER_STEP];
-    h.bc1 = 1.f - powf(h.beta1, tstep);
-    h.bc2 = 1.f - powf(h.beta2, tstep);
   }
   // total gradient norm: fixed-order fp64 sum of the chunk partials (identical in every block)
   double acc = 0.0;
@@ -80,10 +79,11 @@ __global__ void __launch_bounds__(kBlock) clip_adam_k(AdamTables t, AdamHyper h,
     if (threadIdx.x < s) dred[threadIdx.x] += dred[threadIdx.x + s];
     __syncthreads();
   }
-  const float total = (float)sqrt(dred[0]);
+  // grad_scale: the gradients in memory are SUMS over data-parallel replicas; every use below sees grad_scale * g
+  const float total = h.grad_scale * (float)sqrt(dred[0]);
   if (blockIdx.x == 0 && threadIdx.x == 0 && out_norm) *out_norm = total;
-  float coef = 1.f;
-  if (h.max_norm > 0.f) coef = fminf(h.max_norm / (total + 1.0e-6f), 1.f);  // torch.nn.utils.clip_grad_norm_
+  float coef = h.grad_scale;
+  if (h.max_norm > 0.f) coef *= fminf(h.max_norm / (total + 1.0e-6f), 1.f);  // torch.nn.utils.clip_grad_norm_
 
   const int c = blockIdx.x;
   const int ti = t.chunk_tensor[c], off = t.chunk_offset[c];
@@ -94,7 +94,9 @@ __global__ void __launch_bounds__(kBlock) clip_adam_k(AdamTables t, AdamHyper h,
   if (!g) return;  // parameter without gradient this step: untouched, like torch.optim.Adam
   const int n = min(chunk_size, t.numel[ti] - off);
   const float lr = h.lr[t.group[ti]], wd = h.wd[t.group[ti]];
-  const float step_size = lr / h.bc1, inv_sqrt_bc2 = 1.f / sqrtf(h.bc2);
+  const double tstep = (double)t.steps[ti];  // bias corrections as torch computes them (Python floats = fp64)
+  const float bc1 = (float)(1.0 - pow((double)h.beta1, tstep)), bc2 = (float)(1.0 - pow((double)h.beta2, tstep));
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
   auto update = [&](float gr, float& pv, float& mv, float& vv) {
     gr *= coef;
     if (wd != 0.f) gr = fmaf(wd, pv, gr);  // Adam's L2 form of weight_decay
@@ -135,16 +137,17 @@ extern "C" {
 
 int ttk_clip_adam(const int64_t* ptrs, const int32_t* numel, const int32_t* group, const int32_t* chunk_tensor,
                   const int32_t* chunk_offset, int nchunks, int chunk_size, const float* lr4, const float* wd4, float beta1,
-                  float beta2, float eps, float bias_correction1, float bias_correction2, float max_norm, float* partial,
-                  float* out_norm, float* hyper_dev, ttk_stream_t stream) {
-  TTK_REQUIRE(ptrs && numel && group && chunk_tensor && chunk_offset && lr4 && wd4 && partial, "clip_adam: null pointer");
+                  float beta2, float eps, float max_norm, float grad_scale, float* steps, float* partial,
+                  float* out_norm, const float* hyper_dev, ttk_stream_t stream) {
+  TTK_REQUIRE(ptrs && numel && group && chunk_tensor && chunk_offset && lr4 && wd4 && partial && steps, "clip_adam: null pointer");
   TTK_REQUIRE(nchunks > 0 && chunk_size > 0, "clip_adam: bad chunking");
-  AdamTables t{ptrs, numel, group, chunk_tensor, chunk_offset};
+  TTK_REQUIRE(grad_scale > 0.f, "clip_adam: grad_scale must be positive (1 / number of replicas)");
+  AdamTables t{ptrs, numel, group, chunk_tensor, chunk_offset, steps};
   AdamHyper h;
   for (int i = 0; i < 4; ++i) { h.lr[i] = lr4[i]; h.wd[i] = wd4[i]; }
-  h.beta1 = beta1; h.beta2 = beta2; h.eps = eps; h.bc1 = bias_correction1; h.bc2 = bias_correction2; h.max_norm = max_norm;
+  h.beta1 = beta1; h.beta2 = beta2; h.eps = eps; h.max_norm = max_norm; h.grad_scale = grad_scale;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(grad_sqnorm_k, dim3(nchunks), dim3(kBlock), 0, st, t, chunk_size, partial, hyper_dev);
+  hipLaunchKernelGGL(grad_sqnorm_k, dim3(nchunks), dim3(kBlock), 0, st, t, chunk_size, partial);
   hipLaunchKernelGGL(clip_adam_k, dim3(nchunks), dim3(kBlock), 0, st, t, h, chunk_size, nchunks, partial, out_norm, hyper_dev);
   TTK_LAUNCH_CHECK("clip_adam");
 }

@@ -245,7 +245,7 @@ dw_bwd_tiled_k(const float* __restrict__ g_dw, const float* __restrict__ y_dw,
                                                           const float* __restrict__ yprev, float* __restrict__ bn_prev,
                                                           const float* __restrict__ skip_prev, const float* __restrict__ a_in,
                                                           float* __restrict__ g_prev, float* __restrict__ part,
-                                                          float* __restrict__ dwgrad, int B, int H, int W, int C, int Ho, int Wo,
+                                                          float* __restrict__ dwgrad, float* __restrict__ dw_partial, int B, int H, int W, int C, int Ho, int Wo,
                                                           int R, int nbands, int nslabs, int stage_floats, int NI, int NCT, int TW) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // dy[NI][stage_rows][Wo+2][32] + reduction scratch
   const int tid = threadIdx.x, q = tid & (kSlabQuads - 1), slot = tid >> 3;
@@ -378,7 +378,8 @@ dw_bwd_tiled_k(const float* __restrict__ g_dw, const float* __restrict__ y_dw,
       const int t = i / kSlab, c = i % kSlab;
       float a = 0.f;
       for (int wq = 0; wq < kBlock / kWave; ++wq) a += red[((size_t)wq * 9 + t) * kSlab + c];
-      atomicAdd(dwgrad + (size_t)(slab * kSlab + c) * 9 + t, a);
+      if (dw_partial) dw_partial[((size_t)(blockIdx.x / nslabs) * C + slab * kSlab + c) * 9 + t] = a;  // deterministic mode: folded by fold_partials_k
+      else atomicAdd(dwgrad + (size_t)(slab * kSlab + c) * 9 + t, a);
     }
   }
 }
@@ -423,7 +424,7 @@ int ttk_dwconv3x3_fwd(const float* yprev, const float* bn_prev, const float* ski
 
 int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* bn_dw, const float* w, const float* skip_grad,
                            const float* yprev, float* bn_prev, const float* skip_prev, const float* a_in, float* g_prev,
-                           float* part, float* dw, int dw_accumulate, int B, int H, int W, int C, int stride,
+                           float* part, float* dw, int dw_accumulate, float* dw_partial, int B, int H, int W, int C, int stride,
                            ttk_stream_t stream) {
   TTK_REQUIRE(g_dw && y_dw && bn_dw && w && yprev && bn_prev && g_prev, "dwconv3x3_bwd_data: null pointer");
   TTK_REQUIRE(dw_shape_ok2(B, H, W, C, stride), "dwconv3x3_bwd_data: unsupported shape");
@@ -433,13 +434,15 @@ int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* bn
   const size_t stage = (size_t)t.NI * t.stage_rows * ((t.NCT > 1 ? t.TW : Wo) + 2) * kSlab;
   const size_t sm = (stage + 4 * 9 * kSlab + 9 * kSlab) * sizeof(float);  // stage + reduction scratch + filter taps
   hipStream_t st = (hipStream_t)stream;
-  if (dw && !dw_accumulate) hipLaunchKernelGGL(zero_fill_k, dim3((9 * C + 255) / 256), dim3(256), 0, st, dw, (int64_t)9 * C);
+  if (!dw) dw_partial = nullptr;
+  if (dw && !dw_accumulate && !dw_partial) hipLaunchKernelGGL(zero_fill_k, dim3((9 * C + 255) / 256), dim3(256), 0, st, dw, (int64_t)9 * C);
   if (stride == 1)
     hipLaunchKernelGGL(dw_bwd_tiled_k<1>, dim3(t.grid), dim3(kBlock), sm, st, g_dw, y_dw, bn_dw, w, skip_grad, yprev, bn_prev,
-                       skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage, t.NI, t.NCT, t.TW);
+                       skip_prev, a_in, g_prev, part, dw, dw_partial, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage, t.NI, t.NCT, t.TW);
   else
     hipLaunchKernelGGL(dw_bwd_tiled_k<2>, dim3(t.grid), dim3(kBlock), sm, st, g_dw, y_dw, bn_dw, w, skip_grad, yprev, bn_prev,
-                       skip_prev, a_in, g_prev, part, dw, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage, t.NI, t.NCT, t.TW);
+                       skip_prev, a_in, g_prev, part, dw, dw_partial, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage, t.NI, t.NCT, t.TW);
+  if (dw_partial) launch_fold_partials(dw_partial, t.rows, (int64_t)9 * C, dw, dw_accumulate, st);
   TTK_LAUNCH_CHECK("dwconv3x3_bwd_data");
 }
 

@@ -5,6 +5,7 @@
 // wave shuffles.  Tiny next to the backbone (0.1 % of the FLOPs): built for few launches, not for MFMA.
 #include "head_math.h"
 #include "ttk_common.h"
+#include <stdlib.h>
 
 namespace ttk {
 
@@ -235,7 +236,8 @@ __global__ void __launch_bounds__(kBlock) heads_bwd_weight_k(const float* __rest
   const int fq = F >> 2;
   if (idx >= (int64_t)NZ * fq) return;
   const int j = (int)(idx / fq), f = (int)(idx % fq) * 4;
-  const int b0 = blockIdx.y * 64, b1 = min(B, b0 + 64);
+  const int chunk = gridDim.y == 1 ? B : 64;  // one chunk (deterministic mode): plain stores of the complete sums
+  const int b0 = blockIdx.y * chunk, b1 = min(B, b0 + chunk);
   float4 acc = f4(0.f);
   float sb = 0.f;
   for (int b = b0; b < b1; ++b) {
@@ -345,7 +347,9 @@ int ttk_heads_bwd(const float* feat, const float* wcat, const float* z, const in
   hipLaunchKernelGGL(heads_bwd_feat_k, dim3((unsigned)ceil_div(nf, kBlock)), dim3(kBlock), 0, st, dz, wcat, dfeat, B, F, NZ);
   hipLaunchKernelGGL(fill_zero_k, dim3((unsigned)ceil_div((int64_t)NZ * F + NZ, 256)), dim3(256), 0, st, dwcat, (int64_t)NZ * F);
   hipLaunchKernelGGL(fill_zero_k, dim3(1), dim3(256), 0, st, dbcat, (int64_t)NZ);
-  hipLaunchKernelGGL(heads_bwd_weight_k, dim3((unsigned)ceil_div(nw, kBlock), (unsigned)ceil_div(B, 64)), dim3(kBlock), 0, st, dz,
+  // TTK_DETERMINISTIC=1: one chunk of samples per weight instead of B/64 chunks that add atomically (fixed summation order)
+  static const bool det = [] { const char* e = getenv("TTK_DETERMINISTIC"); return e && e[0] != '0'; }();
+  hipLaunchKernelGGL(heads_bwd_weight_k, dim3((unsigned)ceil_div(nw, kBlock), det ? 1u : (unsigned)ceil_div(B, 64)), dim3(kBlock), 0, st, dz,
                      feat, dwcat, dbcat, B, F, NZ);
   if (use_offset && (dP || dPk)) hipLaunchKernelGGL(heads_bwd_offset_k, dim3(64), dim3(kBlock), 0, st, dprow, ids, dP, dPk, B);
   TTK_LAUNCH_CHECK("heads_bwd");

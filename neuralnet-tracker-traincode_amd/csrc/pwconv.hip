@@ -227,8 +227,8 @@ pw_gemm_k(const float* __restrict__ A0, const float* __restrict__ A1,
 template <int BN, int BK, int WR, int WC, int WS>
 __global__ void __launch_bounds__(kBlock) pw_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y,
                                                       const float* __restrict__ bn_pw, const float* __restrict__ Ydw,
-                                                      const float* __restrict__ bn_dw, float* __restrict__ dW, int64_t M,
-                                                      int Cin, int Cout,
+                                                      const float* __restrict__ bn_dw, float* __restrict__ dW,
+                                                      float* __restrict__ partial, int64_t M, int Cin, int Cout,
                                                       int64_t rows_per_slice) {
   static_assert(WR * WC * WS == 4, "4 waves");
   constexpr int TR = BN / WR / 32, TC = BK / WC / 32;
@@ -336,7 +336,8 @@ __global__ void __launch_bounds__(kBlock) pw_wgrad_k(const float* __restrict__ G
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wr * (BN / WR) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int k = k0 + wc * (BK / WC) + j * 32 + (lane & 31);
-        atomicAdd(dW + (size_t)n * Cin + k, acc[i][j][r]);
+        if (WS == 1 && partial) partial[(size_t)blockIdx.y * Cout * Cin + (size_t)n * Cin + k] = acc[i][j][r];  // deterministic mode
+        else atomicAdd((partial ? partial + (size_t)blockIdx.y * Cout * Cin : dW) + (size_t)n * Cin + k, acc[i][j][r]);
       }
 }
 
@@ -530,8 +531,31 @@ int ttk_pwconv1x1_bwd_data(const float* g, const float* y, const float* bn_pw, c
   TTK_LAUNCH_CHECK("pwconv1x1_bwd_data");
 }
 
+// slices of M of the fp32-MFMA weight-gradient kernels
+static void fp32_wgrad_plan(int64_t M, int Cin, int Cout, int& bn, int& bk, int& tiles, int64_t& slices, int64_t& rows) {
+  bn = Cout >= 128 ? 128 : Cout;
+  bk = Cin >= 128 ? 128 : Cin;
+  tiles = (Cout / bn) * (Cin / bk);
+  slices = 1024 / tiles;
+  const int64_t max_slices = ceil_div(M, 256);
+  if (slices > max_slices) slices = max_slices;
+  if (slices < 1) slices = 1;
+  rows = ceil_div(ceil_div(M, slices), 32) * 32;
+  slices = ceil_div(M, rows);
+}
+
 size_t ttk_pwconv_wgrad_partial_bytes(int64_t M, int Cin, int Cout) {
-  return (gemm_mode() == GEMM_F16X2 && pw_shape_ok(M, Cin, Cout)) ? f16_wgrad_partial_bytes(M, Cin, Cout) : 0;
+  if (!pw_shape_ok(M, Cin, Cout)) return 0;
+  if (gemm_mode() == GEMM_F16X2) {
+    const size_t b = f16_wgrad_partial_bytes(M, Cin, Cout);
+    if (b) return b;
+  } else if (gemm_mode() == GEMM_BF16X3 && Cin >= 128 && Cout >= 128 && (int64_t)Cin * Cout >= 128 * 256) {
+    return 0;  // the bf16 kernels have no deterministic form
+  }
+  int bn, bk, tiles;
+  int64_t slices, rows;
+  fp32_wgrad_plan(M, Cin, Cout, bn, bk, tiles, slices, rows);
+  return (size_t)slices * Cin * Cout * sizeof(float);
 }
 
 int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
@@ -544,18 +568,18 @@ int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* bn_pw,
   if (gemm_mode() == GEMM_BF16X3 && launch_split_wgrad(g, y, bn_pw, ydw, bn_dw, dw, M, Cin, Cout, (hipStream_t)stream)) {
     TTK_LAUNCH_CHECK("pwconv1x1_bwd_weight");
   }
-  const int bn = Cout >= 128 ? 128 : Cout, bk = Cin >= 128 ? 128 : Cin;
-  const int tiles = (Cout / bn) * (Cin / bk);
-  int64_t slices = 1024 / tiles;
-  const int64_t max_slices = ceil_div(M, 256);
-  if (slices > max_slices) slices = max_slices;
-  if (slices < 1) slices = 1;
-  int64_t rows = ceil_div(ceil_div(M, slices), 32) * 32;
-  slices = ceil_div(M, rows);
+  int bn, bk, tiles;
+  int64_t slices, rows;
+  fp32_wgrad_plan(M, Cin, Cout, bn, bk, tiles, slices, rows);
   const dim3 grid(tiles, (unsigned)slices), blk(kBlock);
   hipStream_t st = (hipStream_t)stream;
+  // deterministic mode: every slice of M owns partial[slice][Cout][Cin]; the two waves that share an output tile in the
+  // WS = 2 variants add into a ZEROED slot (a + b = b + a: still reproducible); four-wave sharing (32 x 32) is not
+  const bool shared = (bn == 64 && bk == 32) || (bn == 32 && bk == 64);
+  if (partial && bn == 32 && bk == 32) partial = nullptr;
+  if (partial && shared) (void)hipMemsetAsync(partial, 0, (size_t)slices * Cin * Cout * sizeof(float), st);
 #define TTK_WG(BN_, BK_, WR_, WC_, WS_)                                                                               \
-  hipLaunchKernelGGL((pw_wgrad_k<BN_, BK_, WR_, WC_, WS_>), grid, blk, 0, st, g, y, bn_pw, ydw, bn_dw, dw, M, Cin, Cout, \
+  hipLaunchKernelGGL((pw_wgrad_k<BN_, BK_, WR_, WC_, WS_>), grid, blk, 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, \
                      rows)
   if (bn == 128 && bk == 128) TTK_WG(128, 128, 2, 2, 1);
   else if (bn == 128 && bk == 64) TTK_WG(128, 64, 2, 2, 1);
@@ -567,6 +591,7 @@ int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* bn_pw,
   else if (bn == 32 && bk == 64) TTK_WG(32, 64, 1, 2, 2);
   else TTK_WG(32, 32, 1, 1, 4);
 #undef TTK_WG
+  if (partial) launch_fold_partials(partial, (int)slices, (int64_t)Cin * Cout, dw, 1, st);
   TTK_LAUNCH_CHECK("pwconv1x1_bwd_weight");
 }
 

@@ -222,7 +222,7 @@ constexpr int kWgChunk = 32;  // pixels per wave iteration = 16 MFMA k-pairs (fo
 
 __global__ void __launch_bounds__(kBlock) stem_wgrad_mfma_k(const float* __restrict__ g, const float* __restrict__ y,
                                                              const float* __restrict__ bn, const float* __restrict__ x,
-                                                             float* __restrict__ dw, int B, int H, int W, int Ho, int Wo,
+                                                             float* __restrict__ dw, float* __restrict__ partial, int B, int H, int W, int Ho, int Wo,
                                                              int nbands) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int xrows = 2 * kWgBand + 3;
@@ -297,7 +297,8 @@ __global__ void __launch_bounds__(kBlock) stem_wgrad_mfma_k(const float* __restr
   for (int i = threadIdx.x; i < kStemC * 25; i += kBlock) {
     float v = 0.f;
     for (int q = 0; q < kBlock / kWave; ++q) v += red[q * kStemC * 25 + i];
-    atomicAdd(dw + i, v);  // dw[c][tap]
+    if (partial) partial[(size_t)blockIdx.x * (kStemC * 25) + i] = v;  // deterministic mode: folded by fold_partials_k
+    else atomicAdd(dw + i, v);  // dw[c][tap]
   }
 }
 
@@ -325,15 +326,18 @@ int ttk_stem_fwd(const float* x, const float* w, float* y, float* part, int B, i
   TTK_LAUNCH_CHECK("stem_fwd");
 }
 
-int ttk_stem_bwd_weight(const float* g, const float* y, const float* bn, const float* x, float* dw, int accumulate, int B,
-                        int H, int W, ttk_stream_t stream) {
+size_t ttk_stem_wgrad_partial_bytes(void) { return (size_t)1024 * 25 * kStemC * sizeof(float); }
+
+int ttk_stem_bwd_weight(const float* g, const float* y, const float* bn, const float* x, float* dw, int accumulate, float* partial,
+                        int B, int H, int W, ttk_stream_t stream) {
   TTK_REQUIRE(g && y && bn && x && dw, "stem_bwd_weight: null pointer");
   TTK_REQUIRE(B > 0 && H > 4 && W > 4, "stem_bwd_weight: bad shape");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int64_t items = (int64_t)B * Ho * Wo * kStemQuads;
-  if (!accumulate) hipLaunchKernelGGL(zero_k, dim3(4), dim3(256), 0, (hipStream_t)stream, dw, 25 * kStemC);
   int grid = elementwise_grid(items);
   static const bool scalar = [] { const char* e = getenv("TTK_STEM"); return e && strcmp(e, "scalar") == 0; }();
+  if (scalar) partial = nullptr;
+  if (!accumulate && !partial) hipLaunchKernelGGL(zero_k, dim3(4), dim3(256), 0, (hipStream_t)stream, dw, 25 * kStemC);
   if (scalar) {
     if (grid > 512) grid = 512;
     hipLaunchKernelGGL(stem_bwd_weight_k, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, g, y, bn, x, dw, B, H, W, Ho, Wo);
@@ -342,7 +346,8 @@ int ttk_stem_bwd_weight(const float* g, const float* y, const float* bn, const f
     grid = B * nbands < 1024 ? B * nbands : 1024;
     const size_t sm = ((size_t)(2 * kWgBand + 3) * W + (kBlock / kWave) * (kWgChunk * kStemC + kStemC * 25)) * sizeof(float);
     TTK_REQUIRE(sm <= 64 * 1024, "stem_bwd_weight: image too wide for the LDS band (W=%d)", W);
-    hipLaunchKernelGGL(stem_wgrad_mfma_k, dim3(grid), dim3(kBlock), sm, (hipStream_t)stream, g, y, bn, x, dw, B, H, W, Ho, Wo, nbands);
+    hipLaunchKernelGGL(stem_wgrad_mfma_k, dim3(grid), dim3(kBlock), sm, (hipStream_t)stream, g, y, bn, x, dw, partial, B, H, W, Ho, Wo, nbands);
+    if (partial) launch_fold_partials(partial, grid, 25 * kStemC, dw, accumulate, (hipStream_t)stream);
   }
   TTK_LAUNCH_CHECK("stem_bwd_weight");
 }

@@ -55,6 +55,21 @@ __host__ __device__ inline float pow2_scale(float bound) {
   return b.f;
 }
 
+// Deterministic reductions: producers store their partial results row by row (partial[r][n]) instead of adding them
+// atomically, and this kernel folds the rows in a fixed order:  out[i] (+)= partial[0][i] + partial[1][i] + ...
+template <int kDummy = 0>
+__global__ void __launch_bounds__(256) fold_partials_k(const float* __restrict__ partial, int rows, int64_t n, float* __restrict__ out,
+                                                        int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = accumulate ? out[i] : 0.f;
+  for (int r = 0; r < rows; ++r) a += partial[(size_t)r * n + i];
+  out[i] = a;
+}
+inline void launch_fold_partials(const float* partial, int rows, int64_t n, float* out, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(fold_partials_k<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, rows, n, out, accumulate);
+}
+
 // ---- float4 helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

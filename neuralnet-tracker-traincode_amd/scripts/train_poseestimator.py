@@ -5,8 +5,12 @@ MI355X GPUs through the HIP kernels.  `python train_poseestimator.py --ds synthe
 Same functions as the reference script for the parts the hot path needs: `setup_losses` (:170-285),
 `find_variance_parameters` / `setup_lr_with_slower_variance_training` / `create_optimizer` (:114-167),
 `create_net` (:288-296).  Lightning's Trainer is replaced by trackertraincode.train.fit; plotting and
-the HDF5 datasets are not part of this package.  Added flags: --devices (data-parallel replicas, one
-process per GPU; launch with torch.distributed.run).
+the HDF5 datasets are not part of this package.
+
+Data-parallel replicas (no counterpart in the reference, which trains on one device): launch one process per GPU with
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 scripts/train_poseestimator.py ...
+Every rank then trains on its own stream of batches (--batchsize is per GPU), gradients are all-reduced over RCCL while
+backward runs (trackertraincode.parallel), and rank 0 writes the checkpoints.
 """
 from __future__ import annotations
 
@@ -134,26 +138,50 @@ def make_parser():
 
 
 def main():
+    import torch.distributed as dist
+    from trackertraincode import parallel
+
     args = make_parser().parse_args()
     args.input_size = 129
+    world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
     torch.cuda.set_device(device)
+    if world > 1:  # before anything else touches the GPU
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
     train_loader, _, _ = trackertraincode.pipelines.make_pose_estimation_loaders(
-        inputsize=args.input_size, batchsize=args.batchsize, datasets=args.ds, device=device)
+        inputsize=args.input_size, batchsize=args.batchsize, datasets=args.ds, device=device, seed=1234 + rank)
     net = create_net(args).to(device)
+    parallel.broadcast_module_state(net)  # every replica starts from rank 0's weights
     train_crit, _ = setup_losses(args, net)
     optimizer, scheduler = create_optimizer(net, args)
-    callbacks = [train.SwaCallback(start_epoch=args.epochs * 2 // 3)] if args.swa else []
+    callbacks = [train.SwaCallback(start_epoch=args.epochs * 2 // 3)] if (args.swa and rank == 0) else []
+    reducer, grad_sync = None, None
+    if world > 1:
+        reducer = parallel.GradAllReduce()
+        parallel.install(reducer)                  # gradient arenas are all-reduced in place while backward runs
+        optimizer.grad_scale = reducer.grad_scale  # 1/world inside the fused clip+Adam kernel
+        params = list(net.parameters())
+        grad_sync = lambda model: reducer.finish(params)
 
     def report(epoch, out):
         pass
 
-    train.fit(net, train_loader, train_crit, optimizer, scheduler, epochs=args.epochs, callbacks=callbacks, on_step=report)
-    out_dir = join(args.outdir, net.name)
-    os.makedirs(out_dir, exist_ok=True)
-    models.save_model(net.to("cpu"), join(out_dir, "last.ckpt"))
-    for cb in callbacks:
-        cb.on_train_end(out_dir)
+    try:
+        train.fit(net, train_loader, train_crit, optimizer, scheduler, epochs=args.epochs, callbacks=callbacks, on_step=report,
+                  grad_sync=grad_sync)
+    finally:
+        parallel.install(None)
+    if rank == 0:
+        out_dir = join(args.outdir, net.name)
+        os.makedirs(out_dir, exist_ok=True)
+        models.save_model(net.to("cpu"), join(out_dir, "last.ckpt"))
+        for cb in callbacks:
+            cb.on_train_end(out_dir)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

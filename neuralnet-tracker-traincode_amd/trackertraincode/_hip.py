@@ -22,9 +22,9 @@ _SIGNATURES = {
     "ttk_bn_eval_prepare": [_P, _P, _P, _P, _F, _I, _P],
     "ttk_bn_bwd_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _I],
     "ttk_stem_fwd": [_P, _P, _P, _P, _I, _I, _I],
-    "ttk_stem_bwd_weight": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "ttk_stem_bwd_weight": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I],
     "ttk_dwconv3x3_fwd": [_P] * 7 + [_I] * 5,
-    "ttk_dwconv3x3_bwd_data": [_P] * 12 + [_I] * 6,
+    "ttk_dwconv3x3_bwd_data": [_P] * 12 + [_I, _P] + [_I] * 5,
     "ttk_dwconv3x3_bwd_weight": [_P] * 8 + [_I] * 6,
     "ttk_pwconv1x1_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
     "ttk_pwconv1x1_bwd_data": [_P] * 8 + [_L, _I, _I, _P],
@@ -80,7 +80,7 @@ _SIGNATURES = {
     "ttk_affine_warp": [_P, _I, _I, _I, _I, _P, _P, _I, _F, _F],
     "ttk_affine_labels": [_P, _I, _I, _P, _P, _P, _P, _P],
     "ttk_intensity_augment": [_P, _P, _P, _P, _I, _I, _I, _F],
-    "ttk_clip_adam": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _F, _F, _F, _F, _F, _P, _P, _P],
+    "ttk_clip_adam": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P],
 }
 
 ABI_VERSION = 9
@@ -107,6 +107,7 @@ class _Library:
         self.cdll.ttk_pwconv_prepared_bytes.argtypes, self.cdll.ttk_pwconv_prepared_bytes.restype = [c_int, c_int], ctypes.c_size_t
         self.cdll.ttk_partial_rows_dwconv.argtypes, self.cdll.ttk_partial_rows_dwconv.restype = [c_int] * 6, c_int
         self.cdll.ttk_pwconv_wgrad_partial_bytes.argtypes, self.cdll.ttk_pwconv_wgrad_partial_bytes.restype = [c_int64, c_int, c_int], ctypes.c_size_t
+        self.cdll.ttk_stem_wgrad_partial_bytes.argtypes, self.cdll.ttk_stem_wgrad_partial_bytes.restype = [], ctypes.c_size_t
         self._fns = {}
         for name, sig in _SIGNATURES.items():
             fn = getattr(self.cdll, name)  # AttributeError if the symbol is missing: loud by design
@@ -183,4 +184,4 @@ def ptr(t: torch.Tensor | None):
 def exported_symbols() -> list[str]:
     return ["ttk_abi_version", "ttk_last_error_string", "ttk_partial_rows_elementwise",
             "ttk_partial_rows_gemm", "ttk_partial_rows_dwconv", "ttk_heads_num_rows", "ttk_pwconv_prepared_bytes",
-            "ttk_pwconv_wgrad_partial_bytes"] + list(_SIGNATURES)
+            "ttk_pwconv_wgrad_partial_bytes", "ttk_stem_wgrad_partial_bytes"] + list(_SIGNATURES)

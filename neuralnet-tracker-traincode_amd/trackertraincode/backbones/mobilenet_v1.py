@@ -190,8 +190,9 @@ def _forward_impl(x, params, buffers, momentum, eps, training):
     return feat, ctx
 
 
-# Data-parallel hook: called as hook([(param, grad), ...]) whenever a block's parameter gradients are
-# final, in reverse layer order (trackertraincode.parallel.GradAllReduce.on_ready).
+# Data-parallel hook: called as hook(arena, [(param, lo, hi), ...]) whenever a block's parameter gradients - elements
+# [lo, hi) of the flat gradient arena - are final, in reverse layer order (trackertraincode.parallel.GradAllReduce.on_ready
+# all-reduces the ranges in place).
 grad_ready_hook = None
 
 
@@ -221,8 +222,12 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
     for q in params:
         offs.append(total)
         total += (q.numel() + 63) // 64 * 64
+    offs.append(total)
     arena = torch.zeros(total, dtype=torch.float32, device=gfeat.device)
     grads = [arena[o:o + q.numel()].view(q.shape) for o, q in zip(offs, params)]
+
+    def announce(first, last):  # parameters first .. last-1 are final: their slice of the arena (padding included) may travel
+        grad_ready_hook(arena, [(params[i], offs[i], offs[i + 1]) for i in range(first, last)])
     last = ctx.stages[-1]
     C = last.y.shape[-1]
 
@@ -235,8 +240,12 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
     side = _side_stream(gfeat.device) if (_USE_WGRAD_STREAM and not _DETERMINISTIC) else None
     wg_scratch = None
     if _DETERMINISTIC:
+        # one scratch buffer for every weight-gradient reduction of this backward (used one after the other on one stream):
+        # slices / workgroups store partial results there and a second kernel folds them in a fixed order
         need = max(L.pwconv_wgrad_partial_bytes(B * d[2] * d[3], d[4], d[5]) for d in ctx.dims)
-        wg_scratch = torch.empty(max(need, 4) // 4, dtype=torch.float32, device=gfeat.device)
+        need = max(need, L.cdll.ttk_stem_wgrad_partial_bytes())
+        need = max(need, max(L.partial_rows_dwconv(B, d[0], d[1], d[4], d[6], True) * 9 * d[4] * 4 for d in ctx.dims))
+        wg_scratch = torch.empty(need // 4, dtype=torch.float32, device=gfeat.device)
     keep = []
 
     g = torch.empty_like(last.y)
@@ -274,18 +283,18 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         dWd = grads[pi]  # accumulated by the fused weight-gradient path of bwd_data
         g_prev = torch.empty_like(st_prev.y)
         L.call("ttk_dwconv3x3_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), p(g) if has_skip else None, p(st_prev.y),
-               p(st_prev.bn), p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 1, B, h, w_, cin, stride)
+               p(st_prev.bn), p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 1, p(wg_scratch), B, h, w_, cin, stride)
         bwd_finalize(st_prev, L.partial_rows_dwconv(B, h, w_, cin, stride, True), B * h * w_, pi - 2 if k > 0 else 1)
         g = g_prev
         if grad_ready_hook is not None:  # this block's conv + bn_dw gradients and its own bn_sep gradients are final
             if side is not None:
                 main.wait_event(done)
-            grad_ready_hook([(params[i], grads[i]) for i in range(pi, pi + 6)])
+            announce(pi, pi + 6)
     st0 = ctx.stages[0]
     _, _, H, W = ctx.x.shape
-    L.call("ttk_stem_bwd_weight", p(g), p(st0.y), p(st0.bn), p(ctx.x), p(grads[0]), 1, B, H, W)
+    L.call("ttk_stem_bwd_weight", p(g), p(st0.y), p(st0.bn), p(ctx.x), p(grads[0]), 1, p(wg_scratch), B, H, W)
     if grad_ready_hook is not None:
-        grad_ready_hook([(params[i], grads[i]) for i in range(3)])
+        announce(0, 3)
     if side is not None:
         main.wait_stream(side)  # join: everything after backward (clip+Adam) sees the weight gradients
         keep.clear()

@@ -155,17 +155,31 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
     return feat, c
 
 
+# Data-parallel hook (see mobilenet_v1.grad_ready_hook): hook(arena, [(param, lo, hi), ...]) per finished residual block.
+grad_ready_hook = None
+
+
 def _backward_impl(c: _Ctx, gfeat, params):
     L, p = _hip.lib(), _hip.ptr
     B, part, partd = c.B, c.part, c.partd
     dev = gfeat.device
-    grads = [None] * len(params)
     new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    # one zeroed arena for every parameter gradient (the weight-gradient kernels accumulate atomically): one fill launch,
+    # and contiguous ranges that a data-parallel all-reduce can take in place
+    offs, total = [], 0
+    for q in params:
+        offs.append(total)
+        total += (q.numel() + 63) // 64 * 64
+    offs.append(total)
+    arena = torch.zeros(total, dtype=torch.float32, device=dev)
+    grads = [arena[o:o + q.numel()].view(q.shape) for o, q in zip(offs, params)]
+
+    def announce(first, last):
+        if grad_ready_hook is not None:
+            grad_ready_hook(arena, [(params[i], offs[i], offs[i + 1]) for i in range(first, last)])
 
     def bwd_finalize(bn, rows, C, count, gi, scratch=None):
-        dgamma, dbeta = new(C), new(C)
-        L.call("ttk_bn_bwd_finalize", p(scratch if scratch is not None else part), rows, C, count, p(params[gi]), p(bn), p(dgamma), p(dbeta), 0)
-        grads[gi], grads[gi + 1] = dgamma, dbeta
+        L.call("ttk_bn_bwd_finalize", p(scratch if scratch is not None else part), rows, C, count, p(params[gi]), p(bn), p(grads[gi]), p(grads[gi + 1]), 0)
 
     # parameter index of every block's first tensor
     starts, pi, cin = [], 3, 64
@@ -190,22 +204,16 @@ def _backward_impl(c: _Ctx, gfeat, params):
         if has_ds:
             bwd_finalize(k.bnd, rows_gs, C, M, pi + 7, scratch=partd)
         # conv2: weight gradient, then data gradient through relu(bn1(y1)) (+ bn1 sums)
-        dW2 = torch.zeros_like(params[pi + 3])
-        L.call("ttk_conv_bwd_weight", p(gs), p(k.y2), p(k.bn2), p(k.a_mid), p(dW2), B, k.ho, k.ho, C, C, 3, 3, 1, 1)
-        grads[pi + 3] = dW2
+        L.call("ttk_conv_bwd_weight", p(gs), p(k.y2), p(k.bn2), p(k.a_mid), p(grads[pi + 3]), B, k.ho, k.ho, C, C, 3, 3, 1, 1)
         g1 = new(B, k.ho, k.ho, C)
         L.call("ttk_conv_bwd_data", p(gs), p(k.y2), p(k.bn2), p(k.w2b), p(k.y1), p(k.bn1), p(g1), p(part), B, k.ho, k.ho, C, C, 3, 3, 1, 1)
         bwd_finalize(k.bn1, L.partial_rows_gemm(M), C, M, pi + 1)
         # conv1: weight gradient, raw data gradient w.r.t. the block input
-        dW1 = torch.zeros_like(params[pi])
-        L.call("ttk_conv_bwd_weight", p(g1), p(k.y1), p(k.bn1), p(k.a_in), p(dW1), B, k.h, k.h, k.cin, C, 3, 3, k.stride, 1)
-        grads[pi] = dW1
+        L.call("ttk_conv_bwd_weight", p(g1), p(k.y1), p(k.bn1), p(k.a_in), p(grads[pi]), B, k.h, k.h, k.cin, C, 3, 3, k.stride, 1)
         g_in = new(B, k.h, k.h, k.cin)
         L.call("ttk_conv_bwd_data", p(g1), p(k.y1), p(k.bn1), p(k.w1b), None, None, p(g_in), None, B, k.h, k.h, k.cin, C, 3, 3, k.stride, 1)
         if has_ds:
-            dWd = torch.zeros_like(params[pi + 6])
-            L.call("ttk_conv_bwd_weight", p(gs), p(k.yd), p(k.bnd), p(k.a_in), p(dWd), B, k.h, k.h, k.cin, C, 1, 1, k.stride, 0)
-            grads[pi + 6] = dWd
+            L.call("ttk_conv_bwd_weight", p(gs), p(k.yd), p(k.bnd), p(k.a_in), p(grads[pi + 6]), B, k.h, k.h, k.cin, C, 1, 1, k.stride, 0)
             wdb = torch.empty((3, 1, k.cin, C), dtype=torch.int16, device=dev)
             L.call("ttk_conv_weight_repack", p(params[pi + 6]), None, p(wdb), C, k.cin, 1, 1)
             g_sc = new(B, k.h, k.h, k.cin)
@@ -226,9 +234,10 @@ def _backward_impl(c: _Ctx, gfeat, params):
             g0 = new(B, Ho, Ho, 64)
             L.call("ttk_maxpool3x3s2_bwd", p(g_in), p(g_sc), p(c.idx), p(c.y0), p(c.bn0), p(g0), p(part), B, Ho, Ho, 64)
             bwd_finalize(c.bn0, L.partial_rows_elementwise(B * Ho * Ho * 16), 64, B * Ho * Ho, 1)
-            dW0 = torch.empty_like(params[0])
-            L.call("ttk_stem7_bwd_weight", p(g0), p(c.y0), p(c.bn0), p(c.x), p(dW0), B, c.H, c.W)
-            grads[0] = dW0
+            L.call("ttk_stem7_bwd_weight", p(g0), p(c.y0), p(c.bn0), p(c.x), p(grads[0]), B, c.H, c.W)
+        # this block's conv / BatchNorm gradients are final (the stem's after the first block)
+        announce(pi, pi + (9 if has_ds else 6))
+    announce(0, 3)
     return grads
 
 

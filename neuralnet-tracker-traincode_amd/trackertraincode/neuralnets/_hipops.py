@@ -22,6 +22,11 @@ def _call(name, *args):
     _hip.lib().call(name, *args)
 
 
+# Data-parallel hook (trackertraincode.parallel.install): called as hook(arena, [(param, lo, hi), ...]) when the fused
+# heads' parameter gradients - slices of one flat arena - are final (before the backbone's backward starts).
+grad_ready_hook = None
+
+
 # ---------------------------------------------------------------------------------------------
 # heads
 # ---------------------------------------------------------------------------------------------
@@ -52,6 +57,7 @@ class HeadsFn(Function):
               int(pt), int(use_offset), int(rot6d), _p(z), _p(roi), _p(coord), _p(rot), _p(qu), _p(Lc), _p(Lr), _p(pts), _p(shp))
         ctx.save_for_backward(feat, wcat, z, ids32, Pc, Pkc, kp, ke)
         ctx.cfg = (bool(unc), bool(pt), bool(use_offset), bool(rot6d), [w.shape[0] for w in ws])
+        ctx.param_refs = (lin, P, Pk)  # the nn.Parameters themselves (identity is kept through apply): for the data-parallel hook
         outs = [roi, coord, rot, qu]
         if unc:
             outs += [Lc, Lr]
@@ -76,9 +82,12 @@ class HeadsFn(Function):
         if pt:
             g_pts, g_shp = g[k], g[k + 1]
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-        dz, dprow, dfeat, dwcat, dbcat = new(B, NZ), new(B, 8), new(B, F), new(NZ, F), new(NZ)
-        dP = new(8, 4) if Pc is not None else None
-        dPk = new(8, 4) if Pkc is not None else None
+        dz, dprow, dfeat = new(B, NZ), new(B, 8), new(B, F)
+        # every parameter gradient of the heads in ONE flat arena (one all-reduce range for data-parallel replicas)
+        arena = new(NZ * F + NZ + 64)
+        dwcat, dbcat = arena[:NZ * F].view(NZ, F), arena[NZ * F:NZ * F + NZ]
+        dP = arena[NZ * F + NZ:NZ * F + NZ + 32].view(8, 4) if Pc is not None else None
+        dPk = arena[NZ * F + NZ + 32:NZ * F + NZ + 64].view(8, 4) if Pkc is not None else None
         _call("ttk_heads_bwd", _p(feat), _p(wcat), _p(z), _p(ids32), _p(Pc), _p(Pkc), _p(kp), _p(ke), B, F, NZ, int(unc), int(pt),
               int(use_offset), int(rot6d), _p(g_roi), _p(g_coord), _p(g_rot), _p(g_qu), _p(g_Lc), _p(g_Lr), _p(g_pts), _p(g_shp), _p(dz),
               _p(dprow), _p(dfeat), _p(dwcat), _p(dbcat), _p(dP), _p(dPk))
@@ -87,6 +96,17 @@ class HeadsFn(Function):
         for r in rows:
             lin_grads += [dwcat[r0:r0 + r], dbcat[r0:r0 + r]]
             r0 += r
+        if grad_ready_hook is not None:
+            lin, P, Pk = ctx.param_refs
+            entries, r0 = [], 0
+            for i, r in enumerate(rows):
+                entries += [(lin[2 * i], r0 * F, (r0 + r) * F), (lin[2 * i + 1], NZ * F + r0, NZ * F + r0 + r)]
+                r0 += r
+            if dP is not None:
+                entries.append((P, NZ * F + NZ, NZ * F + NZ + 32))
+            if dPk is not None:
+                entries.append((Pk, NZ * F + NZ + 32, NZ * F + NZ + 64))
+            grad_ready_hook(arena, entries)  # the announced range ends with the last table present: every element of it was written
         # inputs: feat, ids, unc, pt, use_offset, rot6d, keypts, keyeig, P, Pk, *lin
         return (dfeat, None, None, None, None, None, None, None, dP, dPk, *lin_grads)
 

@@ -105,15 +105,23 @@ def _as_quat(rot):
 
 
 class CoordPoseNLLLoss(nn.Module):
-    """Independent Normal per coordinate, weighted (reference :72-97); not used by the training script."""
+    """Independent Normal per coordinate, weighted [xy/2, xy/2, size] and averaged over the three (reference :72-97;
+    the training script uses CorrelatedCoordPoseNLLLoss instead).  `coord_scales` are per-coordinate standard
+    deviations [n, 3]."""
 
     def __init__(self, xy_weight: float, head_size_weight: float, distribution: SimpleDistributionSwitch = "gaussian"):
         super().__init__()
         _gaussian_only(distribution)
-        self.register_buffer("weights", torch.as_tensor([xy_weight / 2.0, xy_weight / 2.0, head_size_weight], dtype=torch.float32))
+        self._w = (xy_weight / 2.0, xy_weight / 2.0, float(head_size_weight))  # host copy: no device read per step
+        self.register_buffer("weights", torch.as_tensor(self._w, dtype=torch.float32))
 
     def __call__(self, preds, sample):
-        raise NotImplementedError("CoordPoseNLLLoss is not part of the reference's training configuration (setup_losses uses CorrelatedCoordPoseNLLLoss)")
+        mu, sigma, x = preds["coord"], preds["coord_scales"], sample["coord"]
+        if sigma.shape != mu.shape:
+            raise ValueError(f"CoordPoseNLLLoss: coord_scales {tuple(sigma.shape)} must be per-coordinate like coord {tuple(mu.shape)}")
+        # -mean_d w_d log N(x_d; mu_d, sigma_d): one single-column launch of the Normal kernel per coordinate
+        terms = [_hipops.NormalNllFn.apply(mu[:, d:d + 1], sigma[:, d:d + 1], x[:, d:d + 1], False, 0, 1.0, 1.0) for d in range(3)]
+        return (terms[0] * self._w[0] + terms[1] * self._w[1] + terms[2] * self._w[2]) / 3.0
 
 
 class MixWithUniformProbability(nn.Module):

@@ -1,20 +1,27 @@
 """Data-parallel replicas over RCCL/xGMI (no counterpart in the reference, which is single-device:
 SURVEY.md §2.2).  One process per GPU; every rank holds a full replica (12.9 MB of fp32 parameters),
 crops are sharded over ranks, BatchNorm statistics stay per-replica (what stock DDP would do to the
-reference), and the only exchange step is the gradient all-reduce:
+reference), and the only exchange step is the gradient all-reduce.
 
-  * the backbone's backward hands finished gradient groups to `GradAllReduce.on_ready` in reverse
-    layer order (largest tensors first: dw6 + dw5_6 = 6.3 MB become ready after ~15 % of backward),
-  * each group is packed into one flat buffer and all-reduced (sum) asynchronously on a side stream
-    (torch.distributed "nccl" backend = RCCL on ROCm), overlapping the rest of backward,
-  * `finish()` waits, scales by 1/world and unpacks into the gradient tensors autograd returns.
+Zero-copy exchange.  The backbone's backward writes every parameter gradient into ONE flat arena and
+announces finished ranges of it in reverse layer order (`grad_ready_hook(arena, entries)`, largest
+tensors first: dw6 + dw5_6 = 6.3 MB are final after ~15 % of backward); the fused heads do the same with
+their own small arena.  `GradAllReduce` merges adjacent ranges into buckets of >= `bucket_bytes` and
+all-reduces each bucket IN PLACE, asynchronously, on a side stream (torch.distributed "nccl" backend =
+RCCL on ROCm) while backward continues - no packing copy before the collective, none after it: the
+tensors autograd installs as `param.grad` are views of the arena.  The sums are not divided by the
+world size here; `grad_scale` (= 1/world) is handed to the fused clip+Adam kernel, which reads every
+gradient as grad_scale * g (train.ClipAdam.grad_scale).  `finish()` issues O(buckets) launches.
+
+Gradients that did not come through an arena (a handful of tiny tensors such as DiagonalScaleParameter.hidden_scale)
+are packed into one extra bucket by `finish()`.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of 12.9 MB moves ~22.6 MB per
 GPU, ~0.15 ms - far below a step, so a handful of large buckets is the right granularity.
 """
 from __future__ import annotations
 
-from typing import Iterable, List
+from typing import Iterable, Sequence
 
 import torch
 import torch.distributed as dist
@@ -28,61 +35,115 @@ class GradAllReduce:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self._always = always_reduce
         self.bucket_bytes = bucket_bytes
-        self._pending: list[tuple[torch.Tensor, list[torch.Tensor], object]] = []
-        self._queue: list[torch.Tensor] = []
-        self._queued_bytes = 0
         self._stream = None
+        self._works: list = []                      # collectives in flight
+        self._open = None                           # (arena, lo, hi) still growing towards a bucket
+        self._done: list[tuple[torch.Tensor, int, int]] = []  # ranges already handed to RCCL this step
+        self._entries: list[tuple[torch.nn.Parameter, torch.Tensor, int, int]] = []  # (param, arena, lo, hi)
+        self.collectives = 0                        # issued in the current / last step (tests, launch-count evidence)
+        self.zero_copy = self.copied = 0            # parameters whose .grad was / was not the arena view itself (last finish())
 
-    # ---- called during backward (autograd worker thread) with (param, grad) pairs whose values are final.
-    # The parameter is kept because autograd may CLONE the returned gradient into param.grad (it does
-    # when somebody else - like this object - still references the tensor): finish() writes to param.grad.
-    def on_ready(self, pairs):
-        if self.world == 1 and not self._always:
+    @property
+    def grad_scale(self) -> float:
+        """What the optimiser must multiply the exchanged gradients with (they are sums over the replicas)."""
+        return 1.0 / self.world
+
+    @property
+    def active(self) -> bool:
+        return self.world > 1 or self._always
+
+    # ---- called during backward (autograd worker thread) ---------------------------------------------------------
+    def on_ready(self, arena: torch.Tensor, entries: Sequence[tuple]):
+        """`entries` = [(param, lo, hi), ...]: elements [lo, hi) of the flat float32 `arena` hold the final gradient of
+        `param`; the entries of one call are adjacent (padding between tensors belongs to the range)."""
+        if not self.active or not entries:
             return
-        for p, g in pairs:
-            if g is None:
-                continue
-            self._queue.append((p, g))
-            self._queued_bytes += g.numel() * g.element_size()
-        if self._queued_bytes >= self.bucket_bytes:
+        lo, hi = min(e[1] for e in entries), max(e[2] for e in entries)
+        self._entries += [(p, arena, a, b) for p, a, b in entries]
+        if self._open is not None:
+            o_arena, o_lo, o_hi = self._open
+            if o_arena is arena and lo <= o_hi and hi >= o_lo:
+                self._open = (arena, min(lo, o_lo), max(hi, o_hi))  # adjacent (reverse layer order: the new range ends where the open one begins)
+            else:
+                self._flush()
+                self._open = (arena, lo, hi)
+        else:
+            self._open = (arena, lo, hi)
+        _, o_lo, o_hi = self._open
+        if (o_hi - o_lo) * 4 >= self.bucket_bytes:
             self._flush()
 
-    def _flush(self):
-        if not self._queue:
-            return
-        grads, self._queue, self._queued_bytes = self._queue, [], 0
-        flat = torch.cat([g.reshape(-1) for _, g in grads])
+    def _all_reduce(self, flat: torch.Tensor):
         if flat.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=flat.device)
-            self._stream.wait_stream(torch.cuda.current_stream(flat.device))
+            self._stream.wait_stream(torch.cuda.current_stream(flat.device))  # the producing kernels of this range are enqueued
             with torch.cuda.stream(self._stream):
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            flat.record_stream(self._stream)
         else:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        self._pending.append((flat, grads, work))
+        self._works.append(work)
+        self.collectives += 1
 
-    # ---- called after backward, before the optimiser
-    def finish(self, extra_params: Iterable[torch.nn.Parameter] = ()):
-        """Reduce whatever is still queued (plus the .grad of `extra_params`, e.g. the head parameters),
-        wait for all buckets and write the averaged values into the parameters' gradients."""
-        if self.world == 1 and not self._always:
+    def _flush(self):
+        if self._open is None:
             return
-        seen = {id(p) for _, grads, _ in self._pending for p, _ in grads} | {id(p) for p, _ in self._queue}
-        self.on_ready([(p, p.grad) for p in extra_params if p.grad is not None and id(p) not in seen])
+        arena, lo, hi = self._open
+        self._open = None
+        self._all_reduce(arena[lo:hi])  # a view: the collective works in place
+        self._done.append((arena, lo, hi))
+
+    # ---- called after backward, before the optimiser -------------------------------------------------------------
+    def finish(self, params: Iterable[torch.nn.Parameter] = ()):
+        """Reduce what is still open, plus the gradients of `params` that no arena covered, and make the current stream
+        wait for every collective.  Afterwards each `param.grad` holds the SUM over the replicas."""
+        if not self.active:
+            return
         self._flush()
-        inv = 1.0 / self.world
-        for flat, grads, work in self._pending:
-            work.wait()  # CUDA: makes the current stream wait for the collective
-            flat.mul_(inv)
+        covered = {id(p) for p, _, _, _ in self._entries}
+        rest = [p for p in params if p.grad is not None and id(p) not in covered]
+        packed = None
+        if rest:
+            packed = torch.cat([p.grad.reshape(-1) for p in rest])  # a handful of tiny tensors: one launch
+            self._all_reduce(packed)
+        for w in self._works:
+            w.wait()  # CUDA: the current stream waits for the collective
+        if packed is not None:
             off = 0
-            for p, g in grads:
-                n = g.numel()
-                target = p.grad if (p is not None and p.grad is not None) else g
-                target.copy_(flat[off:off + n].view_as(target))
+            for p in rest:
+                n = p.grad.numel()
+                p.grad.copy_(packed[off:off + n].view_as(p.grad))
                 off += n
-        self._pending.clear()
+        # autograd normally installs the arena views themselves as .grad (zero copy); if it cloned one (the view was
+        # still referenced elsewhere when AccumulateGrad ran) the clone may hold pre-exchange values: overwrite it
+        self.zero_copy = self.copied = 0
+        for p, arena, lo, hi in self._entries:
+            g = p.grad
+            if g is None:
+                continue
+            base = arena.data_ptr() + 4 * lo
+            if g.data_ptr() != base:
+                g.copy_(arena[lo:lo + g.numel()].view_as(g))
+                self.copied += 1
+            else:
+                self.zero_copy += 1
+        self._works.clear()
+        self._done.clear()
+        self._entries.clear()
+
+    def begin_step(self):
+        self.collectives = 0
+
+
+def install(reducer: GradAllReduce | None):
+    """Point the backbones' and the fused heads' gradient-ready hooks at `reducer` (None: remove them)."""
+    from .backbones import mobilenet_v1, resnet
+    from .neuralnets import _hipops
+
+    hook = reducer.on_ready if reducer is not None else None
+    mobilenet_v1.grad_ready_hook = hook
+    resnet.grad_ready_hook = hook
+    _hipops.grad_ready_hook = hook
 
 
 def broadcast_module_state(module: torch.nn.Module, src: int = 0, process_group=None):

@@ -131,15 +131,15 @@ class SyntheticPoseLoader:
 
 
 def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights=None, use_weights_as_sampling_frequency=True,
-                                 enable_image_aug=True, rotation_aug_angle=30.0, roi_override="original", device="cuda"):
-    """Signature of the reference (pipelines.py:359-369).  `datasets` may be the string "synthetic" (or a
-    list of (Tag, weight) pairs) to obtain seeded synthetic loaders with the reference's contract; real
-    dataset ids need the HDF5 pipeline, which this package does not contain."""
+                                 enable_image_aug=True, rotation_aug_angle=30.0, roi_override="original", device="cuda", seed=1234):
+    """Signature of the reference (pipelines.py:359-369) plus `seed` (data-parallel replicas draw different streams).
+    `datasets` may be the string "synthetic" (or a list of (Tag, weight) pairs) to obtain seeded synthetic loaders with
+    the reference's contract; real dataset ids need the HDF5 pipeline, which this package does not contain."""
     if datasets == "synthetic":
         datasets = [(Tag.POSE_WITH_LANDMARKS, 11.0), (Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS, 1.0)]
     if isinstance(datasets, (list, tuple)) and datasets and isinstance(datasets[0], tuple) and isinstance(datasets[0][0], Tag):
-        augs = make_image_augmentations(torch.Generator().manual_seed(99)) if enable_image_aug and str(device).startswith("cuda") else None
-        train = SyntheticPoseLoader(batchsize, datasets, device=device, inputsize=inputsize, image_augmentations=augs)
+        augs = make_image_augmentations(torch.Generator().manual_seed(99 + seed)) if enable_image_aug and str(device).startswith("cuda") else None
+        train = SyntheticPoseLoader(batchsize, datasets, device=device, seed=seed, inputsize=inputsize, image_augmentations=augs)
         test = SyntheticPoseLoader(batchsize, [(Tag.POSE_WITH_LANDMARKS, 1.0)], device=device, seed=4321, inputsize=inputsize,
                                    steps_per_epoch=max(1, 400 // batchsize))
         return train, test, len(train) * batchsize

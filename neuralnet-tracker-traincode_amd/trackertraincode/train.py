@@ -208,23 +208,44 @@ def ExponentialUpThenSteps(optimizer, num_up, gamma, steps):
 # fused clip + Adam
 # ---------------------------------------------------------------------------------------------
 class ClipAdam(torch.optim.Optimizer):
-    """torch.optim.Adam semantics (betas, eps, L2 weight_decay, per-group lr) preceded by
+    """torch.optim.Adam semantics (betas, eps, L2 weight_decay, per-group lr, per-parameter step counts) preceded by
     clip_grad_norm_(all params, max_norm) - one C-ABI call, two kernel launches, no host sync.
-    State layout matches torch.optim.Adam (`step`, `exp_avg`, `exp_avg_sq`)."""
+    State layout matches torch.optim.Adam (`step`, `exp_avg`, `exp_avg_sq`); the step counts live on the device (the
+    kernel advances them), so a step can be captured in a hipGraph and `state_dict()` / `load_state_dict()` resume
+    exactly.  `grad_scale` (default 1): the stored gradients are read as grad_scale * g - 1/world when a
+    data-parallel all-reduce left sums in place (trackertraincode.parallel)."""
 
     CHUNK = 4096  # elements per workgroup: ~800 workgroups for the 3.2 M parameters (16384 left most of the 256 CUs idle)
 
     def __init__(self, params, lr=1.0e-3, betas=(0.9, 0.999), eps=1.0e-8, weight_decay=0.0, max_norm: float | None = 1.0):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # capturable: torch then keeps a loaded `step` as a float32 tensor on the parameter's device
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=True))
         self.param_groups = [g for g in self.param_groups]
         if len([g for g in self.param_groups if g["params"]]) > 4:
             raise ValueError("ClipAdam supports at most 4 non-empty parameter groups")
         if len({(g["betas"], g["eps"]) for g in self.param_groups}) != 1:
             raise ValueError("all groups must share betas and eps")
         self.max_norm = max_norm
+        self.grad_scale = 1.0
         self._tables = None
-        self._t = 0
+        self._uploaded = None      # gradient addresses the device table currently holds
+        self._upload_event = None  # recorded behind the last upload of the pinned table
+        self._t = 0                # optimiser steps taken (host-side count; the per-parameter counts are state[p]["step"])
         self.last_grad_norm: Tensor | None = None
+
+    def _invalidate(self):
+        self._tables, self._uploaded, self._upload_event = None, None, None
+
+    def load_state_dict(self, state_dict):
+        """Resume: the loaded moments / step counts replace the live ones, so every cached device address is stale."""
+        super().load_state_dict(state_dict)
+        self._invalidate()
+        steps = [float(st["step"]) for st in self.state.values() if "step" in st]
+        self._t = int(max(steps)) if steps else 0
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._invalidate()
 
     def _build_tables(self):
         plist, groups = [], []
@@ -232,14 +253,22 @@ class ClipAdam(torch.optim.Optimizer):
             for p in g["params"]:
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                     raise RuntimeError("ClipAdam needs contiguous float32 CUDA parameters")
-                st = self.state[p]
-                if not st:
-                    st["step"] = torch.tensor(0.0)
-                    st["exp_avg"] = torch.zeros_like(p)
-                    st["exp_avg_sq"] = torch.zeros_like(p)
                 plist.append(p)
                 groups.append(gi)
         dev = plist[0].device
+        # per-parameter step counts in ONE device array; state[p]["step"] are views of it (what torch.optim.Adam keeps per
+        # parameter, and what state_dict() saves)
+        steps = torch.zeros(len(plist), dtype=torch.float32, device=dev)
+        for ti, p in enumerate(plist):
+            st = self.state[p]
+            if "step" in st:
+                steps[ti] = float(st["step"])  # only after load_state_dict: rare
+            st["step"] = steps[ti]
+            for key in ("exp_avg", "exp_avg_sq"):
+                if key not in st:
+                    st[key] = torch.zeros_like(p)
+                elif not (st[key].is_cuda and st[key].dtype == torch.float32 and st[key].is_contiguous()):
+                    st[key] = st[key].to(device=dev, dtype=torch.float32).contiguous()
         ct, co = [], []
         for ti, p in enumerate(plist):
             for off in range(0, p.numel(), self.CHUNK):
@@ -249,14 +278,38 @@ class ClipAdam(torch.optim.Optimizer):
         self._tables = dict(
             params=plist, numel=i32([p.numel() for p in plist]), group=i32(groups), chunk_tensor=i32(ct), chunk_offset=i32(co),
             nchunks=len(ct), ptrs_host=torch.zeros((len(plist), 4), dtype=torch.int64).pin_memory(),
-            ptrs=torch.zeros((len(plist), 4), dtype=torch.int64, device=dev),
+            ptrs=torch.zeros((len(plist), 4), dtype=torch.int64, device=dev), steps=steps,
             partial=torch.empty(len(ct), dtype=torch.float32, device=dev), norm=torch.zeros(1, dtype=torch.float32, device=dev),
-            hyper=torch.zeros(12, dtype=torch.float32, device=dev),  # TTK_ADAM_HYPER_* block (include/ttk.h)
+            hyper=torch.zeros(8, dtype=torch.float32, device=dev),  # TTK_ADAM_HYPER_* block (include/ttk.h)
         )
         h = self._tables["ptrs_host"]
         for ti, p in enumerate(plist):
             st = self.state[p]
             h[ti, 0], h[ti, 2], h[ti, 3] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+        self._uploaded = None
+
+    def _upload_grad_pointers(self, T, capturing):
+        """The device table of (param, grad, exp_avg, exp_avg_sq) addresses.  Only the gradient column ever changes, and
+        only when the allocator hands out new addresses; the pinned staging table is rewritten only after the previous
+        asynchronous upload has read it (a host that runs several steps ahead of the GPU would otherwise overwrite the
+        addresses of a step that has not been copied yet)."""
+        gptrs = []
+        for p in T["params"]:
+            g = p.grad
+            if g is not None and not g.is_contiguous():
+                g = p.grad = g.contiguous()
+            gptrs.append(0 if g is None else g.data_ptr())
+        gptrs = tuple(gptrs)
+        if gptrs == self._uploaded:
+            return
+        if self._upload_event is not None and not capturing:
+            self._upload_event.synchronize()
+        T["ptrs_host"][:, 1] = torch.tensor(gptrs, dtype=torch.int64)
+        T["ptrs"].copy_(T["ptrs_host"], non_blocking=True)
+        if not capturing:
+            self._upload_event = torch.cuda.Event()
+            self._upload_event.record()
+        self._uploaded = gptrs
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -264,44 +317,32 @@ class ClipAdam(torch.optim.Optimizer):
         if self._tables is None:
             self._build_tables()
         T = self._tables
-        h = T["ptrs_host"]
-        for ti, p in enumerate(T["params"]):
-            g = p.grad
-            if g is not None and not g.is_contiguous():
-                g = p.grad = g.contiguous()
-            h[ti, 1] = 0 if g is None else g.data_ptr()
-        T["ptrs"].copy_(h, non_blocking=True)
+        capturing = torch.cuda.is_current_stream_capturing()
+        self._upload_grad_pointers(T, capturing)
         b1, b2 = self.param_groups[0]["betas"]
         lr4 = (ctypes.c_float * 4)(*([g["lr"] for g in self.param_groups] + [0.0] * 4)[:4])
         wd4 = (ctypes.c_float * 4)(*([g["weight_decay"] for g in self.param_groups] + [0.0] * 4)[:4])
         p_ = _hip.ptr
-        capturing = torch.cuda.is_current_stream_capturing()
-        if capturing:
-            # inside a hipGraph capture nothing of the step may be baked into launch arguments: learning rates, weight
-            # decays and the step counter are read from (and the counter advanced in) the device block `hyper`
-            hyper, t = p_(T["hyper"]), 1
-        else:
-            self._t += 1
-            hyper, t = None, self._t
+        # inside a hipGraph capture nothing of the step may be baked into launch arguments: learning rates and weight
+        # decays are read from the device block `hyper` (the step counts always live on the device)
+        hyper = p_(T["hyper"]) if capturing else None
         _hip.lib().call("ttk_clip_adam", p_(T["ptrs"]), p_(T["numel"]), p_(T["group"]), p_(T["chunk_tensor"]), p_(T["chunk_offset"]),
-                        T["nchunks"], self.CHUNK, lr4, wd4, b1, b2, self.param_groups[0]["eps"], 1.0 - b1 ** t,
-                        1.0 - b2 ** t, float(self.max_norm or 0.0), p_(T["partial"]), p_(T["norm"]), hyper)
+                        T["nchunks"], self.CHUNK, lr4, wd4, b1, b2, self.param_groups[0]["eps"], float(self.max_norm or 0.0),
+                        float(self.grad_scale), p_(T["steps"]), p_(T["partial"]), p_(T["norm"]), hyper)
         if not capturing:
-            for p in T["params"]:
-                self.state[p]["step"] += 1
+            self._t += 1
         self.last_grad_norm = T["norm"]
         return None
 
     # ---- hipGraph support -----------------------------------------------------------------------
     def sync_hyper_to_device(self):
-        """Write the groups' lr / weight_decay and the current step count into the device block a captured step
-        reads.  Called before a capture and whenever the scheduler changed a learning rate (once per epoch)."""
+        """Write the groups' lr / weight_decay into the device block a captured step reads.  Called before a capture and
+        whenever the scheduler changed a learning rate (once per epoch)."""
         if self._tables is None:
             self._build_tables()
         vals = ([g["lr"] for g in self.param_groups] + [0.0] * 4)[:4] + ([g["weight_decay"] for g in self.param_groups] + [0.0] * 4)[:4]
-        vals += [float(self._t), 0.0, 0.0, 0.0]
         self._tables["hyper"].copy_(torch.tensor(vals, dtype=torch.float32))  # synchronous, pageable: rare
-        self._hyper_sig = tuple(vals[:8])
+        self._hyper_sig = tuple(vals)
 
     def before_graph_replay(self):
         """Push a changed learning rate / weight decay (scheduler step) to the device block before the replay."""
@@ -311,10 +352,8 @@ class ClipAdam(torch.optim.Optimizer):
             self.sync_hyper_to_device()
 
     def after_graph_replay(self):
-        """Host-side bookkeeping of one replayed step (the device counter was advanced by the graph)."""
+        """Host-side bookkeeping of one replayed step (the device counters were advanced by the graph)."""
         self._t += 1
-        for p in self._tables["params"]:
-            self.state[p]["step"] += 1
 
 
 # ---------------------------------------------------------------------------------------------
@@ -383,10 +422,10 @@ def _criterion_weights(c, step):
 class GraphedTrainStep:
     """zero_grad + training_step + backward + ClipAdam.step captured ONCE as a hipGraph and replayed every step.
 
-    A pose-estimator step is ~330 kernel launches, two thirds of them small head / loss / autograd-glue kernels;
-    enqueueing them from Python costs ~11 ms per step next to ~13 ms of GPU work, and that host time is the next
-    bound once the kernels get faster.  A captured graph enqueues the same work with one call.  (The reference has
-    no counterpart: Lightning drives eager PyTorch; `train_poseestimator.py:442-454`.)
+    A pose-estimator step is ~200 kernel launches, half of them small head / loss / bookkeeping kernels; enqueueing
+    them from Python costs ~4.7 ms of host time per step next to ~8.8 ms of GPU work (B = 512) - on a slower host, or
+    at smaller batches, that host time is the bound and a captured graph, which enqueues the same work with one call,
+    removes it.  (The reference has no counterpart: Lightning drives eager PyTorch; `train_poseestimator.py:442-454`.)
 
     The graph stays valid while the sub-batch layout (tags, sizes, fields), the epoch-dependent loss weights and the
     learning-rate-independent launch arguments stay the same: `run()` compares a signature and re-captures when it
@@ -455,7 +494,8 @@ class GraphedTrainStep:
 def fit(model: nn.Module, train_loader, criterions, optimizer, scheduler=None, epochs=1, callbacks=(), on_step=None,
         grad_sync=None):
     """Epoch loop with Lightning's ordering.  `grad_sync(model)`, if given, runs between backward and the
-    optimiser step (data-parallel gradient all-reduce)."""
+    optimiser step (data-parallel: GradAllReduce.finish - waits for the in-place all-reduces that ran during backward).
+    Gradients are dropped (set_to_none) before every step: the arena views autograd installs are the exchange buffers."""
     for cb in callbacks:
         if hasattr(cb, "on_train_start"):
             cb.on_train_start(model)

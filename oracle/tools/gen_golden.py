@@ -15,6 +15,9 @@ What is pinned (SURVEY.md §8 "Caller / harness rows" table):
   optim_<cfg>.npz   a28,a29: 3 steps of clip_grad_norm_(1.0) + 3-group Adam + per-epoch LambdaLR.
   schedule.npz      a28: ExponentialUpThenSteps LR-factor tables for E=200 and E=1500.
   swa.npz           a30: AveragedModel(use_buffers=True) over 3 snapshots.
+  init.npz          a5: weights of a FRESH reference model under torch.manual_seed(s) - the custom conv init law
+                    N(0, sqrt(2/(kh*kw*Cout))) (backbones/mobilenet_v1.py:155-158) applied in the reference's module
+                    construction order (digests of every parameter and buffer, seeds 0 and 7).
 """
 from __future__ import annotations
 
@@ -305,8 +308,26 @@ def gen_swa():
     np.savez_compressed(os.path.join(GOLD, "swa.npz"), **out)
 
 
+def gen_init():
+    """Seed parity of fresh models: torch's CPU generator + the reference's construction order decide every value."""
+    out = {}
+    for seed in (0, 7):
+        torch.manual_seed(seed)
+        net = models.NetworkWithPointHead(enable_point_head=True, enable_uncertainty=True, config="mobilenetv1",
+                                          backbone_args={"use_blurpool": False})
+        for k, v in net.state_dict().items():
+            if k.endswith("keypts") or k.endswith("keyeigvecs"):
+                continue  # the 3DMM blob is absent from the reference checkout: synthetic, not part of the init law
+            out[f"seed{seed}/{k}"] = digest(as_np(v).astype(np.float64))
+    out["meta"] = json.dumps({"seeds": [0, 7], "config": dict(enable_point_head=True, enable_uncertainty=True, config="mobilenetv1",
+                                                               backbone_args={"use_blurpool": False})})
+    np.savez_compressed(os.path.join(GOLD, "init.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["model", "optim", "schedule", "swa"]
+    which = sys.argv[1:] or ["model", "optim", "schedule", "swa", "init"]
+    if "init" in which:
+        gen_init()
     if "schedule" in which:
         gen_schedule()
     if "swa" in which:

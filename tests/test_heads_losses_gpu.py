@@ -85,7 +85,7 @@ def test_every_loss_kernel():
     import trackertraincode.neuralnets.negloglikelihood as NLL
 
     n = 53
-    pred, lab = _loss_inputs(n)
+    pred0, lab = _loss_inputs(n)
     gmm = R.ShapeGmm(os.path.join(GOLDEN, "shapeparams_gmm.npz"))
     cases = [
         ("rot", LS.QuatPoseLoss("approx_distance"), R.loss_rot), ("xy", LS.PoseXYLoss("l2"), R.loss_xy),
@@ -97,9 +97,15 @@ def test_every_loss_kernel():
         ("nllcoord", NLL.CorrelatedCoordPoseNLLLoss(), R.loss_nllcoord), ("nllbox", NLL.BoxNLLLoss(), R.loss_nllbox),
         ("nllpoints3d", NLL.Points3dNLLLoss(0.8, 0.0), R.loss_nllpoints3d),
         ("nllpoints2d", NLL.Points3dNLLLoss(0.8, 0.0, pointdimension=2), lambda p, s: R.loss_nllpoints3d(p, s, 2)),
+        # reference negloglikelihood.py:169-177 and :72-97 restated with torch.distributions (fp64)
+        ("nllshape", NLL.ShapeParamsNLLLoss(), lambda p, s: -torch.distributions.Normal(p["shapeparam"], p["shapeparam_scales"]).log_prob(s["shapeparam"]).mean(-1)),
+        ("nllcoordpose", NLL.CoordPoseNLLLoss(0.6, 0.25),
+         lambda p, s: -torch.distributions.Normal(p["coord"], p["coord_scales"]).log_prob(s["coord"]).mul(torch.tensor([0.3, 0.3, 0.25], dtype=torch.float64)[None, :]).mean(-1)),
     ]
     gv = np.random.default_rng(9).standard_normal(n)
+    diag_scales = np.random.default_rng(11).uniform(0.3, 2, (n, 3))  # CoordPoseNLLLoss: independent per-coordinate scales
     for name, mine, ref in cases:
+        pred = dict(pred0, coord_scales=diag_scales) if name == "nllcoordpose" else pred0
         p64 = {k: torch.from_numpy(np.ascontiguousarray(v)).double().requires_grad_(True) for k, v in pred.items()}
         s64 = {k: torch.from_numpy(v).double() for k, v in lab.items()}
         v_ref = ref(p64, s64)

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 def test_single_rank_rccl_step_equals_plain_step(tmp_path):
     import trackertraincode.backbones.mobilenet_v1 as MB
     import trackertraincode.train as train
+    from trackertraincode import parallel
     from trackertraincode.parallel import GradAllReduce, broadcast_module_state
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -31,16 +32,22 @@ def test_single_rank_rccl_step_equals_plain_step(tmp_path):
             broadcast_module_state(net)
             params = list(net.parameters())
             red = GradAllReduce(bucket_bytes=1 << 20, always_reduce=True) if with_reducer else None
-            MB.grad_ready_hook = red.on_ready if red else None
+            parallel.install(red)
+            collectives = []
             try:
                 losses, first_grads = [], None
                 for it in range(3):
                     for p in params:
                         p.grad = None
+                    if red:
+                        red.begin_step()
                     out = train.training_step(net, make_batches(meta, "cuda"), 0, crit)
                     out["loss"].backward()
                     if red:
                         red.finish(params)
+                        collectives.append(red.collectives)
+                        # zero copy: the gradients autograd installed ARE the views of the arenas that travelled
+                        assert red.copied == 0 and red.zero_copy >= 90, (red.copied, red.zero_copy)
                     if it == 0:  # later steps diverge chaotically at B=8 (atomics order -> Adam), see test_model_gpu
                         torch.cuda.synchronize()
                         first_grads = [p.grad.cpu().numpy().copy() for p in params]
@@ -48,7 +55,11 @@ def test_single_rank_rccl_step_equals_plain_step(tmp_path):
                     losses.append(out["loss"].item())
                 torch.cuda.synchronize()
             finally:
-                MB.grad_ready_hook = None
+                parallel.install(None)
+            if red:
+                # 12.9 MB of backbone gradients in 1 MB buckets + the heads' arena + one packed bucket of stragglers:
+                # O(buckets) collectives, not O(parameters) (the model has ~190 parameter tensors)
+                assert all(5 <= c <= 20 for c in collectives), collectives
             return losses, [p.detach().cpu().numpy().copy() for p in params], first_grads
 
         l0, p0, g0 = run(False)
