@@ -82,13 +82,13 @@ class KernelTimer:
                 K, N, mode, by = co, ci, 1, 4 * (2 * M * co + 2 * M * ci + ci * co)
             else:
                 by = 4 * (2 * M * co + M * ci + ci * co)
-                if ci >= 128 and co >= 128 and ci * co >= 128 * 256 and (ci % 256 == 0 or co % 256 == 0):
-                    return ("pw16_wgrad_k<128, 256>" if ci % 256 == 0 else "pw16_wgrad_k<256, 128>"), fl, by
+                if ci >= 128 and co >= 128 and (ci % 256 == 0 or co % 256 == 0 or (ci == 128 and co == 128)):
+                    return ("pw16_wgrad_k<128, 256, 1>" if ci % 256 == 0 else "pw16_wgrad_k<256, 128, 1>" if co % 256 == 0 else "pw16_wgrad_k<128, 128, 1>"), fl, by
                 return "pw_wgrad_k", fl, by
             if K >= 128 and N % 256 == 0:
-                return f"pw16_k<128, 256, {mode}, {mode}>", fl, by  # <BM, BN, A-operand form, epilogue form>
+                return f"pw16_k<128, 256, {mode}, {mode}, 1>", fl, by  # <BM, BN, A-operand form, epilogue form, register sets>
             if K >= 128 and N == 128:
-                return f"pw16_k<256, 128, {mode}, {mode}>", fl, by
+                return f"pw16_k<256, 128, {mode}, {mode}, 1>", fl, by
             if N == 64 and K == 32:
                 return f"pw_gemm_k<64, 2, 2, {mode}, 1>", fl, by  # single LDS stage
             return (f"pw_gemm_k<{min(N, 128)}, 2, 2, {mode}, 2>" if N >= 64 else f"pw_gemm_k<32, 4, 1, {mode}, 2>"), fl, by

@@ -474,7 +474,10 @@ __global__ void __launch_bounds__(kBlock) pw_prepare_absmax_k(PrepArgs a) {
   for (int i = ty; i < 32; i += kBlock / 32) m = fmaxf(m, fabsf(a.w[l][(int64_t)(r0 + i) * Cin + c0 + tx]));
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(a.out[l] + 8 * (int64_t)Cin * Cout), __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) {  // read first: after the first few blocks almost no wave still has to raise the slot
+    unsigned* slot = reinterpret_cast<unsigned*>(a.out[l] + 8 * (int64_t)Cin * Cout);
+    if (__float_as_uint(m) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, __float_as_uint(m));
+  }
 }
 
 __global__ void __launch_bounds__(kBlock) pw_prepare_weights_k(PrepArgs a) {

@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const float* __restrict__ bn_pw,
              const float* __restrict__ X, const float* __restrict__ bn_x, float* __restrict__ dW, float* __restrict__ partial,
              int64_t M, int Cin, int Cout, int64_t rows_per_slice) {
-  static_assert(BM + BN == 384 && (BM == 128 || BM == 256), "128x256 or 256x128");
+  static_assert((BM + BN == 384 && (BM == 128 || BM == 256)) || (BM == 128 && BN == 128), "128x256, 256x128 or 128x128");
   constexpr int RS = TTK_RS;
   constexpr int APL = BM * 32, BPL = BN * 32;
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -641,8 +641,13 @@ bool f16_gemm_shape(int K, int Nout) {
   return K >= 128 && K % 32 == 0 && ((Nout >= 256 && Nout % 256 == 0) || Nout == 128);
 }
 bool f16_wgrad_shape(int Cin, int Cout) {
-  if (Cin < 128 || Cout < 128 || Cin % 128 || Cout % 128 || (int64_t)Cin * Cout < 128 * 256) return false;
-  return Cin % 256 == 0 || Cout % 256 == 0;
+  if (Cin < 128 || Cout < 128 || Cin % 128 || Cout % 128) return false;
+  return Cin % 256 == 0 || Cout % 256 == 0 || (Cin == 128 && Cout == 128);
+}
+static int f16_wgrad_tiles(int Cin, int Cout) {
+  if (Cin % 256 == 0) return (Cout / 128) * (Cin / 256);
+  if (Cout % 256 == 0) return (Cout / 256) * (Cin / 128);
+  return (Cout / 128) * (Cin / 128);
 }
 
 // slices of M for the weight gradient: one workgroup per CU, all of equal length
@@ -657,7 +662,7 @@ static void wgrad_slices(int64_t M, int tiles, int64_t& slices, int64_t& rows) {
 
 size_t f16_wgrad_partial_bytes(int64_t M, int Cin, int Cout) {
   if (!f16_wgrad_shape(Cin, Cout)) return 0;
-  const int tiles = (Cout / 128) * (Cin / 128) / 2;
+  const int tiles = f16_wgrad_tiles(Cin, Cout);
   int64_t slices, rows;
   wgrad_slices(M, tiles, slices, rows);
   return (size_t)slices * Cin * Cout * sizeof(float);
@@ -666,12 +671,14 @@ size_t f16_wgrad_partial_bytes(int64_t M, int Cin, int Cout) {
 bool launch_f16_wgrad(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
                       float* partial, int64_t M, int Cin, int Cout, hipStream_t st) {
   if (!f16_wgrad_shape(Cin, Cout)) return false;
-  const bool wide = Cin % 256 == 0;  // 128 (Cout) x 256 (Cin) tiles, else 256 x 128
-  const int tiles = wide ? (Cout / 128) * (Cin / 256) : (Cout / 256) * (Cin / 128);
+  const bool wide = Cin % 256 == 0;  // 128 (Cout) x 256 (Cin) tiles, else 256 x 128, else (128 x 128 channels) one 128 x 128 tile
+  const int tiles = f16_wgrad_tiles(Cin, Cout);
   int64_t slices, rows;
   wgrad_slices(M, tiles, slices, rows);
   const dim3 grid(tiles, (unsigned)slices);
-  if (wide)
+  if (!wide && Cout % 256 != 0)
+    hipLaunchKernelGGL((pw16_wgrad_k<128, 128, TTK_DW>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
+  else if (wide)
     hipLaunchKernelGGL((pw16_wgrad_k<128, 256, TTK_DW>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
   else  // (one register set: two spill)
     hipLaunchKernelGGL((pw16_wgrad_k<256, 128, 1>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
@@ -688,7 +695,8 @@ __global__ void __launch_bounds__(256) w16_absmax_k(const float* __restrict__ w,
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(w[i]));
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0) atomicMax(wmax, __float_as_uint(m));  // non-negative floats order like their bit patterns
+  if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > __hip_atomic_load(wmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(wmax, __float_as_uint(m));  // non-negative floats order like their bit patterns
 }
 
 // w[rows][K] fp32 -> two fp16 planes [K/32][rows][32] of w * pow2_scale(*wmax)
