@@ -32,7 +32,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 / fp16 MFMA peak (v_mfma_f32_32x32x16_{bf16,f16}, 32 cycles per issue)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0          # HBM3E spec (6.29 TB/s measured copy)
-ALGO_BYTES_PER_CROP = 55.55e6  # 13 888 321 fp32 elements
+ALGO_BYTES_PER_CROP = 55.55e6  # 13 888 321 fp32 elements (bf16 activation storage: 27.78 MB)
 ALGO_FLOP_PER_CROP = 1.372e9   # 686 045 536 MAC fwd+bwd
 
 
@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="crops per GPU")
     ap.add_argument("--backbone", default="mobilenetv1", choices=["mobilenetv1", "resnet18"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16-all"],
+                    help="BASELINE config 5's storage variant (separate line, dtype bf16; mobilenetv1 only): bf16 = activations bf16 in HBM, their "
+                    "gradients fp32; bf16-all = both bf16")
     ap.add_argument("--traffic-json", default=None, help="rocprofv3 PMC summary (tools/pmc_summary.py) taken with THIS build; "
                     "fills roofline.traffic (null without it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -63,6 +66,8 @@ class KernelTimer:
     """HIP-event timing of the C-ABI calls on the stream they are launched on (torch's current stream),
     with the algorithmic flops/bytes of each call."""
 
+    act_bytes = 4  # bytes per activation element in HBM (2 with --precision bf16)
+
     def __init__(self):
         self.records = []  # (name, start, end, flops, bytes)
         self.enabled = False
@@ -72,36 +77,38 @@ class KernelTimer:
         """(kernel name as rocprofv3 prints it, flops, algorithmic bytes) of one call; fp32 = 4 B/element.
         Mirrors the dispatch rules of csrc/pwconv.hip + pwconv_split.hip + dwconv_tiled.hip."""
         ints = [x for x in a if isinstance(x, int) and not isinstance(x, bool)]
+        eb = KernelTimer.act_bytes
         if name.startswith("ttk_pwconv1x1"):
-            # forward / data gradient end with the scratch pointer of the pre-split weights (an int here)
-            M, ci, co = ints[-3:] if name == "ttk_pwconv1x1_bwd_weight" else ints[-4:-1]
+            # trailing arguments: ..., M, Cin, Cout, [scratch pointer of the split weights,] act_bf16
+            M, ci, co = ints[-4:-1] if name == "ttk_pwconv1x1_bwd_weight" else ints[-5:-2]
             fl = 2 * M * ci * co
             if name == "ttk_pwconv1x1_fwd":
-                K, N, mode, by = ci, co, 0, 4 * (M * ci + M * co + ci * co)
+                K, N, mode, by = ci, co, 0, eb * (M * ci + M * co) + 4 * ci * co
             elif name == "ttk_pwconv1x1_bwd_data":
-                K, N, mode, by = co, ci, 1, 4 * (2 * M * co + 2 * M * ci + ci * co)
+                K, N, mode, by = co, ci, 1, eb * (2 * M * co + 2 * M * ci) + 4 * ci * co
             else:
-                by = 4 * (2 * M * co + M * ci + ci * co)
+                by = eb * (2 * M * co + M * ci) + 4 * ci * co
                 if ci >= 128 and co >= 128 and (ci % 256 == 0 or co % 256 == 0 or (ci == 128 and co == 128)):
-                    return ("pw16_wgrad_k<128, 256, 1>" if ci % 256 == 0 else "pw16_wgrad_k<256, 128, 1>" if co % 256 == 0 else "pw16_wgrad_k<128, 128, 1>"), fl, by
+                    tn = "float" if eb == 4 else "unsigned short"
+                    return (f"pw16_wgrad_k<128, 256, 1, {tn}>" if ci % 256 == 0 else f"pw16_wgrad_k<256, 128, 1, {tn}>" if co % 256 == 0 else f"pw16_wgrad_k<128, 128, 1, {tn}>"), fl, by
                 return "pw_wgrad_k", fl, by
             if K >= 128 and N % 256 == 0:
-                return f"pw16_k<128, 256, {mode}, {mode}, 1>", fl, by  # <BM, BN, A-operand form, epilogue form, register sets>
+                return f"pw16_k<128, 256, {mode}, {mode}, 1, {'float' if eb == 4 else 'unsigned short'}>", fl, by  # <BM, BN, A form, epilogue form, register sets, storage>
             if K >= 128 and N == 128:
-                return f"pw16_k<256, 128, {mode}, {mode}, 1>", fl, by
+                return f"pw16_k<256, 128, {mode}, {mode}, 1, {'float' if eb == 4 else 'unsigned short'}>", fl, by
             if N == 64 and K == 32:
                 return f"pw_gemm_k<64, 2, 2, {mode}, 1>", fl, by  # single LDS stage
             return (f"pw_gemm_k<{min(N, 128)}, 2, 2, {mode}, 2>" if N >= 64 else f"pw_gemm_k<32, 4, 1, {mode}, 2>"), fl, by
         if name == "ttk_dwconv3x3_fwd":
-            B, H, W, C, s_ = ints[-5:]
+            B, H, W, C, s_ = a[-6:-1]
             n_in, n_out = B * H * W * C, B * ((H - 1) // s_ + 1) * ((W - 1) // s_ + 1) * C
-            by = 4 * (n_in * (1 + bool(a[2]) + bool(a[3])) + n_out)
-            return f"dw_fwd_tiled_k<{s_}>", 2 * 9 * n_out, by
+            by = eb * (n_in * (1 + bool(a[2]) + bool(a[3])) + n_out)
+            return f"dw_fwd_tiled_k<{s_}, {'float' if eb == 4 else 'unsigned short'}>", 2 * 9 * n_out, by
         if name == "ttk_dwconv3x3_bwd_data":
-            B, H, W, C, s_ = a[-5:]
+            B, H, W, C, s_ = a[-6:-1]
             n_in, n_out = B * H * W * C, B * ((H - 1) // s_ + 1) * ((W - 1) // s_ + 1) * C
-            by = 4 * (2 * n_out + n_in * (2 + bool(a[4]) + bool(a[7] or a[8])))
-            return f"dw_bwd_tiled_k<{s_}>", 2 * 2 * 9 * n_out, by
+            by = eb * (2 * n_out + n_in * (2 + bool(a[4]) + bool(a[7] or a[8])))
+            return f"dw_bwd_tiled_k<{s_}, {'float' if eb == 4 else 'unsigned short'}>", 2 * 2 * 9 * n_out, by
         if name in ("ttk_conv_fwd", "ttk_conv_bwd_data", "ttk_conv_bwd_weight"):  # ResNet18 implicit GEMMs (split-bf16, 6 products)
             B, H, W, ci, co, kh, kw, s_, _pad = ints[-9:]
             Ho, Wo = (H - 1) // s_ + 1, (W - 1) // s_ + 1
@@ -127,8 +134,8 @@ class KernelTimer:
             kern, fl, by = timer.work(name, args)
             ints = [x for x in args if isinstance(x, int) and not isinstance(x, bool)]
             timer.records.append((kern, s, e, fl, by))
-            timer.shapes.append(tuple(ints[-4:-1]) if name in ("ttk_pwconv1x1_fwd", "ttk_pwconv1x1_bwd_data") else tuple(ints[-3:]) if name == "ttk_pwconv1x1_bwd_weight"
-                                else tuple(ints[-9:]) if name.startswith("ttk_conv_") else tuple(ints[-5:]))
+            timer.shapes.append(tuple(ints[-5:-2]) if name in ("ttk_pwconv1x1_fwd", "ttk_pwconv1x1_bwd_data") else tuple(ints[-4:-1]) if name == "ttk_pwconv1x1_bwd_weight"
+                                else tuple(ints[-9:]) if name.startswith("ttk_conv_") else tuple(args[-6:-1]))
 
         lib.call = call
 
@@ -253,6 +260,8 @@ def main():
     from trackertraincode import parallel
     from trackertraincode.parallel import GradAllReduce, broadcast_module_state
 
+    MB.set_activation_dtype(args.precision)
+    KernelTimer.act_bytes = 4 if args.precision == "fp32" else 2
     net, crit, opt, batches, train = build_step(args, device)
     broadcast_module_state(net)
     reducer = GradAllReduce() if world > 1 else None
@@ -408,13 +417,13 @@ def main():
         line = {
             "metric": f"face-crops/sec fwd+bwd @ batch {args.batch}", "value": crops, "unit": "crops/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": f"NetworkWithPointHead({args.backbone}, point head on, NLL off = training-script defaults): "
                                    "zero_grad + fwd + multi-task loss + bwd" + (" + RCCL grad all-reduce overlapped with bwd" if world > 1 else "") + " + fused clip/Adam step",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "input": "129x129x1 f32",
                        "parallelism": f"dp{world}"},
             "roofline": roof,
-            "step_roofline": ({"hbm_frac_of_8TBs": per_gpu * ALGO_BYTES_PER_CROP / (PEAK_HBM_GBS * 1e9),
+            "step_roofline": ({"hbm_frac_of_8TBs": per_gpu * ALGO_BYTES_PER_CROP * (0.5 if args.precision == "bf16-all" else 1.0) / (PEAK_HBM_GBS * 1e9),
                                "fp32_mfma_frac_of_157TF": per_gpu * ALGO_FLOP_PER_CROP / (PEAK_FP32_MFMA_TFLOPS * 1e12)} if args.backbone == "mobilenetv1"
                               else {"fp32_mfma_frac_of_157TF": per_gpu * 4.203e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12)}),  # 4.203 GFLOP/crop
             "enqueue": ("hipGraph replay (1 capture)" if use_graph[0] else "eager Python launches") + enqueue_note,

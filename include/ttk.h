@@ -66,6 +66,18 @@ enum {
  *                                                         (ttk_avgpool_bwd, ttk_dwconv3x3_bwd_data)
  *   DY_BOUND  >= max |ga*(g-gmean) + gb*(y-mean)|         written by ttk_bn_bwd_finalize from GMAX and the variance */
 enum { TTK_AUX_ACT_BOUND = 0, TTK_AUX_DY_BOUND = 1, TTK_AUX_GMAX = 2 };
+/* Storage of the activation-sized tensors of the MobileNet path.  Entry points with an `act_bf16` argument take them as
+ * `void*`; the argument is a set of TTK_STORE_* bits:
+ *   0                                      everything float32 - the reference's precision, the default
+ *   TTK_STORE_ACT_BF16                     ACTIVATIONS (raw conv outputs y, materialised block inputs) bfloat16, their
+ *                                          GRADIENTS (g, g_dw, g_prev) float32 - `--precision bf16`
+ *   TTK_STORE_ACT_BF16|TTK_STORE_GRAD_BF16 both bfloat16 - `--precision bf16-all` (BatchNorm's backward subtracts the
+ *                                          per-channel mean of a nearly constant gradient: 8 mantissa bits are too few
+ *                                          for the early layers, see tests/test_bf16_gpu.py)
+ * bf16 values are rounded to nearest even on store; BatchNorm statistics are always taken from the values as stored;
+ * arithmetic, statistics, weights and weight gradients are fp32 in every mode. */
+#define TTK_STORE_ACT_BF16 1
+#define TTK_STORE_GRAD_BF16 2
 #define TTK_MAX_PARTIAL_ROWS_ELEMENTWISE 1024
 #define TTK_GEMM_BLOCK_M 128
 
@@ -103,14 +115,15 @@ int ttk_bn_bwd_finalize(float* part, int part_rows, int C, int64_t count, const 
  * x[B][H][W] -> y[B][Ho][Wo][32], Ho = (H+1)/2.  w is the reference's weight (32,1,5,5) as is.
  * part may be NULL (eval).
  * ------------------------------------------------------------------------------------------- */
-int ttk_stem_fwd(const float* x, const float* w, float* y, float* part, int B, int H, int W,
-                 ttk_stream_t stream);
+int ttk_stem_fwd(const float* x, const float* w, void* y, float* part, int B, int H, int W,
+                 int act_bf16, ttk_stream_t stream);
 /* dW[32][25] (+)= sum dy * x, dy formed on load from (g, y, bn = the stem's BatchNorm block). */
 /* partial (nullable): scratch of ttk_stem_wgrad_partial_bytes() - the workgroups store their partial sums there and a
  * second kernel folds them in a fixed order (bitwise reproducible) instead of fp32 atomics. */
 size_t ttk_stem_wgrad_partial_bytes(void);
-int ttk_stem_bwd_weight(const float* g, const float* y, const float* bn, const float* x, float* dw,
-                        int accumulate, float* partial, int B, int H, int W, ttk_stream_t stream);
+int ttk_stem_bwd_weight(const void* g, const void* y, const float* bn, const float* x, float* dw,
+                        int accumulate, float* partial, int B, int H, int W, int act_bf16,
+                        ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Depthwise 3x3, pad 1, stride 1|2, groups=C, bias=False - DepthWiseBlock.conv_dw,
@@ -120,9 +133,9 @@ int ttk_stem_bwd_weight(const float* g, const float* y, const float* bn, const f
  * a_out (nullable): materialise a_in, needed when THIS block has a residual connection
  * (mobilenet_v1.py:70,86-88).  w is the reference's weight (C,1,3,3) as is.
  * ------------------------------------------------------------------------------------------- */
-int ttk_dwconv3x3_fwd(const float* yprev, const float* bn_prev, const float* skip_prev, float* a_out,
-                      const float* w, float* y, float* part, int B, int H, int W, int C, int stride,
-                      ttk_stream_t stream);
+int ttk_dwconv3x3_fwd(const void* yprev, const float* bn_prev, const void* skip_prev, void* a_out,
+                      const float* w, void* y, float* part, int B, int H, int W, int C, int stride,
+                      int act_bf16, ttk_stream_t stream);
 /* Gradient w.r.t. the block input, masked by relu and handed to the producer's BatchNorm:
  *   G      = convT3x3(dy_dw) (+ skip_grad)        dy_dw formed on load from (g_dw, y_dw, bn_dw)
  *   g_prev = G * [a_in > 0]                        -> written, with partials sum(g_prev), sum(g_prev*(yprev-mean))
@@ -132,11 +145,11 @@ int ttk_dwconv3x3_fwd(const float* yprev, const float* bn_prev, const float* ski
  * Raises bn_prev[TTK_BN_AUX][TTK_AUX_GMAX] to max |g_prev| (the bound the previous block's GEMMs scale by).
  * dw_partial (nullable): scratch of ttk_partial_rows_dwconv(.., 1) * 9 * C floats - the fused weight gradient is then
  * folded from per-workgroup rows in a fixed order (bitwise reproducible) instead of fp32 atomics. */
-int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* bn_dw, const float* w,
-                           const float* skip_grad, const float* yprev, float* bn_prev,
-                           const float* skip_prev, const float* a_in, float* g_prev, float* part,
+int ttk_dwconv3x3_bwd_data(const void* g_dw, const void* y_dw, const float* bn_dw, const float* w,
+                           const void* skip_grad, const void* yprev, float* bn_prev,
+                           const void* skip_prev, const void* a_in, void* g_prev, float* part,
                            float* dw, int dw_accumulate, float* dw_partial, int B, int H, int W, int C,
-                           int stride, ttk_stream_t stream);
+                           int stride, int act_bf16, ttk_stream_t stream);
 /* dW[C][9] (+)= sum dy_dw * a_in(taps) (standalone form). */
 int ttk_dwconv3x3_bwd_weight(const float* g_dw, const float* y_dw, const float* bn_dw,
                              const float* yprev, const float* bn_prev, const float* skip_prev,
@@ -154,22 +167,22 @@ int ttk_dwconv3x3_bwd_weight(const float* g_dw, const float* y_dw, const float* 
  * wsplit (forward and data gradient): scratch of ttk_pwconv_prepared_bytes(Cin, Cout) for the split weight operand,
  * or a block that ttk_pwconv_prepare_weights filled (then w / wt == NULL); NULL selects the fp32 MFMA kernels.
  * ------------------------------------------------------------------------------------------- */
-int ttk_pwconv1x1_fwd(const float* ydw, const float* bn_dw, const float* w, float* y, float* part,
-                      int64_t M, int Cin, int Cout, void* wsplit, ttk_stream_t stream);
+int ttk_pwconv1x1_fwd(const void* ydw, const float* bn_dw, const float* w, void* y, float* part,
+                      int64_t M, int Cin, int Cout, void* wsplit, int act_bf16, ttk_stream_t stream);
 /* g_dw[M][Cin] = (dy[M][Cout] . w[Cout][Cin]) * [bn_dw(ydw) > 0],  dy formed on load from (g, y, bn_pw);
  * wt = w transposed ([Cin][Cout], ttk_transpose).  partials: sum(g_dw), sum(g_dw*(ydw-mean)). */
-int ttk_pwconv1x1_bwd_data(const float* g, const float* y, const float* bn_pw, const float* wt,
-                           const float* ydw, const float* bn_dw, float* g_dw, float* part, int64_t M,
-                           int Cin, int Cout, void* wsplit, ttk_stream_t stream);
+int ttk_pwconv1x1_bwd_data(const void* g, const void* y, const float* bn_pw, const float* wt,
+                           const void* ydw, const float* bn_dw, void* g_dw, float* part, int64_t M,
+                           int Cin, int Cout, void* wsplit, int act_bf16, ttk_stream_t stream);
 /* dw[Cout][Cin] += dy^T . a_dw.  dw must be zeroed (or hold the running gradient) before the call.
  * partial == NULL: the M dimension is split over workgroups that add atomically (fp32 atomics: the result depends on
  * the order the hardware commits them).  partial = scratch of ttk_pwconv_wgrad_partial_bytes(M, Cin, Cout) (0 = this
  * shape / GEMM mode has no such form): every slice of M stores its tile and a second kernel adds the slices to dw in a
  * fixed order - bitwise reproducible. */
 size_t ttk_pwconv_wgrad_partial_bytes(int64_t M, int Cin, int Cout);
-int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* bn_pw, const float* ydw,
+int ttk_pwconv1x1_bwd_weight(const void* g, const void* y, const float* bn_pw, const void* ydw,
                              const float* bn_dw, float* dw, float* partial, int64_t M, int Cin, int Cout,
-                             ttk_stream_t stream);
+                             int act_bf16, ttk_stream_t stream);
 /* Weight operands of n (<= 16) pointwise layers (w[i]: [Cout][Cin] fp32 device pointers; w, cin, cout and
  * prepared are HOST arrays): three launches for all layers (|w| maxima, planes).  prepared[i]: device scratch of
  * ttk_pwconv_prepared_bytes(cin[i], cout[i]); pass it as `wsplit` with w == NULL (forward) / wt == NULL (data gradient)
@@ -183,12 +196,12 @@ int ttk_transpose(const float* in, float* out, int rows, int cols, ttk_stream_t 
  * AdaptiveAvgPool2d(1) + view over the last block's output - mobilenet_v1.py:143,180-181.
  *   feat[B][C] = mean_hw max(bn(y) (+ skip), 0)
  * ------------------------------------------------------------------------------------------- */
-int ttk_avgpool_fwd(const float* y, const float* bn, const float* skip, float* feat, int B, int HW,
-                    int C, ttk_stream_t stream);
+int ttk_avgpool_fwd(const void* y, const float* bn, const void* skip, float* feat, int B, int HW,
+                    int C, int act_bf16, ttk_stream_t stream);
 /* g[B][HW][C] = gfeat[B][C]/HW * [bn(y)+skip > 0]; partials sum(g), sum(g*(y-mean)); raises
  * bn[TTK_BN_AUX][TTK_AUX_GMAX] to max |g|. */
-int ttk_avgpool_bwd(const float* gfeat, const float* y, float* bn, const float* skip, float* g,
-                    float* part, int B, int HW, int C, ttk_stream_t stream);
+int ttk_avgpool_bwd(const float* gfeat, const void* y, float* bn, const void* skip, void* g,
+                    float* part, int B, int HW, int C, int act_bf16, ttk_stream_t stream);
 /* a[.][C] = max(bn(y) (+ skip), 0): materialises a post-activation tensor (the `intermediates` list
  * MobileNet.forward returns, mobilenet_v1.py:165-186). */
 int ttk_bn_act(const float* y, const float* bn, const float* skip, float* a, int64_t rows, int C,

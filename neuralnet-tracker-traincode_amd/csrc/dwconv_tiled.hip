@@ -150,11 +150,11 @@ __device__ __forceinline__ void slab_partials(D4 s1, D4 s2, int q, int C, int c_
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-template <int S>
+template <int S, typename T>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3)))
-dw_fwd_tiled_k(const float* __restrict__ yprev, const float* __restrict__ bn_prev,
-                                                          const float* __restrict__ skip_prev, float* __restrict__ a_out,
-                                                          const float* __restrict__ w, float* __restrict__ y,
+dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
+                                                          const T* __restrict__ skip_prev, T* __restrict__ a_out,
+                                                          const float* __restrict__ w, T* __restrict__ y,
                                                           float* __restrict__ part, int B, int H, int W, int C, int Ho, int Wo,
                                                           int R, int nbands, int nslabs, int NI, int NCT, int TW) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [NI][stage_rows][tile width + 2][32] + reduction scratch
@@ -194,8 +194,8 @@ dw_fwd_tiled_k(const float* __restrict__ yprev, const float* __restrict__ bn_pre
         rows[u] = (row >= o0 && row < o1 && col >= cx0 && col < cx0 + tw) ? 1 : 0;  // the one tile this input pixel belongs to
         in[u] = ee < nstage && row >= 0 && row < H && col >= 0 && col < W;
         off[u] = in[u] ? (((size_t)(n0 + img) * H + row) * W + col) * C + slab * kSlab + 4 * q : 0;  // qq == q: kBlock is a multiple of 8
-        yv[u] = in[u] ? ld4nt(yprev + off[u]) : f4(0.f);
-        sk[u] = (in[u] && skip_prev) ? ld4nt(skip_prev + off[u]) : f4(0.f);
+        yv[u] = in[u] ? Act<T>::ldnt(yprev + off[u]) : f4(0.f);
+        sk[u] = (in[u] && skip_prev) ? Act<T>::ldnt(skip_prev + off[u]) : f4(0.f);
       }
 #pragma unroll
       for (int u = 0; u < kFwdU; ++u) {
@@ -204,7 +204,8 @@ dw_fwd_tiled_k(const float* __restrict__ yprev, const float* __restrict__ bn_pre
         float4 a = f4(0.f);
         if (in[u]) {
           a = skip_prev ? bn.act(yv[u], sk[u]) : bn.act(yv[u]);
-          if (S == 1 && a_out && rows[u]) st4(a_out + off[u], a);
+          if (S == 1 && a_out) a = Act<T>::round(a);  // a materialised block input is used as it is stored (residual, backward)
+          if (S == 1 && a_out && rows[u]) Act<T>::st(a_out + off[u], a);
         }
         st4(lds + (size_t)pxs[u] * kSlab + 4 * q, a);
       }
@@ -223,7 +224,8 @@ dw_fwd_tiled_k(const float* __restrict__ yprev, const float* __restrict__ bn_pre
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) acc = fma4(ld4(base + ((size_t)kh * Wp + kw) * kSlab), wr.tap(kh * 3 + kw), acc);
-      st4(y + (((size_t)n * Ho + ho) * Wo + wo) * C + c0, acc);
+      acc = Act<T>::round(acc);  // statistics of what is stored
+      Act<T>::st(y + (((size_t)n * Ho + ho) * Wo + wo) * C + c0, acc);
       s1.add(acc);
       s2.addmul(acc, acc);
     }
@@ -237,14 +239,14 @@ dw_fwd_tiled_k(const float* __restrict__ yprev, const float* __restrict__ bn_pre
 // ---------------------------------------------------------------------------------------------
 // data gradient (+ fused weight gradient)
 // ---------------------------------------------------------------------------------------------
-template <int S>
+template <int S, typename T, typename TG>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3)))  // <= 168 VGPRs: 3 workgroups per CU, as the LDS tile allows
-dw_bwd_tiled_k(const float* __restrict__ g_dw, const float* __restrict__ y_dw,
+dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
                                                           const float* __restrict__ bn_dw, const float* __restrict__ w,
-                                                          const float* __restrict__ skip_grad,
-                                                          const float* __restrict__ yprev, float* __restrict__ bn_prev,
-                                                          const float* __restrict__ skip_prev, const float* __restrict__ a_in,
-                                                          float* __restrict__ g_prev, float* __restrict__ part,
+                                                          const TG* __restrict__ skip_grad,
+                                                          const T* __restrict__ yprev, float* __restrict__ bn_prev,
+                                                          const T* __restrict__ skip_prev, const T* __restrict__ a_in,
+                                                          TG* __restrict__ g_prev, float* __restrict__ part,
                                                           float* __restrict__ dwgrad, float* __restrict__ dw_partial, int B, int H, int W, int C, int Ho, int Wo,
                                                           int R, int nbands, int nslabs, int stage_floats, int NI, int NCT, int TW) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // dy[NI][stage_rows][Wo+2][32] + reduction scratch
@@ -292,8 +294,8 @@ dw_bwd_tiled_k(const float* __restrict__ g_dw, const float* __restrict__ y_dw,
         const int col = (int)(px % (unsigned)Wp) - 1 + cx0, row = ho_lo + (int)(px / (unsigned)Wp);
         in[u] = ee < nstage && col >= 0 && col < Wo;
         const size_t off = in[u] ? (((size_t)(n0 + img) * Ho + row) * Wo + col) * C + slab * kSlab + 4 * q : 0;  // qq == q (see forward)
-        gv[u] = in[u] ? ld4nt(g_dw + off) : f4(0.f);
-        yv[u] = in[u] ? ld4nt(y_dw + off) : f4(0.f);
+        gv[u] = in[u] ? Act<TG>::ldnt(g_dw + off) : f4(0.f);
+        yv[u] = in[u] ? Act<T>::ldnt(y_dw + off) : f4(0.f);
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -317,11 +319,11 @@ dw_bwd_tiled_k(const float* __restrict__ g_dw, const float* __restrict__ y_dw,
       const int hiB = r0 + (int)(ppB / (unsigned)tw), wiB = cx0 + (int)(ppB % (unsigned)tw);
       const size_t offA = (((size_t)(n0 + imgA) * H + hiA) * W + wiA) * C + c0;
       const size_t offB = (((size_t)(n0 + imgB) * H + hiB) * W + wiB) * C + c0;
-      const float4 ypA = ld4nt(yprev + offA), ypB = ld4nt(yprev + offB);
+      const float4 ypA = Act<T>::ldnt(yprev + offA), ypB = Act<T>::ldnt(yprev + offB);
       float4 rawA = f4(0.f), rawB = f4(0.f), sgA = f4(0.f), sgB = f4(0.f);
-      if (a_in) { rawA = ld4nt(a_in + offA); rawB = ld4nt(a_in + offB); }
-      else if (skip_prev) { rawA = ld4nt(skip_prev + offA); rawB = ld4nt(skip_prev + offB); }
-      if (skip_grad) { sgA = ld4nt(skip_grad + offA); sgB = ld4nt(skip_grad + offB); }
+      if (a_in) { rawA = Act<T>::ldnt(a_in + offA); rawB = Act<T>::ldnt(a_in + offB); }
+      else if (skip_prev) { rawA = Act<T>::ldnt(skip_prev + offA); rawB = Act<T>::ldnt(skip_prev + offB); }
+      if (skip_grad) { sgA = Act<TG>::ldnt(skip_grad + offA); sgB = Act<TG>::ldnt(skip_grad + offB); }
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         if (half == 1 && !hasb) break;
@@ -349,8 +351,8 @@ dw_bwd_tiled_k(const float* __restrict__ g_dw, const float* __restrict__ y_dw,
           }
         }
         if (skip_grad) G = add4(G, sg);
-        const float4 gp = mask4(G, a);
-        st4(g_prev + (half ? offB : offA), gp);
+        const float4 gp = Act<TG>::round(mask4(G, a));  // sums and maximum of what is stored
+        Act<TG>::st(g_prev + (half ? offB : offA), gp);
         gmx = fmaxf(fmaxf(gmx, fmaxf(fabsf(gp.x), fabsf(gp.y))), fmaxf(fabsf(gp.z), fabsf(gp.w)));
         s1.add(gp);
         s2.addmul(gp, sub4(yp, bnp.mean));
@@ -404,8 +406,8 @@ int ttk_partial_rows_dwconv(int B, int H, int W, int C, int stride, int backward
   return dw_tiling(B, H, W, C, stride, backward != 0).rows;
 }
 
-int ttk_dwconv3x3_fwd(const float* yprev, const float* bn_prev, const float* skip_prev, float* a_out, const float* w, float* y,
-                      float* part, int B, int H, int W, int C, int stride, ttk_stream_t stream) {
+int ttk_dwconv3x3_fwd(const void* yprev, const float* bn_prev, const void* skip_prev, void* a_out, const float* w, void* y,
+                      float* part, int B, int H, int W, int C, int stride, int act_bf16, ttk_stream_t stream) {
   TTK_REQUIRE(yprev && bn_prev && w && y, "dwconv3x3_fwd: null pointer");
   TTK_REQUIRE(dw_shape_ok2(B, H, W, C, stride), "dwconv3x3_fwd: unsupported shape B=%d H=%d W=%d C=%d stride=%d (C: power of two in 32..1024, W <= 256)", B, H, W, C, stride);
   TTK_REQUIRE(!(a_out && stride != 1), "dwconv3x3_fwd: a_out requires stride 1");
@@ -413,19 +415,18 @@ int ttk_dwconv3x3_fwd(const float* yprev, const float* bn_prev, const float* ski
   const DwTiling t = dw_tiling(B, H, W, C, stride, false);
   const size_t stage = (size_t)t.NI * t.stage_rows * ((t.NCT > 1 ? t.TW : W) + 2) * kSlab;
   const size_t sm = (stage + 16 * kSlab) * sizeof(float);  // + [4][2][32] doubles of reduction scratch
-  if (stride == 1)
-    hipLaunchKernelGGL(dw_fwd_tiled_k<1>, dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, yprev, bn_prev, skip_prev, a_out,
-                       w, y, part, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI, t.NCT, t.TW);
-  else
-    hipLaunchKernelGGL(dw_fwd_tiled_k<2>, dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, yprev, bn_prev, skip_prev, a_out,
-                       w, y, part, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI, t.NCT, t.TW);
+#define TTK_DW_FWD(S_)                                                                                                        \
+  hipLaunchKernelGGL((dw_fwd_tiled_k<S_, ActT>), dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, (const ActT*)yprev, bn_prev, \
+                     (const ActT*)skip_prev, (ActT*)a_out, w, (ActT*)y, part, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI, t.NCT, t.TW)
+  TTK_ACT_DISPATCH(act_bf16, if (stride == 1) TTK_DW_FWD(1); else TTK_DW_FWD(2));
+#undef TTK_DW_FWD
   TTK_LAUNCH_CHECK("dwconv3x3_fwd");
 }
 
-int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* bn_dw, const float* w, const float* skip_grad,
-                           const float* yprev, float* bn_prev, const float* skip_prev, const float* a_in, float* g_prev,
+int ttk_dwconv3x3_bwd_data(const void* g_dw, const void* y_dw, const float* bn_dw, const float* w, const void* skip_grad,
+                           const void* yprev, float* bn_prev, const void* skip_prev, const void* a_in, void* g_prev,
                            float* part, float* dw, int dw_accumulate, float* dw_partial, int B, int H, int W, int C, int stride,
-                           ttk_stream_t stream) {
+                           int act_bf16, ttk_stream_t stream) {
   TTK_REQUIRE(g_dw && y_dw && bn_dw && w && yprev && bn_prev && g_prev, "dwconv3x3_bwd_data: null pointer");
   TTK_REQUIRE(dw_shape_ok2(B, H, W, C, stride), "dwconv3x3_bwd_data: unsupported shape");
   TTK_REQUIRE(!(skip_grad && stride != 1), "dwconv3x3_bwd_data: residual gradient requires stride 1");
@@ -436,12 +437,12 @@ int ttk_dwconv3x3_bwd_data(const float* g_dw, const float* y_dw, const float* bn
   hipStream_t st = (hipStream_t)stream;
   if (!dw) dw_partial = nullptr;
   if (dw && !dw_accumulate && !dw_partial) hipLaunchKernelGGL(zero_fill_k, dim3((9 * C + 255) / 256), dim3(256), 0, st, dw, (int64_t)9 * C);
-  if (stride == 1)
-    hipLaunchKernelGGL(dw_bwd_tiled_k<1>, dim3(t.grid), dim3(kBlock), sm, st, g_dw, y_dw, bn_dw, w, skip_grad, yprev, bn_prev,
-                       skip_prev, a_in, g_prev, part, dw, dw_partial, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage, t.NI, t.NCT, t.TW);
-  else
-    hipLaunchKernelGGL(dw_bwd_tiled_k<2>, dim3(t.grid), dim3(kBlock), sm, st, g_dw, y_dw, bn_dw, w, skip_grad, yprev, bn_prev,
-                       skip_prev, a_in, g_prev, part, dw, dw_partial, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage, t.NI, t.NCT, t.TW);
+#define TTK_DW_BWD(S_)                                                                                                              \
+  hipLaunchKernelGGL((dw_bwd_tiled_k<S_, ActT, GradT>), dim3(t.grid), dim3(kBlock), sm, st, (const GradT*)g_dw, (const ActT*)y_dw, bn_dw, w, \
+                     (const GradT*)skip_grad, (const ActT*)yprev, bn_prev, (const ActT*)skip_prev, (const ActT*)a_in, (GradT*)g_prev, part,  \
+                     dw, dw_partial, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage, t.NI, t.NCT, t.TW)
+  TTK_ACT_DISPATCH(act_bf16, if (stride == 1) TTK_DW_BWD(1); else TTK_DW_BWD(2));
+#undef TTK_DW_BWD
   if (dw_partial) launch_fold_partials(dw_partial, t.rows, (int64_t)9 * C, dw, dw_accumulate, st);
   TTK_LAUNCH_CHECK("dwconv3x3_bwd_data");
 }

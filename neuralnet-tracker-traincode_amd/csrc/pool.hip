@@ -6,8 +6,9 @@
 namespace ttk {
 
 // thread = (sample, channel quad)
-__global__ void __launch_bounds__(kBlock) avgpool_fwd_k(const float* __restrict__ y, const float* __restrict__ bnp,
-                                                         const float* __restrict__ skip,
+template <typename T>
+__global__ void __launch_bounds__(kBlock) avgpool_fwd_k(const T* __restrict__ y, const float* __restrict__ bnp,
+                                                         const T* __restrict__ skip,
                                                          float* __restrict__ feat, int B, int HW, int C) {
   const int quads = C >> 2;
   const int64_t items = (int64_t)B * quads;
@@ -19,15 +20,16 @@ __global__ void __launch_bounds__(kBlock) avgpool_fwd_k(const float* __restrict_
     float4 s = f4(0.f);
     for (int p = 0; p < HW; ++p) {
       const size_t off = ((size_t)n * HW + p) * C + 4 * c4;
-      s = add4(s, skip ? bn.act(ld4(y + off), ld4(skip + off)) : bn.act(ld4(y + off)));
+      s = add4(s, skip ? bn.act(Act<T>::ld(y + off), Act<T>::ld(skip + off)) : bn.act(Act<T>::ld(y + off)));
     }
     st4(feat + (size_t)n * C + 4 * c4, make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv));
   }
 }
 
 // thread = (sample, pixel, channel quad)
-__global__ void __launch_bounds__(kBlock) avgpool_bwd_k(const float* __restrict__ gfeat, const float* __restrict__ y,
-                                                         float* __restrict__ bnp, const float* __restrict__ skip, float* __restrict__ g,
+template <typename T, typename TG>
+__global__ void __launch_bounds__(kBlock) avgpool_bwd_k(const float* __restrict__ gfeat, const T* __restrict__ y,
+                                                         float* __restrict__ bnp, const T* __restrict__ skip, TG* __restrict__ g,
                                                          float* __restrict__ part, int B, int HW, int C, int qshift) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int quads = C >> 2;
@@ -41,11 +43,11 @@ __global__ void __launch_bounds__(kBlock) avgpool_bwd_k(const float* __restrict_
     const int64_t pix = idx >> qshift;
     const int n = (int)(pix / HW);
     const size_t off = (size_t)idx << 2;
-    const float4 yv = ld4(y + off);
-    const float4 a = skip ? bn.act(yv, ld4(skip + off)) : bn.act(yv);
+    const float4 yv = Act<T>::ld(y + off);
+    const float4 a = skip ? bn.act(yv, Act<T>::ld(skip + off)) : bn.act(yv);
     float4 gv = ld4(gfeat + (size_t)n * C + 4 * c4);
-    gv = mask4(make_float4(gv.x * inv, gv.y * inv, gv.z * inv, gv.w * inv), a);
-    st4(g + off, gv);
+    gv = Act<TG>::round(mask4(make_float4(gv.x * inv, gv.y * inv, gv.z * inv, gv.w * inv), a));  // sums / maximum of what is stored
+    Act<TG>::st(g + off, gv);
     gmx = fmaxf(fmaxf(gmx, fmaxf(fabsf(gv.x), fabsf(gv.y))), fmaxf(fabsf(gv.z), fabsf(gv.w)));
     s1 = add4(s1, gv);
     s2 = fma4(gv, sub4(yv, bn.mean), s2);
@@ -71,24 +73,24 @@ static int log2i_(int v) {
 
 extern "C" {
 
-int ttk_avgpool_fwd(const float* y, const float* bn, const float* skip, float* feat, int B, int HW,
-                    int C, ttk_stream_t stream) {
+int ttk_avgpool_fwd(const void* y, const float* bn, const void* skip, float* feat, int B, int HW,
+                    int C, int act_bf16, ttk_stream_t stream) {
   TTK_REQUIRE(y && bn && feat, "avgpool_fwd: null pointer");
   TTK_REQUIRE(B > 0 && HW > 0 && C >= 32 && C <= 1024 && (C & (C - 1)) == 0, "avgpool_fwd: unsupported shape B=%d HW=%d C=%d", B, HW, C);
   const int64_t items = (int64_t)B * (C / 4);
-  hipLaunchKernelGGL(avgpool_fwd_k, dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, y, bn, skip, feat, B, HW,
-                     C);
+  TTK_ACT_DISPATCH(act_bf16, hipLaunchKernelGGL((avgpool_fwd_k<ActT>), dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream,
+                                                (const ActT*)y, bn, (const ActT*)skip, feat, B, HW, C));
   TTK_LAUNCH_CHECK("avgpool_fwd");
 }
 
-int ttk_avgpool_bwd(const float* gfeat, const float* y, float* bn, const float* skip, float* g,
-                    float* part, int B, int HW, int C, ttk_stream_t stream) {
+int ttk_avgpool_bwd(const float* gfeat, const void* y, float* bn, const void* skip, void* g,
+                    float* part, int B, int HW, int C, int act_bf16, ttk_stream_t stream) {
   TTK_REQUIRE(gfeat && y && bn && g, "avgpool_bwd: null pointer");
   TTK_REQUIRE(B > 0 && HW > 0 && C >= 32 && C <= 1024 && (C & (C - 1)) == 0, "avgpool_bwd: unsupported shape");
   const int qs = log2i_(C / 4);
   const int64_t items = ((int64_t)B * HW) << qs;
-  hipLaunchKernelGGL(avgpool_bwd_k, dim3(elementwise_grid(items)), dim3(kBlock), 2 * (size_t)C * sizeof(float),
-                     (hipStream_t)stream, gfeat, y, bn, skip, g, part, B, HW, C, qs);
+  TTK_ACT_DISPATCH(act_bf16, hipLaunchKernelGGL((avgpool_bwd_k<ActT, GradT>), dim3(elementwise_grid(items)), dim3(kBlock), 2 * (size_t)C * sizeof(float),
+                                                (hipStream_t)stream, gfeat, (const ActT*)y, bn, (const ActT*)skip, (GradT*)g, part, B, HW, C, qs));
   TTK_LAUNCH_CHECK("avgpool_bwd");
 }
 

@@ -30,11 +30,13 @@ enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 
 // STAGES = 1: the whole contraction is one LDS stage (K = 32, the first pointwise layer): half the LDS, and with the
 // 168-VGPR cap three workgroups per CU instead of two for this HBM-bound layer.
-template <int BN, int WM, int WN, int MODE, int STAGES = 2>
+// T: storage of activations (y); TO: storage of this kernel's A0 operand and output - activations in the forward pass,
+// activation gradients in the data gradient
+template <int BN, int WM, int WN, int MODE, int STAGES, typename T, typename TO>
 __global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(STAGES == 1 ? 3 : 1, STAGES == 1 ? 3 : 8)))
-pw_gemm_k(const float* __restrict__ A0, const float* __restrict__ A1,
+pw_gemm_k(const TO* __restrict__ A0, const T* __restrict__ A1,
                                                      const float* __restrict__ bnA, const float* __restrict__ Bm,
-                                                     float* __restrict__ out, const float* __restrict__ E0,
+                                                     TO* __restrict__ out, const T* __restrict__ E0,
                                                      const float* __restrict__ bnE, float* __restrict__ part, int64_t M,
                                                      int K, int Nout) {
   // bnA: BatchNorm block [TTK_BN_ROWS][K] of the layer that produced the A operand (contraction channels);
@@ -85,8 +87,8 @@ pw_gemm_k(const float* __restrict__ A0, const float* __restrict__ A1,
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
       const int64_t row = m0 + p * ROWS_PER_PASS + lrow;
-      ra0[p] = (row < M) ? ld4nt(A0 + row * K + k0) : f4(0.f);
-      if constexpr (MODE == MODE_DGRAD) ra1[p] = (row < M) ? ld4nt(A1 + row * K + k0) : f4(0.f);
+      ra0[p] = (row < M) ? Act<TO>::ldnt(A0 + row * K + k0) : f4(0.f);
+      if constexpr (MODE == MODE_DGRAD) ra1[p] = (row < M) ? Act<T>::ldnt(A1 + row * K + k0) : f4(0.f);
     }
 #pragma unroll
     for (int p = 0; p < B_PASSES; ++p) {
@@ -183,13 +185,14 @@ pw_gemm_k(const float* __restrict__ A0, const float* __restrict__ A1,
     float4 v = ld4(Cs + row * LDC + 4 * c4);
     const size_t o = (size_t)grow * Nout + col;
     if constexpr (MODE == MODE_FWD) {
-      st4(out + o, v);
+      v = Act<TO>::round(v);  // statistics of what is stored
+      Act<TO>::st(out + o, v);
       s1 = add4(s1, v);
       s2 = fma4(v, v, s2);
     } else {
-      const float4 yc = sub4(ld4nt(E0 + o), emean);
-      v = mask4(v, fma4(esc, yc, ebeta));
-      st4(out + o, v);
+      const float4 yc = sub4(Act<T>::ldnt(E0 + o), emean);
+      v = Act<TO>::round(mask4(v, fma4(esc, yc, ebeta)));
+      Act<TO>::st(out + o, v);
       s1 = add4(s1, v);
       s2 = fma4(v, yc, s2);
     }
@@ -224,9 +227,9 @@ pw_gemm_k(const float* __restrict__ A0, const float* __restrict__ A1,
 // Work split: grid.x = output tiles of dW, grid.y = slices of M; each wave may additionally own a
 // slice of the 32-row stage (WS) when the dW tile is too small to feed 4 waves.
 // ---------------------------------------------------------------------------------------------
-template <int BN, int BK, int WR, int WC, int WS>
-__global__ void __launch_bounds__(kBlock) pw_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y,
-                                                      const float* __restrict__ bn_pw, const float* __restrict__ Ydw,
+template <int BN, int BK, int WR, int WC, int WS, typename T, typename TG>
+__global__ void __launch_bounds__(kBlock) pw_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y,
+                                                      const float* __restrict__ bn_pw, const T* __restrict__ Ydw,
                                                       const float* __restrict__ bn_dw, float* __restrict__ dW,
                                                       float* __restrict__ partial, int64_t M, int Cin, int Cout,
                                                       int64_t rows_per_slice) {
@@ -262,8 +265,8 @@ __global__ void __launch_bounds__(kBlock) pw_wgrad_k(const float* __restrict__ G
       const int row = f / (BN / 4), q = f % (BN / 4);
       const int64_t m = ms + row;
       if (row < MS && m < m_end) {
-        rg[p] = ld4nt(G + m * Cout + n0 + 4 * q);
-        ry[p] = ld4nt(Y + m * Cout + n0 + 4 * q);
+        rg[p] = Act<TG>::ldnt(G + m * Cout + n0 + 4 * q);
+        ry[p] = Act<T>::ldnt(Y + m * Cout + n0 + 4 * q);
       } else {
         rg[p] = f4(0.f);
         ry[p] = f4(0.f);
@@ -274,7 +277,7 @@ __global__ void __launch_bounds__(kBlock) pw_wgrad_k(const float* __restrict__ G
       const int f = p * kBlock + tid;
       const int row = f / (BK / 4), q = f % (BK / 4);
       const int64_t m = ms + row;
-      ra[p] = (row < MS && m < m_end) ? ld4nt(Ydw + m * Cin + k0 + 4 * q) : f4(0.f);
+      ra[p] = (row < MS && m < m_end) ? Act<T>::ldnt(Ydw + m * Cin + k0 + 4 * q) : f4(0.f);
     }
   };
   auto store_stage = [&](int64_t ms, int buf) {
@@ -359,11 +362,12 @@ static bool pw_shape_ok(int64_t M, int Cin, int Cout) {
 }
 
 // pwconv_f16.hip: the compute-bound shapes on the fp16 pipe with 2-piece operand splits (three products) - the default
-template <int MODE>
-bool launch_f16_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
+template <int MODE, typename T, typename TO>
+bool launch_f16_gemm(const TO* A0, const T* A1, const float* bnA, const float* Bm, TO* out, const T* E0,
                      const float* bnE, float* part, int64_t M, int K, int Nout, void* planes, float* wmax, hipStream_t st);
 bool f16_gemm_shape(int K, int Nout);
-bool launch_f16_wgrad(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
+template <typename T, typename TG>
+bool launch_f16_wgrad(const TG* g, const T* y, const float* bn_pw, const T* ydw, const float* bn_dw, float* dw,
                       float* partial, int64_t M, int Cin, int Cout, hipStream_t st);
 size_t f16_wgrad_partial_bytes(int64_t M, int Cin, int Cout);
 
@@ -396,24 +400,29 @@ static int gemm_mode() {
 static size_t prep_bwd_offset(size_t n) { return gemm_mode() == GEMM_BF16X3 ? 6 * n : 4 * n; }
 static size_t prep_hdr_offset(size_t n) { return gemm_mode() == GEMM_BF16X3 ? 12 * n : 8 * n; }
 
-template <int MODE>
-static void launch_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
+template <int MODE, typename T, typename TO>
+static bool launch_gemm(const TO* A0, const T* A1, const float* bnA, const float* Bm, TO* out, const T* E0,
                         const float* bnE, float* part, int64_t M, int K, int Nout, void* region, float* hdr, hipStream_t st) {
   const int mode = gemm_mode();
-  if (mode == GEMM_F16X2 && launch_f16_gemm<MODE>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, region, hdr, st)) return;
-  if (mode == GEMM_BF16X3 && launch_split_gemm<MODE>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, region, st)) return;
+  if (mode == GEMM_F16X2 && launch_f16_gemm<MODE, T, TO>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, region, hdr, st)) return true;
+  if constexpr (!Act<T>::kBf16 && !Act<TO>::kBf16) {
+    if (mode == GEMM_BF16X3 && launch_split_gemm<MODE>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, region, st)) return true;
+  } else {
+    if (mode == GEMM_BF16X3) return false;  // the 3-piece bf16 kernels read fp32 activations only
+  }
   if (!Bm) Bm = static_cast<const float*>(region);  // prepared operand of a shape that stays on the fp32 kernels
   const dim3 blk(kBlock);
   const unsigned gm = (unsigned)ceil_div(M, BM);
   if (Nout >= 128)
-    hipLaunchKernelGGL((pw_gemm_k<128, 2, 2, MODE>), dim3((Nout / 128) * gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K,
+    hipLaunchKernelGGL((pw_gemm_k<128, 2, 2, MODE, 2, T, TO>), dim3((Nout / 128) * gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K,
                        Nout);
   else if (Nout == 64 && K == BKT)
-    hipLaunchKernelGGL((pw_gemm_k<64, 2, 2, MODE, 1>), dim3(gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
+    hipLaunchKernelGGL((pw_gemm_k<64, 2, 2, MODE, 1, T, TO>), dim3(gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
   else if (Nout == 64)
-    hipLaunchKernelGGL((pw_gemm_k<64, 2, 2, MODE>), dim3(gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
+    hipLaunchKernelGGL((pw_gemm_k<64, 2, 2, MODE, 2, T, TO>), dim3(gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
   else
-    hipLaunchKernelGGL((pw_gemm_k<32, 4, 1, MODE>), dim3(gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
+    hipLaunchKernelGGL((pw_gemm_k<32, 4, 1, MODE, 2, T, TO>), dim3(gm), blk, 0, st, A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout);
+  return true;
 }
 
 // ---- all pointwise layers' weight operands (ttk_pwconv_prepare_weights) -----------------------------------------------
@@ -507,30 +516,36 @@ using namespace ttk;
 
 extern "C" {
 
-int ttk_pwconv1x1_fwd(const float* ydw, const float* bn_dw, const float* w, float* y, float* part, int64_t M, int Cin, int Cout,
-                      void* wsplit, ttk_stream_t stream) {
+int ttk_pwconv1x1_fwd(const void* ydw, const float* bn_dw, const float* w, void* y, float* part, int64_t M, int Cin, int Cout,
+                      void* wsplit, int act_bf16, ttk_stream_t stream) {
   TTK_REQUIRE(ydw && bn_dw && y && (w || wsplit), "pwconv1x1_fwd: null pointer");
   TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_fwd: unsupported shape M=%lld Cin=%d Cout=%d (channels: powers of two in 32..1024)", (long long)M, Cin, Cout);
   TTK_REQUIRE(ceil_div(M, BM) <= 65535, "pwconv1x1_fwd: M=%lld too large for one launch", (long long)M);
   unsigned char* ws = static_cast<unsigned char*>(wsplit);
   const size_t n = (size_t)Cin * Cout;
-  launch_gemm<MODE_FWD>(ydw, nullptr, bn_dw, w, y, nullptr, nullptr, part, M, Cin, Cout, ws, ws ? reinterpret_cast<float*>(ws + prep_hdr_offset(n)) : nullptr,
-                        (hipStream_t)stream);
+  float* hdr = ws ? reinterpret_cast<float*>(ws + prep_hdr_offset(n)) : nullptr;
+  bool ok = false;
+  TTK_ACT_DISPATCH(act_bf16, ok = launch_gemm<MODE_FWD, ActT, ActT>((const ActT*)ydw, nullptr, bn_dw, w, (ActT*)y, nullptr, nullptr, part, M, Cin, Cout, ws,
+                                                              hdr, (hipStream_t)stream));
+  TTK_REQUIRE(ok, "pwconv1x1_fwd: bf16 activations need TTK_GEMM=f16x2 (default) or f32mfma");
   TTK_LAUNCH_CHECK("pwconv1x1_fwd");
 }
 
-int ttk_pwconv1x1_bwd_data(const float* g, const float* y, const float* bn_pw, const float* wt, const float* ydw,
-                           const float* bn_dw, float* g_dw, float* part, int64_t M, int Cin, int Cout, void* wsplit,
-                           ttk_stream_t stream) {
+int ttk_pwconv1x1_bwd_data(const void* g, const void* y, const float* bn_pw, const float* wt, const void* ydw,
+                           const float* bn_dw, void* g_dw, float* part, int64_t M, int Cin, int Cout, void* wsplit,
+                           int act_bf16, ttk_stream_t stream) {
   TTK_REQUIRE(g && y && bn_pw && (wt || wsplit) && ydw && bn_dw && g_dw, "pwconv1x1_bwd_data: null pointer");
   TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_bwd_data: unsupported shape");
   TTK_REQUIRE(ceil_div(M, BM) <= 65535, "pwconv1x1_bwd_data: M too large for one launch");
   unsigned char* ws = static_cast<unsigned char*>(wsplit);
   const size_t n = (size_t)Cin * Cout;
   unsigned char* region = (ws && !wt) ? ws + prep_bwd_offset(n) : ws;  // data-gradient half of a prepared block
+  float* hdr = ws ? reinterpret_cast<float*>(ws + prep_hdr_offset(n)) : nullptr;
   // contraction over Cout, output columns = Cin, B operand = wt[Cin][Cout]
-  launch_gemm<MODE_DGRAD>(g, y, bn_pw, wt, g_dw, ydw, bn_dw, part, M, Cout, Cin, region, ws ? reinterpret_cast<float*>(ws + prep_hdr_offset(n)) : nullptr,
-                          (hipStream_t)stream);
+  bool ok = false;
+  TTK_ACT_DISPATCH(act_bf16, ok = launch_gemm<MODE_DGRAD, ActT, GradT>((const GradT*)g, (const ActT*)y, bn_pw, wt, (GradT*)g_dw, (const ActT*)ydw, bn_dw, part,
+                                                                M, Cout, Cin, region, hdr, (hipStream_t)stream));
+  TTK_REQUIRE(ok, "pwconv1x1_bwd_data: bf16 activations need TTK_GEMM=f16x2 (default) or f32mfma");
   TTK_LAUNCH_CHECK("pwconv1x1_bwd_data");
 }
 
@@ -561,14 +576,19 @@ size_t ttk_pwconv_wgrad_partial_bytes(int64_t M, int Cin, int Cout) {
   return (size_t)slices * Cin * Cout * sizeof(float);
 }
 
-int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
-                             float* partial, int64_t M, int Cin, int Cout, ttk_stream_t stream) {
+int ttk_pwconv1x1_bwd_weight(const void* g, const void* y, const float* bn_pw, const void* ydw, const float* bn_dw, float* dw,
+                             float* partial, int64_t M, int Cin, int Cout, int act_bf16, ttk_stream_t stream) {
   TTK_REQUIRE(g && y && bn_pw && ydw && bn_dw && dw, "pwconv1x1_bwd_weight: null pointer");
   TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_bwd_weight: unsupported shape");
-  if (gemm_mode() == GEMM_F16X2 && launch_f16_wgrad(g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, (hipStream_t)stream)) {
-    TTK_LAUNCH_CHECK("pwconv1x1_bwd_weight");
+  TTK_REQUIRE(!(act_bf16 && gemm_mode() == GEMM_BF16X3), "pwconv1x1_bwd_weight: bf16 activations need TTK_GEMM=f16x2 (default) or f32mfma");
+  if (gemm_mode() == GEMM_F16X2) {
+    bool done = false;
+    TTK_ACT_DISPATCH(act_bf16, done = launch_f16_wgrad<ActT, GradT>((const GradT*)g, (const ActT*)y, bn_pw, (const ActT*)ydw, bn_dw, dw, partial, M, Cin, Cout,
+                                                             (hipStream_t)stream));
+    if (done) { TTK_LAUNCH_CHECK("pwconv1x1_bwd_weight"); }
   }
-  if (gemm_mode() == GEMM_BF16X3 && launch_split_wgrad(g, y, bn_pw, ydw, bn_dw, dw, M, Cin, Cout, (hipStream_t)stream)) {
+  if (gemm_mode() == GEMM_BF16X3 && launch_split_wgrad((const float*)g, (const float*)y, bn_pw, (const float*)ydw, bn_dw, dw, M, Cin, Cout,
+                                                      (hipStream_t)stream)) {
     TTK_LAUNCH_CHECK("pwconv1x1_bwd_weight");
   }
   int bn, bk, tiles;
@@ -581,18 +601,19 @@ int ttk_pwconv1x1_bwd_weight(const float* g, const float* y, const float* bn_pw,
   const bool shared = (bn == 64 && bk == 32) || (bn == 32 && bk == 64);
   if (partial && bn == 32 && bk == 32) partial = nullptr;
   if (partial && shared) (void)hipMemsetAsync(partial, 0, (size_t)slices * Cin * Cout * sizeof(float), st);
-#define TTK_WG(BN_, BK_, WR_, WC_, WS_)                                                                               \
-  hipLaunchKernelGGL((pw_wgrad_k<BN_, BK_, WR_, WC_, WS_>), grid, blk, 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, \
-                     rows)
-  if (bn == 128 && bk == 128) TTK_WG(128, 128, 2, 2, 1);
-  else if (bn == 128 && bk == 64) TTK_WG(128, 64, 2, 2, 1);
-  else if (bn == 128 && bk == 32) TTK_WG(128, 32, 4, 1, 1);
-  else if (bn == 64 && bk == 128) TTK_WG(64, 128, 2, 2, 1);
-  else if (bn == 64 && bk == 64) TTK_WG(64, 64, 2, 2, 1);
-  else if (bn == 64 && bk == 32) TTK_WG(64, 32, 2, 1, 2);
-  else if (bn == 32 && bk == 128) TTK_WG(32, 128, 1, 4, 1);
-  else if (bn == 32 && bk == 64) TTK_WG(32, 64, 1, 2, 2);
-  else TTK_WG(32, 32, 1, 1, 4);
+#define TTK_WG(BN_, BK_, WR_, WC_, WS_)                                                                                                 \
+  hipLaunchKernelGGL((pw_wgrad_k<BN_, BK_, WR_, WC_, WS_, ActT, GradT>), grid, blk, 0, st, (const GradT*)g, (const ActT*)y, bn_pw, (const ActT*)ydw, bn_dw, \
+                     dw, partial, M, Cin, Cout, rows)
+  TTK_ACT_DISPATCH(act_bf16,
+                   if (bn == 128 && bk == 128) TTK_WG(128, 128, 2, 2, 1);
+                   else if (bn == 128 && bk == 64) TTK_WG(128, 64, 2, 2, 1);
+                   else if (bn == 128 && bk == 32) TTK_WG(128, 32, 4, 1, 1);
+                   else if (bn == 64 && bk == 128) TTK_WG(64, 128, 2, 2, 1);
+                   else if (bn == 64 && bk == 64) TTK_WG(64, 64, 2, 2, 1);
+                   else if (bn == 64 && bk == 32) TTK_WG(64, 32, 2, 1, 2);
+                   else if (bn == 32 && bk == 128) TTK_WG(32, 128, 1, 4, 1);
+                   else if (bn == 32 && bk == 64) TTK_WG(32, 64, 1, 2, 2);
+                   else TTK_WG(32, 32, 1, 1, 4));
 #undef TTK_WG
   if (partial) launch_fold_partials(partial, (int)slices, (int64_t)Cin * Cout, dw, 1, st);
   TTK_LAUNCH_CHECK("pwconv1x1_bwd_weight");

@@ -65,6 +65,13 @@ __device__ __forceinline__ void split_store16(f32x4 v, unsigned char* dst, int p
   *reinterpret_cast<uint2*>(dst + plane) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
 }
 
+// 4 consecutive activation values as f32x4 (streamed: non-temporal)
+template <typename T>
+__device__ __forceinline__ f32x4 ld_act4(const T* p) {
+  const float4 v = Act<T>::ldnt(p);
+  return f32x4{v.x, v.y, v.z, v.w};
+}
+
 // The consumer side of one block tile: `nks` super-stages (k32) of ds_read_b128 fragments + 3-product MFMAs into
 // acc[TM][TN].  Executes exactly 1 + nks barriers (matching the producers).
 template <int BM, int BN, int RS>
@@ -173,10 +180,12 @@ __device__ __forceinline__ void producer_schedule(int nks, Prefetch&& prefetch, 
 // A: fp32 rows [M][K] (formed on load: forward relu(bn(y)), data gradient ga*(g-gmean)+gb*(y-mean)), bound in
 // bnA[TTK_BN_AUX][AMODE == BNRELU ? TTK_AUX_ACT_BOUND : TTK_AUX_DY_BOUND]; Bq: two fp16 planes [K/32][Nout][32] of the
 // weights scaled by pow2_scale(*wmax).
-template <int BM, int BN, int AMODE, int EMODE, int D>
+// T: storage of activations (A1 = y, E0 = mask operand); TO: storage of the A0 operand and of the output - activations in the
+// forward pass, activation gradients in the data gradient
+template <int BM, int BN, int AMODE, int EMODE, int D, typename T, typename TO>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-pw16_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* __restrict__ bnA,
-       const uint16_t* __restrict__ Bq, const float* __restrict__ wmax, float* __restrict__ out, const float* __restrict__ E0,
+pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restrict__ bnA,
+       const uint16_t* __restrict__ Bq, const float* __restrict__ wmax, TO* __restrict__ out, const T* __restrict__ E0,
        const float* __restrict__ bnE, float* __restrict__ part, int64_t M, int K, int Nout) {
   static_assert((BM == 128 && BN == 256) || (BM == 256 && BN == 128), "tile shapes");
   constexpr int RS = TTK_RS;
@@ -232,8 +241,8 @@ pw16_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* 
       const int kc0 = ks * 32;
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
-        ra0[set][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A0 + arow[i] + kc0));
-        if constexpr (AMODE == AMODE_BNGRAD) ra1[set][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A1 + arow[i] + kc0));
+        ra0[set][i] = ld_act4<TO>(A0 + arow[i] + kc0);
+        if constexpr (AMODE == AMODE_BNGRAD) ra1[set][i] = ld_act4<T>(A1 + arow[i] + kc0);
       }
       if constexpr (AMODE == AMODE_BNRELU) {
         q[set][0] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_SCALE * K + kc0);
@@ -374,7 +383,7 @@ pw16_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* 
 #pragma unroll
     for (int i = 0; i < EI; ++i) {
       const int64_t grow = m0 + half * 128 + rr + RGH * i;
-      e0[i] = grow < M ? ld4(E0 + (size_t)grow * Nout + col) : f4(0.f);
+      e0[i] = grow < M ? Act<T>::ld(E0 + (size_t)grow * Nout + col) : f4(0.f);
     }
   }
   __syncthreads();
@@ -398,15 +407,16 @@ pw16_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* 
     v = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
     const size_t o = (size_t)grow * Nout + col;
     if constexpr (EMODE == EMODE_STATS) {
+      v = Act<TO>::round(v);  // statistics of what is stored
 #if !(defined(TTK_EXP) && TTK_EXP == 1)
-      st4(out + o, v);
+      Act<TO>::st(out + o, v);
 #endif
       s1 = add4(s1, v);
       s2 = fma4(v, v, s2);
     } else {
       const float4 yc = sub4(e0[i], emean);
-      v = mask4(v, fma4(esc, yc, ebeta));
-      st4(out + o, v);
+      v = Act<TO>::round(mask4(v, fma4(esc, yc, ebeta)));
+      Act<TO>::st(out + o, v);
       s1 = add4(s1, v);
       s2 = fma4(v, yc, s2);
     }
@@ -434,10 +444,10 @@ pw16_k(const float* __restrict__ A0, const float* __restrict__ A1, const float* 
 // otherwise (deterministic mode) slice s stores its tile to partial[s][Cout][Cin] and wgrad_reduce_k folds the slices
 // in a fixed order.
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int D>
+template <int BM, int BN, int D, typename T, typename TG>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const float* __restrict__ bn_pw,
-             const float* __restrict__ X, const float* __restrict__ bn_x, float* __restrict__ dW, float* __restrict__ partial,
+pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __restrict__ bn_pw,
+             const T* __restrict__ X, const float* __restrict__ bn_x, float* __restrict__ dW, float* __restrict__ partial,
              int64_t M, int Cin, int Cout, int64_t rows_per_slice) {
   static_assert((BM + BN == 384 && (BM == 128 || BM == 256)) || (BM == 128 && BN == 128), "128x256, 256x128 or 128x128");
   constexpr int RS = TTK_RS;
@@ -448,10 +458,10 @@ pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const flo
   const int tid = threadIdx.x;
   // XCD-aware order: give each XCD whole slices (all dW tiles of a slice run side by side on ONE L2, so the slice's
   // operand rows are fetched from HBM once, not once per tile).
-  const unsigned T = gridDim.x, NG = T * gridDim.y, Lid = blockIdx.y * T + blockIdx.x;
+  const unsigned NT = gridDim.x, NG = NT * gridDim.y, Lid = blockIdx.y * NT + blockIdx.x;
   const unsigned xq = NG / 8, xr = NG % 8, xcd = Lid % 8;
   const unsigned logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + Lid / 8;
-  const unsigned tile = logical % T, slice = logical / T;
+  const unsigned tile = logical % NT, slice = logical / NT;
   const int tiles_k = Cin / BN;
   const int n0 = (tile / tiles_k) * BM, k0 = (tile % tiles_k) * BN;
   const int64_t m_begin = (int64_t)slice * rows_per_slice;
@@ -491,9 +501,9 @@ pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const flo
     // Steps whose 32 rows all lie inside the slice (all but possibly the last one) take a path without row clamps and
     // zero fills.
     const int nfull = (int)((m_end - m_begin) / 32);
-    const float* gp[AP];
-    const float* yp[AP];
-    const float* xp[BP];
+    const TG* gp[AP];
+    const T* yp[AP];
+    const T* xp[BP];
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       gp[p] = G + (m_begin + 4 * mb) * Cout + ca[p];
@@ -510,8 +520,8 @@ pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const flo
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int p = 0; p < AP; ++p) {
-            rg[set][p][i] = *reinterpret_cast<const f32x4*>(gp[p] + base + (int64_t)i * Cout);
-            ry[set][p][i] = *reinterpret_cast<const f32x4*>(yp[p] + base + (int64_t)i * Cout);
+            rg[set][p][i] = ld_act4<TG>(gp[p] + base + (int64_t)i * Cout);
+            ry[set][p][i] = ld_act4<T>(yp[p] + base + (int64_t)i * Cout);
           }
         return;
       }
@@ -521,8 +531,8 @@ pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const flo
         row = row < m_end ? row : m_end - 1;
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-          rg[set][p][i] = *reinterpret_cast<const f32x4*>(G + row * Cout + ca[p]);
-          ry[set][p][i] = *reinterpret_cast<const f32x4*>(Y + row * Cout + ca[p]);
+          rg[set][p][i] = ld_act4<TG>(G + row * Cout + ca[p]);
+          ry[set][p][i] = ld_act4<T>(Y + row * Cout + ca[p]);
         }
       }
     };
@@ -533,7 +543,7 @@ pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const flo
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int p = 0; p < BP; ++p) rx[set][p][i] = *reinterpret_cast<const f32x4*>(xp[p] + base + (int64_t)i * Cin);
+          for (int p = 0; p < BP; ++p) rx[set][p][i] = ld_act4<T>(xp[p] + base + (int64_t)i * Cin);
         return;
       }
       const int64_t r0 = m_begin + (int64_t)ks * 32 + 4 * mb;
@@ -542,7 +552,7 @@ pw16_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const flo
         int64_t row = r0 + i;
         row = row < m_end ? row : m_end - 1;
 #pragma unroll
-        for (int p = 0; p < BP; ++p) rx[set][p][i] = *reinterpret_cast<const f32x4*>(X + row * Cin + cb[p]);
+        for (int p = 0; p < BP; ++p) rx[set][p][i] = ld_act4<T>(X + row * Cin + cb[p]);
       }
     };
     auto store_a = [&](int ks, auto setc) {
@@ -668,7 +678,8 @@ size_t f16_wgrad_partial_bytes(int64_t M, int Cin, int Cout) {
   return (size_t)slices * Cin * Cout * sizeof(float);
 }
 
-bool launch_f16_wgrad(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
+template <typename T, typename TG>
+bool launch_f16_wgrad(const TG* g, const T* y, const float* bn_pw, const T* ydw, const float* bn_dw, float* dw,
                       float* partial, int64_t M, int Cin, int Cout, hipStream_t st) {
   if (!f16_wgrad_shape(Cin, Cout)) return false;
   const bool wide = Cin % 256 == 0;  // 128 (Cout) x 256 (Cin) tiles, else 256 x 128, else (128 x 128 channels) one 128 x 128 tile
@@ -677,11 +688,11 @@ bool launch_f16_wgrad(const float* g, const float* y, const float* bn_pw, const 
   wgrad_slices(M, tiles, slices, rows);
   const dim3 grid(tiles, (unsigned)slices);
   if (!wide && Cout % 256 != 0)
-    hipLaunchKernelGGL((pw16_wgrad_k<128, 128, TTK_DW>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
+    hipLaunchKernelGGL((pw16_wgrad_k<128, 128, TTK_DW, T, TG>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
   else if (wide)
-    hipLaunchKernelGGL((pw16_wgrad_k<128, 256, TTK_DW>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
+    hipLaunchKernelGGL((pw16_wgrad_k<128, 256, TTK_DW, T, TG>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
   else  // (one register set: two spill)
-    hipLaunchKernelGGL((pw16_wgrad_k<256, 128, 1>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
+    hipLaunchKernelGGL((pw16_wgrad_k<256, 128, 1, T, TG>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
   if (partial) {
     const int64_t n = (int64_t)Cin * Cout;
     hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, st, partial, dw, n, (int)slices);
@@ -717,8 +728,8 @@ __global__ void w16_split_k(const float* __restrict__ w, uint16_t* __restrict__ 
 // Returns true when the shape was handled here (and the kernels launched on `st`).  Bm != nullptr: raw weight rows
 // [Nout][K] that are split into `planes` first (per-call form, unit tests); wmax: the layer's |w| maximum (a device
 // float that the per-call form computes itself).
-template <int MODE>
-bool launch_f16_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
+template <int MODE, typename T, typename TO>
+bool launch_f16_gemm(const TO* A0, const T* A1, const float* bnA, const float* Bm, TO* out, const T* E0,
                      const float* bnE, float* part, int64_t M, int K, int Nout, void* planes, float* wmax, hipStream_t st) {
   constexpr int AM = MODE == SMODE_FWD ? AMODE_BNRELU : AMODE_BNGRAD, EM = MODE == SMODE_FWD ? EMODE_STATS : EMODE_MASK;
   if (!planes || !wmax || !f16_gemm_shape(K, Nout)) return false;
@@ -732,21 +743,31 @@ bool launch_f16_gemm(const float* A0, const float* A1, const float* bnA, const f
   }
   if (Nout >= 256 && Nout % 256 == 0) {
     const unsigned tiles = (unsigned)(ceil_div(M, 128) * (Nout / 256));
-    hipLaunchKernelGGL((pw16_k<128, 256, AM, EM, TTK_D>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout);
+    hipLaunchKernelGGL((pw16_k<128, 256, AM, EM, TTK_D, T, TO>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout);
     return true;
   }
   if (Nout == 128) {
     const unsigned tiles = (unsigned)ceil_div(M, 256);
     constexpr int D = (MODE == SMODE_DGRAD || TTK_D > 2) ? 1 : TTK_D;  // eight A rows per thread: more sets spill
-    hipLaunchKernelGGL((pw16_k<256, 128, AM, EM, D>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout);
+    hipLaunchKernelGGL((pw16_k<256, 128, AM, EM, D, T, TO>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout);
     return true;
   }
   return false;
 }
 
-template bool launch_f16_gemm<SMODE_FWD>(const float*, const float*, const float*, const float*, float*, const float*,
-                                         const float*, float*, int64_t, int, int, void*, float*, hipStream_t);
-template bool launch_f16_gemm<SMODE_DGRAD>(const float*, const float*, const float*, const float*, float*, const float*,
-                                           const float*, float*, int64_t, int, int, void*, float*, hipStream_t);
+#define TTK_INST(T_, TG_)                                                                                                              \
+  template bool launch_f16_gemm<SMODE_FWD, T_, T_>(const T_*, const T_*, const float*, const float*, T_*, const T_*, const float*, float*, \
+                                                   int64_t, int, int, void*, float*, hipStream_t);                                         \
+  template bool launch_f16_gemm<SMODE_DGRAD, T_, TG_>(const TG_*, const T_*, const float*, const float*, TG_*, const T_*, const float*,    \
+                                                      float*, int64_t, int, int, void*, float*, hipStream_t);                              \
+  template bool launch_f16_wgrad<T_, TG_>(const TG_*, const T_*, const float*, const T_*, const float*, float*, float*, int64_t, int, int, \
+                                          hipStream_t);
+TTK_INST(float, float)
+TTK_INST(bf16_t, bf16_t)
+template bool launch_f16_gemm<SMODE_DGRAD, bf16_t, float>(const float*, const bf16_t*, const float*, const float*, float*, const bf16_t*, const float*,
+                                                          float*, int64_t, int, int, void*, float*, hipStream_t);
+template bool launch_f16_wgrad<bf16_t, float>(const float*, const bf16_t*, const float*, const bf16_t*, const float*, float*, float*, int64_t, int, int,
+                                              hipStream_t);
+#undef TTK_INST
 
 }  // namespace ttk

@@ -166,8 +166,9 @@ __device__ __forceinline__ float stem_patch(const float* __restrict__ x, int n, 
   return (ok && tap < 25 && hi >= 0 && hi < H && wi >= 0 && wi < W) ? x[((size_t)n * H + hi) * W + wi] : 0.f;
 }
 
+template <typename T>
 __global__ void __launch_bounds__(kBlock) stem_fwd_mfma_k(const float* __restrict__ x, const float* __restrict__ w,
-                                                           float* __restrict__ y, float* __restrict__ part, int B, int H,
+                                                           T* __restrict__ y, float* __restrict__ part, int B, int H,
                                                            int W, int Ho, int Wo) {
   __shared__ float red[kBlock / kWave][2 * kStemC];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, hk = lane >> 5;
@@ -189,14 +190,14 @@ __global__ void __launch_bounds__(kBlock) stem_fwd_mfma_k(const float* __restric
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
     for (int j = 0; j < 13; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bw[j], acc, 0, 0, 0);
-    float* yt = y + (size_t)t * 32 * kStemC + r;  // column r of the tile's 32 pixels
+    T* yt = y + (size_t)t * 32 * kStemC + r;  // column r of the tile's 32 pixels
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = (e & 3) + 8 * (e >> 2) + 4 * hk;
       if (t * 32 + row < P) {
-        yt[(size_t)row * kStemC] = acc[e];  // 32 lanes = the 128 bytes of one pixel
-        s1 += acc[e];
-        s2 = fmaf(acc[e], acc[e], s2);
+        const float v = Act<T>::st1(yt + (size_t)row * kStemC, acc[e]);  // 32 lanes = one pixel (128 bytes of fp32); statistics of the stored value
+        s1 += v;
+        s2 = fmaf(v, v, s2);
       }
     }
   }
@@ -220,7 +221,8 @@ __global__ void __launch_bounds__(kBlock) stem_fwd_mfma_k(const float* __restric
 constexpr int kWgBand = 13;   // 65 = 5 x 13 output rows
 constexpr int kWgChunk = 32;  // pixels per wave iteration = 16 MFMA k-pairs (four 16-byte loads per lane and tensor in flight)
 
-__global__ void __launch_bounds__(kBlock) stem_wgrad_mfma_k(const float* __restrict__ g, const float* __restrict__ y,
+template <typename T, typename TG>
+__global__ void __launch_bounds__(kBlock) stem_wgrad_mfma_k(const TG* __restrict__ g, const T* __restrict__ y,
                                                              const float* __restrict__ bn, const float* __restrict__ x,
                                                              float* __restrict__ dw, float* __restrict__ partial, int B, int H, int W, int Ho, int Wo,
                                                              int nbands) {
@@ -257,8 +259,8 @@ __global__ void __launch_bounds__(kBlock) stem_wgrad_mfma_k(const float* __restr
       for (int u = 0; u < kWgChunk / 8; ++u) {
         const int pp = p0 + pl + 8 * u;
         const size_t o = (pix0 + (pp < npix ? pp : 0)) * kStemC + 4 * c4;
-        gvs[u] = ld4nt(g + o);
-        yvs[u] = ld4nt(y + o);
+        gvs[u] = Act<TG>::ldnt(g + o);
+        yvs[u] = Act<T>::ldnt(y + o);
       }
 #pragma unroll
       for (int u = 0; u < kWgChunk / 8; ++u) {
@@ -313,40 +315,44 @@ using namespace ttk;
 
 extern "C" {
 
-int ttk_stem_fwd(const float* x, const float* w, float* y, float* part, int B, int H, int W, ttk_stream_t stream) {
+int ttk_stem_fwd(const float* x, const float* w, void* y, float* part, int B, int H, int W, int act_bf16, ttk_stream_t stream) {
   TTK_REQUIRE(x && w && y, "stem_fwd: null pointer");
   TTK_REQUIRE(B > 0 && H > 4 && W > 4, "stem_fwd: bad shape B=%d H=%d W=%d", B, H, W);
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int64_t items = (int64_t)B * Ho * Wo * kStemQuads;  // sizes the partial rows (ttk_partial_rows_elementwise)
   static const bool scalar = [] { const char* e = getenv("TTK_STEM"); return e && strcmp(e, "scalar") == 0; }();
+  TTK_REQUIRE(!(scalar && act_bf16), "stem_fwd: TTK_STEM=scalar has no bf16-storage form");
   if (scalar)  // TTK_STEM=scalar: the VALU kernels (A/B timing)
-    hipLaunchKernelGGL(stem_fwd_k, dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, x, w, y, part, B, H, W, Ho, Wo);
+    hipLaunchKernelGGL(stem_fwd_k, dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, x, w, (float*)y, part, B, H, W, Ho, Wo);
   else
-    hipLaunchKernelGGL(stem_fwd_mfma_k, dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, x, w, y, part, B, H, W, Ho, Wo);
+    TTK_ACT_DISPATCH(act_bf16, hipLaunchKernelGGL((stem_fwd_mfma_k<ActT>), dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, x, w,
+                                                  (ActT*)y, part, B, H, W, Ho, Wo));
   TTK_LAUNCH_CHECK("stem_fwd");
 }
 
 size_t ttk_stem_wgrad_partial_bytes(void) { return (size_t)1024 * 25 * kStemC * sizeof(float); }
 
-int ttk_stem_bwd_weight(const float* g, const float* y, const float* bn, const float* x, float* dw, int accumulate, float* partial,
-                        int B, int H, int W, ttk_stream_t stream) {
+int ttk_stem_bwd_weight(const void* g, const void* y, const float* bn, const float* x, float* dw, int accumulate, float* partial,
+                        int B, int H, int W, int act_bf16, ttk_stream_t stream) {
   TTK_REQUIRE(g && y && bn && x && dw, "stem_bwd_weight: null pointer");
   TTK_REQUIRE(B > 0 && H > 4 && W > 4, "stem_bwd_weight: bad shape");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int64_t items = (int64_t)B * Ho * Wo * kStemQuads;
   int grid = elementwise_grid(items);
   static const bool scalar = [] { const char* e = getenv("TTK_STEM"); return e && strcmp(e, "scalar") == 0; }();
+  TTK_REQUIRE(!(scalar && act_bf16), "stem_bwd_weight: TTK_STEM=scalar has no bf16-storage form");
   if (scalar) partial = nullptr;
   if (!accumulate && !partial) hipLaunchKernelGGL(zero_k, dim3(4), dim3(256), 0, (hipStream_t)stream, dw, 25 * kStemC);
   if (scalar) {
     if (grid > 512) grid = 512;
-    hipLaunchKernelGGL(stem_bwd_weight_k, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, g, y, bn, x, dw, B, H, W, Ho, Wo);
+    hipLaunchKernelGGL(stem_bwd_weight_k, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, (const float*)g, (const float*)y, bn, x, dw, B, H, W, Ho, Wo);
   } else {
     const int nbands = (Ho + kWgBand - 1) / kWgBand;
     grid = B * nbands < 1024 ? B * nbands : 1024;
     const size_t sm = ((size_t)(2 * kWgBand + 3) * W + (kBlock / kWave) * (kWgChunk * kStemC + kStemC * 25)) * sizeof(float);
     TTK_REQUIRE(sm <= 64 * 1024, "stem_bwd_weight: image too wide for the LDS band (W=%d)", W);
-    hipLaunchKernelGGL(stem_wgrad_mfma_k, dim3(grid), dim3(kBlock), sm, (hipStream_t)stream, g, y, bn, x, dw, partial, B, H, W, Ho, Wo, nbands);
+    TTK_ACT_DISPATCH(act_bf16, hipLaunchKernelGGL((stem_wgrad_mfma_k<ActT, GradT>), dim3(grid), dim3(kBlock), sm, (hipStream_t)stream, (const GradT*)g,
+                                                  (const ActT*)y, bn, x, dw, partial, B, H, W, Ho, Wo, nbands));
     if (partial) launch_fold_partials(partial, grid, 25 * kStemC, dw, accumulate, (hipStream_t)stream);
   }
   TTK_LAUNCH_CHECK("stem_bwd_weight");

@@ -102,6 +102,56 @@ __device__ __forceinline__ float4 sub4(float4 a, float4 b) {
   return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
 }
 
+// ---- storage type of the activation tensors that cross HBM ------------------------------------------------------
+// float (the reference's precision, the default) or bf16 (`--precision bf16`, BASELINE config 5): raw conv outputs and
+// their gradients are then rounded to nearest-even bf16 on their way out and widened on load; BatchNorm statistics are
+// taken from the ROUNDED values (the consumer normalises exactly what is stored), all arithmetic, LDS tiles, weights,
+// statistics and weight gradients stay fp32.  Offsets are in elements either way.
+typedef uint16_t bf16_t;  // storage only
+typedef __bf16 ttk_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ttk_f32x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct Act;
+template <> struct Act<float> {
+  static constexpr bool kBf16 = false;
+  __device__ __forceinline__ static float4 ld(const float* p) { return ld4(p); }
+  __device__ __forceinline__ static float4 ldnt(const float* p) { return ld4nt(p); }
+  __device__ __forceinline__ static float4 round(float4 v) { return v; }
+  __device__ __forceinline__ static void st(float* p, float4 v) { st4(p, v); }
+  __device__ __forceinline__ static float st1(float* p, float v) { *p = v; return v; }  // scalar store; returns the stored value
+};
+template <> struct Act<bf16_t> {
+  static constexpr bool kBf16 = true;
+  __device__ __forceinline__ static float4 widen(uint2 u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+  }
+  __device__ __forceinline__ static float4 ld(const bf16_t* p) { return widen(*reinterpret_cast<const uint2*>(p)); }
+  __device__ __forceinline__ static float4 ldnt(const bf16_t* p) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 u = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+    return widen(make_uint2(u.x, u.y));
+  }
+  __device__ __forceinline__ static uint2 pack(float4 v) {  // round to nearest even (v_cvt_pk_bf16_f32)
+    const ttk_bf16x2 a = __builtin_convertvector(ttk_f32x2{v.x, v.y}, ttk_bf16x2), b = __builtin_convertvector(ttk_f32x2{v.z, v.w}, ttk_bf16x2);
+    return make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+  }
+  __device__ __forceinline__ static float4 round(float4 v) { return widen(pack(v)); }  // the value the consumer will read
+  __device__ __forceinline__ static void st(bf16_t* p, float4 v) { *reinterpret_cast<uint2*>(p) = pack(v); }
+  __device__ __forceinline__ static float st1(bf16_t* p, float v) {
+    const __bf16 b = (__bf16)v;
+    const uint16_t u = __builtin_bit_cast(uint16_t, b);
+    *p = u;
+    return __uint_as_float((unsigned)u << 16);
+  }
+};
+// dispatch of a launch on the storage flag of the C-ABI: bit 0 = activations (ActT) bf16, bit 1 = activation GRADIENTS
+// (GradT) bf16 (TTK_STORE_* in ttk.h; gradients in bf16 only together with activations)
+#define TTK_ACT_DISPATCH(flag, ...)                                                               \
+  do {                                                                                            \
+    if (((flag) & 3) == 3) { using ActT = ::ttk::bf16_t; using GradT = ::ttk::bf16_t; __VA_ARGS__; } \
+    else if ((flag) & 1) { using ActT = ::ttk::bf16_t; using GradT = float; __VA_ARGS__; }        \
+    else { using ActT = float; using GradT = float; __VA_ARGS__; }                                \
+  } while (0)
+
 // The "apply on load" forms of BatchNorm (see ttk.h).  Every layer owns one block
 // bn[TTK_BN_ROWS][C] of per-channel constants.  Both forms SUBTRACT FIRST:
 //   forward : a  = max(scale*(y - mean) + beta (+skip), 0)

@@ -134,6 +134,9 @@ def make_parser():
     p.add_argument("--no-roi-train", default=True, action="store_false", dest="with_roi_train")
     p.add_argument("--rampup-nll-losses", default=False, action="store_true")
     p.add_argument("--enable-6drot", default=False, action="store_true")
+    # not a flag of the reference (it trains in fp32 only): storage of the backbone's activations in HBM
+    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16-all"],
+                   help="bf16: activations cross HBM as bfloat16, their gradients stay fp32; bf16-all: both bfloat16 (statistics / accumulation / weights fp32)")
     return p
 
 
@@ -143,6 +146,9 @@ def main():
 
     args = make_parser().parse_args()
     args.input_size = 129
+    from trackertraincode.backbones import mobilenet_v1
+
+    mobilenet_v1.set_activation_dtype(args.precision)
     world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
     torch.cuda.set_device(device)

@@ -21,18 +21,18 @@ _SIGNATURES = {
     "ttk_bn_fwd_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _F, _F, _P],
     "ttk_bn_eval_prepare": [_P, _P, _P, _P, _F, _I, _P],
     "ttk_bn_bwd_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _I],
-    "ttk_stem_fwd": [_P, _P, _P, _P, _I, _I, _I],
-    "ttk_stem_bwd_weight": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I],
-    "ttk_dwconv3x3_fwd": [_P] * 7 + [_I] * 5,
-    "ttk_dwconv3x3_bwd_data": [_P] * 12 + [_I, _P] + [_I] * 5,
+    "ttk_stem_fwd": [_P, _P, _P, _P, _I, _I, _I, _I],
+    "ttk_stem_bwd_weight": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I],
+    "ttk_dwconv3x3_fwd": [_P] * 7 + [_I] * 6,
+    "ttk_dwconv3x3_bwd_data": [_P] * 12 + [_I, _P] + [_I] * 6,
     "ttk_dwconv3x3_bwd_weight": [_P] * 8 + [_I] * 6,
-    "ttk_pwconv1x1_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
-    "ttk_pwconv1x1_bwd_data": [_P] * 8 + [_L, _I, _I, _P],
-    "ttk_pwconv1x1_bwd_weight": [_P] * 7 + [_L, _I, _I],
+    "ttk_pwconv1x1_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _I],
+    "ttk_pwconv1x1_bwd_data": [_P] * 8 + [_L, _I, _I, _P, _I],
+    "ttk_pwconv1x1_bwd_weight": [_P] * 7 + [_L, _I, _I, _I],
     "ttk_pwconv_prepare_weights": [_I, _P, _P, _P, _P],
     "ttk_transpose": [_P, _P, _I, _I],
-    "ttk_avgpool_fwd": [_P, _P, _P, _P, _I, _I, _I],
-    "ttk_avgpool_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
+    "ttk_avgpool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I],
+    "ttk_avgpool_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
     "ttk_bn_act": [_P, _P, _P, _P, _L, _I],
     "ttk_stem7_fwd": [_P, _P, _P, _P, _I, _I, _I],
     "ttk_stem7_bwd_weight": [_P, _P, _P, _P, _P, _I, _I, _I],

@@ -75,6 +75,31 @@ class DepthWiseBlock(nn.Module):
         return self.relu(out)
 
 
+# Storage type of the activation tensors that cross HBM during TRAINING (raw conv outputs, materialised block inputs and
+# their gradients): torch.float32 - the reference's precision, the default and the only mode `bench.py`'s headline uses - or
+# torch.bfloat16 (`--precision bf16`, BASELINE config 5): half the activation bytes; BatchNorm statistics (taken from the
+# rounded values), all arithmetic, weights and weight gradients stay fp32 (csrc/ttk_common.h: Act<T>).
+_ACT_DTYPE = torch.float32
+_GRAD_DTYPE = torch.float32
+
+
+def set_activation_dtype(mode):
+    """Storage of the backbone's activation-sized tensors in training: "fp32" (default), "bf16" (activations bfloat16,
+    their gradients float32) or "bf16-all" (both bfloat16; torch.float32 / torch.bfloat16 are accepted for the first and
+    the last).  BatchNorm's backward subtracts per-channel means of nearly constant gradients, which 8 mantissa bits do
+    not survive in the early layers: keep the gradients in fp32 unless you measure otherwise."""
+    global _ACT_DTYPE, _GRAD_DTYPE
+    mode = {torch.float32: "fp32", torch.bfloat16: "bf16-all", "f32": "fp32"}.get(mode, mode)
+    if mode not in ("fp32", "bf16", "bf16-all"):
+        raise ValueError(f'activation storage must be "fp32", "bf16" or "bf16-all", got {mode}')
+    _ACT_DTYPE = torch.float32 if mode == "fp32" else torch.bfloat16
+    _GRAD_DTYPE = torch.bfloat16 if mode == "bf16-all" else torch.float32
+
+
+def get_activation_dtype():
+    return _ACT_DTYPE, _GRAD_DTYPE
+
+
 _BN_ROWS = 8  # TTK_BN_ROWS: scale, beta, mean, rstd, ga, gb, gmean, (pad) - see include/ttk.h
 
 
@@ -118,10 +143,10 @@ def _part_buffer(B, H, W, device):
 
 class _Ctx:
     """Everything one forward pass leaves behind for its backward."""
-    __slots__ = ("x", "stages", "a_in", "part", "dims", "pool_skip", "wparams", "HW", "B", "prep")
+    __slots__ = ("x", "stages", "a_in", "part", "dims", "pool_skip", "wparams", "HW", "B", "prep", "bf", "gdt")
 
 
-def _forward_impl(x, params, buffers, momentum, eps, training):
+def _forward_impl(x, params, buffers, momentum, eps, training, act_dtype=torch.float32, grad_dtype=torch.float32):
     """Launches the forward kernels.  `params`: flat list [conv1.w, bn1.w, bn1.b, (dw.w, bn_dw.w,
     bn_dw.b, pw.w, bn_sep.w, bn_sep.b) x 13]; `buffers`: flat list of (running_mean, running_var,
     num_batches_tracked) per BN in the same order."""
@@ -134,6 +159,8 @@ def _forward_impl(x, params, buffers, momentum, eps, training):
     ctx = _Ctx()
     ctx.x, ctx.part, ctx.B = x, part, B
     ctx.stages, ctx.a_in, ctx.dims = [], [], []
+    bf = int(act_dtype == torch.bfloat16) | (2 if grad_dtype == torch.bfloat16 else 0)  # TTK_STORE_* bits
+    ctx.bf, ctx.gdt = bf, grad_dtype
     bns = _BnArena([32] + [c for _, cin, cout, _ in _BLOCKS for c in (cin, cout)], dev)
 
     def finalize(bn, rows, C, count, gamma, beta, bi):
@@ -152,8 +179,8 @@ def _forward_impl(x, params, buffers, momentum, eps, training):
     ctx.prep = list(torch.split(pool, sizes))
     L.pwconv_prepare_weights(w_pws, ctx.prep)
     # ---- stem (reference :122-126,161-163)
-    y0 = torch.empty((B, Ho, Wo, 32), dtype=torch.float32, device=dev)
-    L.call("ttk_stem_fwd", p(x), p(params[0]), p(y0), part_arg, B, H, W)
+    y0 = torch.empty((B, Ho, Wo, 32), dtype=act_dtype, device=dev)
+    L.call("ttk_stem_fwd", p(x), p(params[0]), p(y0), part_arg, B, H, W, bf)
     bn = bns.take(32)
     finalize(bn, L.partial_rows_elementwise(B * Ho * Wo * 8), 32, B * Ho * Wo, params[1], params[2], 0)
     prev = _Stage(y0, bn, None)
@@ -166,14 +193,14 @@ def _forward_impl(x, params, buffers, momentum, eps, training):
         has_skip = stride == 1 and cin == cout
         ho, wo = (h - 1) // stride + 1, (w_ - 1) // stride + 1
         a_in = torch.empty_like(prev.y) if has_skip else None
-        ydw = torch.empty((B, ho, wo, cin), dtype=torch.float32, device=dev)
+        ydw = torch.empty((B, ho, wo, cin), dtype=act_dtype, device=dev)
         L.call("ttk_dwconv3x3_fwd", p(prev.y), p(prev.bn), p(prev.skip), p(a_in), p(w_dw), p(ydw), part_arg, B, h, w_, cin,
-               stride)
+               stride, bf)
         bn_dw = bns.take(cin)
         finalize(bn_dw, L.partial_rows_dwconv(B, h, w_, cin, stride, False), cin, B * ho * wo, g_dw, b_dw, bi)
-        ypw = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=dev)
+        ypw = torch.empty((B, ho, wo, cout), dtype=act_dtype, device=dev)
         M = B * ho * wo
-        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(ypw), part_arg, M, cin, cout, p(ctx.prep[len(ctx.dims)]))
+        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(ypw), part_arg, M, cin, cout, p(ctx.prep[len(ctx.dims)]), bf)
         bn_pw = bns.take(cout)
         finalize(bn_pw, L.partial_rows_gemm(M), cout, M, g_pw, b_pw, bi + 1)
         bi += 2
@@ -185,7 +212,7 @@ def _forward_impl(x, params, buffers, momentum, eps, training):
         h, w_ = ho, wo
     C = prev.y.shape[-1]
     feat = torch.empty((B, C), dtype=torch.float32, device=dev)
-    L.call("ttk_avgpool_fwd", p(prev.y), p(prev.bn), p(prev.skip), p(feat), B, h * w_, C)
+    L.call("ttk_avgpool_fwd", p(prev.y), p(prev.bn), p(prev.skip), p(feat), B, h * w_, C, bf)
     ctx.HW = h * w_
     return feat, ctx
 
@@ -216,7 +243,7 @@ def _side_stream(device):
 def _backward_impl(ctx: _Ctx, gfeat, params):
     L = _hip.lib()
     p = _hip.ptr
-    B, part = ctx.B, ctx.part
+    B, part, bf = ctx.B, ctx.part, ctx.bf
     # one zeroed arena for every parameter gradient (the weight-gradient kernels accumulate atomically): one fill launch
     offs, total = [], 0
     for q in params:
@@ -248,8 +275,8 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         wg_scratch = torch.empty(need // 4, dtype=torch.float32, device=gfeat.device)
     keep = []
 
-    g = torch.empty_like(last.y)
-    L.call("ttk_avgpool_bwd", p(gfeat), p(last.y), p(last.bn), p(last.skip), p(g), p(part), B, ctx.HW, C)
+    g = torch.empty(last.y.shape, dtype=ctx.gdt, device=last.y.device)
+    L.call("ttk_avgpool_bwd", p(gfeat), p(last.y), p(last.bn), p(last.skip), p(g), p(part), B, ctx.HW, C, bf)
     bwd_finalize(last, L.partial_rows_elementwise(B * ctx.HW * (C // 4)), B * ctx.HW, len(params) - 2)
 
     for k in range(len(_BLOCKS) - 1, -1, -1):
@@ -268,22 +295,22 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
             ev.record(main)  # g, bn_pw backward constants and the zeroed dW are ready
             side.wait_event(ev)
             with torch.cuda.stream(side):
-                L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW), None, M, cin, cout)
+                L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW), None, M, cin, cout, bf)
                 if grad_ready_hook is not None:
                     done = torch.cuda.Event()
                     done.record(side)
             keep.append(g)  # main must not recycle g's memory while the side stream still reads it
         else:
-            L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW), p(wg_scratch), M, cin, cout)
-        g_dw = torch.empty_like(st_dw.y)
+            L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW), p(wg_scratch), M, cin, cout, bf)
+        g_dw = torch.empty(st_dw.y.shape, dtype=ctx.gdt, device=st_dw.y.device)
         L.call("ttk_pwconv1x1_bwd_data", p(g), p(st_pw.y), p(st_pw.bn), None, p(st_dw.y), p(st_dw.bn), p(g_dw), p(part), M,
-               cin, cout, p(ctx.prep[k]))
+               cin, cout, p(ctx.prep[k]), bf)
         bwd_finalize(st_dw, L.partial_rows_gemm(M), M, pi + 1)
         # -- depthwise: weight gradient, then data gradient (+ residual gradient, + producer's bn sums)
         dWd = grads[pi]  # accumulated by the fused weight-gradient path of bwd_data
-        g_prev = torch.empty_like(st_prev.y)
+        g_prev = torch.empty(st_prev.y.shape, dtype=ctx.gdt, device=st_prev.y.device)
         L.call("ttk_dwconv3x3_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), p(g) if has_skip else None, p(st_prev.y),
-               p(st_prev.bn), p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 1, p(wg_scratch), B, h, w_, cin, stride)
+               p(st_prev.bn), p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 1, p(wg_scratch), B, h, w_, cin, stride, bf)
         bwd_finalize(st_prev, L.partial_rows_dwconv(B, h, w_, cin, stride, True), B * h * w_, pi - 2 if k > 0 else 1)
         g = g_prev
         if grad_ready_hook is not None:  # this block's conv + bn_dw gradients and its own bn_sep gradients are final
@@ -292,7 +319,7 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
             announce(pi, pi + 6)
     st0 = ctx.stages[0]
     _, _, H, W = ctx.x.shape
-    L.call("ttk_stem_bwd_weight", p(g), p(st0.y), p(st0.bn), p(ctx.x), p(grads[0]), 1, p(wg_scratch), B, H, W)
+    L.call("ttk_stem_bwd_weight", p(g), p(st0.y), p(st0.bn), p(ctx.x), p(grads[0]), 1, p(wg_scratch), B, H, W, bf)
     if grad_ready_hook is not None:
         announce(0, 3)
     if side is not None:
@@ -306,7 +333,7 @@ class _MobileNetFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, momentum, eps, buffers, *params):
-        feat, c = _forward_impl(x, params, buffers, momentum, eps, training=True)
+        feat, c = _forward_impl(x, params, buffers, momentum, eps, training=True, act_dtype=_ACT_DTYPE, grad_dtype=_GRAD_DTYPE)
         ctx.c = c
         ctx.nparams = len(params)
         ctx.save_for_backward(*params)

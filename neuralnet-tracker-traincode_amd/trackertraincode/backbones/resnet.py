@@ -151,7 +151,7 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
     k = c.blocks[-1]
     assert k.yd is None, "the pooled block has an identity shortcut in ResNet18"
     feat = new(B, cin)
-    L.call("ttk_avgpool_fwd", p(k.y2), p(k.bn2), p(k.a_in), p(feat), B, h * h, cin)
+    L.call("ttk_avgpool_fwd", p(k.y2), p(k.bn2), p(k.a_in), p(feat), B, h * h, cin, 0)
     return feat, c
 
 
@@ -192,7 +192,7 @@ def _backward_impl(c: _Ctx, gfeat, params):
     k = c.blocks[-1]
     C, hw = k.cout, k.ho * k.ho
     gs = new(B, k.ho, k.ho, C)
-    L.call("ttk_avgpool_bwd", p(gfeat), p(k.y2), p(k.bn2), p(k.a_in), p(gs), p(part), B, hw, C)
+    L.call("ttk_avgpool_bwd", p(gfeat), p(k.y2), p(k.bn2), p(k.a_in), p(gs), p(part), B, hw, C, 0)
     rows_gs = L.partial_rows_elementwise(B * hw * (C // 4))
     for bidx in range(len(_PLAN) - 1, -1, -1):
         k = c.blocks[bidx]

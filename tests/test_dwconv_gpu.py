@@ -66,7 +66,7 @@ def test_dwconv_fwd_and_bwd_against_float64(B, H, W, C, stride, skip):
     y = torch.full((B, Ho, Wo, C), float("nan"), device="cuda")
     rows = L.partial_rows_dwconv(B, H, W, C, stride, False)
     part = torch.full((rows, 2, C), float("nan"), device="cuda")
-    L.call("ttk_dwconv3x3_fwd", p(d_yprev), p(d_bnp), p(d_skip), p(a_out), p(d_w), p(y), p(part), B, H, W, C, stride)
+    L.call("ttk_dwconv3x3_fwd", p(d_yprev), p(d_bnp), p(d_skip), p(a_out), p(d_w), p(y), p(part), B, H, W, C, stride, 0)
     torch.cuda.synchronize()
     assert torch.isfinite(y).all() and torch.isfinite(part).all()
     scale = y_ref.abs().max().item()
@@ -96,7 +96,7 @@ def test_dwconv_fwd_and_bwd_against_float64(B, H, W, C, stride, skip):
         part_b = torch.full((rows_b, 2, C), float("nan"), device="cuda")
         dwg = torch.zeros(C, 9, device="cuda")
         L.call("ttk_dwconv3x3_bwd_data", p(d_g), p(d_y), p(d_bnd), p(d_w), p(d_sg), p(d_yprev), p(d_bnp), p(d_skip),
-               p(a_out) if materialised else None, p(g_prev), p(part_b), p(dwg), 1, None, B, H, W, C, stride)
+               p(a_out) if materialised else None, p(g_prev), p(part_b), p(dwg), 1, None, B, H, W, C, stride, 0)
         torch.cuda.synchronize()
         # deterministic form of the fused weight gradient: per-workgroup rows folded in a fixed order, twice bit-identical
         det = []
@@ -104,7 +104,7 @@ def test_dwconv_fwd_and_bwd_against_float64(B, H, W, C, stride, skip):
             scratch = torch.full((rows_b * 9 * C,), float("nan"), device="cuda")
             dwd, gp2, pb2 = torch.zeros(C, 9, device="cuda"), torch.empty_like(g_prev), torch.empty_like(part_b)
             L.call("ttk_dwconv3x3_bwd_data", p(d_g), p(d_y), p(d_bnd), p(d_w), p(d_sg), p(d_yprev), p(d_bnp), p(d_skip),
-                   p(a_out) if materialised else None, p(gp2), p(pb2), p(dwd), 1, p(scratch), B, H, W, C, stride)
+                   p(a_out) if materialised else None, p(gp2), p(pb2), p(dwd), 1, p(scratch), B, H, W, C, stride, 0)
             torch.cuda.synchronize()
             det.append(dwd)
         assert torch.equal(det[0], det[1])
@@ -135,7 +135,7 @@ def test_stem_fwd_and_weight_gradient_against_float64(B, H, W):
     y = torch.full((B, Ho, Wo, 32), float("nan"), device="cuda")
     rows = L.partial_rows_elementwise(B * Ho * Wo * 8)
     part = torch.full((rows, 2, 32), float("nan"), device="cuda")
-    L.call("ttk_stem_fwd", p(d_x), p(d_w), p(y), p(part), B, H, W)
+    L.call("ttk_stem_fwd", p(d_x), p(d_w), p(y), p(part), B, H, W, 0)
     torch.cuda.synchronize()
     assert (y.cpu().double() - y_ref).abs().max().item() <= 3e-6 * y_ref.abs().max().item()
     ps = part.cpu().double().sum(0)
@@ -149,7 +149,7 @@ def test_stem_fwd_and_weight_gradient_against_float64(B, H, W):
     F.conv2d(x, wl, stride=2, padding=2).backward(_nchw(dy).contiguous())
     dw = torch.zeros(32, 25, device="cuda")
     d_g, d_bn = gr.float().cuda(), bn.float().cuda()
-    L.call("ttk_stem_bwd_weight", p(d_g), p(y), p(d_bn), p(d_x), p(dw), 1, None, B, H, W)
+    L.call("ttk_stem_bwd_weight", p(d_g), p(y), p(d_bn), p(d_x), p(dw), 1, None, B, H, W, 0)
     torch.cuda.synchronize()
     ref = wl.grad.reshape(32, 25)
     assert (dw.cpu().double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
@@ -157,7 +157,7 @@ def test_stem_fwd_and_weight_gradient_against_float64(B, H, W):
     for _ in range(2):  # deterministic form: workgroup partials in scratch, folded in a fixed order
         scratch = torch.full((L.cdll.ttk_stem_wgrad_partial_bytes() // 4,), float("nan"), device="cuda")
         dwd = torch.zeros(32, 25, device="cuda")
-        L.call("ttk_stem_bwd_weight", p(d_g), p(y), p(d_bn), p(d_x), p(dwd), 1, p(scratch), B, H, W)
+        L.call("ttk_stem_bwd_weight", p(d_g), p(y), p(d_bn), p(d_x), p(dwd), 1, p(scratch), B, H, W, 0)
         torch.cuda.synchronize()
         det.append(dwd)
     assert torch.equal(det[0], det[1])

@@ -68,7 +68,7 @@ def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout, loose):
     y = torch.empty(M, Cout, device=dev)
     part = torch.full((rows, 2, Cout), float("nan"), device=dev)
     wq = torch.empty(L.pwconv_prepared_bytes(Cin, Cout), dtype=torch.uint8, device=dev)  # scratch for the split weight operand
-    L.call("ttk_pwconv1x1_fwd", p(d_ydw), p(d_bn), p(d_w), p(y), p(part), M, Cin, Cout, p(wq))
+    L.call("ttk_pwconv1x1_fwd", p(d_ydw), p(d_bn), p(d_w), p(y), p(part), M, Cin, Cout, p(wq), 0)
     torch.cuda.synchronize()
     e_hip, e_f32 = _rel(y.cpu().numpy(), y64), _rel(y32, y64)
     print(f"fwd   M={M} K={Cin} N={Cout}: hip {e_hip:.2e}  fp32 chain {e_f32:.2e}")
@@ -92,7 +92,7 @@ def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout, loose):
     g_dw = torch.empty(M, Cin, device=dev)
     part2 = torch.full((rows, 2, Cin), float("nan"), device=dev)
     d_g, d_bnpw = t(g), t(bn_pw)  # named: a temporary would be recycled by the allocator before the kernel runs
-    L.call("ttk_pwconv1x1_bwd_data", p(d_g), p(y), p(d_bnpw), p(wt), p(d_ydw), p(d_bn), p(g_dw), p(part2), M, Cin, Cout, p(wq))
+    L.call("ttk_pwconv1x1_bwd_data", p(d_g), p(y), p(d_bnpw), p(wt), p(d_ydw), p(d_bn), p(g_dw), p(part2), M, Cin, Cout, p(wq), 0)
     torch.cuda.synchronize()
     out = g_dw.cpu().numpy()
     e_hip, e_f32 = _rel(out * safe, gd64 * safe), _rel(gd32 * safe, gd64 * safe)
@@ -109,7 +109,7 @@ def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout, loose):
     dw64 = dy32.astype(np.float64).T @ a32.astype(np.float64)
     dw32 = _chain32(np.ascontiguousarray(dy32.T), a32)
     dW = torch.zeros(Cout, Cin, device=dev)
-    L.call("ttk_pwconv1x1_bwd_weight", p(d_g), p(y), p(d_bnpw), p(d_ydw), p(d_bn), p(dW), None, M, Cin, Cout)
+    L.call("ttk_pwconv1x1_bwd_weight", p(d_g), p(y), p(d_bnpw), p(d_ydw), p(d_bn), p(dW), None, M, Cin, Cout, 0)
     torch.cuda.synchronize()
     e_hip, e_f32 = _rel(dW.cpu().numpy(), dw64), _rel(dw32, dw64)
     print(f"wgrad M={M} Cout={Cout} Cin={Cin}: hip {e_hip:.2e}  fp32 chain {e_f32:.2e}")
@@ -121,7 +121,7 @@ def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout, loose):
         for _ in range(2):
             scratch = torch.full((nbytes // 4,), float("nan"), device=dev)
             dWd = torch.zeros(Cout, Cin, device=dev)
-            L.call("ttk_pwconv1x1_bwd_weight", p(d_g), p(y), p(d_bnpw), p(d_ydw), p(d_bn), p(dWd), p(scratch), M, Cin, Cout)
+            L.call("ttk_pwconv1x1_bwd_weight", p(d_g), p(y), p(d_bnpw), p(d_ydw), p(d_bn), p(dWd), p(scratch), M, Cin, Cout, 0)
             torch.cuda.synchronize()
             runs.append(dWd)
         assert torch.equal(runs[0], runs[1])
@@ -151,13 +151,13 @@ def test_prepared_weights_match_per_call_split():
         out = []
         for prepared in (False, True):
             y, part = torch.empty(M, Cout, device=dev), torch.zeros(rows, 2, Cout, device=dev)
-            L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None if prepared else p(w), p(y), p(part), M, Cin, Cout, p(q if prepared else wq))
+            L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None if prepared else p(w), p(y), p(part), M, Cin, Cout, p(q if prepared else wq), 0)
             gd, part2 = torch.empty(M, Cin, device=dev), torch.zeros(rows, 2, Cin, device=dev)
             L.call("ttk_pwconv1x1_bwd_data", p(g), p(y), p(bn_pw), None if prepared else p(wt), p(ydw), p(bn_dw), p(gd), p(part2), M, Cin, Cout,
-                   p(q if prepared else wq))
+                   p(q if prepared else wq), 0)
             torch.cuda.synchronize()
             out.append((y, part, gd, part2))
         for a, b in zip(*out):
             assert torch.equal(a, b), (M, Cin, Cout)
     with pytest.raises(RuntimeError, match="null pointer"):
-        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(y), None, M, Cin, Cout, None)
+        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(y), None, M, Cin, Cout, None, 0)

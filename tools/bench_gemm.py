@@ -12,26 +12,28 @@ import trackertraincode._hip as H  # noqa: E402
 L, p = H.lib(), H.ptr
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 IT = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+BF = int(os.environ.get("BF16", "0"))  # BF16=1: bf16 activation storage
+ADT = torch.bfloat16 if BF else torch.float32
 shapes = [("dw2_1", 65, 32, 64, 1), ("dw2_2", 33, 64, 128, 1), ("dw3_1", 33, 128, 128, 1), ("dw3_2", 17, 128, 256, 1), ("dw4_1", 17, 256, 256, 1),
           ("dw4_2", 9, 256, 512, 1), ("dw5_x", 9, 512, 512, 5), ("dw5_6", 5, 512, 1024, 1), ("dw6", 5, 1024, 1024, 1)]
 tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
 dev = "cuda"
 for name, hw, ci, co, mult in shapes:
     M = B * hw * hw
-    ydw, y, g = torch.randn(M, ci, device=dev), torch.randn(M, co, device=dev), torch.randn(M, co, device=dev) * 1e-3
+    ydw, y, g = torch.randn(M, ci, device=dev).to(ADT), torch.randn(M, co, device=dev).to(ADT), (torch.randn(M, co, device=dev) * 1e-3).to(ADT)
     w = torch.randn(co, ci, device=dev) * (2.0 / co) ** 0.5
     bn_dw, bn_pw = torch.rand(8, ci, device=dev) + 0.5, torch.rand(8, co, device=dev) + 0.5
     bn_dw[2], bn_pw[2], bn_pw[6] = 0.1, 0.1, 0.0  # means
     bn_dw[7], bn_pw[7] = 0.0, 0.0
     bn_dw[7, 0], bn_pw[7, 1] = 12.0, 0.05  # TTK_AUX_ACT_BOUND, TTK_AUX_DY_BOUND (generous for this data)
-    out, gdw, dW = torch.empty(M, co, device=dev), torch.empty(M, ci, device=dev), torch.zeros(co, ci, device=dev)
+    out, gdw, dW = torch.empty(M, co, device=dev, dtype=ADT), torch.empty(M, ci, device=dev, dtype=ADT), torch.zeros(co, ci, device=dev)
     prep = torch.empty(L.pwconv_prepared_bytes(ci, co), dtype=torch.uint8, device=dev)
     L.pwconv_prepare_weights([w], [prep])
     part = torch.empty(L.partial_rows_gemm(M) * 2 * max(ci, co), device=dev)
     calls = {
-        "fwd": lambda: L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(out), p(part), M, ci, co, p(prep)),
-        "dgrad": lambda: L.call("ttk_pwconv1x1_bwd_data", p(g), p(y), p(bn_pw), None, p(ydw), p(bn_dw), p(gdw), p(part), M, ci, co, p(prep)),
-        "wgrad": lambda: L.call("ttk_pwconv1x1_bwd_weight", p(g), p(y), p(bn_pw), p(ydw), p(bn_dw), p(dW), None, M, ci, co),
+        "fwd": lambda: L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(out), p(part), M, ci, co, p(prep), BF),
+        "dgrad": lambda: L.call("ttk_pwconv1x1_bwd_data", p(g), p(y), p(bn_pw), None, p(ydw), p(bn_dw), p(gdw), p(part), M, ci, co, p(prep), BF),
+        "wgrad": lambda: L.call("ttk_pwconv1x1_bwd_weight", p(g), p(y), p(bn_pw), p(ydw), p(bn_dw), p(dW), None, M, ci, co, BF),
     }
     line = f"{name:6s} M={M:8d} K={ci:4d} N={co:4d} "
     for k, fn in calls.items():
