@@ -83,6 +83,9 @@ enum { TTK_AUX_ACT_BOUND = 0, TTK_AUX_DY_BOUND = 1, TTK_AUX_GMAX = 2 };
 
 int ttk_abi_version(void);
 const char* ttk_last_error_string(void);
+/* Entry points report launch failures through hipGetLastError(), which is per thread and sticky: call this first to drop an
+ * error that some EARLIER HIP call of the process left pending (returns it).  The shipped host does so before every call. */
+int ttk_clear_error(void);
 
 /* Number of rows of the `part` buffer ([rows][2][C] floats) that a producer writes. */
 int ttk_partial_rows_elementwise(int64_t work_items); /* stem / depthwise / pool kernels        */

@@ -152,6 +152,10 @@ using namespace ttk;
 extern "C" {
 
 int ttk_abi_version(void) { return TTK_ABI_VERSION; }
+/* hipGetLastError() is per thread and STICKY: an error left behind by any earlier HIP call of the process (device probing
+ * during start-up, another library) would be reported by the next entry point's launch check.  The host clears it before a
+ * call; returns what was pending. */
+int ttk_clear_error(void) { return (int)hipGetLastError(); }
 const char* ttk_last_error_string(void) { return ttk::g_err; }
 
 int ttk_partial_rows_elementwise(int64_t work_items) { return elementwise_grid(work_items); }

@@ -97,6 +97,8 @@ class _Library:
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.cdll.ttk_last_error_string.restype = c_char_p
         self.cdll.ttk_abi_version.restype = c_int
+        self.cdll.ttk_clear_error.restype = c_int
+        self._clear = self.cdll.ttk_clear_error
         v = self.cdll.ttk_abi_version()
         if v != ABI_VERSION:
             raise RuntimeError(f"libttk_hip.so ABI version {v}, host expects {ABI_VERSION}: rebuild")
@@ -117,6 +119,7 @@ class _Library:
 
     def call(self, name: str, *args):
         stream = torch.cuda.current_stream().cuda_stream
+        self._clear()  # a stale error of an unrelated earlier HIP call must not be blamed on this launch
         rc = self._fns[name](*args, stream)
         if rc != 0:
             msg = self.cdll.ttk_last_error_string().decode(errors="replace")
@@ -182,6 +185,6 @@ def ptr(t: torch.Tensor | None):
 
 
 def exported_symbols() -> list[str]:
-    return ["ttk_abi_version", "ttk_last_error_string", "ttk_partial_rows_elementwise",
+    return ["ttk_abi_version", "ttk_last_error_string", "ttk_clear_error", "ttk_partial_rows_elementwise",
             "ttk_partial_rows_gemm", "ttk_partial_rows_dwconv", "ttk_heads_num_rows", "ttk_pwconv_prepared_bytes",
             "ttk_pwconv_wgrad_partial_bytes", "ttk_stem_wgrad_partial_bytes"] + list(_SIGNATURES)
