@@ -109,13 +109,14 @@ class KernelTimer:
             n_in, n_out = B * H * W * C, B * ((H - 1) // s_ + 1) * ((W - 1) // s_ + 1) * C
             by = eb * (2 * n_out + n_in * (2 + bool(a[4]) + bool(a[7] or a[8])))
             return f"dw_bwd_tiled_k<{s_}, {'float' if eb == 4 else 'unsigned short'}>", 2 * 2 * 9 * n_out, by
-        if name in ("ttk_conv_fwd", "ttk_conv_bwd_data", "ttk_conv_bwd_weight"):  # ResNet18 implicit GEMMs (split-bf16, 6 products)
+        if name in ("ttk_conv_fwd", "ttk_conv_bwd_data", "ttk_conv_bwd_weight"):  # ResNet18 implicit GEMMs
             B, H, W, ci, co, kh, kw, s_, _pad = ints[-9:]
             Ho, Wo = (H - 1) // s_ + 1, (W - 1) // s_ + 1
             fl = 2 * B * Ho * Wo * ci * co * kh * kw
             n_in, n_out = B * H * W * ci, B * Ho * Wo * co
             by = 4 * {"ttk_conv_fwd": n_in + n_out, "ttk_conv_bwd_data": 2 * n_out + 2 * n_in, "ttk_conv_bwd_weight": 2 * n_out + n_in}[name]
-            return name.replace("ttk_", "") + " (pw_split_k implicit GEMM)", fl, by
+            kern = "pw_split_k" if os.environ.get("TTK_GEMM") == "bf16x3" else "pw16_k"  # 6 | 3 sixteen-bit MFMA products per fp32 product
+            return name.replace("ttk_", "") + f" ({kern} implicit GEMM)", fl, by
         return name, 0, 0
 
     def wrap(self, lib):
@@ -393,7 +394,7 @@ def main():
             def roofline_of(k):
                 v = ks[k]
                 sec, launches = v["ms"] * 1e-3, v["calls_per_step"] * roof_steps
-                products = 3 if k.startswith("pw16") else 6 if "pw_split" in k else 0  # 16-bit MFMA products per fp32 product
+                products = 3 if "pw16" in k else 6 if "pw_split" in k else 0  # 16-bit MFMA products per fp32 product
                 hbm = products == 0
                 if hbm:
                     ach, peak, unit = v["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s"

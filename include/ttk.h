@@ -42,7 +42,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 9
+#define TTK_ABI_VERSION 10
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -215,49 +215,58 @@ int ttk_bn_act(const float* y, const float* bn, const float* skip, float* a, int
  * torchvision.models.resnet.BasicBlock/conv3x3/conv1x1, an un-vendored dependency of the reference) as implicit
  * GEMMs on the matrix cores.  Channels-last activations a[B][H][W][C] that are already post-BatchNorm/ReLU
  * ("materialised"); k in {1,3}, stride in {1,2}, pad = k/2; Cin % 32 == 0, Cout % 64 == 0.
- *   ttk_conv_weight_repack  w[Cout][Cin][KH][KW] -> w_fwd[3][KH*KW*Cin/32][Cout][32], w_bwd[3][KH*KW*Cout/32][Cin][32] (either may be
- *                           NULL): 16-bit piece planes (h, m, l) of the exact 3-way bf16 split of every weight, i.e.
- *                           3 * 2 bytes per element - the form the GEMM producers move without arithmetic
- *   ttk_conv_fwd            y[B][Ho][Wo][Cout] raw conv output + part[ttk_partial_rows_gemm(B*Ho*Wo)][2][Cout]
+ *   ttk_conv_weight_repack  w[Cout][Cin][KH][KW] -> w_fwd[.][KH*KW*Cin/32][Cout][32], w_bwd[.][KH*KW*Cout/32][Cin][32] (either may be
+ *                           NULL; each a buffer of 3 * 2 bytes per weight): the 16-bit piece planes the GEMM producers
+ *                           move without arithmetic - two fp16 planes of w * 2^s followed by a float header holding
+ *                           max |w| (default), or TTK_GEMM=bf16x3: the three planes (h, m, l) of the exact bf16 split
+ *   ttk_conv_fwd            y[B][Ho][Wo][Cout] raw conv output + part[ttk_partial_rows_gemm(B*Ho*Wo)][2][Cout].
+ *                           a_bound: device float >= max |a_in| (the fp16 form scales by it) - the TTK_AUX_ACT_BOUND slot
+ *                           of the BatchNorm block that formed a_in (ttk_bn_fwd_finalize bounds relu(bn(y)) and hence
+ *                           its max-pool; ttk_bn_add_act raises the slot to max a)
  *   ttk_conv_bwd_data       g_in[B][H][W][Cin] = conv^T(dy), dy = ga*(g-gmean)+gb*(y-mean) formed on load from the conv
  *                           output's gradient g, raw output y and BatchNorm block bn.  With mask_y/mask_bn (the conv
  *                           input was relu(mask_bn(mask_y))): masked, and part[ttk_partial_rows_gemm(B*H*W)][2][Cin]
- *                           receives (sum g_in, sum g_in*(mask_y-mean)); without: raw gradient, part untouched.
- *   ttk_conv_bwd_weight     dw[Cout][Cin][KH][KW] += sum_pixels dy (x) a_in (fp32 atomics; zero dw first)
+ *                           receives (sum g_in, sum g_in*(mask_y-mean)) and mask_bn[TTK_BN_AUX][TTK_AUX_GMAX] is raised
+ *                           to max |g_in|; without: raw gradient, part untouched.  bn[TTK_BN_AUX][TTK_AUX_DY_BOUND]
+ *                           must bound |dy| (ttk_bn_bwd_finalize, from the TTK_AUX_GMAX the producer of g raised).
+ *   ttk_conv_bwd_weight     dw[Cout][Cin][KH][KW] += sum_pixels dy (x) a_in (fp32 atomics; zero dw first); a_bound as above
  * ------------------------------------------------------------------------------------------- */
 int ttk_conv_weight_repack(const float* w, void* w_fwd, void* w_bwd, int Cout, int Cin, int KH, int KW,
                            ttk_stream_t stream);
-int ttk_conv_fwd(const float* a_in, const void* w_fwd, float* y, float* part, int B, int H, int W, int Cin,
-                 int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream);
+int ttk_conv_fwd(const float* a_in, const float* a_bound, const void* w_fwd, float* y, float* part, int B, int H, int W,
+                 int Cin, int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream);
 int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const void* w_bwd, const float* mask_y,
-                      const float* mask_bn, float* g_in, float* part, int B, int H, int W, int Cin, int Cout,
+                      float* mask_bn, float* g_in, float* part, int B, int H, int W, int Cin, int Cout,
                       int KH, int KW, int stride, int pad, ttk_stream_t stream);
-int ttk_conv_bwd_weight(const float* g, const float* y, const float* bn, const float* a_in, float* dw, int B, int H,
-                        int W, int Cin, int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream);
+int ttk_conv_bwd_weight(const float* g, const float* y, const float* bn, const float* a_in, const float* a_bound, float* dw,
+                        int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The non-GEMM kernels of the ResNet18 variant (backbones/resnet.py:52-104: torchvision ResNet18, 1-channel 7x7 stem).
  *   ttk_stem7_fwd          y[B][65][65][64] = conv7x7/s2/p3(x[B][1][H][W]) + part[ttk_partial_rows_elementwise(B*Ho*Wo*16)][2][64]
  *   ttk_stem7_bwd_weight   dw[64][1][7][7] (overwritten) from dy = ga*(g-gmean)+gb*(y-mean)
- *   ttk_maxpool3x3s2_fwd   a[B][Ho][Wo][C] = maxpool3x3/s2/p1(relu(bn(y))), idx = window position of the first maximum
+ *   ttk_maxpool3x3s2_fwd   a[B][Ho][Wo][C] = maxpool3x3/s2/p1(relu(bn(y))), idx = window position of the first maximum;
+ *                          raises bn[TTK_BN_AUX][TTK_AUX_ACT_BOUND] to max a
  *   ttk_maxpool3x3s2_bwd   g[B][H][W][C] = gradient w.r.t. bn(y) (ReLU mask applied) from ga (+ gb) w.r.t. the pooled
  *                          activation; part[ttk_partial_rows_elementwise(B*H*W*C/4)][2][C] = (sum g, sum g*(y-mean))
  *   ttk_bn_add_act         a = relu(bn(y) + r); r = res, or res_bn(res) when res is the raw downsample-conv output
- *                          (BasicBlock: out = relu(bn2(conv2) + identity)), or nothing
+ *                          (BasicBlock: out = relu(bn2(conv2) + identity)), or nothing.  Raises
+ *                          bn[TTK_BN_AUX][TTK_AUX_ACT_BOUND] to max a (the a_bound of the convolutions that read a).
  *   ttk_residual_bwd       gs = (ga (+ gb)) * [a > 0]; part = sums for bn(y); partd (with yd, bnd) = sums for the
- *                          downsample BatchNorm; rows of both = ttk_partial_rows_elementwise(rows*C/4)
+ *                          downsample BatchNorm; rows of both = ttk_partial_rows_elementwise(rows*C/4).  Raises
+ *                          TTK_AUX_GMAX of bn (and bnd) to max |gs|.
  * ------------------------------------------------------------------------------------------- */
 int ttk_stem7_fwd(const float* x, const float* w, float* y, float* part, int B, int H, int W, ttk_stream_t stream);
 int ttk_stem7_bwd_weight(const float* g, const float* y, const float* bn, const float* x, float* dw, int B, int H,
                          int W, ttk_stream_t stream);
-int ttk_maxpool3x3s2_fwd(const float* y, const float* bn, float* a, unsigned char* idx, int B, int H, int W, int C,
+int ttk_maxpool3x3s2_fwd(const float* y, float* bn, float* a, unsigned char* idx, int B, int H, int W, int C,
                          ttk_stream_t stream);
 int ttk_maxpool3x3s2_bwd(const float* ga, const float* gb, const unsigned char* idx, const float* y, const float* bn,
                          float* g, float* part, int B, int H, int W, int C, ttk_stream_t stream);
-int ttk_bn_add_act(const float* y, const float* bn, const float* res, const float* res_bn, float* a, int64_t rows,
+int ttk_bn_add_act(const float* y, float* bn, const float* res, const float* res_bn, float* a, int64_t rows,
                    int C, ttk_stream_t stream);
-int ttk_residual_bwd(const float* ga, const float* gb, const float* a, const float* y, const float* bn, const float* yd,
-                     const float* bnd, float* gs, float* part, float* partd, int64_t rows, int C, ttk_stream_t stream);
+int ttk_residual_bwd(const float* ga, const float* gb, const float* a, const float* y, float* bn, const float* yd,
+                     float* bnd, float* gs, float* part, float* partd, int64_t rows, int C, ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-task heads - everything NetworkWithPointHead.forward does after the backbone

@@ -1,7 +1,8 @@
 // Dense convolutions of the ResNet18 backbone variant (reference: backbones/resnet.py:52-104; the arithmetic is
 // torchvision.models.resnet.BasicBlock / conv3x3 / conv1x1, un-vendored in the reference) as implicit GEMMs on the
-// split-bf16 producer/consumer kernel of pwconv_split.hip: channels-last activations [B][H][W][C], GEMM rows = pixels,
-// contraction = (tap, channel).  Activations are materialised here (post-BatchNorm/ReLU tensors) - ResNet18 is
+// producer/consumer split kernels of pwconv_f16.hip (fp16 pipe, two pieces per operand, three products; the default)
+// or pwconv_split.hip (TTK_GEMM=bf16x3: three bf16 pieces, six products): channels-last activations [B][H][W][C], GEMM
+// rows = pixels, contraction = (tap, channel).  Activations are materialised here (post-BatchNorm/ReLU tensors) - ResNet18 is
 // matrix-bound (150 flop/B), the extra elementwise passes are ~10 % of its step.
 #include "ttk_common.h"
 #include "conv_geom.h"
@@ -32,6 +33,42 @@ __global__ void conv_weight_repack_k(const float* __restrict__ w, uint16_t* __re
   }
 }
 
+// fp16 form: max |w| (ordered-uint atomicMax into *wmax, zeroed by the caller), then the two planes of w * pow2_scale(max)
+// in the same [K/32][N][32] layouts, each followed by a copy of the maximum (the header the GEMMs read their scale from).
+__global__ void __launch_bounds__(256) conv_weight_absmax_k(const float* __restrict__ w, int64_t n, unsigned* __restrict__ wmax) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > __hip_atomic_load(wmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(wmax, __float_as_uint(m));
+}
+
+__global__ void conv_weight_repack16_k(const float* __restrict__ w, uint16_t* __restrict__ wf, uint16_t* __restrict__ wb,
+                                       const float* __restrict__ wmax, int Cout, int Cin, int T) {
+  const int64_t n = (int64_t)Cout * Cin * T;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float mx = *wmax;
+  if (i == 0) {
+    if (wf && reinterpret_cast<const float*>(wf + 2 * n) != wmax) *reinterpret_cast<float*>(wf + 2 * n) = mx;
+    if (wb && reinterpret_cast<const float*>(wb + 2 * n) != wmax) *reinterpret_cast<float*>(wb + 2 * n) = mx;
+  }
+  const int t = (int)(i % T), ci = (int)((i / T) % Cin), co = (int)(i / ((int64_t)T * Cin));
+  const float x = w[i] * pow2_scale(mx);
+  const _Float16 hh = (_Float16)x;
+  const _Float16 ll = (_Float16)(x - (float)hh);
+  const uint16_t h = __builtin_bit_cast(uint16_t, hh), l = __builtin_bit_cast(uint16_t, ll);
+  if (wf) {
+    const size_t o = ((size_t)(t * (Cin >> 5) + (ci >> 5)) * Cout + co) * 32 + (ci & 31);
+    wf[o] = h; wf[n + o] = l;
+  }
+  if (wb) {
+    const size_t o = ((size_t)(t * (Cout >> 5) + (co >> 5)) * Cin + ci) * 32 + (co & 31);
+    wb[o] = h; wb[n + o] = l;
+  }
+}
+
 static bool conv_shape_ok(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
   return B > 0 && H > 0 && W > 0 && Cin >= 32 && Cin % 32 == 0 && Cout >= 64 && Cout % 64 == 0 && KH == KW && (KH == 1 || KH == 3) &&
          (stride == 1 || stride == 2) && pad == KH / 2;
@@ -46,19 +83,33 @@ extern "C" {
 int ttk_conv_weight_repack(const float* w, void* w_fwd, void* w_bwd, int Cout, int Cin, int KH, int KW, ttk_stream_t stream) {
   TTK_REQUIRE(w && (w_fwd || w_bwd) && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "conv_weight_repack: bad arguments");
   const int64_t n = (int64_t)Cout * Cin * KH * KW;
+  if (gemm_mode() == GEMM_F16X2) {
+    float* hdr = reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(w_fwd ? w_fwd : w_bwd) + 2 * n);  // behind the two planes
+    (void)hipMemsetAsync(hdr, 0, sizeof(float), (hipStream_t)stream);
+    hipLaunchKernelGGL(conv_weight_absmax_k, dim3((unsigned)(n / 1024 < 1 ? 1 : (n / 1024 > 256 ? 256 : n / 1024))), dim3(256), 0,
+                       (hipStream_t)stream, w, n, reinterpret_cast<unsigned*>(hdr));
+    hipLaunchKernelGGL(conv_weight_repack16_k, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_fwd,
+                       (uint16_t*)w_bwd, hdr, Cout, Cin, KH * KW);
+    TTK_LAUNCH_CHECK("conv_weight_repack");
+  }
   hipLaunchKernelGGL(conv_weight_repack_k, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_fwd, (uint16_t*)w_bwd,
                      Cout, Cin, KH * KW);
   TTK_LAUNCH_CHECK("conv_weight_repack");
 }
 
-int ttk_conv_fwd(const float* a_in, const void* w_fwd, float* y, float* part, int B, int H, int W, int Cin, int Cout, int KH, int KW,
-                 int stride, int pad, ttk_stream_t stream) {
-  TTK_REQUIRE(a_in && w_fwd && y, "conv_fwd: null pointer");
+int ttk_conv_fwd(const float* a_in, const float* a_bound, const void* w_fwd, float* y, float* part, int B, int H, int W, int Cin, int Cout,
+                 int KH, int KW, int stride, int pad, ttk_stream_t stream) {
+  TTK_REQUIRE(a_in && a_bound && w_fwd && y, "conv_fwd: null pointer");
   TTK_REQUIRE(conv_shape_ok(B, H, W, Cin, Cout, KH, KW, stride, pad), "conv_fwd: unsupported shape B=%d H=%d W=%d Cin=%d Cout=%d k=%d s=%d p=%d", B, H, W, Cin, Cout, KH, stride, pad);
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   const ConvGeom geo{H, W, Ho, Wo, stride, pad, KW, Cin, 0};
-  const bool ok = launch_conv_gemm(AMODE_PLAIN, EMODE_STATS, a_in, nullptr, nullptr, (const uint16_t*)w_fwd, y, nullptr, nullptr, part,
-                                   (int64_t)B * Ho * Wo, KH * KW * Cin, Cout, geo, (hipStream_t)stream);
+  const uint16_t* wq = (const uint16_t*)w_fwd;
+  const int K = KH * KW * Cin;
+  const bool ok = gemm_mode() == GEMM_F16X2
+                      ? launch_conv_gemm16(AMODE_PLAIN, EMODE_STATS, a_in, nullptr, nullptr, a_bound, wq, (const float*)(wq + 2 * (size_t)K * Cout), y,
+                                           nullptr, nullptr, part, (int64_t)B * Ho * Wo, K, Cout, geo, (hipStream_t)stream)
+                      : launch_conv_gemm(AMODE_PLAIN, EMODE_STATS, a_in, nullptr, nullptr, wq, y, nullptr, nullptr, part, (int64_t)B * Ho * Wo, K,
+                                         Cout, geo, (hipStream_t)stream);
   TTK_REQUIRE(ok, "conv_fwd: no kernel for this shape");
   TTK_LAUNCH_CHECK("conv_fwd");
 }
@@ -68,27 +119,34 @@ int ttk_conv_fwd(const float* a_in, const void* w_fwd, float* y, float* part, in
 // result is masked with it and part gets the BatchNorm-backward sums (sum g, sum g*(mask_y-mean)) of bn_in; without
 // them the raw gradient is written and part is not touched.
 int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const void* w_bwd, const float* mask_y,
-                      const float* mask_bn, float* g_in, float* part, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                      float* mask_bn, float* g_in, float* part, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                       int stride, int pad, ttk_stream_t stream) {
   TTK_REQUIRE(g && y && bn && w_bwd && g_in, "conv_bwd_data: null pointer");
   TTK_REQUIRE((mask_y == nullptr) == (mask_bn == nullptr), "conv_bwd_data: mask_y and mask_bn go together");
   TTK_REQUIRE(conv_shape_ok(B, H, W, Cin, Cout, KH, KW, stride, pad) && Cin % 64 == 0, "conv_bwd_data: unsupported shape");
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   const ConvGeom geo{Ho, Wo, H, W, stride, pad, KW, Cout, 1};
-  const bool ok = launch_conv_gemm(AMODE_BNGRAD, mask_y ? EMODE_MASK : EMODE_PLAIN, g, y, bn, (const uint16_t*)w_bwd, g_in, mask_y, mask_bn,
-                                   mask_y ? part : nullptr, (int64_t)B * H * W, KH * KW * Cout, Cin, geo, (hipStream_t)stream);
+  const uint16_t* wq = (const uint16_t*)w_bwd;
+  const int K = KH * KW * Cout, em = mask_y ? EMODE_MASK : EMODE_PLAIN;
+  const bool ok = gemm_mode() == GEMM_F16X2
+                      ? launch_conv_gemm16(AMODE_BNGRAD, em, g, y, bn, nullptr, wq, (const float*)(wq + 2 * (size_t)K * Cin), g_in, mask_y, mask_bn,
+                                           mask_y ? part : nullptr, (int64_t)B * H * W, K, Cin, geo, (hipStream_t)stream)
+                      : launch_conv_gemm(AMODE_BNGRAD, em, g, y, bn, wq, g_in, mask_y, mask_bn, mask_y ? part : nullptr, (int64_t)B * H * W, K, Cin, geo,
+                                         (hipStream_t)stream);
   TTK_REQUIRE(ok, "conv_bwd_data: no kernel for this shape");
   TTK_LAUNCH_CHECK("conv_bwd_data");
 }
 
 // dw[Cout][Cin][KH][KW] += sum_{pixels} dy (x) a_in.  The caller zeroes dw (or accumulates on purpose).
-int ttk_conv_bwd_weight(const float* g, const float* y, const float* bn, const float* a_in, float* dw, int B, int H, int W,
-                        int Cin, int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream) {
-  TTK_REQUIRE(g && y && bn && a_in && dw, "conv_bwd_weight: null pointer");
+int ttk_conv_bwd_weight(const float* g, const float* y, const float* bn, const float* a_in, const float* a_bound, float* dw, int B, int H,
+                        int W, int Cin, int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream) {
+  TTK_REQUIRE(g && y && bn && a_in && a_bound && dw, "conv_bwd_weight: null pointer");
   TTK_REQUIRE(conv_shape_ok(B, H, W, Cin, Cout, KH, KW, stride, pad), "conv_bwd_weight: unsupported shape");
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   const ConvGeom geo{H, W, Ho, Wo, stride, pad, KW, Cin, 0};
-  const bool ok = launch_conv_wgrad(g, y, bn, a_in, dw, (int64_t)B * Ho * Wo, Cout, KH * KW, geo, (hipStream_t)stream);
+  const bool ok = gemm_mode() == GEMM_F16X2
+                      ? launch_conv_wgrad16(g, y, bn, a_in, a_bound, dw, (int64_t)B * Ho * Wo, Cout, KH * KW, geo, (hipStream_t)stream)
+                      : launch_conv_wgrad(g, y, bn, a_in, dw, (int64_t)B * Ho * Wo, Cout, KH * KW, geo, (hipStream_t)stream);
   TTK_REQUIRE(ok, "conv_bwd_weight: no kernel for this shape");
   TTK_LAUNCH_CHECK("conv_bwd_weight");
 }

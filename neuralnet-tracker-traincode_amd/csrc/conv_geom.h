@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 namespace ttk {
 
@@ -18,11 +20,31 @@ struct ConvGeom {
   int Hs, Ws, Hg, Wg, stride, pad, KW, Kc, transposed;
 };
 
+// TTK_GEMM=f32mfma keeps every pointwise conv on v_mfma_f32_32x32x2_f32, bf16x3 selects the 3-piece bf16 split (A/B
+// timing and numerics comparisons; the ResNet18 convolutions have no fp32 form and take bf16x3 for both)
+enum { GEMM_F16X2 = 0, GEMM_BF16X3 = 1, GEMM_F32 = 2 };
+inline int gemm_mode() {
+  static const int mode = [] {
+    const char* e = getenv("TTK_GEMM");
+    if (e && strcmp(e, "f32mfma") == 0) return (int)GEMM_F32;
+    if (e && strcmp(e, "bf16x3") == 0) return (int)GEMM_BF16X3;
+    return (int)GEMM_F16X2;
+  }();
+  return mode;
+}
+
 bool launch_conv_gemm(int amode, int emode, const float* A0, const float* A1, const float* bnA, const uint16_t* Bm, float* out,
                       const float* E0, const float* bnE, float* part, int64_t M, int K, int Nout, const ConvGeom& geo,
                       hipStream_t st);
 
 bool launch_conv_wgrad(const float* g, const float* y, const float* bn, const float* a_in, float* dw, int64_t M, int Cout,
                        int taps, const ConvGeom& geo, hipStream_t st);
+
+// fp16-pipe forms (pwconv_f16.hip): Bq = two fp16 planes scaled by pow2_scale(*wmax); a_bound = bound of a plain A operand
+bool launch_conv_gemm16(int amode, int emode, const float* A0, const float* A1, const float* bnA, const float* a_bound, const uint16_t* Bq,
+                        const float* wmax, float* out, const float* E0, float* bnE, float* part, int64_t M, int K, int Nout,
+                        const ConvGeom& geo, hipStream_t st);
+bool launch_conv_wgrad16(const float* g, const float* y, const float* bn, const float* a_in, const float* a_bound, float* dw, int64_t M,
+                         int Cout, int taps, const ConvGeom& geo, hipStream_t st);
 
 }  // namespace ttk

@@ -15,6 +15,7 @@
 // 32-63 hold k=8s+4..8s+7, so the j-th register of both operands forms the k-pair {8s+j, 8s+4+j} of
 // one 32x32x2 MFMA - the sum over k is order-free, so no shuffling is needed.
 #include "ttk_common.h"
+#include "conv_geom.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -382,18 +383,6 @@ bool split_gemm_shape(int K, int Nout);
 bool launch_split_wgrad(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
                         int64_t M, int Cin, int Cout, hipStream_t st);
 
-enum { GEMM_F16X2 = 0, GEMM_BF16X3 = 1, GEMM_F32 = 2 };
-static int gemm_mode() {
-  // TTK_GEMM=f32mfma keeps every pointwise conv on v_mfma_f32_32x32x2_f32, bf16x3 selects the 3-piece bf16 split
-  // (A/B timing and numerics comparisons)
-  static const int mode = [] {
-    const char* e = getenv("TTK_GEMM");
-    if (e && strcmp(e, "f32mfma") == 0) return (int)GEMM_F32;
-    if (e && strcmp(e, "bf16x3") == 0) return (int)GEMM_BF16X3;
-    return (int)GEMM_F16X2;
-  }();
-  return mode;
-}
 // Layout of a prepared weight block of n = Cin*Cout elements.  fp16 / fp32 modes: [forward operand 4n][data-gradient
 // operand 4n][header: |w| maximum] - an operand is two fp16 planes or, for the shapes that stay on the fp32 kernels,
 // the fp32 rows; bf16 mode: [forward 6n][data gradient 6n].

@@ -182,12 +182,17 @@ __device__ __forceinline__ void producer_schedule(int nks, Prefetch&& prefetch, 
 // weights scaled by pow2_scale(*wmax).
 // T: storage of activations (A1 = y, E0 = mask operand); TO: storage of the A0 operand and of the output - activations in the
 // forward pass, activation gradients in the data gradient
-template <int BM, int BN, int AMODE, int EMODE, int D, typename T, typename TO>
+// GATHER (conv.hip, the ResNet18 variant): implicit-GEMM convolution - the A rows are gathered per tap (conv_geom.h),
+// K = taps * geo.Kc, the BatchNorm block of the A operand has geo.Kc channels; AMODE_PLAIN: A0 is a materialised
+// activation whose bound is *a_bound; the masked epilogue raises bnE[TTK_BN_AUX][TTK_AUX_GMAX] to max |out|.
+template <int BM, int BN, int AMODE, int EMODE, int D, typename T, typename TO, bool GATHER = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restrict__ bnA,
        const uint16_t* __restrict__ Bq, const float* __restrict__ wmax, TO* __restrict__ out, const T* __restrict__ E0,
-       const float* __restrict__ bnE, float* __restrict__ part, int64_t M, int K, int Nout) {
-  static_assert((BM == 128 && BN == 256) || (BM == 256 && BN == 128), "tile shapes");
+       float* __restrict__ bnE, float* __restrict__ part, int64_t M, int K, int Nout, const float* __restrict__ a_bound,
+       ConvGeom geo) {
+  static_assert((BM == 128 && BN == 256) || (BM == 256 && BN == 128) || (BM == 256 && BN == 64), "tile shapes");
+  static_assert(GATHER || AMODE != AMODE_PLAIN, "plain A operands come from the convolutions");
   constexpr int RS = TTK_RS;
   constexpr int APL = BM * 32, BPL = BN * 32;  // bytes of one piece plane of a k16 stage
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -207,7 +212,9 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
   const int n0 = bx * BN;
   const int nks = K / 32;
   const bool producer = __builtin_amdgcn_readfirstlane(tid) >= 256;
-  const float sa = pow2_scale(bnA[(size_t)TTK_BN_AUX * K + (AMODE == AMODE_BNRELU ? TTK_AUX_ACT_BOUND : TTK_AUX_DY_BOUND)]);
+  const int Kc = GATHER ? geo.Kc : K;  // channels per tap
+  const float sa = pow2_scale(AMODE == AMODE_PLAIN ? *a_bound
+                                                   : bnA[(size_t)TTK_BN_AUX * Kc + (AMODE == AMODE_BNRELU ? TTK_AUX_ACT_BOUND : TTK_AUX_DY_BOUND)]);
   const float sb = pow2_scale(*wmax);
 
   if (producer) {
@@ -220,17 +227,33 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
     f32x4 ra0[D][AP], ra1[D][AMODE == AMODE_BNGRAD ? AP : 1], q[D][NQ];
     constexpr int BI = BN / 64;  // B rows per thread and piece plane: 64 rows x 4 chunks of 16 B (8 k) per pass
     u32x4 rb[D][2][BI];
-    int64_t arow[AP];
+    int64_t arow[GATHER ? 1 : AP];
+    int gbase[GATHER ? AP : 1], gh[GATHER ? AP : 1], gw[GATHER ? AP : 1];  // gather: image base pixel, grid coordinates
+    unsigned vmask[D];  // gather: rows whose tap falls inside the source tensor, per register set
+    const int kpt = Kc / 32;  // k32 steps per tap
+    if constexpr (!GATHER) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      int64_t row = m0 + row0 + 32 * i;
-      arow[i] = (row < M ? row : M - 1) * (int64_t)K + kq8 * 4;  // clamp: rows past M are computed but never stored
+      for (int i = 0; i < AP; ++i) {
+        int64_t row = m0 + row0 + 32 * i;
+        arow[i] = (row < M ? row : M - 1) * (int64_t)K + kq8 * 4;  // clamp: rows past M are computed but never stored
+      }
+    } else {
+      const int hw = geo.Hg * geo.Wg;
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        const int64_t row = m0 + row0 + 32 * i;
+        const int rr = (int)(row < M ? row : M - 1);
+        const int n = rr / hw, rem = rr - n * hw;
+        gh[i] = rem / geo.Wg;
+        gw[i] = rem - gh[i] * geo.Wg;
+        gbase[i] = row < M ? n * geo.Hs * geo.Ws : -1;
+      }
     }
     const int brow = pt >> 2, bc4 = pt & 3;
     const uint16_t* bp = Bq + (int64_t)(n0 + brow) * 32 + bc4 * 8;
     const int64_t bplane = (int64_t)K * Nout;
     unsigned char* wbase_b = lds + (bc4 >> 1) * kStride16 + 2 * APL;
-    const float* cp = bnA + kq8 * 4;
+    const float* cp = AMODE == AMODE_PLAIN ? nullptr : bnA + kq8 * 4;
     unsigned char* wbase = lds + sub * kStride16 + o8;
 
     auto load_a = [&](int ks, auto setc) {
@@ -238,21 +261,46 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
 #if defined(TTK_EXP) && (TTK_EXP == 2 || TTK_EXP == 6)
       if (ks >= D) return;  // timing experiment: A is loaded for the first steps only
 #endif
-      const int kc0 = ks * 32;
+      const int tap = GATHER ? ks / kpt : 0, kc0 = (ks - tap * kpt) * 32;
+      if constexpr (!GATHER) {
 #pragma unroll
-      for (int i = 0; i < AP; ++i) {
-        ra0[set][i] = ld_act4<TO>(A0 + arow[i] + kc0);
-        if constexpr (AMODE == AMODE_BNGRAD) ra1[set][i] = ld_act4<T>(A1 + arow[i] + kc0);
+        for (int i = 0; i < AP; ++i) {
+          ra0[set][i] = ld_act4<TO>(A0 + arow[i] + kc0);
+          if constexpr (AMODE == AMODE_BNGRAD) ra1[set][i] = ld_act4<T>(A1 + arow[i] + kc0);
+        }
+      } else {  // the taps re-read their neighbours' rows: cached loads
+        const int kh = tap / geo.KW, kw = tap - kh * geo.KW;
+        unsigned vm = 0u;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+          int sh, sw;
+          bool ok = gbase[i] >= 0;
+          if (!geo.transposed) {
+            sh = gh[i] * geo.stride - geo.pad + kh;
+            sw = gw[i] * geo.stride - geo.pad + kw;
+          } else {
+            const int th = gh[i] + geo.pad - kh, tw = gw[i] + geo.pad - kw, sm = geo.stride - 1;  // stride 1 or 2
+            ok = ok && th >= 0 && tw >= 0 && ((th | tw) & sm) == 0;
+            sh = th >> sm;
+            sw = tw >> sm;
+          }
+          ok = ok && (unsigned)sh < (unsigned)geo.Hs && (unsigned)sw < (unsigned)geo.Ws;
+          const int64_t off = ok ? ((int64_t)(gbase[i] + sh * geo.Ws + sw) * Kc + kc0 + kq8 * 4) : (int64_t)(kq8 * 4);
+          vm |= (ok ? 1u : 0u) << i;
+          ra0[set][i] = *reinterpret_cast<const f32x4*>(A0 + off);
+          if constexpr (AMODE == AMODE_BNGRAD) ra1[set][i] = *reinterpret_cast<const f32x4*>(A1 + off);
+        }
+        vmask[set] = vm;
       }
       if constexpr (AMODE == AMODE_BNRELU) {
-        q[set][0] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_SCALE * K + kc0);
-        q[set][1] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * K + kc0);
-        q[set][2] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_BETA * K + kc0);
-      } else {
-        q[set][0] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GA * K + kc0);
-        q[set][1] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GMEAN * K + kc0);
-        q[set][2] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GB * K + kc0);
-        q[set][3] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * K + kc0);
+        q[set][0] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_SCALE * Kc + kc0);
+        q[set][1] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * Kc + kc0);
+        q[set][2] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_BETA * Kc + kc0);
+      } else if constexpr (AMODE == AMODE_BNGRAD) {
+        q[set][0] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GA * Kc + kc0);
+        q[set][1] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GMEAN * Kc + kc0);
+        q[set][2] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GB * Kc + kc0);
+        q[set][3] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * Kc + kc0);
       }
     };
     auto load_b = [&](int ks, auto setc) {
@@ -273,16 +321,21 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
 #endif
       unsigned char* S = wbase + (ks % RS) * 2 * kStride16;
       // the scale S_a rides on the per-channel constants (exact: a power of two)
-      const f32x4 c0 = q[set][0] * sa, c2 = q[set][2] * sa;
+      f32x4 c0, c2;
+      if constexpr (AMODE != AMODE_PLAIN) { c0 = q[set][0] * sa; c2 = q[set][2] * sa; }
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
         f32x4 v;
         if constexpr (AMODE == AMODE_BNRELU) {
           v = c0 * (ra0[set][i] - q[set][1]) + c2;
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        } else {
+        } else if constexpr (AMODE == AMODE_BNGRAD) {
           v = c0 * (ra0[set][i] - q[set][1]) + c2 * (ra1[set][i] - q[set][NQ - 1]);
+        } else {
+          v = ra0[set][i] * sa;
         }
+        if constexpr (GATHER)
+          if (!((vmask[set] >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};  // zero padding / taps that miss the stride grid
         split_store16(v, S + swz16(row0 + 32 * i, chunk), APL);
       }
     };
@@ -398,6 +451,7 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
     esc = ld4(bnE + TTK_BN_SCALE * Nout + col); emean = ld4(bnE + TTK_BN_MEAN * Nout + col); ebeta = ld4(bnE + TTK_BN_BETA * Nout + col);
   }
   float4 s1 = f4(0.f), s2 = f4(0.f);
+  float vmx = 0.f;
 #pragma unroll
   for (int i = 0; i < EI; ++i) {
     const int row = half * 128 + rr + RGH * i;
@@ -406,7 +460,9 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
     float4 v = ld4(Cs + row * LDC + 4 * c4);
     v = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
     const size_t o = (size_t)grow * Nout + col;
-    if constexpr (EMODE == EMODE_STATS) {
+    if constexpr (EMODE == EMODE_PLAIN) {
+      Act<TO>::st(out + o, Act<TO>::round(v));
+    } else if constexpr (EMODE == EMODE_STATS) {
       v = Act<TO>::round(v);  // statistics of what is stored
 #if !(defined(TTK_EXP) && TTK_EXP == 1)
       Act<TO>::st(out + o, v);
@@ -419,7 +475,15 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
       Act<TO>::st(out + o, v);
       s1 = add4(s1, v);
       s2 = fma4(v, yc, s2);
+      if constexpr (GATHER) vmx = fmaxf(vmx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
+  }
+  if constexpr (GATHER && EMODE == EMODE_MASK) {  // the bound the next layer's split GEMMs scale this gradient by
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) vmx = fmaxf(vmx, __shfl_xor(vmx, off));
+    unsigned* slot = reinterpret_cast<unsigned*>(bnE + (size_t)TTK_BN_AUX * Nout + TTK_AUX_GMAX);
+    if ((tid & 63) == 0 && __float_as_uint(vmx) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(slot, __float_as_uint(vmx));
   }
   if (part) {
     st4(red + (rg * 2 + 0) * BN + 4 * c4, s1);
@@ -444,12 +508,17 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
 // otherwise (deterministic mode) slice s stores its tile to partial[s][Cout][Cin] and wgrad_reduce_k folds the slices
 // in a fixed order.
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int D, typename T, typename TG>
+// CONV (conv.hip, the ResNet18 variant): the columns are (tap, input channel) - Cin holds their number taps * geo.Kc - and
+// X is the materialised input activation [B][Hs][Ws][Kc] with bound *x_bound; the rows m enumerate OUTPUT pixels
+// (Hg x Wg per image) and column (tap, ci) reads the input pixel the tap points at (zero outside).  Partial tiles
+// (Cout < BM, Cin % BN != 0) are masked; dW is torch's [Cout][Kc][taps].
+template <int BM, int BN, int D, typename T, typename TG, bool CONV = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __restrict__ bn_pw,
              const T* __restrict__ X, const float* __restrict__ bn_x, float* __restrict__ dW, float* __restrict__ partial,
-             int64_t M, int Cin, int Cout, int64_t rows_per_slice) {
-  static_assert((BM + BN == 384 && (BM == 128 || BM == 256)) || (BM == 128 && BN == 128), "128x256, 256x128 or 128x128");
+             int64_t M, int Cin, int Cout, int64_t rows_per_slice, const float* __restrict__ x_bound, ConvGeom geo) {
+  static_assert((BM + BN == 384 && (BM == 128 || BM == 256)) || (BM == 128 && BN == 128) || (CONV && BM == 64 && BN == 256),
+                "128x256, 256x128, 128x128 or (convolutions) 64x256");
   constexpr int RS = TTK_RS;
   constexpr int APL = BM * 32, BPL = BN * 32;
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -462,28 +531,40 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
   const unsigned xq = NG / 8, xr = NG % 8, xcd = Lid % 8;
   const unsigned logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + Lid / 8;
   const unsigned tile = logical % NT, slice = logical / NT;
-  const int tiles_k = Cin / BN;
+  const int tiles_k = CONV ? (Cin + BN - 1) / BN : Cin / BN;
   const int n0 = (tile / tiles_k) * BM, k0 = (tile % tiles_k) * BN;
+  const int Kc = CONV ? geo.Kc : Cin;  // row length of X
   const int64_t m_begin = (int64_t)slice * rows_per_slice;
   const int64_t m_end = (m_begin + rows_per_slice < M) ? m_begin + rows_per_slice : M;
   if (m_begin >= m_end) return;  // uniform over the block, before any barrier (the host sizes the slices so that none is empty)
   const int nks = (int)((m_end - m_begin + 31) / 32);
   const bool producer = __builtin_amdgcn_readfirstlane(tid) >= 256;
   const float sa = pow2_scale(bn_pw[(size_t)TTK_BN_AUX * Cout + TTK_AUX_DY_BOUND]);
-  const float sb = pow2_scale(bn_x[(size_t)TTK_BN_AUX * Cin + TTK_AUX_ACT_BOUND]);
+  const float sb = pow2_scale(CONV ? *x_bound : bn_x[(size_t)TTK_BN_AUX * Cin + TTK_AUX_ACT_BOUND]);
 
   if (producer) {
     __builtin_amdgcn_s_setprio(3);
     const int pt = tid - 256;
     const int mb = pt & 7, cq = pt >> 3;  // 8 row blocks of 4 rows x 32 channel quads per pass
     const int sub = mb >> 2, chunk = (mb >> 1) & 1, o8 = (mb & 1) * 8;
-    constexpr int AP = BM / 128, BP = BN / 128;
+    constexpr int AP = BM >= 128 ? BM / 128 : 1, BP = BN / 128;
     f32x4 rg[D][AP][4], ry[D][AP][4], rx[D][BP][4];
     f32x4 ga[AP], gb[AP], gmean[AP], ymean[AP], sc[BP], mu[BP], be[BP];
     int ca[AP], cb[BP];
+    // convolutions: tap of the B columns, validity of this thread's A rows / B columns (partial tiles), and per register
+    // set the (pass, row) pairs of the in-flight B loads that hit the source tensor
+    int kh[CONV ? BP : 1], kw[CONV ? BP : 1];
+    bool va[AP], vb[BP];
+    unsigned bmask[D];
+    const bool a_on = BM >= 128 || cq < BM / 4;  // a 64-row A tile occupies half of the producers' channel quads
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       ca[p] = n0 + 4 * (cq + 32 * p);
+      va[p] = true;
+      if constexpr (CONV) {
+        va[p] = a_on && ca[p] < Cout;
+        if (!va[p]) ca[p] = 0;
+      }
       ga[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GA * Cout + ca[p]) * sa;
       gb[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GB * Cout + ca[p]) * sa;
       gmean[p] = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GMEAN * Cout + ca[p]);
@@ -492,9 +573,18 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
       cb[p] = k0 + 4 * (cq + 32 * p);
-      sc[p] = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_SCALE * Cin + cb[p]) * sb;
-      mu[p] = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_MEAN * Cin + cb[p]);
-      be[p] = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_BETA * Cin + cb[p]) * sb;
+      vb[p] = true;
+      if constexpr (CONV) {
+        vb[p] = cb[p] < Cin;
+        const int cc = vb[p] ? cb[p] : 0, tap = cc / Kc;
+        cb[p] = cc - tap * Kc;
+        kh[p] = tap / geo.KW;
+        kw[p] = tap - kh[p] * geo.KW;
+      } else {
+        sc[p] = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_SCALE * Cin + cb[p]) * sb;
+        mu[p] = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_MEAN * Cin + cb[p]);
+        be[p] = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_BETA * Cin + cb[p]) * sb;
+      }
     }
     unsigned char* wbase = lds + sub * kStride16 + o8;
 
@@ -510,10 +600,12 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
       yp[p] = Y + (m_begin + 4 * mb) * Cout + ca[p];
     }
 #pragma unroll
-    for (int p = 0; p < BP; ++p) xp[p] = X + (m_begin + 4 * mb) * Cin + cb[p];
+    for (int p = 0; p < BP; ++p) xp[p] = X + (m_begin + 4 * mb) * Kc + cb[p];
 
     auto load_a = [&](int ks, auto setc) {
       constexpr int set = decltype(setc)::value;
+      if constexpr (BM < 128)
+        if (!a_on) return;
       if (ks < nfull) {
         const int64_t base = (int64_t)ks * 32 * Cout;
 #pragma unroll
@@ -538,6 +630,32 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
     };
     auto load_b = [&](int ks, auto setc) {
       constexpr int set = decltype(setc)::value;
+      if constexpr (CONV) {
+        // (n, ho, wo) of the first of the four consecutive output pixels by division, the others by carry
+        const int64_t r0 = m_begin + (int64_t)ks * 32 + 4 * mb;
+        const int hw = geo.Hg * geo.Wg;
+        const int rr = (int)(r0 < m_end ? r0 : m_end - 1);
+        int n = rr / hw, rem = rr - n * hw, ho = rem / geo.Wg, wo = rem - ho * geo.Wg;
+        unsigned bm = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool rowok = r0 + i < m_end;
+#pragma unroll
+          for (int p = 0; p < BP; ++p) {
+            const int hi = ho * geo.stride - geo.pad + kh[p], wi = wo * geo.stride - geo.pad + kw[p];
+            const bool ok = rowok && vb[p] && (unsigned)hi < (unsigned)geo.Hs && (unsigned)wi < (unsigned)geo.Ws;
+            const int64_t off = ok ? ((int64_t)((n * geo.Hs + hi) * geo.Ws + wi) * Kc + cb[p]) : (int64_t)cb[p];
+            bm |= (ok ? 1u : 0u) << (4 * p + i);
+            rx[set][p][i] = *reinterpret_cast<const f32x4*>(X + off);  // re-read by the neighbouring taps: cached
+          }
+          if (++wo == geo.Wg) {
+            wo = 0;
+            if (++ho == geo.Hg) { ho = 0; ++n; }
+          }
+        }
+        bmask[set] = bm;
+        return;
+      }
       if (ks < nfull) {
         const int64_t base = (int64_t)ks * 32 * Cin;
 #pragma unroll
@@ -560,15 +678,17 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
       unsigned char* S = wbase + (ks % RS) * 2 * kStride16;
       const int64_t row0 = m_begin + (int64_t)ks * 32 + 4 * mb;
       const bool masked = ks >= nfull;  // uniform
+      if constexpr (BM < 128)
+        if (!a_on) return;
 #pragma unroll
       for (int p = 0; p < AP; ++p) {
         f32x4 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = ga[p] * (rg[set][p][i] - gmean[p]) + gb[p] * (ry[set][p][i] - ymean[p]);
-        if (masked) {
+        if (masked || (CONV && !va[p])) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            if (row0 + i >= m_end) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the slice contribute nothing
+            if (row0 + i >= m_end || !va[p]) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the slice contribute nothing
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -585,10 +705,14 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
         f32x4 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          v[i] = sc[p] * (rx[set][p][i] - mu[p]) + be[p];
-          v[i].x = fmaxf(v[i].x, 0.f); v[i].y = fmaxf(v[i].y, 0.f); v[i].z = fmaxf(v[i].z, 0.f); v[i].w = fmaxf(v[i].w, 0.f);
+          if constexpr (CONV) {
+            v[i] = ((bmask[set] >> (4 * p + i)) & 1u) ? rx[set][p][i] * sb : f32x4{0.f, 0.f, 0.f, 0.f};
+          } else {
+            v[i] = sc[p] * (rx[set][p][i] - mu[p]) + be[p];
+            v[i].x = fmaxf(v[i].x, 0.f); v[i].y = fmaxf(v[i].y, 0.f); v[i].z = fmaxf(v[i].z, 0.f); v[i].w = fmaxf(v[i].w, 0.f);
+          }
         }
-        if (masked) {
+        if (!CONV && masked) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             if (row0 + i >= m_end) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -622,16 +746,21 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
     consume_tile16<BM, BN, RS>(lds, nks, wm, wn, r, h, acc);
     const float inv = 1.f / (sa * sb);
     float* dst = partial ? partial + (size_t)slice * Cout * Cin : dW;
+    const int taps = CONV ? Cin / Kc : 1;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = k0 + wn * (BN / 2) + j * 32 + r;
+      if (CONV && col >= Cin) continue;
+      const int tap = CONV ? col / Kc : 0, ci = col - tap * Kc;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = n0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (partial) dst[(size_t)row * Cin + col] = acc[i][j][e] * inv;
-          else atomicAdd(dst + (size_t)row * Cin + col, acc[i][j][e] * inv);
+          if (CONV && row >= Cout) continue;
+          float* q = dst + ((size_t)row * Kc + ci) * taps + tap;  // pointwise: [row][col]; convolution: [co][ci][tap]
+          if (partial) *q = acc[i][j][e] * inv;
+          else atomicAdd(q, acc[i][j][e] * inv);
         }
     }
   }
@@ -688,11 +817,11 @@ bool launch_f16_wgrad(const TG* g, const T* y, const float* bn_pw, const T* ydw,
   wgrad_slices(M, tiles, slices, rows);
   const dim3 grid(tiles, (unsigned)slices);
   if (!wide && Cout % 256 != 0)
-    hipLaunchKernelGGL((pw16_wgrad_k<128, 128, TTK_DW, T, TG>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
+    hipLaunchKernelGGL((pw16_wgrad_k<128, 128, TTK_DW, T, TG>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows, nullptr, ConvGeom{});
   else if (wide)
-    hipLaunchKernelGGL((pw16_wgrad_k<128, 256, TTK_DW, T, TG>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
+    hipLaunchKernelGGL((pw16_wgrad_k<128, 256, TTK_DW, T, TG>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows, nullptr, ConvGeom{});
   else  // (one register set: two spill)
-    hipLaunchKernelGGL((pw16_wgrad_k<256, 128, 1, T, TG>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows);
+    hipLaunchKernelGGL((pw16_wgrad_k<256, 128, 1, T, TG>), grid, dim3(512), 0, st, g, y, bn_pw, ydw, bn_dw, dw, partial, M, Cin, Cout, rows, nullptr, ConvGeom{});
   if (partial) {
     const int64_t n = (int64_t)Cin * Cout;
     hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, st, partial, dw, n, (int)slices);
@@ -743,15 +872,60 @@ bool launch_f16_gemm(const TO* A0, const T* A1, const float* bnA, const float* B
   }
   if (Nout >= 256 && Nout % 256 == 0) {
     const unsigned tiles = (unsigned)(ceil_div(M, 128) * (Nout / 256));
-    hipLaunchKernelGGL((pw16_k<128, 256, AM, EM, TTK_D, T, TO>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout);
+    hipLaunchKernelGGL((pw16_k<128, 256, AM, EM, TTK_D, T, TO>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, const_cast<float*>(bnE), part, M, K,
+                       Nout, nullptr, ConvGeom{});
     return true;
   }
   if (Nout == 128) {
     const unsigned tiles = (unsigned)ceil_div(M, 256);
     constexpr int D = (MODE == SMODE_DGRAD || TTK_D > 2) ? 1 : TTK_D;  // eight A rows per thread: more sets spill
-    hipLaunchKernelGGL((pw16_k<256, 128, AM, EM, D, T, TO>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout);
+    hipLaunchKernelGGL((pw16_k<256, 128, AM, EM, D, T, TO>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, const_cast<float*>(bnE), part, M, K,
+                       Nout, nullptr, ConvGeom{});
     return true;
   }
+  return false;
+}
+
+// dw[Cout][Kc][taps] += sum over output pixels of dy (x) gathered input activation (conv.hip)
+bool launch_conv_wgrad16(const float* g, const float* y, const float* bn, const float* a_in, const float* a_bound, float* dw, int64_t M,
+                         int Cout, int taps, const ConvGeom& geo, hipStream_t st) {
+  if (geo.Kc % 4 != 0 || Cout % 4 != 0) return false;
+  const int ncols = taps * geo.Kc;
+  const bool narrow = Cout <= 64;
+  const int tiles = (int)(ceil_div(Cout, narrow ? 64 : 128) * ceil_div(ncols, 256));
+  int64_t slices, rows;
+  wgrad_slices(M, tiles, slices, rows);
+  const dim3 grid(tiles, (unsigned)slices);
+  if (narrow)
+    hipLaunchKernelGGL((pw16_wgrad_k<64, 256, 1, float, float, true>), grid, dim3(512), 0, st, g, y, bn, a_in, nullptr, dw, nullptr, M, ncols, Cout,
+                       rows, a_bound, geo);
+  else
+    hipLaunchKernelGGL((pw16_wgrad_k<128, 256, 1, float, float, true>), grid, dim3(512), 0, st, g, y, bn, a_in, nullptr, dw, nullptr, M, ncols, Cout,
+                       rows, a_bound, geo);
+  return true;
+}
+
+// Implicit-GEMM convolution launches (conv.hip): Bq = two fp16 planes [K/32][Nout][32] (K = (tap, channel)) scaled by
+// pow2_scale(*wmax).  Nout a multiple of 64, geo.Kc a multiple of 32.
+bool launch_conv_gemm16(int amode, int emode, const float* A0, const float* A1, const float* bnA, const float* a_bound, const uint16_t* Bq,
+                        const float* wmax, float* out, const float* E0, float* bnE, float* part, int64_t M, int K, int Nout,
+                        const ConvGeom& geo, hipStream_t st) {
+#define TTK_CONV_LAUNCH(BM_, BN_, AM_, EM_)                                                                                        \
+  hipLaunchKernelGGL((pw16_k<BM_, BN_, AM_, EM_, 1, float, float, true>), dim3((unsigned)(ceil_div(M, BM_) * (Nout / BN_))), dim3(512), 0, st, \
+                     A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout, a_bound, geo)
+#define TTK_CONV_TILES(AM_, EM_)                                   \
+  do {                                                             \
+    if (Nout % 256 == 0) TTK_CONV_LAUNCH(128, 256, AM_, EM_);      \
+    else if (Nout % 128 == 0) TTK_CONV_LAUNCH(256, 128, AM_, EM_); \
+    else TTK_CONV_LAUNCH(256, 64, AM_, EM_);                       \
+    return true;                                                   \
+  } while (0)
+  if (Nout % 64 != 0 || geo.Kc % 32 != 0) return false;
+  if (amode == AMODE_PLAIN && emode == EMODE_STATS) TTK_CONV_TILES(AMODE_PLAIN, EMODE_STATS);
+  if (amode == AMODE_BNGRAD && emode == EMODE_MASK) TTK_CONV_TILES(AMODE_BNGRAD, EMODE_MASK);
+  if (amode == AMODE_BNGRAD && emode == EMODE_PLAIN) TTK_CONV_TILES(AMODE_BNGRAD, EMODE_PLAIN);
+#undef TTK_CONV_TILES
+#undef TTK_CONV_LAUNCH
   return false;
 }
 

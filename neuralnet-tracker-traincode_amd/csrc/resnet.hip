@@ -89,13 +89,14 @@ __global__ void __launch_bounds__(kBlock) stem7_fwd_k(const float* __restrict__ 
 
 // ---- max-pool 3x3 / stride 2 / pad 1 over relu(bn(y)); idx = window position (kh*3+kw) of the FIRST maximum, which is
 // what torch's max_pool2d backward routes the gradient to.  thread = (output pixel, channel quad).
-__global__ void __launch_bounds__(kBlock) maxpool_fwd_k(const float* __restrict__ y, const float* __restrict__ bnp,
+__global__ void __launch_bounds__(kBlock) maxpool_fwd_k(const float* __restrict__ y, float* __restrict__ bnp,
                                                          float* __restrict__ a, unsigned char* __restrict__ idx, int B, int H,
                                                          int W, int Ho, int Wo, int C) {
   const int quads = C >> 2;
   const int c4 = threadIdx.x & (quads - 1);
   const BnApply4 bn = BnApply4::load(bnp, C, 4 * c4);
   const int64_t items = (int64_t)B * Ho * Wo * quads;
+  float amax = 0.f;
   for (int64_t it = (int64_t)blockIdx.x * kBlock + threadIdx.x; it < items; it += (int64_t)gridDim.x * kBlock) {
     int64_t pix = it / quads;
     const int wo = (int)(pix % Wo), ho = (int)((pix / Wo) % Ho), n = (int)(pix / ((int64_t)Wo * Ho));
@@ -118,7 +119,9 @@ __global__ void __launch_bounds__(kBlock) maxpool_fwd_k(const float* __restrict_
     }
     st4(a + (size_t)it * 4, m);
     *reinterpret_cast<uchar4*>(idx + (size_t)it * 4) = am;
+    amax = fmaxf(amax, fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w)));
   }
+  wave_raise_max(bnp + (size_t)TTK_BN_AUX * C + TTK_AUX_ACT_BOUND, amax);  // the bound the consuming convolutions scale a by
 }
 
 // gradient w.r.t. the BatchNorm output of y (already through the ReLU mask) + that BatchNorm's backward sums.
@@ -165,7 +168,7 @@ __global__ void __launch_bounds__(kBlock) maxpool_bwd_k(const float* __restrict_
 }
 
 // a = relu(bn(y) + r), r = res (an activation) or res_bn(res) (a raw conv output, the downsample branch) or nothing
-__global__ void __launch_bounds__(kBlock) bn_add_act_k(const float* __restrict__ y, const float* __restrict__ bnp,
+__global__ void __launch_bounds__(kBlock) bn_add_act_k(const float* __restrict__ y, float* __restrict__ bnp,
                                                         const float* __restrict__ res, const float* __restrict__ res_bn,
                                                         float* __restrict__ a, int64_t items, int C) {
   const int quads = C >> 2;
@@ -173,12 +176,16 @@ __global__ void __launch_bounds__(kBlock) bn_add_act_k(const float* __restrict__
   const BnApply4 bn = BnApply4::load(bnp, C, 4 * c4);
   BnApply4 rb = bn;
   if (res_bn) rb = BnApply4::load(res_bn, C, 4 * c4);
+  float amax = 0.f;
   for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * kBlock) {
     const size_t off = (size_t)idx << 2;
     float4 v = bn.pre(ld4(y + off));
     if (res) v = add4(v, res_bn ? rb.pre(ld4(res + off)) : ld4(res + off));
-    st4(a + off, relu4(v));
+    v = relu4(v);
+    st4(a + off, v);
+    amax = fmaxf(amax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
   }
+  wave_raise_max(bnp + (size_t)TTK_BN_AUX * C + TTK_AUX_ACT_BOUND, amax);  // the bound the consuming convolutions scale a by
 }
 
 // gs = (ga (+ gb)) * [a > 0]: gradient w.r.t. s = bn(y) + r of a block whose output activation is a = relu(s).
@@ -186,8 +193,8 @@ __global__ void __launch_bounds__(kBlock) bn_add_act_k(const float* __restrict__
 // downsample branch's BatchNorm.
 __global__ void __launch_bounds__(kBlock) residual_bwd_k(const float* __restrict__ ga, const float* __restrict__ gb,
                                                           const float* __restrict__ a, const float* __restrict__ y,
-                                                          const float* __restrict__ bnp, const float* __restrict__ yd,
-                                                          const float* __restrict__ bnd, float* __restrict__ gs,
+                                                          float* __restrict__ bnp, const float* __restrict__ yd,
+                                                          float* __restrict__ bnd, float* __restrict__ gs,
                                                           float* __restrict__ part, float* __restrict__ partd, int64_t items,
                                                           int C) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -196,16 +203,21 @@ __global__ void __launch_bounds__(kBlock) residual_bwd_k(const float* __restrict
   const float4 mean = ld4(bnp + TTK_BN_MEAN * C + 4 * c4);
   const float4 meand = yd ? ld4(bnd + TTK_BN_MEAN * C + 4 * c4) : f4(0.f);
   float4 s1 = f4(0.f), s2 = f4(0.f), t2 = f4(0.f);
+  float gmx = 0.f;
   for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * kBlock) {
     const size_t off = (size_t)idx << 2;
     float4 gv = ld4(ga + off);
     if (gb) gv = add4(gv, ld4(gb + off));
     gv = mask4(gv, ld4(a + off));
     st4(gs + off, gv);
+    gmx = fmaxf(gmx, fmaxf(fmaxf(fabsf(gv.x), fabsf(gv.y)), fmaxf(fabsf(gv.z), fabsf(gv.w))));
     s1 = add4(s1, gv);
     s2 = fma4(gv, sub4(ld4(y + off), mean), s2);
     if (yd) t2 = fma4(gv, sub4(ld4(yd + off), meand), t2);
   }
+  // max |gs|: the bound behind the DY_BOUND of both BatchNorms this gradient flows into (ttk.h, TTK_AUX_GMAX)
+  wave_raise_max(bnp + (size_t)TTK_BN_AUX * C + TTK_AUX_GMAX, gmx);
+  if (yd) wave_raise_max(bnd + (size_t)TTK_BN_AUX * C + TTK_AUX_GMAX, gmx);
   block_channel_partials<1024>(s1, s2, c4, C, part + (size_t)blockIdx.x * 2 * C, smem);
   if (yd) {
     __syncthreads();
@@ -241,7 +253,7 @@ int ttk_stem7_bwd_weight(const float* g, const float* y, const float* bn, const 
   TTK_LAUNCH_CHECK("stem7_bwd_weight");
 }
 
-int ttk_maxpool3x3s2_fwd(const float* y, const float* bn, float* a, unsigned char* idx, int B, int H, int W, int C,
+int ttk_maxpool3x3s2_fwd(const float* y, float* bn, float* a, unsigned char* idx, int B, int H, int W, int C,
                          ttk_stream_t stream) {
   TTK_REQUIRE(y && bn && a && idx, "maxpool3x3s2_fwd: null pointer");
   TTK_REQUIRE(B > 0 && H > 1 && W > 1 && ew_shape_ok(1, C), "maxpool3x3s2_fwd: unsupported shape");
@@ -264,7 +276,7 @@ int ttk_maxpool3x3s2_bwd(const float* ga, const float* gb, const unsigned char* 
   TTK_LAUNCH_CHECK("maxpool3x3s2_bwd");
 }
 
-int ttk_bn_add_act(const float* y, const float* bn, const float* res, const float* res_bn, float* a, int64_t rows, int C,
+int ttk_bn_add_act(const float* y, float* bn, const float* res, const float* res_bn, float* a, int64_t rows, int C,
                    ttk_stream_t stream) {
   TTK_REQUIRE(y && bn && a && (res || !res_bn), "bn_add_act: bad arguments");
   TTK_REQUIRE(ew_shape_ok(rows, C), "bn_add_act: unsupported shape rows=%lld C=%d", (long long)rows, C);
@@ -275,8 +287,8 @@ int ttk_bn_add_act(const float* y, const float* bn, const float* res, const floa
   TTK_LAUNCH_CHECK("bn_add_act");
 }
 
-int ttk_residual_bwd(const float* ga, const float* gb, const float* a, const float* y, const float* bn, const float* yd,
-                     const float* bnd, float* gs, float* part, float* partd, int64_t rows, int C, ttk_stream_t stream) {
+int ttk_residual_bwd(const float* ga, const float* gb, const float* a, const float* y, float* bn, const float* yd,
+                     float* bnd, float* gs, float* part, float* partd, int64_t rows, int C, ttk_stream_t stream) {
   TTK_REQUIRE(ga && a && y && bn && gs && part, "residual_bwd: null pointer");
   TTK_REQUIRE((yd == nullptr) == (bnd == nullptr) && (yd == nullptr) == (partd == nullptr), "residual_bwd: yd, bnd, partd go together");
   TTK_REQUIRE(ew_shape_ok(rows, C), "residual_bwd: unsupported shape");

@@ -55,6 +55,16 @@ __host__ __device__ inline float pow2_scale(float bound) {
   return b.f;
 }
 
+// Raises the non-negative float at *slot (ordered like its bit pattern; zeroed once per step) to the maximum of v over
+// the wavefront.  The read keeps the atomic off the common path (the slot is almost always already larger).
+__device__ __forceinline__ void wave_raise_max(float* slot, float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  unsigned* u = reinterpret_cast<unsigned*>(slot);
+  if ((threadIdx.x & 63) == 0 && __float_as_uint(v) > __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(u, __float_as_uint(v));
+}
+
 // Deterministic reductions: producers store their partial results row by row (partial[r][n]) instead of adding them
 // atomically, and this kernel folds the rows in a fixed order:  out[i] (+)= partial[0][i] + partial[1][i] + ...
 template <int kDummy = 0>

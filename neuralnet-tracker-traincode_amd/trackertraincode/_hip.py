@@ -41,9 +41,9 @@ _SIGNATURES = {
     "ttk_bn_add_act": [_P, _P, _P, _P, _P, _L, _I],
     "ttk_residual_bwd": [_P] * 10 + [_L, _I],
     "ttk_conv_weight_repack": [_P, _P, _P, _I, _I, _I, _I],
-    "ttk_conv_fwd": [_P, _P, _P, _P] + [_I] * 9,
+    "ttk_conv_fwd": [_P, _P, _P, _P, _P] + [_I] * 9,
     "ttk_conv_bwd_data": [_P] * 8 + [_I] * 9,
-    "ttk_conv_bwd_weight": [_P] * 5 + [_I] * 9,
+    "ttk_conv_bwd_weight": [_P] * 6 + [_I] * 9,
     "ttk_heads_fwd": [_P] * 8 + [_I] * 7 + [_P] * 9,
     "ttk_heads_bwd": [_P] * 8 + [_I] * 7 + [_P] * 15,
     "ttk_diag_scale_fwd": [_P, _P, _I],
@@ -83,7 +83,7 @@ _SIGNATURES = {
     "ttk_clip_adam": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P],
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class _Library:

@@ -8,7 +8,8 @@ restated from torchvision.models.resnet.  The module tree keeps torchvision's na
 
 CUDA tensors in training mode run hand-written HIP kernels through the C-ABI (include/ttk.h): the 7x7 stem, the
 max-pool and the residual/BatchNorm elementwise passes in csrc/resnet.hip, every dense 3x3 / strided 1x1 convolution
-as an implicit GEMM on the split-bf16 producer/consumer kernel (csrc/conv.hip, csrc/pwconv_split.hip).  Activations
+as an implicit GEMM on the fp16-split producer/consumer kernels (csrc/conv.hip, csrc/pwconv_f16.hip; operand magnitude
+bounds travel in row TTK_BN_AUX of the BatchNorm blocks, which therefore come from one zeroed arena per step).  Activations
 are channels-last and materialised (post BatchNorm/ReLU); BatchNorm statistics follow the partial-sum -> fp64 finalize
 scheme of the MobileNet backbone.  `use_blurpool=True` (reference :33-50,63-66) is not built.
 """
@@ -45,8 +46,15 @@ class BasicBlock(nn.Module):
         return self.relu(out + identity)
 
 
-def _bn_work(C, device):
-    return torch.empty((_BN_ROWS, C), dtype=torch.float32, device=device)
+_BN_AUX = 7  # TTK_BN_AUX: [0] = TTK_AUX_ACT_BOUND of the activation this BatchNorm forms
+
+
+def _bn_channels():
+    out, cin = [64], 64
+    for planes, stride in _PLAN:
+        out += [planes, planes] + ([planes] if stride != 1 or cin != planes else [])
+        cin = planes
+    return out
 
 
 class _Ctx:
@@ -55,7 +63,7 @@ class _Ctx:
 
 class _Blk:
     """What one BasicBlock leaves behind for backward."""
-    __slots__ = ("a_in", "y1", "bn1", "a_mid", "y2", "bn2", "yd", "bnd", "a_out", "h", "ho", "cin", "cout", "stride", "w1b", "w2b")
+    __slots__ = ("a_in", "a_bn", "y1", "bn1", "a_mid", "y2", "bn2", "yd", "bnd", "a_out", "h", "ho", "cin", "cout", "stride", "w1b", "w2b")
 
 
 def _part_buffers(B, device):
@@ -81,8 +89,13 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
     c.part, c.partd = _part_buffers(B, dev)
     part = c.part
     new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-    newq = lambda *s: torch.empty((3,) + s, dtype=torch.int16, device=dev)  # pre-split (3 bf16 piece planes) weight operands
+    newq = lambda *s: torch.empty((3,) + s, dtype=torch.int16, device=dev)  # pre-split weight operands (2 fp16 planes + header | 3 bf16 planes)
     bi = [0]
+    # every BatchNorm block of the step from one zeroed allocation (the kernels raise the bounds of row TTK_BN_AUX with atomicMax)
+    from .mobilenet_v1 import _BnArena
+    arena = _BnArena(_bn_channels(), dev)
+    _bn_work = lambda C, _dev: arena.take(C)
+    bound = lambda bn: p(bn[_BN_AUX])  # device float: bound of the activation formed from this BatchNorm
 
     def finalize(bn, rows, C, count, gamma, beta, scratch=None):
         rm, rv, nbt = buffers[3 * bi[0]: 3 * bi[0] + 3]
@@ -104,21 +117,21 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
     c.idx = torch.empty((B, h, h, 64), dtype=torch.uint8, device=dev)
     L.call("ttk_maxpool3x3s2_fwd", p(c.y0), p(c.bn0), p(c.a1), p(c.idx), B, Ho, Ho, 64)
 
-    a_in, cin, pi = c.a1, 64, 3
+    a_in, a_bn, cin, pi = c.a1, c.bn0, 64, 3
     c.blocks = []
     for bidx, (planes, stride) in enumerate(_PLAN):
         has_ds = stride != 1 or cin != planes
         w1, g1, b1, w2, g2, b2 = params[pi:pi + 6]
         pi += 6
         k = _Blk()
-        k.a_in, k.h, k.cin, k.cout, k.stride = a_in, h, cin, planes, stride
+        k.a_in, k.a_bn, k.h, k.cin, k.cout, k.stride = a_in, a_bn, h, cin, planes, stride
         ho = (h - 1) // stride + 1
         k.ho = ho
         M = B * ho * ho
         w1f, k.w1b = newq(9, planes, cin), newq(9, cin, planes)
         L.call("ttk_conv_weight_repack", p(w1), p(w1f), p(k.w1b), planes, cin, 3, 3)
         k.y1 = new(B, ho, ho, planes)
-        L.call("ttk_conv_fwd", p(a_in), p(w1f), p(k.y1), p(part), B, h, h, cin, planes, 3, 3, stride, 1)
+        L.call("ttk_conv_fwd", p(a_in), bound(a_bn), p(w1f), p(k.y1), p(part), B, h, h, cin, planes, 3, 3, stride, 1)
         k.bn1 = _bn_work(planes, dev)
         finalize(k.bn1, L.partial_rows_gemm(M), planes, M, g1, b1)
         k.a_mid = new(B, ho, ho, planes)
@@ -126,7 +139,7 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
         w2f, k.w2b = newq(9, planes, planes), newq(9, planes, planes)
         L.call("ttk_conv_weight_repack", p(w2), p(w2f), p(k.w2b), planes, planes, 3, 3)
         k.y2 = new(B, ho, ho, planes)
-        L.call("ttk_conv_fwd", p(k.a_mid), p(w2f), p(k.y2), p(part), B, ho, ho, planes, planes, 3, 3, 1, 1)
+        L.call("ttk_conv_fwd", p(k.a_mid), bound(k.bn1), p(w2f), p(k.y2), p(part), B, ho, ho, planes, planes, 3, 3, 1, 1)
         k.bn2 = _bn_work(planes, dev)
         finalize(k.bn2, L.partial_rows_gemm(M), planes, M, g2, b2)
         k.yd = k.bnd = None
@@ -136,14 +149,14 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
             wdf = newq(1, planes, cin)
             L.call("ttk_conv_weight_repack", p(wd), p(wdf), None, planes, cin, 1, 1)
             k.yd = new(B, ho, ho, planes)
-            L.call("ttk_conv_fwd", p(a_in), p(wdf), p(k.yd), p(part), B, h, h, cin, planes, 1, 1, stride, 0)
+            L.call("ttk_conv_fwd", p(a_in), bound(a_bn), p(wdf), p(k.yd), p(part), B, h, h, cin, planes, 1, 1, stride, 0)
             k.bnd = _bn_work(planes, dev)
             finalize(k.bnd, L.partial_rows_gemm(M), planes, M, gd, bd)
         last = bidx == len(_PLAN) - 1
         if not last:  # the last block's output is only pooled: relu(bn2(y2) + identity) is formed inside the pooling kernel
             k.a_out = new(B, ho, ho, planes)
             L.call("ttk_bn_add_act", p(k.y2), p(k.bn2), p(k.yd if has_ds else a_in), p(k.bnd) if has_ds else None, p(k.a_out), M, planes)
-            a_in = k.a_out
+            a_in, a_bn = k.a_out, k.bn2
         else:
             k.a_out = None
         c.blocks.append(k)
@@ -164,6 +177,7 @@ def _backward_impl(c: _Ctx, gfeat, params):
     B, part, partd = c.B, c.part, c.partd
     dev = gfeat.device
     new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    bound = lambda bn: p(bn[_BN_AUX])
     # one zeroed arena for every parameter gradient (the weight-gradient kernels accumulate atomically): one fill launch,
     # and contiguous ranges that a data-parallel all-reduce can take in place
     offs, total = [], 0
@@ -204,16 +218,16 @@ def _backward_impl(c: _Ctx, gfeat, params):
         if has_ds:
             bwd_finalize(k.bnd, rows_gs, C, M, pi + 7, scratch=partd)
         # conv2: weight gradient, then data gradient through relu(bn1(y1)) (+ bn1 sums)
-        L.call("ttk_conv_bwd_weight", p(gs), p(k.y2), p(k.bn2), p(k.a_mid), p(grads[pi + 3]), B, k.ho, k.ho, C, C, 3, 3, 1, 1)
+        L.call("ttk_conv_bwd_weight", p(gs), p(k.y2), p(k.bn2), p(k.a_mid), bound(k.bn1), p(grads[pi + 3]), B, k.ho, k.ho, C, C, 3, 3, 1, 1)
         g1 = new(B, k.ho, k.ho, C)
         L.call("ttk_conv_bwd_data", p(gs), p(k.y2), p(k.bn2), p(k.w2b), p(k.y1), p(k.bn1), p(g1), p(part), B, k.ho, k.ho, C, C, 3, 3, 1, 1)
         bwd_finalize(k.bn1, L.partial_rows_gemm(M), C, M, pi + 1)
         # conv1: weight gradient, raw data gradient w.r.t. the block input
-        L.call("ttk_conv_bwd_weight", p(g1), p(k.y1), p(k.bn1), p(k.a_in), p(grads[pi]), B, k.h, k.h, k.cin, C, 3, 3, k.stride, 1)
+        L.call("ttk_conv_bwd_weight", p(g1), p(k.y1), p(k.bn1), p(k.a_in), bound(k.a_bn), p(grads[pi]), B, k.h, k.h, k.cin, C, 3, 3, k.stride, 1)
         g_in = new(B, k.h, k.h, k.cin)
         L.call("ttk_conv_bwd_data", p(g1), p(k.y1), p(k.bn1), p(k.w1b), None, None, p(g_in), None, B, k.h, k.h, k.cin, C, 3, 3, k.stride, 1)
         if has_ds:
-            L.call("ttk_conv_bwd_weight", p(gs), p(k.yd), p(k.bnd), p(k.a_in), p(grads[pi + 6]), B, k.h, k.h, k.cin, C, 1, 1, k.stride, 0)
+            L.call("ttk_conv_bwd_weight", p(gs), p(k.yd), p(k.bnd), p(k.a_in), bound(k.a_bn), p(grads[pi + 6]), B, k.h, k.h, k.cin, C, 1, 1, k.stride, 0)
             wdb = torch.empty((3, 1, k.cin, C), dtype=torch.int16, device=dev)
             L.call("ttk_conv_weight_repack", p(params[pi + 6]), None, p(wdb), C, k.cin, 1, 1)
             g_sc = new(B, k.h, k.h, k.cin)

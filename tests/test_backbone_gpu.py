@@ -126,7 +126,7 @@ def test_entry_points_reject_bad_arguments():
     with pytest.raises(RuntimeError, match="dwconv3x3_fwd"):
         L.call("ttk_dwconv3x3_fwd", p(t), p(t), None, None, p(t), p(t), None, 1, 8, 8, 32, 3, 0)  # stride 3
     with pytest.raises(RuntimeError, match="conv_fwd"):
-        L.call("ttk_conv_fwd", p(t), p(t), p(t), p(t), 1, 8, 8, 64, 64, 5, 5, 1, 2)  # 5x5 is not a ResNet18 conv
+        L.call("ttk_conv_fwd", p(t), p(t), p(t), p(t), p(t), 1, 8, 8, 64, 64, 5, 5, 1, 2)  # 5x5 is not a ResNet18 conv
     with pytest.raises(RuntimeError, match="heads_fwd"):
         L.call("ttk_heads_fwd", p(t), p(t), p(t), None, None, None, None, None, 4, 1024, 7, 0, 0, 0, 0, p(t), p(t), p(t), p(t), p(t), None, None,
                None, None)  # NZ does not match the configuration

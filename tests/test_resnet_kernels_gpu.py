@@ -90,6 +90,7 @@ def test_maxpool(B, H, C):
     L.call("ttk_maxpool3x3s2_fwd", p(d_y), p(d_bn), p(a), p(idx), B, H, H, C)
     torch.cuda.synchronize()
     np.testing.assert_allclose(a.cpu().numpy(), a64.detach().permute(0, 2, 3, 1).numpy(), rtol=1e-6, atol=1e-6)
+    assert float(d_bn[7, 0]) == float(a.max())  # TTK_AUX_ACT_BOUND: what the first residual block's convolutions scale by
     ga, gb = rng.normal(0, 1, (B, Ho, Ho, C)).astype(np.float32), rng.normal(0, 1, (B, Ho, Ho, C)).astype(np.float32)
     (gs_ref,) = torch.autograd.grad(a64, s64, torch.from_numpy(ga + gb).double().permute(0, 3, 1, 2))
     gs_ref = gs_ref.permute(0, 2, 3, 1).numpy()
@@ -119,6 +120,7 @@ def test_bn_add_act_and_residual_bwd(rows, C):
         L.call("ttk_bn_add_act", p(d_y), p(d_bn), p(res), p(res_bn), p(out), rows, C)
         torch.cuda.synchronize()
         np.testing.assert_allclose(out.cpu().numpy(), np.maximum(ref, 0), rtol=1e-5, atol=1e-6)
+        assert float(d_bn[7, 0]) >= float(out.max())  # TTK_AUX_ACT_BOUND raised to the maximum of what was written
     ga, gb = rng.normal(0, 1, (rows, C)).astype(np.float32), rng.normal(0, 1, (rows, C)).astype(np.float32)
     d_ga, d_gb = t(ga), t(gb)
     prow = L.partial_rows_elementwise(rows * (C // 4))
@@ -130,6 +132,7 @@ def test_bn_add_act_and_residual_bwd(rows, C):
     np.testing.assert_allclose(gs.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
     _sums_close(part, ref, y - bn[BN_MEAN])
     _sums_close(partd, ref, yd - bnd[BN_MEAN])
+    assert float(d_bn[7, 2]) == float(d_bnd[7, 2]) == float(gs.abs().max())  # TTK_AUX_GMAX of both BatchNorms
     L.call("ttk_residual_bwd", p(d_ga), None, p(d_act), p(d_y), p(d_bn), None, None, p(gs), p(part), None, rows, C)
     torch.cuda.synchronize()
     np.testing.assert_allclose(gs.cpu().numpy(), ga * (act > 0), rtol=1e-6, atol=1e-6)
