@@ -16,8 +16,14 @@ enum { EMODE_STATS = 0, EMODE_MASK = 1, EMODE_PLAIN = 2 };
 // source pixel   forward:    (gh*stride - pad + kh, gw*stride - pad + kw)            [grid = output, source = input]
 //                transposed: ((gh + pad - kh)/stride, (gw + pad - kw)/stride) if divisible  [grid = input, source = output]
 // of a [n][Hs][Ws][Kc] tensor, or contributes zero outside it.  The B operand is [tap][Nout][Kc].
+// Parity classes (par = 1; fp16 kernels, transposed stride-2 only): a grid pixel (gh, gw) of a stride-2 data gradient is
+// reached by the taps with kh = gh + pad (mod 2) only - 1, 2, 2 or 4 of the 9 taps of a 3x3 kernel, one of the four
+// classes of a strided 1x1 kernel - so the launch enumerates the pixels class by class ((gh & 1, gw & 1) = (1,1), (1,0),
+// (0,1), (0,0): longest contraction first) and every tile contracts over its class's taps only.  ctile[c] = first tile
+// of class c, nimg = images (the rows of class c are nimg x its pixels).
 struct ConvGeom {
   int Hs, Ws, Hg, Wg, stride, pad, KW, Kc, transposed;
+  int par, nimg, ctile[4];
 };
 
 // TTK_GEMM=f32mfma keeps every pointwise conv on v_mfma_f32_32x32x2_f32, bf16x3 selects the 3-piece bf16 split (A/B

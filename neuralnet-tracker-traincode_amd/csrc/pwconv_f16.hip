@@ -206,13 +206,28 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
   // XCD-aware tile order (see pwconv.hip): every XCD gets a contiguous range of tiles.
   const unsigned G = gridDim.x, Lid = blockIdx.x, NB = Nout / BN;
   const unsigned xq = G / 8, xr = G % 8, xcd = Lid % 8;
-  const unsigned tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + Lid / 8;
+  unsigned tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + Lid / 8;
+  const int Kc = GATHER ? geo.Kc : K;  // channels per tap
+  int nks = K / 32;
+  // parity classes of a stride-2 data gradient (conv_geom.h): this tile's class, its pixel grid and tap set
+  int ph = 0, pw = 0, Hc = geo.Hg, Wc = geo.Wg, nkw = 1;
+  const bool classes = GATHER && geo.par;
+  if (classes) {
+    tile = Lid;  // round-robin over the XCDs: every XCD gets a mix of long and short classes
+    const int c = tile >= (unsigned)geo.ctile[2] ? (tile >= (unsigned)geo.ctile[3] ? 3 : 2) : (tile >= (unsigned)geo.ctile[1] ? 1 : 0);
+    tile -= geo.ctile[c];
+    ph = c < 2;
+    pw = !(c & 1);
+    Hc = (geo.Hg - ph + 1) >> 1;
+    Wc = (geo.Wg - pw + 1) >> 1;
+    M = (int64_t)geo.nimg * Hc * Wc;
+    nkw = geo.KW == 3 && pw ? 2 : 1;
+    nks = (geo.KW == 3 && ph ? 2 : 1) * nkw * (Kc / 32);
+  }
   const unsigned bx = tile % NB, by = tile / NB;
   const int64_t m0 = (int64_t)by * BM;
   const int n0 = bx * BN;
-  const int nks = K / 32;
   const bool producer = __builtin_amdgcn_readfirstlane(tid) >= 256;
-  const int Kc = GATHER ? geo.Kc : K;  // channels per tap
   const float sa = pow2_scale(AMODE == AMODE_PLAIN ? *a_bound
                                                    : bnA[(size_t)TTK_BN_AUX * Kc + (AMODE == AMODE_BNRELU ? TTK_AUX_ACT_BOUND : TTK_AUX_DY_BOUND)]);
   const float sb = pow2_scale(*wmax);
@@ -238,14 +253,15 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
         arow[i] = (row < M ? row : M - 1) * (int64_t)K + kq8 * 4;  // clamp: rows past M are computed but never stored
       }
     } else {
-      const int hw = geo.Hg * geo.Wg;
+      const int hw = Hc * Wc;
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
         const int64_t row = m0 + row0 + 32 * i;
         const int rr = (int)(row < M ? row : M - 1);
         const int n = rr / hw, rem = rr - n * hw;
-        gh[i] = rem / geo.Wg;
-        gw[i] = rem - gh[i] * geo.Wg;
+        gh[i] = rem / Wc;
+        gw[i] = rem - gh[i] * Wc;
+        if (classes) { gh[i] = 2 * gh[i] + ph; gw[i] = 2 * gw[i] + pw; }
         gbase[i] = row < M ? n * geo.Hs * geo.Ws : -1;
       }
     }
@@ -261,7 +277,12 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
 #if defined(TTK_EXP) && (TTK_EXP == 2 || TTK_EXP == 6)
       if (ks >= D) return;  // timing experiment: A is loaded for the first steps only
 #endif
-      const int tap = GATHER ? ks / kpt : 0, kc0 = (ks - tap * kpt) * 32;
+      const int tapc = GATHER ? ks / kpt : 0, kc0 = (ks - tapc * kpt) * 32;
+      int tap = tapc;
+      if (classes) {  // the class's tap number -> (kh, kw): kh = 1 | {0, 2} for even | odd rows of a 3x3 kernel, 0 for 1x1
+        const int jh = tapc / nkw, jw = tapc - jh * nkw;
+        tap = (geo.KW == 3 ? (ph ? 2 * jh : 1) * 3 + (pw ? 2 * jw : 1) : 0);
+      }
       if constexpr (!GATHER) {
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
@@ -308,7 +329,13 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
 #if defined(TTK_EXP) && (TTK_EXP == 3 || TTK_EXP == 6)
       if (ks >= D) return;  // timing experiment
 #endif
-      const uint16_t* b = bp + (int64_t)ks * Nout * 32;
+      int kb = ks;  // k32 step of the weight operand
+      if (classes) {
+        const int tapc = ks / kpt, jh = tapc / nkw, jw = tapc - jh * nkw;
+        const int tap = (geo.KW == 3 ? (ph ? 2 * jh : 1) * 3 + (pw ? 2 * jw : 1) : 0);
+        kb = tap * kpt + (ks - tapc * kpt);
+      }
+      const uint16_t* b = bp + (int64_t)kb * Nout * 32;
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -459,7 +486,11 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
     if (grow >= M) break;
     float4 v = ld4(Cs + row * LDC + 4 * c4);
     v = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
-    const size_t o = (size_t)grow * Nout + col;
+    size_t o = (size_t)grow * Nout + col;
+    if (classes) {  // class-local row -> pixel
+      const int rr = (int)grow, hw = Hc * Wc, n = rr / hw, rem = rr - n * hw, ch = rem / Wc, cw = rem - ch * Wc;
+      o = ((size_t)(n * geo.Hg + 2 * ch + ph) * geo.Wg + 2 * cw + pw) * Nout + col;
+    }
     if constexpr (EMODE == EMODE_PLAIN) {
       Act<TO>::st(out + o, Act<TO>::round(v));
     } else if constexpr (EMODE == EMODE_STATS) {
@@ -517,6 +548,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __restrict__ bn_pw,
              const T* __restrict__ X, const float* __restrict__ bn_x, float* __restrict__ dW, float* __restrict__ partial,
              int64_t M, int Cin, int Cout, int64_t rows_per_slice, const float* __restrict__ x_bound, ConvGeom geo) {
+  static_assert(!CONV || D == 1, "the convolution producers carry their pixel from step to step");
   static_assert((BM + BN == 384 && (BM == 128 || BM == 256)) || (BM == 128 && BN == 128) || (CONV && BM == 64 && BN == 256),
                 "128x256, 256x128, 128x128 or (convolutions) 64x256");
   constexpr int RS = TTK_RS;
@@ -601,9 +633,30 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
     }
 #pragma unroll
     for (int p = 0; p < BP; ++p) xp[p] = X + (m_begin + 4 * mb) * Kc + cb[p];
+    // convolutions: output pixel (pn, pho, pwo) of this thread's first row of the next step, the step increments, the
+    // per-column-group offset of the tap, the rows left in the slice
+    int pn = 0, pho = 0, pwo = 0, dn32 = 0, dh32 = 0, dw32 = 0, prows = 0, tapoff[BP];
+    if constexpr (CONV) {
+      const int64_t r0 = m_begin + 4 * mb;
+      const int hw = geo.Hg * geo.Wg;
+      pn = (int)(r0 / hw);
+      const int rem = (int)(r0 - (int64_t)pn * hw);
+      pho = rem / geo.Wg;
+      pwo = rem - pho * geo.Wg;
+      const int q32 = 32 / geo.Wg;
+      dw32 = 32 - q32 * geo.Wg;
+      dn32 = q32 / geo.Hg;
+      dh32 = q32 - dn32 * geo.Hg;
+      prows = (int)(m_end - r0);
+#pragma unroll
+      for (int p = 0; p < BP; ++p) tapoff[p] = (kh[p] * geo.Ws + kw[p]) * Kc + cb[p];
+    }
 
     auto load_a = [&](int ks, auto setc) {
       constexpr int set = decltype(setc)::value;
+#if defined(TTK_EXP) && (TTK_EXP == 11)
+      if (ks >= 1) return;  // timing experiment: the A operand is loaded for the first step only
+#endif
       if constexpr (BM < 128)
         if (!a_on) return;
       if (ks < nfull) {
@@ -630,30 +683,47 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
     };
     auto load_b = [&](int ks, auto setc) {
       constexpr int set = decltype(setc)::value;
+#if defined(TTK_EXP) && (TTK_EXP == 12)
+      if (ks >= 1) return;  // timing experiment: the B operand is loaded for the first step only
+#endif
       if constexpr (CONV) {
-        // (n, ho, wo) of the first of the four consecutive output pixels by division, the others by carry
-        const int64_t r0 = m_begin + (int64_t)ks * 32 + 4 * mb;
-        const int hw = geo.Hg * geo.Wg;
-        const int rr = (int)(r0 < m_end ? r0 : m_end - 1);
-        int n = rr / hw, rem = rr - n * hw, ho = rem / geo.Wg, wo = rem - ho * geo.Wg;
+        // The producers' instruction count IS this kernel's speed (a first version with two divisions per step,
+        // 64-bit offsets and branches for the carries ran at 10 k cycles per step, 6 x the MFMA time): the pixel of
+        // the thread's first row is carried from step to step (the calls come in step order, D == 1), the other three
+        // rows by branch-free carries, the offsets are 32-bit (the host checks the tensor size) and split into a
+        // per-row part and a per-column-group constant.
         unsigned bm = 0u;
+        int wo = pwo, ho = pho, n = pn;
+        const int left = prows - ks * 32;  // rows of the slice from this thread's first row of the step on
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const bool rowok = r0 + i < m_end;
+          const int hr = ho * geo.stride - geo.pad, wr = wo * geo.stride - geo.pad;
+          const int base = ((n * geo.Hs + hr) * geo.Ws + wr) * Kc;
 #pragma unroll
           for (int p = 0; p < BP; ++p) {
-            const int hi = ho * geo.stride - geo.pad + kh[p], wi = wo * geo.stride - geo.pad + kw[p];
-            const bool ok = rowok && vb[p] && (unsigned)hi < (unsigned)geo.Hs && (unsigned)wi < (unsigned)geo.Ws;
-            const int64_t off = ok ? ((int64_t)((n * geo.Hs + hi) * geo.Ws + wi) * Kc + cb[p]) : (int64_t)cb[p];
+            const bool ok = i < left && vb[p] && (unsigned)(hr + kh[p]) < (unsigned)geo.Hs && (unsigned)(wr + kw[p]) < (unsigned)geo.Ws;
+            const unsigned off = ok ? (unsigned)(base + tapoff[p]) : (unsigned)cb[p];
             bm |= (ok ? 1u : 0u) << (4 * p + i);
-            rx[set][p][i] = *reinterpret_cast<const f32x4*>(X + off);  // re-read by the neighbouring taps: cached
+            // re-read by the neighbouring taps: cached loads
+            rx[set][p][i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(X) + (size_t)(off * 4u));
           }
-          if (++wo == geo.Wg) {
-            wo = 0;
-            if (++ho == geo.Hg) { ho = 0; ++n; }
-          }
+          ++wo;
+          const bool cw = wo == geo.Wg;
+          wo = cw ? 0 : wo;
+          ho += cw;
+          const bool ch = ho == geo.Hg;
+          ho = ch ? 0 : ho;
+          n += ch;
         }
         bmask[set] = bm;
+        // 32 rows on: 32 = (dn32 * Hg + dh32) * Wg + dw32
+        pwo += dw32;
+        const bool cw = pwo >= geo.Wg;
+        pwo -= cw ? geo.Wg : 0;
+        pho += dh32 + cw;
+        const bool ch = pho >= geo.Hg;
+        pho -= ch ? geo.Hg : 0;
+        pn += dn32 + ch;
         return;
       }
       if (ks < nfull) {
@@ -678,6 +748,9 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
       unsigned char* S = wbase + (ks % RS) * 2 * kStride16;
       const int64_t row0 = m_begin + (int64_t)ks * 32 + 4 * mb;
       const bool masked = ks >= nfull;  // uniform
+#if defined(TTK_EXP) && (TTK_EXP == 13)
+      if (ks >= 1) return;  // timing experiment: no conversion / LDS writes
+#endif
       if constexpr (BM < 128)
         if (!a_on) return;
 #pragma unroll
@@ -700,6 +773,9 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
       unsigned char* S = wbase + (ks % RS) * 2 * kStride16 + 2 * APL;
       const int64_t row0 = m_begin + (int64_t)ks * 32 + 4 * mb;
       const bool masked = ks >= nfull;  // uniform
+#if defined(TTK_EXP) && (TTK_EXP == 13)
+      if (ks >= 1) return;  // timing experiment
+#endif
 #pragma unroll
       for (int p = 0; p < BP; ++p) {
         f32x4 v[4];
@@ -890,6 +966,8 @@ bool launch_f16_gemm(const TO* A0, const T* A1, const float* bnA, const float* B
 bool launch_conv_wgrad16(const float* g, const float* y, const float* bn, const float* a_in, const float* a_bound, float* dw, int64_t M,
                          int Cout, int taps, const ConvGeom& geo, hipStream_t st) {
   if (geo.Kc % 4 != 0 || Cout % 4 != 0) return false;
+  const int64_t nimg = M / ((int64_t)geo.Hg * geo.Wg);
+  if (nimg * geo.Hs * geo.Ws * geo.Kc >= (int64_t)1 << 29) return false;  // 32-bit byte offsets into a_in (with the halo's slack)
   const int ncols = taps * geo.Kc;
   const bool narrow = Cout <= 64;
   const int tiles = (int)(ceil_div(Cout, narrow ? 64 : 128) * ceil_div(ncols, 256));
@@ -910,9 +988,31 @@ bool launch_conv_wgrad16(const float* g, const float* y, const float* bn, const 
 bool launch_conv_gemm16(int amode, int emode, const float* A0, const float* A1, const float* bnA, const float* a_bound, const uint16_t* Bq,
                         const float* wmax, float* out, const float* E0, float* bnE, float* part, int64_t M, int K, int Nout,
                         const ConvGeom& geo, hipStream_t st) {
+  ConvGeom gq = geo;
+  gq.par = 0;
+  // stride-2 data gradients without a masked epilogue (ResNet: every strided one): parity classes (conv_geom.h)
+  const bool classes = geo.transposed && geo.stride == 2 && emode == EMODE_PLAIN && (geo.KW == 3 || geo.KW == 1);
+  if (classes && geo.KW == 1)  // a strided 1x1 kernel reaches the (even, even) pixels only
+    (void)hipMemsetAsync(out, 0, (size_t)M * Nout * sizeof(float), st);
+  auto grid_of = [&](int bm, int bn) -> unsigned {
+    if (!classes) return (unsigned)(ceil_div(M, bm) * (Nout / bn));
+    gq.par = 1;
+    gq.nimg = (int)(M / ((int64_t)geo.Hg * geo.Wg));
+    int t = 0;
+    for (int c = 0; c < 4; ++c) {
+      const int ph = c < 2, pw = !(c & 1);
+      const int64_t mc = (int64_t)gq.nimg * ((geo.Hg - ph + 1) >> 1) * ((geo.Wg - pw + 1) >> 1);
+      gq.ctile[c] = t;
+      if (geo.KW == 3 || c == 3) t += (int)(ceil_div(mc, bm) * (Nout / bn));
+    }
+    return (unsigned)t;
+  };
 #define TTK_CONV_LAUNCH(BM_, BN_, AM_, EM_)                                                                                        \
-  hipLaunchKernelGGL((pw16_k<BM_, BN_, AM_, EM_, 1, float, float, true>), dim3((unsigned)(ceil_div(M, BM_) * (Nout / BN_))), dim3(512), 0, st, \
-                     A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout, a_bound, geo)
+  do {                                                                                                                             \
+    const unsigned grid_ = grid_of(BM_, BN_);                                                                                      \
+    hipLaunchKernelGGL((pw16_k<BM_, BN_, AM_, EM_, 1, float, float, true>), dim3(grid_), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, \
+                       part, M, K, Nout, a_bound, gq);                                                                             \
+  } while (0)
 #define TTK_CONV_TILES(AM_, EM_)                                   \
   do {                                                             \
     if (Nout % 256 == 0) TTK_CONV_LAUNCH(128, 256, AM_, EM_);      \

@@ -16,6 +16,8 @@ IT = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 shapes = [("l1", 33, 64, 64, 3, 1, 4), ("l2a", 33, 64, 128, 3, 2, 1), ("l2d", 33, 64, 128, 1, 2, 1), ("l2", 17, 128, 128, 3, 1, 3),
           ("l3a", 17, 128, 256, 3, 2, 1), ("l3d", 17, 128, 256, 1, 2, 1), ("l3", 9, 256, 256, 3, 1, 3),
           ("l4a", 9, 256, 512, 3, 2, 1), ("l4d", 9, 256, 512, 1, 2, 1), ("l4", 5, 512, 512, 3, 1, 3)]
+if os.environ.get("EXTRA"):  # the MobileNet dw5_x pointwise shape through the convolution kernels (code-generation comparison)
+    shapes = [("pw5", 9, 512, 512, 1, 1, 0)]
 tot = {"fwd": 0.0, "dgrad": 0.0, "dgrad_m": 0.0, "wgrad": 0.0}
 dev = "cuda"
 for name, hw, ci, co, k, s, mult in shapes:
