@@ -229,7 +229,13 @@ int ttk_bn_act(const float* y, const float* bn, const float* skip, float* a, int
  *                           receives (sum g_in, sum g_in*(mask_y-mean)) and mask_bn[TTK_BN_AUX][TTK_AUX_GMAX] is raised
  *                           to max |g_in|; without: raw gradient, part untouched.  bn[TTK_BN_AUX][TTK_AUX_DY_BOUND]
  *                           must bound |dy| (ttk_bn_bwd_finalize, from the TTK_AUX_GMAX the producer of g raised).
- *   ttk_conv_bwd_weight     dw[Cout][Cin][KH][KW] += sum_pixels dy (x) a_in (fp32 atomics; zero dw first); a_bound as above
+ *   ttk_conv_bwd_weight     dw[Cout][Cin][KH][KW] += sum_pixels dy (x) a_in; a_bound as above.  partial = scratch of
+ *                           ttk_conv_wgrad_partial_bytes(...) bytes (0 = the call takes none): the slices of the pixel range
+ *                           store their tiles side by side and a second kernel folds them in a fixed order into dw
+ *                           (bitwise reproducible, and several times faster than the alternative, partial == NULL: one
+ *                           fp32 atomicAdd per slice and element at torch's 36-byte tap stride)
+ *                           Both gradients accept y == NULL: g then already holds dy (ttk_bn_bwd_apply; fp16 kernels only) -
+ *                           half the operand bytes through the L1, which is what bounds these kernels.
  * ------------------------------------------------------------------------------------------- */
 int ttk_conv_weight_repack(const float* w, void* w_fwd, void* w_bwd, int Cout, int Cin, int KH, int KW,
                            ttk_stream_t stream);
@@ -238,8 +244,9 @@ int ttk_conv_fwd(const float* a_in, const float* a_bound, const void* w_fwd, flo
 int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const void* w_bwd, const float* mask_y,
                       float* mask_bn, float* g_in, float* part, int B, int H, int W, int Cin, int Cout,
                       int KH, int KW, int stride, int pad, ttk_stream_t stream);
+size_t ttk_conv_wgrad_partial_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int ttk_conv_bwd_weight(const float* g, const float* y, const float* bn, const float* a_in, const float* a_bound, float* dw,
-                        int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream);
+                        float* partial, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The non-GEMM kernels of the ResNet18 variant (backbones/resnet.py:52-104: torchvision ResNet18, 1-channel 7x7 stem).
@@ -252,6 +259,7 @@ int ttk_conv_bwd_weight(const float* g, const float* y, const float* bn, const f
  *   ttk_bn_add_act         a = relu(bn(y) + r); r = res, or res_bn(res) when res is the raw downsample-conv output
  *                          (BasicBlock: out = relu(bn2(conv2) + identity)), or nothing.  Raises
  *                          bn[TTK_BN_AUX][TTK_AUX_ACT_BOUND] to max a (the a_bound of the convolutions that read a).
+ *   ttk_bn_bwd_apply       dy = ga*(g-gmean) + gb*(y-mean), materialised once for a convolution's two gradients
  *   ttk_residual_bwd       gs = (ga (+ gb)) * [a > 0]; part = sums for bn(y); partd (with yd, bnd) = sums for the
  *                          downsample BatchNorm; rows of both = ttk_partial_rows_elementwise(rows*C/4).  Raises
  *                          TTK_AUX_GMAX of bn (and bnd) to max |gs|.
@@ -265,6 +273,7 @@ int ttk_maxpool3x3s2_bwd(const float* ga, const float* gb, const unsigned char* 
                          float* g, float* part, int B, int H, int W, int C, ttk_stream_t stream);
 int ttk_bn_add_act(const float* y, float* bn, const float* res, const float* res_bn, float* a, int64_t rows,
                    int C, ttk_stream_t stream);
+int ttk_bn_bwd_apply(const float* g, const float* y, const float* bn, float* dy, int64_t rows, int C, ttk_stream_t stream);
 int ttk_residual_bwd(const float* ga, const float* gb, const float* a, const float* y, float* bn, const float* yd,
                      float* bnd, float* gs, float* part, float* partd, int64_t rows, int C, ttk_stream_t stream);
 

@@ -121,7 +121,8 @@ int ttk_conv_fwd(const float* a_in, const float* a_bound, const void* w_fwd, flo
 int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const void* w_bwd, const float* mask_y,
                       float* mask_bn, float* g_in, float* part, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                       int stride, int pad, ttk_stream_t stream) {
-  TTK_REQUIRE(g && y && bn && w_bwd && g_in, "conv_bwd_data: null pointer");
+  TTK_REQUIRE(g && bn && w_bwd && g_in, "conv_bwd_data: null pointer");
+  TTK_REQUIRE(y || gemm_mode() == GEMM_F16X2, "conv_bwd_data: a materialised dy (y == NULL) needs the fp16 kernels");
   TTK_REQUIRE((mask_y == nullptr) == (mask_bn == nullptr), "conv_bwd_data: mask_y and mask_bn go together");
   TTK_REQUIRE(conv_shape_ok(B, H, W, Cin, Cout, KH, KW, stride, pad) && Cin % 64 == 0, "conv_bwd_data: unsupported shape");
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
@@ -129,8 +130,9 @@ int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const voi
   const uint16_t* wq = (const uint16_t*)w_bwd;
   const int K = KH * KW * Cout, em = mask_y ? EMODE_MASK : EMODE_PLAIN;
   const bool ok = gemm_mode() == GEMM_F16X2
-                      ? launch_conv_gemm16(AMODE_BNGRAD, em, g, y, bn, nullptr, wq, (const float*)(wq + 2 * (size_t)K * Cin), g_in, mask_y, mask_bn,
-                                           mask_y ? part : nullptr, (int64_t)B * H * W, K, Cin, geo, (hipStream_t)stream)
+                      ? launch_conv_gemm16(y ? AMODE_BNGRAD : AMODE_PLAIN, em, g, y, bn, bn + (size_t)TTK_BN_AUX * Cout + TTK_AUX_DY_BOUND, wq,
+                                           (const float*)(wq + 2 * (size_t)K * Cin), g_in, mask_y, mask_bn, mask_y ? part : nullptr,
+                                           (int64_t)B * H * W, K, Cin, geo, (hipStream_t)stream)
                       : launch_conv_gemm(AMODE_BNGRAD, em, g, y, bn, wq, g_in, mask_y, mask_bn, mask_y ? part : nullptr, (int64_t)B * H * W, K, Cin, geo,
                                          (hipStream_t)stream);
   TTK_REQUIRE(ok, "conv_bwd_data: no kernel for this shape");
@@ -138,14 +140,21 @@ int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const voi
 }
 
 // dw[Cout][Cin][KH][KW] += sum_{pixels} dy (x) a_in.  The caller zeroes dw (or accumulates on purpose).
-int ttk_conv_bwd_weight(const float* g, const float* y, const float* bn, const float* a_in, const float* a_bound, float* dw, int B, int H,
-                        int W, int Cin, int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream) {
-  TTK_REQUIRE(g && y && bn && a_in && a_bound && dw, "conv_bwd_weight: null pointer");
+size_t ttk_conv_wgrad_partial_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+  if (gemm_mode() != GEMM_F16X2 || !conv_shape_ok(B, H, W, Cin, Cout, KH, KW, stride, pad)) return 0;
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  return conv_wgrad16_partial_bytes((int64_t)B * Ho * Wo, Cout, KH * KW * Cin, KH * KW);
+}
+
+int ttk_conv_bwd_weight(const float* g, const float* y, const float* bn, const float* a_in, const float* a_bound, float* dw, float* partial,
+                        int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream) {
+  TTK_REQUIRE(g && bn && a_in && a_bound && dw, "conv_bwd_weight: null pointer");
+  TTK_REQUIRE(y || gemm_mode() == GEMM_F16X2, "conv_bwd_weight: a materialised dy (y == NULL) needs the fp16 kernels");
   TTK_REQUIRE(conv_shape_ok(B, H, W, Cin, Cout, KH, KW, stride, pad), "conv_bwd_weight: unsupported shape");
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   const ConvGeom geo{H, W, Ho, Wo, stride, pad, KW, Cin, 0};
   const bool ok = gemm_mode() == GEMM_F16X2
-                      ? launch_conv_wgrad16(g, y, bn, a_in, a_bound, dw, (int64_t)B * Ho * Wo, Cout, KH * KW, geo, (hipStream_t)stream)
+                      ? launch_conv_wgrad16(g, y, bn, a_in, a_bound, dw, partial, (int64_t)B * Ho * Wo, Cout, KH * KW, geo, (hipStream_t)stream)
                       : launch_conv_wgrad(g, y, bn, a_in, dw, (int64_t)B * Ho * Wo, Cout, KH * KW, geo, (hipStream_t)stream);
   TTK_REQUIRE(ok, "conv_bwd_weight: no kernel for this shape");
   TTK_LAUNCH_CHECK("conv_bwd_weight");

@@ -50,7 +50,8 @@ bool launch_conv_wgrad(const float* g, const float* y, const float* bn, const fl
 bool launch_conv_gemm16(int amode, int emode, const float* A0, const float* A1, const float* bnA, const float* a_bound, const uint16_t* Bq,
                         const float* wmax, float* out, const float* E0, float* bnE, float* part, int64_t M, int K, int Nout,
                         const ConvGeom& geo, hipStream_t st);
-bool launch_conv_wgrad16(const float* g, const float* y, const float* bn, const float* a_in, const float* a_bound, float* dw, int64_t M,
-                         int Cout, int taps, const ConvGeom& geo, hipStream_t st);
+bool launch_conv_wgrad16(const float* g, const float* y, const float* bn, const float* a_in, const float* a_bound, float* dw, float* partial,
+                         int64_t M, int Cout, int taps, const ConvGeom& geo, hipStream_t st);
+size_t conv_wgrad16_partial_bytes(int64_t M, int Cout, int ncols, int taps);
 
 }  // namespace ttk

@@ -543,7 +543,9 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
 // X is the materialised input activation [B][Hs][Ws][Kc] with bound *x_bound; the rows m enumerate OUTPUT pixels
 // (Hg x Wg per image) and column (tap, ci) reads the input pixel the tap points at (zero outside).  Partial tiles
 // (Cout < BM, Cin % BN != 0) are masked; dW is torch's [Cout][Kc][taps].
-template <int BM, int BN, int D, typename T, typename TG, bool CONV = false>
+// APLAIN (convolutions): G already holds dy (ttk_bn_bwd_apply materialised it once for the weight and the data gradient:
+// half the A bytes through the L1 and no BatchNorm arithmetic here); Y is not read.
+template <int BM, int BN, int D, typename T, typename TG, bool CONV = false, bool APLAIN = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __restrict__ bn_pw,
              const T* __restrict__ X, const float* __restrict__ bn_x, float* __restrict__ dW, float* __restrict__ partial,
@@ -580,7 +582,7 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
     const int mb = pt & 7, cq = pt >> 3;  // 8 row blocks of 4 rows x 32 channel quads per pass
     const int sub = mb >> 2, chunk = (mb >> 1) & 1, o8 = (mb & 1) * 8;
     constexpr int AP = BM >= 128 ? BM / 128 : 1, BP = BN / 128;
-    f32x4 rg[D][AP][4], ry[D][AP][4], rx[D][BP][4];
+    f32x4 rg[D][AP][4], ry[D][APLAIN ? 1 : AP][4], rx[D][BP][4];
     f32x4 ga[AP], gb[AP], gmean[AP], ymean[AP], sc[BP], mu[BP], be[BP];
     int ca[AP], cb[BP];
     // convolutions: tap of the B columns, validity of this thread's A rows / B columns (partial tiles), and per register
@@ -666,7 +668,7 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
 #pragma unroll
           for (int p = 0; p < AP; ++p) {
             rg[set][p][i] = ld_act4<TG>(gp[p] + base + (int64_t)i * Cout);
-            ry[set][p][i] = ld_act4<T>(yp[p] + base + (int64_t)i * Cout);
+            if constexpr (!APLAIN) ry[set][p][i] = ld_act4<T>(yp[p] + base + (int64_t)i * Cout);
           }
         return;
       }
@@ -677,7 +679,7 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
           rg[set][p][i] = ld_act4<TG>(G + row * Cout + ca[p]);
-          ry[set][p][i] = ld_act4<T>(Y + row * Cout + ca[p]);
+          if constexpr (!APLAIN) ry[set][p][i] = ld_act4<T>(Y + row * Cout + ca[p]);
         }
       }
     };
@@ -757,7 +759,10 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
       for (int p = 0; p < AP; ++p) {
         f32x4 v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = ga[p] * (rg[set][p][i] - gmean[p]) + gb[p] * (ry[set][p][i] - ymean[p]);
+        for (int i = 0; i < 4; ++i) {
+          if constexpr (APLAIN) v[i] = rg[set][p][i] * sa;
+          else v[i] = ga[p] * (rg[set][p][i] - gmean[p]) + gb[p] * (ry[set][p][i] - ymean[p]);
+        }
         if (masked || (CONV && !va[p])) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
@@ -821,6 +826,9 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     consume_tile16<BM, BN, RS>(lds, nks, wm, wn, r, h, acc);
     const float inv = 1.f / (sa * sb);
+#if defined(TTK_EXP) && TTK_EXP == 15
+    if (acc[0][0][0] != 12345.678f) return;  // timing experiment: no epilogue
+#endif
     float* dst = partial ? partial + (size_t)slice * Cout * Cin : dW;
     const int taps = CONV ? Cin / Kc : 1;
 #pragma unroll
@@ -834,9 +842,10 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
         for (int e = 0; e < 16; ++e) {
           const int row = n0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
           if (CONV && row >= Cout) continue;
-          float* q = dst + ((size_t)row * Kc + ci) * taps + tap;  // pointwise: [row][col]; convolution: [co][ci][tap]
-          if (partial) *q = acc[i][j][e] * inv;
-          else atomicAdd(q, acc[i][j][e] * inv);
+          // pointwise and the convolutions' partial slices: [row][col] (lanes side by side); convolution without
+          // scratch: torch's [co][ci][tap] - 36-byte strided atomics, several times the cost of the whole main loop
+          if (partial) dst[(size_t)row * Cin + col] = acc[i][j][e] * inv;
+          else atomicAdd(dst + ((size_t)row * Kc + ci) * taps + tap, acc[i][j][e] * inv);
         }
     }
   }
@@ -849,6 +858,20 @@ __global__ void __launch_bounds__(256) wgrad_reduce_k(const float* __restrict__ 
   float4 a = ld4(dW + i);
   for (int s = 0; s < slices; ++s) a = add4(a, ld4(partial + (size_t)s * n + i));
   st4(dW + i, a);
+}
+
+// dW[co][ci][tap] += partial[0][co][tap*Kc+ci] + partial[1][..] + ... (fixed order: bitwise reproducible); one thread per
+// (co, tap, ci): the slice reads are coalesced, the one strided write per element is cheap
+__global__ void __launch_bounds__(256) conv_wgrad_reduce_k(const float* __restrict__ partial, float* __restrict__ dW, int Cout, int Kc, int taps,
+                                                            int slices) {
+  const int64_t n = (int64_t)Cout * Kc * taps;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int ncols = Kc * taps;
+  const int co = (int)(i / ncols), col = (int)(i - (int64_t)co * ncols), tap = col / Kc, ci = col - tap * Kc;
+  float a = 0.f;
+  for (int s = 0; s < slices; ++s) a += partial[(size_t)s * n + i];
+  dW[((size_t)co * Kc + ci) * taps + tap] += a;
 }
 
 // The [M][K] x [Nout][K]^T shapes that run on these kernels (everything else: fp32 MFMA, pwconv.hip).
@@ -963,23 +986,39 @@ bool launch_f16_gemm(const TO* A0, const T* A1, const float* bnA, const float* B
 }
 
 // dw[Cout][Kc][taps] += sum over output pixels of dy (x) gathered input activation (conv.hip)
-bool launch_conv_wgrad16(const float* g, const float* y, const float* bn, const float* a_in, const float* a_bound, float* dw, int64_t M,
-                         int Cout, int taps, const ConvGeom& geo, hipStream_t st) {
+static void conv_wgrad_plan(int64_t M, int Cout, int ncols, int& tiles, int64_t& slices, int64_t& rows) {
+  tiles = (int)(ceil_div(Cout, Cout <= 64 ? 64 : 128) * ceil_div(ncols, 256));
+  wgrad_slices(M, tiles, slices, rows);
+}
+size_t conv_wgrad16_partial_bytes(int64_t M, int Cout, int ncols, int taps) {
+  if (taps == 1) return 0;  // 1x1: the atomics are coalesced ([co][ci] = the GEMM's layout) and measured faster than the fold
+  int tiles;
+  int64_t slices, rows;
+  conv_wgrad_plan(M, Cout, ncols, tiles, slices, rows);
+  return (size_t)slices * Cout * ncols * sizeof(float);
+}
+
+bool launch_conv_wgrad16(const float* g, const float* y, const float* bn, const float* a_in, const float* a_bound, float* dw, float* partial,
+                         int64_t M, int Cout, int taps, const ConvGeom& geo, hipStream_t st) {  // y == nullptr: g is dy
   if (geo.Kc % 4 != 0 || Cout % 4 != 0) return false;
   const int64_t nimg = M / ((int64_t)geo.Hg * geo.Wg);
   if (nimg * geo.Hs * geo.Ws * geo.Kc >= (int64_t)1 << 29) return false;  // 32-bit byte offsets into a_in (with the halo's slack)
   const int ncols = taps * geo.Kc;
   const bool narrow = Cout <= 64;
-  const int tiles = (int)(ceil_div(Cout, narrow ? 64 : 128) * ceil_div(ncols, 256));
+  if (taps == 1) partial = nullptr;
+  int tiles;
   int64_t slices, rows;
-  wgrad_slices(M, tiles, slices, rows);
+  conv_wgrad_plan(M, Cout, ncols, tiles, slices, rows);
   const dim3 grid(tiles, (unsigned)slices);
-  if (narrow)
-    hipLaunchKernelGGL((pw16_wgrad_k<64, 256, 1, float, float, true>), grid, dim3(512), 0, st, g, y, bn, a_in, nullptr, dw, nullptr, M, ncols, Cout,
-                       rows, a_bound, geo);
-  else
-    hipLaunchKernelGGL((pw16_wgrad_k<128, 256, 1, float, float, true>), grid, dim3(512), 0, st, g, y, bn, a_in, nullptr, dw, nullptr, M, ncols, Cout,
-                       rows, a_bound, geo);
+#define TTK_WGRAD_LAUNCH(BM_, PLAIN_)                                                                                                          \
+  hipLaunchKernelGGL((pw16_wgrad_k<BM_, 256, 1, float, float, true, PLAIN_>), grid, dim3(512), 0, st, g, y, bn, a_in, nullptr, dw, partial, M, ncols, \
+                     Cout, rows, a_bound, geo)
+  if (narrow) { if (y) TTK_WGRAD_LAUNCH(64, false); else TTK_WGRAD_LAUNCH(64, true); }
+  else        { if (y) TTK_WGRAD_LAUNCH(128, false); else TTK_WGRAD_LAUNCH(128, true); }
+#undef TTK_WGRAD_LAUNCH
+  if (partial)
+    hipLaunchKernelGGL(conv_wgrad_reduce_k, dim3((unsigned)ceil_div((int64_t)Cout * ncols, 256)), dim3(256), 0, st, partial, dw, Cout, geo.Kc, taps,
+                       (int)slices);
   return true;
 }
 
@@ -1024,6 +1063,8 @@ bool launch_conv_gemm16(int amode, int emode, const float* A0, const float* A1, 
   if (amode == AMODE_PLAIN && emode == EMODE_STATS) TTK_CONV_TILES(AMODE_PLAIN, EMODE_STATS);
   if (amode == AMODE_BNGRAD && emode == EMODE_MASK) TTK_CONV_TILES(AMODE_BNGRAD, EMODE_MASK);
   if (amode == AMODE_BNGRAD && emode == EMODE_PLAIN) TTK_CONV_TILES(AMODE_BNGRAD, EMODE_PLAIN);
+  if (amode == AMODE_PLAIN && emode == EMODE_MASK) TTK_CONV_TILES(AMODE_PLAIN, EMODE_MASK);  // data gradient of a materialised dy
+  if (amode == AMODE_PLAIN && emode == EMODE_PLAIN) TTK_CONV_TILES(AMODE_PLAIN, EMODE_PLAIN);
 #undef TTK_CONV_TILES
 #undef TTK_CONV_LAUNCH
   return false;

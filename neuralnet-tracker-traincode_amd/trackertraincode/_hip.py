@@ -40,10 +40,11 @@ _SIGNATURES = {
     "ttk_maxpool3x3s2_bwd": [_P] * 7 + [_I] * 4,
     "ttk_bn_add_act": [_P, _P, _P, _P, _P, _L, _I],
     "ttk_residual_bwd": [_P] * 10 + [_L, _I],
+    "ttk_bn_bwd_apply": [_P, _P, _P, _P, _L, _I],
     "ttk_conv_weight_repack": [_P, _P, _P, _I, _I, _I, _I],
     "ttk_conv_fwd": [_P, _P, _P, _P, _P] + [_I] * 9,
     "ttk_conv_bwd_data": [_P] * 8 + [_I] * 9,
-    "ttk_conv_bwd_weight": [_P] * 6 + [_I] * 9,
+    "ttk_conv_bwd_weight": [_P] * 7 + [_I] * 9,
     "ttk_heads_fwd": [_P] * 8 + [_I] * 7 + [_P] * 9,
     "ttk_heads_bwd": [_P] * 8 + [_I] * 7 + [_P] * 15,
     "ttk_diag_scale_fwd": [_P, _P, _I],
@@ -109,6 +110,7 @@ class _Library:
         self.cdll.ttk_pwconv_prepared_bytes.argtypes, self.cdll.ttk_pwconv_prepared_bytes.restype = [c_int, c_int], ctypes.c_size_t
         self.cdll.ttk_partial_rows_dwconv.argtypes, self.cdll.ttk_partial_rows_dwconv.restype = [c_int] * 6, c_int
         self.cdll.ttk_pwconv_wgrad_partial_bytes.argtypes, self.cdll.ttk_pwconv_wgrad_partial_bytes.restype = [c_int64, c_int, c_int], ctypes.c_size_t
+        self.cdll.ttk_conv_wgrad_partial_bytes.argtypes, self.cdll.ttk_conv_wgrad_partial_bytes.restype = [c_int] * 9, ctypes.c_size_t
         self.cdll.ttk_stem_wgrad_partial_bytes.argtypes, self.cdll.ttk_stem_wgrad_partial_bytes.restype = [], ctypes.c_size_t
         self._fns = {}
         for name, sig in _SIGNATURES.items():
@@ -127,6 +129,10 @@ class _Library:
 
     def pwconv_prepared_bytes(self, cin: int, cout: int) -> int:
         return self.cdll.ttk_pwconv_prepared_bytes(cin, cout)
+
+    def conv_wgrad_partial_bytes(self, B, H, W, cin, cout, k, stride) -> int:
+        """Scratch bytes of ttk_conv_bwd_weight's slice-wise (atomic-free) weight gradient; 0 = the call takes none."""
+        return self.cdll.ttk_conv_wgrad_partial_bytes(B, H, W, cin, cout, k, k, stride, k // 2)
 
     def pwconv_wgrad_partial_bytes(self, m: int, cin: int, cout: int) -> int:
         """Scratch bytes of the deterministic (fixed-order) weight-gradient reduction; 0 = this shape has none."""
@@ -187,4 +193,4 @@ def ptr(t: torch.Tensor | None):
 def exported_symbols() -> list[str]:
     return ["ttk_abi_version", "ttk_last_error_string", "ttk_clear_error", "ttk_partial_rows_elementwise",
             "ttk_partial_rows_gemm", "ttk_partial_rows_dwconv", "ttk_heads_num_rows", "ttk_pwconv_prepared_bytes",
-            "ttk_pwconv_wgrad_partial_bytes", "ttk_stem_wgrad_partial_bytes"] + list(_SIGNATURES)
+            "ttk_pwconv_wgrad_partial_bytes", "ttk_stem_wgrad_partial_bytes", "ttk_conv_wgrad_partial_bytes"] + list(_SIGNATURES)

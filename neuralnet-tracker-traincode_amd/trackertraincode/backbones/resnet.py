@@ -15,6 +15,8 @@ scheme of the MobileNet backbone.  `use_blurpool=True` (reference :33-50,63-66) 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -46,6 +48,7 @@ class BasicBlock(nn.Module):
         return self.relu(out + identity)
 
 
+_MATERIALISE_DY = os.environ.get("TTK_GEMM") != "bf16x3"
 _BN_AUX = 7  # TTK_BN_AUX: [0] = TTK_AUX_ACT_BOUND of the activation this BatchNorm forms
 
 
@@ -192,8 +195,25 @@ def _backward_impl(c: _Ctx, gfeat, params):
         if grad_ready_hook is not None:
             grad_ready_hook(arena, [(params[i], offs[i], offs[i + 1]) for i in range(first, last)])
 
+    def through_bn(g, y, bn, rows, C):
+        """-> (dy | g, None | y pointer): the 3x3 convolutions' two gradients read dy = ga*(g-gmean)+gb*(y-mean) materialised
+        once (fp16 kernels: half the operand bytes per pass - the data gradient gathers it nine times); TTK_GEMM=bf16x3
+        forms it on load as before."""
+        if not _MATERIALISE_DY:
+            return g, p(y)
+        dy = torch.empty_like(g)
+        L.call("ttk_bn_bwd_apply", p(g), p(y), p(bn), p(dy), rows, C)
+        return dy, None
+
     def bwd_finalize(bn, rows, C, count, gi, scratch=None):
         L.call("ttk_bn_bwd_finalize", p(scratch if scratch is not None else part), rows, C, count, p(params[gi]), p(bn), p(grads[gi]), p(grads[gi + 1]), 0)
+
+    # scratch of the slice-wise (atomic-free, reproducible) weight gradients: one buffer, sized for the largest call
+    need = 0
+    for k in c.blocks:
+        need = max(need, L.conv_wgrad_partial_bytes(B, k.h, k.h, k.cin, k.cout, 3, k.stride), L.conv_wgrad_partial_bytes(B, k.ho, k.ho, k.cout, k.cout, 3, 1),
+                   L.conv_wgrad_partial_bytes(B, k.h, k.h, k.cin, k.cout, 1, k.stride) if k.yd is not None else 0)
+    wscratch = torch.empty(need // 4, dtype=torch.float32, device=dev) if need else None
 
     # parameter index of every block's first tensor
     starts, pi, cin = [], 3, 64
@@ -218,16 +238,20 @@ def _backward_impl(c: _Ctx, gfeat, params):
         if has_ds:
             bwd_finalize(k.bnd, rows_gs, C, M, pi + 7, scratch=partd)
         # conv2: weight gradient, then data gradient through relu(bn1(y1)) (+ bn1 sums)
-        L.call("ttk_conv_bwd_weight", p(gs), p(k.y2), p(k.bn2), p(k.a_mid), bound(k.bn1), p(grads[pi + 3]), B, k.ho, k.ho, C, C, 3, 3, 1, 1)
+        dy2, y2 = through_bn(gs, k.y2, k.bn2, M, C)
+        L.call("ttk_conv_bwd_weight", p(dy2), y2, p(k.bn2), p(k.a_mid), bound(k.bn1), p(grads[pi + 3]), p(wscratch), B, k.ho, k.ho, C, C, 3, 3, 1, 1)
         g1 = new(B, k.ho, k.ho, C)
-        L.call("ttk_conv_bwd_data", p(gs), p(k.y2), p(k.bn2), p(k.w2b), p(k.y1), p(k.bn1), p(g1), p(part), B, k.ho, k.ho, C, C, 3, 3, 1, 1)
+        L.call("ttk_conv_bwd_data", p(dy2), y2, p(k.bn2), p(k.w2b), p(k.y1), p(k.bn1), p(g1), p(part), B, k.ho, k.ho, C, C, 3, 3, 1, 1)
+        del dy2
         bwd_finalize(k.bn1, L.partial_rows_gemm(M), C, M, pi + 1)
         # conv1: weight gradient, raw data gradient w.r.t. the block input
-        L.call("ttk_conv_bwd_weight", p(g1), p(k.y1), p(k.bn1), p(k.a_in), bound(k.a_bn), p(grads[pi]), B, k.h, k.h, k.cin, C, 3, 3, k.stride, 1)
+        dy1, y1 = through_bn(g1, k.y1, k.bn1, M, C)
+        L.call("ttk_conv_bwd_weight", p(dy1), y1, p(k.bn1), p(k.a_in), bound(k.a_bn), p(grads[pi]), p(wscratch), B, k.h, k.h, k.cin, C, 3, 3, k.stride, 1)
         g_in = new(B, k.h, k.h, k.cin)
-        L.call("ttk_conv_bwd_data", p(g1), p(k.y1), p(k.bn1), p(k.w1b), None, None, p(g_in), None, B, k.h, k.h, k.cin, C, 3, 3, k.stride, 1)
+        L.call("ttk_conv_bwd_data", p(dy1), y1, p(k.bn1), p(k.w1b), None, None, p(g_in), None, B, k.h, k.h, k.cin, C, 3, 3, k.stride, 1)
+        del dy1
         if has_ds:
-            L.call("ttk_conv_bwd_weight", p(gs), p(k.yd), p(k.bnd), p(k.a_in), bound(k.a_bn), p(grads[pi + 6]), B, k.h, k.h, k.cin, C, 1, 1, k.stride, 0)
+            L.call("ttk_conv_bwd_weight", p(gs), p(k.yd), p(k.bnd), p(k.a_in), bound(k.a_bn), p(grads[pi + 6]), p(wscratch), B, k.h, k.h, k.cin, C, 1, 1, k.stride, 0)
             wdb = torch.empty((3, 1, k.cin, C), dtype=torch.int16, device=dev)
             L.call("ttk_conv_weight_repack", p(params[pi + 6]), None, p(wdb), C, k.cin, 1, 1)
             g_sc = new(B, k.h, k.h, k.cin)

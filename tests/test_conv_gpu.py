@@ -104,8 +104,26 @@ def test_conv_fwd_bwd_data_bwd_weight(B, H, Cin, Cout, k, stride):
         yc = (mask_y.astype(np.float64) - mbn[BN_MEAN]).reshape(-1, Cin)
         np.testing.assert_allclose(ps[:, 1].sum(0), (o64 * yc).sum(0), rtol=0, atol=3e-5 * np.abs(o64 * yc).sum(0).max())
 
+    # ---- the same two gradients from a materialised dy (ttk_bn_bwd_apply; y == NULL)
+    d_dy = torch.empty_like(d_g)
+    L.call("ttk_bn_bwd_apply", p(d_g), p(y), p(d_bn), p(d_dy), M, Cout)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(d_dy.cpu().numpy(), dy, rtol=1e-5, atol=1e-6)
+    L.call("ttk_conv_bwd_data", p(d_dy), None, p(d_bn), p(w_b), None, None, p(g_in), None, B, H, W, Cin, Cout, k, k, stride, pad)
+    dw2 = torch.zeros(Cout, Cin, k, k, device=dev)
+    nb = L.conv_wgrad_partial_bytes(B, H, W, Cin, Cout, k, stride)
+    assert (nb > 0) == (k == 3)  # 1x1 kernels keep the (coalesced) atomics
+    scratch = torch.full((nb // 4,), float("nan"), device=dev) if nb else None  # slice-wise, atomic-free form
+    L.call("ttk_conv_bwd_weight", p(d_dy), None, p(d_bn), p(d_a), p(a_bound), p(dw2), p(scratch), B, H, W, Cin, Cout, k, k, stride, pad)
+    torch.cuda.synchronize()
+    assert _rel(g_in.cpu().numpy(), ga_ref) < 1.5e-6
+    assert _rel(dw2.cpu().numpy(), gw_ref.numpy()) < 1.5e-6
+    dw3 = torch.zeros_like(dw2)  # the slice-wise form is bitwise reproducible
+    L.call("ttk_conv_bwd_weight", p(d_dy), None, p(d_bn), p(d_a), p(a_bound), p(dw3), p(scratch), B, H, W, Cin, Cout, k, k, stride, pad)
+    assert k == 1 or torch.equal(dw2, dw3)
+
     # ---- weight gradient (accumulates onto a zeroed buffer; torch layout [Cout][Cin][k][k])
     dw = torch.zeros(Cout, Cin, k, k, device=dev)
-    L.call("ttk_conv_bwd_weight", p(d_g), p(y), p(d_bn), p(d_a), p(a_bound), p(dw), B, H, W, Cin, Cout, k, k, stride, pad)
+    L.call("ttk_conv_bwd_weight", p(d_g), p(y), p(d_bn), p(d_a), p(a_bound), p(dw), None, B, H, W, Cin, Cout, k, k, stride, pad)
     torch.cuda.synchronize()
     assert _rel(dw.cpu().numpy(), gw_ref.numpy()) < 1.5e-6

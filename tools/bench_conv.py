@@ -18,7 +18,7 @@ shapes = [("l1", 33, 64, 64, 3, 1, 4), ("l2a", 33, 64, 128, 3, 2, 1), ("l2d", 33
           ("l4a", 9, 256, 512, 3, 2, 1), ("l4d", 9, 256, 512, 1, 2, 1), ("l4", 5, 512, 512, 3, 1, 3)]
 if os.environ.get("EXTRA"):  # the MobileNet dw5_x pointwise shape through the convolution kernels (code-generation comparison)
     shapes = [("pw5", 9, 512, 512, 1, 1, 0)]
-tot = {"fwd": 0.0, "dgrad": 0.0, "dgrad_m": 0.0, "wgrad": 0.0}
+tot = {"fwd": 0.0, "dy": 0.0, "dgrad": 0.0, "dgrad_m": 0.0, "wgrad": 0.0}
 dev = "cuda"
 for name, hw, ci, co, k, s, mult in shapes:
     pad = k // 2
@@ -31,15 +31,20 @@ for name, hw, ci, co, k, s, mult in shapes:
     bn[2], bn[6], bn[7], mbn[7] = 0.1, 0.0, 0.0, 0.0
     bn[7, 1] = 0.05  # TTK_AUX_DY_BOUND
     a_bound = torch.tensor([8.0], device=dev)
+    dy = torch.empty_like(g)
+    nb = L.conv_wgrad_partial_bytes(B, hw, hw, ci, co, k, s)
+    scr = torch.empty(nb // 4, device=dev) if nb and not os.environ.get("ATOMIC") else None  # slice-wise weight gradient (ATOMIC=1: fp32 atomics)
+    yp = p(y) if os.environ.get("TTK_GEMM") == "bf16x3" or os.environ.get("ONLOAD") else None  # None: the gradients read the materialised dy
     wf, wb = torch.empty(3, k * k, co, ci, dtype=torch.int16, device=dev), torch.empty(3, k * k, ci, co, dtype=torch.int16, device=dev)
     L.call("ttk_conv_weight_repack", p(w), p(wf), p(wb), co, ci, k, k)
     out, gin, dw = torch.empty(B, ho, ho, co, device=dev), torch.empty(B, hw, hw, ci, device=dev), torch.zeros(co, ci, k, k, device=dev)
     part = torch.empty(max(L.partial_rows_gemm(M), L.partial_rows_gemm(B * hw * hw)) * 2 * max(ci, co), device=dev)
     calls = {
         "fwd": lambda: L.call("ttk_conv_fwd", p(a), p(a_bound), p(wf), p(out), p(part), B, hw, hw, ci, co, k, k, s, pad),
-        "dgrad": lambda: L.call("ttk_conv_bwd_data", p(g), p(y), p(bn), p(wb), None, None, p(gin), None, B, hw, hw, ci, co, k, k, s, pad),
-        "dgrad_m": lambda: L.call("ttk_conv_bwd_data", p(g), p(y), p(bn), p(wb), p(a), p(mbn), p(gin), p(part), B, hw, hw, ci, co, k, k, s, pad),
-        "wgrad": lambda: L.call("ttk_conv_bwd_weight", p(g), p(y), p(bn), p(a), p(a_bound), p(dw), B, hw, hw, ci, co, k, k, s, pad),
+        "dy": lambda: L.call("ttk_bn_bwd_apply", p(g), p(y), p(bn), p(dy), M, co),
+        "dgrad": lambda: L.call("ttk_conv_bwd_data", p(dy), yp, p(bn), p(wb), None, None, p(gin), None, B, hw, hw, ci, co, k, k, s, pad),
+        "dgrad_m": lambda: L.call("ttk_conv_bwd_data", p(dy), yp, p(bn), p(wb), p(a), p(mbn), p(gin), p(part), B, hw, hw, ci, co, k, k, s, pad),
+        "wgrad": lambda: L.call("ttk_conv_bwd_weight", p(dy), yp, p(bn), p(a), p(a_bound), p(dw), p(scr), B, hw, hw, ci, co, k, k, s, pad),
     }
     line = f"{name:4s} M={M:7d} K={k * k * ci:5d} N={co:4d} "
     for kk, fn in calls.items():
