@@ -239,6 +239,9 @@ int ttk_bn_act(const float* y, const float* bn, const float* skip, float* a, int
  * ------------------------------------------------------------------------------------------- */
 int ttk_conv_weight_repack(const float* w, void* w_fwd, void* w_bwd, int Cout, int Cin, int KH, int KW,
                            ttk_stream_t stream);
+/* the same for n <= 24 weight tensors (square kernels of size ksize[i] in {1,3}) in three launches: a training step's 19 */
+int ttk_conv_prepare_weights(int n, const float* const* w, void* const* w_fwd, void* const* w_bwd, const int* cout,
+                             const int* cin, const int* ksize, ttk_stream_t stream);
 int ttk_conv_fwd(const float* a_in, const float* a_bound, const void* w_fwd, float* y, float* part, int B, int H, int W,
                  int Cin, int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream);
 int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const void* w_bwd, const float* mask_y,
@@ -257,8 +260,11 @@ int ttk_conv_bwd_weight(const float* g, const float* y, const float* bn, const f
  *   ttk_maxpool3x3s2_bwd   g[B][H][W][C] = gradient w.r.t. bn(y) (ReLU mask applied) from ga (+ gb) w.r.t. the pooled
  *                          activation; part[ttk_partial_rows_elementwise(B*H*W*C/4)][2][C] = (sum g, sum g*(y-mean))
  *   ttk_bn_add_act         a = relu(bn(y) + r); r = res, or res_bn(res) when res is the raw downsample-conv output
- *                          (BasicBlock: out = relu(bn2(conv2) + identity)), or nothing.  Raises
- *                          bn[TTK_BN_AUX][TTK_AUX_ACT_BOUND] to max a (the a_bound of the convolutions that read a).
+ *                          (BasicBlock: out = relu(bn2(conv2) + identity)), or nothing.  bn[TTK_BN_AUX][TTK_AUX_ACT_BOUND]
+ *                          becomes the a_bound of the convolutions that read a: measure == 0 (training) - the bound of
+ *                          relu(bn(y)) that ttk_bn_fwd_finalize left there, plus *res_bound (bound of r: the shortcut
+ *                          activation's a_bound, or res_bn's TTK_AUX_ACT_BOUND slot; NULL without r); measure != 0
+ *                          (eval: no batch statistics) - raised to the measured max a.
  *   ttk_bn_bwd_apply       dy = ga*(g-gmean) + gb*(y-mean), materialised once for a convolution's two gradients
  *   ttk_residual_bwd       gs = (ga (+ gb)) * [a > 0]; part = sums for bn(y); partd (with yd, bnd) = sums for the
  *                          downsample BatchNorm; rows of both = ttk_partial_rows_elementwise(rows*C/4).  Raises
@@ -271,8 +277,8 @@ int ttk_maxpool3x3s2_fwd(const float* y, float* bn, float* a, unsigned char* idx
                          ttk_stream_t stream);
 int ttk_maxpool3x3s2_bwd(const float* ga, const float* gb, const unsigned char* idx, const float* y, const float* bn,
                          float* g, float* part, int B, int H, int W, int C, ttk_stream_t stream);
-int ttk_bn_add_act(const float* y, float* bn, const float* res, const float* res_bn, float* a, int64_t rows,
-                   int C, ttk_stream_t stream);
+int ttk_bn_add_act(const float* y, float* bn, const float* res, const float* res_bn, float* a, const float* res_bound,
+                   int measure, int64_t rows, int C, ttk_stream_t stream);
 int ttk_bn_bwd_apply(const float* g, const float* y, const float* bn, float* dy, int64_t rows, int C, ttk_stream_t stream);
 int ttk_residual_bwd(const float* ga, const float* gb, const float* a, const float* y, float* bn, const float* yd,
                      float* bnd, float* gs, float* part, float* partd, int64_t rows, int C, ttk_stream_t stream);

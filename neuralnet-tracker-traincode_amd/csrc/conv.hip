@@ -69,6 +69,62 @@ __global__ void conv_weight_repack16_k(const float* __restrict__ w, uint16_t* __
   }
 }
 
+// ---- all convolutions' weight operands in three launches (ttk_conv_prepare_weights) ----
+constexpr int kConvPrepMax = 24;
+constexpr int kConvPrepChunk = 2048;  // weights per workgroup
+struct ConvPrepArgs {
+  const float* w[kConvPrepMax];
+  uint16_t* wf[kConvPrepMax];
+  uint16_t* wb[kConvPrepMax];
+  int cout[kConvPrepMax], cin[kConvPrepMax], taps[kConvPrepMax];
+  int first_chunk[kConvPrepMax + 1];
+  int n;
+};
+__device__ __forceinline__ int conv_prep_layer(const ConvPrepArgs& a) {
+  int l = 0;
+  while (l + 1 < a.n && (int)blockIdx.x >= a.first_chunk[l + 1]) ++l;
+  return l;
+}
+__device__ __forceinline__ float* conv_prep_hdr(const ConvPrepArgs& a, int l, bool fwd) {
+  const int64_t n = (int64_t)a.cout[l] * a.cin[l] * a.taps[l];
+  return reinterpret_cast<float*>((fwd ? a.wf[l] : a.wb[l]) + 2 * n);
+}
+__global__ void conv_prepare_zero_k(ConvPrepArgs a) {
+  const int l = threadIdx.x;
+  if (l < a.n) *conv_prep_hdr(a, l, a.wf[l] != nullptr) = 0.f;
+}
+__global__ void __launch_bounds__(256) conv_prepare_absmax_k(ConvPrepArgs a) {
+  const int l = conv_prep_layer(a);
+  const int64_t n = (int64_t)a.cout[l] * a.cin[l] * a.taps[l], i0 = (int64_t)(blockIdx.x - a.first_chunk[l]) * kConvPrepChunk;
+  float m = 0.f;
+  for (int64_t i = i0 + threadIdx.x; i < i0 + kConvPrepChunk && i < n; i += 256) m = fmaxf(m, fabsf(a.w[l][i]));
+  wave_raise_max(conv_prep_hdr(a, l, a.wf[l] != nullptr), m);
+}
+__global__ void __launch_bounds__(256) conv_prepare_repack_k(ConvPrepArgs a) {
+  const int l = conv_prep_layer(a);
+  const int Cout = a.cout[l], Cin = a.cin[l], T = a.taps[l];
+  const int64_t n = (int64_t)Cout * Cin * T, i0 = (int64_t)(blockIdx.x - a.first_chunk[l]) * kConvPrepChunk;
+  uint16_t *wf = a.wf[l], *wb = a.wb[l];
+  const float mx = *conv_prep_hdr(a, l, wf != nullptr);
+  if (i0 == 0 && threadIdx.x == 0 && wf && wb) *conv_prep_hdr(a, l, false) = mx;  // the data-gradient operand's copy of the header
+  const float sc = pow2_scale(mx);
+  for (int64_t i = i0 + threadIdx.x; i < i0 + kConvPrepChunk && i < n; i += 256) {
+    const int t = (int)(i % T), ci = (int)((i / T) % Cin), co = (int)(i / ((int64_t)T * Cin));
+    const float x = a.w[l][i] * sc;
+    const _Float16 hh = (_Float16)x;
+    const _Float16 ll = (_Float16)(x - (float)hh);
+    const uint16_t h = __builtin_bit_cast(uint16_t, hh), lo = __builtin_bit_cast(uint16_t, ll);
+    if (wf) {
+      const size_t o = ((size_t)(t * (Cin >> 5) + (ci >> 5)) * Cout + co) * 32 + (ci & 31);
+      wf[o] = h; wf[n + o] = lo;
+    }
+    if (wb) {
+      const size_t o = ((size_t)(t * (Cout >> 5) + (co >> 5)) * Cin + ci) * 32 + (co & 31);
+      wb[o] = h; wb[n + o] = lo;
+    }
+  }
+}
+
 static bool conv_shape_ok(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
   return B > 0 && H > 0 && W > 0 && Cin >= 32 && Cin % 32 == 0 && Cout >= 64 && Cout % 64 == 0 && KH == KW && (KH == 1 || KH == 3) &&
          (stride == 1 || stride == 2) && pad == KH / 2;
@@ -95,6 +151,35 @@ int ttk_conv_weight_repack(const float* w, void* w_fwd, void* w_bwd, int Cout, i
   hipLaunchKernelGGL(conv_weight_repack_k, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_fwd, (uint16_t*)w_bwd,
                      Cout, Cin, KH * KW);
   TTK_LAUNCH_CHECK("conv_weight_repack");
+}
+
+int ttk_conv_prepare_weights(int n, const float* const* w, void* const* w_fwd, void* const* w_bwd, const int* cout, const int* cin,
+                             const int* ksize, ttk_stream_t stream) {
+  TTK_REQUIRE(n > 0 && n <= kConvPrepMax && w && w_fwd && w_bwd && cout && cin && ksize, "conv_prepare_weights: bad arguments (at most %d tensors)", kConvPrepMax);
+  for (int i = 0; i < n; ++i)
+    TTK_REQUIRE(w[i] && (w_fwd[i] || w_bwd[i]) && cout[i] > 0 && cin[i] > 0 && cout[i] % 32 == 0 && cin[i] % 32 == 0 && (ksize[i] == 1 || ksize[i] == 3),
+                "conv_prepare_weights: bad tensor %d", i);
+  if (gemm_mode() != GEMM_F16X2) {  // the bf16 comparison path: tensor by tensor
+    for (int i = 0; i < n; ++i) {
+      const int rc = ttk_conv_weight_repack(w[i], w_fwd[i], w_bwd[i], cout[i], cin[i], ksize[i], ksize[i], stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  ConvPrepArgs a;
+  a.n = n;
+  int chunks = 0;
+  for (int i = 0; i < n; ++i) {
+    a.w[i] = w[i]; a.wf[i] = (uint16_t*)w_fwd[i]; a.wb[i] = (uint16_t*)w_bwd[i];
+    a.cout[i] = cout[i]; a.cin[i] = cin[i]; a.taps[i] = ksize[i] * ksize[i];
+    a.first_chunk[i] = chunks;
+    chunks += (int)ceil_div((int64_t)cout[i] * cin[i] * a.taps[i], kConvPrepChunk);
+  }
+  a.first_chunk[n] = chunks;
+  hipLaunchKernelGGL(conv_prepare_zero_k, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(conv_prepare_absmax_k, dim3(chunks), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(conv_prepare_repack_k, dim3(chunks), dim3(256), 0, (hipStream_t)stream, a);
+  TTK_LAUNCH_CHECK("conv_prepare_weights");
 }
 
 int ttk_conv_fwd(const float* a_in, const float* a_bound, const void* w_fwd, float* y, float* part, int B, int H, int W, int Cin, int Cout,

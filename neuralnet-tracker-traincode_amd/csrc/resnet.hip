@@ -170,7 +170,8 @@ __global__ void __launch_bounds__(kBlock) maxpool_bwd_k(const float* __restrict_
 // a = relu(bn(y) + r), r = res (an activation) or res_bn(res) (a raw conv output, the downsample branch) or nothing
 __global__ void __launch_bounds__(kBlock) bn_add_act_k(const float* __restrict__ y, float* __restrict__ bnp,
                                                         const float* __restrict__ res, const float* __restrict__ res_bn,
-                                                        float* __restrict__ a, int64_t items, int C) {
+                                                        float* __restrict__ a, const float* __restrict__ res_bound, int measure,
+                                                        int64_t items, int C) {
   const int quads = C >> 2;
   const int c4 = threadIdx.x & (quads - 1);
   const BnApply4 bn = BnApply4::load(bnp, C, 4 * c4);
@@ -183,9 +184,14 @@ __global__ void __launch_bounds__(kBlock) bn_add_act_k(const float* __restrict__
     if (res) v = add4(v, res_bn ? rb.pre(ld4(res + off)) : ld4(res + off));
     v = relu4(v);
     st4(a + off, v);
-    amax = fmaxf(amax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+    if (measure) amax = fmaxf(amax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
   }
-  wave_raise_max(bnp + (size_t)TTK_BN_AUX * C + TTK_AUX_ACT_BOUND, amax);  // the bound the consuming convolutions scale a by
+  // The bound the consuming convolutions scale a by.  Training: relu(bn(y) + r) <= bound(relu(bn(y))) + bound(r), both already
+  // known from the batch statistics (ttk_bn_fwd_finalize) - measuring the maximum instead cost as much as the pass itself
+  // (tens of thousands of waves finishing together and racing for one atomic).  Without statistics (eval): the measured maximum.
+  float* slot = bnp + (size_t)TTK_BN_AUX * C + TTK_AUX_ACT_BOUND;
+  if (measure) wave_raise_max(slot, amax);
+  else if (res_bound && blockIdx.x == 0 && threadIdx.x == 0) *slot += *res_bound;  // nothing else touches the slot during this launch
 }
 
 // dy = ga*(g-gmean) + gb*(y-mean): the gradient w.r.t. a conv output through its BatchNorm, written once for the
@@ -291,14 +297,14 @@ int ttk_maxpool3x3s2_bwd(const float* ga, const float* gb, const unsigned char* 
   TTK_LAUNCH_CHECK("maxpool3x3s2_bwd");
 }
 
-int ttk_bn_add_act(const float* y, float* bn, const float* res, const float* res_bn, float* a, int64_t rows, int C,
-                   ttk_stream_t stream) {
+int ttk_bn_add_act(const float* y, float* bn, const float* res, const float* res_bn, float* a, const float* res_bound, int measure,
+                   int64_t rows, int C, ttk_stream_t stream) {
   TTK_REQUIRE(y && bn && a && (res || !res_bn), "bn_add_act: bad arguments");
   TTK_REQUIRE(ew_shape_ok(rows, C), "bn_add_act: unsupported shape rows=%lld C=%d", (long long)rows, C);
   const int64_t items = rows * (C / 4);
   int64_t grid = ceil_div(items, kBlock);
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(bn_add_act_k, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, y, bn, res, res_bn, a, items, C);
+  hipLaunchKernelGGL(bn_add_act_k, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, y, bn, res, res_bn, a, res_bound, measure, items, C);
   TTK_LAUNCH_CHECK("bn_add_act");
 }
 

@@ -38,10 +38,11 @@ _SIGNATURES = {
     "ttk_stem7_bwd_weight": [_P, _P, _P, _P, _P, _I, _I, _I],
     "ttk_maxpool3x3s2_fwd": [_P, _P, _P, _P, _I, _I, _I, _I],
     "ttk_maxpool3x3s2_bwd": [_P] * 7 + [_I] * 4,
-    "ttk_bn_add_act": [_P, _P, _P, _P, _P, _L, _I],
+    "ttk_bn_add_act": [_P, _P, _P, _P, _P, _P, _I, _L, _I],
     "ttk_residual_bwd": [_P] * 10 + [_L, _I],
     "ttk_bn_bwd_apply": [_P, _P, _P, _P, _L, _I],
     "ttk_conv_weight_repack": [_P, _P, _P, _I, _I, _I, _I],
+    "ttk_conv_prepare_weights": [_I, _P, _P, _P, _P, _P, _P],
     "ttk_conv_fwd": [_P, _P, _P, _P, _P] + [_I] * 9,
     "ttk_conv_bwd_data": [_P] * 8 + [_I] * 9,
     "ttk_conv_bwd_weight": [_P] * 7 + [_I] * 9,
@@ -137,6 +138,14 @@ class _Library:
     def pwconv_wgrad_partial_bytes(self, m: int, cin: int, cout: int) -> int:
         """Scratch bytes of the deterministic (fixed-order) weight-gradient reduction; 0 = this shape has none."""
         return self.cdll.ttk_pwconv_wgrad_partial_bytes(m, cin, cout)
+
+    def conv_prepare_weights(self, weights, w_fwd, w_bwd):
+        """ttk_conv_prepare_weights: `weights[i]` [Cout, Cin, k, k] fp32, `w_fwd[i]` / `w_bwd[i]` int16 buffers of 3 * numel
+        elements (either may be None)."""
+        n = len(weights)
+        PA, IA = c_void_p * n, c_int * n
+        self.call("ttk_conv_prepare_weights", n, PA(*[ptr(w) for w in weights]), PA(*[ptr(t) for t in w_fwd]), PA(*[ptr(t) for t in w_bwd]),
+                  IA(*[int(w.shape[0]) for w in weights]), IA(*[int(w.shape[1]) for w in weights]), IA(*[int(w.shape[2]) for w in weights]))
 
     def pwconv_prepare_weights(self, weights, prepared):
         """One launch: forward and data-gradient weight operands of every pointwise layer (`weights[i]`: [Cout, Cin(,1,1)]

@@ -66,7 +66,7 @@ class _Ctx:
 
 class _Blk:
     """What one BasicBlock leaves behind for backward."""
-    __slots__ = ("a_in", "a_bn", "y1", "bn1", "a_mid", "y2", "bn2", "yd", "bnd", "a_out", "h", "ho", "cin", "cout", "stride", "w1b", "w2b")
+    __slots__ = ("a_in", "a_bn", "y1", "bn1", "a_mid", "y2", "bn2", "yd", "bnd", "a_out", "h", "ho", "cin", "cout", "stride", "w1b", "w2b", "wdb")
 
 
 def _part_buffers(B, device):
@@ -92,7 +92,6 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
     c.part, c.partd = _part_buffers(B, dev)
     part = c.part
     new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-    newq = lambda *s: torch.empty((3,) + s, dtype=torch.int16, device=dev)  # pre-split weight operands (2 fp16 planes + header | 3 bf16 planes)
     bi = [0]
     # every BatchNorm block of the step from one zeroed allocation (the kernels raise the bounds of row TTK_BN_AUX with atomicMax)
     from .mobilenet_v1 import _BnArena
@@ -120,6 +119,22 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
     c.idx = torch.empty((B, h, h, 64), dtype=torch.uint8, device=dev)
     L.call("ttk_maxpool3x3s2_fwd", p(c.y0), p(c.bn0), p(c.a1), p(c.idx), B, Ho, Ho, 64)
 
+    # forward and data-gradient operands of all 19 convolution weights: one allocation, three launches
+    convs, cin, pi = [], 64, 3
+    for planes, stride in _PLAN:
+        has_ds = stride != 1 or cin != planes
+        convs += [params[pi], params[pi + 3]] + ([params[pi + 6]] if has_ds else [])
+        pi += 9 if has_ds else 6
+        cin = planes
+    pool = torch.empty(sum(6 * w.numel() for w in convs), dtype=torch.int16, device=dev)  # 6 bytes per weight and operand (2 fp16 planes + header | 3 bf16 planes), two operands
+    wops, off = [], 0
+    for w in convs:
+        n3 = 3 * w.numel()
+        wops.append((pool[off:off + n3], pool[off + n3:off + 2 * n3]))
+        off += 2 * n3
+    L.conv_prepare_weights(convs, [f for f, _ in wops], [b for _, b in wops])
+    wops = iter(wops)
+
     a_in, a_bn, cin, pi = c.a1, c.bn0, 64, 3
     c.blocks = []
     for bidx, (planes, stride) in enumerate(_PLAN):
@@ -131,16 +146,15 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
         ho = (h - 1) // stride + 1
         k.ho = ho
         M = B * ho * ho
-        w1f, k.w1b = newq(9, planes, cin), newq(9, cin, planes)
-        L.call("ttk_conv_weight_repack", p(w1), p(w1f), p(k.w1b), planes, cin, 3, 3)
+        w1f, k.w1b = next(wops)
+        w2f, k.w2b = next(wops)
+        wdf, k.wdb = next(wops) if has_ds else (None, None)
         k.y1 = new(B, ho, ho, planes)
         L.call("ttk_conv_fwd", p(a_in), bound(a_bn), p(w1f), p(k.y1), p(part), B, h, h, cin, planes, 3, 3, stride, 1)
         k.bn1 = _bn_work(planes, dev)
         finalize(k.bn1, L.partial_rows_gemm(M), planes, M, g1, b1)
         k.a_mid = new(B, ho, ho, planes)
-        L.call("ttk_bn_add_act", p(k.y1), p(k.bn1), None, None, p(k.a_mid), M, planes)
-        w2f, k.w2b = newq(9, planes, planes), newq(9, planes, planes)
-        L.call("ttk_conv_weight_repack", p(w2), p(w2f), p(k.w2b), planes, planes, 3, 3)
+        L.call("ttk_bn_add_act", p(k.y1), p(k.bn1), None, None, p(k.a_mid), None, int(not training), M, planes)
         k.y2 = new(B, ho, ho, planes)
         L.call("ttk_conv_fwd", p(k.a_mid), bound(k.bn1), p(w2f), p(k.y2), p(part), B, ho, ho, planes, planes, 3, 3, 1, 1)
         k.bn2 = _bn_work(planes, dev)
@@ -149,8 +163,6 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
         if has_ds:
             wd, gd, bd = params[pi:pi + 3]
             pi += 3
-            wdf = newq(1, planes, cin)
-            L.call("ttk_conv_weight_repack", p(wd), p(wdf), None, planes, cin, 1, 1)
             k.yd = new(B, ho, ho, planes)
             L.call("ttk_conv_fwd", p(a_in), bound(a_bn), p(wdf), p(k.yd), p(part), B, h, h, cin, planes, 1, 1, stride, 0)
             k.bnd = _bn_work(planes, dev)
@@ -158,7 +170,8 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
         last = bidx == len(_PLAN) - 1
         if not last:  # the last block's output is only pooled: relu(bn2(y2) + identity) is formed inside the pooling kernel
             k.a_out = new(B, ho, ho, planes)
-            L.call("ttk_bn_add_act", p(k.y2), p(k.bn2), p(k.yd if has_ds else a_in), p(k.bnd) if has_ds else None, p(k.a_out), M, planes)
+            L.call("ttk_bn_add_act", p(k.y2), p(k.bn2), p(k.yd if has_ds else a_in), p(k.bnd) if has_ds else None, p(k.a_out),
+                   bound(k.bnd if has_ds else a_bn), int(not training), M, planes)
             a_in, a_bn = k.a_out, k.bn2
         else:
             k.a_out = None
@@ -252,10 +265,8 @@ def _backward_impl(c: _Ctx, gfeat, params):
         del dy1
         if has_ds:
             L.call("ttk_conv_bwd_weight", p(gs), p(k.yd), p(k.bnd), p(k.a_in), bound(k.a_bn), p(grads[pi + 6]), p(wscratch), B, k.h, k.h, k.cin, C, 1, 1, k.stride, 0)
-            wdb = torch.empty((3, 1, k.cin, C), dtype=torch.int16, device=dev)
-            L.call("ttk_conv_weight_repack", p(params[pi + 6]), None, p(wdb), C, k.cin, 1, 1)
             g_sc = new(B, k.h, k.h, k.cin)
-            L.call("ttk_conv_bwd_data", p(gs), p(k.yd), p(k.bnd), p(wdb), None, None, p(g_sc), None, B, k.h, k.h, k.cin, C, 1, 1, k.stride, 0)
+            L.call("ttk_conv_bwd_data", p(gs), p(k.yd), p(k.bnd), p(k.wdb), None, None, p(g_sc), None, B, k.h, k.h, k.cin, C, 1, 1, k.stride, 0)
         else:
             g_sc = gs  # identity shortcut
         if bidx > 0:

@@ -117,10 +117,17 @@ def test_bn_add_act_and_residual_bwd(rows, C):
     d_y, d_yd, d_act, d_bn, d_bnd = t(y), t(yd), t(act), t(bn), t(bnd)
     out = torch.empty(rows, C, device=dev)
     for res, res_bn, ref in ((None, None, _pre(bn, y)), (d_act, None, _pre(bn, y) + act), (d_yd, d_bnd, _pre(bn, y) + _pre(bnd, yd))):
-        L.call("ttk_bn_add_act", p(d_y), p(d_bn), p(res), p(res_bn), p(out), rows, C)
+        d_bn[7, 0] = 0.0
+        L.call("ttk_bn_add_act", p(d_y), p(d_bn), p(res), p(res_bn), p(out), None, 1, rows, C)  # measure: eval mode
         torch.cuda.synchronize()
         np.testing.assert_allclose(out.cpu().numpy(), np.maximum(ref, 0), rtol=1e-5, atol=1e-6)
-        assert float(d_bn[7, 0]) >= float(out.max())  # TTK_AUX_ACT_BOUND raised to the maximum of what was written
+        assert float(d_bn[7, 0]) == float(out.max())  # TTK_AUX_ACT_BOUND raised to the maximum of what was written
+        d_bn[7, 0] = 2.5  # training: the bound of relu(bn(y)) from the statistics + the bound of the residual
+        rb = torch.tensor([1.25], device=dev)
+        L.call("ttk_bn_add_act", p(d_y), p(d_bn), p(res), p(res_bn), p(out), p(rb) if res is not None else None, 0, rows, C)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out.cpu().numpy(), np.maximum(ref, 0), rtol=1e-5, atol=1e-6)
+        assert float(d_bn[7, 0]) == (3.75 if res is not None else 2.5)
     ga, gb = rng.normal(0, 1, (rows, C)).astype(np.float32), rng.normal(0, 1, (rows, C)).astype(np.float32)
     d_ga, d_gb = t(ga), t(gb)
     prow = L.partial_rows_elementwise(rows * (C // 4))

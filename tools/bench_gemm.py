@@ -29,11 +29,13 @@ for name, hw, ci, co, mult in shapes:
     out, gdw, dW = torch.empty(M, co, device=dev, dtype=ADT), torch.empty(M, ci, device=dev, dtype=ADT), torch.zeros(co, ci, device=dev)
     prep = torch.empty(L.pwconv_prepared_bytes(ci, co), dtype=torch.uint8, device=dev)
     L.pwconv_prepare_weights([w], [prep])
+    nb = L.pwconv_wgrad_partial_bytes(M, ci, co) if os.environ.get("PARTIAL") else 0  # PARTIAL=1: slice partials + fixed-order fold instead of atomics
+    scr = torch.empty(nb // 4, device=dev) if nb else None
     part = torch.empty(L.partial_rows_gemm(M) * 2 * max(ci, co), device=dev)
     calls = {
         "fwd": lambda: L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(out), p(part), M, ci, co, p(prep), BF),
         "dgrad": lambda: L.call("ttk_pwconv1x1_bwd_data", p(g), p(y), p(bn_pw), None, p(ydw), p(bn_dw), p(gdw), p(part), M, ci, co, p(prep), BF),
-        "wgrad": lambda: L.call("ttk_pwconv1x1_bwd_weight", p(g), p(y), p(bn_pw), p(ydw), p(bn_dw), p(dW), None, M, ci, co, BF),
+        "wgrad": lambda: L.call("ttk_pwconv1x1_bwd_weight", p(g), p(y), p(bn_pw), p(ydw), p(bn_dw), p(dW), p(scr), M, ci, co, BF),
     }
     line = f"{name:6s} M={M:8d} K={ci:4d} N={co:4d} "
     for k, fn in calls.items():
