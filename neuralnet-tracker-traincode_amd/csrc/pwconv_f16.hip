@@ -74,7 +74,7 @@ __device__ __forceinline__ f32x4 ld_act4(const T* p) {
 
 // The consumer side of one block tile: `nks` super-stages (k32) of ds_read_b128 fragments + 3-product MFMAs into
 // acc[TM][TN].  Executes exactly 1 + nks barriers (matching the producers).
-template <int BM, int BN, int RS>
+template <int BM, int BN, int RS, int STRIDE = kStride16>
 __device__ __forceinline__ void consume_tile16(const unsigned char* lds, int nks, int wm, int wn, int r, int h,
                                                f32x16 (&acc)[BM / 64][BN / 64], long long* barrier_wait = nullptr) {
   constexpr int APL = BM * 32, BPL = BN * 32;
@@ -106,7 +106,7 @@ __device__ __forceinline__ void consume_tile16(const unsigned char* lds, int nks
     const int slot_n = slot + 1 == RS ? 0 : slot + 1;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
-      const unsigned char* S = lds + (slot * 2 + sub) * kStride16;
+      const unsigned char* S = lds + (slot * 2 + sub) * STRIDE;
       if (RS == 2 && sub == 0) fetch_first(S, hold, strm[0]);  // first stage after the barrier: nothing could be prefetched across it
 #pragma unroll
       for (int x = 0; x < TS; ++x) {
@@ -115,9 +115,9 @@ __device__ __forceinline__ void consume_tile16(const unsigned char* lds, int nks
 #pragma unroll
           for (int p = 0; p < 2; ++p) strm[cur ^ 1][p] = *reinterpret_cast<const f16x8*>(S + p * SPL + strm_off[x + 1]);
         } else if (sub == 0) {
-          fetch_first(S + kStride16, hold_n, strm[cur ^ 1]);
+          fetch_first(S + STRIDE, hold_n, strm[cur ^ 1]);
         } else if (RS == 3) {
-          if (it + 1 < nks) fetch_first(lds + slot_n * 2 * kStride16, hold_n, strm[cur ^ 1]);  // complete since the previous barrier
+          if (it + 1 < nks) fetch_first(lds + slot_n * 2 * STRIDE, hold_n, strm[cur ^ 1]);  // complete since the previous barrier
         }
         // three piece products, smallest first; (pa, pb) index the A and B pieces (0 = h, 1 = l)
 #define TTK_PROD16(pa, pb)                                                                                      \
@@ -186,12 +186,12 @@ __device__ __forceinline__ void producer_schedule(int nks, Prefetch&& prefetch, 
 // K = taps * geo.Kc, the BatchNorm block of the A operand has geo.Kc channels; AMODE_PLAIN: A0 is a materialised
 // activation whose bound is *a_bound; the masked epilogue raises bnE[TTK_BN_AUX][TTK_AUX_GMAX] to max |out|.
 template <int BM, int BN, int AMODE, int EMODE, int D, typename T, typename TO, bool GATHER = false>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BM + BN <= 256 ? 4 : 2, BM + BN <= 256 ? 4 : 2)))
 pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restrict__ bnA,
        const uint16_t* __restrict__ Bq, const float* __restrict__ wmax, TO* __restrict__ out, const T* __restrict__ E0,
        float* __restrict__ bnE, float* __restrict__ part, int64_t M, int K, int Nout, const float* __restrict__ a_bound,
        ConvGeom geo) {
-  static_assert((BM == 128 && BN == 256) || (BM == 256 && BN == 128) || (BM == 256 && BN == 64), "tile shapes");
+  static_assert((BM == 128 && BN == 256) || (BM == 256 && BN == 128) || (BM == 256 && BN == 64) || (BM == 128 && BN == 64), "tile shapes");
   static_assert(GATHER || AMODE != AMODE_PLAIN, "plain A operands come from the convolutions");
   constexpr int RS = TTK_RS;
   constexpr int APL = BM * 32, BPL = BN * 32;  // bytes of one piece plane of a k16 stage
@@ -199,7 +199,10 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
   constexpr int LDC = BN + 4;
   constexpr int QN = BN / 4, RG = 512 / QN, HALVES = BM / 128, RGH = RG / HALVES, EI = 128 / RGH;
   constexpr int kEpiBytes = BM * LDC * 4 + RG * 2 * BN * 4;
-  constexpr int kSmemBytes = ring_bytes(RS) > kEpiBytes ? ring_bytes(RS) : kEpiBytes;
+  // small tiles: a smaller ring, so that two workgroups share a CU (twice the producer waves, and one's prologue / epilogue
+  // under the other's main loop)
+  constexpr int kStr = BM + BN <= 256 ? 64 * (BM + BN) + 64 : kStride16;
+  constexpr int kSmemBytes = RS * 2 * kStr > kEpiBytes ? RS * 2 * kStr : kEpiBytes;
   __shared__ __attribute__((aligned(16))) unsigned char lds[kSmemBytes];
 
   const int tid = threadIdx.x;
@@ -268,9 +271,9 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
     const int brow = pt >> 2, bc4 = pt & 3;
     const uint16_t* bp = Bq + (int64_t)(n0 + brow) * 32 + bc4 * 8;
     const int64_t bplane = (int64_t)K * Nout;
-    unsigned char* wbase_b = lds + (bc4 >> 1) * kStride16 + 2 * APL;
+    unsigned char* wbase_b = lds + (bc4 >> 1) * kStr + 2 * APL;
     const float* cp = AMODE == AMODE_PLAIN ? nullptr : bnA + kq8 * 4;
-    unsigned char* wbase = lds + sub * kStride16 + o8;
+    unsigned char* wbase = lds + sub * kStr + o8;
 
     auto load_a = [&](int ks, auto setc) {
       constexpr int set = decltype(setc)::value;
@@ -346,7 +349,7 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
 #if defined(TTK_EXP) && (TTK_EXP == 6 || TTK_EXP == 7)
       if (ks >= D) return;  // timing experiment: no conversion / LDS writes
 #endif
-      unsigned char* S = wbase + (ks % RS) * 2 * kStride16;
+      unsigned char* S = wbase + (ks % RS) * 2 * kStr;
       // the scale S_a rides on the per-channel constants (exact: a power of two)
       f32x4 c0, c2;
       if constexpr (AMODE != AMODE_PLAIN) { c0 = q[set][0] * sa; c2 = q[set][2] * sa; }
@@ -371,7 +374,7 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
 #if defined(TTK_EXP) && (TTK_EXP == 6 || TTK_EXP == 8)
       if (ks >= D) return;  // timing experiment
 #endif
-      unsigned char* S = wbase_b + (ks % RS) * 2 * kStride16;
+      unsigned char* S = wbase_b + (ks % RS) * 2 * kStr;
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -428,7 +431,7 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
     const long long c0 = __builtin_readcyclecounter();
     const long long t0 = __builtin_amdgcn_s_memrealtime();
     long long bwait = 0;
-    consume_tile16<BM, BN, RS>(lds, nks, wm, wn, r, h, acc, &bwait);
+    consume_tile16<BM, BN, RS, kStr>(lds, nks, wm, wn, r, h, acc, &bwait);
     if (tile == 0 && tid == 0 && part) {
       float* dbg = part + (size_t)ceil_div(M, 128) * 2 * Nout;
       dbg[0] = (float)(__builtin_readcyclecounter() - c0);
@@ -437,7 +440,7 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
       dbg[3] = (float)bwait;
     }
 #else
-    consume_tile16<BM, BN, RS>(lds, nks, wm, wn, r, h, acc);
+    consume_tile16<BM, BN, RS, kStr>(lds, nks, wm, wn, r, h, acc);
 #endif
     // ---- accumulators -> LDS image [BM][LDC] (the ring is dead: the loop ended with a barrier)
     float* Cs = reinterpret_cast<float*>(lds);
@@ -546,17 +549,20 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
 // APLAIN (convolutions): G already holds dy (ttk_bn_bwd_apply materialised it once for the weight and the data gradient:
 // half the A bytes through the L1 and no BatchNorm arithmetic here); Y is not read.
 template <int BM, int BN, int D, typename T, typename TG, bool CONV = false, bool APLAIN = false>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(CONV && BM + BN <= 256 ? 4 : 2, CONV && BM + BN <= 256 ? 4 : 2)))
 pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __restrict__ bn_pw,
              const T* __restrict__ X, const float* __restrict__ bn_x, float* __restrict__ dW, float* __restrict__ partial,
              int64_t M, int Cin, int Cout, int64_t rows_per_slice, const float* __restrict__ x_bound, ConvGeom geo) {
-  static_assert(!CONV || D == 1, "the convolution producers carry their pixel from step to step");
-  static_assert((BM + BN == 384 && (BM == 128 || BM == 256)) || (BM == 128 && BN == 128) || (CONV && BM == 64 && BN == 256),
-                "128x256, 256x128, 128x128 or (convolutions) 64x256");
+  static_assert((BM + BN == 384 && (BM == 128 || BM == 256)) || (BM == 128 && BN == 128) || (CONV && BM == 64 && (BN == 256 || BN == 192)),
+                "128x256, 256x128, 128x128 or (convolutions) 64x256, 64x192");
   constexpr int RS = TTK_RS;
   constexpr int APL = BM * 32, BPL = BN * 32;
   constexpr int TM = BM / 64, TN = BN / 64;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[ring_bytes(RS)];
+  // small convolution tiles: a smaller ring, so that two workgroups share a CU (twice the producer waves - their VALU work
+  // bounds these tiles; measured 439 -> 312 us on ResNet layer1.  The pointwise 128x128 tile of the MobileNet backbone
+  // does NOT gain: 139 -> 189 us with the 128 registers that leaves per wave)
+  constexpr int kStr = CONV && BM + BN <= 256 ? 64 * (BM + BN) + 64 : kStride16;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RS * 2 * kStr];
 
   const int tid = threadIdx.x;
   // XCD-aware order: give each XCD whole slices (all dW tiles of a slice run side by side on ONE L2, so the slice's
@@ -581,7 +587,7 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
     const int pt = tid - 256;
     const int mb = pt & 7, cq = pt >> 3;  // 8 row blocks of 4 rows x 32 channel quads per pass
     const int sub = mb >> 2, chunk = (mb >> 1) & 1, o8 = (mb & 1) * 8;
-    constexpr int AP = BM >= 128 ? BM / 128 : 1, BP = BN / 128;
+    constexpr int AP = BM >= 128 ? BM / 128 : 1, BP = (BN + 127) / 128;
     f32x4 rg[D][AP][4], ry[D][APLAIN ? 1 : AP][4], rx[D][BP][4];
     f32x4 ga[AP], gb[AP], gmean[AP], ymean[AP], sc[BP], mu[BP], be[BP];
     int ca[AP], cb[BP];
@@ -609,7 +615,7 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
       cb[p] = k0 + 4 * (cq + 32 * p);
       vb[p] = true;
       if constexpr (CONV) {
-        vb[p] = cb[p] < Cin;
+        vb[p] = cb[p] < Cin && 4 * (cq + 32 * p) < BN;  // (a 192-column tile ends inside the second pass)
         const int cc = vb[p] ? cb[p] : 0, tap = cc / Kc;
         cb[p] = cc - tap * Kc;
         kh[p] = tap / geo.KW;
@@ -620,7 +626,7 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
         be[p] = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_BETA * Cin + cb[p]) * sb;
       }
     }
-    unsigned char* wbase = lds + sub * kStride16 + o8;
+    unsigned char* wbase = lds + sub * kStr + o8;
 
     // Steps whose 32 rows all lie inside the slice (all but possibly the last one) take a path without row clamps and
     // zero fills.
@@ -691,7 +697,7 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
       if constexpr (CONV) {
         // The producers' instruction count IS this kernel's speed (a first version with two divisions per step,
         // 64-bit offsets and branches for the carries ran at 10 k cycles per step, 6 x the MFMA time): the pixel of
-        // the thread's first row is carried from step to step (the calls come in step order, D == 1), the other three
+        // the thread's first row is carried from call to call (they come in step order for every D), the other three
         // rows by branch-free carries, the offsets are 32-bit (the host checks the tensor size) and split into a
         // per-row part and a per-column-group constant.
         unsigned bm = 0u;
@@ -747,7 +753,7 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
     };
     auto store_a = [&](int ks, auto setc) {
       constexpr int set = decltype(setc)::value;
-      unsigned char* S = wbase + (ks % RS) * 2 * kStride16;
+      unsigned char* S = wbase + (ks % RS) * 2 * kStr;
       const int64_t row0 = m_begin + (int64_t)ks * 32 + 4 * mb;
       const bool masked = ks >= nfull;  // uniform
 #if defined(TTK_EXP) && (TTK_EXP == 13)
@@ -775,7 +781,7 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
     };
     auto store_b = [&](int ks, auto setc) {
       constexpr int set = decltype(setc)::value;
-      unsigned char* S = wbase + (ks % RS) * 2 * kStride16 + 2 * APL;
+      unsigned char* S = wbase + (ks % RS) * 2 * kStr + 2 * APL;
       const int64_t row0 = m_begin + (int64_t)ks * 32 + 4 * mb;
       const bool masked = ks >= nfull;  // uniform
 #if defined(TTK_EXP) && (TTK_EXP == 13)
@@ -783,6 +789,8 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
 #endif
 #pragma unroll
       for (int p = 0; p < BP; ++p) {
+        if constexpr (BN % 128 != 0)
+          if (4 * (cq + 32 * p) >= BN) continue;  // rows past the tile: not even zeros (the next plane starts there)
         f32x4 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -824,7 +832,7 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    consume_tile16<BM, BN, RS>(lds, nks, wm, wn, r, h, acc);
+    consume_tile16<BM, BN, RS, kStr>(lds, nks, wm, wn, r, h, acc);
     const float inv = 1.f / (sa * sb);
 #if defined(TTK_EXP) && TTK_EXP == 15
     if (acc[0][0][0] != 12345.678f) return;  // timing experiment: no epilogue
@@ -889,8 +897,8 @@ static int f16_wgrad_tiles(int Cin, int Cout) {
 }
 
 // slices of M for the weight gradient: one workgroup per CU, all of equal length
-static void wgrad_slices(int64_t M, int tiles, int64_t& slices, int64_t& rows) {
-  slices = 256 / tiles;
+static void wgrad_slices(int64_t M, int tiles, int64_t& slices, int64_t& rows, int blocks = 256) {
+  slices = blocks / tiles;
   if (slices < 1) slices = 1;
   const int64_t max_slices = ceil_div(M, 128);
   if (slices > max_slices) slices = max_slices;
@@ -986,9 +994,12 @@ bool launch_f16_gemm(const TO* A0, const T* A1, const float* bnA, const float* B
 }
 
 // dw[Cout][Kc][taps] += sum over output pixels of dy (x) gathered input activation (conv.hip)
+// 64 output channels (ResNet layer1: 9 taps x 64 = 576 columns): 64x192 tiles = 3 taps each - no masked quarter as with
+// 256-column tiles, and a tile's taps are the three kw of one kernel row, i.e. the same input rows one pixel apart
+static int conv_wgrad_bn(int Cout, int ncols) { return Cout <= 64 && ncols % 192 == 0 && ncols % 256 != 0 ? 192 : 256; }
 static void conv_wgrad_plan(int64_t M, int Cout, int ncols, int& tiles, int64_t& slices, int64_t& rows) {
-  tiles = (int)(ceil_div(Cout, Cout <= 64 ? 64 : 128) * ceil_div(ncols, 256));
-  wgrad_slices(M, tiles, slices, rows);
+  tiles = (int)(ceil_div(Cout, Cout <= 64 ? 64 : 128) * ceil_div(ncols, conv_wgrad_bn(Cout, ncols)));
+  wgrad_slices(M, tiles, slices, rows, conv_wgrad_bn(Cout, ncols) == 192 ? 512 : 256);  // 64x192 tiles: two workgroups per CU
 }
 size_t conv_wgrad16_partial_bytes(int64_t M, int Cout, int ncols, int taps) {
   if (taps == 1) return 0;  // 1x1: the atomics are coalesced ([co][ci] = the GEMM's layout) and measured faster than the fold
@@ -1010,11 +1021,15 @@ bool launch_conv_wgrad16(const float* g, const float* y, const float* bn, const 
   int64_t slices, rows;
   conv_wgrad_plan(M, Cout, ncols, tiles, slices, rows);
   const dim3 grid(tiles, (unsigned)slices);
-#define TTK_WGRAD_LAUNCH(BM_, PLAIN_)                                                                                                          \
-  hipLaunchKernelGGL((pw16_wgrad_k<BM_, 256, 1, float, float, true, PLAIN_>), grid, dim3(512), 0, st, g, y, bn, a_in, nullptr, dw, partial, M, ncols, \
+#ifndef TTK_DC
+#define TTK_DC 1
+#endif
+#define TTK_WGRAD_LAUNCH(BM_, BN_, PLAIN_)                                                                                                      \
+  hipLaunchKernelGGL((pw16_wgrad_k<BM_, BN_, (BM_ == 64 ? TTK_DC : 1), float, float, true, PLAIN_>), grid, dim3(512), 0, st, g, y, bn, a_in, nullptr, dw, partial, M, ncols, \
                      Cout, rows, a_bound, geo)
-  if (narrow) { if (y) TTK_WGRAD_LAUNCH(64, false); else TTK_WGRAD_LAUNCH(64, true); }
-  else        { if (y) TTK_WGRAD_LAUNCH(128, false); else TTK_WGRAD_LAUNCH(128, true); }
+  if (narrow && conv_wgrad_bn(Cout, ncols) == 192) { if (y) TTK_WGRAD_LAUNCH(64, 192, false); else TTK_WGRAD_LAUNCH(64, 192, true); }
+  else if (narrow) { if (y) TTK_WGRAD_LAUNCH(64, 256, false); else TTK_WGRAD_LAUNCH(64, 256, true); }
+  else             { if (y) TTK_WGRAD_LAUNCH(128, 256, false); else TTK_WGRAD_LAUNCH(128, 256, true); }
 #undef TTK_WGRAD_LAUNCH
   if (partial)
     hipLaunchKernelGGL(conv_wgrad_reduce_k, dim3((unsigned)ceil_div((int64_t)Cout * ncols, 256)), dim3(256), 0, st, partial, dw, Cout, geo.Kc, taps,
@@ -1056,10 +1071,12 @@ bool launch_conv_gemm16(int amode, int emode, const float* A0, const float* A1, 
   do {                                                             \
     if (Nout % 256 == 0) TTK_CONV_LAUNCH(128, 256, AM_, EM_);      \
     else if (Nout % 128 == 0) TTK_CONV_LAUNCH(256, 128, AM_, EM_); \
+    else if (narrow) TTK_CONV_LAUNCH(128, 64, AM_, EM_);           \
     else TTK_CONV_LAUNCH(256, 64, AM_, EM_);                       \
     return true;                                                   \
   } while (0)
   if (Nout % 64 != 0 || geo.Kc % 32 != 0) return false;
+  static const bool narrow = !getenv("TTK_CONV_WIDE64");  // 64 output channels: 128x64 tiles, two workgroups per CU (default) | 256x64
   if (amode == AMODE_PLAIN && emode == EMODE_STATS) TTK_CONV_TILES(AMODE_PLAIN, EMODE_STATS);
   if (amode == AMODE_BNGRAD && emode == EMODE_MASK) TTK_CONV_TILES(AMODE_BNGRAD, EMODE_MASK);
   if (amode == AMODE_BNGRAD && emode == EMODE_PLAIN) TTK_CONV_TILES(AMODE_BNGRAD, EMODE_PLAIN);
