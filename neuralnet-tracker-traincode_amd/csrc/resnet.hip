@@ -5,12 +5,14 @@
 // the dense 3x3 / 1x1 convolutions are in conv.hip.
 #include "ttk_common.h"
 #include "stem_wgrad.h"
+#include <stdlib.h>
 
 namespace ttk {
 
 constexpr int kS7C = 64;      // stem output channels
 constexpr int kS7K = 7;       // 7x7, stride 2, pad 3
 constexpr int kS7Half = 32;   // channels per workgroup column (blockIdx.y)
+constexpr int kS7Wp = 192;    // stem7_fwd_mfma_k: row pitch of a wave's input patch = three 64-lane strips
 
 // thread = TWO horizontally adjacent output pixels x 32 channels (same scheme as stem.hip, see there): the filter
 // bank of this channel half sits in LDS as wt[tap][c] and is read with wave-uniform (broadcast) ds_read_b128.
@@ -83,6 +85,138 @@ __global__ void __launch_bounds__(kBlock) stem7_fwd_k(const float* __restrict__ 
       float a = 0.f;
       for (int i = 0; i < kBlock / kWave; ++i) a += red[i][threadIdx.x];  // fixed wave order
       part[(size_t)blockIdx.x * 2 * kS7C + (size_t)which * kS7C + cbase + c] = a;
+    }
+  }
+}
+
+// The same convolution on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation - an fma
+// chain's accuracy): 13.6 GFLOP at B = 512 ran VALU-bound (0.53 ms) on the kernel above; the output's 92 us of HBM writes
+// are the floor.  One WAVE = 32 consecutive output pixels (row-major inside an image) x 64 channels: the (at most 9)
+// input rows its pixels touch are staged in a private LDS patch [9][Wp] (zero padded), MFMA j multiplies the pixels'
+// values under taps 2j, 2j+1 (lanes 0-31 | 32-63: one ds_read_b32 each, conflict-free at stride 2) with the two filter
+// rows held in registers.  Wave-private LDS: no workgroup barrier in the loop; groups go round-robin over all waves.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(kBlock) stem7_fwd_mfma_k(const float* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ y, float* __restrict__ part, int B, int H, int W,
+                                                            int Ho, int Wo, int PR, int wave_floats) {
+  extern __shared__ __attribute__((aligned(16))) float smem7[];
+  __shared__ float red[kBlock / kWave][2 * kS7C];
+  constexpr int kTaps = kS7K * kS7K, kSteps = (kTaps + 1) / 2;  // 49 taps, 25 MFMAs (the 50th tap has zero weights)
+  constexpr int kLdo = kS7C + 4;                                 // row pitch of the output image in LDS
+  constexpr int Wp = kS7Wp;                                      // row pitch of the input patch (3 zero columns left; W + 7 <= Wp)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, px = lane & 31, half = lane >> 5;
+  float* patch = smem7 + (size_t)wv * wave_floats;  // [PR][Wp] input rows, then (aliased) the [32][kLdo] output image
+  // B operand: lane (n = px, k = half) of MFMA j and channel tile t holds w[32 t + px][2 j + half]
+  float wreg[2][kSteps];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < kSteps; ++j) {
+      const int tap = 2 * j + half;
+      wreg[t][j] = tap < kTaps ? w[(size_t)(32 * t + px) * kTaps + tap] : 0.f;
+    }
+  // LDS offset of the tap of MFMA j relative to the pixel's window origin, for the lower / upper lane half
+  auto toff = [](int j, int hf) {
+    const int tap = 2 * j + hf < kTaps ? 2 * j + hf : 0, kh = tap / kS7K;
+    return kh * Wp + tap - kh * kS7K;
+  };
+  const int hw = Ho * Wo, gpi = (hw + 31) / 32;  // 32-pixel groups per image
+  const int groups = B * gpi, nwaves = (int)gridDim.x * (kBlock / kWave);  // (the host checks B * gpi < 2^31)
+  const int c4 = lane & 15, prow = lane >> 4;  // output pass: 16 lanes x float4 = one pixel's 64 channels, 4 pixels per instruction
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+  // The input rows of a group are fetched into registers one group ahead (27 independent loads in flight under the
+  // previous group's MFMAs and output pass; a load -> LDS-write loop paid one memory latency per element, 13 us per group).
+  // Nine rows x three 64-column strips cover every patch of up to 9 rows x 192 columns; taller patches (narrow images:
+  // 32 pixels span several rows) take further rounds without the overlap.
+  float v[9][3];
+  auto fetch = [&](int g, int r0) {
+    const int n = g / gpi, p0 = (g - n * gpi) * 32, oh0 = p0 / Wo;
+    const float* xn = x + (size_t)n * H * W;
+#pragma unroll
+    for (int rr = 0; rr < 9; ++rr) {
+      const int hi = 2 * oh0 - 3 + r0 + rr;
+      const bool rok = r0 + rr < PR && hi >= 0 && hi < H;
+      const float* xr = xn + (size_t)(rok ? hi : 0) * W;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int wi = lane + 64 * k - 3;
+        const bool ok = rok && wi >= 0 && wi < W;
+        const float t = xr[ok ? wi : 0];  // unconditional (clamped) load: a predicated one is a branch with its own wait
+        v[rr][k] = ok ? t : 0.f;
+      }
+    }
+  };
+  auto stash = [&](int r0) {
+#pragma unroll
+    for (int rr = 0; rr < 9; ++rr)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        patch[(r0 + rr) * Wp + lane + 64 * k] = v[rr][k];  // unconditional: the patch holds whole rounds of 9 rows x 192 columns
+      }
+  };
+  const int g_first = (int)blockIdx.x * (kBlock / kWave) + wv;
+  if (g_first < groups) fetch(g_first, 0);
+  for (int gidx = g_first; gidx < groups; gidx += nwaves) {
+    const int n = gidx / gpi, p0 = (gidx - n * gpi) * 32;
+    const int oh0 = p0 / Wo;
+    __builtin_amdgcn_wave_barrier();  // (same wave, LDS in order) the previous group's output pass is done before the patch is overwritten
+    stash(0);
+    for (int r0 = 9; r0 < PR; r0 += 9) { fetch(gidx, r0); stash(r0); }
+#if !(defined(S7_EXP) && S7_EXP == 3)
+    if (gidx + nwaves < groups) fetch(gidx + nwaves, 0);
+#endif
+    __builtin_amdgcn_wave_barrier();
+    const int p = p0 + px;
+    const int pc = p < hw ? p : hw - 1, oh = pc / Wo, ow = pc - oh * Wo;
+    const float* win = patch + (2 * (oh - oh0)) * Wp + 2 * ow;
+    f32x16_t acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < kSteps; ++j) {
+      const float a = win[half ? toff(j, 1) : toff(j, 0)];
+#if defined(S7_EXP) && S7_EXP == 1
+      asm volatile("" ::"v"(a));
+      continue;
+#endif
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[0][j], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[1][j], acc1, 0, 0, 0);
+    }
+    // accumulator element e of lane (n = px, half): pixel row (e & 3) + 8 (e >> 2) + 4 half of the group, channel px (+32).
+    // Through LDS (the patch is dead) so that the stores are 16 bytes per lane, whole 256-byte pixel rows
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+      patch[row * kLdo + px] = acc0[e];
+      patch[row * kLdo + 32 + px] = acc1[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    float* yg = y + ((size_t)n * hw + p0) * kS7C;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = prow + 4 * i;
+      if (p0 + row < hw) {
+        const float4 v = ld4(patch + row * kLdo + 4 * c4);
+#if !(defined(S7_EXP) && S7_EXP == 2)
+        st4(yg + (size_t)row * kS7C + 4 * c4, v);
+#endif
+        s1 = add4(s1, v);
+        s2 = fma4(v, v, s2);
+      }
+    }
+  }
+  if (part) {  // channels 4 c4 .. 4 c4 + 3: fold the four lanes of a quad column, then the waves in a fixed order
+    s1.x += __shfl_xor(s1.x, 16); s1.y += __shfl_xor(s1.y, 16); s1.z += __shfl_xor(s1.z, 16); s1.w += __shfl_xor(s1.w, 16);
+    s2.x += __shfl_xor(s2.x, 16); s2.y += __shfl_xor(s2.y, 16); s2.z += __shfl_xor(s2.z, 16); s2.w += __shfl_xor(s2.w, 16);
+    s1.x += __shfl_xor(s1.x, 32); s1.y += __shfl_xor(s1.y, 32); s1.z += __shfl_xor(s1.z, 32); s1.w += __shfl_xor(s1.w, 32);
+    s2.x += __shfl_xor(s2.x, 32); s2.y += __shfl_xor(s2.y, 32); s2.z += __shfl_xor(s2.z, 32); s2.w += __shfl_xor(s2.w, 32);
+    if (lane < 16) { st4(&red[wv][4 * c4], s1); st4(&red[wv][kS7C + 4 * c4], s2); }
+    __syncthreads();
+    if (threadIdx.x < 2 * kS7C) {
+      float a = 0.f;
+      for (int i = 0; i < kBlock / kWave; ++i) a += red[i][threadIdx.x];
+      part[(size_t)blockIdx.x * 2 * kS7C + threadIdx.x] = a;
     }
   }
 }
@@ -259,8 +393,17 @@ int ttk_stem7_fwd(const float* x, const float* w, float* y, float* part, int B, 
   TTK_REQUIRE(B > 0 && H > 6 && W > 6, "stem7_fwd: bad shape B=%d H=%d W=%d", B, H, W);
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   const int64_t items = (int64_t)B * Ho * Wo * (kS7C / 4);  // sizes the partial rows (ttk_partial_rows_elementwise)
-  hipLaunchKernelGGL(stem7_fwd_k, dim3(elementwise_grid(items), kS7C / kS7Half), dim3(kBlock), 0, (hipStream_t)stream, x, w, y, part,
-                     B, H, W, Ho, Wo);
+  const int PR = 2 * ((Wo + 30) / Wo) + 7;          // input rows under 32 consecutive output pixels
+  const int prows = (PR + 8) / 9 * 9;               // staged in rounds of 9
+  const int wave_floats = prows * kS7Wp > 32 * (kS7C + 4) ? prows * kS7Wp : 32 * (kS7C + 4);
+  const size_t smem = (size_t)(kBlock / kWave) * wave_floats * sizeof(float);
+  static const bool valu = getenv("TTK_STEM7_VALU") != nullptr;  // the previous kernel (A/B timing)
+  if (!valu && smem <= 60 * 1024 && W + 7 <= kS7Wp && (int64_t)B * ((Ho * Wo + 31) / 32) < ((int64_t)1 << 30))
+    hipLaunchKernelGGL(stem7_fwd_mfma_k, dim3(elementwise_grid(items)), dim3(kBlock), smem, (hipStream_t)stream, x, w, y, part, B, H, W, Ho, Wo,
+                       PR, wave_floats);
+  else
+    hipLaunchKernelGGL(stem7_fwd_k, dim3(elementwise_grid(items), kS7C / kS7Half), dim3(kBlock), 0, (hipStream_t)stream, x, w, y, part,
+                       B, H, W, Ho, Wo);
   TTK_LAUNCH_CHECK("stem7_fwd");
 }
 
