@@ -234,8 +234,9 @@ int ttk_bn_act(const float* y, const float* bn, const float* skip, float* a, int
  *                           store their tiles side by side and a second kernel folds them in a fixed order into dw
  *                           (bitwise reproducible, and several times faster than the alternative, partial == NULL: one
  *                           fp32 atomicAdd per slice and element at torch's 36-byte tap stride)
- *                           Both gradients accept y == NULL: g then already holds dy (ttk_bn_bwd_apply; fp16 kernels only) -
- *                           half the operand bytes through the L1, which is what bounds these kernels.
+ *                           Both gradients accept y == NULL: g then holds dy as ttk_bn_bwd_apply wrote it - two fp16
+ *                           planes [rows][Cout] (h, then l) of dy * 2^s (fp16 kernels only): half the operand bytes
+ *                           through the L1, which is what bounds these kernels, and producers that only move data.
  * ------------------------------------------------------------------------------------------- */
 int ttk_conv_weight_repack(const float* w, void* w_fwd, void* w_bwd, int Cout, int Cin, int KH, int KW,
                            ttk_stream_t stream);
@@ -265,7 +266,9 @@ int ttk_conv_bwd_weight(const float* g, const float* y, const float* bn, const f
  *                          relu(bn(y)) that ttk_bn_fwd_finalize left there, plus *res_bound (bound of r: the shortcut
  *                          activation's a_bound, or res_bn's TTK_AUX_ACT_BOUND slot; NULL without r); measure != 0
  *                          (eval: no batch statistics) - raised to the measured max a.
- *   ttk_bn_bwd_apply       dy = ga*(g-gmean) + gb*(y-mean), materialised once for a convolution's two gradients
+ *   ttk_bn_bwd_apply       dy = ga*(g-gmean) + gb*(y-mean), materialised once for a convolution's two gradients in the form
+ *                          the fp16-split GEMMs consume: dy[2][rows][C] fp16 = h = fp16(dy*2^s), l = fp16(dy*2^s - h) with
+ *                          2^s * bn[TTK_BN_AUX][TTK_AUX_DY_BOUND] in [2^14, 2^15) (4 bytes per element, like fp32)
  *   ttk_residual_bwd       gs = (ga (+ gb)) * [a > 0]; part = sums for bn(y); partd (with yd, bnd) = sums for the
  *                          downsample BatchNorm; rows of both = ttk_partial_rows_elementwise(rows*C/4).  Raises
  *                          TTK_AUX_GMAX of bn (and bnd) to max |gs|.
@@ -279,7 +282,7 @@ int ttk_maxpool3x3s2_bwd(const float* ga, const float* gb, const unsigned char* 
                          float* g, float* part, int B, int H, int W, int C, ttk_stream_t stream);
 int ttk_bn_add_act(const float* y, float* bn, const float* res, const float* res_bn, float* a, const float* res_bound,
                    int measure, int64_t rows, int C, ttk_stream_t stream);
-int ttk_bn_bwd_apply(const float* g, const float* y, const float* bn, float* dy, int64_t rows, int C, ttk_stream_t stream);
+int ttk_bn_bwd_apply(const float* g, const float* y, const float* bn, void* dy, int64_t rows, int C, ttk_stream_t stream);
 int ttk_residual_bwd(const float* ga, const float* gb, const float* a, const float* y, float* bn, const float* yd,
                      float* bnd, float* gs, float* part, float* partd, int64_t rows, int C, ttk_stream_t stream);
 

@@ -215,7 +215,9 @@ int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const voi
   const uint16_t* wq = (const uint16_t*)w_bwd;
   const int K = KH * KW * Cout, em = mask_y ? EMODE_MASK : EMODE_PLAIN;
   const bool ok = gemm_mode() == GEMM_F16X2
-                      ? launch_conv_gemm16(y ? AMODE_BNGRAD : AMODE_PLAIN, em, g, y, bn, bn + (size_t)TTK_BN_AUX * Cout + TTK_AUX_DY_BOUND, wq,
+                      ? launch_conv_gemm16(y ? AMODE_BNGRAD : AMODE_PLANES, em, g,
+                                           y ? y : reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(g) + (size_t)B * Ho * Wo * Cout), bn,
+                                           bn + (size_t)TTK_BN_AUX * Cout + TTK_AUX_DY_BOUND, wq,
                                            (const float*)(wq + 2 * (size_t)K * Cin), g_in, mask_y, mask_bn, mask_y ? part : nullptr,
                                            (int64_t)B * H * W, K, Cin, geo, (hipStream_t)stream)
                       : launch_conv_gemm(AMODE_BNGRAD, em, g, y, bn, wq, g_in, mask_y, mask_bn, mask_y ? part : nullptr, (int64_t)B * H * W, K, Cin, geo,

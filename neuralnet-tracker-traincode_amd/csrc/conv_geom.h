@@ -8,7 +8,9 @@
 namespace ttk {
 
 // A-operand forms (what the producers compute from the loaded rows) and epilogue forms
-enum { AMODE_BNRELU = 0, AMODE_BNGRAD = 1, AMODE_PLAIN = 2 };
+// AMODE_PLANES: the A operand arrives already split - A0 / A1 = the h / l fp16 planes [rows][Kc] of x * pow2_scale(bound)
+// (ttk_bn_bwd_apply writes dy that way) - and the producers only move it (fp16 kernels)
+enum { AMODE_BNRELU = 0, AMODE_BNGRAD = 1, AMODE_PLAIN = 2, AMODE_PLANES = 3 };
 enum { EMODE_STATS = 0, EMODE_MASK = 1, EMODE_PLAIN = 2 };
 
 // Implicit-GEMM convolution (ResNet 3x3 / strided 1x1, backbones/resnet.py): the GEMM rows enumerate the pixels of a

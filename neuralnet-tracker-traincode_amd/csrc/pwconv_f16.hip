@@ -192,7 +192,8 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
        float* __restrict__ bnE, float* __restrict__ part, int64_t M, int K, int Nout, const float* __restrict__ a_bound,
        ConvGeom geo) {
   static_assert((BM == 128 && BN == 256) || (BM == 256 && BN == 128) || (BM == 256 && BN == 64) || (BM == 128 && BN == 64), "tile shapes");
-  static_assert(GATHER || AMODE != AMODE_PLAIN, "plain A operands come from the convolutions");
+  static_assert(GATHER || (AMODE != AMODE_PLAIN && AMODE != AMODE_PLANES), "plain A operands come from the convolutions");
+  constexpr bool PLANES = AMODE == AMODE_PLANES;
   constexpr int RS = TTK_RS;
   constexpr int APL = BM * 32, BPL = BN * 32;  // bytes of one piece plane of a k16 stage
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -231,7 +232,7 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
   const int64_t m0 = (int64_t)by * BM;
   const int n0 = bx * BN;
   const bool producer = __builtin_amdgcn_readfirstlane(tid) >= 256;
-  const float sa = pow2_scale(AMODE == AMODE_PLAIN ? *a_bound
+  const float sa = pow2_scale(AMODE == AMODE_PLAIN || PLANES ? *a_bound
                                                    : bnA[(size_t)TTK_BN_AUX * Kc + (AMODE == AMODE_BNRELU ? TTK_AUX_ACT_BOUND : TTK_AUX_DY_BOUND)]);
   const float sb = pow2_scale(*wmax);
 
@@ -242,7 +243,8 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
     const int sub = kq8 >> 2, chunk = (kq8 >> 1) & 1, o8 = (kq8 & 1) * 8;
     constexpr int AP = BM / 32;
     constexpr int NQ = AMODE == AMODE_BNGRAD ? 4 : 3;
-    f32x4 ra0[D][AP], ra1[D][AMODE == AMODE_BNGRAD ? AP : 1], q[D][NQ];
+    f32x4 ra0[D][PLANES ? 1 : AP], ra1[D][AMODE == AMODE_BNGRAD ? AP : 1], q[D][NQ];
+    u32x4 rp[D][PLANES ? AP : 1];  // planes: 8 k-values (16 bytes) of one piece plane per row and lane
     constexpr int BI = BN / 64;  // B rows per thread and piece plane: 64 rows x 4 chunks of 16 B (8 k) per pass
     u32x4 rb[D][2][BI];
     int64_t arow[GATHER ? 1 : AP];
@@ -272,8 +274,11 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
     const uint16_t* bp = Bq + (int64_t)(n0 + brow) * 32 + bc4 * 8;
     const int64_t bplane = (int64_t)K * Nout;
     unsigned char* wbase_b = lds + (bc4 >> 1) * kStr + 2 * APL;
-    const float* cp = AMODE == AMODE_PLAIN ? nullptr : bnA + kq8 * 4;
+    const float* cp = AMODE == AMODE_PLAIN || PLANES ? nullptr : bnA + kq8 * 4;
     unsigned char* wbase = lds + sub * kStr + o8;
+    // planes: lane kq8 moves piece plane kq8 >> 2, k-values 8 (kq8 & 3) .. + 7 of the k32 step: k16 stage (kq8 >> 1) & 1, 16-byte half kq8 & 1
+    const uint16_t* plane_src = PLANES ? (kq8 >> 2 ? reinterpret_cast<const uint16_t*>(A1) : reinterpret_cast<const uint16_t*>(A0)) : nullptr;
+    unsigned char* wbase_p = lds + ((kq8 >> 1) & 1) * kStr + (kq8 >> 2) * APL;
 
     auto load_a = [&](int ks, auto setc) {
       constexpr int set = decltype(setc)::value;
@@ -309,10 +314,16 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
             sw = tw >> sm;
           }
           ok = ok && (unsigned)sh < (unsigned)geo.Hs && (unsigned)sw < (unsigned)geo.Ws;
-          const int64_t off = ok ? ((int64_t)(gbase[i] + sh * geo.Ws + sw) * Kc + kc0 + kq8 * 4) : (int64_t)(kq8 * 4);
-          vm |= (ok ? 1u : 0u) << i;
-          ra0[set][i] = *reinterpret_cast<const f32x4*>(A0 + off);
-          if constexpr (AMODE == AMODE_BNGRAD) ra1[set][i] = *reinterpret_cast<const f32x4*>(A1 + off);
+          if constexpr (PLANES) {
+            const int64_t off = ok ? ((int64_t)(gbase[i] + sh * geo.Ws + sw) * Kc + kc0 + (kq8 & 3) * 8) : (int64_t)0;
+            const u32x4 t = *reinterpret_cast<const u32x4*>(plane_src + off);
+            rp[set][i] = ok ? t : u32x4{0u, 0u, 0u, 0u};  // zero padding / taps that miss the stride grid
+          } else {
+            const int64_t off = ok ? ((int64_t)(gbase[i] + sh * geo.Ws + sw) * Kc + kc0 + kq8 * 4) : (int64_t)(kq8 * 4);
+            vm |= (ok ? 1u : 0u) << i;
+            ra0[set][i] = *reinterpret_cast<const f32x4*>(A0 + off);
+            if constexpr (AMODE == AMODE_BNGRAD) ra1[set][i] = *reinterpret_cast<const f32x4*>(A1 + off);
+          }
         }
         vmask[set] = vm;
       }
@@ -349,6 +360,12 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
 #if defined(TTK_EXP) && (TTK_EXP == 6 || TTK_EXP == 7)
       if (ks >= D) return;  // timing experiment: no conversion / LDS writes
 #endif
+      if constexpr (PLANES) {  // no arithmetic: the 16-byte chunk straight into the ring
+        unsigned char* Sp = wbase_p + (ks % RS) * 2 * kStr;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) *reinterpret_cast<u32x4*>(Sp + swz16(row0 + 32 * i, kq8 & 1)) = rp[set][i];
+        return;
+      }
       unsigned char* S = wbase + (ks % RS) * 2 * kStr;
       // the scale S_a rides on the per-channel constants (exact: a power of two)
       f32x4 c0, c2;
@@ -361,7 +378,7 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         } else if constexpr (AMODE == AMODE_BNGRAD) {
           v = c0 * (ra0[set][i] - q[set][1]) + c2 * (ra1[set][i] - q[set][NQ - 1]);
-        } else {
+        } else if constexpr (AMODE == AMODE_PLAIN) {
           v = ra0[set][i] * sa;
         }
         if constexpr (GATHER)
@@ -548,7 +565,9 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
 // (Cout < BM, Cin % BN != 0) are masked; dW is torch's [Cout][Kc][taps].
 // APLAIN (convolutions): G already holds dy (ttk_bn_bwd_apply materialised it once for the weight and the data gradient:
 // half the A bytes through the L1 and no BatchNorm arithmetic here); Y is not read.
-template <int BM, int BN, int D, typename T, typename TG, bool CONV = false, bool APLAIN = false>
+// APLANES: G / Y are the h / l fp16 planes [M][Cout] of dy * pow2_scale(bound) (ttk_bn_bwd_apply): the A producers only
+// transpose 16-bit values (v_perm) - no loads of y, no BatchNorm arithmetic, no conversion.
+template <int BM, int BN, int D, typename T, typename TG, bool CONV = false, bool APLAIN = false, bool APLANES = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(CONV && BM + BN <= 256 ? 4 : 2, CONV && BM + BN <= 256 ? 4 : 2)))
 pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __restrict__ bn_pw,
              const T* __restrict__ X, const float* __restrict__ bn_x, float* __restrict__ dW, float* __restrict__ partial,
@@ -588,7 +607,12 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
     const int mb = pt & 7, cq = pt >> 3;  // 8 row blocks of 4 rows x 32 channel quads per pass
     const int sub = mb >> 2, chunk = (mb >> 1) & 1, o8 = (mb & 1) * 8;
     constexpr int AP = BM >= 128 ? BM / 128 : 1, BP = (BN + 127) / 128;
-    f32x4 rg[D][AP][4], ry[D][APLAIN ? 1 : AP][4], rx[D][BP][4];
+    f32x4 rg[D][APLANES ? 1 : AP][4], ry[D][APLAIN || APLANES ? 1 : AP][4], rx[D][BP][4];
+    u32x4 rpa[D][APLANES ? AP : 1][4];  // planes: 4 rows x 8 channels of one piece plane
+    // planes: the 32 channel-quad lanes of a pass are 2 planes x 16 channel octets (64-row tiles: 2 x 8)
+    constexpr int OP = (BM >= 128 ? 128 : BM) / 8;
+    const int aplane = cq / OP, aoct = cq - aplane * OP;
+    const uint16_t* asrc = APLANES ? (aplane ? reinterpret_cast<const uint16_t*>(Y) : reinterpret_cast<const uint16_t*>(G)) : nullptr;
     f32x4 ga[AP], gb[AP], gmean[AP], ymean[AP], sc[BP], mu[BP], be[BP];
     int ca[AP], cb[BP];
     // convolutions: tap of the B columns, validity of this thread's A rows / B columns (partial tiles), and per register
@@ -599,7 +623,7 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
     const bool a_on = BM >= 128 || cq < BM / 4;  // a 64-row A tile occupies half of the producers' channel quads
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      ca[p] = n0 + 4 * (cq + 32 * p);
+      ca[p] = APLANES ? n0 + 128 * p + 8 * aoct : n0 + 4 * (cq + 32 * p);
       va[p] = true;
       if constexpr (CONV) {
         va[p] = a_on && ca[p] < Cout;
@@ -667,6 +691,16 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
 #endif
       if constexpr (BM < 128)
         if (!a_on) return;
+      if constexpr (APLANES) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int64_t row = m_begin + (int64_t)ks * 32 + 4 * mb + i;
+          row = row < m_end ? row : m_end - 1;
+#pragma unroll
+          for (int p = 0; p < AP; ++p) rpa[set][p][i] = *reinterpret_cast<const u32x4*>(asrc + row * Cout + ca[p]);
+        }
+        return;
+      }
       if (ks < nfull) {
         const int64_t base = (int64_t)ks * 32 * Cout;
 #pragma unroll
@@ -761,6 +795,23 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
 #endif
       if constexpr (BM < 128)
         if (!a_on) return;
+      if constexpr (APLANES) {
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+          u32x4 r[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) r[i] = (row0 + i < m_end && va[p]) ? rpa[set][p][i] : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {  // dword d = channels 2d, 2d+1 of the four rows -> per channel its four consecutive k
+            const unsigned lo01 = __builtin_amdgcn_perm(r[1][d], r[0][d], 0x05040100u), lo23 = __builtin_amdgcn_perm(r[3][d], r[2][d], 0x05040100u);
+            const unsigned hi01 = __builtin_amdgcn_perm(r[1][d], r[0][d], 0x07060302u), hi23 = __builtin_amdgcn_perm(r[3][d], r[2][d], 0x07060302u);
+            unsigned char* dst = S + aplane * APL;
+            *reinterpret_cast<uint2*>(dst + swz16(128 * p + 8 * aoct + 2 * d, chunk)) = make_uint2(lo01, lo23);
+            *reinterpret_cast<uint2*>(dst + swz16(128 * p + 8 * aoct + 2 * d + 1, chunk)) = make_uint2(hi01, hi23);
+          }
+        }
+        return;
+      }
 #pragma unroll
       for (int p = 0; p < AP; ++p) {
         f32x4 v[4];
@@ -1024,8 +1075,10 @@ bool launch_conv_wgrad16(const float* g, const float* y, const float* bn, const 
 #ifndef TTK_DC
 #define TTK_DC 1
 #endif
+  // y == nullptr: g holds dy as two fp16 planes [M][Cout] (h, then l)
+  const float* yy = y ? y : reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(g) + M * Cout);
 #define TTK_WGRAD_LAUNCH(BM_, BN_, PLAIN_)                                                                                                      \
-  hipLaunchKernelGGL((pw16_wgrad_k<BM_, BN_, (BM_ == 64 ? TTK_DC : 1), float, float, true, PLAIN_>), grid, dim3(512), 0, st, g, y, bn, a_in, nullptr, dw, partial, M, ncols, \
+  hipLaunchKernelGGL((pw16_wgrad_k<BM_, BN_, (BM_ == 64 ? TTK_DC : 1), float, float, true, false, PLAIN_>), grid, dim3(512), 0, st, g, yy, bn, a_in, nullptr, dw, partial, M, ncols, \
                      Cout, rows, a_bound, geo)
   if (narrow && conv_wgrad_bn(Cout, ncols) == 192) { if (y) TTK_WGRAD_LAUNCH(64, 192, false); else TTK_WGRAD_LAUNCH(64, 192, true); }
   else if (narrow) { if (y) TTK_WGRAD_LAUNCH(64, 256, false); else TTK_WGRAD_LAUNCH(64, 256, true); }
@@ -1082,6 +1135,9 @@ bool launch_conv_gemm16(int amode, int emode, const float* A0, const float* A1, 
   if (amode == AMODE_BNGRAD && emode == EMODE_PLAIN) TTK_CONV_TILES(AMODE_BNGRAD, EMODE_PLAIN);
   if (amode == AMODE_PLAIN && emode == EMODE_MASK) TTK_CONV_TILES(AMODE_PLAIN, EMODE_MASK);  // data gradient of a materialised dy
   if (amode == AMODE_PLAIN && emode == EMODE_PLAIN) TTK_CONV_TILES(AMODE_PLAIN, EMODE_PLAIN);
+  if (amode == AMODE_PLANES && emode == EMODE_MASK) TTK_CONV_TILES(AMODE_PLANES, EMODE_MASK);
+  if (amode == AMODE_PLANES && emode == EMODE_PLAIN) TTK_CONV_TILES(AMODE_PLANES, EMODE_PLAIN);
+  if (amode == AMODE_PLANES && emode == EMODE_STATS) TTK_CONV_TILES(AMODE_PLANES, EMODE_STATS);
 #undef TTK_CONV_TILES
 #undef TTK_CONV_LAUNCH
   return false;

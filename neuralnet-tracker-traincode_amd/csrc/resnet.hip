@@ -330,16 +330,44 @@ __global__ void __launch_bounds__(kBlock) bn_add_act_k(const float* __restrict__
 
 // dy = ga*(g-gmean) + gb*(y-mean): the gradient w.r.t. a conv output through its BatchNorm, written once for the
 // convolution's weight and data gradients (both then read 4 instead of 8 bytes per element, the data gradient nine times).
+// Written as the fp16-split GEMMs consume it (pwconv_f16.hip): two fp16 planes [rows][C] - h = fp16(dy S), then l = fp16(dy S - h),
+// S = pow2_scale(bn[TTK_BN_AUX][TTK_AUX_DY_BOUND]) - the same 4 bytes per element as fp32, and the GEMM producers move them
+// without arithmetic.  thread = (row, 8 channels): one 16-byte store per plane.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& l) {
+  const f16x2_t hh = __builtin_convertvector(f32x2_t{a, b}, f16x2_t);
+  const f32x2_t back = __builtin_convertvector(hh, f32x2_t);
+  const f16x2_t ll = __builtin_convertvector(f32x2_t{a - back.x, b - back.y}, f16x2_t);
+  h = __builtin_bit_cast(unsigned, hh);
+  l = __builtin_bit_cast(unsigned, ll);
+}
 __global__ void __launch_bounds__(kBlock) bn_bwd_apply_k(const float* __restrict__ g, const float* __restrict__ y,
-                                                          const float* __restrict__ bnp, float* __restrict__ dy, int64_t items, int C) {
-  const int quads = C >> 2;
-  const int c4 = threadIdx.x & (quads - 1);
-  const float4 ga = ld4(bnp + TTK_BN_GA * C + 4 * c4), gb = ld4(bnp + TTK_BN_GB * C + 4 * c4);
-  const float4 gmean = ld4(bnp + TTK_BN_GMEAN * C + 4 * c4), mean = ld4(bnp + TTK_BN_MEAN * C + 4 * c4);
+                                                          const float* __restrict__ bnp, uint16_t* __restrict__ dy, int64_t items, int C) {
+  const int octs = C >> 3;
+  const int c8 = threadIdx.x & (octs - 1);
+  const float s = pow2_scale(bnp[(size_t)TTK_BN_AUX * C + TTK_AUX_DY_BOUND]);
+  float ga[8], gb[8], gmean[8], mean[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ga[j] = bnp[TTK_BN_GA * C + 8 * c8 + j] * s;
+    gb[j] = bnp[TTK_BN_GB * C + 8 * c8 + j] * s;
+    gmean[j] = bnp[TTK_BN_GMEAN * C + 8 * c8 + j];
+    mean[j] = bnp[TTK_BN_MEAN * C + 8 * c8 + j];
+  }
+  uint16_t* lo = dy + (size_t)items * 8;
   for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * kBlock) {
-    const size_t off = (size_t)idx << 2;
-    const float4 gv = sub4(ld4(g + off), gmean), yv = sub4(ld4nt(y + off), mean);  // g is read again (shortcut branch), y is not
-    st4(dy + off, make_float4(ga.x * gv.x + gb.x * yv.x, ga.y * gv.y + gb.y * yv.y, ga.z * gv.z + gb.z * yv.z, ga.w * gv.w + gb.w * yv.w));
+    const size_t off = (size_t)idx << 3;
+    const float4 g0 = ld4(g + off), g1 = ld4(g + off + 4);  // g is read again (shortcut branch), y is not
+    const float4 y0 = ld4nt(y + off), y1 = ld4nt(y + off + 4);
+    const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, yv[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ga[j] * (gv[j] - gmean[j]) + gb[j] * (yv[j] - mean[j]);
+    uint4 h, l;
+    split2(v[0], v[1], h.x, l.x); split2(v[2], v[3], h.y, l.y); split2(v[4], v[5], h.z, l.z); split2(v[6], v[7], h.w, l.w);
+    *reinterpret_cast<uint4*>(dy + off) = h;
+    *reinterpret_cast<uint4*>(lo + off) = l;
   }
 }
 
@@ -451,13 +479,13 @@ int ttk_bn_add_act(const float* y, float* bn, const float* res, const float* res
   TTK_LAUNCH_CHECK("bn_add_act");
 }
 
-int ttk_bn_bwd_apply(const float* g, const float* y, const float* bn, float* dy, int64_t rows, int C, ttk_stream_t stream) {
+int ttk_bn_bwd_apply(const float* g, const float* y, const float* bn, void* dy, int64_t rows, int C, ttk_stream_t stream) {
   TTK_REQUIRE(g && y && bn && dy, "bn_bwd_apply: null pointer");
   TTK_REQUIRE(ew_shape_ok(rows, C), "bn_bwd_apply: unsupported shape rows=%lld C=%d", (long long)rows, C);
-  const int64_t items = rows * (C / 4);
+  const int64_t items = rows * (C / 8);
   int64_t grid = ceil_div(items, kBlock);
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(bn_bwd_apply_k, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, g, y, bn, dy, items, C);
+  hipLaunchKernelGGL(bn_bwd_apply_k, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, g, y, bn, (uint16_t*)dy, items, C);
   TTK_LAUNCH_CHECK("bn_bwd_apply");
 }
 
