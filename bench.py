@@ -400,7 +400,8 @@ def main():
                     ach, peak, unit = v["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s"
                 else:
                     ach, peak, unit = v["flops"] / sec / 1e12, PEAK_BF16_MFMA_TFLOPS / products, "TFLOP/s"
-                tr = traffic.get(k)
+                # the labels of work() are prefixes of the profiler's kernel names (trailing template arguments omitted)
+                tr = traffic.get(k) or next((v_ for k_, v_ in traffic.items() if k_.startswith(k.rstrip(">"))), None)
                 return {"bound": "hbm" if hbm else "mfma", "kernel": k, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                         "traffic": tr["bytes_per_launch"] if tr else None, "algorithmic_bytes_per_launch": v["bytes"] / launches,
                         "flops_per_launch": v["flops"] / launches, "launch_avg_us": v["ms"] / launches * 1e3,
