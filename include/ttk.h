@@ -42,7 +42,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 10
+#define TTK_ABI_VERSION 11
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -255,7 +255,8 @@ int ttk_conv_bwd_weight(const float* g, const float* y, const float* bn, const f
 /* ---------------------------------------------------------------------------------------------
  * The non-GEMM kernels of the ResNet18 variant (backbones/resnet.py:52-104: torchvision ResNet18, 1-channel 7x7 stem).
  *   ttk_stem7_fwd          y[B][65][65][64] = conv7x7/s2/p3(x[B][1][H][W]) + part[ttk_partial_rows_elementwise(B*Ho*Wo*16)][2][64]
- *   ttk_stem7_bwd_weight   dw[64][1][7][7] (overwritten) from dy = ga*(g-gmean)+gb*(y-mean)
+ *   ttk_stem7_bwd_weight   dw[64][1][7][7] (overwritten) from dy = ga*(g-gmean)+gb*(y-mean); partial (nullable) = scratch of
+ *                          ttk_stem7_wgrad_partial_bytes: workgroup partials folded in a fixed order instead of atomics
  *   ttk_maxpool3x3s2_fwd   a[B][Ho][Wo][C] = maxpool3x3/s2/p1(relu(bn(y))), idx = window position of the first maximum;
  *                          raises bn[TTK_BN_AUX][TTK_AUX_ACT_BOUND] to max a
  *   ttk_maxpool3x3s2_bwd   g[B][H][W][C] = gradient w.r.t. bn(y) (ReLU mask applied) from ga (+ gb) w.r.t. the pooled
@@ -274,8 +275,9 @@ int ttk_conv_bwd_weight(const float* g, const float* y, const float* bn, const f
  *                          TTK_AUX_GMAX of bn (and bnd) to max |gs|.
  * ------------------------------------------------------------------------------------------- */
 int ttk_stem7_fwd(const float* x, const float* w, float* y, float* part, int B, int H, int W, ttk_stream_t stream);
-int ttk_stem7_bwd_weight(const float* g, const float* y, const float* bn, const float* x, float* dw, int B, int H,
-                         int W, ttk_stream_t stream);
+size_t ttk_stem7_wgrad_partial_bytes(int B, int H, int W);
+int ttk_stem7_bwd_weight(const float* g, const float* y, const float* bn, const float* x, float* dw, float* partial, int B,
+                         int H, int W, ttk_stream_t stream);
 int ttk_maxpool3x3s2_fwd(const float* y, float* bn, float* a, unsigned char* idx, int B, int H, int W, int C,
                          ttk_stream_t stream);
 int ttk_maxpool3x3s2_bwd(const float* ga, const float* gb, const unsigned char* idx, const float* y, const float* bn,

@@ -1052,8 +1052,14 @@ static void conv_wgrad_plan(int64_t M, int Cout, int ncols, int& tiles, int64_t&
   tiles = (int)(ceil_div(Cout, Cout <= 64 ? 64 : 128) * ceil_div(ncols, conv_wgrad_bn(Cout, ncols)));
   wgrad_slices(M, tiles, slices, rows, conv_wgrad_bn(Cout, ncols) == 192 ? 512 : 256);  // 64x192 tiles: two workgroups per CU
 }
+static bool deterministic_mode() {
+  static const bool det = [] { const char* e = getenv("TTK_DETERMINISTIC"); return e && e[0] != '0'; }();
+  return det;
+}
 size_t conv_wgrad16_partial_bytes(int64_t M, int Cout, int ncols, int taps) {
-  if (taps == 1) return 0;  // 1x1: the atomics are coalesced ([co][ci] = the GEMM's layout) and measured faster than the fold
+  // 1x1: the atomics are coalesced ([co][ci] = the GEMM's layout) and measured faster than the fold - unless a fixed summation
+  // order is asked for (TTK_DETERMINISTIC=1)
+  if (taps == 1 && !deterministic_mode()) return 0;
   int tiles;
   int64_t slices, rows;
   conv_wgrad_plan(M, Cout, ncols, tiles, slices, rows);
@@ -1067,7 +1073,7 @@ bool launch_conv_wgrad16(const float* g, const float* y, const float* bn, const 
   if (nimg * geo.Hs * geo.Ws * geo.Kc >= (int64_t)1 << 29) return false;  // 32-bit byte offsets into a_in (with the halo's slack)
   const int ncols = taps * geo.Kc;
   const bool narrow = Cout <= 64;
-  if (taps == 1) partial = nullptr;
+  if (taps == 1 && !deterministic_mode()) partial = nullptr;
   int tiles;
   int64_t slices, rows;
   conv_wgrad_plan(M, Cout, ncols, tiles, slices, rows);

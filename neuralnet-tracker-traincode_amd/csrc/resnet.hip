@@ -435,13 +435,18 @@ int ttk_stem7_fwd(const float* x, const float* w, float* y, float* part, int B, 
   TTK_LAUNCH_CHECK("stem7_fwd");
 }
 
-int ttk_stem7_bwd_weight(const float* g, const float* y, const float* bn, const float* x, float* dw, int B, int H, int W,
+size_t ttk_stem7_wgrad_partial_bytes(int B, int H, int W) {
+  if (B <= 0 || H <= 6 || W <= 6) return 0;
+  return (size_t)stem_wgrad_grid(B, (H + 6 - 7) / 2 + 1) * kS7C * kS7K * kS7K * sizeof(float);
+}
+
+int ttk_stem7_bwd_weight(const float* g, const float* y, const float* bn, const float* x, float* dw, float* partial, int B, int H, int W,
                          ttk_stream_t stream) {
   TTK_REQUIRE(g && y && bn && x && dw, "stem7_bwd_weight: null pointer");
   TTK_REQUIRE(B > 0 && H > 6 && W > 6, "stem7_bwd_weight: bad shape");
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   (void)hipMemsetAsync(dw, 0, sizeof(float) * kS7C * kS7K * kS7K, (hipStream_t)stream);
-  launch_stem_wgrad<kS7K, kS7C>(g, y, bn, x, dw, B, H, W, Ho, Wo, (hipStream_t)stream);
+  launch_stem_wgrad<kS7K, kS7C>(g, y, bn, x, dw, partial, B, H, W, Ho, Wo, (hipStream_t)stream);
   TTK_LAUNCH_CHECK("stem7_bwd_weight");
 }
 

@@ -17,8 +17,8 @@ namespace ttk {
 template <int KS, int C>
 __global__ void __launch_bounds__(kBlock) stem_wgrad_lds_k(const float* __restrict__ g, const float* __restrict__ y,
                                                             const float* __restrict__ bn, const float* __restrict__ x,
-                                                            float* __restrict__ dw, int B, int H, int W, int Ho, int Wo,
-                                                            int Wp4, int Wo4) {
+                                                            float* __restrict__ dw, float* __restrict__ partial, int B, int H, int W,
+                                                            int Ho, int Wo, int Wp4, int Wo4) {
   constexpr int PAD = KS / 2, TAPS = KS * KS, G = kBlock / C;
   constexpr int NX = (6 + KS + 3) / 4;  // float4 loads covering x[8q .. 8q + 6 + KS - 1]
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -72,19 +72,29 @@ __global__ void __launch_bounds__(kBlock) stem_wgrad_lds_k(const float* __restri
     }
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < C * TAPS; i += kBlock) atomicAdd(dw + i, red[i]);  // dw[c][tap], zeroed by the caller
+  // dw[c][tap] (zeroed by the caller) - or, deterministic mode, this workgroup's row of partial[grid][C * TAPS], folded in a
+  // fixed order afterwards
+  for (int i = threadIdx.x; i < C * TAPS; i += kBlock) {
+    if (partial) partial[(size_t)blockIdx.x * C * TAPS + i] = red[i];
+    else atomicAdd(dw + i, red[i]);
+  }
+}
+
+inline int stem_wgrad_grid(int B, int Ho) {
+  // few, persistent workgroups: every workgroup ends with one atomicAdd per weight, and same-address atomics serialise
+  int64_t grid = (int64_t)B * Ho;
+  return (int)(grid > 1024 ? 1024 : grid);
 }
 
 template <int KS, int C>
-inline void launch_stem_wgrad(const float* g, const float* y, const float* bn, const float* x, float* dw, int B, int H, int W, int Ho,
-                              int Wo, hipStream_t st) {
-  // few, persistent workgroups: every workgroup ends with one atomicAdd per weight, and same-address atomics serialise
-  int64_t grid = (int64_t)B * Ho;
-  if (grid > 1024) grid = 1024;
+inline void launch_stem_wgrad(const float* g, const float* y, const float* bn, const float* x, float* dw, float* partial, int B, int H, int W,
+                              int Ho, int Wo, hipStream_t st) {
+  const int grid = stem_wgrad_grid(B, Ho);
   const int Wo4 = ((Wo + 3) / 4) * 4;
   const int Wp4 = ((2 * Wo4 + KS + 6 + 3) / 4) * 4 + 16;  // the last quad reads 4*NX floats from 8*q
   const size_t sm = (size_t)(KS * Wp4 + C * Wo4 + C * KS * KS) * sizeof(float);
-  hipLaunchKernelGGL((stem_wgrad_lds_k<KS, C>), dim3((unsigned)grid), dim3(kBlock), sm, st, g, y, bn, x, dw, B, H, W, Ho, Wo, Wp4, Wo4);
+  hipLaunchKernelGGL((stem_wgrad_lds_k<KS, C>), dim3((unsigned)grid), dim3(kBlock), sm, st, g, y, bn, x, dw, partial, B, H, W, Ho, Wo, Wp4, Wo4);
+  if (partial) launch_fold_partials(partial, grid, (int64_t)C * KS * KS, dw, 1, st);
 }
 
 }  // namespace ttk

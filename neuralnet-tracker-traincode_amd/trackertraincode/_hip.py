@@ -35,7 +35,7 @@ _SIGNATURES = {
     "ttk_avgpool_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
     "ttk_bn_act": [_P, _P, _P, _P, _L, _I],
     "ttk_stem7_fwd": [_P, _P, _P, _P, _I, _I, _I],
-    "ttk_stem7_bwd_weight": [_P, _P, _P, _P, _P, _I, _I, _I],
+    "ttk_stem7_bwd_weight": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
     "ttk_maxpool3x3s2_fwd": [_P, _P, _P, _P, _I, _I, _I, _I],
     "ttk_maxpool3x3s2_bwd": [_P] * 7 + [_I] * 4,
     "ttk_bn_add_act": [_P, _P, _P, _P, _P, _P, _I, _L, _I],
@@ -85,7 +85,7 @@ _SIGNATURES = {
     "ttk_clip_adam": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P],
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class _Library:
@@ -112,6 +112,7 @@ class _Library:
         self.cdll.ttk_partial_rows_dwconv.argtypes, self.cdll.ttk_partial_rows_dwconv.restype = [c_int] * 6, c_int
         self.cdll.ttk_pwconv_wgrad_partial_bytes.argtypes, self.cdll.ttk_pwconv_wgrad_partial_bytes.restype = [c_int64, c_int, c_int], ctypes.c_size_t
         self.cdll.ttk_conv_wgrad_partial_bytes.argtypes, self.cdll.ttk_conv_wgrad_partial_bytes.restype = [c_int] * 9, ctypes.c_size_t
+        self.cdll.ttk_stem7_wgrad_partial_bytes.argtypes, self.cdll.ttk_stem7_wgrad_partial_bytes.restype = [c_int] * 3, ctypes.c_size_t
         self.cdll.ttk_stem_wgrad_partial_bytes.argtypes, self.cdll.ttk_stem_wgrad_partial_bytes.restype = [], ctypes.c_size_t
         self._fns = {}
         for name, sig in _SIGNATURES.items():
@@ -202,4 +203,4 @@ def ptr(t: torch.Tensor | None):
 def exported_symbols() -> list[str]:
     return ["ttk_abi_version", "ttk_last_error_string", "ttk_clear_error", "ttk_partial_rows_elementwise",
             "ttk_partial_rows_gemm", "ttk_partial_rows_dwconv", "ttk_heads_num_rows", "ttk_pwconv_prepared_bytes",
-            "ttk_pwconv_wgrad_partial_bytes", "ttk_stem_wgrad_partial_bytes", "ttk_conv_wgrad_partial_bytes"] + list(_SIGNATURES)
+            "ttk_pwconv_wgrad_partial_bytes", "ttk_stem_wgrad_partial_bytes", "ttk_conv_wgrad_partial_bytes", "ttk_stem7_wgrad_partial_bytes"] + list(_SIGNATURES)

@@ -49,6 +49,7 @@ class BasicBlock(nn.Module):
 
 
 _MATERIALISE_DY = os.environ.get("TTK_GEMM") != "bf16x3"
+_DETERMINISTIC = os.environ.get("TTK_DETERMINISTIC", "0") != "0"  # bitwise reproducible steps (tests/test_determinism_gpu.py)
 _BN_AUX = 7  # TTK_BN_AUX: [0] = TTK_AUX_ACT_BOUND of the activation this BatchNorm forms
 
 
@@ -283,7 +284,10 @@ def _backward_impl(c: _Ctx, gfeat, params):
             g0 = new(B, Ho, Ho, 64)
             L.call("ttk_maxpool3x3s2_bwd", p(g_in), p(g_sc), p(c.idx), p(c.y0), p(c.bn0), p(g0), p(part), B, Ho, Ho, 64)
             bwd_finalize(c.bn0, L.partial_rows_elementwise(B * Ho * Ho * 16), 64, B * Ho * Ho, 1)
-            L.call("ttk_stem7_bwd_weight", p(g0), p(c.y0), p(c.bn0), p(c.x), p(grads[0]), B, c.H, c.W)
+            sp = None
+            if _DETERMINISTIC:  # workgroup partials + a fixed-order fold instead of atomics (the 3x3 convolutions always fold; the
+                sp = torch.empty(L.cdll.ttk_stem7_wgrad_partial_bytes(B, c.H, c.W) // 4, dtype=torch.float32, device=dev)  # 1x1 ones under the same flag)
+            L.call("ttk_stem7_bwd_weight", p(g0), p(c.y0), p(c.bn0), p(c.x), p(grads[0]), p(sp), B, c.H, c.W)
         # this block's conv / BatchNorm gradients are final (the stem's after the first block)
         announce(pi, pi + (9 if has_ds else 6))
     announce(0, 3)
