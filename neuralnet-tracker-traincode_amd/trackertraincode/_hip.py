@@ -30,6 +30,7 @@ _SIGNATURES = {
     "ttk_pwconv1x1_bwd_data": [_P] * 8 + [_L, _I, _I, _P, _I],
     "ttk_pwconv1x1_bwd_weight": [_P] * 7 + [_L, _I, _I, _I],
     "ttk_pwconv_prepare_weights": [_I, _P, _P, _P, _P],
+    "ttk_pwconv1x1_bwd_fused": [_P] * 10 + [_L, _I, _I],
     "ttk_transpose": [_P, _P, _I, _I],
     "ttk_avgpool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I],
     "ttk_avgpool_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
@@ -112,6 +113,8 @@ class _Library:
         self.cdll.ttk_partial_rows_dwconv.argtypes, self.cdll.ttk_partial_rows_dwconv.restype = [c_int] * 6, c_int
         self.cdll.ttk_pwconv_wgrad_partial_bytes.argtypes, self.cdll.ttk_pwconv_wgrad_partial_bytes.restype = [c_int64, c_int, c_int], ctypes.c_size_t
         self.cdll.ttk_conv_wgrad_partial_bytes.argtypes, self.cdll.ttk_conv_wgrad_partial_bytes.restype = [c_int] * 9, ctypes.c_size_t
+        self.cdll.ttk_pwconv1x1_bwd_fused_rows.argtypes, self.cdll.ttk_pwconv1x1_bwd_fused_rows.restype = [c_int64, c_int, c_int], c_int
+        self.cdll.ttk_pwconv1x1_bwd_fused_partial_bytes.argtypes, self.cdll.ttk_pwconv1x1_bwd_fused_partial_bytes.restype = [c_int64, c_int, c_int], ctypes.c_size_t
         self.cdll.ttk_stem7_wgrad_partial_bytes.argtypes, self.cdll.ttk_stem7_wgrad_partial_bytes.restype = [c_int] * 3, ctypes.c_size_t
         self.cdll.ttk_stem_wgrad_partial_bytes.argtypes, self.cdll.ttk_stem_wgrad_partial_bytes.restype = [], ctypes.c_size_t
         self._fns = {}
@@ -203,4 +206,5 @@ def ptr(t: torch.Tensor | None):
 def exported_symbols() -> list[str]:
     return ["ttk_abi_version", "ttk_last_error_string", "ttk_clear_error", "ttk_partial_rows_elementwise",
             "ttk_partial_rows_gemm", "ttk_partial_rows_dwconv", "ttk_heads_num_rows", "ttk_pwconv_prepared_bytes",
-            "ttk_pwconv_wgrad_partial_bytes", "ttk_stem_wgrad_partial_bytes", "ttk_conv_wgrad_partial_bytes", "ttk_stem7_wgrad_partial_bytes"] + list(_SIGNATURES)
+            "ttk_pwconv_wgrad_partial_bytes", "ttk_stem_wgrad_partial_bytes", "ttk_conv_wgrad_partial_bytes", "ttk_stem7_wgrad_partial_bytes",
+            "ttk_pwconv1x1_bwd_fused_rows", "ttk_pwconv1x1_bwd_fused_partial_bytes"] + list(_SIGNATURES)

@@ -230,6 +230,7 @@ _USE_WGRAD_STREAM = os.environ.get("TTK_WGRAD_STREAM", "0") != "0"
 # TTK_DETERMINISTIC=1: every weight-gradient reduction runs in a fixed order (slices of M stored to scratch and folded
 # by a second kernel instead of fp32 atomics): two runs of a step give bitwise equal gradients.
 _DETERMINISTIC = os.environ.get("TTK_DETERMINISTIC", "0") != "0"
+_FUSED_PW_BWD = os.environ.get("TTK_FUSED_PW_BWD", "1") != "0"  # 0: the two-kernel backward of the first pointwise layers (A/B timing)
 _SIDE_STREAMS: dict = {}
 
 
@@ -271,6 +272,7 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         # slices / workgroups store partial results there and a second kernel folds them in a fixed order
         need = max(L.pwconv_wgrad_partial_bytes(B * d[2] * d[3], d[4], d[5]) for d in ctx.dims)
         need = max(need, L.cdll.ttk_stem_wgrad_partial_bytes())
+        need = max(need, max(L.cdll.ttk_pwconv1x1_bwd_fused_partial_bytes(B * d[2] * d[3], d[4], d[5]) for d in ctx.dims))
         need = max(need, max(L.partial_rows_dwconv(B, d[0], d[1], d[4], d[6], True) * 9 * d[4] * 4 for d in ctx.dims))
         wg_scratch = torch.empty(need // 4, dtype=torch.float32, device=gfeat.device)
     keep = []
@@ -290,7 +292,15 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         # consumer inside backward, so it runs on a second HIP stream next to the data-gradient chain: its
         # tail (too few tiles left for 256 CUs) and the HBM-bound depthwise kernels fill each other's gaps.
         dW = grads[pi + 3]
-        if side is not None:
+        g_dw = torch.empty(st_dw.y.shape, dtype=ctx.gdt, device=st_dw.y.device)
+        fused_rows = L.cdll.ttk_pwconv1x1_bwd_fused_rows(M, cin, cout) if (_FUSED_PW_BWD and bf == 0 and side is None) else 0
+        if fused_rows:
+            # the first two pointwise layers (HBM-bound, the largest activations): weight and data gradient in ONE kernel - g,
+            # the conv output and the depthwise output are read once instead of twice (csrc/pw_bwd_fused.hip)
+            L.call("ttk_pwconv1x1_bwd_fused", p(g), p(st_pw.y), p(st_pw.bn), p(w_pw), p(st_dw.y), p(st_dw.bn), p(g_dw), p(dW),
+                   p(wg_scratch), p(part), M, cin, cout)
+            bwd_finalize(st_dw, fused_rows, M, pi + 1)
+        elif side is not None:
             ev = torch.cuda.Event()
             ev.record(main)  # g, bn_pw backward constants and the zeroed dW are ready
             side.wait_event(ev)
@@ -302,10 +312,10 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
             keep.append(g)  # main must not recycle g's memory while the side stream still reads it
         else:
             L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW), p(wg_scratch), M, cin, cout, bf)
-        g_dw = torch.empty(st_dw.y.shape, dtype=ctx.gdt, device=st_dw.y.device)
-        L.call("ttk_pwconv1x1_bwd_data", p(g), p(st_pw.y), p(st_pw.bn), None, p(st_dw.y), p(st_dw.bn), p(g_dw), p(part), M,
-               cin, cout, p(ctx.prep[k]), bf)
-        bwd_finalize(st_dw, L.partial_rows_gemm(M), M, pi + 1)
+        if not fused_rows:
+            L.call("ttk_pwconv1x1_bwd_data", p(g), p(st_pw.y), p(st_pw.bn), None, p(st_dw.y), p(st_dw.bn), p(g_dw), p(part), M,
+                   cin, cout, p(ctx.prep[k]), bf)
+            bwd_finalize(st_dw, L.partial_rows_gemm(M), M, pi + 1)
         # -- depthwise: weight gradient, then data gradient (+ residual gradient, + producer's bn sums)
         dWd = grads[pi]  # accumulated by the fused weight-gradient path of bwd_data
         g_prev = torch.empty(st_prev.y.shape, dtype=ctx.gdt, device=st_prev.y.device)

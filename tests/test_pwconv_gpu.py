@@ -161,3 +161,61 @@ def test_prepared_weights_match_per_call_split():
             assert torch.equal(a, b), (M, Cin, Cout)
     with pytest.raises(RuntimeError, match="null pointer"):
         L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(y), None, M, Cin, Cout, None, 0)
+
+
+@pytest.mark.parametrize("M,Cin,Cout", [(64 * 300 + 17, 32, 64), (64 * 1100 + 63, 32, 64), (64 * 200 + 1, 64, 128), (64 * 700 + 40, 64, 128), (50, 64, 128)])
+def test_fused_bwd_matches_fp64_and_the_two_kernels(M, Cin, Cout):
+    """ttk_pwconv1x1_bwd_fused (first two pointwise layers: weight + data gradient from one read of the operands) against
+    float64 numpy, against the two kernels it replaces, and - with the scratch buffer - bitwise reproducible."""
+    import trackertraincode._hip as Hh
+    L, p = Hh.lib(), Hh.ptr
+    rng = np.random.default_rng(M + Cin)
+    g = (rng.normal(0, 1, (M, Cout)) * 1e-2).astype(np.float32)
+    y = rng.normal(0, 1, (M, Cout)).astype(np.float32)
+    ydw = rng.normal(0, 1, (M, Cin)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cout, Cin)) * np.sqrt(2.0 / Cout)).astype(np.float32)
+    bn_pw, bn_dw = _bn_block(Cout, rng), _bn_block(Cin, rng)
+    dy = bn_pw[BN_GA].astype(np.float64) * (g - bn_pw[BN_GMEAN]) + bn_pw[BN_GB].astype(np.float64) * (y - bn_pw[BN_MEAN])
+    yc = ydw.astype(np.float64) - bn_dw[BN_MEAN]
+    pre = bn_dw[BN_SCALE] * yc + bn_dw[BN_BETA]
+    gdw_ref = (dy @ w.astype(np.float64)) * (pre > 0)
+    dw_ref = dy.T @ np.maximum(pre, 0)
+    dev = "cuda"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_g, d_y, d_ydw, d_w, d_bnpw, d_bndw = t(g), t(y), t(ydw), t(w), t(bn_pw), t(bn_dw)
+    rows = L.cdll.ttk_pwconv1x1_bwd_fused_rows(M, Cin, Cout)
+    assert rows > 0
+    g_dw = torch.full((M, Cin), float("nan"), device=dev)
+    part = torch.full((rows, 2, Cin), float("nan"), device=dev)
+    dw = torch.zeros(Cout, Cin, device=dev)
+    L.call("ttk_pwconv1x1_bwd_fused", p(d_g), p(d_y), p(d_bnpw), p(d_w), p(d_ydw), p(d_bndw), p(g_dw), p(dw), None, p(part), M, Cin, Cout)
+    torch.cuda.synchronize()
+    safe = np.abs(pre) > 1e-4  # a pre-activation within rounding of zero may fall on either side of the ReLU
+    out = g_dw.cpu().numpy()
+    assert np.isfinite(out).all()
+    assert _rel(out * safe, gdw_ref * safe) < 2e-6
+    assert _rel(dw.cpu().numpy(), dw_ref) < 2e-6
+    ps = part.cpu().numpy().astype(np.float64)
+    o64 = out.astype(np.float64)
+    np.testing.assert_allclose(ps[:, 0].sum(0), o64.sum(0), rtol=0, atol=3e-5 * np.abs(o64).sum(0).max())
+    np.testing.assert_allclose(ps[:, 1].sum(0), (o64 * yc).sum(0), rtol=0, atol=3e-5 * np.abs(o64 * yc).sum(0).max())
+    # the two kernels it replaces compute the same fp32 arithmetic (exact products, fp32 accumulation, another summation order)
+    g_dw2 = torch.empty(M, Cin, device=dev)
+    part2 = torch.empty(L.partial_rows_gemm(M), 2, Cin, device=dev)
+    dw2 = torch.zeros(Cout, Cin, device=dev)
+    wt = d_w.t().contiguous()
+    L.call("ttk_pwconv1x1_bwd_data", p(d_g), p(d_y), p(d_bnpw), p(wt), p(d_ydw), p(d_bndw), p(g_dw2), p(part2), M, Cin, Cout, None, 0)
+    L.call("ttk_pwconv1x1_bwd_weight", p(d_g), p(d_y), p(d_bnpw), p(d_ydw), p(d_bndw), p(dw2), None, M, Cin, Cout, 0)
+    torch.cuda.synchronize()
+    assert _rel(out * safe, g_dw2.cpu().numpy() * safe) < 2e-6 and _rel(dw.cpu().numpy(), dw2.cpu().numpy()) < 2e-6
+    # deterministic form
+    nb = L.cdll.ttk_pwconv1x1_bwd_fused_partial_bytes(M, Cin, Cout)
+    scratch = torch.full((nb // 4,), float("nan"), device=dev)
+    res = []
+    for _ in range(2):
+        dwp = torch.zeros(Cout, Cin, device=dev)
+        L.call("ttk_pwconv1x1_bwd_fused", p(d_g), p(d_y), p(d_bnpw), p(d_w), p(d_ydw), p(d_bndw), p(g_dw), p(dwp), p(scratch), p(part), M, Cin, Cout)
+        torch.cuda.synchronize()
+        res.append((dwp.clone(), g_dw.clone(), part.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+    assert _rel(res[0][0].cpu().numpy(), dw_ref) < 2e-6

@@ -37,6 +37,9 @@ for name, hw, ci, co, mult in shapes:
         "dgrad": lambda: L.call("ttk_pwconv1x1_bwd_data", p(g), p(y), p(bn_pw), None, p(ydw), p(bn_dw), p(gdw), p(part), M, ci, co, p(prep), BF),
         "wgrad": lambda: L.call("ttk_pwconv1x1_bwd_weight", p(g), p(y), p(bn_pw), p(ydw), p(bn_dw), p(dW), p(scr), M, ci, co, BF),
     }
+    if L.cdll.ttk_pwconv1x1_bwd_fused_rows(M, ci, co) and not BF:  # the first two layers: both gradients in one kernel
+        fpart = torch.empty(L.cdll.ttk_pwconv1x1_bwd_fused_rows(M, ci, co) * 2 * ci, device=dev)
+        calls["fused"] = lambda: L.call("ttk_pwconv1x1_bwd_fused", p(g), p(y), p(bn_pw), p(w), p(ydw), p(bn_dw), p(gdw), p(dW), None, p(fpart), M, ci, co)
     line = f"{name:6s} M={M:8d} K={ci:4d} N={co:4d} "
     for k, fn in calls.items():
         for _ in range(3):
@@ -49,6 +52,6 @@ for name, hw, ci, co, mult in shapes:
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / IT
         line += f"| {k} {us:7.1f} us {2 * M * ci * co / us / 1e6:6.1f} TF "
-        tot[k] += us * mult
+        tot[k] = tot.get(k, 0.0) + us * mult
     print(line, flush=True)
 print("per-step totals (us):", {k: round(v) for k, v in tot.items()}, "sum", round(sum(tot.values())))
