@@ -78,6 +78,9 @@ class KernelTimer:
         Mirrors the dispatch rules of csrc/pwconv.hip + pwconv_split.hip + dwconv_tiled.hip."""
         ints = [x for x in a if isinstance(x, int) and not isinstance(x, bool)]
         eb = KernelTimer.act_bytes
+        if name == "ttk_pwconv1x1_bwd_fused":  # first two pointwise layers: weight + data gradient, operands read once (HBM-bound)
+            M, ci, co = ints[-3:]
+            return f"pw_bwd_fused_k<{ci}, {co}>", 4 * M * ci * co, 4 * (2 * M * co + 2 * M * ci) + 4 * ci * co
         if name.startswith("ttk_pwconv1x1"):
             # trailing arguments: ..., M, Cin, Cout, [scratch pointer of the split weights,] act_bf16
             M, ci, co = ints[-4:-1] if name == "ttk_pwconv1x1_bwd_weight" else ints[-5:-2]
@@ -135,7 +138,8 @@ class KernelTimer:
             kern, fl, by = timer.work(name, args)
             ints = [x for x in args if isinstance(x, int) and not isinstance(x, bool)]
             timer.records.append((kern, s, e, fl, by))
-            timer.shapes.append(tuple(ints[-5:-2]) if name in ("ttk_pwconv1x1_fwd", "ttk_pwconv1x1_bwd_data") else tuple(ints[-4:-1]) if name == "ttk_pwconv1x1_bwd_weight"
+            timer.shapes.append(tuple(ints[-3:]) if name == "ttk_pwconv1x1_bwd_fused" else tuple(ints[-5:-2]) if name in ("ttk_pwconv1x1_fwd", "ttk_pwconv1x1_bwd_data")
+                                else tuple(ints[-4:-1]) if name == "ttk_pwconv1x1_bwd_weight"
                                 else tuple(ints[-9:]) if name.startswith("ttk_conv_") else tuple(args[-6:-1]))
 
         lib.call = call

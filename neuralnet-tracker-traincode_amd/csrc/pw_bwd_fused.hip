@@ -73,7 +73,9 @@ __global__ void __launch_bounds__(512) pw_bwd_fused_k(const float* __restrict__ 
     wsc[j] = bn_dw[TTK_BN_SCALE * CIN + col];
     wbe[j] = bn_dw[TTK_BN_BETA * CIN + col];
   }
-  auto wgrad_jobs = [&](int st) {
+  // between(k) runs after the k-th group of four MFMAs (k < WGW * BM / 8): the data gradient's epilogue rides there, in the
+  // issue slots the matrix instructions leave free
+  auto wgrad_jobs = [&](int st, auto&& between) {
     const float* Dy = DyS + st * BM * LDY;
     const float* Yc = YcS + st * BM * LDC;
 #pragma unroll
@@ -81,14 +83,25 @@ __global__ void __launch_bounds__(512) pw_bwd_fused_k(const float* __restrict__ 
       const int mt = (wj0 + j) / NTC, nt = (wj0 + j) % NTC;
       const float* ap = Dy + (4 * h) * LDY + mt * 32 + r32;
       const float* bp = Yc + (4 * h) * LDC + nt * 32 + r32;
+      // fragments of the next four MFMAs are requested before the current four issue (the compiler's own order waited for
+      // every ds_read right in front of its MFMA: the matrix pipe idled for an LDS latency per instruction pair)
+      float a[2][4], b[2][4];
 #pragma unroll
-      for (int q = 0; q < BM / 8; ++q)
+      for (int i = 0; i < 4; ++i) { a[0][i] = ap[i * LDY]; b[0][i] = bp[i * LDC]; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float a = ap[(8 * q + i) * LDY];
-          const float b = fmaxf(fmaf(wsc[j], bp[(8 * q + i) * LDC], wbe[j]), 0.f);
-          wacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, wacc[j], 0, 0, 0);
+      for (int q = 0; q < BM / 8; ++q) {
+        const int cur = q & 1;
+        if (q + 1 < BM / 8) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { a[cur ^ 1][i] = ap[(8 * (q + 1) + i) * LDY]; b[cur ^ 1][i] = bp[(8 * (q + 1) + i) * LDC]; }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          wacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], fmaxf(fmaf(wsc[j], b[cur][i], wbe[j]), 0.f), wacc[j], 0, 0, 0);
+        between(j * (BM / 8) + q);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
 
@@ -150,7 +163,7 @@ __global__ void __launch_bounds__(512) pw_bwd_fused_k(const float* __restrict__ 
         store(tn, (it + 1) & 1);
         if (tn + (int)gridDim.x < ntiles) load(tn + gridDim.x);  // lands under the MFMAs below
       }
-      if constexpr (WG_PROD) wgrad_jobs(it & 1);
+      if constexpr (WG_PROD) wgrad_jobs(it & 1, [](int) {});
       __syncthreads();
     }
   } else {
@@ -181,18 +194,22 @@ __global__ void __launch_bounds__(512) pw_bwd_fused_k(const float* __restrict__ 
           for (int e = 0; e < 16; ++e) acc[e] = 0.f;
           const float* ap = Dy + (mt * 32 + r32) * LDY + 4 * h;
           const float* bp = Wt + (nt * 32 + r32) * LDW + 4 * h;
+          float4 a4[2], b4[2];
+          a4[0] = ld4(ap); b4[0] = ld4(bp);
 #pragma unroll
           for (int q = 0; q < COUT / 8; ++q) {
-            const float4 a4 = ld4(ap + 8 * q), b4 = ld4(bp + 8 * q);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+            const int cur = q & 1;
+            if (q + 1 < COUT / 8) { a4[cur ^ 1] = ld4(ap + 8 * (q + 1)); b4[cur ^ 1] = ld4(bp + 8 * (q + 1)); }  // one group ahead
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[cur].x, b4[cur].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[cur].y, b4[cur].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[cur].z, b4[cur].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[cur].w, b4[cur].w, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
           }
           // accumulator element e of lane (r32, h): row (e & 3) + 8 (e >> 2) + 4 h of the tile, column r32
           const int col = nt * 32 + r32;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
+          auto epi = [&](int e) {
             const int row = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             const float yc = Yc[row * LDC + col];
             const float out = fmaf(dsc[j], yc, dbe[j]) > 0.f ? acc[e] : 0.f;  // ReLU mask of bn_dw
@@ -201,11 +218,17 @@ __global__ void __launch_bounds__(512) pw_bwd_fused_k(const float* __restrict__ 
               s1[j] += out;
               s2[j] = fmaf(out, yc, s2[j]);
             }
+          };
+          if constexpr (!WG_PROD && WG >= 4 && WGW * (BM / 8) == 16) {
+            wgrad_jobs(st, epi);  // 16 groups of weight-gradient MFMAs, one epilogue element behind each
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) epi(e);
           }
         }
       }
-      if constexpr (!WG_PROD)
-        if (has_wg) wgrad_jobs(st);
+      if constexpr (!WG_PROD && !(WG >= 4 && WGW * (BM / 8) == 16))
+        if (has_wg) wgrad_jobs(st, [](int) {});
       __syncthreads();
     }
     // ---- BatchNorm-backward sums of bn_dw: fold the lane halves, then the waves of a ci tile in a fixed order
