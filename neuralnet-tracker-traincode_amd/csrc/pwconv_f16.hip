@@ -935,7 +935,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_reduce_k(const float* __restri
 
 // The [M][K] x [Nout][K]^T shapes that run on these kernels (everything else: fp32 MFMA, pwconv.hip).
 bool f16_gemm_shape(int K, int Nout) {
-  return K >= 128 && K % 32 == 0 && ((Nout >= 256 && Nout % 256 == 0) || Nout == 128);
+  return K >= 64 && K % 32 == 0 && ((Nout >= 256 && Nout % 256 == 0) || Nout == 128);
 }
 bool f16_wgrad_shape(int Cin, int Cout) {
   if (Cin < 128 || Cout < 128 || Cin % 128 || Cout % 128) return false;
