@@ -97,7 +97,7 @@ class KernelTimer:
                 return "pw_wgrad_k", fl, by
             if K >= 128 and N % 256 == 0:
                 return f"pw16_k<128, 256, {mode}, {mode}, 1, {'float' if eb == 4 else 'unsigned short'}>", fl, by  # <BM, BN, A form, epilogue form, register sets, storage>
-            if K >= 128 and N == 128:
+            if K >= 64 and N == 128:
                 return f"pw16_k<256, 128, {mode}, {mode}, 1, {'float' if eb == 4 else 'unsigned short'}>", fl, by
             if N == 64 and K == 32:
                 return f"pw_gemm_k<64, 2, 2, {mode}, 1>", fl, by  # single LDS stage
