@@ -328,6 +328,154 @@ __global__ void __launch_bounds__(kBlock) bn_add_act_k(const float* __restrict__
   else if (res_bound && blockIdx.x == 0 && threadIdx.x == 0) *slot += *res_bound;  // nothing else touches the slot during this launch
 }
 
+// Weight gradient of the 7x7 stem on the fp32 matrix pipe:  dW[c][tap] = sum_pixels dy[pixel][c] * x[tap of pixel],
+// dy = ga*(g-gmean) + gb*(y-mean) formed on load.  The VALU kernel of stem_wgrad.h is compute-bound here (13.6 GFLOP at
+// B = 512: 0.49 ms against 0.19 ms of HBM time).  As the forward kernel, one WAVE = 32 consecutive output pixels: their
+// input rows sit in a private LDS patch, dy[32][64] beside it; v_mfma_f32_32x32x2_f32 with M = channels (2 tiles), N = taps
+// (2 tiles: 49 of 64), K = pixel pairs - 64 MFMAs per group, accumulated in registers over all groups of the wave.  Patch
+// pitch 201: the lanes of a B fragment are taps, bank (9 kh + kw) mod 32 - at most 2-way.  The workgroup's sum leaves as a
+// row of `partial` (folded in a fixed order by the caller) or, without scratch, as one atomicAdd per weight.
+constexpr int kS7WpW = 201;
+__global__ void __launch_bounds__(kBlock) stem7_wgrad_mfma_k(const float* __restrict__ g, const float* __restrict__ y,
+                                                              const float* __restrict__ bn, const float* __restrict__ x,
+                                                              float* __restrict__ dw, float* __restrict__ partial, int B, int H, int W,
+                                                              int Ho, int Wo, int PR, int patch_floats, int wave_floats) {
+  extern __shared__ __attribute__((aligned(16))) float smem7[];
+  constexpr int kTaps = kS7K * kS7K, Wp = kS7WpW, kLd = kS7C + 4;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n32 = lane & 31, half = lane >> 5;
+  float* patch = smem7 + (size_t)wv * wave_floats;  // [rounds of 9][Wp] input rows
+  float* dyS = patch + patch_floats;                // [32][kLd]
+  // taps of this lane in the two N tiles (the second tile holds taps 32..48)
+  const int tapA = n32, tapB = 32 + n32;
+  const bool okB = tapB < kTaps;
+  const int offA = (tapA / kS7K) * Wp + tapA % kS7K;
+  const int offB = okB ? (tapB / kS7K) * Wp + tapB % kS7K : 0;
+  const int c4 = lane & 15, prow = lane >> 4;  // dy staging: 16 lanes x float4 = one pixel's 64 channels
+  const float4 ga = ld4(bn + TTK_BN_GA * kS7C + 4 * c4), gb = ld4(bn + TTK_BN_GB * kS7C + 4 * c4);
+  const float4 gmean = ld4(bn + TTK_BN_GMEAN * kS7C + 4 * c4), mean = ld4(bn + TTK_BN_MEAN * kS7C + 4 * c4);
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int hw = Ho * Wo, gpi = (hw + 31) / 32;
+  const int groups = B * gpi, nwaves = (int)gridDim.x * (kBlock / kWave);
+  float v[9][3];
+  float4 rg[8], ry[8];
+  auto fetch_x = [&](int gi, int r0) {
+    const int n = gi / gpi, p0 = (gi - n * gpi) * 32, oh0 = p0 / Wo;
+    const float* xn = x + (size_t)n * H * W;
+#pragma unroll
+    for (int rr = 0; rr < 9; ++rr) {
+      const int hi = 2 * oh0 - 3 + r0 + rr;
+      const bool rok = r0 + rr < PR && hi >= 0 && hi < H;
+      const float* xr = xn + (size_t)(rok ? hi : 0) * W;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int wi = lane + 64 * k - 3;
+        const bool ok = rok && wi >= 0 && wi < W;
+        const float t = xr[ok ? wi : 0];  // unconditional (clamped) load
+        v[rr][k] = ok ? t : 0.f;
+      }
+    }
+  };
+  auto fetch_gy = [&](int gi) {
+    const int n = gi / gpi, p0 = (gi - n * gpi) * 32;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int p = p0 + prow + 4 * i;
+      const size_t o = ((size_t)n * hw + (p < hw ? p : hw - 1)) * kS7C + 4 * c4;
+      rg[i] = ld4nt(g + o);
+      ry[i] = ld4nt(y + o);
+    }
+  };
+  // Input rows and g / y of a group are fetched one group ahead (in flight under the previous group's MFMAs).  Measured
+  // alternatives, all slower: validity applied at the LDS write instead of behind the load (655 us), all loads issued at the
+  // group's start and waited for once (663 us) - this compiler serialises the 27 scalar loads in both.
+  const int g_first = (int)blockIdx.x * (kBlock / kWave) + wv;
+  if (g_first < groups) { fetch_x(g_first, 0); fetch_gy(g_first); }
+  for (int gidx = g_first; gidx < groups; gidx += nwaves) {
+    const int n = gidx / gpi, p0 = (gidx - n * gpi) * 32, oh0 = p0 / Wo;
+    __builtin_amdgcn_wave_barrier();  // the previous group's fragment reads are done (same wave, LDS in order)
+#pragma unroll
+    for (int rr = 0; rr < 9; ++rr)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) patch[rr * Wp + lane + 64 * k] = v[rr][k];
+    for (int r0 = 9; r0 < PR; r0 += 9) {
+      fetch_x(gidx, r0);
+#pragma unroll
+      for (int rr = 0; rr < 9; ++rr)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) patch[(r0 + rr) * Wp + lane + 64 * k] = v[rr][k];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int pl = prow + 4 * i;
+      float4 d = fma4(ga, sub4(rg[i], gmean), mul4(gb, sub4(ry[i], mean)));
+      if (p0 + pl >= hw) d = f4(0.f);  // pixels past the image end contribute nothing
+      st4(dyS + pl * kLd + 4 * c4, d);
+    }
+    if (gidx + nwaves < groups) { fetch_x(gidx + nwaves, 0); fetch_gy(gidx + nwaves); }  // in flight under the MFMAs
+    __builtin_amdgcn_wave_barrier();
+    // pixel of this lane's k slot: p0 + 2 j + half, walked with a branch-free carry; the fragments of pixel pair j + 1 are
+    // requested before the four MFMAs of pair j issue (waiting for each ds_read right in front of its MFMA left the matrix
+    // pipe idle for an LDS latency per pair)
+    int pidx = p0 + half;
+    int oh = (pidx < hw ? pidx : hw - 1) / Wo, ow = (pidx < hw ? pidx : hw - 1) - oh * Wo;
+    float fa0[2], fa1[2], fbA[2], fbB[2];
+    auto frag = [&](int j, int set) {
+      const float* win = patch + (2 * (oh - oh0)) * Wp + 2 * ow;
+      fbA[set] = win[offA];
+      fbB[set] = win[offB];
+      fa0[set] = dyS[(2 * j + half) * kLd + n32];
+      fa1[set] = dyS[(2 * j + half) * kLd + 32 + n32];
+      // two pixels on (clamped at the image end: those pixels' dy is zero)
+      ow += 2;
+      const bool cw = ow >= Wo;
+      ow -= cw ? Wo : 0;
+      oh += cw;
+      const bool ce = oh * Wo + ow >= hw;
+      oh = ce ? oh0 : oh;
+      ow = ce ? 0 : ow;
+    };
+    frag(0, 0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int cur = j & 1;
+      if (j + 1 < 16) frag(j + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const float bB = okB ? fbB[cur] : 0.f;
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cur], fbA[cur], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cur], bB, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur], fbA[cur], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur], bB, acc[1][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- the four waves' sums, in wave order, then the workgroup's row / atomics.  acc[mt][nt][e]: channel 32 mt + (e & 3) +
+  // 8 (e >> 2) + 4 half, tap 32 nt + n32
+  __syncthreads();
+  float* red = smem7;  // [4][64][49] (50 KB: the patches are dead)
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int c = 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * half, tap = 32 * nt + n32;
+        if (tap < kTaps) red[(wv * kS7C + c) * kTaps + tap] = acc[mt][nt][e];
+      }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kS7C * kTaps; i += kBlock) {
+    float a = 0.f;
+    for (int w_ = 0; w_ < kBlock / kWave; ++w_) a += red[w_ * kS7C * kTaps + i];
+    if (partial) partial[(size_t)blockIdx.x * kS7C * kTaps + i] = a;
+    else atomicAdd(dw + i, a);
+  }
+}
+
 // dy = ga*(g-gmean) + gb*(y-mean): the gradient w.r.t. a conv output through its BatchNorm, written once for the
 // convolution's weight and data gradients (both then read 4 instead of 8 bytes per element, the data gradient nine times).
 // Written as the fp16-split GEMMs consume it (pwconv_f16.hip): two fp16 planes [rows][C] - h = fp16(dy S), then l = fp16(dy S - h),
@@ -446,7 +594,20 @@ int ttk_stem7_bwd_weight(const float* g, const float* y, const float* bn, const 
   TTK_REQUIRE(B > 0 && H > 6 && W > 6, "stem7_bwd_weight: bad shape");
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   (void)hipMemsetAsync(dw, 0, sizeof(float) * kS7C * kS7K * kS7K, (hipStream_t)stream);
-  launch_stem_wgrad<kS7K, kS7C>(g, y, bn, x, dw, partial, B, H, W, Ho, Wo, (hipStream_t)stream);
+  const int PR = 2 * ((Wo + 30) / Wo) + 7, prows = (PR + 8) / 9 * 9;
+  const int patch_floats = prows * kS7WpW, wave_floats = patch_floats + 32 * (kS7C + 4);
+  size_t smem = (size_t)(kBlock / kWave) * wave_floats * sizeof(float);
+  const size_t red_bytes = (size_t)(kBlock / kWave) * kS7C * kS7K * kS7K * sizeof(float);
+  if (smem < red_bytes) smem = red_bytes;
+  static const bool valu = getenv("TTK_STEM7_VALU") != nullptr;  // the previous kernels (A/B timing)
+  if (!valu && smem <= 64 * 1024 && W + 7 <= 192 && (int64_t)B * ((Ho * Wo + 31) / 32) < ((int64_t)1 << 30)) {
+    const int grid = stem_wgrad_grid(B, Ho);
+    hipLaunchKernelGGL(stem7_wgrad_mfma_k, dim3(grid), dim3(kBlock), smem, (hipStream_t)stream, g, y, bn, x, dw, partial, B, H, W, Ho, Wo, PR,
+                       patch_floats, wave_floats);
+    if (partial) launch_fold_partials(partial, grid, (int64_t)kS7C * kS7K * kS7K, dw, 1, (hipStream_t)stream);
+  } else {
+    launch_stem_wgrad<kS7K, kS7C>(g, y, bn, x, dw, partial, B, H, W, Ho, Wo, (hipStream_t)stream);
+  }
   TTK_LAUNCH_CHECK("stem7_bwd_weight");
 }
 

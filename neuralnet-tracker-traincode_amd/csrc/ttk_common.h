@@ -76,8 +76,31 @@ __global__ void __launch_bounds__(256) fold_partials_k(const float* __restrict__
   for (int r = 0; r < rows; ++r) a += partial[(size_t)r * n + i];
   out[i] = a;
 }
+// many rows, few outputs (the stem's 1024 workgroup rows of 3136 weights): 8 row groups per output, each summed in row order,
+// then the 8 group sums in group order - still a fixed order, 8 times the parallelism and 32-float coalesced row reads
+template <int kDummy = 0>
+__global__ void __launch_bounds__(256) fold_partials_wide_k(const float* __restrict__ partial, int rows, int64_t n, float* __restrict__ out,
+                                                             int accumulate) {
+  __shared__ float sm[8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + tx;
+  float a = 0.f;
+  if (i < n)
+    for (int r = ty; r < rows; r += 8) a += partial[(size_t)r * n + i];
+  sm[ty][tx] = a;
+  __syncthreads();
+  if (ty == 0 && i < n) {
+    float t = accumulate ? out[i] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += sm[q][tx];
+    out[i] = t;
+  }
+}
 inline void launch_fold_partials(const float* partial, int rows, int64_t n, float* out, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(fold_partials_k<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, rows, n, out, accumulate);
+  if (rows >= 64 && n <= 65536)
+    hipLaunchKernelGGL(fold_partials_wide_k<0>, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, partial, rows, n, out, accumulate);
+  else
+    hipLaunchKernelGGL(fold_partials_k<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, rows, n, out, accumulate);
 }
 
 // ---- float4 helpers -------------------------------------------------------------------------
