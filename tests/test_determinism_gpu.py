@@ -1,8 +1,8 @@
 """TTK_DETERMINISTIC=1: every weight-gradient reduction of the step runs in a fixed order (slices of M / workgroup partials
 stored to scratch and folded by a second kernel instead of fp32 atomics; the heads' weight gradient as one chunk).
 Two runs of the same six training steps then give BITWISE equal losses and parameters - what the reference's CPU path
-does by construction.  (The default mode keeps the atomics: the deterministic step measured 18 % slower, mostly the single-chunk
-heads kernel and the many-slice fp32 partials; run-to-run noise of the default ~1e-7 in the gradients.)"""
+does by construction.  (The default mode keeps the atomics: the deterministic step measures 6 % slower; run-to-run noise of the
+default ~1e-7 in the gradients.)"""
 import os
 import subprocess
 import sys
