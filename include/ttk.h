@@ -42,7 +42,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 11
+#define TTK_ABI_VERSION 12
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -190,16 +190,18 @@ int ttk_pwconv1x1_bwd_weight(const void* g, const void* y, const float* bn_pw, c
  * prepared are HOST arrays): three launches for all layers (|w| maxima, planes).  prepared[i]: device scratch of
  * ttk_pwconv_prepared_bytes(cin[i], cout[i]); pass it as `wsplit` with w == NULL (forward) / wt == NULL (data gradient)
  * to skip the per-call split and transpose launches. */
-/* Weight AND data gradient of the first two pointwise layers (Cin -> Cout = 32 -> 64, 64 -> 128; fp32 storage) in one kernel:
- * g, y and ydw are read once instead of twice (these layers are HBM-bound).  w[Cout][Cin] raw weights; dw accumulates
+/* Weight AND data gradient of the first pointwise layers (Cin -> Cout = 32 -> 64, 64 -> 128, 128 -> 128; fp32 storage) in one
+ * kernel: g, y and ydw are read once instead of twice (these layers are HBM-bound).  32 -> 64 and 64 -> 128 run on the fp32
+ * matrix pipe from the raw weights w[Cout][Cin] (wsplit unused); 128 -> 128 on the fp16 pipe from the block that
+ * ttk_pwconv_prepare_weights filled (wsplit; w unused), with the operand bounds of row TTK_BN_AUX.  dw accumulates
  * (fp32 atomics per workgroup, or - partial = scratch of ttk_pwconv1x1_bwd_fused_partial_bytes - workgroup rows folded in a
  * fixed order); g_dw and part as ttk_pwconv1x1_bwd_data, with ttk_pwconv1x1_bwd_fused_rows(M, Cin, Cout) partial rows
  * (0 = this shape has no fused form). */
 int ttk_pwconv1x1_bwd_fused_rows(int64_t M, int Cin, int Cout);
 size_t ttk_pwconv1x1_bwd_fused_partial_bytes(int64_t M, int Cin, int Cout);
-int ttk_pwconv1x1_bwd_fused(const float* g, const float* y, const float* bn_pw, const float* w, const float* ydw,
-                            const float* bn_dw, float* g_dw, float* dw, float* partial, float* part, int64_t M, int Cin,
-                            int Cout, ttk_stream_t stream);
+int ttk_pwconv1x1_bwd_fused(const float* g, const float* y, const float* bn_pw, const float* w, const void* wsplit,
+                            const float* ydw, const float* bn_dw, float* g_dw, float* dw, float* partial, float* part,
+                            int64_t M, int Cin, int Cout, ttk_stream_t stream);
 size_t ttk_pwconv_prepared_bytes(int Cin, int Cout);
 int ttk_pwconv_prepare_weights(int n, const float* const* w, const int* cin, const int* cout,
                                void* const* prepared, ttk_stream_t stream);

@@ -1,4 +1,4 @@
-// Backward of the first pointwise convolutions (32 -> 64 and 64 -> 128 channels; DepthWiseBlock.conv_sep + bn_sep,
+// Backward of the first pointwise convolutions (32 -> 64, 64 -> 128 and - second half of this file - 128 -> 128 channels; DepthWiseBlock.conv_sep + bn_sep,
 // backbones/mobilenet_v1.py:67-68,82-84) as ONE kernel: data gradient and weight gradient from one read of the operands.
 //
 // These layers have the largest activations of the network and are HBM-bound.  As two kernels (pwconv.hip: pw_gemm_k
@@ -19,6 +19,7 @@
 // The MFMA's two k slots of a lane half h take k = 8q + 4h + i, i = 0..3, for four consecutive instructions, so that the
 // data gradient's fragments are ds_read_b128 (4 k-values per read) - any k order is a valid contraction order.
 #include "ttk_common.h"
+#include "conv_geom.h"
 
 namespace ttk {
 
@@ -266,11 +267,232 @@ __global__ void __launch_bounds__(512) pw_bwd_fused_k(const float* __restrict__ 
   }
 }
 
-static bool fused_shape(int Cin, int Cout) { return (Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 128); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The 128 -> 128 layer: the same fusion on the fp16 matrix pipe (fp32 MFMA would bind: 8.4 MFLOP per 64 rows).  Arithmetic
+// of pwconv_f16.hip: operands scaled by powers of two taken from their bounds (dy: TTK_AUX_DY_BOUND of bn_pw, a:
+// TTK_AUX_ACT_BOUND of bn_dw, W: the |w| maximum in the prepared block), cut into two fp16 pieces, three products.
+//
+// What makes it fit: the WEIGHTS live in registers.  Consumer wave w owns input-channel tile w (32 of 128) for both products;
+// its data-gradient B fragments (W^T planes of 32 ci x 128 co: 8 k16 steps x 2 planes) are 64 VGPRs loaded once from the
+// prepared data-gradient operand, so LDS only holds the per-stage tiles of 32 rows, double-buffered (2 x 65 KB):
+//   DyR  dy row-major   [plane][32 rows][128 co]  - data gradient, A operand (k = co); 16-byte chunk XOR (row & 15)
+//   DyT  dy transposed  [k16][plane][128 co][16 rows] - weight gradient, A operand (k = rows); layout of pwconv_f16.hip
+//   AT   a  transposed  [k16][plane][128 ci][16 rows] - weight gradient, B operand
+//   Yc   ydw - mean, fp32 [32][132] - ReLU mask and the BatchNorm-backward sums of the epilogue
+// The producers load 4 rows x 4 channels per thread (as the weight-gradient kernels do) and write both layouts of dy from the
+// same registers.  Per 32 rows a consumer wave issues 24 (data gradient) + 24 (weight gradient) MFMAs = 1536 cycles against
+// 64 KB of operands through the CU (6400 cycles): memory-bound, as it should be.
+typedef _Float16 fz16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 fz16x2 __attribute__((ext_vector_type(2)));
+typedef float fz32x2 __attribute__((ext_vector_type(2)));
+typedef float fz32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int fz_swz(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 3) & 1)) << 4); }
+// h / l fp16 pieces of 4 (already scaled) values: 8 bytes each
+__device__ __forceinline__ void fz_split(fz32x4 v, uint2& h, uint2& l) {
+  const fz16x2 h01 = __builtin_convertvector(fz32x2{v.x, v.y}, fz16x2), h23 = __builtin_convertvector(fz32x2{v.z, v.w}, fz16x2);
+  const fz32x2 f01 = __builtin_convertvector(h01, fz32x2), f23 = __builtin_convertvector(h23, fz32x2);
+  const fz16x2 l01 = __builtin_convertvector(fz32x2{v.x - f01.x, v.y - f01.y}, fz16x2);
+  const fz16x2 l23 = __builtin_convertvector(fz32x2{v.z - f23.x, v.w - f23.y}, fz16x2);
+  h = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+  l = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+}
+
+constexpr int kF16C = 128, kF16BM = 32;
+constexpr int kF16RowPlane = kF16BM * kF16C * 2;       // bytes of one plane of DyR
+constexpr int kF16TPlane = kF16C * 32;                 // bytes of one plane of one k16 stage of DyT / AT
+constexpr int kF16Ldc = kF16C + 4;
+constexpr int kF16Stage = 2 * kF16RowPlane + 2 * (2 * 2 * kF16TPlane) + kF16BM * kF16Ldc * 4;  // DyR + DyT + AT + Yc
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+pw_bwd_fused16_k(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ bn_pw, const uint16_t* __restrict__ wq,
+                 const float* __restrict__ wmax, const float* __restrict__ ydw, const float* __restrict__ bn_dw, float* __restrict__ g_dw,
+                 float* __restrict__ dW, float* __restrict__ wpartial, float* __restrict__ part, int64_t M, int ntiles) {
+  constexpr int C = kF16C, BM = kF16BM;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kF16Stage + 4 * 2 * C * 4];
+  float* red = reinterpret_cast<float*>(lds + 2 * kF16Stage);  // [4][2][32]: every wave owns its 32 channels
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 4;
+  const int r32 = lane & 31, h = lane >> 5;
+  const float sa = pow2_scale(bn_pw[(size_t)TTK_BN_AUX * C + TTK_AUX_DY_BOUND]);
+  const float sx = pow2_scale(bn_dw[(size_t)TTK_BN_AUX * C + TTK_AUX_ACT_BOUND]);
+  const float sw = pow2_scale(*wmax);
+  auto stage_ptr = [&](int st) { return lds + st * kF16Stage; };
+
+  if (producer) {
+    const int pt = tid - 256;
+    const int mb = pt & 7, cq = pt >> 3;  // 8 row blocks of 4 rows x 32 channel quads
+    const int sub = mb >> 2, chunk = (mb >> 1) & 1, o8 = (mb & 1) * 8;
+    const fz32x4 ga = *reinterpret_cast<const fz32x4*>(bn_pw + TTK_BN_GA * C + 4 * cq) * sa;
+    const fz32x4 gb = *reinterpret_cast<const fz32x4*>(bn_pw + TTK_BN_GB * C + 4 * cq) * sa;
+    const fz32x4 gmean = *reinterpret_cast<const fz32x4*>(bn_pw + TTK_BN_GMEAN * C + 4 * cq);
+    const fz32x4 ymean = *reinterpret_cast<const fz32x4*>(bn_pw + TTK_BN_MEAN * C + 4 * cq);
+    const fz32x4 dsc = *reinterpret_cast<const fz32x4*>(bn_dw + TTK_BN_SCALE * C + 4 * cq) * sx;
+    const fz32x4 dbe = *reinterpret_cast<const fz32x4*>(bn_dw + TTK_BN_BETA * C + 4 * cq) * sx;
+    const fz32x4 dmean = *reinterpret_cast<const fz32x4*>(bn_dw + TTK_BN_MEAN * C + 4 * cq);
+    fz32x4 rg[4], ry[4], rc[4];
+    auto load = [&](int t) {
+      const int64_t r0 = (int64_t)t * BM + 4 * mb;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t row = r0 + i < M ? r0 + i : M - 1;
+        const float4 a = ld4nt(g + row * C + 4 * cq), b = ld4nt(y + row * C + 4 * cq), c = ld4(ydw + row * C + 4 * cq);
+        rg[i] = fz32x4{a.x, a.y, a.z, a.w}; ry[i] = fz32x4{b.x, b.y, b.z, b.w}; rc[i] = fz32x4{c.x, c.y, c.z, c.w};
+      }
+    };
+    auto store = [&](int t, int st) {
+      unsigned char* S = stage_ptr(st);
+      unsigned char* DyR = S;
+      unsigned char* DyT = S + 2 * kF16RowPlane;
+      unsigned char* AT = DyT + 2 * 2 * kF16TPlane;
+      float* Yc = reinterpret_cast<float*>(AT + 2 * 2 * kF16TPlane);
+      const int64_t r0 = (int64_t)t * BM + 4 * mb;
+      fz32x4 dy[4], av[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dy[i] = ga * (rg[i] - gmean) + gb * (ry[i] - ymean);
+        const fz32x4 yc = rc[i] - dmean;
+        fz32x4 a = dsc * yc + dbe;
+        a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+        if (r0 + i >= M) { dy[i] = fz32x4{0.f, 0.f, 0.f, 0.f}; a = dy[i]; }  // rows past the end contribute nothing
+        av[i] = a;
+        *reinterpret_cast<fz32x4*>(Yc + (4 * mb + i) * kF16Ldc + 4 * cq) = yc;
+        // dy row-major: 8-byte piece cq of row 4 mb + i, 16-byte chunk XOR (row & 15)
+        uint2 ph, pl;
+        fz_split(dy[i], ph, pl);
+        const int row = 4 * mb + i, off = row * (C * 2) + ((((cq >> 1) ^ (row & 15))) << 4) + (cq & 1) * 8;
+        *reinterpret_cast<uint2*>(DyR + off) = ph;
+        *reinterpret_cast<uint2*>(DyR + kF16RowPlane + off) = pl;
+      }
+      // transposed: channel 4 cq + e, four consecutive rows 4 mb .. 4 mb + 3 (k) -> 8 bytes per plane
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        uint2 ph, pl;
+        const int off = sub * (2 * kF16TPlane) + fz_swz(4 * cq + e, chunk) + o8;
+        fz_split(fz32x4{dy[0][e], dy[1][e], dy[2][e], dy[3][e]}, ph, pl);
+        *reinterpret_cast<uint2*>(DyT + off) = ph;
+        *reinterpret_cast<uint2*>(DyT + kF16TPlane + off) = pl;
+        fz_split(fz32x4{av[0][e], av[1][e], av[2][e], av[3][e]}, ph, pl);
+        *reinterpret_cast<uint2*>(AT + off) = ph;
+        *reinterpret_cast<uint2*>(AT + kF16TPlane + off) = pl;
+      }
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) {
+      load(t);
+      store(t, 0);
+      if (t + (int)gridDim.x < ntiles) load(t + gridDim.x);
+    }
+    __syncthreads();
+    for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
+      const int tn = t + gridDim.x;
+      if (tn < ntiles) {
+        store(tn, (it + 1) & 1);
+        if (tn + (int)gridDim.x < ntiles) load(tn + gridDim.x);
+      }
+      __syncthreads();
+    }
+  } else {
+    const int ci = 32 * wave + r32;  // this lane's input channel (data-gradient column, weight-gradient column)
+    // data-gradient B fragments: W^T planes [co / 32][ci][32] of the prepared operand, k16 step s, lane half h: co 16 s + 8 h ..
+    fz16x8 Wf[8][2];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int co = 16 * s + 8 * h;
+      const size_t idx = ((size_t)(co >> 5) * C + ci) * 32 + (co & 31);
+      Wf[s][0] = *reinterpret_cast<const fz16x8*>(wq + idx);
+      Wf[s][1] = *reinterpret_cast<const fz16x8*>(wq + (size_t)C * C + idx);
+    }
+    const float dsc = bn_dw[TTK_BN_SCALE * C + ci], dbe = bn_dw[TTK_BN_BETA * C + ci];
+    const float inv_dg = 1.f / (sa * sw), inv_wg = 1.f / (sa * sx);
+    f32x16 wacc[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) wacc[tt][e] = 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    __syncthreads();  // stage 0
+    int it = 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x, ++it) {
+      const unsigned char* S = stage_ptr(it & 1);
+      const unsigned char* DyR = S;
+      const unsigned char* DyT = S + 2 * kF16RowPlane;
+      const unsigned char* AT = DyT + 2 * 2 * kF16TPlane;
+      const float* Yc = reinterpret_cast<const float*>(AT + 2 * 2 * kF16TPlane);
+      const int64_t m0 = (int64_t)t * BM;
+      // ---- data gradient: 32 rows x this wave's 32 ci, contraction over the 128 co
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int off = r32 * (C * 2) + ((((2 * s + h) ^ (r32 & 15))) << 4);
+        const fz16x8 ah = *reinterpret_cast<const fz16x8*>(DyR + off), al = *reinterpret_cast<const fz16x8*>(DyR + kF16RowPlane + off);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Wf[s][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Wf[s][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Wf[s][0], acc, 0, 0, 0);
+      }
+      // ---- weight gradient: dW[co tile tt][this wave's ci tile] += dy^T a over the 32 rows (two k16 stages)
+      fz16x8 bh[2], bl[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int off = s * (2 * kF16TPlane) + fz_swz(ci, h);
+        bh[s] = *reinterpret_cast<const fz16x8*>(AT + off);
+        bl[s] = *reinterpret_cast<const fz16x8*>(AT + kF16TPlane + off);
+      }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int off = s * (2 * kF16TPlane) + fz_swz(32 * tt + r32, h);
+          const fz16x8 ah = *reinterpret_cast<const fz16x8*>(DyT + off), al = *reinterpret_cast<const fz16x8*>(DyT + kF16TPlane + off);
+          wacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], wacc[tt], 0, 0, 0);
+          wacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], wacc[tt], 0, 0, 0);
+          wacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], wacc[tt], 0, 0, 0);
+        }
+      // ---- data-gradient epilogue: accumulator element e of lane (r32, h) = row (e & 3) + 8 (e >> 2) + 4 h, column ci
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const float yc = Yc[row * kF16Ldc + ci];
+        const float out = fmaf(dsc, yc, dbe) > 0.f ? acc[e] * inv_dg : 0.f;
+        if (m0 + row < M) {
+          g_dw[(size_t)(m0 + row) * C + ci] = out;
+          s1 += out;
+          s2 = fmaf(out, yc, s2);
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = 32 * tt + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const float v = wacc[tt][e] * inv_wg;
+        if (wpartial) wpartial[(size_t)blockIdx.x * C * C + co * C + ci] = v;
+        else atomicAdd(dW + co * C + ci, v);
+      }
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (h == 0) { red[(wave * 2 + 0) * 32 + r32] = s1; red[(wave * 2 + 1) * 32 + r32] = s2; }
+  }
+  __syncthreads();
+  if (part && tid < 2 * C) {
+    const int which = tid / C, c = tid % C;
+    part[(size_t)blockIdx.x * 2 * C + which * C + c] = red[((c >> 5) * 2 + which) * 32 + (c & 31)];
+  }
+}
+
+static bool fused_shape(int Cin, int Cout) {
+  // (the 128 -> 128 form reads the fp16 planes of the prepared weight block: default TTK_GEMM mode only)
+  return (Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 128) || (Cin == 128 && Cout == 128 && gemm_mode() == GEMM_F16X2);
+}
 
 static int fused_grid(int64_t M, int Cin) {
-  const int64_t ntiles = ceil_div(M, kFusedBM);
-  const int64_t cap = Cin == 32 ? 512 : 256;  // two workgroups per CU fit for the 32 -> 64 layer (62 KB of LDS), one for 64 -> 128
+  const int64_t ntiles = ceil_div(M, Cin == 128 ? kF16BM : kFusedBM);
+  const int64_t cap = Cin == 32 ? 512 : 256;  // two workgroups per CU fit for the 32 -> 64 layer (62 KB of LDS), one for the others
   return (int)(ntiles < cap ? ntiles : cap);
 }
 
@@ -286,13 +508,21 @@ size_t ttk_pwconv1x1_bwd_fused_partial_bytes(int64_t M, int Cin, int Cout) {
   return fused_shape(Cin, Cout) && M > 0 ? (size_t)fused_grid(M, Cin) * Cin * Cout * sizeof(float) : 0;
 }
 
-int ttk_pwconv1x1_bwd_fused(const float* g, const float* y, const float* bn_pw, const float* w, const float* ydw, const float* bn_dw,
-                            float* g_dw, float* dw, float* partial, float* part, int64_t M, int Cin, int Cout, ttk_stream_t stream) {
-  TTK_REQUIRE(g && y && bn_pw && w && ydw && bn_dw && g_dw && dw, "pwconv1x1_bwd_fused: null pointer");
-  TTK_REQUIRE(fused_shape(Cin, Cout) && M > 0, "pwconv1x1_bwd_fused: only the 32 -> 64 and 64 -> 128 layers (got %d -> %d)", Cin, Cout);
-  const int ntiles = (int)ceil_div(M, kFusedBM), grid = fused_grid(M, Cin);
+int ttk_pwconv1x1_bwd_fused(const float* g, const float* y, const float* bn_pw, const float* w, const void* wsplit, const float* ydw,
+                            const float* bn_dw, float* g_dw, float* dw, float* partial, float* part, int64_t M, int Cin, int Cout,
+                            ttk_stream_t stream) {
+  TTK_REQUIRE(g && y && bn_pw && ydw && bn_dw && g_dw && dw, "pwconv1x1_bwd_fused: null pointer");
+  TTK_REQUIRE(fused_shape(Cin, Cout) && M > 0, "pwconv1x1_bwd_fused: only the 32 -> 64, 64 -> 128 and 128 -> 128 layers (got %d -> %d)", Cin, Cout);
+  TTK_REQUIRE(Cin == 128 ? wsplit != nullptr : w != nullptr, "pwconv1x1_bwd_fused: 128 -> 128 needs the prepared weight block, the others the raw weights");
+  const int ntiles = (int)ceil_div(M, Cin == 128 ? kF16BM : kFusedBM), grid = fused_grid(M, Cin);
   hipStream_t st = (hipStream_t)stream;
-  if (Cin == 32) {
+  if (Cin == 128) {
+    // prepared block (ttk_pwconv_prepare_weights, fp16 mode): [forward planes 4n][data-gradient planes 4n][|w| maximum]
+    const size_t n = (size_t)Cin * Cout;
+    const unsigned char* ws = static_cast<const unsigned char*>(wsplit);
+    hipLaunchKernelGGL(pw_bwd_fused16_k, dim3(grid), dim3(512), 0, st, g, y, bn_pw, reinterpret_cast<const uint16_t*>(ws + 4 * n),
+                       reinterpret_cast<const float*>(ws + 8 * n), ydw, bn_dw, g_dw, dw, partial, part, M, ntiles);
+  } else if (Cin == 32) {
     hipLaunchKernelGGL((pw_bwd_fused_k<32, 64>), dim3(grid), dim3(512), 0, st, g, y, bn_pw, w, ydw, bn_dw, g_dw, dw, partial, part, M, ntiles);
   } else {
     hipLaunchKernelGGL((pw_bwd_fused_k<64, 128>), dim3(grid), dim3(512), 0, st, g, y, bn_pw, w, ydw, bn_dw, g_dw, dw, partial, part, M, ntiles);

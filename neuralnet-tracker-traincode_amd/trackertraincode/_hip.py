@@ -30,7 +30,7 @@ _SIGNATURES = {
     "ttk_pwconv1x1_bwd_data": [_P] * 8 + [_L, _I, _I, _P, _I],
     "ttk_pwconv1x1_bwd_weight": [_P] * 7 + [_L, _I, _I, _I],
     "ttk_pwconv_prepare_weights": [_I, _P, _P, _P, _P],
-    "ttk_pwconv1x1_bwd_fused": [_P] * 10 + [_L, _I, _I],
+    "ttk_pwconv1x1_bwd_fused": [_P] * 11 + [_L, _I, _I],
     "ttk_transpose": [_P, _P, _I, _I],
     "ttk_avgpool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I],
     "ttk_avgpool_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
@@ -86,7 +86,7 @@ _SIGNATURES = {
     "ttk_clip_adam": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P],
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class _Library:

@@ -295,9 +295,9 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         g_dw = torch.empty(st_dw.y.shape, dtype=ctx.gdt, device=st_dw.y.device)
         fused_rows = L.cdll.ttk_pwconv1x1_bwd_fused_rows(M, cin, cout) if (_FUSED_PW_BWD and bf == 0 and side is None) else 0
         if fused_rows:
-            # the first two pointwise layers (HBM-bound, the largest activations): weight and data gradient in ONE kernel - g,
+            # the first three pointwise layers (HBM-bound, the largest activations): weight and data gradient in ONE kernel - g,
             # the conv output and the depthwise output are read once instead of twice (csrc/pw_bwd_fused.hip)
-            L.call("ttk_pwconv1x1_bwd_fused", p(g), p(st_pw.y), p(st_pw.bn), p(w_pw), p(st_dw.y), p(st_dw.bn), p(g_dw), p(dW),
+            L.call("ttk_pwconv1x1_bwd_fused", p(g), p(st_pw.y), p(st_pw.bn), p(w_pw), p(ctx.prep[k]), p(st_dw.y), p(st_dw.bn), p(g_dw), p(dW),
                    p(wg_scratch), p(part), M, cin, cout)
             bwd_finalize(st_dw, fused_rows, M, pi + 1)
         elif side is not None:

@@ -185,11 +185,16 @@ def test_gradients_vs_fp64_oracle():
     assert not bad, [(k, f"{a:.1e}", f"{b:.1e}") for k, a, b in bad]
 
 
-def test_graphed_train_step_matches_eager():
+def test_graphed_train_step_matches_eager(monkeypatch):
     """The captured hipGraph step (train.GraphedTrainStep) must walk the same trajectory as the eager step: same
     kernels, Adam's step count / learning rates read from device memory instead of launch arguments, a learning-rate
-    change in the middle (no re-capture) and a loss-weight change (re-capture)."""
+    change in the middle (no re-capture) and a loss-weight change (re-capture).  The backbone's weight-gradient reductions run
+    in their fixed-order form here (the host side of TTK_DETERMINISTIC=1): with fp32 atomics the B = 8 trajectory is chaotic
+    (Adam's normalised update turns summation-order noise into +-lr steps) and the comparison failed about one run in five."""
+    import trackertraincode.backbones.mobilenet_v1 as MB
     import trackertraincode.train as train
+
+    monkeypatch.setattr(MB, "_DETERMINISTIC", True)
 
     d, meta = load_golden("model_full.npz")
     S = train_script()

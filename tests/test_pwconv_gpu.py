@@ -163,7 +163,8 @@ def test_prepared_weights_match_per_call_split():
         L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(y), None, M, Cin, Cout, None, 0)
 
 
-@pytest.mark.parametrize("M,Cin,Cout", [(64 * 300 + 17, 32, 64), (64 * 1100 + 63, 32, 64), (64 * 200 + 1, 64, 128), (64 * 700 + 40, 64, 128), (50, 64, 128)])
+@pytest.mark.parametrize("M,Cin,Cout", [(64 * 300 + 17, 32, 64), (64 * 1100 + 63, 32, 64), (64 * 200 + 1, 64, 128), (64 * 700 + 40, 64, 128), (50, 64, 128),
+                                        (32 * 500 + 9, 128, 128), (32 * 1300 + 31, 128, 128), (20, 128, 128)])
 def test_fused_bwd_matches_fp64_and_the_two_kernels(M, Cin, Cout):
     """ttk_pwconv1x1_bwd_fused (first two pointwise layers: weight + data gradient from one read of the operands) against
     float64 numpy, against the two kernels it replaces, and - with the scratch buffer - bitwise reproducible."""
@@ -183,18 +184,25 @@ def test_fused_bwd_matches_fp64_and_the_two_kernels(M, Cin, Cout):
     dev = "cuda"
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     d_g, d_y, d_ydw, d_w, d_bnpw, d_bndw = t(g), t(y), t(ydw), t(w), t(bn_pw), t(bn_dw)
+    prep = None
+    if Cin == 128:  # the fp16-pipe form: prepared weight planes and the operand bounds of row TTK_BN_AUX (1.7x loose, as the step's are)
+        prep = torch.empty(L.pwconv_prepared_bytes(Cin, Cout), dtype=torch.uint8, device=dev)
+        L.pwconv_prepare_weights([d_w.view(Cout, Cin, 1, 1)], [prep])
+        d_bnpw[BN_AUX, AUX_DY_BOUND] = 1.7 * float(np.abs(dy).max())
+        d_bndw[BN_AUX, AUX_ACT_BOUND] = 1.7 * float(np.maximum(pre, 0).max())
     rows = L.cdll.ttk_pwconv1x1_bwd_fused_rows(M, Cin, Cout)
     assert rows > 0
     g_dw = torch.full((M, Cin), float("nan"), device=dev)
     part = torch.full((rows, 2, Cin), float("nan"), device=dev)
     dw = torch.zeros(Cout, Cin, device=dev)
-    L.call("ttk_pwconv1x1_bwd_fused", p(d_g), p(d_y), p(d_bnpw), p(d_w), p(d_ydw), p(d_bndw), p(g_dw), p(dw), None, p(part), M, Cin, Cout)
+    L.call("ttk_pwconv1x1_bwd_fused", p(d_g), p(d_y), p(d_bnpw), p(d_w), p(prep), p(d_ydw), p(d_bndw), p(g_dw), p(dw), None, p(part), M, Cin, Cout)
     torch.cuda.synchronize()
     safe = np.abs(pre) > 1e-4  # a pre-activation within rounding of zero may fall on either side of the ReLU
     out = g_dw.cpu().numpy()
     assert np.isfinite(out).all()
-    assert _rel(out * safe, gdw_ref * safe) < 2e-6
-    assert _rel(dw.cpu().numpy(), dw_ref) < 2e-6
+    tol = 2e-6 if Cin < 128 else 3e-6  # fp32 MFMA (exact products) | fp16 split (an fp32 fma chain's accuracy)
+    assert _rel(out * safe, gdw_ref * safe) < tol
+    assert _rel(dw.cpu().numpy(), dw_ref) < tol
     ps = part.cpu().numpy().astype(np.float64)
     o64 = out.astype(np.float64)
     np.testing.assert_allclose(ps[:, 0].sum(0), o64.sum(0), rtol=0, atol=3e-5 * np.abs(o64).sum(0).max())
@@ -204,18 +212,19 @@ def test_fused_bwd_matches_fp64_and_the_two_kernels(M, Cin, Cout):
     part2 = torch.empty(L.partial_rows_gemm(M), 2, Cin, device=dev)
     dw2 = torch.zeros(Cout, Cin, device=dev)
     wt = d_w.t().contiguous()
-    L.call("ttk_pwconv1x1_bwd_data", p(d_g), p(d_y), p(d_bnpw), p(wt), p(d_ydw), p(d_bndw), p(g_dw2), p(part2), M, Cin, Cout, None, 0)
+    wq2 = torch.empty(L.pwconv_prepared_bytes(Cin, Cout), dtype=torch.uint8, device=dev)  # (named: see above)
+    L.call("ttk_pwconv1x1_bwd_data", p(d_g), p(d_y), p(d_bnpw), p(wt), p(d_ydw), p(d_bndw), p(g_dw2), p(part2), M, Cin, Cout, p(wq2), 0)
     L.call("ttk_pwconv1x1_bwd_weight", p(d_g), p(d_y), p(d_bnpw), p(d_ydw), p(d_bndw), p(dw2), None, M, Cin, Cout, 0)
     torch.cuda.synchronize()
-    assert _rel(out * safe, g_dw2.cpu().numpy() * safe) < 2e-6 and _rel(dw.cpu().numpy(), dw2.cpu().numpy()) < 2e-6
+    assert _rel(out * safe, g_dw2.cpu().numpy() * safe) < tol and _rel(dw.cpu().numpy(), dw2.cpu().numpy()) < tol
     # deterministic form
     nb = L.cdll.ttk_pwconv1x1_bwd_fused_partial_bytes(M, Cin, Cout)
     scratch = torch.full((nb // 4,), float("nan"), device=dev)
     res = []
     for _ in range(2):
         dwp = torch.zeros(Cout, Cin, device=dev)
-        L.call("ttk_pwconv1x1_bwd_fused", p(d_g), p(d_y), p(d_bnpw), p(d_w), p(d_ydw), p(d_bndw), p(g_dw), p(dwp), p(scratch), p(part), M, Cin, Cout)
+        L.call("ttk_pwconv1x1_bwd_fused", p(d_g), p(d_y), p(d_bnpw), p(d_w), p(prep), p(d_ydw), p(d_bndw), p(g_dw), p(dwp), p(scratch), p(part), M, Cin, Cout)
         torch.cuda.synchronize()
         res.append((dwp.clone(), g_dw.clone(), part.clone()))
     assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
-    assert _rel(res[0][0].cpu().numpy(), dw_ref) < 2e-6
+    assert _rel(res[0][0].cpu().numpy(), dw_ref) < tol

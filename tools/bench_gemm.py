@@ -39,7 +39,7 @@ for name, hw, ci, co, mult in shapes:
     }
     if L.cdll.ttk_pwconv1x1_bwd_fused_rows(M, ci, co) and not BF:  # the first two layers: both gradients in one kernel
         fpart = torch.empty(L.cdll.ttk_pwconv1x1_bwd_fused_rows(M, ci, co) * 2 * ci, device=dev)
-        calls["fused"] = lambda: L.call("ttk_pwconv1x1_bwd_fused", p(g), p(y), p(bn_pw), p(w), p(ydw), p(bn_dw), p(gdw), p(dW), None, p(fpart), M, ci, co)
+        calls["fused"] = lambda: L.call("ttk_pwconv1x1_bwd_fused", p(g), p(y), p(bn_pw), p(w), p(prep), p(ydw), p(bn_dw), p(gdw), p(dW), None, p(fpart), M, ci, co)
     line = f"{name:6s} M={M:8d} K={ci:4d} N={co:4d} "
     for k, fn in calls.items():
         for _ in range(3):
