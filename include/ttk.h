@@ -191,9 +191,11 @@ int ttk_pwconv1x1_bwd_weight(const void* g, const void* y, const float* bn_pw, c
  * ttk_pwconv_prepared_bytes(cin[i], cout[i]); pass it as `wsplit` with w == NULL (forward) / wt == NULL (data gradient)
  * to skip the per-call split and transpose launches. */
 /* Weight AND data gradient of the first pointwise layers (Cin -> Cout = 32 -> 64, 64 -> 128, 128 -> 128; fp32 storage) in one
- * kernel: g, y and ydw are read once instead of twice (these layers are HBM-bound).  32 -> 64 and 64 -> 128 run on the fp32
- * matrix pipe from the raw weights w[Cout][Cin] (wsplit unused); 128 -> 128 on the fp16 pipe from the block that
- * ttk_pwconv_prepare_weights filled (wsplit; w unused), with the operand bounds of row TTK_BN_AUX.  dw accumulates
+ * kernel: g, y and ydw are read once instead of twice (these layers are HBM-bound).  32 -> 64 runs on the fp32 matrix pipe
+ * from the raw weights w[Cout][Cin] (wsplit unused); 128 -> 128 on the fp16 pipe from the block that
+ * ttk_pwconv_prepare_weights filled (wsplit; w unused), with the operand bounds of row TTK_BN_AUX; 64 -> 128 on the fp16
+ * pipe too in the default TTK_GEMM mode (w AND wsplit: the raw weights, cut in the kernel with the block's |w| scale),
+ * on fp32 MFMA otherwise.  dw accumulates
  * (fp32 atomics per workgroup, or - partial = scratch of ttk_pwconv1x1_bwd_fused_partial_bytes - workgroup rows folded in a
  * fixed order); g_dw and part as ttk_pwconv1x1_bwd_data, with ttk_pwconv1x1_bwd_fused_rows(M, Cin, Cout) partial rows
  * (0 = this shape has no fused form). */

@@ -299,83 +299,109 @@ __device__ __forceinline__ void fz_split(fz32x4 v, uint2& h, uint2& l) {
   l = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
 }
 
-constexpr int kF16C = 128, kF16BM = 32;
-constexpr int kF16RowPlane = kF16BM * kF16C * 2;       // bytes of one plane of DyR
-constexpr int kF16TPlane = kF16C * 32;                 // bytes of one plane of one k16 stage of DyT / AT
-constexpr int kF16Ldc = kF16C + 4;
-constexpr int kF16Stage = 2 * kF16RowPlane + 2 * (2 * 2 * kF16TPlane) + kF16BM * kF16Ldc * 4;  // DyR + DyT + AT + Yc
+constexpr int kF16BM = 32;
+template <int CIN, int COUT>
+struct F16Shape {
+  static constexpr int RowPlane = kF16BM * COUT * 2;  // bytes of one plane of DyR
+  static constexpr int TPlaneY = COUT * 32;           // bytes of one plane of one k16 stage of DyT
+  static constexpr int TPlaneA = CIN * 32;            // ... of AT
+  static constexpr int Ldc = CIN + 4;
+  static constexpr int Stage = 2 * RowPlane + 2 * 2 * TPlaneY + 2 * 2 * TPlaneA + kF16BM * Ldc * 4;  // DyR + DyT + AT + Yc
+  static constexpr int NCI = CIN / 32, NCO = COUT / 32;  // 32-channel tiles
+  static constexpr int GROUPS = 4 / NCI;                 // consumer-wave groups that share the ci tiles
+  static constexpr int COW = NCO / GROUPS;               // weight-gradient co tiles per wave
+};
 
+// CIN -> COUT = 128 -> 128 (consumer wave w: data-gradient ci tile w, weight-gradient tiles [all 4 co][ci tile w]) or 64 -> 128
+// (waves 0,1: data-gradient ci tile w; wave w: weight-gradient tiles [co tiles 2 (w >> 1), +1][ci tile w & 1]; the fp32-MFMA
+// form of this layer was matrix-bound).
+template <int CIN, int COUT>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 pw_bwd_fused16_k(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ bn_pw, const uint16_t* __restrict__ wq,
-                 const float* __restrict__ wmax, const float* __restrict__ ydw, const float* __restrict__ bn_dw, float* __restrict__ g_dw,
+                 const float* __restrict__ wraw, const float* __restrict__ wmax, const float* __restrict__ ydw, const float* __restrict__ bn_dw, float* __restrict__ g_dw,
                  float* __restrict__ dW, float* __restrict__ wpartial, float* __restrict__ part, int64_t M, int ntiles) {
-  constexpr int C = kF16C, BM = kF16BM;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kF16Stage + 4 * 2 * C * 4];
-  float* red = reinterpret_cast<float*>(lds + 2 * kF16Stage);  // [4][2][32]: every wave owns its 32 channels
+  using S_ = F16Shape<CIN, COUT>;
+  constexpr int BM = kF16BM, NCI = S_::NCI, COW = S_::COW, kStage = S_::Stage, kRowPlane = S_::RowPlane, kTY = S_::TPlaneY, kTA = S_::TPlaneA,
+                kLdc = S_::Ldc;
+  static_assert((CIN == 128 || CIN == 64) && COUT == 128, "shapes");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStage + 4 * 2 * 32 * 4];
+  float* red = reinterpret_cast<float*>(lds + 2 * kStage);  // [4][2][32]: the data-gradient waves' 32 channels each
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool producer = wave >= 4;
   const int r32 = lane & 31, h = lane >> 5;
-  const float sa = pow2_scale(bn_pw[(size_t)TTK_BN_AUX * C + TTK_AUX_DY_BOUND]);
-  const float sx = pow2_scale(bn_dw[(size_t)TTK_BN_AUX * C + TTK_AUX_ACT_BOUND]);
+  const float sa = pow2_scale(bn_pw[(size_t)TTK_BN_AUX * COUT + TTK_AUX_DY_BOUND]);
+  const float sx = pow2_scale(bn_dw[(size_t)TTK_BN_AUX * CIN + TTK_AUX_ACT_BOUND]);
   const float sw = pow2_scale(*wmax);
-  auto stage_ptr = [&](int st) { return lds + st * kF16Stage; };
+  auto stage_ptr = [&](int st) { return lds + st * kStage; };
 
   if (producer) {
     const int pt = tid - 256;
-    const int mb = pt & 7, cq = pt >> 3;  // 8 row blocks of 4 rows x 32 channel quads
+    const int mb = pt & 7, cq = pt >> 3;  // 8 row blocks of 4 rows x 32 channel quads (COUT = 128; the first CIN / 4 of them also carry ydw)
+    const bool a_on = cq < CIN / 4;
+    const int cqa = a_on ? cq : 0;
     const int sub = mb >> 2, chunk = (mb >> 1) & 1, o8 = (mb & 1) * 8;
-    const fz32x4 ga = *reinterpret_cast<const fz32x4*>(bn_pw + TTK_BN_GA * C + 4 * cq) * sa;
-    const fz32x4 gb = *reinterpret_cast<const fz32x4*>(bn_pw + TTK_BN_GB * C + 4 * cq) * sa;
-    const fz32x4 gmean = *reinterpret_cast<const fz32x4*>(bn_pw + TTK_BN_GMEAN * C + 4 * cq);
-    const fz32x4 ymean = *reinterpret_cast<const fz32x4*>(bn_pw + TTK_BN_MEAN * C + 4 * cq);
-    const fz32x4 dsc = *reinterpret_cast<const fz32x4*>(bn_dw + TTK_BN_SCALE * C + 4 * cq) * sx;
-    const fz32x4 dbe = *reinterpret_cast<const fz32x4*>(bn_dw + TTK_BN_BETA * C + 4 * cq) * sx;
-    const fz32x4 dmean = *reinterpret_cast<const fz32x4*>(bn_dw + TTK_BN_MEAN * C + 4 * cq);
+    const fz32x4 ga = *reinterpret_cast<const fz32x4*>(bn_pw + TTK_BN_GA * COUT + 4 * cq) * sa;
+    const fz32x4 gb = *reinterpret_cast<const fz32x4*>(bn_pw + TTK_BN_GB * COUT + 4 * cq) * sa;
+    const fz32x4 gmean = *reinterpret_cast<const fz32x4*>(bn_pw + TTK_BN_GMEAN * COUT + 4 * cq);
+    const fz32x4 ymean = *reinterpret_cast<const fz32x4*>(bn_pw + TTK_BN_MEAN * COUT + 4 * cq);
+    const fz32x4 dsc = *reinterpret_cast<const fz32x4*>(bn_dw + TTK_BN_SCALE * CIN + 4 * cqa) * sx;
+    const fz32x4 dbe = *reinterpret_cast<const fz32x4*>(bn_dw + TTK_BN_BETA * CIN + 4 * cqa) * sx;
+    const fz32x4 dmean = *reinterpret_cast<const fz32x4*>(bn_dw + TTK_BN_MEAN * CIN + 4 * cqa);
     fz32x4 rg[4], ry[4], rc[4];
     auto load = [&](int t) {
       const int64_t r0 = (int64_t)t * BM + 4 * mb;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int64_t row = r0 + i < M ? r0 + i : M - 1;
-        const float4 a = ld4nt(g + row * C + 4 * cq), b = ld4nt(y + row * C + 4 * cq), c = ld4(ydw + row * C + 4 * cq);
-        rg[i] = fz32x4{a.x, a.y, a.z, a.w}; ry[i] = fz32x4{b.x, b.y, b.z, b.w}; rc[i] = fz32x4{c.x, c.y, c.z, c.w};
+        const float4 a = ld4nt(g + row * COUT + 4 * cq), b = ld4nt(y + row * COUT + 4 * cq);
+        rg[i] = fz32x4{a.x, a.y, a.z, a.w}; ry[i] = fz32x4{b.x, b.y, b.z, b.w};
+        if (a_on) {
+          const float4 c = ld4(ydw + row * CIN + 4 * cqa);
+          rc[i] = fz32x4{c.x, c.y, c.z, c.w};
+        }
       }
     };
     auto store = [&](int t, int st) {
       unsigned char* S = stage_ptr(st);
       unsigned char* DyR = S;
-      unsigned char* DyT = S + 2 * kF16RowPlane;
-      unsigned char* AT = DyT + 2 * 2 * kF16TPlane;
-      float* Yc = reinterpret_cast<float*>(AT + 2 * 2 * kF16TPlane);
+      unsigned char* DyT = S + 2 * kRowPlane;
+      unsigned char* AT = DyT + 2 * 2 * kTY;
+      float* Yc = reinterpret_cast<float*>(AT + 2 * 2 * kTA);
       const int64_t r0 = (int64_t)t * BM + 4 * mb;
       fz32x4 dy[4], av[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         dy[i] = ga * (rg[i] - gmean) + gb * (ry[i] - ymean);
-        const fz32x4 yc = rc[i] - dmean;
-        fz32x4 a = dsc * yc + dbe;
-        a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
-        if (r0 + i >= M) { dy[i] = fz32x4{0.f, 0.f, 0.f, 0.f}; a = dy[i]; }  // rows past the end contribute nothing
-        av[i] = a;
-        *reinterpret_cast<fz32x4*>(Yc + (4 * mb + i) * kF16Ldc + 4 * cq) = yc;
+        if (r0 + i >= M) dy[i] = fz32x4{0.f, 0.f, 0.f, 0.f};  // rows past the end contribute nothing
         // dy row-major: 8-byte piece cq of row 4 mb + i, 16-byte chunk XOR (row & 15)
         uint2 ph, pl;
         fz_split(dy[i], ph, pl);
-        const int row = 4 * mb + i, off = row * (C * 2) + ((((cq >> 1) ^ (row & 15))) << 4) + (cq & 1) * 8;
+        const int row = 4 * mb + i, off = row * (COUT * 2) + ((((cq >> 1) ^ (row & 15))) << 4) + (cq & 1) * 8;
         *reinterpret_cast<uint2*>(DyR + off) = ph;
-        *reinterpret_cast<uint2*>(DyR + kF16RowPlane + off) = pl;
+        *reinterpret_cast<uint2*>(DyR + kRowPlane + off) = pl;
+        if (a_on) {
+          const fz32x4 yc = rc[i] - dmean;
+          fz32x4 a = dsc * yc + dbe;
+          a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+          if (r0 + i >= M) a = fz32x4{0.f, 0.f, 0.f, 0.f};
+          av[i] = a;
+          *reinterpret_cast<fz32x4*>(Yc + (4 * mb + i) * kLdc + 4 * cqa) = yc;
+        }
       }
       // transposed: channel 4 cq + e, four consecutive rows 4 mb .. 4 mb + 3 (k) -> 8 bytes per plane
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         uint2 ph, pl;
-        const int off = sub * (2 * kF16TPlane) + fz_swz(4 * cq + e, chunk) + o8;
         fz_split(fz32x4{dy[0][e], dy[1][e], dy[2][e], dy[3][e]}, ph, pl);
-        *reinterpret_cast<uint2*>(DyT + off) = ph;
-        *reinterpret_cast<uint2*>(DyT + kF16TPlane + off) = pl;
-        fz_split(fz32x4{av[0][e], av[1][e], av[2][e], av[3][e]}, ph, pl);
-        *reinterpret_cast<uint2*>(AT + off) = ph;
-        *reinterpret_cast<uint2*>(AT + kF16TPlane + off) = pl;
+        const int offy = sub * (2 * kTY) + fz_swz(4 * cq + e, chunk) + o8;
+        *reinterpret_cast<uint2*>(DyT + offy) = ph;
+        *reinterpret_cast<uint2*>(DyT + kTY + offy) = pl;
+        if (a_on) {
+          fz_split(fz32x4{av[0][e], av[1][e], av[2][e], av[3][e]}, ph, pl);
+          const int offa = sub * (2 * kTA) + fz_swz(4 * cqa + e, chunk) + o8;
+          *reinterpret_cast<uint2*>(AT + offa) = ph;
+          *reinterpret_cast<uint2*>(AT + kTA + offa) = pl;
+        }
       }
     };
     int t = blockIdx.x;
@@ -394,21 +420,35 @@ pw_bwd_fused16_k(const float* __restrict__ g, const float* __restrict__ y, const
       __syncthreads();
     }
   } else {
-    const int ci = 32 * wave + r32;  // this lane's input channel (data-gradient column, weight-gradient column)
+    const bool has_dg = wave < NCI;                 // data gradient: ci tile `wave`
+    const int cit = wave % NCI, cog = wave / NCI;   // weight gradient: ci tile, group of co tiles
+    const int ci_dg = 32 * (has_dg ? wave : 0) + r32, ci_wg = 32 * cit + r32;
     // data-gradient B fragments: W^T planes [co / 32][ci][32] of the prepared operand, k16 step s, lane half h: co 16 s + 8 h ..
-    fz16x8 Wf[8][2];
+    fz16x8 Wf[COUT / 16][2];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < COUT / 16; ++s) {
       const int co = 16 * s + 8 * h;
-      const size_t idx = ((size_t)(co >> 5) * C + ci) * 32 + (co & 31);
-      Wf[s][0] = *reinterpret_cast<const fz16x8*>(wq + idx);
-      Wf[s][1] = *reinterpret_cast<const fz16x8*>(wq + (size_t)C * C + idx);
-    }
-    const float dsc = bn_dw[TTK_BN_SCALE * C + ci], dbe = bn_dw[TTK_BN_BETA * C + ci];
-    const float inv_dg = 1.f / (sa * sw), inv_wg = 1.f / (sa * sx);
-    f32x16 wacc[4];
+      if (CIN == 128) {
+        const size_t idx = ((size_t)(co >> 5) * CIN + ci_dg) * 32 + (co & 31);
+        Wf[s][0] = *reinterpret_cast<const fz16x8*>(wq + idx);
+        Wf[s][1] = *reinterpret_cast<const fz16x8*>(wq + (size_t)CIN * COUT + idx);
+      } else {
+        // 64 -> 128: the prepared block of this layer holds no fp16 data-gradient planes (its stand-alone data gradient runs on
+        // fp32 MFMA) - cut the raw weights here, once per workgroup, with the block's |w| scale
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
+        for (int e = 0; e < 8; ++e) {
+          const float xs = wraw[(size_t)(co + e) * CIN + ci_dg] * sw;
+          const _Float16 hh = (_Float16)xs;
+          Wf[s][0][e] = hh;
+          Wf[s][1][e] = (_Float16)(xs - (float)hh);
+        }
+      }
+    }
+    const float dsc = bn_dw[TTK_BN_SCALE * CIN + ci_dg], dbe = bn_dw[TTK_BN_BETA * CIN + ci_dg];
+    const float inv_dg = 1.f / (sa * sw), inv_wg = 1.f / (sa * sx);
+    f32x16 wacc[COW];
+#pragma unroll
+    for (int tt = 0; tt < COW; ++tt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) wacc[tt][e] = 0.f;
     float s1 = 0.f, s2 = 0.f;
@@ -417,81 +457,88 @@ pw_bwd_fused16_k(const float* __restrict__ g, const float* __restrict__ y, const
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x, ++it) {
       const unsigned char* S = stage_ptr(it & 1);
       const unsigned char* DyR = S;
-      const unsigned char* DyT = S + 2 * kF16RowPlane;
-      const unsigned char* AT = DyT + 2 * 2 * kF16TPlane;
-      const float* Yc = reinterpret_cast<const float*>(AT + 2 * 2 * kF16TPlane);
+      const unsigned char* DyT = S + 2 * kRowPlane;
+      const unsigned char* AT = DyT + 2 * 2 * kTY;
+      const float* Yc = reinterpret_cast<const float*>(AT + 2 * 2 * kTA);
       const int64_t m0 = (int64_t)t * BM;
-      // ---- data gradient: 32 rows x this wave's 32 ci, contraction over the 128 co
+      // ---- data gradient: 32 rows x this wave's 32 ci, contraction over the co
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      if (has_dg) {
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const int off = r32 * (C * 2) + ((((2 * s + h) ^ (r32 & 15))) << 4);
-        const fz16x8 ah = *reinterpret_cast<const fz16x8*>(DyR + off), al = *reinterpret_cast<const fz16x8*>(DyR + kF16RowPlane + off);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Wf[s][1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Wf[s][0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Wf[s][0], acc, 0, 0, 0);
+        for (int s = 0; s < COUT / 16; ++s) {
+          const int off = r32 * (COUT * 2) + ((((2 * s + h) ^ (r32 & 15))) << 4);
+          const fz16x8 ah = *reinterpret_cast<const fz16x8*>(DyR + off), al = *reinterpret_cast<const fz16x8*>(DyR + kRowPlane + off);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Wf[s][1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Wf[s][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Wf[s][0], acc, 0, 0, 0);
+        }
       }
-      // ---- weight gradient: dW[co tile tt][this wave's ci tile] += dy^T a over the 32 rows (two k16 stages)
+      // ---- weight gradient: dW[co tile][this wave's ci tile] += dy^T a over the 32 rows (two k16 stages)
       fz16x8 bh[2], bl[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int off = s * (2 * kF16TPlane) + fz_swz(ci, h);
+        const int off = s * (2 * kTA) + fz_swz(ci_wg, h);
         bh[s] = *reinterpret_cast<const fz16x8*>(AT + off);
-        bl[s] = *reinterpret_cast<const fz16x8*>(AT + kF16TPlane + off);
+        bl[s] = *reinterpret_cast<const fz16x8*>(AT + kTA + off);
       }
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
+      for (int tt = 0; tt < COW; ++tt)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const int off = s * (2 * kF16TPlane) + fz_swz(32 * tt + r32, h);
-          const fz16x8 ah = *reinterpret_cast<const fz16x8*>(DyT + off), al = *reinterpret_cast<const fz16x8*>(DyT + kF16TPlane + off);
+          const int off = s * (2 * kTY) + fz_swz(32 * (cog * COW + tt) + r32, h);
+          const fz16x8 ah = *reinterpret_cast<const fz16x8*>(DyT + off), al = *reinterpret_cast<const fz16x8*>(DyT + kTY + off);
           wacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], wacc[tt], 0, 0, 0);
           wacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], wacc[tt], 0, 0, 0);
           wacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], wacc[tt], 0, 0, 0);
         }
       // ---- data-gradient epilogue: accumulator element e of lane (r32, h) = row (e & 3) + 8 (e >> 2) + 4 h, column ci
+      if (has_dg) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-        const float yc = Yc[row * kF16Ldc + ci];
-        const float out = fmaf(dsc, yc, dbe) > 0.f ? acc[e] * inv_dg : 0.f;
-        if (m0 + row < M) {
-          g_dw[(size_t)(m0 + row) * C + ci] = out;
-          s1 += out;
-          s2 = fmaf(out, yc, s2);
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+          const float yc = Yc[row * kLdc + ci_dg];
+          const float out = fmaf(dsc, yc, dbe) > 0.f ? acc[e] * inv_dg : 0.f;
+          if (m0 + row < M) {
+            g_dw[(size_t)(m0 + row) * CIN + ci_dg] = out;
+            s1 += out;
+            s2 = fmaf(out, yc, s2);
+          }
         }
       }
       __syncthreads();
     }
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
+    for (int tt = 0; tt < COW; ++tt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int co = 32 * tt + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int co = 32 * (cog * COW + tt) + (e & 3) + 8 * (e >> 2) + 4 * h;
         const float v = wacc[tt][e] * inv_wg;
-        if (wpartial) wpartial[(size_t)blockIdx.x * C * C + co * C + ci] = v;
-        else atomicAdd(dW + co * C + ci, v);
+        if (wpartial) wpartial[(size_t)blockIdx.x * COUT * CIN + co * CIN + ci_wg] = v;
+        else atomicAdd(dW + co * CIN + ci_wg, v);
       }
     s1 += __shfl_xor(s1, 32);
     s2 += __shfl_xor(s2, 32);
-    if (h == 0) { red[(wave * 2 + 0) * 32 + r32] = s1; red[(wave * 2 + 1) * 32 + r32] = s2; }
+    if (h == 0 && has_dg) { red[(wave * 2 + 0) * 32 + r32] = s1; red[(wave * 2 + 1) * 32 + r32] = s2; }
   }
   __syncthreads();
-  if (part && tid < 2 * C) {
-    const int which = tid / C, c = tid % C;
-    part[(size_t)blockIdx.x * 2 * C + which * C + c] = red[((c >> 5) * 2 + which) * 32 + (c & 31)];
+  if (part && tid < 2 * CIN) {
+    const int which = tid / CIN, c = tid % CIN;
+    part[(size_t)blockIdx.x * 2 * CIN + which * CIN + c] = red[((c >> 5) * 2 + which) * 32 + (c & 31)];
   }
 }
 
+// 128 -> 128 always runs on the fp16 pipe; 64 -> 128 too when the prepared block holds fp16 planes (default TTK_GEMM mode), else
+// on fp32 MFMA from the raw weights
+static bool fused_f16(int Cin) { return Cin == 128 || (Cin == 64 && gemm_mode() == GEMM_F16X2 && !getenv("TTK_FUSED_FP32")); }
 static bool fused_shape(int Cin, int Cout) {
   // (the 128 -> 128 form reads the fp16 planes of the prepared weight block: default TTK_GEMM mode only)
   return (Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 128) || (Cin == 128 && Cout == 128 && gemm_mode() == GEMM_F16X2);
 }
 
 static int fused_grid(int64_t M, int Cin) {
-  const int64_t ntiles = ceil_div(M, Cin == 128 ? kF16BM : kFusedBM);
+  const int64_t ntiles = ceil_div(M, fused_f16(Cin) ? kF16BM : kFusedBM);
   const int64_t cap = Cin == 32 ? 512 : 256;  // two workgroups per CU fit for the 32 -> 64 layer (62 KB of LDS), one for the others
   return (int)(ntiles < cap ? ntiles : cap);
 }
@@ -513,15 +560,20 @@ int ttk_pwconv1x1_bwd_fused(const float* g, const float* y, const float* bn_pw, 
                             ttk_stream_t stream) {
   TTK_REQUIRE(g && y && bn_pw && ydw && bn_dw && g_dw && dw, "pwconv1x1_bwd_fused: null pointer");
   TTK_REQUIRE(fused_shape(Cin, Cout) && M > 0, "pwconv1x1_bwd_fused: only the 32 -> 64, 64 -> 128 and 128 -> 128 layers (got %d -> %d)", Cin, Cout);
-  TTK_REQUIRE(Cin == 128 ? wsplit != nullptr : w != nullptr, "pwconv1x1_bwd_fused: 128 -> 128 needs the prepared weight block, the others the raw weights");
-  const int ntiles = (int)ceil_div(M, Cin == 128 ? kF16BM : kFusedBM), grid = fused_grid(M, Cin);
+  TTK_REQUIRE((Cin == 128 || w) && (!fused_f16(Cin) || wsplit),
+              "pwconv1x1_bwd_fused: the fp16 forms (128 -> 128; 64 -> 128 in the default mode) need the prepared weight block, 32 -> 64 and 64 -> 128 the raw weights");
+  const int ntiles = (int)ceil_div(M, fused_f16(Cin) ? kF16BM : kFusedBM), grid = fused_grid(M, Cin);
   hipStream_t st = (hipStream_t)stream;
-  if (Cin == 128) {
+  if (fused_f16(Cin)) {
     // prepared block (ttk_pwconv_prepare_weights, fp16 mode): [forward planes 4n][data-gradient planes 4n][|w| maximum]
     const size_t n = (size_t)Cin * Cout;
     const unsigned char* ws = static_cast<const unsigned char*>(wsplit);
-    hipLaunchKernelGGL(pw_bwd_fused16_k, dim3(grid), dim3(512), 0, st, g, y, bn_pw, reinterpret_cast<const uint16_t*>(ws + 4 * n),
-                       reinterpret_cast<const float*>(ws + 8 * n), ydw, bn_dw, g_dw, dw, partial, part, M, ntiles);
+    const uint16_t* wq = reinterpret_cast<const uint16_t*>(ws + 4 * n);
+    const float* wmx = reinterpret_cast<const float*>(ws + 8 * n);
+    if (Cin == 128)
+      hipLaunchKernelGGL((pw_bwd_fused16_k<128, 128>), dim3(grid), dim3(512), 0, st, g, y, bn_pw, wq, w, wmx, ydw, bn_dw, g_dw, dw, partial, part, M, ntiles);
+    else
+      hipLaunchKernelGGL((pw_bwd_fused16_k<64, 128>), dim3(grid), dim3(512), 0, st, g, y, bn_pw, wq, w, wmx, ydw, bn_dw, g_dw, dw, partial, part, M, ntiles);
   } else if (Cin == 32) {
     hipLaunchKernelGGL((pw_bwd_fused_k<32, 64>), dim3(grid), dim3(512), 0, st, g, y, bn_pw, w, ydw, bn_dw, g_dw, dw, partial, part, M, ntiles);
   } else {
