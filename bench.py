@@ -80,7 +80,8 @@ class KernelTimer:
         eb = KernelTimer.act_bytes
         if name == "ttk_pwconv1x1_bwd_fused":  # first two pointwise layers: weight + data gradient, operands read once (HBM-bound)
             M, ci, co = ints[-3:]
-            return f"pw_bwd_fused_k<{ci}, {co}>", 4 * M * ci * co, 4 * (2 * M * co + 2 * M * ci) + 4 * ci * co
+            f16 = ci == 128 or (ci == 64 and os.environ.get("TTK_GEMM") not in ("f32mfma", "bf16x3") and not os.environ.get("TTK_FUSED_FP32"))  # csrc/pw_bwd_fused.hip: fused_f16
+            return f"pw_bwd_fused{'16' if f16 else ''}_k<{ci}, {co}>", 4 * M * ci * co, 4 * (2 * M * co + 2 * M * ci) + 4 * ci * co
         if name.startswith("ttk_pwconv1x1"):
             # trailing arguments: ..., M, Cin, Cout, [scratch pointer of the split weights,] act_bf16
             M, ci, co = ints[-4:-1] if name == "ttk_pwconv1x1_bwd_weight" else ints[-5:-2]
