@@ -187,7 +187,7 @@ int ttk_pwconv1x1_bwd_weight(const void* g, const void* y, const float* bn_pw, c
                              const float* bn_dw, float* dw, float* partial, int64_t M, int Cin, int Cout,
                              int act_bf16, ttk_stream_t stream);
 /* Weight operands of n (<= 16) pointwise layers (w[i]: [Cout][Cin] fp32 device pointers; w, cin, cout and
- * prepared are HOST arrays): three launches for all layers (|w| maxima, planes).  prepared[i]: device scratch of
+ * prepared are HOST arrays): two launches for all layers (workgroup |w| maxima; planes).  prepared[i]: device scratch of
  * ttk_pwconv_prepared_bytes(cin[i], cout[i]); pass it as `wsplit` with w == NULL (forward) / wt == NULL (data gradient)
  * to skip the per-call split and transpose launches. */
 /* Weight AND data gradient of the first pointwise layers (Cin -> Cout = 32 -> 64, 64 -> 128, 128 -> 128; fp32 storage) in one
@@ -254,7 +254,7 @@ int ttk_bn_act(const float* y, const float* bn, const float* skip, float* a, int
  * ------------------------------------------------------------------------------------------- */
 int ttk_conv_weight_repack(const float* w, void* w_fwd, void* w_bwd, int Cout, int Cin, int KH, int KW,
                            ttk_stream_t stream);
-/* the same for n <= 24 weight tensors (square kernels of size ksize[i] in {1,3}) in three launches: a training step's 19 */
+/* the same for n <= 24 weight tensors (square kernels of size ksize[i] in {1,3}) in two launches: a training step's 19 */
 int ttk_conv_prepare_weights(int n, const float* const* w, void* const* w_fwd, void* const* w_bwd, const int* cout,
                              const int* cin, const int* ksize, ttk_stream_t stream);
 int ttk_conv_fwd(const float* a_in, const float* a_bound, const void* w_fwd, float* y, float* part, int B, int H, int W,

@@ -69,9 +69,8 @@ __global__ void conv_weight_repack16_k(const float* __restrict__ w, uint16_t* __
   }
 }
 
-// ---- all convolutions' weight operands in three launches (ttk_conv_prepare_weights) ----
+// ---- all convolutions' weight operands in two launches (ttk_conv_prepare_weights) ----
 constexpr int kConvPrepMax = 24;
-constexpr int kConvPrepChunk = 2048;  // weights per workgroup
 struct ConvPrepArgs {
   const float* w[kConvPrepMax];
   uint16_t* wf[kConvPrepMax];
@@ -89,38 +88,79 @@ __device__ __forceinline__ float* conv_prep_hdr(const ConvPrepArgs& a, int l, bo
   const int64_t n = (int64_t)a.cout[l] * a.cin[l] * a.taps[l];
   return reinterpret_cast<float*>((fwd ? a.wf[l] : a.wb[l]) + 2 * n);
 }
-__global__ void conv_prepare_zero_k(ConvPrepArgs a) {
-  const int l = threadIdx.x;
-  if (l < a.n) *conv_prep_hdr(a, l, a.wf[l] != nullptr) = 0.f;
-}
+// |w| maxima without atomics: kConvParts workgroups per tensor leave their maxima behind the header (the buffers hold 3 n
+// halves, the fp16 form uses 2 n + the header), every repack workgroup folds the kConvParts values of its tensor.
+constexpr int kConvParts = 64;
+__device__ __forceinline__ float* conv_prep_parts(const ConvPrepArgs& a, int l) { return conv_prep_hdr(a, l, a.wf[l] != nullptr) + 16; }
 __global__ void __launch_bounds__(256) conv_prepare_absmax_k(ConvPrepArgs a) {
-  const int l = conv_prep_layer(a);
-  const int64_t n = (int64_t)a.cout[l] * a.cin[l] * a.taps[l], i0 = (int64_t)(blockIdx.x - a.first_chunk[l]) * kConvPrepChunk;
+  __shared__ float sm[4];
+  const int l = blockIdx.y;
+  const int64_t n4 = (int64_t)a.cout[l] * a.cin[l] * a.taps[l] / 4;  // cout, cin multiples of 32
+  const float4* w4 = reinterpret_cast<const float4*>(a.w[l]);
   float m = 0.f;
-  for (int64_t i = i0 + threadIdx.x; i < i0 + kConvPrepChunk && i < n; i += 256) m = fmaxf(m, fabsf(a.w[l][i]));
-  wave_raise_max(conv_prep_hdr(a, l, a.wf[l] != nullptr), m);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)kConvParts * 256) {
+    const float4 v = w4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) conv_prep_parts(a, l)[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
 }
+// One workgroup = one 32 x 32 (co, ci) tile of a tensor over all its taps: the source rows (32 ci x T taps contiguous per co)
+// are read coalesced into LDS, and both operand layouts leave as 8-byte pieces of contiguous 2 KB runs
+//   wf[t][ci/32][co][ci%32]: the tile's 32 co rows of 32 ci     wb[t][co/32][ci][co%32]: its 32 ci rows of 32 co
+// (the element-wise form wrote 2-byte pieces scattered over the planes: 256 us for ResNet18's 11 M weights).
 __global__ void __launch_bounds__(256) conv_prepare_repack_k(ConvPrepArgs a) {
+  __shared__ float tile[9][32][33];
   const int l = conv_prep_layer(a);
   const int Cout = a.cout[l], Cin = a.cin[l], T = a.taps[l];
-  const int64_t n = (int64_t)Cout * Cin * T, i0 = (int64_t)(blockIdx.x - a.first_chunk[l]) * kConvPrepChunk;
+  const int64_t n = (int64_t)Cout * Cin * T;
+  const int tl = blockIdx.x - a.first_chunk[l], tci = Cin >> 5, co0 = (tl / tci) * 32, ci0 = (tl % tci) * 32;
   uint16_t *wf = a.wf[l], *wb = a.wb[l];
-  const float mx = *conv_prep_hdr(a, l, wf != nullptr);
-  if (i0 == 0 && threadIdx.x == 0 && wf && wb) *conv_prep_hdr(a, l, false) = mx;  // the data-gradient operand's copy of the header
+  static_assert(kConvParts == 64, "one value per lane");
+  float mx = conv_prep_parts(a, l)[threadIdx.x & 63];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if (tl == 0 && threadIdx.x == 0) {
+    if (wf) *conv_prep_hdr(a, l, true) = mx;
+    if (wb) *conv_prep_hdr(a, l, false) = mx;
+  }
   const float sc = pow2_scale(mx);
-  for (int64_t i = i0 + threadIdx.x; i < i0 + kConvPrepChunk && i < n; i += 256) {
-    const int t = (int)(i % T), ci = (int)((i / T) % Cin), co = (int)(i / ((int64_t)T * Cin));
-    const float x = a.w[l][i] * sc;
-    const _Float16 hh = (_Float16)x;
-    const _Float16 ll = (_Float16)(x - (float)hh);
-    const uint16_t h = __builtin_bit_cast(uint16_t, hh), lo = __builtin_bit_cast(uint16_t, ll);
-    if (wf) {
-      const size_t o = ((size_t)(t * (Cin >> 5) + (ci >> 5)) * Cout + co) * 32 + (ci & 31);
-      wf[o] = h; wf[n + o] = lo;
+  const int rowlen = 32 * T;  // contiguous source floats per co
+  for (int e = threadIdx.x; e < 32 * rowlen; e += 256) {
+    const int co = e / rowlen, r = e - co * rowlen, ci = r / T, t = r - ci * T;
+    tile[t][co][ci] = a.w[l][((int64_t)(co0 + co) * Cin + ci0) * T + r] * sc;
+  }
+  __syncthreads();
+  const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+  for (int t = 0; t < T; ++t) {
+    if (wf) {  // row = co, 4 consecutive ci
+      uint16_t h[4], lo[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x = tile[t][row][c4 + j];
+        const _Float16 hh = (_Float16)x;
+        h[j] = __builtin_bit_cast(uint16_t, hh);
+        lo[j] = __builtin_bit_cast(uint16_t, (_Float16)(x - (float)hh));
+      }
+      const size_t o = ((size_t)(t * tci + (ci0 >> 5)) * Cout + co0 + row) * 32 + c4;
+      *reinterpret_cast<uint2*>(wf + o) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+      *reinterpret_cast<uint2*>(wf + n + o) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
     }
-    if (wb) {
-      const size_t o = ((size_t)(t * (Cout >> 5) + (co >> 5)) * Cin + ci) * 32 + (co & 31);
-      wb[o] = h; wb[n + o] = lo;
+    if (wb) {  // row = ci, 4 consecutive co
+      uint16_t h[4], lo[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x = tile[t][c4 + j][row];
+        const _Float16 hh = (_Float16)x;
+        h[j] = __builtin_bit_cast(uint16_t, hh);
+        lo[j] = __builtin_bit_cast(uint16_t, (_Float16)(x - (float)hh));
+      }
+      const size_t o = ((size_t)(t * (Cout >> 5) + (co0 >> 5)) * Cin + ci0 + row) * 32 + c4;
+      *reinterpret_cast<uint2*>(wb + o) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+      *reinterpret_cast<uint2*>(wb + n + o) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
     }
   }
 }
@@ -173,11 +213,10 @@ int ttk_conv_prepare_weights(int n, const float* const* w, void* const* w_fwd, v
     a.w[i] = w[i]; a.wf[i] = (uint16_t*)w_fwd[i]; a.wb[i] = (uint16_t*)w_bwd[i];
     a.cout[i] = cout[i]; a.cin[i] = cin[i]; a.taps[i] = ksize[i] * ksize[i];
     a.first_chunk[i] = chunks;
-    chunks += (int)ceil_div((int64_t)cout[i] * cin[i] * a.taps[i], kConvPrepChunk);
+    chunks += (cout[i] / 32) * (cin[i] / 32);  // one workgroup per 32 x 32 (co, ci) tile
   }
   a.first_chunk[n] = chunks;
-  hipLaunchKernelGGL(conv_prepare_zero_k, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(conv_prepare_absmax_k, dim3(chunks), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(conv_prepare_absmax_k, dim3(kConvParts, n), dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(conv_prepare_repack_k, dim3(chunks), dim3(256), 0, (hipStream_t)stream, a);
   TTK_LAUNCH_CHECK("conv_prepare_weights");
 }

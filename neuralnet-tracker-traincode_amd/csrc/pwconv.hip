@@ -456,26 +456,28 @@ __device__ __forceinline__ int prep_layer(const PrepArgs& a) {
   return l;
 }
 
-__global__ void pw_prepare_zero_k(PrepArgs a) {
-  const int l = threadIdx.x;
-  if (l < a.n) *reinterpret_cast<unsigned*>(a.out[l] + 8 * (int64_t)a.cin[l] * a.cout[l]) = 0u;
+// |w| maximum of every layer, in two steps without atomics: kPrepParts workgroups per layer leave their maxima behind the
+// block's header, and every workgroup of pw_prepare_weights_k folds the kPrepParts values of its layer.  (The first form - one
+// workgroup per 32x32 tile probing and raising one slot per layer - spent 33 us on 12 400 agent-scope reads of 13 addresses.)
+constexpr int kPrepParts = 64;
+__device__ __forceinline__ float* prep_parts(const PrepArgs& a, int l) {
+  return reinterpret_cast<float*>(a.out[l] + 8 * (int64_t)a.cin[l] * a.cout[l] + 64);
 }
-
-// |w| maximum of every layer (non-negative floats order like their bit patterns: integer atomicMax)
 __global__ void __launch_bounds__(kBlock) pw_prepare_absmax_k(PrepArgs a) {
-  const int l = prep_layer(a);
-  const int tile = blockIdx.x - a.first_tile[l];
-  const int Cin = a.cin[l], Cout = a.cout[l];
-  const int tk = Cin / 32, r0 = (tile / tk) * 32, c0 = (tile % tk) * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  __shared__ float sm[kBlock / kWave];
+  const int l = blockIdx.y;
+  const int64_t n4 = (int64_t)a.cin[l] * a.cout[l] / 4;
+  const float4* w4 = reinterpret_cast<const float4*>(a.w[l]);
   float m = 0.f;
-  for (int i = ty; i < 32; i += kBlock / 32) m = fmaxf(m, fabsf(a.w[l][(int64_t)(r0 + i) * Cin + c0 + tx]));
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)kPrepParts * kBlock) {
+    const float4 v = w4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0) {  // read first: after the first few blocks almost no wave still has to raise the slot
-    unsigned* slot = reinterpret_cast<unsigned*>(a.out[l] + 8 * (int64_t)Cin * Cout);
-    if (__float_as_uint(m) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, __float_as_uint(m));
-  }
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) prep_parts(a, l)[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
 }
 
 __global__ void __launch_bounds__(kBlock) pw_prepare_weights_k(PrepArgs a) {
@@ -488,7 +490,15 @@ __global__ void __launch_bounds__(kBlock) pw_prepare_weights_k(PrepArgs a) {
   const float* w = a.w[l];
   unsigned char* fwd = a.out[l];
   unsigned char* bwd = a.out[l] + (a.mode == GEMM_BF16X3 ? 6 : 4) * n;
-  const float s = a.mode == GEMM_F16X2 ? pow2_scale(*reinterpret_cast<const float*>(a.out[l] + 8 * n)) : 1.f;
+  float s = 1.f;
+  if (a.mode == GEMM_F16X2) {
+    static_assert(kPrepParts == kWave, "one value per lane");
+    float m = prep_parts(a, l)[threadIdx.x & 63];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (tile == 0 && threadIdx.x == 0) *reinterpret_cast<float*>(a.out[l] + 8 * n) = m;  // the header the GEMMs take their scale from
+    s = pow2_scale(m);
+  }
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int i = ty; i < 32; i += kBlock / 32) {
     const float x = w[(int64_t)(r0 + i) * Cin + c0 + tx];
@@ -610,7 +620,7 @@ int ttk_pwconv1x1_bwd_weight(const void* g, const void* y, const float* bn_pw, c
 
 size_t ttk_pwconv_prepared_bytes(int Cin, int Cout) {
   const size_t n = (size_t)Cin * Cout;
-  return prep_hdr_offset(n) + 64;
+  return prep_hdr_offset(n) + 64 + kPrepParts * sizeof(float);  // planes, header, workgroup maxima of the prepare step
 }
 
 int ttk_pwconv_prepare_weights(int n, const float* const* w, const int* cin, const int* cout, void* const* prepared,
@@ -633,10 +643,7 @@ int ttk_pwconv_prepare_weights(int n, const float* const* w, const int* cin, con
   }
   a.first_tile[n] = tiles;
   hipStream_t st = (hipStream_t)stream;
-  if (a.mode == GEMM_F16X2) {
-    hipLaunchKernelGGL(pw_prepare_zero_k, dim3(1), dim3(kPrepMax), 0, st, a);
-    hipLaunchKernelGGL(pw_prepare_absmax_k, dim3(tiles), dim3(kBlock), 0, st, a);
-  }
+  if (a.mode == GEMM_F16X2) hipLaunchKernelGGL(pw_prepare_absmax_k, dim3(kPrepParts, n), dim3(kBlock), 0, st, a);
   hipLaunchKernelGGL(pw_prepare_weights_k, dim3(tiles), dim3(kBlock), 0, st, a);
   TTK_LAUNCH_CHECK("pwconv_prepare_weights");
 }
