@@ -42,7 +42,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 12
+#define TTK_ABI_VERSION 13
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -112,6 +112,16 @@ int ttk_bn_eval_prepare(const float* gamma, const float* beta, const float* runn
  * the parameter gradients dgamma/dbeta (nullable; accumulate != 0: += instead of =). */
 int ttk_bn_bwd_finalize(float* part, int part_rows, int C, int64_t count, const float* gamma,
                         float* bn, float* dgamma, float* dbeta, int accumulate, ttk_stream_t stream);
+
+/* Backward constants of a FROZEN BatchNorm (eval-mode statistics while the convolutions train: NetworkWithPointHead
+ * .prepare_finetune() + train(), models.py:378-394, modelcomponents.py:208-215): rows GA = SCALE, GB = 0, GMEAN = 0, and
+ * TTK_AUX_DY_BOUND from TTK_AUX_GMAX.  bn holds ttk_bn_eval_prepare's rows; no partial sums are read, gamma / beta get no
+ * gradient (the reference freezes them). */
+int ttk_bn_bwd_frozen(float* bn, int C, ttk_stream_t stream);
+/* Forward half: after ttk_bn_eval_prepare, raise bn[TTK_BN_AUX][TTK_AUX_ACT_BOUND] to a bound of relu(scale*(y-mean)+beta) over
+ * this batch from the producer's partial sums (as ttk_bn_fwd_finalize does for batch statistics), so that the fp16 GEMMs of the
+ * backward pass scale their operands; nothing else of bn is written. */
+int ttk_bn_frozen_bound(float* part, int part_rows, int C, int64_t count, float* bn, ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stem: nn.Conv2d(1, 32, 5, stride 2, pad 2, bias=False)  - mobilenet_v1.py:122-124,161.
@@ -418,7 +428,7 @@ int ttk_intensity_augment(const float* x, float* y, const float* params, const f
  * torch.optim.Adam (scripts/train_poseestimator.py:147-167 create_optimizer, :442-445
  * gradient_clip_val=1.0) in two launches, no host sync.  Device tables: ptrs[ntensors][4] =
  * {param, grad (0 = no gradient), exp_avg, exp_avg_sq} addresses; numel[ntensors]; group[ntensors]
- * (index into the host arrays lr4/wd4); chunk_tensor/chunk_offset[nchunks] cut the tensors into
+ * (index into the host arrays lr4/wd4 of TTK_ADAM_MAX_GROUPS floats each); chunk_tensor/chunk_offset[nchunks] cut the tensors into
  * chunks of chunk_size elements.  steps[ntensors] (DEVICE floats): torch.optim.Adam's per-parameter `step`, kept on
  * the device - the call adds 1 for every tensor that has a gradient and derives the bias corrections
  * 1 - beta^step from it (fp64), so nothing about the step count is a launch argument and the call can sit inside a
@@ -428,9 +438,10 @@ int ttk_intensity_augment(const float* x, float* y, const float* params, const f
  * float[TTK_ADAM_HYPER_FLOATS]): when given, the per-group learning rates and weight decays are read from it instead
  * of lr4/wd4 (a captured graph then follows a scheduler without re-capture).
  * ------------------------------------------------------------------------------------------- */
-#define TTK_ADAM_HYPER_LR 0     /* [4] */
-#define TTK_ADAM_HYPER_WD 4     /* [4] */
-#define TTK_ADAM_HYPER_FLOATS 8
+#define TTK_ADAM_MAX_GROUPS 128 /* parameter groups (NetworkWithPointHead.prepare_finetune: one per backbone sub-module, 66) */
+#define TTK_ADAM_HYPER_LR 0     /* [TTK_ADAM_MAX_GROUPS] */
+#define TTK_ADAM_HYPER_WD 128   /* [TTK_ADAM_MAX_GROUPS] */
+#define TTK_ADAM_HYPER_FLOATS 256
 int ttk_clip_adam(const int64_t* ptrs, const int32_t* numel, const int32_t* group,
                   const int32_t* chunk_tensor, const int32_t* chunk_offset, int nchunks, int chunk_size,
                   const float* lr4, const float* wd4, float beta1, float beta2, float eps, float max_norm,

@@ -20,7 +20,7 @@ struct AdamTables {
   float* steps;                 // [ntensors]: updates applied to each tensor so far (torch.optim.Adam's per-parameter `step`)
 };
 struct AdamHyper {
-  float lr[4], wd[4];
+  float lr[TTK_ADAM_MAX_GROUPS], wd[TTK_ADAM_MAX_GROUPS];
   float beta1, beta2, eps, max_norm, grad_scale;
 };
 
@@ -66,10 +66,6 @@ __global__ void __launch_bounds__(kBlock) clip_adam_k(AdamTables t, AdamHyper h,
                                                        const float* __restrict__ partial, float* __restrict__ out_norm,
                                                        const float* __restrict__ hyper_dev) {
   __shared__ double dred[kBlock];
-  if (hyper_dev) {  // learning rates / weight decays live in device memory (same launch arguments every replay of a graph)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { h.lr[i] = hyper_dev[TTK_ADAM_HYPER_LR + i]; h.wd[i] = hyper_dev[TTK_ADAM_HYPER_WD + i]; }
-  }
   // total gradient norm: fixed-order fp64 sum of the chunk partials (identical in every block)
   double acc = 0.0;
   for (int i = threadIdx.x; i < nchunks; i += kBlock) acc += (double)partial[i];
@@ -93,7 +89,9 @@ __global__ void __launch_bounds__(kBlock) clip_adam_k(AdamTables t, AdamHyper h,
   float* v = reinterpret_cast<float*>(t.ptrs[4 * ti + 3]);
   if (!g) return;  // parameter without gradient this step: untouched, like torch.optim.Adam
   const int n = min(chunk_size, t.numel[ti] - off);
-  const float lr = h.lr[t.group[ti]], wd = h.wd[t.group[ti]];
+  // hyper_dev: learning rates / weight decays live in device memory (same launch arguments every replay of a graph)
+  const int gi = t.group[ti];
+  const float lr = hyper_dev ? hyper_dev[TTK_ADAM_HYPER_LR + gi] : h.lr[gi], wd = hyper_dev ? hyper_dev[TTK_ADAM_HYPER_WD + gi] : h.wd[gi];
   const double tstep = (double)t.steps[ti];  // bias corrections as torch computes them (Python floats = fp64)
   const float bc1 = (float)(1.0 - pow((double)h.beta1, tstep)), bc2 = (float)(1.0 - pow((double)h.beta2, tstep));
   const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
@@ -144,7 +142,7 @@ int ttk_clip_adam(const int64_t* ptrs, const int32_t* numel, const int32_t* grou
   TTK_REQUIRE(grad_scale > 0.f, "clip_adam: grad_scale must be positive (1 / number of replicas)");
   AdamTables t{ptrs, numel, group, chunk_tensor, chunk_offset, steps};
   AdamHyper h;
-  for (int i = 0; i < 4; ++i) { h.lr[i] = lr4[i]; h.wd[i] = wd4[i]; }
+  for (int i = 0; i < TTK_ADAM_MAX_GROUPS; ++i) { h.lr[i] = lr4[i]; h.wd[i] = wd4[i]; }
   h.beta1 = beta1; h.beta2 = beta2; h.eps = eps; h.max_norm = max_norm; h.grad_scale = grad_scale;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(grad_sqnorm_k, dim3(nchunks), dim3(kBlock), 0, st, t, chunk_size, partial);

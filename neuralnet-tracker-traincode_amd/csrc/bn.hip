@@ -121,6 +121,65 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_k(const float* __restric
   }
 }
 
+// Backward through a FROZEN BatchNorm (eval-mode statistics, reference modelcomponents.py:208-215 freeze_norm_stats: the layer
+// is the fixed affine map scale*(y - mean) + beta): dy = scale * g, so ga = scale, gb = 0, gmean = 0; the bound of |dy| is
+// max|scale| * max|g|.  One workgroup.
+__global__ void __launch_bounds__(256) bn_bwd_frozen_k(float* __restrict__ bn, int C) {
+  __shared__ float sm[4];
+  float m = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float sc = bn[TTK_BN_SCALE * C + c];
+    bn[TTK_BN_GA * C + c] = sc;
+    bn[TTK_BN_GB * C + c] = 0.f;
+    bn[TTK_BN_GMEAN * C + c] = 0.f;
+    m = fmaxf(m, fabsf(sc));
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float gmax = bn[(size_t)TTK_BN_AUX * C + TTK_AUX_GMAX];
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    if (gmax > 0.f) bn[(size_t)TTK_BN_AUX * C + TTK_AUX_DY_BOUND] = m * gmax * 1.0001f;
+  }
+}
+
+// Forward half of the frozen mode: the constants come from the running statistics (bn_eval_prepare_k), but the fp16 GEMMs still
+// want a bound of relu(scale*(y - mean_run) + beta) over THIS batch.  From the batch sums (mean_b, var_b):
+//   |scale*(y - mean_run) + beta| <= |scale| * (sqrt(count * var_b) + |mean_b - mean_run|) + |beta|     (Cauchy-Schwarz, as above)
+__global__ void __launch_bounds__(1024) bn_frozen_bound_k(const float* __restrict__ part, int rows, int C, double inv_count,
+                                                          float* __restrict__ bn) {
+  __shared__ double sm[2][32][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+#pragma unroll 4
+    for (int r = rl; r < rows; r += 32) {
+      a += (double)part[((size_t)r * 2 + 0) * C + c];
+      b += (double)part[((size_t)r * 2 + 1) * C + c];
+    }
+  }
+  sm[0][rl][cl] = a;
+  sm[1][rl][cl] = b;
+  __syncthreads();
+  float bound = 0.f;
+  if (rl == 0 && c < C) {
+    for (int i = 1; i < 32; ++i) { a += sm[0][i][cl]; b += sm[1][i][cl]; }
+    const double mean = a * inv_count;
+    double var = b * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double dev = sqrt((var + 1.0e-6 * (b * inv_count)) / inv_count);
+    bound = (float)(fabs((double)bn[TTK_BN_SCALE * C + c]) * (dev + fabs(mean - (double)bn[TTK_BN_MEAN * C + c])) + fabs((double)bn[TTK_BN_BETA * C + c])) * 1.0001f;
+  }
+  if (rl == 0) {
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) bound = fmaxf(bound, __shfl_xor(bound, off));
+    if (cl == 0) atomicMax(reinterpret_cast<unsigned*>(bn + (size_t)TTK_BN_AUX * C + TTK_AUX_ACT_BOUND), __float_as_uint(bound));
+  }
+}
+
 // rows r, r+F, r+2F, ... are summed into row r (r < F), in place: thread (r, i) owns element i of all
 // rows congruent to r, so no other thread reads or writes what it touches.
 constexpr int kFoldRows = 1024;
@@ -193,6 +252,19 @@ int ttk_bn_bwd_finalize(float* part, int part_rows, int C, int64_t count, const 
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, part_rows, C,
                      1.0 / (double)count, gamma, bn, dgamma, dbeta, accumulate);
   TTK_LAUNCH_CHECK("bn_bwd_finalize");
+}
+
+int ttk_bn_frozen_bound(float* part, int part_rows, int C, int64_t count, float* bn, ttk_stream_t stream) {
+  TTK_REQUIRE(part && bn && C > 0 && part_rows > 0 && count > 0, "bn_frozen_bound: bad arguments");
+  part_rows = fold_if_needed(part, part_rows, C, (hipStream_t)stream);
+  hipLaunchKernelGGL(bn_frozen_bound_k, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, part_rows, C, 1.0 / (double)count, bn);
+  TTK_LAUNCH_CHECK("bn_frozen_bound");
+}
+
+int ttk_bn_bwd_frozen(float* bn, int C, ttk_stream_t stream) {
+  TTK_REQUIRE(bn && C > 0, "bn_bwd_frozen: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_frozen_k, dim3(1), dim3(256), 0, (hipStream_t)stream, bn, C);
+  TTK_LAUNCH_CHECK("bn_bwd_frozen");
 }
 
 }  // extern "C"

@@ -19,6 +19,8 @@ _P, _I, _L, _F, _D = c_void_p, c_int, c_int64, c_float, c_double
 # name -> argument types (the trailing stream pointer is added automatically)
 _SIGNATURES = {
     "ttk_bn_fwd_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _F, _F, _P],
+    "ttk_bn_bwd_frozen": [_P, _I],
+    "ttk_bn_frozen_bound": [_P, _I, _I, _L, _P],
     "ttk_bn_eval_prepare": [_P, _P, _P, _P, _F, _I, _P],
     "ttk_bn_bwd_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _I],
     "ttk_stem_fwd": [_P, _P, _P, _P, _I, _I, _I, _I],
@@ -86,7 +88,7 @@ _SIGNATURES = {
     "ttk_clip_adam": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P],
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class _Library:

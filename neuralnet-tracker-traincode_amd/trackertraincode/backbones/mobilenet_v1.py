@@ -143,10 +143,10 @@ def _part_buffer(B, H, W, device):
 
 class _Ctx:
     """Everything one forward pass leaves behind for its backward."""
-    __slots__ = ("x", "stages", "a_in", "part", "dims", "pool_skip", "wparams", "HW", "B", "prep", "bf", "gdt")
+    __slots__ = ("x", "stages", "a_in", "part", "dims", "pool_skip", "wparams", "HW", "B", "prep", "bf", "gdt", "frozen")
 
 
-def _forward_impl(x, params, buffers, momentum, eps, training, act_dtype=torch.float32, grad_dtype=torch.float32):
+def _forward_impl(x, params, buffers, momentum, eps, training, act_dtype=torch.float32, grad_dtype=torch.float32, frozen=False):
     """Launches the forward kernels.  `params`: flat list [conv1.w, bn1.w, bn1.b, (dw.w, bn_dw.w,
     bn_dw.b, pw.w, bn_sep.w, bn_sep.b) x 13]; `buffers`: flat list of (running_mean, running_var,
     num_batches_tracked) per BN in the same order."""
@@ -158,6 +158,7 @@ def _forward_impl(x, params, buffers, momentum, eps, training, act_dtype=torch.f
     part = _part_buffer(B, H, W, dev)
     ctx = _Ctx()
     ctx.x, ctx.part, ctx.B = x, part, B
+    ctx.frozen = frozen  # backward through eval-mode BatchNorm: the fixed affine map (ttk_bn_bwd_frozen)
     ctx.stages, ctx.a_in, ctx.dims = [], [], []
     bf = int(act_dtype == torch.bfloat16) | (2 if grad_dtype == torch.bfloat16 else 0)  # TTK_STORE_* bits
     ctx.bf, ctx.gdt = bf, grad_dtype
@@ -170,8 +171,10 @@ def _forward_impl(x, params, buffers, momentum, eps, training, act_dtype=torch.f
                    float(momentum), float(eps), p(bn))
         else:
             L.call("ttk_bn_eval_prepare", p(gamma), p(beta), p(rm), p(rv), float(eps), C, p(bn))
+            if frozen:  # a backward pass follows: its fp16 GEMMs want the activation bound of this batch
+                L.call("ttk_bn_frozen_bound", p(part), rows, C, count, p(bn))
 
-    part_arg = p(part) if training else None
+    part_arg = p(part) if (training or frozen) else None
     # forward and data-gradient weight operands of all 13 pointwise convs, one launch
     w_pws = [params[3 + 6 * k + 3] for k in range(len(_BLOCKS))]
     sizes = [L.pwconv_prepared_bytes(cin, cout) for _, cin, cout, _ in _BLOCKS]
@@ -262,6 +265,9 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
     def bwd_finalize(stage: _Stage, rows, count, gi):
         """BatchNorm backward constants of `stage` + its dgamma/dbeta -> grads[gi], grads[gi+1]"""
         Cc = stage.y.shape[-1]
+        if ctx.frozen:  # frozen statistics (fine-tuning): no sums, no gamma / beta gradient
+            L.call("ttk_bn_bwd_frozen", p(stage.bn), Cc)
+            return
         L.call("ttk_bn_bwd_finalize", p(part), rows, Cc, count, p(params[gi]), p(stage.bn), p(grads[gi]), p(grads[gi + 1]), 0)
 
     main = torch.cuda.current_stream(gfeat.device)
@@ -342,8 +348,8 @@ class _MobileNetFn(torch.autograd.Function):
     """One autograd node for the whole backbone: saves raw conv outputs + BN constants."""
 
     @staticmethod
-    def forward(ctx, x, momentum, eps, buffers, *params):
-        feat, c = _forward_impl(x, params, buffers, momentum, eps, training=True, act_dtype=_ACT_DTYPE, grad_dtype=_GRAD_DTYPE)
+    def forward(ctx, x, momentum, eps, buffers, frozen, *params):
+        feat, c = _forward_impl(x, params, buffers, momentum, eps, training=not frozen, act_dtype=_ACT_DTYPE, grad_dtype=_GRAD_DTYPE, frozen=frozen)
         ctx.c = c
         ctx.nparams = len(params)
         ctx.save_for_backward(*params)
@@ -354,7 +360,7 @@ class _MobileNetFn(torch.autograd.Function):
         params = ctx.saved_tensors
         grads = _backward_impl(ctx.c, gfeat.contiguous(), params)
         ctx.c = None
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, None, *grads)
 
 
 class MobileNet(nn.Module):
@@ -426,12 +432,16 @@ class MobileNet(nn.Module):
         x = x.contiguous()
         bn_training = [bn.training for bn in self._bns()]
         if self.training and all(bn_training):
-            return _MobileNetFn.apply(x, momentum, eps, self._flat_buffers(), *self._flat_params())
+            return _MobileNetFn.apply(x, momentum, eps, self._flat_buffers(), False, *self._flat_params())
         if any(bn_training):
             raise NotImplementedError("mixed train/eval BatchNorm layers are not supported by the fused backbone")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._flat_params()):
-            raise NotImplementedError("gradients through the eval-mode (frozen BatchNorm) backbone are not built; "
-                                      "wrap inference in torch.no_grad()")
+            # every BatchNorm in eval mode, convolutions trainable: fine-tuning with frozen statistics (reference
+            # models.py:391-394 + modelcomponents.py:208-215, which also freezes gamma and beta)
+            if any(p.requires_grad for bn in self._bns() for p in bn.parameters()):
+                raise NotImplementedError("eval-mode BatchNorm layers with trainable weight / bias are not built: freeze them "
+                                          "(modelcomponents.freeze_norm_stats) or put the layers in training mode")
+            return _MobileNetFn.apply(x, momentum, eps, self._flat_buffers(), True, *self._flat_params())
         feat, _ = _forward_impl(x, [q.detach() for q in self._flat_params()], self._flat_buffers(), momentum, eps, False)
         return feat
 

@@ -62,7 +62,7 @@ def _bn_channels():
 
 
 class _Ctx:
-    __slots__ = ("x", "B", "H", "W", "y0", "bn0", "idx", "a1", "blocks", "part", "partd", "last")
+    __slots__ = ("x", "B", "H", "W", "y0", "bn0", "idx", "a1", "blocks", "part", "partd", "last", "frozen")
 
 
 class _Blk:
@@ -90,6 +90,7 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
     B, _, H, W = x.shape
     c = _Ctx()
     c.x, c.B, c.H, c.W = x, B, H, W
+    c.frozen = not training  # backward through eval-mode BatchNorm: the fixed affine map (ttk_bn_bwd_frozen)
     c.part, c.partd = _part_buffers(B, dev)
     part = c.part
     new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
@@ -220,6 +221,9 @@ def _backward_impl(c: _Ctx, gfeat, params):
         return dy, None
 
     def bwd_finalize(bn, rows, C, count, gi, scratch=None):
+        if c.frozen:  # frozen statistics (fine-tuning): no sums, no gamma / beta gradient
+            L.call("ttk_bn_bwd_frozen", p(bn), C)
+            return
         L.call("ttk_bn_bwd_finalize", p(scratch if scratch is not None else part), rows, C, count, p(params[gi]), p(bn), p(grads[gi]), p(grads[gi + 1]), 0)
 
     # scratch of the slice-wise (atomic-free, reproducible) weight gradients: one buffer, sized for the largest call
@@ -296,8 +300,8 @@ def _backward_impl(c: _Ctx, gfeat, params):
 
 class _ResNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, momentum, eps, buffers, *params):
-        feat, c = _forward_impl(x, params, buffers, momentum, eps)
+    def forward(ctx, x, momentum, eps, buffers, frozen, *params):
+        feat, c = _forward_impl(x, params, buffers, momentum, eps, training=not frozen)
         ctx.c = c
         ctx.save_for_backward(*params)
         return feat
@@ -306,7 +310,7 @@ class _ResNetFn(torch.autograd.Function):
     def backward(ctx, gfeat):
         grads = _backward_impl(ctx.c, gfeat.contiguous(), ctx.saved_tensors)
         ctx.c = None
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, None, *grads)
 
 
 class ResNetBackbone(nn.Module):
@@ -381,12 +385,15 @@ class ResNetBackbone(nn.Module):
             raise NotImplementedError("all BatchNorm layers must share one momentum/eps")
         bn_training = [b.training for b in bns]
         if self.training and all(bn_training):
-            return _ResNetFn.apply(x.contiguous(), moms.pop(), epss.pop(), self._flat_buffers(), *self._flat_params())
+            return _ResNetFn.apply(x.contiguous(), moms.pop(), epss.pop(), self._flat_buffers(), False, *self._flat_params())
         if any(bn_training):
             raise NotImplementedError("mixed train/eval BatchNorm layers are not supported by the fused backbone")
         if torch.is_grad_enabled() and any(q.requires_grad for q in self._flat_params()):
-            raise NotImplementedError("gradients through the eval-mode (frozen BatchNorm) backbone are not built; "
-                                      "wrap inference in torch.no_grad()")
+            # fine-tuning with frozen statistics (reference models.py:391-394 + modelcomponents.py:208-215)
+            if any(q.requires_grad for b in bns for q in b.parameters()):
+                raise NotImplementedError("eval-mode BatchNorm layers with trainable weight / bias are not built: freeze them "
+                                          "(modelcomponents.freeze_norm_stats) or put the layers in training mode")
+            return _ResNetFn.apply(x.contiguous(), moms.pop(), epss.pop(), self._flat_buffers(), True, *self._flat_params())
         feat, _ = _forward_impl(x.contiguous(), [q.detach() for q in self._flat_params()], self._flat_buffers(), moms.pop(), epss.pop(),
                                 training=False)
         return feat

@@ -297,13 +297,11 @@ class NetworkWithPointHead(nn.Module):
         return groups
 
     def train(self, mode=True):
-        if mode and self.finetune:
-            # reference :391-394 freezes the BatchNorm statistics here; the fused backbone has no backward through
-            # eval-mode BatchNorm (and ClipAdam takes at most 4 parameter groups), so say so up front instead of failing
-            # in the first forward pass
-            raise NotImplementedError("fine-tuning with frozen BatchNorm statistics (prepare_finetune() + train()) is not built "
-                                      "for the HIP backbone: train all layers, or fine-tune with the reference on the exported checkpoint")
         super().train(mode)
+        if mode and self.finetune:
+            # reference :391-394: the backbone's normalisation layers stay in eval mode with frozen affine parameters; the HIP
+            # backbone then runs its backward through the fixed affine maps (ttk_bn_bwd_frozen)
+            self.convnet.apply(freeze_norm_stats)
         return self
 
 

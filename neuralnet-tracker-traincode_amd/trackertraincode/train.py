@@ -215,14 +215,15 @@ class ClipAdam(torch.optim.Optimizer):
     exactly.  `grad_scale` (default 1): the stored gradients are read as grad_scale * g - 1/world when a
     data-parallel all-reduce left sums in place (trackertraincode.parallel)."""
 
+    MAX_GROUPS = 128  # TTK_ADAM_MAX_GROUPS (prepare_finetune() of the default backbone returns 66, one per backbone sub-module)
     CHUNK = 4096  # elements per workgroup: ~800 workgroups for the 3.2 M parameters (16384 left most of the 256 CUs idle)
 
     def __init__(self, params, lr=1.0e-3, betas=(0.9, 0.999), eps=1.0e-8, weight_decay=0.0, max_norm: float | None = 1.0):
         # capturable: torch then keeps a loaded `step` as a float32 tensor on the parameter's device
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=True))
         self.param_groups = [g for g in self.param_groups]
-        if len([g for g in self.param_groups if g["params"]]) > 4:
-            raise ValueError("ClipAdam supports at most 4 non-empty parameter groups")
+        if len(self.param_groups) > self.MAX_GROUPS:
+            raise ValueError(f"ClipAdam supports at most {self.MAX_GROUPS} parameter groups")
         if len({(g["betas"], g["eps"]) for g in self.param_groups}) != 1:
             raise ValueError("all groups must share betas and eps")
         self.max_norm = max_norm
@@ -280,7 +281,7 @@ class ClipAdam(torch.optim.Optimizer):
             nchunks=len(ct), ptrs_host=torch.zeros((len(plist), 4), dtype=torch.int64).pin_memory(),
             ptrs=torch.zeros((len(plist), 4), dtype=torch.int64, device=dev), steps=steps,
             partial=torch.empty(len(ct), dtype=torch.float32, device=dev), norm=torch.zeros(1, dtype=torch.float32, device=dev),
-            hyper=torch.zeros(8, dtype=torch.float32, device=dev),  # TTK_ADAM_HYPER_* block (include/ttk.h)
+            hyper=torch.zeros(2 * self.MAX_GROUPS, dtype=torch.float32, device=dev),  # TTK_ADAM_HYPER_* block (include/ttk.h)
         )
         h = self._tables["ptrs_host"]
         for ti, p in enumerate(plist):
@@ -320,8 +321,9 @@ class ClipAdam(torch.optim.Optimizer):
         capturing = torch.cuda.is_current_stream_capturing()
         self._upload_grad_pointers(T, capturing)
         b1, b2 = self.param_groups[0]["betas"]
-        lr4 = (ctypes.c_float * 4)(*([g["lr"] for g in self.param_groups] + [0.0] * 4)[:4])
-        wd4 = (ctypes.c_float * 4)(*([g["weight_decay"] for g in self.param_groups] + [0.0] * 4)[:4])
+        G = self.MAX_GROUPS
+        lr4 = (ctypes.c_float * G)(*([g["lr"] for g in self.param_groups] + [0.0] * G)[:G])
+        wd4 = (ctypes.c_float * G)(*([g["weight_decay"] for g in self.param_groups] + [0.0] * G)[:G])
         p_ = _hip.ptr
         # inside a hipGraph capture nothing of the step may be baked into launch arguments: learning rates and weight
         # decays are read from the device block `hyper` (the step counts always live on the device)
@@ -334,19 +336,23 @@ class ClipAdam(torch.optim.Optimizer):
         self.last_grad_norm = T["norm"]
         return None
 
+    def _hyper_values(self):
+        G = self.MAX_GROUPS
+        return ([g["lr"] for g in self.param_groups] + [0.0] * G)[:G] + ([g["weight_decay"] for g in self.param_groups] + [0.0] * G)[:G]
+
     # ---- hipGraph support -----------------------------------------------------------------------
     def sync_hyper_to_device(self):
         """Write the groups' lr / weight_decay into the device block a captured step reads.  Called before a capture and
         whenever the scheduler changed a learning rate (once per epoch)."""
         if self._tables is None:
             self._build_tables()
-        vals = ([g["lr"] for g in self.param_groups] + [0.0] * 4)[:4] + ([g["weight_decay"] for g in self.param_groups] + [0.0] * 4)[:4]
+        vals = self._hyper_values()
         self._tables["hyper"].copy_(torch.tensor(vals, dtype=torch.float32))  # synchronous, pageable: rare
         self._hyper_sig = tuple(vals)
 
     def before_graph_replay(self):
         """Push a changed learning rate / weight decay (scheduler step) to the device block before the replay."""
-        vals = tuple(([g["lr"] for g in self.param_groups] + [0.0] * 4)[:4] + ([g["weight_decay"] for g in self.param_groups] + [0.0] * 4)[:4])
+        vals = tuple(self._hyper_values())
         if vals != getattr(self, "_hyper_sig", None):
             torch.cuda.current_stream().synchronize()  # earlier replays still read the old values
             self.sync_hyper_to_device()
