@@ -210,3 +210,23 @@ def test_conv_bn_fusion_keeps_the_eval_output():
     with torch.no_grad():
         a, b = gm(x), fused(x)
     assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+
+
+def test_prepare_finetune_freezes_norm_layers_like_the_reference():
+    """models.py:378-394: prepare_finetune() returns one parameter group per backbone sub-module (+ the rest), and train() then
+    keeps every normalisation layer of the backbone in eval mode with frozen affine parameters (modelcomponents.py:208-215)."""
+    import torch
+    from trackertraincode.neuralnets.models import NetworkWithPointHead
+
+    net = NetworkWithPointHead(enable_point_head=False, enable_uncertainty=False)
+    groups = net.prepare_finetune()
+    flat = [p for g in groups for p in g]
+    assert len(flat) == len(set(map(id, flat))) == len(list(net.parameters()))
+    assert len(groups) == 13 * 5 + 1  # conv_dw, bn_dw, conv_sep, bn_sep, relu of the 13 blocks; everything else
+    assert net.train() is net and net.training
+    bns = [m for m in net.convnet.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    assert len(bns) == 27 and not any(m.training for m in bns)
+    assert not any(p.requires_grad for m in bns for p in m.parameters())
+    assert all(p.requires_grad for n, p in net.named_parameters() if ".bn" not in n)
+    net.eval()
+    assert not net.training
