@@ -402,6 +402,29 @@ int ttk_loss_normal_bwd(const float* mu, const float* sigma, const float* x, con
 int ttk_loss_gmm_fwd(const float* x, const double* ck, const double* mu, const double* sinv, int K, double fudge, int n, float* v, double* post, ttk_stream_t stream);
 int ttk_loss_gmm_bwd(const float* x, const double* mu, const double* sinv, const double* post, int K, double fudge, const float* gv, int n, float* gx, ttk_stream_t stream);
 
+/* Up to TTK_LOSS_BATCH_MAX of the loss ops above in ONE launch.  The ~30 loss kernels of a training step move a few KB each and
+ * do not depend on one another, but on one stream each costs ~4.5 us of launch-to-completion latency.  An op carries the
+ * arguments of its entry point in signature order - pointers in p[], ints in i[], floats in f[], the double in d - and
+ * `items`, the threads it needs (n for the per-sample ops rot / rot6d / ortho6d / quatreg / nllrot / nllcoord; 64 n for the
+ * wave-per-sample reductions mse_rows_fwd, mse_cols_fwd, points_fwd, normal_fwd, gmm_fwd; one per output element for the other
+ * backward ops).  The ops of one call must be independent (none reads what another writes).  `ops` is a HOST array. */
+#define TTK_LOSS_BATCH_MAX 32
+enum {
+  TTK_OP_ROT_FWD, TTK_OP_ROT_BWD, TTK_OP_ROT6D_FWD, TTK_OP_ROT6D_BWD, TTK_OP_ORTHO6D_FWD, TTK_OP_ORTHO6D_BWD,
+  TTK_OP_QUATREG_FWD, TTK_OP_QUATREG_BWD, TTK_OP_MSE_ROWS_FWD, TTK_OP_MSE_ROWS_BWD, TTK_OP_MSE_COLS_FWD, TTK_OP_MSE_COLS_BWD,
+  TTK_OP_POINTS_FWD, TTK_OP_POINTS_BWD, TTK_OP_NLLROT_FWD, TTK_OP_NLLROT_BWD, TTK_OP_NLLCOORD_FWD, TTK_OP_NLLCOORD_BWD,
+  TTK_OP_NORMAL_FWD, TTK_OP_NORMAL_BWD, TTK_OP_GMM_FWD, TTK_OP_GMM_BWD, TTK_OP_COUNT
+};
+typedef struct ttk_loss_op {
+  int kind;  /* TTK_OP_* */
+  int items;
+  const void* p[6];
+  int i[4];
+  float f[2];
+  double d;
+} ttk_loss_op;
+int ttk_loss_batch(int nops, const ttk_loss_op* ops, ttk_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * On-GPU intensity augmentation - the kornia chain of trackertraincode/pipelines.py:508-532
  * (container: datatransformation/batch/intensity.py:30-41) in one pass: one workgroup per image, the image stays in

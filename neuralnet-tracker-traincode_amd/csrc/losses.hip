@@ -35,27 +35,27 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;              \
   if (s >= (n)) return;
 
-__global__ void loss_rot_fwd_k(const float* q, const float* t, int n, float* v) {
+__device__ __forceinline__ void loss_rot_fwd_body(const float* q, const float* t, int n, float* v) {
   TTK_SAMPLE_INDEX(n);
   v[s] = lm::rot_loss(q + 4 * s, t + 4 * s);
 }
-__global__ void loss_rot_bwd_k(const float* q, const float* t, const float* gv, int n, float* gq) {
+__device__ __forceinline__ void loss_rot_bwd_body(const float* q, const float* t, const float* gv, int n, float* gq) {
   TTK_SAMPLE_INDEX(n);
   lm::rot_loss_bwd(q + 4 * s, t + 4 * s, gv[s], gq + 4 * s);
 }
-__global__ void loss_rot6d_fwd_k(const float* R, const float* t, int n, float* v) {
+__device__ __forceinline__ void loss_rot6d_fwd_body(const float* R, const float* t, int n, float* v) {
   TTK_SAMPLE_INDEX(n);
   v[s] = lm::rot6d_loss(R + 9 * s, t + 4 * s);
 }
-__global__ void loss_rot6d_bwd_k(const float* t, const float* gv, int n, float* gR) {
+__device__ __forceinline__ void loss_rot6d_bwd_body(const float* t, const float* gv, int n, float* gR) {
   TTK_SAMPLE_INDEX(n);
   lm::rot6d_loss_bwd(t + 4 * s, gv[s], gR + 9 * s);
 }
-__global__ void loss_ortho6d_fwd_k(const float* z, int n, float* v) {
+__device__ __forceinline__ void loss_ortho6d_fwd_body(const float* z, int n, float* v) {
   TTK_SAMPLE_INDEX(n);
   v[s] = lm::ortho6d_loss(z + 6 * s);
 }
-__global__ void loss_ortho6d_bwd_k(const float* z, const float* gv, int n, float* gz) {
+__device__ __forceinline__ void loss_ortho6d_bwd_body(const float* z, const float* gv, int n, float* gz) {
   TTK_SAMPLE_INDEX(n);
   lm::ortho6d_loss_bwd(z + 6 * s, gv[s], gz + 6 * s);
 }
@@ -67,16 +67,16 @@ __global__ void mat_to_quat_bwd_k(const float* m, const float* gq, int n, float*
   TTK_SAMPLE_INDEX(n);
   lm::from_matrix_bwd(m + 9 * s, gq + 4 * s, gm + 9 * s);
 }
-__global__ void loss_quatreg_fwd_k(const float* q, int n, float* v) {
+__device__ __forceinline__ void loss_quatreg_fwd_body(const float* q, int n, float* v) {
   TTK_SAMPLE_INDEX(n);
   v[s] = lm::quatreg_loss(q + 4 * s);
 }
-__global__ void loss_quatreg_bwd_k(const float* q, const float* gv, int n, float* gq) {
+__device__ __forceinline__ void loss_quatreg_bwd_body(const float* q, const float* gv, int n, float* gq) {
   TTK_SAMPLE_INDEX(n);
   lm::quatreg_loss_bwd(q + 4 * s, gv[s], gq + 4 * s);
 }
 // mean_d (p - t)^2
-__global__ void loss_mse_rows_fwd_k(const float* p, const float* t, int n, int D, float* v) {
+__device__ __forceinline__ void loss_mse_rows_fwd_body(const float* p, const float* t, int n, int D, float* v) {
   TTK_WAVE_SAMPLE(n);
   float acc = 0.f;
   for (int d = lane; d < D; d += 64) {
@@ -86,14 +86,14 @@ __global__ void loss_mse_rows_fwd_k(const float* p, const float* t, int n, int D
   acc = wave_sum_f(acc);
   if (lane == 0) v[s] = acc / (float)D;
 }
-__global__ void loss_mse_rows_bwd_k(const float* p, const float* t, const float* gv, int n, int D, float* gp) {
+__device__ __forceinline__ void loss_mse_rows_bwd_body(const float* p, const float* t, const float* gv, int n, int D, float* gp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * D) return;
   gp[i] = 2.f * (p[i] - t[i]) * gv[i / D] / (float)D;
 }
 // the same over the column window [c0, c0 + Dc) of rows that are Dt floats apart (p and t alike); the gradient is written
 // for the whole row, zero outside the window
-__global__ void loss_mse_cols_fwd_k(const float* p, const float* t, int n, int Dt, int c0, int Dc, float* v) {
+__device__ __forceinline__ void loss_mse_cols_fwd_body(const float* p, const float* t, int n, int Dt, int c0, int Dc, float* v) {
   TTK_WAVE_SAMPLE(n);
   float acc = 0.f;
   for (int d = lane; d < Dc; d += 64) {
@@ -103,7 +103,7 @@ __global__ void loss_mse_cols_fwd_k(const float* p, const float* t, int n, int D
   acc = wave_sum_f(acc);
   if (lane == 0) v[s] = acc / (float)Dc;
 }
-__global__ void loss_mse_cols_bwd_k(const float* p, const float* t, const float* gv, int n, int Dt, int c0, int Dc, float* gp) {
+__device__ __forceinline__ void loss_mse_cols_bwd_body(const float* p, const float* t, const float* gv, int n, int Dt, int c0, int Dc, float* gp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * Dt) return;
   const int d = i % Dt - c0;
@@ -165,7 +165,7 @@ __global__ void weighted_sum_bwd_k(SumTerms a, float scale, const float* gout) {
   }
 }
 // mean_p( w_p * sum_{d<dim} (p - t)^2 )
-__global__ void loss_points_fwd_k(const float* p, const float* t, int n, int dim, float chin, float eye, float* v) {
+__device__ __forceinline__ void loss_points_fwd_body(const float* p, const float* t, int n, int dim, float chin, float eye, float* v) {
   TTK_WAVE_SAMPLE(n);
   float acc = 0.f;
   for (int k = lane; k < 68; k += 64) {
@@ -179,32 +179,32 @@ __global__ void loss_points_fwd_k(const float* p, const float* t, int n, int dim
   acc = wave_sum_f(acc);
   if (lane == 0) v[s] = acc / 68.f;
 }
-__global__ void loss_points_bwd_k(const float* p, const float* t, const float* gv, int n, int dim, float chin, float eye,
+__device__ __forceinline__ void loss_points_bwd_body(const float* p, const float* t, const float* gv, int n, int dim, float chin, float eye,
                                   float* gp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * 204) return;
   const int s = i / 204, r = i % 204, k = r / 3, d = r % 3;
   gp[i] = d < dim ? 2.f * lm::point_weight(k, chin, eye) * (p[i] - t[i]) * gv[s] / 68.f : 0.f;
 }
-__global__ void loss_nllrot_fwd_k(const float* q, const float* t, const float* L, int n, float* v) {
+__device__ __forceinline__ void loss_nllrot_fwd_body(const float* q, const float* t, const float* L, int n, float* v) {
   TTK_SAMPLE_INDEX(n);
   v[s] = lm::nllrot_loss(q + 4 * s, t + 4 * s, L + 9 * s);
 }
-__global__ void loss_nllrot_bwd_k(const float* q, const float* t, const float* L, const float* gv, int n, float* gq, float* gL) {
+__device__ __forceinline__ void loss_nllrot_bwd_body(const float* q, const float* t, const float* L, const float* gv, int n, float* gq, float* gL) {
   TTK_SAMPLE_INDEX(n);
   lm::nllrot_loss_bwd(q + 4 * s, t + 4 * s, L + 9 * s, gv[s], gq + 4 * s, gL + 9 * s);
 }
-__global__ void loss_nllcoord_fwd_k(const float* c, const float* t, const float* L, int n, float* v) {
+__device__ __forceinline__ void loss_nllcoord_fwd_body(const float* c, const float* t, const float* L, int n, float* v) {
   TTK_SAMPLE_INDEX(n);
   v[s] = lm::nllcoord_loss(c + 3 * s, t + 3 * s, L + 9 * s);
 }
-__global__ void loss_nllcoord_bwd_k(const float* c, const float* t, const float* L, const float* gv, int n, float* gc, float* gL) {
+__device__ __forceinline__ void loss_nllcoord_bwd_body(const float* c, const float* t, const float* L, const float* gv, int n, float* gc, float* gL) {
   TTK_SAMPLE_INDEX(n);
   lm::nllcoord_loss_bwd(c + 3 * s, t + 3 * s, L + 9 * s, gv[s], gc + 3 * s, gL + 9 * s);
 }
 // -mean over `per` elements of w * Normal(mu, sigma).log_prob(x); elements laid out [n][rows][3] with
 // only the first `dim` of every 3 used when rows3 != 0 (points), else plain [n][per].
-__global__ void loss_normal_fwd_k(const float* mu, const float* sg, const float* x, int n, int per, int points, int dim,
+__device__ __forceinline__ void loss_normal_fwd_body(const float* mu, const float* sg, const float* x, int n, int per, int points, int dim,
                                   float chin, float eye, float* v) {
   TTK_WAVE_SAMPLE(n);
   float acc = 0.f;
@@ -228,7 +228,7 @@ __global__ void loss_normal_fwd_k(const float* mu, const float* sg, const float*
     if (lane == 0) v[s] = acc / (float)per;
   }
 }
-__global__ void loss_normal_bwd_k(const float* mu, const float* sg, const float* x, const float* gv, int n, int per,
+__device__ __forceinline__ void loss_normal_bwd_body(const float* mu, const float* sg, const float* x, const float* gv, int n, int per,
                                   int points, int dim, float chin, float eye, float* gmu, float* gsg) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int stride = points ? 204 : per;
@@ -246,7 +246,7 @@ __global__ void loss_normal_bwd_k(const float* mu, const float* sg, const float*
   gmu[i] = a;
   gsg[i] = b;
 }
-__global__ void loss_gmm_fwd_k(const float* x, const double* ck, const double* mu, const double* sinv, int K, double fudge,
+__device__ __forceinline__ void loss_gmm_fwd_body(const float* x, const double* ck, const double* mu, const double* sinv, int K, double fudge,
                                int n, float* v, double* post) {
   TTK_WAVE_SAMPLE(n);
   double a[16];
@@ -268,7 +268,7 @@ __global__ void loss_gmm_fwd_k(const float* x, const double* ck, const double* m
   if (lane == 0) v[s] = (float)(-(mx + log(sum)) * fudge);
 }
 // d/dx_d = fudge * sum_k post_k (x_d - mu_kd) sinv_kd^2
-__global__ void loss_gmm_bwd_k(const float* x, const double* mu, const double* sinv, const double* post, int K, double fudge,
+__device__ __forceinline__ void loss_gmm_bwd_body(const float* x, const double* mu, const double* sinv, const double* post, int K, double fudge,
                                const float* gv, int n, float* gx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * 50) return;
@@ -281,7 +281,76 @@ __global__ void loss_gmm_bwd_k(const float* x, const double* mu, const double* s
   gx[i] = (float)(fudge * acc * (double)gv[s]);
 }
 
+// ---- the thin kernels of the single-op entry points ------------------------------------------------------------------
+__global__ void loss_rot_fwd_k(const float* q, const float* t, int n, float* v) { loss_rot_fwd_body(q, t, n, v); }
+__global__ void loss_rot_bwd_k(const float* q, const float* t, const float* gv, int n, float* gq) { loss_rot_bwd_body(q, t, gv, n, gq); }
+__global__ void loss_rot6d_fwd_k(const float* R, const float* t, int n, float* v) { loss_rot6d_fwd_body(R, t, n, v); }
+__global__ void loss_rot6d_bwd_k(const float* t, const float* gv, int n, float* gR) { loss_rot6d_bwd_body(t, gv, n, gR); }
+__global__ void loss_ortho6d_fwd_k(const float* z, int n, float* v) { loss_ortho6d_fwd_body(z, n, v); }
+__global__ void loss_ortho6d_bwd_k(const float* z, const float* gv, int n, float* gz) { loss_ortho6d_bwd_body(z, gv, n, gz); }
+__global__ void loss_quatreg_fwd_k(const float* q, int n, float* v) { loss_quatreg_fwd_body(q, n, v); }
+__global__ void loss_quatreg_bwd_k(const float* q, const float* gv, int n, float* gq) { loss_quatreg_bwd_body(q, gv, n, gq); }
+__global__ void loss_mse_rows_fwd_k(const float* p, const float* t, int n, int D, float* v) { loss_mse_rows_fwd_body(p, t, n, D, v); }
+__global__ void loss_mse_rows_bwd_k(const float* p, const float* t, const float* gv, int n, int D, float* gp) { loss_mse_rows_bwd_body(p, t, gv, n, D, gp); }
+__global__ void loss_mse_cols_fwd_k(const float* p, const float* t, int n, int Dt, int c0, int Dc, float* v) { loss_mse_cols_fwd_body(p, t, n, Dt, c0, Dc, v); }
+__global__ void loss_mse_cols_bwd_k(const float* p, const float* t, const float* gv, int n, int Dt, int c0, int Dc, float* gp) { loss_mse_cols_bwd_body(p, t, gv, n, Dt, c0, Dc, gp); }
+__global__ void loss_points_fwd_k(const float* p, const float* t, int n, int dim, float chin, float eye, float* v) { loss_points_fwd_body(p, t, n, dim, chin, eye, v); }
+__global__ void loss_points_bwd_k(const float* p, const float* t, const float* gv, int n, int dim, float chin, float eye, float* gp) { loss_points_bwd_body(p, t, gv, n, dim, chin, eye, gp); }
+__global__ void loss_nllrot_fwd_k(const float* q, const float* t, const float* L, int n, float* v) { loss_nllrot_fwd_body(q, t, L, n, v); }
+__global__ void loss_nllrot_bwd_k(const float* q, const float* t, const float* L, const float* gv, int n, float* gq, float* gL) { loss_nllrot_bwd_body(q, t, L, gv, n, gq, gL); }
+__global__ void loss_nllcoord_fwd_k(const float* c, const float* t, const float* L, int n, float* v) { loss_nllcoord_fwd_body(c, t, L, n, v); }
+__global__ void loss_nllcoord_bwd_k(const float* c, const float* t, const float* L, const float* gv, int n, float* gc, float* gL) { loss_nllcoord_bwd_body(c, t, L, gv, n, gc, gL); }
+__global__ void loss_normal_fwd_k(const float* mu, const float* sg, const float* x, int n, int per, int points, int dim, float chin, float eye, float* v) { loss_normal_fwd_body(mu, sg, x, n, per, points, dim, chin, eye, v); }
+__global__ void loss_normal_bwd_k(const float* mu, const float* sg, const float* x, const float* gv, int n, int per, int points, int dim, float chin, float eye, float* gmu, float* gsg) { loss_normal_bwd_body(mu, sg, x, gv, n, per, points, dim, chin, eye, gmu, gsg); }
+__global__ void loss_gmm_fwd_k(const float* x, const double* ck, const double* mu, const double* sinv, int K, double fudge, int n, float* v, double* post) { loss_gmm_fwd_body(x, ck, mu, sinv, K, fudge, n, v, post); }
+__global__ void loss_gmm_bwd_k(const float* x, const double* mu, const double* sinv, const double* post, int K, double fudge, const float* gv, int n, float* gx) { loss_gmm_bwd_body(x, mu, sinv, post, K, fudge, gv, n, gx); }
+
+// ---- many loss ops in ONE launch (ttk_loss_batch): blockIdx.y picks the op, blockIdx.x its 256-thread block --------------
+// The ~30 loss kernels of a step are a few KB each and independent of one another, but on one stream each costs its ~4.5 us of
+// launch-to-completion latency; batched they cost one.  Arguments sit in the op in the order of the entry point's signature:
+// pointers in p[], ints in i[], floats in f[], the double in d.
+constexpr int kBatchMax = TTK_LOSS_BATCH_MAX;
+struct BatchArgs {
+  ttk_loss_op op[kBatchMax];
+};
+#define P_(k) static_cast<const float*>(o.p[k])
+#define W_(k) static_cast<float*>(const_cast<void*>(o.p[k]))
+#define D_(k) static_cast<const double*>(o.p[k])
+__global__ void __launch_bounds__(256) loss_batch_k(BatchArgs a) {
+  const ttk_loss_op& o = a.op[blockIdx.y];
+  if ((long long)blockIdx.x * 256 >= (long long)o.items) return;
+  switch (o.kind) {
+    case TTK_OP_ROT_FWD: loss_rot_fwd_body(P_(0), P_(1), o.i[0], W_(2)); break;
+    case TTK_OP_ROT_BWD: loss_rot_bwd_body(P_(0), P_(1), P_(2), o.i[0], W_(3)); break;
+    case TTK_OP_ROT6D_FWD: loss_rot6d_fwd_body(P_(0), P_(1), o.i[0], W_(2)); break;
+    case TTK_OP_ROT6D_BWD: loss_rot6d_bwd_body(P_(0), P_(1), o.i[0], W_(2)); break;
+    case TTK_OP_ORTHO6D_FWD: loss_ortho6d_fwd_body(P_(0), o.i[0], W_(1)); break;
+    case TTK_OP_ORTHO6D_BWD: loss_ortho6d_bwd_body(P_(0), P_(1), o.i[0], W_(2)); break;
+    case TTK_OP_QUATREG_FWD: loss_quatreg_fwd_body(P_(0), o.i[0], W_(1)); break;
+    case TTK_OP_QUATREG_BWD: loss_quatreg_bwd_body(P_(0), P_(1), o.i[0], W_(2)); break;
+    case TTK_OP_MSE_ROWS_FWD: loss_mse_rows_fwd_body(P_(0), P_(1), o.i[0], o.i[1], W_(2)); break;
+    case TTK_OP_MSE_ROWS_BWD: loss_mse_rows_bwd_body(P_(0), P_(1), P_(2), o.i[0], o.i[1], W_(3)); break;
+    case TTK_OP_MSE_COLS_FWD: loss_mse_cols_fwd_body(P_(0), P_(1), o.i[0], o.i[1], o.i[2], o.i[3], W_(2)); break;
+    case TTK_OP_MSE_COLS_BWD: loss_mse_cols_bwd_body(P_(0), P_(1), P_(2), o.i[0], o.i[1], o.i[2], o.i[3], W_(3)); break;
+    case TTK_OP_POINTS_FWD: loss_points_fwd_body(P_(0), P_(1), o.i[0], o.i[1], o.f[0], o.f[1], W_(2)); break;
+    case TTK_OP_POINTS_BWD: loss_points_bwd_body(P_(0), P_(1), P_(2), o.i[0], o.i[1], o.f[0], o.f[1], W_(3)); break;
+    case TTK_OP_NLLROT_FWD: loss_nllrot_fwd_body(P_(0), P_(1), P_(2), o.i[0], W_(3)); break;
+    case TTK_OP_NLLROT_BWD: loss_nllrot_bwd_body(P_(0), P_(1), P_(2), P_(3), o.i[0], W_(4), W_(5)); break;
+    case TTK_OP_NLLCOORD_FWD: loss_nllcoord_fwd_body(P_(0), P_(1), P_(2), o.i[0], W_(3)); break;
+    case TTK_OP_NLLCOORD_BWD: loss_nllcoord_bwd_body(P_(0), P_(1), P_(2), P_(3), o.i[0], W_(4), W_(5)); break;
+    case TTK_OP_NORMAL_FWD: loss_normal_fwd_body(P_(0), P_(1), P_(2), o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.f[1], W_(3)); break;
+    case TTK_OP_NORMAL_BWD: loss_normal_bwd_body(P_(0), P_(1), P_(2), P_(3), o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.f[1], W_(4), W_(5)); break;
+    case TTK_OP_GMM_FWD: loss_gmm_fwd_body(P_(0), D_(1), D_(2), D_(3), o.i[0], o.d, o.i[1], W_(4), static_cast<double*>(const_cast<void*>(o.p[5]))); break;
+    case TTK_OP_GMM_BWD: loss_gmm_bwd_body(P_(0), D_(1), D_(2), D_(3), o.i[0], o.d, P_(4), o.i[1], W_(5)); break;
+    default: break;
+  }
+}
+#undef P_
+#undef W_
+#undef D_
+
 }  // namespace ttk
+
 
 using namespace ttk;
 
@@ -475,6 +544,19 @@ int ttk_loss_gmm_bwd(const float* x, const double* mu, const double* sinv, const
   TTK_REQUIRE(x && mu && sinv && post && gv && gx && n > 0 && K > 0, "loss_gmm_bwd: bad arguments");
   hipLaunchKernelGGL(loss_gmm_bwd_k, TTK_GRID(n * 50), x, mu, sinv, post, K, fudge, gv, n, gx);
   TTK_LAUNCH_CHECK("loss_gmm_bwd");
+}
+
+int ttk_loss_batch(int nops, const ttk_loss_op* ops, ttk_stream_t stream) {
+  TTK_REQUIRE(nops > 0 && nops <= kBatchMax && ops, "loss_batch: 1..%d ops", kBatchMax);
+  BatchArgs a{};
+  int items = 0;
+  for (int k = 0; k < nops; ++k) {
+    TTK_REQUIRE(ops[k].kind >= 0 && ops[k].kind < TTK_OP_COUNT && ops[k].items > 0, "loss_batch: op %d: bad kind or item count", k);
+    a.op[k] = ops[k];
+    if (ops[k].items > items) items = ops[k].items;
+  }
+  hipLaunchKernelGGL(loss_batch_k, dim3((unsigned)((items + 255) / 256), (unsigned)nops), dim3(256), 0, (hipStream_t)stream, a);
+  TTK_LAUNCH_CHECK("loss_batch");
 }
 
 }  // extern "C"

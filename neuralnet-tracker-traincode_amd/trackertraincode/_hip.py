@@ -80,6 +80,7 @@ _SIGNATURES = {
     "ttk_loss_normal_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P],
     "ttk_loss_gmm_fwd": [_P, _P, _P, _P, _I, _D, _I, _P, _P],
     "ttk_loss_gmm_bwd": [_P, _P, _P, _P, _I, _D, _P, _I, _P],
+    "ttk_loss_batch": [_I, _P],
     "ttk_view_roi": [_P, _P, _P, _F, _I, _P],
     "ttk_roi_transform": [_P, _P, _I, _I, _P],
     "ttk_affine_warp": [_P, _I, _I, _I, _I, _P, _P, _I, _F, _F],
@@ -89,6 +90,27 @@ _SIGNATURES = {
 }
 
 ABI_VERSION = 13
+
+
+class LossOp(ctypes.Structure):
+    """ttk_loss_op (include/ttk.h): one loss op of a ttk_loss_batch launch."""
+    _fields_ = [("kind", c_int), ("items", c_int), ("p", c_void_p * 6), ("i", c_int * 4), ("f", c_float * 2), ("d", c_double)]
+
+
+LOSS_BATCH_MAX = 32
+# entry point -> (TTK_OP_* kind, threads the op needs as a function of its argument tuple); the arguments are packed into
+# p[] / i[] / f[] / d in signature order
+_n = lambda k: (lambda a: a[k])
+LOSS_BATCH_OPS = {
+    "ttk_loss_rot_fwd": (0, _n(2)), "ttk_loss_rot_bwd": (1, _n(3)), "ttk_loss_rot6d_fwd": (2, _n(2)), "ttk_loss_rot6d_bwd": (3, _n(2)),
+    "ttk_loss_ortho6d_fwd": (4, _n(1)), "ttk_loss_ortho6d_bwd": (5, _n(2)), "ttk_loss_quatreg_fwd": (6, _n(1)), "ttk_loss_quatreg_bwd": (7, _n(2)),
+    "ttk_loss_mse_rows_fwd": (8, lambda a: a[2] * 64), "ttk_loss_mse_rows_bwd": (9, lambda a: a[3] * a[4]),
+    "ttk_loss_mse_cols_fwd": (10, lambda a: a[2] * 64), "ttk_loss_mse_cols_bwd": (11, lambda a: a[3] * a[4]),
+    "ttk_loss_points_fwd": (12, lambda a: a[2] * 64), "ttk_loss_points_bwd": (13, lambda a: a[3] * 204),
+    "ttk_loss_nllrot_fwd": (14, _n(3)), "ttk_loss_nllrot_bwd": (15, _n(4)), "ttk_loss_nllcoord_fwd": (16, _n(3)), "ttk_loss_nllcoord_bwd": (17, _n(4)),
+    "ttk_loss_normal_fwd": (18, lambda a: a[3] * 64), "ttk_loss_normal_bwd": (19, lambda a: a[4] * (204 if a[6] else a[5])),
+    "ttk_loss_gmm_fwd": (20, lambda a: a[6] * 64), "ttk_loss_gmm_bwd": (21, lambda a: a[7] * 50),
+}
 
 
 class _Library:
@@ -133,6 +155,30 @@ class _Library:
         if rc != 0:
             msg = self.cdll.ttk_last_error_string().decode(errors="replace")
             raise RuntimeError(f"{name} failed (code {rc}): {msg}")
+
+    def loss_batch(self, ops):
+        """ttk_loss_batch: `ops` = [(entry point name, argument tuple as for call()), ...], mutually independent; one launch
+        per LOSS_BATCH_MAX ops."""
+        for lo in range(0, len(ops), LOSS_BATCH_MAX):
+            chunk = ops[lo:lo + LOSS_BATCH_MAX]
+            arr = (LossOp * len(chunk))()
+            for o, (name, args) in zip(arr, chunk):
+                kind, items = LOSS_BATCH_OPS[name]
+                o.kind, o.items = kind, int(items(args))
+                np_ = ni = nf = 0
+                for ty, v in zip(_SIGNATURES[name], args):
+                    if ty is _P:
+                        o.p[np_] = v
+                        np_ += 1
+                    elif ty is _I:
+                        o.i[ni] = int(v)
+                        ni += 1
+                    elif ty is _F:
+                        o.f[nf] = float(v)
+                        nf += 1
+                    else:
+                        o.d = float(v)
+            self.call("ttk_loss_batch", len(chunk), arr)
 
     def pwconv_prepared_bytes(self, cin: int, cout: int) -> int:
         return self.cdll.ttk_pwconv_prepared_bytes(cin, cout)

@@ -4,12 +4,58 @@ Every function here requires CUDA tensors and the HIP library: there is no PyTor
 module API in losses.py / negloglikelihood.py / models.py raises for CPU tensors in training)."""
 from __future__ import annotations
 
+import os
+import threading
+
 import torch
 from torch.autograd import Function
 
 from .. import _hip
 
-_p = _hip.ptr
+# ---------------------------------------------------------------------------------------------
+# launch batching of the loss ops (ttk_loss_batch)
+# ---------------------------------------------------------------------------------------------
+class _Batch:
+    """Loss launches collected instead of issued; flush() issues them as one ttk_loss_batch launch.  Only ops that do not
+    depend on one another may meet in a batch (train.default_compute_loss: the per-sample values of all criterions in the
+    forward pass, their gradients in the backward pass)."""
+
+    def __init__(self):
+        self.ops, self.keep, self.records = [], [], []
+        self.deferring = False  # set while a Function driven by apply() / BatchedLossFn runs: only ITS launches are deferred
+
+    def flush(self):
+        ops, self.ops = self.ops, []
+        if ops:
+            _hip.lib().loss_batch(ops)
+        self.keep = []  # the launch is on the stream: the caching allocator may recycle the temporaries behind it
+
+
+_BATCHING = os.environ.get("TTK_LOSS_BATCH", "1") != "0"  # 0: one launch per loss op (A/B timing)
+_TLS = threading.local()  # the open batch of this thread (backward runs on autograd's worker thread)
+
+
+def _batch() -> _Batch | None:
+    return getattr(_TLS, "batch", None)
+
+
+class loss_batch:
+    """with loss_batch() as b: loss Functions applied through `apply` below defer their launches into b."""
+
+    def __enter__(self):
+        self.prev, _TLS.batch = _batch(), _Batch()
+        return _TLS.batch
+
+    def __exit__(self, *exc):
+        _TLS.batch = self.prev
+        return False
+
+
+def _p(t):
+    b = _batch()
+    if b is not None and b.deferring and t is not None:
+        b.keep.append(t)  # a deferred launch reads this pointer later: the tensor must outlive the flush
+    return _hip.ptr(t)
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -19,7 +65,76 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 def _call(name, *args):
+    b = _batch()
+    if b is not None and b.deferring and name in _hip.LOSS_BATCH_OPS:
+        b.ops.append((name, args))
+        return
     _hip.lib().call(name, *args)
+
+
+class _Ctx:
+    """What a loss Function's forward / backward use of the autograd context, for Functions driven by BatchedLossFn."""
+
+    def __init__(self):
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def set_materialize_grads(self, _flag):
+        pass
+
+
+def apply(fn, *args):
+    """fn.apply(*args) - or, inside loss_batch(), the same forward with its launch deferred: the returned per-sample values are
+    filled in by the batch's flush and carry no autograd history; the batch records what BatchedLossFn needs to run
+    fn.backward.  Only for call sites that hand the result back untouched (nothing may read it before the flush)."""
+    b = _batch() if _BATCHING else None
+    if b is None or not all(a.is_cuda for a in args if isinstance(a, torch.Tensor)):
+        return fn.apply(*args)
+    ctx = _Ctx()
+    b.deferring = True
+    try:
+        with torch.no_grad():
+            v = fn.forward(ctx, *args)
+    finally:
+        b.deferring = False
+    b.records.append((fn, ctx, args, v))
+    return v
+
+
+class BatchedLossFn(Function):
+    """scale * sum_k w_k * sum_i sample_w_k[i] * val_k[i] over all loss terms of a step, with the terms' own forward and backward
+    kernels batched: forward = one ttk_loss_batch launch (the deferred ops of `batch`) + one weighted sum; backward = one
+    launch for d loss / d values + one ttk_loss_batch launch for every term's gradient.  `records[k]` (fn, ctx, args, v)
+    describes deferred term k, inputs `tensors[slots[k][j]]` are its differentiable arguments; the trailing `ordinary` values are
+    terms computed the usual way (autograd history of their own)."""
+
+    @staticmethod
+    def forward(ctx, batch, records, slots, scalars, sample_ws, scale, n_inputs, *tensors):
+        batch.flush()
+        ordinary = list(tensors[n_inputs:])
+        vals = [r[3] for r in records] + ordinary
+        loss = WeightedSumFn.forward(ctx, scalars, sample_ws, scale, *vals)
+        ctx.rec = (records, slots, n_inputs, len(ordinary))
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        records, slots, n_inputs, n_ord = ctx.rec
+        gvals = WeightedSumFn.backward(ctx, g)[3:]
+        grads = [None] * n_inputs
+        with loss_batch() as b:
+            b.deferring = True
+            outs = [fn.backward(fctx, gv) for (fn, fctx, _, _), gv in zip(records, gvals)]
+            b.deferring = False
+            b.flush()
+        for sl, out in zip(slots, outs):
+            out = out if isinstance(out, tuple) else (out,)
+            for pos, j in sl:  # argument position of the Function -> index into the distinct inputs
+                if out[pos] is not None:
+                    grads[j] = out[pos] if grads[j] is None else grads[j] + out[pos]
+        return (None,) * 7 + tuple(grads) + tuple(gvals[len(records):])
 
 
 # Data-parallel hook (trackertraincode.parallel.install): called as hook(arena, [(param, lo, hi), ...]) when the fused
@@ -276,9 +391,9 @@ class MseColsFn(Function):
 def mse_cols(p, t, c0, nc):
     """mean((p[..., c0:c0+nc] - t[..., c0:c0+nc])**2, -1) per sample."""
     if p.dim() == 2 and t.shape == p.shape:
-        return MseColsFn.apply(p, t, c0, nc)
+        return apply(MseColsFn, p, t, c0, nc)
     sl = slice(c0, c0 + nc) if nc > 1 else c0
-    return MseRowsFn.apply(p[..., sl], t[..., sl])
+    return apply(MseRowsFn, p[..., sl], t[..., sl])
 
 
 class SplitRowsFn(Function):

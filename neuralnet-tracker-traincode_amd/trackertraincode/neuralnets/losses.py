@@ -39,7 +39,7 @@ class QuatPoseLoss:
 
     def __call__(self, pred, sample):
         quat = pred[self._prefix + "rot"]
-        return _hipops.RotLossFn.apply(quat.value if hasattr(quat, "value") else quat, sample["pose"])
+        return _hipops.apply(_hipops.RotLossFn, quat.value if hasattr(quat, "value") else quat, sample["pose"])
 
 
 class PoseSizeLoss:
@@ -62,7 +62,7 @@ class PoseXYLoss:
 
 class ShapeParameterLoss:
     def eval_on_params(self, pred, target):
-        return _hipops.MseRowsFn.apply(pred, target)
+        return _hipops.apply(_hipops.MseRowsFn, pred, target)
 
     def __call__(self, pred, sample):
         return self.eval_on_params(pred["shapeparam"], sample["shapeparam"])
@@ -85,7 +85,7 @@ class ShapePlausibilityLoss(nn.Module):
         x = pred["shapeparam"]
         if self._ck.device != x.device:
             self.to(x.device)
-        return _hipops.GmmNllFn.apply(x, self._ck, self._mu, self._sinv, 0.001 / self.gmm.n_components)
+        return _hipops.apply(_hipops.GmmNllFn, x, self._ck, self._mu, self._sinv, 0.001 / self.gmm.n_components)
 
 
 class QuaternionNormalizationSoftConstraint:
@@ -95,7 +95,7 @@ class QuaternionNormalizationSoftConstraint:
     def __call__(self, pred, sample):
         q = pred[self._prefix + "unnormalized_quat"]
         assert q.dim() == 2 and q.shape[-1] == 4
-        return _hipops.QuatRegFn.apply(q)
+        return _hipops.apply(_hipops.QuatRegFn, q)
 
 
 class Points3dLoss(nn.Module):
@@ -110,7 +110,7 @@ class Points3dLoss(nn.Module):
     def _eval_on_points(self, pred, target):
         assert target.shape == pred.shape, f"Mismatch {target.shape} vs {pred.shape}"
         assert target.shape[1] == 68 and target.shape[2] == 3
-        return _hipops.PointsLossFn.apply(pred, target, self.pointdimension, self.chin_weight, self.eye_weights)
+        return _hipops.apply(_hipops.PointsLossFn, pred, target, self.pointdimension, self.chin_weight, self.eye_weights)
 
     def forward(self, pred, sample):
         return self._eval_on_points(pred[self._prefix + "pt3d_68"], sample["pt3d_68"])
@@ -122,7 +122,7 @@ class BoxLoss:
         self.dataname = dataname
 
     def __call__(self, pred, sample):
-        return _hipops.MseRowsFn.apply(pred[self.dataname], sample[self.dataname])
+        return _hipops.apply(_hipops.MseRowsFn, pred[self.dataname], sample[self.dataname])
 
 
 class Rot6dReprLoss:
@@ -130,11 +130,11 @@ class Rot6dReprLoss:
 
     def __call__(self, pred_batch, target_batch):
         pred = pred_batch["rot"]
-        return _hipops.Rot6dLossFn.apply(pred.value if hasattr(pred, "value") else pred, target_batch["pose"])
+        return _hipops.apply(_hipops.Rot6dLossFn, pred.value if hasattr(pred, "value") else pred, target_batch["pose"])
 
 
 class Rot6dNormalizationSoftConstraint:
     """mean((M M^T - I_2)^2) of the raw 6D features (reference :61-64, torch6drotation.py:20-24)."""
 
     def __call__(self, pred_batch, target_batch):
-        return _hipops.Ortho6dFn.apply(pred_batch["unnormalized_6drepr"])
+        return _hipops.apply(_hipops.Ortho6dFn, pred_batch["unnormalized_6drepr"])

@@ -143,7 +143,7 @@ class CorrelatedCoordPoseNLLLoss(nn.Module):
         self.uniform_mixing = MixWithUniformProbability(4.0)  # [-1,1] x [-1,1] x [0,1]
 
     def __call__(self, preds, sample):
-        return _hipops.NllCoordFn.apply(preds["coord"], sample["coord"], preds["coord_scales"])
+        return _hipops.apply(_hipops.NllCoordFn, preds["coord"], sample["coord"], preds["coord_scales"])
 
 
 class BoxNLLLoss(nn.Module):
@@ -153,7 +153,7 @@ class BoxNLLLoss(nn.Module):
         self.dataname = dataname
 
     def __call__(self, pred, sample):
-        return _hipops.NormalNllFn.apply(pred[self.dataname], pred[self.dataname + "_scales"], sample[self.dataname], False, 0, 1.0, 1.0)
+        return _hipops.apply(_hipops.NormalNllFn, pred[self.dataname], pred[self.dataname + "_scales"], sample[self.dataname], False, 0, 1.0, 1.0)
 
 
 class Points3dNLLLoss(nn.Module):
@@ -166,7 +166,7 @@ class Points3dNLLLoss(nn.Module):
         self.chin_weight, self.eye_weight, self.pointdimension = float(chin_weight), float(eye_weight), pointdimension
 
     def __call__(self, preds, sample):
-        return _hipops.NormalNllFn.apply(preds["pt3d_68"], preds["pt3d_68_scales"], sample["pt3d_68"], True,
+        return _hipops.apply(_hipops.NormalNllFn, preds["pt3d_68"], preds["pt3d_68_scales"], sample["pt3d_68"], True,
                                          self.pointdimension, self.chin_weight, self.eye_weight)
 
 
@@ -176,7 +176,7 @@ class ShapeParamsNLLLoss(nn.Module):
         _gaussian_only(distribution)
 
     def __call__(self, preds, sample):
-        return _hipops.NormalNllFn.apply(preds["shapeparam"], preds["shapeparam_scales"], sample["shapeparam"], False, 0, 1.0, 1.0)
+        return _hipops.apply(_hipops.NormalNllFn, preds["shapeparam"], preds["shapeparam_scales"], sample["shapeparam"], False, 0, 1.0, 1.0)
 
 
 class QuatPoseNLLLoss(nn.Module):
@@ -188,4 +188,4 @@ class QuatPoseNLLLoss(nn.Module):
         self.uniform_mixing = MixWithUniformProbability(torch.pi ** 4 * 4.0 / 3.0)
 
     def __call__(self, preds, sample):
-        return _hipops.NllRotFn.apply(_as_quat(preds["rot"]), sample["pose"], preds["pose_scales_tril"])
+        return _hipops.apply(_hipops.NllRotFn, _as_quat(preds["rot"]), sample["pose"], preds["pose_scales_tril"])

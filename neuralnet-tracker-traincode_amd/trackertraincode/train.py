@@ -161,24 +161,52 @@ def default_compute_loss(preds: dict, batch: List[Batch], current_epoch: int, lo
 
     all_lossvals: list[list[LossVal]] = []
     sizes = [subset.meta.prefixshape[0] for subset in batch]
-    for subset, subpreds in zip(batch, _split_predictions(preds, sizes)):
-        crit = loss[subset.meta.tag] if isinstance(loss, dict) else loss
-        terms = crit.evaluate(subpreds, subset, current_epoch)
-        dw = None
-        if "dataset_weight" in subset:
-            dw = subset["dataset_weight"]
-            assert dw.size(0) == subset.meta.batchsize
-        all_lossvals.append([v._replace(weight=SampleWeight(v.weight, dw, v.val)) for v in terms])
+    # the criterions' HIP kernels are independent of one another: their launches are collected and issued as ONE
+    # (neuralnets/_hipops.py: loss_batch / apply / BatchedLossFn), forward here and backward in BatchedLossFn.backward
+    with _hipops.loss_batch() as lb:
+        for subset, subpreds in zip(batch, _split_predictions(preds, sizes)):
+            crit = loss[subset.meta.tag] if isinstance(loss, dict) else loss
+            terms = crit.evaluate(subpreds, subset, current_epoch)
+            dw = None
+            if "dataset_weight" in subset:
+                dw = subset["dataset_weight"]
+                assert dw.size(0) == subset.meta.batchsize
+            all_lossvals.append([v._replace(weight=SampleWeight(v.weight, dw, v.val)) for v in terms])
     batchsize = sum(subset.meta.batchsize for subset in batch)
     flat = list(itertools.chain.from_iterable(all_lossvals))
     if flat and all(v.val.is_cuda and v.val.dtype == torch.float32 for v in flat):
-        loss_sum = _hipops.WeightedSumFn.apply([v.weight.scalar for v in flat], [v.weight.per_sample for v in flat], 1.0 / batchsize,
-                                               *[v.val for v in flat])
+        loss_sum = _batched_loss_sum(lb, flat, 1.0 / batchsize)
     else:  # host-side logic on CPU tensors (tests); the reference's formula
+        lb.flush()
         by_name = concatenated_lossvals_by_name(flat)
         loss_sum = torch.concat([v * w for v, w in by_name.values()]).sum() / batchsize
     all_lossvals = [[v._replace(val=v.val.detach()) for v in terms] for terms in all_lossvals]
     return loss_sum, all_lossvals
+
+
+def _batched_loss_sum(lb, flat, scale):
+    """The weighted sum over all terms; the terms whose kernels were deferred into `lb` go through BatchedLossFn together."""
+    from .neuralnets import _hipops
+    by_val = {id(r[3]): r for r in lb.records}
+    deferred = [v for v in flat if id(v.val) in by_val]
+    ordinary = [v for v in flat if id(v.val) not in by_val]
+    if not deferred:
+        lb.flush()
+        return _hipops.WeightedSumFn.apply([v.weight.scalar for v in flat], [v.weight.per_sample for v in flat], scale, *[v.val for v in flat])
+    records = [by_val[id(v.val)] for v in deferred]
+    inputs, index, slots = [], {}, []
+    for _fn, _ctx, args, _v in records:  # the distinct differentiable inputs of the deferred terms
+        sl = []
+        for pos, a in enumerate(args):
+            if isinstance(a, Tensor) and a.requires_grad:
+                if id(a) not in index:
+                    index[id(a)] = len(inputs)
+                    inputs.append(a)
+                sl.append((pos, index[id(a)]))
+        slots.append(sl)
+    order = deferred + ordinary
+    return _hipops.BatchedLossFn.apply(lb, records, slots, [v.weight.scalar for v in order], [v.weight.per_sample for v in order], scale,
+                                       len(inputs), *inputs, *[v.val for v in ordinary])
 
 
 # ---------------------------------------------------------------------------------------------
