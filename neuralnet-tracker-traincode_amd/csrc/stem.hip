@@ -252,9 +252,10 @@ __global__ void __launch_bounds__(kBlock) stem_wgrad_mfma_k(const TG* __restrict
     __syncthreads();
     const int npix = (ho1 - ho0) * Wo;
     const size_t pix0 = ((size_t)n * Ho + ho0) * Wo;  // the band's pixels are contiguous in g / y
-    for (int p0 = wv * kWgChunk; p0 < npix; p0 += (kBlock / kWave) * kWgChunk) {
-      // ---- dy of 16 pixels x 32 channels: two 16-byte loads per lane and tensor
-      float4 gvs[kWgChunk / 8], yvs[kWgChunk / 8];
+    // the loads of the NEXT chunk are issued before this chunk's MFMAs (the wave had nothing in flight while it multiplied:
+    // 153 -> 146 us at B = 512)
+    float4 gvs[kWgChunk / 8], yvs[kWgChunk / 8];
+    auto load_chunk = [&](int p0) {
 #pragma unroll
       for (int u = 0; u < kWgChunk / 8; ++u) {
         const int pp = p0 + pl + 8 * u;
@@ -262,6 +263,10 @@ __global__ void __launch_bounds__(kBlock) stem_wgrad_mfma_k(const TG* __restrict
         gvs[u] = Act<TG>::ldnt(g + o);
         yvs[u] = Act<T>::ldnt(y + o);
       }
+    };
+    if (wv * kWgChunk < npix) load_chunk(wv * kWgChunk);
+    for (int p0 = wv * kWgChunk; p0 < npix; p0 += (kBlock / kWave) * kWgChunk) {
+      // ---- dy of 32 pixels x 32 channels: four 16-byte loads per lane and tensor (requested one chunk earlier)
 #pragma unroll
       for (int u = 0; u < kWgChunk / 8; ++u) {
         const int pp = p0 + pl + 8 * u;
@@ -273,6 +278,7 @@ __global__ void __launch_bounds__(kBlock) stem_wgrad_mfma_k(const TG* __restrict
         }
         st4(dyw + (pl + 8 * u) * kStemC + 4 * c4, d);
       }
+      if (p0 + (kBlock / kWave) * kWgChunk < npix) load_chunk(p0 + (kBlock / kWave) * kWgChunk);
       __builtin_amdgcn_wave_barrier();  // the tile is wave-private; LDS executes a wave's accesses in order
       // pixel of this lane's k index: p0 + 2j + hk; its (row, column) inside the band advance without divisions
       int ho = (p0 + hk) / Wo, wo = (p0 + hk) - ho * Wo;

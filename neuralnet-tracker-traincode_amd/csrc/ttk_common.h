@@ -149,6 +149,8 @@ template <> struct Act<float> {
   __device__ __forceinline__ static float4 ld(const float* p) { return ld4(p); }
   __device__ __forceinline__ static float4 ldnt(const float* p) { return ld4nt(p); }
   __device__ __forceinline__ static float4 round(float4 v) { return v; }
+  // (streaming / non-temporal stores of the outputs were measured: the depthwise forward, which re-reads what the previous kernel
+  // left in L2 / MALL, went 0.72 -> 0.85 ms per step; the step 8.05 -> 8.13 ms)
   __device__ __forceinline__ static void st(float* p, float4 v) { st4(p, v); }
   __device__ __forceinline__ static float st1(float* p, float v) { *p = v; return v; }  // scalar store; returns the stored value
 };

@@ -16,3 +16,7 @@ def run(fn, name):
 run(lambda: L.call("ttk_stem_fwd", p(x), p(w), p(y), p(part), B, 129, 129, 0), "stem_fwd")
 ref = torch.nn.functional.conv2d(x[:4].double().cpu(), w.double().cpu(), stride=2, padding=2).permute(0, 2, 3, 1)
 print("rel err", float((y[:4].cpu().double() - ref).norm() / ref.norm()))
+g = torch.randn(B, 65, 65, 32, device="cuda") * 1e-3
+bn = torch.rand(8, 32, device="cuda") + 0.5
+dw = torch.zeros(32, 25, device="cuda")
+run(lambda: L.call("ttk_stem_bwd_weight", p(g), p(y), p(bn), p(x), p(dw), 1, None, B, 129, 129, 0), "stem_wgrad")
