@@ -78,3 +78,53 @@ def test_weighted_sum_matches_reference_formula():
     assert abs(out.item() - ref.item()) <= 1e-6 * abs(ref.item()) + 1e-7
     for v, r in zip(vals, ref_vals):
         torch.testing.assert_close(v.grad, r.grad.float(), rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("cfg", ["full", "default", "rot6d"])
+def test_batched_loss_launches_equal_single_launches(cfg, monkeypatch):
+    """train.default_compute_loss issues all criterions' kernels as one ttk_loss_batch launch (and all their gradients as
+    another, BatchedLossFn); with batching off every loss op is its own launch through its own autograd node.  Same kernels'
+    bodies, same inputs: the loss, every per-sample value and the gradient reaching every prediction tensor must agree to
+    the last bit or, where three gradients meet in one tensor, to the rounding of a different summation order."""
+    import itertools
+
+    import trackertraincode.train as train
+    from trackertraincode.neuralnets import _hipops
+    from util import build_net, load_golden, make_batches, script_args, train_script
+
+    _, meta = load_golden(f"model_{cfg}.npz")
+    S = train_script()
+    torch.manual_seed(0)
+    net = build_net(meta, "cuda").train()
+    crit, _ = S.setup_losses(script_args(meta["flags"]), net)
+    batches = make_batches(meta, "cuda")
+    inputs = torch.concat([b["image"] for b in batches], dim=0)
+    ids = torch.concat([b["coord_convention_id"] for b in batches], dim=0)
+    with torch.no_grad():
+        preds0 = net(inputs, ids)
+
+    def run(batching):
+        monkeypatch.setattr(_hipops, "_BATCHING", batching)
+        preds = {k: (type(v)(v.value.detach().clone().requires_grad_(True)) if hasattr(v, "value") else v.detach().clone().requires_grad_(True))
+                 for k, v in preds0.items()}
+        leaves = {k: (v.value if hasattr(v, "value") else v) for k, v in preds.items()}
+        launches = []
+        orig = _hipops._hip.lib().call
+        monkeypatch.setattr(_hipops._hip.lib(), "call", lambda name, *a: (launches.append(name), orig(name, *a))[1])
+        loss, vals = train.default_compute_loss(preds, batches, 150, crit)
+        loss.backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(_hipops._hip.lib(), "call", orig)
+        by_name = train.concatenated_lossvals_by_name(itertools.chain.from_iterable(vals))
+        return loss.detach(), {k: v[0] for k, v in by_name.items()}, {k: t.grad for k, t in leaves.items()}, launches
+
+    la, va, ga, na = run(True)
+    lb, vb, gb, nb = run(False)
+    assert na.count("ttk_loss_batch") == 2 and not [n for n in na if n.startswith("ttk_loss_") and n != "ttk_loss_batch" and n in _hipops._hip.LOSS_BATCH_OPS]
+    assert "ttk_loss_batch" not in nb and len([n for n in nb if n.startswith("ttk_loss_")]) >= 10
+    assert torch.equal(la, lb)
+    assert va.keys() == vb.keys() and all(torch.equal(va[k], vb[k]) for k in va)
+    for k in ga:
+        assert (ga[k] is None) == (gb[k] is None), k
+        if ga[k] is not None:
+            torch.testing.assert_close(ga[k], gb[k], rtol=1e-6, atol=1e-9, msg=k)
