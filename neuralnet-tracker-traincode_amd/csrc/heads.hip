@@ -216,11 +216,15 @@ __global__ void __launch_bounds__(kBlock) heads_bwd_sample_k(HeadsArgs a, const 
   }
 }
 
-// dfeat[b][f] = sum_j dz[b][j] * W[j][f]
+// dfeat[b][f] = sum_j dz[b][j] * W[j][f]; the same threads zero dW / db for the weight kernel that follows (it adds atomically:
+// two fill launches less)
 __global__ void __launch_bounds__(kBlock) heads_bwd_feat_k(const float* __restrict__ dz, const float* __restrict__ wcat,
-                                                            float* __restrict__ dfeat, int B, int F, int NZ) {
+                                                            float* __restrict__ dfeat, float* __restrict__ dw_zero, float* __restrict__ db_zero,
+                                                            int B, int F, int NZ) {
   const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int fq = F >> 2;
+  if (idx < (int64_t)NZ * fq) st4(dw_zero + 4 * idx, f4(0.f));
+  if (idx < NZ) db_zero[idx] = 0.f;
   if (idx >= (int64_t)B * fq) return;
   const int b = (int)(idx / fq), f = (int)(idx % fq) * 4;
   float4 acc = f4(0.f);
@@ -268,11 +272,6 @@ __global__ void __launch_bounds__(kBlock) heads_bwd_offset_k(const float* __rest
   }
   float* out = mod ? dPk : dP;
   if (threadIdx.x == 0 && out) out[4 * r + c] = red[0];
-}
-
-__global__ void fill_zero_k(float* p, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = 0.f;
 }
 
 // DiagonalScaleParameter (negloglikelihood.py:50-65): out_i = elu1(h0)*elu1(h_{1+i}) + 1e-6
@@ -344,9 +343,8 @@ int ttk_heads_bwd(const float* feat, const float* wcat, const float* z, const in
   HeadsGradIn g{g_roi, g_coord, g_rot, g_qu, g_Lc, g_Lr, g_pts, g_shp};
   hipLaunchKernelGGL(heads_bwd_sample_k, dim3((B + 3) / 4), dim3(kBlock), 0, st, a, z, g, dz, dprow);
   const int64_t nf = (int64_t)B * (F / 4), nw = (int64_t)NZ * (F / 4);
-  hipLaunchKernelGGL(heads_bwd_feat_k, dim3((unsigned)ceil_div(nf, kBlock)), dim3(kBlock), 0, st, dz, wcat, dfeat, B, F, NZ);
-  hipLaunchKernelGGL(fill_zero_k, dim3((unsigned)ceil_div((int64_t)NZ * F + NZ, 256)), dim3(256), 0, st, dwcat, (int64_t)NZ * F);
-  hipLaunchKernelGGL(fill_zero_k, dim3(1), dim3(256), 0, st, dbcat, (int64_t)NZ);
+  hipLaunchKernelGGL(heads_bwd_feat_k, dim3((unsigned)ceil_div(nf > nw ? nf : nw, kBlock)), dim3(kBlock), 0, st, dz, wcat, dfeat, dwcat, dbcat, B, F,
+                     NZ);
   // TTK_DETERMINISTIC=1: one chunk of samples per weight instead of B/64 chunks that add atomically (fixed summation order)
   static const bool det = [] { const char* e = getenv("TTK_DETERMINISTIC"); return e && e[0] != '0'; }();
   hipLaunchKernelGGL(heads_bwd_weight_k, dim3((unsigned)ceil_div(nw, kBlock), det ? 1u : (unsigned)ceil_div(B, 64)), dim3(kBlock), 0, st, dz,
