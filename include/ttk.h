@@ -98,7 +98,7 @@ int ttk_partial_rows_gemm(int64_t M);                 /* pointwise (MFMA) kernel
  * running_var receives the UNBIASED batch variance, normalisation uses the biased one;
  * num_batches_tracked (int64 scalar on the device, may be NULL) is incremented.
  * ------------------------------------------------------------------------------------------- */
-/* `part` is scratch: when part_rows > 1024 the finalize kernels first fold it IN PLACE to 1024 rows.
+/* `part` is scratch: when part_rows > 1280 the finalize kernels first fold it IN PLACE to 1024 rows.
  * Writes rows SCALE, BETA, MEAN, RSTD of bn and raises bn[TTK_BN_AUX][TTK_AUX_ACT_BOUND]. */
 int ttk_bn_fwd_finalize(float* part, int part_rows, int C, int64_t count,
                         const float* gamma, const float* beta,
