@@ -40,8 +40,7 @@ __global__ void __launch_bounds__(kBlock) avgpool_bwd_k(const float* __restrict_
   float4 s1 = f4(0.f), s2 = f4(0.f);
   float gmx = 0.f;  // max |g| (ttk.h, TTK_AUX_GMAX)
   for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * kBlock) {
-    const int64_t pix = idx >> qshift;
-    const int n = (int)(pix / HW);
+    const int n = (int)((unsigned)(idx >> qshift) / (unsigned)HW);  // 32-bit division (the host checks that B * HW fits)
     const size_t off = (size_t)idx << 2;
     const float4 yv = Act<T>::ld(y + off);
     const float4 a = skip ? bn.act(yv, Act<T>::ld(skip + off)) : bn.act(yv);
@@ -87,6 +86,7 @@ int ttk_avgpool_bwd(const float* gfeat, const void* y, float* bn, const void* sk
                     float* part, int B, int HW, int C, int act_bf16, ttk_stream_t stream) {
   TTK_REQUIRE(gfeat && y && bn && g, "avgpool_bwd: null pointer");
   TTK_REQUIRE(B > 0 && HW > 0 && C >= 32 && C <= 1024 && (C & (C - 1)) == 0, "avgpool_bwd: unsupported shape");
+  TTK_REQUIRE((int64_t)B * HW < (int64_t)1 << 31, "avgpool_bwd: too many pixels for 32-bit indexing");
   const int qs = log2i_(C / 4);
   const int64_t items = ((int64_t)B * HW) << qs;
   TTK_ACT_DISPATCH(act_bf16, hipLaunchKernelGGL((avgpool_bwd_k<ActT, GradT>), dim3(elementwise_grid(items)), dim3(kBlock), 2 * (size_t)C * sizeof(float),
