@@ -171,6 +171,8 @@ __global__ void __launch_bounds__(kBlock) stem_fwd_mfma_k(const float* __restric
                                                            T* __restrict__ y, float* __restrict__ part, int B, int H,
                                                            int W, int Ho, int Wo) {
   __shared__ float red[kBlock / kWave][2 * kStemC];
+  constexpr int kTileLd = 36;  // floats per pixel row of the transposition tile (16-byte aligned rows, conflict-free b128 reads)
+  __shared__ __attribute__((aligned(16))) float tile[kBlock / kWave][32 * kTileLd];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, hk = lane >> 5;
   float bw[13];  // B fragments: w[c = r][tap = 2j + hk]
 #pragma unroll
@@ -178,26 +180,65 @@ __global__ void __launch_bounds__(kBlock) stem_fwd_mfma_k(const float* __restric
   float s1 = 0.f, s2 = 0.f;  // column r, rows of this lane's half
   const int64_t P = (int64_t)B * Ho * Wo, tiles = (P + 31) / 32;
   const int HoWo = Ho * Wo;
-  for (int64_t t = (int64_t)blockIdx.x * (kBlock / kWave) + wv; t < tiles; t += (int64_t)gridDim.x * (kBlock / kWave)) {
+  // the patch of the NEXT tile is requested before this tile's MFMAs and stores (a wave had nothing in flight while it
+  // multiplied and wrote; four waves per SIMD do not cover a dependent chain of gather -> 13 MFMAs -> transpose -> store).
+  // 105 -> 99 us at B = 512 with the 16-byte stores below.  Timing-only builds: without the patch loads 62 us, without the
+  // stores 82, without the MFMAs 90 - the 13 strided dword gathers per lane are what is left to remove (an LDS-staged input
+  // band as in the weight gradient).
+  const int64_t tstep = (int64_t)gridDim.x * (kBlock / kWave);
+  float an[13];
+  auto load_patch = [&](int64_t t) {
     const int64_t px = t * 32 + r;
     const bool ok = px < P;
-    const int n = (int)(px / HoWo), rem = (int)(px - (int64_t)n * HoWo), ho = rem / Wo, wo = rem - ho * Wo;
+    const unsigned pxu = ok ? (unsigned)px : 0u;  // (B * Ho * Wo < 2^31: checked by the host)
+    const int n = (int)(pxu / (unsigned)HoWo), rem = (int)(pxu - (unsigned)n * (unsigned)HoWo), ho = rem / Wo, wo = rem - ho * Wo;
+#pragma unroll
+    for (int j = 0; j < 13; ++j) an[j] = stem_patch(x, n, ho, wo, 2 * j + hk, H, W, ok);
+  };
+  const int64_t t0 = (int64_t)blockIdx.x * (kBlock / kWave) + wv;
+  if (t0 < tiles) load_patch(t0);
+  for (int64_t t = t0; t < tiles; t += tstep) {
     float a[13];
 #pragma unroll
-    for (int j = 0; j < 13; ++j) a[j] = stem_patch(x, n, ho, wo, 2 * j + hk, H, W, ok);
+    for (int j = 0; j < 13; ++j) a[j] = an[j];
+    if (t + tstep < tiles) load_patch(t + tstep);
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
     for (int j = 0; j < 13; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bw[j], acc, 0, 0, 0);
-    T* yt = y + (size_t)t * 32 * kStemC + r;  // column r of the tile's 32 pixels
+    if constexpr (!Act<T>::kBf16) {
+      // fp32 storage: the tile goes through a wave-private LDS transpose and leaves as four 16-byte stores per lane (1 KB
+      // contiguous per instruction) instead of sixteen 4-byte stores
+      float* tw = &tile[wv][0];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = (e & 3) + 8 * (e >> 2) + 4 * hk;
-      if (t * 32 + row < P) {
-        const float v = Act<T>::st1(yt + (size_t)row * kStemC, acc[e]);  // 32 lanes = one pixel (128 bytes of fp32); statistics of the stored value
-        s1 += v;
-        s2 = fmaf(v, v, s2);
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * hk;
+        tw[row * kTileLd + r] = acc[e];
+        if (t * 32 + row < P) {
+          s1 += acc[e];
+          s2 = fmaf(acc[e], acc[e], s2);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // wave-private: LDS executes a wave's accesses in order
+      float* yt4 = reinterpret_cast<float*>(y) + (size_t)t * 32 * kStemC;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = lane + 64 * i, px_ = q >> 3, c4 = q & 7;
+        const float4 v = ld4(tw + px_ * kTileLd + 4 * c4);
+        if (t * 32 + px_ < P) st4(yt4 + (size_t)q * 4, v);
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      T* yt = y + (size_t)t * 32 * kStemC + r;  // column r of the tile's 32 pixels
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * hk;
+        if (t * 32 + row < P) {
+          const float v = Act<T>::st1(yt + (size_t)row * kStemC, acc[e]);  // 32 lanes = one pixel; statistics of the stored value
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+        }
       }
     }
   }
@@ -328,6 +369,7 @@ int ttk_stem_fwd(const float* x, const float* w, void* y, float* part, int B, in
   const int64_t items = (int64_t)B * Ho * Wo * kStemQuads;  // sizes the partial rows (ttk_partial_rows_elementwise)
   static const bool scalar = [] { const char* e = getenv("TTK_STEM"); return e && strcmp(e, "scalar") == 0; }();
   TTK_REQUIRE(!(scalar && act_bf16), "stem_fwd: TTK_STEM=scalar has no bf16-storage form");
+  TTK_REQUIRE((int64_t)B * Ho * Wo < (int64_t)1 << 31, "stem_fwd: too many output pixels for 32-bit indexing");
   if (scalar)  // TTK_STEM=scalar: the VALU kernels (A/B timing)
     hipLaunchKernelGGL(stem_fwd_k, dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, x, w, (float*)y, part, B, H, W, Ho, Wo);
   else
