@@ -13,6 +13,12 @@
 // the fused depthwise weight gradient accumulate in registers across tiles and leave the block once
 // (one partial row + 288 float atomics per workgroup).
 #include "ttk_common.h"
+#ifndef TTK_DW_FWD_U
+#define TTK_DW_FWD_U 6
+#endif
+#ifndef TTK_DW_FWD_U2
+#define TTK_DW_FWD_U2 6
+#endif
 
 namespace ttk {
 
@@ -21,7 +27,10 @@ constexpr int kSlabQuads = kSlab / 4;
 constexpr int kPixSlots = kBlock / kSlabQuads;  // 32 pixels in flight per pass
 constexpr int kLdsPixBudget = 368;   // (rows) x (W+2) pixels of 128 B each: <= 47 KB -> 3 workgroups per CU (560 -> 2 per CU measured slower)
 constexpr int kMaxDwBlocks = 768;   // 3 workgroups per CU x 256 CUs: one resident wave of persistent workgroups
-constexpr int kFwdU = 4;             // staging elements per thread and iteration (forward)
+// staging elements per thread and iteration (forward): their loads are in flight together, and the bytes in flight per CU are
+// what these kernels' throughput follows.  Six fit the 168-register budget of three workgroups per CU when the layer has no
+// residual input to load beside them (the largest layers), four otherwise.
+constexpr int kFwdUSkip = 4, kFwdUPlain = TTK_DW_FWD_U, kFwdUPlain2 = TTK_DW_FWD_U2;
 
 struct DwTiling {
   int R, nbands, nslabs, grid, rows;  // rows = partial rows = grid / nslabs
@@ -150,7 +159,7 @@ __device__ __forceinline__ void slab_partials(D4 s1, D4 s2, int q, int C, int c_
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-template <int S, typename T>
+template <int S, typename T, bool SKIP>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3)))
 dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
                                                           const T* __restrict__ skip_prev, T* __restrict__ a_out,
@@ -179,8 +188,9 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
     // elements per thread and iteration so that their loads are in flight together (the staging phase is where this
     // kernel touches HBM).
     const int nstage = nimg * (int)PI * kSlabQuads;
+    constexpr int kFwdU = SKIP ? kFwdUSkip : (S == 2 ? kFwdUPlain2 : kFwdUPlain);
     for (int e = tid; e < nstage; e += kFwdU * kBlock) {
-      float4 yv[kFwdU], sk[kFwdU];
+      float4 yv[kFwdU], sk[SKIP ? kFwdU : 1];
       size_t off[kFwdU];
       bool in[kFwdU];
       int pxs[kFwdU], rows[kFwdU];
@@ -195,7 +205,7 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
         in[u] = ee < nstage && row >= 0 && row < H && col >= 0 && col < W;
         off[u] = in[u] ? (((size_t)(n0 + img) * H + row) * W + col) * C + slab * kSlab + 4 * q : 0;  // qq == q: kBlock is a multiple of 8
         yv[u] = in[u] ? Act<T>::ldnt(yprev + off[u]) : f4(0.f);
-        sk[u] = (in[u] && skip_prev) ? Act<T>::ldnt(skip_prev + off[u]) : f4(0.f);
+        if constexpr (SKIP) sk[u] = in[u] ? Act<T>::ldnt(skip_prev + off[u]) : f4(0.f);
       }
 #pragma unroll
       for (int u = 0; u < kFwdU; ++u) {
@@ -203,7 +213,8 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
         if (ee >= nstage) break;
         float4 a = f4(0.f);
         if (in[u]) {
-          a = skip_prev ? bn.act(yv[u], sk[u]) : bn.act(yv[u]);
+          if constexpr (SKIP) a = bn.act(yv[u], sk[u]);
+          else a = bn.act(yv[u]);
           if (S == 1 && a_out) a = Act<T>::round(a);  // a materialised block input is used as it is stored (residual, backward)
           if (S == 1 && a_out && rows[u]) Act<T>::st(a_out + off[u], a);
         }
@@ -415,10 +426,11 @@ int ttk_dwconv3x3_fwd(const void* yprev, const float* bn_prev, const void* skip_
   const DwTiling t = dw_tiling(B, H, W, C, stride, false);
   const size_t stage = (size_t)t.NI * t.stage_rows * ((t.NCT > 1 ? t.TW : W) + 2) * kSlab;
   const size_t sm = (stage + 16 * kSlab) * sizeof(float);  // + [4][2][32] doubles of reduction scratch
-#define TTK_DW_FWD(S_)                                                                                                        \
-  hipLaunchKernelGGL((dw_fwd_tiled_k<S_, ActT>), dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, (const ActT*)yprev, bn_prev, \
+#define TTK_DW_FWD(S_, SK_)                                                                                                        \
+  hipLaunchKernelGGL((dw_fwd_tiled_k<S_, ActT, SK_>), dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, (const ActT*)yprev, bn_prev, \
                      (const ActT*)skip_prev, (ActT*)a_out, w, (ActT*)y, part, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI, t.NCT, t.TW)
-  TTK_ACT_DISPATCH(act_bf16, if (stride == 1) TTK_DW_FWD(1); else TTK_DW_FWD(2));
+  TTK_ACT_DISPATCH(act_bf16, if (stride == 1) { if (skip_prev) TTK_DW_FWD(1, true); else TTK_DW_FWD(1, false); }
+                             else { if (skip_prev) TTK_DW_FWD(2, true); else TTK_DW_FWD(2, false); });
 #undef TTK_DW_FWD
   TTK_LAUNCH_CHECK("dwconv3x3_fwd");
 }
