@@ -22,7 +22,7 @@
 
 namespace ttk {
 
-constexpr int kSlab = 32;            // channels per tile
+constexpr int kSlab = 32;            // channels per tile (the kernels shift by 5 where they index LDS pixels)
 constexpr int kSlabQuads = kSlab / 4;
 constexpr int kPixSlots = kBlock / kSlabQuads;  // 32 pixels in flight per pass
 constexpr int kLdsPixBudget = 368;   // (rows) x (W+2) pixels of 128 B each: <= 47 KB -> 3 workgroups per CU (560 -> 2 per CU measured slower)
@@ -85,6 +85,17 @@ inline DwTiling dw_tiling(int B, int H, int W, int C, int stride, bool backward)
   t.grid = t.rows * t.nslabs;
   return t;
 }
+
+// n / d for the tile-local pixel indices (0 <= n < 2^20, 1 <= d < 2^12) in four VALU operations: (n + 0.5) / d is at least 0.5 / d
+// away from every integer and the float product is off by less than 2^-22 of its value, so the truncation is exact.  The
+// integer divisions these replace (~30 operations each, two to six per staged or produced pixel) made the kernels of the large
+// layers VALU-bound: timing-only builds without loads, without stores or with one tap all ran within 7 % of the full kernel.
+struct TileDiv {
+  float inv;
+  unsigned d;
+  __device__ __forceinline__ explicit TileDiv(unsigned d_) : inv(1.0f / (float)d_), d(d_) {}
+  __device__ __forceinline__ unsigned div(unsigned n) const { return (unsigned)(((float)n + 0.5f) * inv); }
+};
 
 struct SlabWeights {  // w[c][tap] of 4 consecutive channels
   float v[36];
@@ -169,13 +180,15 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [NI][stage_rows][tile width + 2][32] + reduction scratch
   const int tid = threadIdx.x, q = tid & (kSlabQuads - 1), slot = tid >> 3;
   const int slab = blockIdx.x % nslabs, c0 = slab * kSlab + 4 * q;
+  const int cshift = __builtin_ctz((unsigned)C);  // C is a power of two
   SlabWeights wr;
   wr.load(w, c0);
   const BnApply4 bn = BnApply4::load(bn_prev, C, c0);
   D4 s1{0.0, 0.0, 0.0, 0.0}, s2{0.0, 0.0, 0.0, 0.0};
-  const int64_t tiles = (int64_t)((B + NI - 1) / NI) * nbands * NCT;
-  for (int64_t t = blockIdx.x / nslabs; t < tiles; t += gridDim.x / nslabs) {
-    const int ct = (int)(t % NCT), band = (int)((t / NCT) % nbands), n0 = (int)(t / ((int64_t)NCT * nbands)) * NI;  // NI > 1 implies one tile per image
+  const unsigned tiles = (unsigned)((B + NI - 1) / NI) * nbands * NCT;  // (< 2^31: checked by the host)
+  for (unsigned t = blockIdx.x / nslabs; t < tiles; t += gridDim.x / nslabs) {
+    const unsigned tb = t / (unsigned)NCT, ti = tb / (unsigned)nbands;
+    const int ct = (int)(t - tb * NCT), band = (int)(tb - ti * nbands), n0 = (int)ti * NI;  // NI > 1 implies one tile per image
     const int nimg = min(NI, B - n0);
     const int cx0 = ct * TW, tw = NCT > 1 ? min(TW, Wo - cx0) : Wo;  // output columns [cx0, cx0 + tw) (column tiles: stride 1)
     const int Wp = NCT > 1 ? tw + 2 : W + 2;                          // staged input columns cx0-1 .. cx0+tw (or -1 .. W)
@@ -183,6 +196,16 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
     const int i0 = o0 * S - 1;                     // first staged input row (may be -1)
     const int nrows = (o1 - 1 - o0) * S + 3;
     const unsigned PI = (unsigned)(nrows * Wp);    // staged pixels per image
+    const TileDiv dPI(PI), dWp((unsigned)Wp), dtw((unsigned)tw);
+    // Addresses: one 64-bit base per tile and tensor, 32-bit element offsets formed with 24-bit multiplies (v_mul_u32_u24 is a
+    // full-rate instruction; the 32-bit / 64-bit integer multiplies of the size_t form run at a quarter of that rate, and at
+    // ten per staged element they were a third of these VALU-bound kernels' issue slots)
+    // (the bases are uniform over the workgroup - scalar registers; the lane's channel quad rides in the 32-bit offset)
+    const size_t tin = (size_t)n0 * H * W * C + slab * kSlab, tout = (size_t)n0 * Ho * Wo * C + slab * kSlab;
+    const T* ytile = yprev + tin;
+    const T* sktile = SKIP ? skip_prev + tin : nullptr;
+    T* aotile = a_out ? a_out + tin : nullptr;
+    T* youttile = y + tout;
     __syncthreads();  // previous tile's readers are done
     // ---- stage: a_in rows i0 .. i0+nrows-1, columns -1 .. W (zero outside the image) of nimg images.  Several
     // elements per thread and iteration so that their loads are in flight together (the staging phase is where this
@@ -191,21 +214,22 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
     constexpr int kFwdU = SKIP ? kFwdUSkip : (S == 2 ? kFwdUPlain2 : kFwdUPlain);
     for (int e = tid; e < nstage; e += kFwdU * kBlock) {
       float4 yv[kFwdU], sk[SKIP ? kFwdU : 1];
-      size_t off[kFwdU];
+      unsigned off[kFwdU];
       bool in[kFwdU];
       int pxs[kFwdU], rows[kFwdU];
 #pragma unroll
       for (int u = 0; u < kFwdU; ++u) {
         const int ee = e + u * kBlock;
         const unsigned pxa = (unsigned)ee >> 3;              // pixel slot in LDS over all images of the tile
-        const unsigned img = NI > 1 ? pxa / PI : 0u, px = NI > 1 ? pxa - img * PI : pxa;
-        const int col = (int)(px % (unsigned)Wp) - 1 + cx0, row = i0 + (int)(px / (unsigned)Wp);
+        const unsigned img = NI > 1 ? dPI.div(pxa) : 0u, px = NI > 1 ? pxa - __umul24(img, PI) : pxa;
+        const unsigned prow = dWp.div(px);
+        const int col = (int)(px - __umul24(prow, (unsigned)Wp)) - 1 + cx0, row = i0 + (int)prow;
         pxs[u] = (int)pxa;
         rows[u] = (row >= o0 && row < o1 && col >= cx0 && col < cx0 + tw) ? 1 : 0;  // the one tile this input pixel belongs to
         in[u] = ee < nstage && row >= 0 && row < H && col >= 0 && col < W;
-        off[u] = in[u] ? (((size_t)(n0 + img) * H + row) * W + col) * C + slab * kSlab + 4 * q : 0;  // qq == q: kBlock is a multiple of 8
-        yv[u] = in[u] ? Act<T>::ldnt(yprev + off[u]) : f4(0.f);
-        if constexpr (SKIP) sk[u] = in[u] ? Act<T>::ldnt(skip_prev + off[u]) : f4(0.f);
+        off[u] = in[u] ? ((__umul24(__umul24(img, (unsigned)H) + (unsigned)row, (unsigned)W) + (unsigned)col) << cshift) + 4 * q : 0u;  // qq == q: kBlock is a multiple of 8
+        yv[u] = in[u] ? Act<T>::ldnt(ytile + off[u]) : f4(0.f);
+        if constexpr (SKIP) sk[u] = in[u] ? Act<T>::ldnt(sktile + off[u]) : f4(0.f);
       }
 #pragma unroll
       for (int u = 0; u < kFwdU; ++u) {
@@ -216,7 +240,7 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
           if constexpr (SKIP) a = bn.act(yv[u], sk[u]);
           else a = bn.act(yv[u]);
           if (S == 1 && a_out) a = Act<T>::round(a);  // a materialised block input is used as it is stored (residual, backward)
-          if (S == 1 && a_out && rows[u]) Act<T>::st(a_out + off[u], a);
+          if (S == 1 && a_out && rows[u]) Act<T>::st(aotile + off[u], a);
         }
         st4(lds + (size_t)pxs[u] * kSlab + 4 * q, a);
       }
@@ -225,18 +249,19 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
     // ---- stencil
     const unsigned npix1 = (unsigned)((o1 - o0) * tw);  // output pixels per image
     const int npix = nimg * (int)npix1;
+    const TileDiv dnp(npix1);
     for (int p = slot; p < npix; p += kPixSlots) {
-      const unsigned img = NI > 1 ? (unsigned)p / npix1 : 0u, pp = NI > 1 ? (unsigned)p - img * npix1 : (unsigned)p;
-      const int n = n0 + (int)img;
-      const int ho = o0 + (int)(pp / (unsigned)tw), wl = (int)(pp % (unsigned)tw), wo = cx0 + wl;
-      const float* base = lds + ((size_t)img * PI + (size_t)((ho - o0) * S) * Wp + wl * S) * kSlab + 4 * q;  // tap (0,0): row ho*S-1, col wo*S-1
+      const unsigned img = NI > 1 ? dnp.div((unsigned)p) : 0u, pp = NI > 1 ? (unsigned)p - __umul24(img, npix1) : (unsigned)p;
+      const unsigned prow = dtw.div(pp);
+      const int ho = o0 + (int)prow, wl = (int)(pp - __umul24(prow, (unsigned)tw)), wo = cx0 + wl;
+      const float* base = lds + ((__umul24(img, PI) + __umul24(prow * S, (unsigned)Wp) + (unsigned)(wl * S)) << 5) + 4 * q;  // tap (0,0): row ho*S-1, col wo*S-1
       float4 acc = f4(0.f);
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) acc = fma4(ld4(base + ((size_t)kh * Wp + kw) * kSlab), wr.tap(kh * 3 + kw), acc);
       acc = Act<T>::round(acc);  // statistics of what is stored
-      Act<T>::st(y + (((size_t)n * Ho + ho) * Wo + wo) * C + c0, acc);
+      Act<T>::st(youttile + ((__umul24(__umul24(img, (unsigned)Ho) + (unsigned)ho, (unsigned)Wo) + (unsigned)wo) << cshift) + 4 * q, acc);
       s1.add(acc);
       s2.addmul(acc, acc);
     }
@@ -271,6 +296,7 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
     for (int t = 0; t < 9; ++t)
       st4(wt + t * kSlab + 4 * q, make_float4(w[(size_t)(c0 + 0) * 9 + t], w[(size_t)(c0 + 1) * 9 + t], w[(size_t)(c0 + 2) * 9 + t], w[(size_t)(c0 + 3) * 9 + t]));
   }
+  const int cshift = __builtin_ctz((unsigned)C);  // C is a power of two
   const BnApply4 bnp = BnApply4::load(bn_prev, C, c0);
   const BnGrad4 bg = BnGrad4::load(bn_dw, C, c0);
   D4 s1{0.0, 0.0, 0.0, 0.0}, s2{0.0, 0.0, 0.0, 0.0};
@@ -278,9 +304,10 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
   float4 wacc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wacc[t] = f4(0.f);
-  const int64_t tiles = (int64_t)((B + NI - 1) / NI) * nbands * NCT;
-  for (int64_t t = blockIdx.x / nslabs; t < tiles; t += gridDim.x / nslabs) {
-    const int ct = (int)(t % NCT), band = (int)((t / NCT) % nbands), n0 = (int)(t / ((int64_t)NCT * nbands)) * NI;  // NI > 1 implies one tile per image
+  const unsigned tiles = (unsigned)((B + NI - 1) / NI) * nbands * NCT;  // (< 2^31: checked by the host)
+  for (unsigned t = blockIdx.x / nslabs; t < tiles; t += gridDim.x / nslabs) {
+    const unsigned tb = t / (unsigned)NCT, ti = tb / (unsigned)nbands;
+    const int ct = (int)(t - tb * NCT), band = (int)(tb - ti * nbands), n0 = (int)ti * NI;  // NI > 1 implies one tile per image
     const int nimg = min(NI, B - n0);
     const int cx0 = ct * TW, tw = NCT > 1 ? min(TW, W - cx0) : W;  // input columns [cx0, cx0 + tw) (column tiles: stride 1)
     const int Wp = NCT > 1 ? tw + 2 : Wo + 2;                       // staged dy columns cx0-1 .. cx0+tw (or -1 .. Wo)
@@ -290,6 +317,16 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
     const int ho_hi = min(Ho - 1, r1 / S);
     const int nrows = ho_hi - ho_lo + 1;
     const unsigned PI = (unsigned)(nrows * Wp);  // staged pixels per image
+    const TileDiv dPI(PI), dWp((unsigned)Wp), dtw((unsigned)tw);
+    // one 64-bit base per tile and tensor, 32-bit element offsets from 24-bit multiplies (see the forward kernel)
+    const size_t tdy = (size_t)n0 * Ho * Wo * C + slab * kSlab, tin = (size_t)n0 * H * W * C + slab * kSlab;  // uniform: scalar registers
+    const TG* gtile = g_dw + tdy;
+    const T* ydtile = y_dw + tdy;
+    const T* yptile = yprev + tin;
+    const T* aitile = a_in ? a_in + tin : nullptr;
+    const T* sktile = skip_prev ? skip_prev + tin : nullptr;
+    const TG* sgtile = skip_grad ? skip_grad + tin : nullptr;
+    TG* gptile = g_prev + tin;
     __syncthreads();
     // ---- stage dy rows ho_lo..ho_hi, columns -1..Wo (zeros outside) of nimg images; two elements per thread and
     // iteration (four loads in flight)
@@ -301,12 +338,13 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
       for (int u = 0; u < 2; ++u) {
         const int ee = e + u * kBlock;
         const unsigned pxa = (unsigned)ee >> 3;
-        const unsigned img = NI > 1 ? pxa / PI : 0u, px = NI > 1 ? pxa - img * PI : pxa;
-        const int col = (int)(px % (unsigned)Wp) - 1 + cx0, row = ho_lo + (int)(px / (unsigned)Wp);
+        const unsigned img = NI > 1 ? dPI.div(pxa) : 0u, px = NI > 1 ? pxa - __umul24(img, PI) : pxa;
+        const unsigned prow = dWp.div(px);
+        const int col = (int)(px - __umul24(prow, (unsigned)Wp)) - 1 + cx0, row = ho_lo + (int)prow;
         in[u] = ee < nstage && col >= 0 && col < Wo;
-        const size_t off = in[u] ? (((size_t)(n0 + img) * Ho + row) * Wo + col) * C + slab * kSlab + 4 * q : 0;  // qq == q (see forward)
-        gv[u] = in[u] ? Act<TG>::ldnt(g_dw + off) : f4(0.f);
-        yv[u] = in[u] ? Act<T>::ldnt(y_dw + off) : f4(0.f);
+        const unsigned off = in[u] ? ((__umul24(__umul24(img, (unsigned)Ho) + (unsigned)row, (unsigned)Wo) + (unsigned)col) << cshift) + 4 * q : 0u;  // qq == q (see forward)
+        gv[u] = in[u] ? Act<TG>::ldnt(gtile + off) : f4(0.f);
+        yv[u] = in[u] ? Act<T>::ldnt(ydtile + off) : f4(0.f);
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -318,28 +356,30 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
     __syncthreads();
     const unsigned npix1 = (unsigned)((r1 - r0) * tw);  // input pixels per image
     const int npix = nimg * (int)npix1;
+    const TileDiv dnp(npix1);
     // two pixels per thread and iteration: their (up to six) global loads are issued back to back before either
     // pixel's LDS taps are read
     for (int p = slot; p < npix; p += 2 * kPixSlots) {
       const int pb = p + kPixSlots;
       const bool hasb = pb < npix;
-      const unsigned imgA = NI > 1 ? (unsigned)p / npix1 : 0u, ppA = NI > 1 ? (unsigned)p - imgA * npix1 : (unsigned)p;
-      const unsigned imgB = (NI > 1 && hasb) ? (unsigned)pb / npix1 : imgA;
-      const unsigned ppB = hasb ? ((NI > 1) ? (unsigned)pb - imgB * npix1 : (unsigned)pb) : ppA;
-      const int hiA = r0 + (int)(ppA / (unsigned)tw), wiA = cx0 + (int)(ppA % (unsigned)tw);
-      const int hiB = r0 + (int)(ppB / (unsigned)tw), wiB = cx0 + (int)(ppB % (unsigned)tw);
-      const size_t offA = (((size_t)(n0 + imgA) * H + hiA) * W + wiA) * C + c0;
-      const size_t offB = (((size_t)(n0 + imgB) * H + hiB) * W + wiB) * C + c0;
-      const float4 ypA = Act<T>::ldnt(yprev + offA), ypB = Act<T>::ldnt(yprev + offB);
+      const unsigned imgA = NI > 1 ? dnp.div((unsigned)p) : 0u, ppA = NI > 1 ? (unsigned)p - __umul24(imgA, npix1) : (unsigned)p;
+      const unsigned imgB = (NI > 1 && hasb) ? dnp.div((unsigned)pb) : imgA;
+      const unsigned ppB = hasb ? ((NI > 1) ? (unsigned)pb - __umul24(imgB, npix1) : (unsigned)pb) : ppA;
+      const unsigned prA = dtw.div(ppA), prB = dtw.div(ppB);
+      const int hiA = r0 + (int)prA, wiA = cx0 + (int)(ppA - __umul24(prA, (unsigned)tw));
+      const int hiB = r0 + (int)prB, wiB = cx0 + (int)(ppB - __umul24(prB, (unsigned)tw));
+      const unsigned offA = ((__umul24(__umul24(imgA, (unsigned)H) + (unsigned)hiA, (unsigned)W) + (unsigned)wiA) << cshift) + 4 * q;
+      const unsigned offB = ((__umul24(__umul24(imgB, (unsigned)H) + (unsigned)hiB, (unsigned)W) + (unsigned)wiB) << cshift) + 4 * q;
+      const float4 ypA = Act<T>::ldnt(yptile + offA), ypB = Act<T>::ldnt(yptile + offB);
       float4 rawA = f4(0.f), rawB = f4(0.f), sgA = f4(0.f), sgB = f4(0.f);
-      if (a_in) { rawA = Act<T>::ldnt(a_in + offA); rawB = Act<T>::ldnt(a_in + offB); }
-      else if (skip_prev) { rawA = Act<T>::ldnt(skip_prev + offA); rawB = Act<T>::ldnt(skip_prev + offB); }
-      if (skip_grad) { sgA = Act<TG>::ldnt(skip_grad + offA); sgB = Act<TG>::ldnt(skip_grad + offB); }
+      if (a_in) { rawA = Act<T>::ldnt(aitile + offA); rawB = Act<T>::ldnt(aitile + offB); }
+      else if (skip_prev) { rawA = Act<T>::ldnt(sktile + offA); rawB = Act<T>::ldnt(sktile + offB); }
+      if (skip_grad) { sgA = Act<TG>::ldnt(sgtile + offA); sgB = Act<TG>::ldnt(sgtile + offB); }
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         if (half == 1 && !hasb) break;
         const int hi = half ? hiB : hiA, wi = half ? wiB : wiA;
-        const float* dyimg = lds + (size_t)(half ? imgB : imgA) * PI * kSlab;
+        const float* dyimg = lds + (__umul24(half ? imgB : imgA, PI) << 5);
         const float4 yp = half ? ypB : ypA, raw = half ? rawB : rawA, sg = half ? sgB : sgA;
         float4 a;
         if (a_in) a = raw;
@@ -356,14 +396,14 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
             const int tw = wi + 1 - kw;  // -1 .. W
             if (S == 2 && (tw & 1)) continue;
             const int wo = (S == 1) ? tw : (tw >> 1);  // -1 or Wo hit the zero padding columns (S=1); always inside for S=2
-            const float4 dy = ld4(dyimg + ((size_t)(ho - ho_lo) * Wp + wo - cx0 + 1) * kSlab + 4 * q);
+            const float4 dy = ld4(dyimg + ((__mul24(ho - ho_lo, Wp) + wo - cx0 + 1) << 5) + 4 * q);
             G = fma4(dy, ld4(wt + (kh * 3 + kw) * kSlab + 4 * q), G);
             wacc[kh * 3 + kw] = fma4(dy, a, wacc[kh * 3 + kw]);
           }
         }
         if (skip_grad) G = add4(G, sg);
         const float4 gp = Act<TG>::round(mask4(G, a));  // sums and maximum of what is stored
-        Act<TG>::st(g_prev + (half ? offB : offA), gp);
+        Act<TG>::st(gptile + (half ? offB : offA), gp);
         gmx = fmaxf(fmaxf(gmx, fmaxf(fabsf(gp.x), fabsf(gp.y))), fmaxf(fabsf(gp.z), fabsf(gp.w)));
         s1.add(gp);
         s2.addmul(gp, sub4(yp, bnp.mean));
@@ -424,6 +464,7 @@ int ttk_dwconv3x3_fwd(const void* yprev, const float* bn_prev, const void* skip_
   TTK_REQUIRE(!(a_out && stride != 1), "dwconv3x3_fwd: a_out requires stride 1");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const DwTiling t = dw_tiling(B, H, W, C, stride, false);
+  TTK_REQUIRE((int64_t)((B + t.NI - 1) / t.NI) * t.nbands * t.NCT < ((int64_t)1 << 31), "dwconv3x3_fwd: too many tiles for 32-bit indexing");
   const size_t stage = (size_t)t.NI * t.stage_rows * ((t.NCT > 1 ? t.TW : W) + 2) * kSlab;
   const size_t sm = (stage + 16 * kSlab) * sizeof(float);  // + [4][2][32] doubles of reduction scratch
 #define TTK_DW_FWD(S_, SK_)                                                                                                        \
@@ -444,6 +485,7 @@ int ttk_dwconv3x3_bwd_data(const void* g_dw, const void* y_dw, const float* bn_d
   TTK_REQUIRE(!(skip_grad && stride != 1), "dwconv3x3_bwd_data: residual gradient requires stride 1");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const DwTiling t = dw_tiling(B, H, W, C, stride, true);
+  TTK_REQUIRE((int64_t)((B + t.NI - 1) / t.NI) * t.nbands * t.NCT < ((int64_t)1 << 31), "dwconv3x3_bwd_data: too many tiles for 32-bit indexing");
   const size_t stage = (size_t)t.NI * t.stage_rows * ((t.NCT > 1 ? t.TW : Wo) + 2) * kSlab;
   const size_t sm = (stage + 4 * 9 * kSlab + 9 * kSlab) * sizeof(float);  // stage + reduction scratch + filter taps
   hipStream_t st = (hipStream_t)stream;
