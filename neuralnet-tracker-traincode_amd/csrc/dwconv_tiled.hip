@@ -16,6 +16,9 @@
 #ifndef TTK_DW_FWD_U
 #define TTK_DW_FWD_U 6
 #endif
+#ifndef TTK_DW_BWD_U
+#define TTK_DW_BWD_U 4
+#endif
 #ifndef TTK_DW_FWD_U2
 #define TTK_DW_FWD_U2 6
 #endif
@@ -331,11 +334,12 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
     // ---- stage dy rows ho_lo..ho_hi, columns -1..Wo (zeros outside) of nimg images; two elements per thread and
     // iteration (four loads in flight)
     const int nstage = nimg * (int)PI * kSlabQuads;
-    for (int e = tid; e < nstage; e += 2 * kBlock) {
-      float4 gv[2], yv[2];
-      bool in[2];
+    constexpr int kBwdU = TTK_DW_BWD_U;  // staged elements per thread and iteration: 2 * kBwdU loads in flight
+    for (int e = tid; e < nstage; e += kBwdU * kBlock) {
+      float4 gv[kBwdU], yv[kBwdU];
+      bool in[kBwdU];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < kBwdU; ++u) {
         const int ee = e + u * kBlock;
         const unsigned pxa = (unsigned)ee >> 3;
         const unsigned img = NI > 1 ? dPI.div(pxa) : 0u, px = NI > 1 ? pxa - __umul24(img, PI) : pxa;
@@ -347,7 +351,7 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
         yv[u] = in[u] ? Act<T>::ldnt(ydtile + off) : f4(0.f);
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < kBwdU; ++u) {
         const int ee = e + u * kBlock;
         if (ee >= nstage) break;
         st4(lds + (size_t)(ee >> 3) * kSlab + 4 * q, in[u] ? bg.dy(gv[u], yv[u]) : f4(0.f));
