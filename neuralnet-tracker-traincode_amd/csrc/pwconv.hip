@@ -34,7 +34,7 @@ enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 // T: storage of activations (y); TO: storage of this kernel's A0 operand and output - activations in the forward pass,
 // activation gradients in the data gradient
 template <int BN, int WM, int WN, int MODE, int STAGES, typename T, typename TO>
-__global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(STAGES == 1 ? 3 : 1, STAGES == 1 ? 3 : 8)))
+__global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(STAGES == 1 ? 4 : 1, STAGES == 1 ? 4 : 8)))
 pw_gemm_k(const TO* __restrict__ A0, const T* __restrict__ A1,
                                                      const float* __restrict__ bnA, const float* __restrict__ Bm,
                                                      TO* __restrict__ out, const T* __restrict__ E0,
