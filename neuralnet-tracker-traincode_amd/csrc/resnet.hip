@@ -260,7 +260,9 @@ __global__ void __launch_bounds__(kBlock) maxpool_fwd_k(const float* __restrict_
 
 // gradient w.r.t. the BatchNorm output of y (already through the ReLU mask) + that BatchNorm's backward sums.
 // ga (+ gb): gradient(s) w.r.t. the pooled activation.  thread = (input pixel, channel quad).
-__global__ void __launch_bounds__(kBlock) maxpool_bwd_k(const float* __restrict__ ga, const float* __restrict__ gb,
+// 1024 threads per workgroup: the partial rows cap this streaming gather at 1024 workgroups, and four waves each left a CU with
+// 16 waves in flight (377 -> 304 us at B = 512)
+__global__ void __launch_bounds__(1024) maxpool_bwd_k(const float* __restrict__ ga, const float* __restrict__ gb,
                                                          const unsigned char* __restrict__ idx, const float* __restrict__ y,
                                                          const float* __restrict__ bnp, float* __restrict__ g,
                                                          float* __restrict__ part, int B, int H, int W, int Ho, int Wo, int C) {
@@ -272,7 +274,7 @@ __global__ void __launch_bounds__(kBlock) maxpool_bwd_k(const float* __restrict_
   // kernel 9 % (414 -> 378 us at B = 512; two items in flight per thread on top of it: no further gain)
   const unsigned items = (unsigned)B * H * W * quads, qshift = __builtin_ctz(quads);
   float4 s1 = f4(0.f), s2 = f4(0.f);
-  for (unsigned it = blockIdx.x * kBlock + threadIdx.x; it < items; it += gridDim.x * kBlock) {
+  for (unsigned it = blockIdx.x * 1024 + threadIdx.x; it < items; it += gridDim.x * 1024) {
     const unsigned pix = it >> qshift, row = pix / (unsigned)W;
     const int wi = (int)(pix - row * (unsigned)W), n = (int)(row / (unsigned)H), hi = (int)(row - (unsigned)n * (unsigned)H);
     const float4 yv = ld4(y + (size_t)it * 4);
@@ -300,7 +302,7 @@ __global__ void __launch_bounds__(kBlock) maxpool_bwd_k(const float* __restrict_
     s1 = add4(s1, gv);
     s2 = fma4(gv, sub4(yv, bn.mean), s2);
   }
-  if (part) block_channel_partials<1024>(s1, s2, c4, C, part + (size_t)blockIdx.x * 2 * C, smem);
+  if (part) block_channel_partials<1024, 1024>(s1, s2, c4, C, part + (size_t)blockIdx.x * 2 * C, smem);
 }
 
 // a = relu(bn(y) + r), r = res (an activation) or res_bn(res) (a raw conv output, the downsample branch) or nothing
@@ -524,7 +526,10 @@ __global__ void __launch_bounds__(kBlock) bn_bwd_apply_k(const float* __restrict
 // gs = (ga (+ gb)) * [a > 0]: gradient w.r.t. s = bn(y) + r of a block whose output activation is a = relu(s).
 // part: BatchNorm-backward sums of bn(y) (sum gs, sum gs*(y-mean)); partd (with yd, bnd): the same for the
 // downsample branch's BatchNorm.
-__global__ void __launch_bounds__(kBlock) residual_bwd_k(const float* __restrict__ ga, const float* __restrict__ gb,
+// (256 threads: with 1024 - which pays in maxpool_bwd_k, one large tensor - the eight calls of a step lose 0.2 ms in total: the
+// small late layers do not fill such workgroups and pay their 16-wave reduction tail twice)
+constexpr int kEwBlock = kBlock;
+__global__ void __launch_bounds__(kEwBlock) residual_bwd_k(const float* __restrict__ ga, const float* __restrict__ gb,
                                                           const float* __restrict__ a, const float* __restrict__ y,
                                                           float* __restrict__ bnp, const float* __restrict__ yd,
                                                           float* __restrict__ bnd, float* __restrict__ gs,
@@ -537,7 +542,7 @@ __global__ void __launch_bounds__(kBlock) residual_bwd_k(const float* __restrict
   const float4 meand = yd ? ld4(bnd + TTK_BN_MEAN * C + 4 * c4) : f4(0.f);
   float4 s1 = f4(0.f), s2 = f4(0.f), t2 = f4(0.f);
   float gmx = 0.f;
-  for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * kBlock) {
+  for (int64_t idx = (int64_t)blockIdx.x * kEwBlock + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * kEwBlock) {
     const size_t off = (size_t)idx << 2;
     float4 gv = ld4(ga + off);
     if (gb) gv = add4(gv, ld4(gb + off));
@@ -551,10 +556,10 @@ __global__ void __launch_bounds__(kBlock) residual_bwd_k(const float* __restrict
   // max |gs|: the bound behind the DY_BOUND of both BatchNorms this gradient flows into (ttk.h, TTK_AUX_GMAX)
   wave_raise_max(bnp + (size_t)TTK_BN_AUX * C + TTK_AUX_GMAX, gmx);
   if (yd) wave_raise_max(bnd + (size_t)TTK_BN_AUX * C + TTK_AUX_GMAX, gmx);
-  block_channel_partials<1024>(s1, s2, c4, C, part + (size_t)blockIdx.x * 2 * C, smem);
+  block_channel_partials<1024, kEwBlock>(s1, s2, c4, C, part + (size_t)blockIdx.x * 2 * C, smem);
   if (yd) {
     __syncthreads();
-    block_channel_partials<1024>(s1, t2, c4, C, partd + (size_t)blockIdx.x * 2 * C, smem);
+    block_channel_partials<1024, kEwBlock>(s1, t2, c4, C, partd + (size_t)blockIdx.x * 2 * C, smem);
   }
 }
 
@@ -633,7 +638,7 @@ int ttk_maxpool3x3s2_bwd(const float* ga, const float* gb, const unsigned char* 
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const int64_t items = (int64_t)B * H * W * (C / 4);
   TTK_REQUIRE(items < (int64_t)1 << 31, "maxpool3x3s2_bwd: tensor too large for 32-bit indexing");
-  hipLaunchKernelGGL(maxpool_bwd_k, dim3(elementwise_grid(items)), dim3(kBlock), 2 * (size_t)C * sizeof(float), (hipStream_t)stream,
+  hipLaunchKernelGGL(maxpool_bwd_k, dim3(elementwise_grid(items)), dim3(1024), 2 * (size_t)C * sizeof(float), (hipStream_t)stream,
                      ga, gb, idx, y, bn, g, part, B, H, W, Ho, Wo, C);
   TTK_LAUNCH_CHECK("maxpool3x3s2_bwd");
 }
@@ -665,7 +670,7 @@ int ttk_residual_bwd(const float* ga, const float* gb, const float* a, const flo
   TTK_REQUIRE((yd == nullptr) == (bnd == nullptr) && (yd == nullptr) == (partd == nullptr), "residual_bwd: yd, bnd, partd go together");
   TTK_REQUIRE(ew_shape_ok(rows, C), "residual_bwd: unsupported shape");
   const int64_t items = rows * (C / 4);
-  hipLaunchKernelGGL(residual_bwd_k, dim3(elementwise_grid(items)), dim3(kBlock), 2 * (size_t)C * sizeof(float), (hipStream_t)stream,
+  hipLaunchKernelGGL(residual_bwd_k, dim3(elementwise_grid(items)), dim3(kEwBlock), 2 * (size_t)C * sizeof(float), (hipStream_t)stream,
                      ga, gb, a, y, bn, yd, bnd, gs, part, partd, items, C);
   TTK_LAUNCH_CHECK("residual_bwd");
 }

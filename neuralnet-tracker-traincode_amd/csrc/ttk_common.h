@@ -218,7 +218,7 @@ struct BnGrad4 {
 // has accumulated s1/s2 over its items.  Lanes that own the same quad are folded with wave
 // shuffles (they sit `lanes_per_item` apart), then the waves meet in LDS; the block writes ONE row
 // part[row][2][C].  Deterministic: no global atomics.
-template <int MAXC>
+template <int MAXC, int NT = kBlock>
 __device__ __forceinline__ void block_channel_partials(float4 s1, float4 s2, int c4, int C, float* part_row,
                                                         float* smem /* [2*MAXC] */) {
   const int tid = threadIdx.x;
@@ -230,12 +230,12 @@ __device__ __forceinline__ void block_channel_partials(float4 s1, float4 s2, int
     s2.x += __shfl_xor(s2.x, off); s2.y += __shfl_xor(s2.y, off);
     s2.z += __shfl_xor(s2.z, off); s2.w += __shfl_xor(s2.w, off);
   }
-  for (int i = tid; i < 2 * C; i += kBlock) smem[i] = 0.f;
+  for (int i = tid; i < 2 * C; i += NT) smem[i] = 0.f;
   __syncthreads();
   const int lane = tid & (kWave - 1);
   const bool owner = (quads >= kWave) || (lane < quads);
   // fixed-order accumulation (wave 0, then 1, ...): bitwise reproducible, no LDS atomics
-  for (int w = 0; w < kBlock / kWave; ++w) {
+  for (int w = 0; w < NT / kWave; ++w) {
     if ((tid >> 6) == w && owner) {
       float* d = smem + 4 * c4;
       d[0] += s1.x; d[1] += s1.y; d[2] += s1.z; d[3] += s1.w;
@@ -244,7 +244,7 @@ __device__ __forceinline__ void block_channel_partials(float4 s1, float4 s2, int
     }
     __syncthreads();
   }
-  for (int i = tid; i < 2 * C; i += kBlock) part_row[i] = smem[i];
+  for (int i = tid; i < 2 * C; i += NT) part_row[i] = smem[i];
 }
 
 }  // namespace ttk
