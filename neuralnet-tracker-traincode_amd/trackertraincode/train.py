@@ -516,9 +516,21 @@ class GraphedTrainStep:
             self._capture(batches, epoch)
             self._sig = sig
             return out
+        # new batches -> the graph's static inputs: all float32 tensors in one launch (ttk_multi_copy), the rest (ids) one by one
+        fsrc, fdst = [], []
         for dst, src in zip(self._static, batches):
             for k, v in src.items():
-                dst[k].copy_(v, non_blocking=True)
+                d = dst[k]
+                if v is d or (torch.is_tensor(v) and v.data_ptr() == d.data_ptr() and v.numel() == d.numel()):
+                    continue  # the loader already wrote into the static tensor
+                if (torch.is_tensor(v) and v.is_cuda and v.dtype == torch.float32 and d.dtype == torch.float32 and v.is_contiguous() and d.is_contiguous()
+                        and v.numel() == d.numel()):
+                    fsrc.append(v)
+                    fdst.append(d)
+                else:
+                    d.copy_(v, non_blocking=True)
+        if fdst:
+            _hip.lib().multi_copy(fsrc, fdst)
         self.optimizer.before_graph_replay()
         self.graph.replay()
         self.optimizer.after_graph_replay()
