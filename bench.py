@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--traffic-json", default=None, help="rocprofv3 PMC summary (tools/pmc_summary.py) taken with THIS build; "
                     "fills roofline.traffic (null without it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-copy-probe", action="store_true", help="skip the same-process streaming probe (copy_probe object)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-call HIP-event instrumentation (roofline = null)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel from Python instead of replaying one captured hipGraph")
     ap.add_argument("--force-graph", action="store_true", help="always replay the captured hipGraph (default at N=1: whichever of graph replay "
@@ -202,6 +203,50 @@ def build_step(args, device):
                                  device=device, seed=1234 + rank)
     batches = next(iter(loader))
     return net, crit, opt, batches, train
+
+
+def copy_probe(device):
+    """What THIS box's memory system streams, measured in this process right after the timed region (ttk_stream_probe,
+    csrc/probe.hip): a 1 GB read-only sweep, a 1:1 copy and the depthwise backward's 5:1 read:write mix, each as a linear
+    sweep and in the 128-byte-slab shape of the depthwise kernels (a 32-channel slab of a 512-channel channels-last tensor),
+    16 B per lane, >= 72 KiB in flight per CU.  Best of a small sweep (loads in flight, workgroups per CU, cache policy),
+    each timed with HIP events over 3 launches after one warm-up.  GB/s of bytes read + written."""
+    import trackertraincode._hip as H
+    L, p = H.lib(), H.ptr
+    n = 1 << 28  # floats: 1 GiB
+    src = torch.empty(n, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty(n, dtype=torch.float32, device=device)
+    sink = torch.zeros(4, dtype=torch.float32, device=device)
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    out = {}
+    for label, nread, nwrite in (("read", 1, 0), ("copy", 1, 1), ("mix5to1", 5, 1)):
+        per = (n // nread) // 1024 * 1024          # floats per stream
+        for shape, row_bytes, seg in (("linear", 4096, 4096), ("slab128", 2048, 128)):
+            rows = per * 4 // row_bytes
+            best = (0.0, None)
+            for unroll in (4, 8):
+                for bpc in (4, 8):
+                    for nt in (1, 0):
+                        if unroll * nread > 40:
+                            continue
+                        def launch():
+                            L.call("ttk_stream_probe", p(src), p(dst) if nwrite else None, p(sink), rows, row_bytes, seg, nread, nwrite, per * 4, unroll, nt,
+                                   cus * bpc)
+                        launch()
+                        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        s0.record()
+                        for _ in range(3):
+                            launch()
+                        s1.record()
+                        s1.synchronize()
+                        gbs = 3 * (nread + nwrite) * per * 4 / (s0.elapsed_time(s1) * 1e-3) / 1e9
+                        if gbs > best[0]:
+                            best = (gbs, f"{unroll * nread} x 16 B per lane in flight, {bpc} workgroups per CU, {'non-temporal' if nt else 'plain'} loads")
+            out[f"{label}_{shape}_GBs"] = round(best[0], 1)
+            out[f"{label}_{shape}_config"] = best[1]
+    out["note"] = ("ttk_stream_probe on this device: bytes read + written per second; linear = contiguous sweep, slab128 = 128-byte pieces 2048 B apart "
+                   "(the depthwise kernels' 32-channel slab at C = 512); 1 GiB per measurement")
+    return out
 
 
 def cpu_baseline(args):
@@ -440,6 +485,8 @@ def main():
                                    max(sum(v["ms"] for k, v in ks.items() if k.startswith("pw")) * 1e-3, 1e-12) / 1e12) if ks else None,
             "dominant_kernel": dominant, "top_kernels": top5,
         }
+        if world == 1 and not args.no_copy_probe:
+            line["copy_probe"] = copy_probe(device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line))

@@ -42,7 +42,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 13
+#define TTK_ABI_VERSION 14
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -491,6 +491,18 @@ int ttk_affine_warp(const void* src, int src_is_u8, int B, int Hs, int Ws, const
                     int N, float mul, float add, ttk_stream_t stream);
 int ttk_affine_labels(const float* tr, int B, int N, float* coord, float* pose, float* roi,
                       const float* pts_in, float* pts_out, ttk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Streaming probe (measurement infrastructure: bench.py `copy_probe`, tools/stream_sweep.py; no reference counterpart).
+ * Streams `nread` (1, 2 or 5) source tensors of `rows` x `row_bytes`, `stream_bytes` apart, in the access shape of the
+ * step's HBM-bound kernels - every workgroup reads `seg_bytes`-wide column slices of consecutive rows, 16 bytes per lane,
+ * `unroll` (1, 2, 4, 8) x nread loads per lane in flight (seg_bytes == row_bytes: a linear sweep; 128 / 256: the
+ * 32- / 64-channel slab of a channels-last tensor) - adds them and writes the sum to `nwrite` destination tensors of the
+ * same shape (0: read only; *sink receives a dummy value that keeps the loads alive).  nontemporal: streaming loads.
+ * `blocks` persistent workgroups of 256 threads.  The caller times it with events on `stream`.
+ * ------------------------------------------------------------------------------------------- */
+int ttk_stream_probe(const float* src, float* dst, float* sink, int64_t rows, int row_bytes, int seg_bytes, int nread, int nwrite,
+                     int64_t stream_bytes, int unroll, int nontemporal, int blocks, ttk_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -374,6 +374,7 @@ size_t f16_wgrad_partial_bytes(int64_t M, int Cin, int Cout);
 
 // pwconv_split.hip: the same shapes on the bf16 pipe with exact 3-piece splits (six products; TTK_GEMM=bf16x3, and the
 // implicit-GEMM convolutions of the ResNet18 variant)
+#ifdef TTK_WITH_BF16X3
 template <int MODE>
 bool launch_split_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
                        const float* bnE, float* part, int64_t M, int K, int Nout, void* wsplit, hipStream_t st);
@@ -382,6 +383,13 @@ bool split_gemm_shape(int K, int Nout);
 
 bool launch_split_wgrad(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
                         int64_t M, int Cin, int Cout, hipStream_t st);
+#else  // not built (conv_geom.h): gemm_mode() never returns GEMM_BF16X3
+template <int MODE>
+inline bool launch_split_gemm(const float*, const float*, const float*, const float*, float*, const float*, const float*, float*, int64_t, int, int, void*,
+                              hipStream_t) { return false; }
+inline bool split_gemm_shape(int, int) { return false; }
+inline bool launch_split_wgrad(const float*, const float*, const float*, const float*, const float*, float*, int64_t, int, int, hipStream_t) { return false; }
+#endif
 
 // Layout of a prepared weight block of n = Cin*Cout elements.  fp16 / fp32 modes: [forward operand 4n][data-gradient
 // operand 4n][header: |w| maximum] - an operand is two fp16 planes or, for the shapes that stay on the fp32 kernels,

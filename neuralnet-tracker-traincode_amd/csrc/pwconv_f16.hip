@@ -76,7 +76,7 @@ __device__ __forceinline__ f32x4 ld_act4(const T* p) {
 // acc[TM][TN].  Executes exactly 1 + nks barriers (matching the producers).
 template <int BM, int BN, int RS, int STRIDE = kStride16>
 __device__ __forceinline__ void consume_tile16(const unsigned char* lds, int nks, int wm, int wn, int r, int h,
-                                               f32x16 (&acc)[BM / 64][BN / 64], long long* barrier_wait = nullptr) {
+                                               f32x16 (&acc)[BM / 64][BN / 64]) {
   constexpr int APL = BM * 32, BPL = BN * 32;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr bool HOLD_A = TM <= TN;  // hold the smaller fragment set in registers, stream the other
@@ -127,11 +127,7 @@ __device__ __forceinline__ void consume_tile16(const unsigned char* lds, int nks
   else                                                                                                        \
     acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(strm[cur][pa], hold[y][pb], acc[x][y], 0, 0, 0);       \
   }
-#if defined(TTK_EXP) && TTK_EXP == 4
-        asm volatile("" ::"v"(strm[cur][0]), "v"(strm[cur][1]), "v"(hold[0][0]), "v"(hold[0][1]));  // timing experiment: fragments read, no MFMAs
-#else
         TTK_PROD16(0, 1) TTK_PROD16(1, 0) TTK_PROD16(0, 0)
-#endif
 #undef TTK_PROD16
       }
       if (sub == 0 || RS == 3) {
@@ -141,13 +137,7 @@ __device__ __forceinline__ void consume_tile16(const unsigned char* lds, int nks
           for (int y = 0; y < TH; ++y) hold[y][p] = hold_n[y][p];
       }
     }
-#if defined(TTK_EXP) && TTK_EXP == 9
-    const long long b0 = __builtin_readcyclecounter();
     __syncthreads();
-    if (barrier_wait) *barrier_wait += __builtin_readcyclecounter() - b0;
-#else
-    __syncthreads();
-#endif
     slot = slot_n;
   }
 }
@@ -282,9 +272,6 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
 
     auto load_a = [&](int ks, auto setc) {
       constexpr int set = decltype(setc)::value;
-#if defined(TTK_EXP) && (TTK_EXP == 2 || TTK_EXP == 6)
-      if (ks >= D) return;  // timing experiment: A is loaded for the first steps only
-#endif
       const int tapc = GATHER ? ks / kpt : 0, kc0 = (ks - tapc * kpt) * 32;
       int tap = tapc;
       if (classes) {  // the class's tap number -> (kh, kw): kh = 1 | {0, 2} for even | odd rows of a 3x3 kernel, 0 for 1x1
@@ -340,9 +327,6 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
     };
     auto load_b = [&](int ks, auto setc) {
       constexpr int set = decltype(setc)::value;
-#if defined(TTK_EXP) && (TTK_EXP == 3 || TTK_EXP == 6)
-      if (ks >= D) return;  // timing experiment
-#endif
       int kb = ks;  // k32 step of the weight operand
       if (classes) {
         const int tapc = ks / kpt, jh = tapc / nkw, jw = tapc - jh * nkw;
@@ -357,9 +341,6 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
     };
     auto store_a = [&](int ks, auto setc) {
       constexpr int set = decltype(setc)::value;
-#if defined(TTK_EXP) && (TTK_EXP == 6 || TTK_EXP == 7)
-      if (ks >= D) return;  // timing experiment: no conversion / LDS writes
-#endif
       if constexpr (PLANES) {  // no arithmetic: the 16-byte chunk straight into the ring
         unsigned char* Sp = wbase_p + (ks % RS) * 2 * kStr;
 #pragma unroll
@@ -388,9 +369,6 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
     };
     auto store_b = [&](int ks, auto setc) {  // no arithmetic: 16-byte chunks (8 k of one piece) straight into the ring
       constexpr int set = decltype(setc)::value;
-#if defined(TTK_EXP) && (TTK_EXP == 6 || TTK_EXP == 8)
-      if (ks >= D) return;  // timing experiment
-#endif
       unsigned char* S = wbase_b + (ks % RS) * 2 * kStr;
 #pragma unroll
       for (int p = 0; p < 2; ++p)
@@ -398,41 +376,17 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
         for (int i = 0; i < BI; ++i) *reinterpret_cast<u32x4*>(S + p * BPL + swz16(brow + 64 * i, bc4 & 1)) = rb[set][p][i];
     };
     // B is consumed first in a step and reloaded at once, then A
-#if defined(TTK_EXP) && TTK_EXP == 9
-    long long tb = 0, ta = 0;  // cycles in the B part / the A part of produce() (the rest of the loop is barrier wait)
-    const long long p0 = __builtin_readcyclecounter();
-#endif
     producer_schedule<D, RS>(
         nks,
         [&](int s, auto setc) { load_b(s, setc); load_a(s, setc); __builtin_amdgcn_sched_barrier(0); },
         [&](int s, auto setc) {
-#if defined(TTK_EXP) && TTK_EXP == 9
-          const long long q0 = __builtin_readcyclecounter();
-#endif
           store_b(s, setc);
           if (s + D < nks) load_b(s + D, setc);
           __builtin_amdgcn_sched_barrier(0);
-#if defined(TTK_EXP) && TTK_EXP == 9
-          __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the LDS writes are done
-          const long long q1 = __builtin_readcyclecounter();
-          tb += q1 - q0;
-#endif
           store_a(s, setc);
           if (s + D < nks) load_a(s + D, setc);
           __builtin_amdgcn_sched_barrier(0);
-#if defined(TTK_EXP) && TTK_EXP == 9
-          __builtin_amdgcn_s_waitcnt(0xc07f);
-          ta += __builtin_readcyclecounter() - q1;
-#endif
         });
-#if defined(TTK_EXP) && TTK_EXP == 9
-    if (tile == 0 && tid == 256 && part) {
-      float* dbg = part + (size_t)ceil_div(M, 128) * 2 * Nout;
-      dbg[4] = (float)(__builtin_readcyclecounter() - p0);
-      dbg[5] = (float)tb;
-      dbg[6] = (float)ta;
-    }
-#endif
   } else {
     const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
@@ -443,22 +397,7 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-#if defined(TTK_EXP) && TTK_EXP == 9
-    // clock diagnostic: shader cycles and 100 MHz real-time ticks around the main loop of tile 0 -> behind the partial rows
-    const long long c0 = __builtin_readcyclecounter();
-    const long long t0 = __builtin_amdgcn_s_memrealtime();
-    long long bwait = 0;
-    consume_tile16<BM, BN, RS, kStr>(lds, nks, wm, wn, r, h, acc, &bwait);
-    if (tile == 0 && tid == 0 && part) {
-      float* dbg = part + (size_t)ceil_div(M, 128) * 2 * Nout;
-      dbg[0] = (float)(__builtin_readcyclecounter() - c0);
-      dbg[1] = (float)(__builtin_amdgcn_s_memrealtime() - t0);
-      dbg[2] = (float)nks;
-      dbg[3] = (float)bwait;
-    }
-#else
     consume_tile16<BM, BN, RS, kStr>(lds, nks, wm, wn, r, h, acc);
-#endif
     // ---- accumulators -> LDS image [BM][LDC] (the ring is dead: the loop ended with a barrier)
     float* Cs = reinterpret_cast<float*>(lds);
 #pragma unroll
@@ -487,9 +426,6 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
     }
   }
   __syncthreads();
-#if defined(TTK_EXP) && TTK_EXP == 5
-  if (M > 0) return;  // timing experiment: no epilogue
-#endif
   const float inv = 1.f / (sa * sb);  // exact: a power of two
   const float* Cs = reinterpret_cast<const float*>(lds);
   float* red = reinterpret_cast<float*>(lds + BM * LDC * 4);  // [RG][2][BN]
@@ -515,9 +451,7 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
       Act<TO>::st(out + o, Act<TO>::round(v));
     } else if constexpr (EMODE == EMODE_STATS) {
       v = Act<TO>::round(v);  // statistics of what is stored
-#if !(defined(TTK_EXP) && TTK_EXP == 1)
       Act<TO>::st(out + o, v);
-#endif
       s1 = add4(s1, v);
       s2 = fma4(v, v, s2);
     } else {
@@ -686,9 +620,6 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
 
     auto load_a = [&](int ks, auto setc) {
       constexpr int set = decltype(setc)::value;
-#if defined(TTK_EXP) && (TTK_EXP == 11)
-      if (ks >= 1) return;  // timing experiment: the A operand is loaded for the first step only
-#endif
       if constexpr (BM < 128)
         if (!a_on) return;
       if constexpr (APLANES) {
@@ -725,9 +656,6 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
     };
     auto load_b = [&](int ks, auto setc) {
       constexpr int set = decltype(setc)::value;
-#if defined(TTK_EXP) && (TTK_EXP == 12)
-      if (ks >= 1) return;  // timing experiment: the B operand is loaded for the first step only
-#endif
       if constexpr (CONV) {
         // The producers' instruction count IS this kernel's speed (a first version with two divisions per step,
         // 64-bit offsets and branches for the carries ran at 10 k cycles per step, 6 x the MFMA time): the pixel of
@@ -790,9 +718,6 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
       unsigned char* S = wbase + (ks % RS) * 2 * kStr;
       const int64_t row0 = m_begin + (int64_t)ks * 32 + 4 * mb;
       const bool masked = ks >= nfull;  // uniform
-#if defined(TTK_EXP) && (TTK_EXP == 13)
-      if (ks >= 1) return;  // timing experiment: no conversion / LDS writes
-#endif
       if constexpr (BM < 128)
         if (!a_on) return;
       if constexpr (APLANES) {
@@ -835,9 +760,6 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
       unsigned char* S = wbase + (ks % RS) * 2 * kStr + 2 * APL;
       const int64_t row0 = m_begin + (int64_t)ks * 32 + 4 * mb;
       const bool masked = ks >= nfull;  // uniform
-#if defined(TTK_EXP) && (TTK_EXP == 13)
-      if (ks >= 1) return;  // timing experiment
-#endif
 #pragma unroll
       for (int p = 0; p < BP; ++p) {
         if constexpr (BN % 128 != 0)
@@ -885,9 +807,6 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     consume_tile16<BM, BN, RS, kStr>(lds, nks, wm, wn, r, h, acc);
     const float inv = 1.f / (sa * sb);
-#if defined(TTK_EXP) && TTK_EXP == 15
-    if (acc[0][0][0] != 12345.678f) return;  // timing experiment: no epilogue
-#endif
     float* dst = partial ? partial + (size_t)slice * Cout * Cin : dW;
     const int taps = CONV ? Cin / Kc : 1;
 #pragma unroll

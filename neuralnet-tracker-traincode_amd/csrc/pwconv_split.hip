@@ -590,42 +590,6 @@ pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const
     if (nks > 1) load_b(1);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-#if defined(TTK_EXP) && TTK_EXP == 20
-    // cycle stamps of the producer phases, summed over the steps, wave 4 of workgroup 0 -> dW[0..7] (timing experiment)
-    long long tw[7] = {0, 0, 0, 0, 0, 0, 0};
-    auto touch = [&](auto& arr) { asm volatile("" : "+v"(arr)); };
-    for (int it = 0; it < nks; ++it) {
-      const long long c0 = __builtin_readcyclecounter();
-      long long c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0;
-      if (it + 1 < nks) {
-        for (int i = 0; i < 4; ++i) { touch(rg[0][i]); touch(ry[0][i]); }
-        __builtin_amdgcn_sched_barrier(0);
-        c1 = __builtin_readcyclecounter();
-        store_a(it + 1);
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the LDS writes are done
-        __builtin_amdgcn_sched_barrier(0);
-        c2 = __builtin_readcyclecounter();
-        if (it + 2 < nks) load_a(it + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        c3 = __builtin_readcyclecounter();
-        for (int q = 0; q < BP; ++q) for (int i = 0; i < 4; ++i) touch(rx[q][i]);
-        __builtin_amdgcn_sched_barrier(0);
-        c4 = __builtin_readcyclecounter();
-        store_b(it + 1);
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_sched_barrier(0);
-        c5 = __builtin_readcyclecounter();
-        if (it + 2 < nks) load_b(it + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        c6 = __builtin_readcyclecounter();
-      }
-      __syncthreads();
-      const long long c7 = __builtin_readcyclecounter();
-      tw[0] += c1 - c0; tw[1] += c2 - c1; tw[2] += c3 - c2; tw[3] += c4 - c3; tw[4] += c5 - c4; tw[5] += c6 - c5; tw[6] += c7 - c6;
-    }
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 256)
-      for (int i = 0; i < 7; ++i) dW[i] = (float)tw[i] / (float)nks;
-#else
     for (int it = 0; it < nks; ++it) {
       if (it + 1 < nks) {
         store_a(it + 1);
@@ -637,7 +601,6 @@ pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const
       }
       __syncthreads();
     }
-#endif
   } else {
     const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
@@ -649,9 +612,6 @@ pw_split_wgrad_k(const float* __restrict__ G, const float* __restrict__ Y, const
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     consume_tile<BM, BN>(lds, nks, wm, wn, r, h, acc);
-#if defined(TTK_EXP) && TTK_EXP == 20
-    if (acc[0][0][0] != 12345.678f) return;
-#endif
     const int taps = CONV ? Ncols / Kc : 1;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {

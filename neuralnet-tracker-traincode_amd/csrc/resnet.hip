@@ -162,9 +162,7 @@ __global__ void __launch_bounds__(kBlock) stem7_fwd_mfma_k(const float* __restri
     __builtin_amdgcn_wave_barrier();  // (same wave, LDS in order) the previous group's output pass is done before the patch is overwritten
     stash(0);
     for (int r0 = 9; r0 < PR; r0 += 9) { fetch(gidx, r0); stash(r0); }
-#if !(defined(S7_EXP) && S7_EXP == 3)
     if (gidx + nwaves < groups) fetch(gidx + nwaves, 0);
-#endif
     __builtin_amdgcn_wave_barrier();
     const int p = p0 + px;
     const int pc = p < hw ? p : hw - 1, oh = pc / Wo, ow = pc - oh * Wo;
@@ -175,10 +173,6 @@ __global__ void __launch_bounds__(kBlock) stem7_fwd_mfma_k(const float* __restri
 #pragma unroll
     for (int j = 0; j < kSteps; ++j) {
       const float a = win[half ? toff(j, 1) : toff(j, 0)];
-#if defined(S7_EXP) && S7_EXP == 1
-      asm volatile("" ::"v"(a));
-      continue;
-#endif
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[0][j], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[1][j], acc1, 0, 0, 0);
     }
@@ -198,9 +192,7 @@ __global__ void __launch_bounds__(kBlock) stem7_fwd_mfma_k(const float* __restri
       const int row = prow + 4 * i;
       if (p0 + row < hw) {
         const float4 v = ld4(patch + row * kLdo + 4 * c4);
-#if !(defined(S7_EXP) && S7_EXP == 2)
         st4(yg + (size_t)row * kS7C + 4 * c4, v);
-#endif
         s1 = add4(s1, v);
         s2 = fma4(v, v, s2);
       }

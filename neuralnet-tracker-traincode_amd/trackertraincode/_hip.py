@@ -87,9 +87,10 @@ _SIGNATURES = {
     "ttk_affine_labels": [_P, _I, _I, _P, _P, _P, _P, _P],
     "ttk_intensity_augment": [_P, _P, _P, _P, _I, _I, _I, _F],
     "ttk_clip_adam": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P],
+    "ttk_stream_probe": [_P, _P, _P, _L, _I, _I, _I, _I, _L, _I, _I, _I],
 }
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class LossOp(ctypes.Structure):
@@ -142,6 +143,7 @@ class _Library:
         self.cdll.ttk_stem7_wgrad_partial_bytes.argtypes, self.cdll.ttk_stem7_wgrad_partial_bytes.restype = [c_int] * 3, ctypes.c_size_t
         self.cdll.ttk_stem_wgrad_partial_bytes.argtypes, self.cdll.ttk_stem_wgrad_partial_bytes.restype = [], ctypes.c_size_t
         self._fns = {}
+        self._stale_reported = False
         for name, sig in _SIGNATURES.items():
             fn = getattr(self.cdll, name)  # AttributeError if the symbol is missing: loud by design
             fn.argtypes = list(sig) + [c_void_p]
@@ -150,7 +152,13 @@ class _Library:
 
     def call(self, name: str, *args):
         stream = torch.cuda.current_stream().cuda_stream
-        self._clear()  # a stale error of an unrelated earlier HIP call must not be blamed on this launch
+        # a stale error of an unrelated earlier HIP call must not be blamed on this launch - but it must not vanish either
+        stale = self._clear()
+        if stale and not self._stale_reported:
+            self._stale_reported = True
+            import warnings
+            warnings.warn(f"a HIP error (hipError_t {stale}) from an earlier launch was pending when {name} was called; it was NOT raised by {name}",
+                          RuntimeWarning, stacklevel=2)
         rc = self._fns[name](*args, stream)
         if rc != 0:
             msg = self.cdll.ttk_last_error_string().decode(errors="replace")

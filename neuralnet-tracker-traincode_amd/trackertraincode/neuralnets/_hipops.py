@@ -51,6 +51,17 @@ class loss_batch:
         return False
 
 
+class unbatched:
+    """with unbatched(): loss Functions launch one by one again (inside or outside a loss_batch block)."""
+
+    def __enter__(self):
+        self.prev, _TLS.batch = _batch(), None
+
+    def __exit__(self, *exc):
+        _TLS.batch = self.prev
+        return False
+
+
 def _p(t):
     b = _batch()
     if b is not None and b.deferring and t is not None:

@@ -159,19 +159,37 @@ def default_compute_loss(preds: dict, batch: List[Batch], current_epoch: int, lo
     the TOTAL batch size so that a loss a sub-batch does not have counts as zero."""
     from .neuralnets import _hipops
 
-    all_lossvals: list[list[LossVal]] = []
     sizes = [subset.meta.prefixshape[0] for subset in batch]
-    # the criterions' HIP kernels are independent of one another: their launches are collected and issued as ONE
-    # (neuralnets/_hipops.py: loss_batch / apply / BatchedLossFn), forward here and backward in BatchedLossFn.backward
-    with _hipops.loss_batch() as lb:
-        for subset, subpreds in zip(batch, _split_predictions(preds, sizes)):
+    split = _split_predictions(preds, sizes)
+
+    def evaluate_all():
+        out: list[list[LossVal]] = []
+        for subset, subpreds in zip(batch, split):
             crit = loss[subset.meta.tag] if isinstance(loss, dict) else loss
             terms = crit.evaluate(subpreds, subset, current_epoch)
             dw = None
             if "dataset_weight" in subset:
                 dw = subset["dataset_weight"]
                 assert dw.size(0) == subset.meta.batchsize
-            all_lossvals.append([v._replace(weight=SampleWeight(v.weight, dw, v.val)) for v in terms])
+            out.append([v._replace(weight=SampleWeight(v.weight, dw, v.val)) for v in terms])
+        return out
+
+    # the criterions' HIP kernels are independent of one another: their launches are collected and issued as ONE
+    # (neuralnets/_hipops.py: loss_batch / apply / BatchedLossFn), forward here and backward in BatchedLossFn.backward
+    with _hipops.loss_batch() as lb:
+        all_lossvals = evaluate_all()
+    returned = {id(v.val) for terms in all_lossvals for v in terms}
+    if any(id(r[3]) not in returned for r in lb.records):
+        # A criterion did arithmetic on a deferred per-sample value (scaled it, sliced it, added two losses: the reference's
+        # Criterion accepts any callable) - that read memory the batch had not filled yet, and the term would get no gradient.
+        # Nothing was launched so far: throw the deferred pass away and evaluate every term with one launch per loss op.
+        _warn_once("a Criterion post-processes the value of a batched loss kernel; this step's losses run unbatched "
+                   "(wrap the arithmetic into the loss function's autograd, or set TTK_LOSS_BATCH=0, to silence this)")
+        lb.ops.clear()
+        lb.records.clear()
+        lb.keep.clear()
+        with _hipops.unbatched():
+            all_lossvals = evaluate_all()
     batchsize = sum(subset.meta.batchsize for subset in batch)
     flat = list(itertools.chain.from_iterable(all_lossvals))
     if flat and all(v.val.is_cuda and v.val.dtype == torch.float32 for v in flat):
@@ -184,6 +202,16 @@ def default_compute_loss(preds: dict, batch: List[Batch], current_epoch: int, lo
     return loss_sum, all_lossvals
 
 
+_WARNED: set = set()
+
+
+def _warn_once(msg):
+    if msg not in _WARNED:
+        _WARNED.add(msg)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
 def _batched_loss_sum(lb, flat, scale):
     """The weighted sum over all terms; the terms whose kernels were deferred into `lb` go through BatchedLossFn together."""
     from .neuralnets import _hipops
@@ -194,6 +222,7 @@ def _batched_loss_sum(lb, flat, scale):
         lb.flush()
         return _hipops.WeightedSumFn.apply([v.weight.scalar for v in flat], [v.weight.per_sample for v in flat], scale, *[v.val for v in flat])
     records = [by_val[id(v.val)] for v in deferred]
+    assert len(records) == len(lb.records), "a deferred loss term was dropped"  # (default_compute_loss re-evaluates unbatched before this can happen)
     inputs, index, slots = [], {}, []
     for _fn, _ctx, args, _v in records:  # the distinct differentiable inputs of the deferred terms
         sl = []

@@ -128,3 +128,45 @@ def test_batched_loss_launches_equal_single_launches(cfg, monkeypatch):
         assert (ga[k] is None) == (gb[k] is None), k
         if ga[k] is not None:
             torch.testing.assert_close(ga[k], gb[k], rtol=1e-6, atol=1e-9, msg=k)
+
+
+def test_criterion_that_post_processes_a_batched_loss_keeps_its_gradient(monkeypatch):
+    """The reference's Criterion takes ANY callable (train.py:65-75).  One that does arithmetic on the per-sample values of a
+    batched loss kernel (here: twice the rotation loss plus the size loss, as one term) would read memory the deferred launch
+    has not filled and lose its gradient; default_compute_loss detects the unmatched record and evaluates the step's terms
+    unbatched instead - same loss and gradients as with batching switched off, plus one RuntimeWarning."""
+    import trackertraincode.train as train
+    from trackertraincode.neuralnets import _hipops, losses
+    from util import build_net, load_golden, make_batches
+
+    _, meta = load_golden("model_default.npz")
+    net = build_net(meta, "cuda").train()
+    batches = make_batches(meta, "cuda")
+    inputs = torch.concat([b["image"] for b in batches], dim=0)
+    ids = torch.concat([b["coord_convention_id"] for b in batches], dim=0)
+    with torch.no_grad():
+        preds0 = net(inputs, ids)
+    rot, size = losses.QuatPoseLoss("approx_distance"), losses.PoseSizeLoss("l2")
+    crit = train.CriterionGroup([train.Criterion("combo", lambda p, b: 2.0 * rot(p, b) + size(p, b)[: b.meta.batchsize], 0.7),
+                                 train.Criterion("xy", losses.PoseXYLoss("l2"), 1.0)])
+
+    def run(batching):
+        monkeypatch.setattr(_hipops, "_BATCHING", batching)
+        monkeypatch.setattr(train, "_WARNED", set())
+        preds = {k: (type(v)(v.value.detach().clone().requires_grad_(True)) if hasattr(v, "value") else v.detach().clone().requires_grad_(True))
+                 for k, v in preds0.items()}
+        leaves = {k: (v.value if hasattr(v, "value") else v) for k, v in preds.items()}
+        loss, _ = train.default_compute_loss(preds, batches, 0, crit)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach(), {k: t.grad for k, t in leaves.items()}
+
+    with pytest.warns(RuntimeWarning, match="post-processes"):
+        la, ga = run(True)
+    lb, gb = run(False)
+    assert torch.equal(la, lb)
+    assert ga["rot"] is not None and float(ga["rot"].abs().max()) > 0 and float(ga["coord"].abs().max()) > 0
+    for k in ga:
+        assert (ga[k] is None) == (gb[k] is None), k
+        if ga[k] is not None:
+            torch.testing.assert_close(ga[k], gb[k], rtol=1e-6, atol=1e-9, msg=k)

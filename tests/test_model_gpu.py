@@ -164,8 +164,8 @@ def test_gradients_vs_fp64_oracle():
     # needed because of ReLU flips: at B=8 about 100 of the 15 M ReLU inputs lie within 1e-5 of zero, and whether one of
     # them is >0 depends on the last bits of the BatchNorm statistics.  A flip moves every upstream parameter gradient
     # in whichever fp32 implementation it happens - by 2e-3 when it sits in a 5x5 layer (200 values per channel at B=8),
-    # and the fp32 CPU oracle itself shows 1e-3..6e-3 from its own flips (tools/debug/grad_flip_check.py prints the
-    # table; with the scalar and the MFMA stem kernel the flips land in different layers, everything else is 1e-6; regrouping the
+    # and the fp32 CPU oracle itself shows 1e-3..6e-3 from its own flips (measured layer by layer in round 1;
+    # with the scalar and the MFMA stem kernel the flips land in different layers, everything else is 1e-6; regrouping the
     # stem's BatchNorm partial sums - the LDS-band stem kernel - moved them again: 7.4e-3 on the bn_sep weights upstream of one,
     # hence 1e-2 and not the 5e-3 that held for the earlier kernels' flips).  Tight precision is pinned by the per-op
     # tests (heads 5e-6, losses 1e-5 vs fp64: tests/test_heads_losses_gpu.py) and by test_backbone_gpu.py.

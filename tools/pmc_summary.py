@@ -5,7 +5,11 @@ Corrections (MI355X_MICROARCH.md, HBM section): both counters are in KB; on gfx9
 requests of wide (16 B/lane) streaming reads at 64 B, so it is doubled; WRITE_SIZE is exact for 16-B/lane stores and
 float atomics.
 
-usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+An optional third pass (TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum) adds, per kernel, the L2 hit rate
+TCC_HIT / (TCC_HIT + TCC_MISS) and the read requests the CUs' L1s sent to L2 (what a GEMM tile re-streams from L2, which
+the memory-side FETCH_SIZE does not see).
+
+usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [<l2_counter_collection.csv>]"""
 import collections, csv, json, re, sys
 
 
@@ -24,9 +28,10 @@ def collect(path, counter):
 
 
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+l2 = {c: collect(sys.argv[4], c) for c in ("TCC_HIT_sum", "TCC_MISS_sum", "TCP_TCC_READ_REQ_sum")} if len(sys.argv) > 4 else None
 out = {}
 for k in sorted(set(fetch) | set(write)):
-    if not (k.startswith("pw_") or k.startswith("dw_") or k.startswith("stem") or k.startswith("bn_") or k.startswith("heads")
+    if not (k.startswith("pw") or k.startswith("dw_") or k.startswith("stem") or k.startswith("bn_") or k.startswith("heads")
             or k.startswith("loss") or k.startswith("avgpool") or k.startswith("clip_adam") or k.startswith("affine")):
         continue
     nf, f = fetch.get(k, [0, 0.0])
@@ -34,6 +39,12 @@ for k in sorted(set(fetch) | set(write)):
     n = max(nf, nw, 1)
     fb, wb = 2.0 * 1024.0 * f / max(nf, 1), 1024.0 * w / max(nw, 1)
     out[k] = {"launches": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "bytes_per_launch": fb + wb}
+    if l2 is not None and k in l2["TCC_HIT_sum"]:
+        nh, hit = l2["TCC_HIT_sum"][k]
+        _, miss = l2["TCC_MISS_sum"].get(k, [0, 0.0])
+        _, rd = l2["TCP_TCC_READ_REQ_sum"].get(k, [0, 0.0])
+        out[k].update(l2_hit_rate=hit / max(hit + miss, 1.0), l2_hits_per_launch=hit / max(nh, 1), l2_misses_per_launch=miss / max(nh, 1),
+                      l1_read_requests_to_l2_per_launch=rd / max(nh, 1))
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --serial-streams`, "
                      "KB -> bytes, FETCH_SIZE doubled (gfx950 wide-read rule)", "kernels": out}, open(sys.argv[3], "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["bytes_per_launch"] * kv[1]["launches"])[:12]:
