@@ -42,7 +42,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 14
+#define TTK_ABI_VERSION 15
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -90,7 +90,10 @@ int ttk_clear_error(void);
 /* Number of rows of the `part` buffer ([rows][2][C] floats) that a producer writes. */
 int ttk_partial_rows_elementwise(int64_t work_items); /* stem / depthwise / pool kernels        */
 int ttk_partial_rows_dwconv(int B, int H, int W, int C, int stride, int backward); /* depthwise fwd (0) / data-grad (1) */
-int ttk_partial_rows_gemm(int64_t M);                 /* pointwise (MFMA) kernels: ceil(M/128)  */
+int ttk_partial_rows_gemm(int64_t M);                 /* MFMA kernels with 128-row partial sums: ceil(M/128) (convolutions, fused backward inputs) */
+/* rows of partial sums ttk_pwconv1x1_fwd (K = Cin, Nout = Cout) / ttk_pwconv1x1_bwd_data (K = Cout, Nout = Cin) write for M rows: one per
+ * row block of the kernel that runs the shape - ceil(M/128), or the row-block tiling of csrc/pwconv_r.hip for K >= 128, Nout % 256 == 0 */
+int ttk_partial_rows_pwconv(int64_t M, int K, int Nout);
 
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm2d statistics - replaces F.batch_norm(training=True, momentum, eps) as called through

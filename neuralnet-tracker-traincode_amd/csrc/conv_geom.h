@@ -71,4 +71,12 @@ bool launch_conv_wgrad16(const float* g, const float* y, const float* bn, const 
                          int64_t M, int Cout, int taps, const ConvGeom& geo, hipStream_t st);
 size_t conv_wgrad16_partial_bytes(int64_t M, int Cout, int ncols, int taps);
 
+// Row-block GEMMs (pwconv_r.hip): element (row, k) of a [rows][K] weight operand inside one piece plane [K/16][rows][16] whose two
+// 16-byte chunks per row are swapped where (row >> 3) & 1 - the LDS image of a k16 stage, so that LDS-DMA copies it linearly
+__host__ __device__ inline int64_t r_plane_index(int row, int k, int rows) {
+  return ((int64_t)(k >> 4) * rows + row) * 16 + ((((k >> 3) & 1) ^ ((row >> 3) & 1)) << 3) + (k & 7);
+}
+bool f16r_gemm_shape(int K, int Nout);
+int f16r_partial_rows(int64_t M, int K, int Nout);
+
 }  // namespace ttk

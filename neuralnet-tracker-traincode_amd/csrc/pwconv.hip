@@ -372,6 +372,12 @@ bool launch_f16_wgrad(const TG* g, const T* y, const float* bn_pw, const T* ydw,
                       float* partial, int64_t M, int Cin, int Cout, hipStream_t st);
 size_t f16_wgrad_partial_bytes(int64_t M, int Cin, int Cout);
 
+// pwconv_r.hip: the wide layers (K >= 128, Nout a multiple of 256) in row-block form: 8 consumer waves, variable tile height,
+// LDS-DMA weight planes in the [K/16][Nout][16] layout (conv_geom.h: r_plane_index)
+template <int MODE, typename T, typename TO>
+bool launch_f16r_gemm(const TO* A0, const T* A1, const float* bnA, const float* Bm, TO* out, const T* E0, const float* bnE, float* part,
+                      int64_t M, int K, int Nout, void* planes, float* wmax, hipStream_t st);
+
 // pwconv_split.hip: the same shapes on the bf16 pipe with exact 3-piece splits (six products; TTK_GEMM=bf16x3, and the
 // implicit-GEMM convolutions of the ResNet18 variant)
 #ifdef TTK_WITH_BF16X3
@@ -401,6 +407,7 @@ template <int MODE, typename T, typename TO>
 static bool launch_gemm(const TO* A0, const T* A1, const float* bnA, const float* Bm, TO* out, const T* E0,
                         const float* bnE, float* part, int64_t M, int K, int Nout, void* region, float* hdr, hipStream_t st) {
   const int mode = gemm_mode();
+  if (mode == GEMM_F16X2 && launch_f16r_gemm<MODE, T, TO>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, region, hdr, st)) return true;
   if (mode == GEMM_F16X2 && launch_f16_gemm<MODE, T, TO>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, region, hdr, st)) return true;
   if constexpr (!Act<T>::kBf16 && !Act<TO>::kBf16) {
     if (mode == GEMM_BF16X3 && launch_split_gemm<MODE>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, region, st)) return true;
@@ -435,14 +442,14 @@ struct PrepArgs {
 
 // element (row, k) of a [rows][K] operand: fp32 in place, or its piece planes in the split kernels' [K/32][rows][32] order
 // (bf16 mode: three exact pieces; fp16 mode: two round-to-nearest pieces of x * s)
-__device__ __forceinline__ void prep_store(unsigned char* region, bool split, int mode, float s, int row, int k, int rows, int K, float x) {
+__device__ __forceinline__ void prep_store(unsigned char* region, int split, int mode, float s, int row, int k, int rows, int K, float x) {
   const int64_t n = (int64_t)rows * K;
   if (!split) {
     reinterpret_cast<float*>(region)[(int64_t)row * K + k] = x;
     return;
   }
   uint16_t* q = reinterpret_cast<uint16_t*>(region);
-  const int64_t idx = ((int64_t)(k >> 5) * rows + row) * 32 + (k & 31);
+  const int64_t idx = split == 2 ? r_plane_index(row, k, rows) : ((int64_t)(k >> 5) * rows + row) * 32 + (k & 31);
   if (mode == GEMM_BF16X3) {
     const float r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
     const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
@@ -522,6 +529,11 @@ __global__ void __launch_bounds__(kBlock) pw_prepare_weights_k(PrepArgs a) {
 using namespace ttk;
 
 extern "C" {
+
+int ttk_partial_rows_pwconv(int64_t M, int K, int Nout) {
+  const int r = f16r_partial_rows(M, K, Nout);
+  return r ? r : (int)ceil_div(M, BM);
+}
 
 int ttk_pwconv1x1_fwd(const void* ydw, const float* bn_dw, const float* w, void* y, float* part, int64_t M, int Cin, int Cout,
                       void* wsplit, int act_bf16, ttk_stream_t stream) {
@@ -646,8 +658,9 @@ int ttk_pwconv_prepare_weights(int n, const float* const* w, const int* cin, con
     a.cout[i] = cout[i];
     a.first_tile[i] = tiles;
     tiles += (cin[i] / 32) * (cout[i] / 32);
-    a.split_fwd[i] = a.mode == GEMM_F16X2 ? f16_gemm_shape(cin[i], cout[i]) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cin[i], cout[i]));
-    a.split_bwd[i] = a.mode == GEMM_F16X2 ? f16_gemm_shape(cout[i], cin[i]) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cout[i], cin[i]));
+    // 0: fp32 rows; 1: piece planes [K/32][rows][32]; 2: the row-block kernels' planes [K/16][rows][16] (pwconv_r.hip)
+    a.split_fwd[i] = a.mode == GEMM_F16X2 ? (f16r_gemm_shape(cin[i], cout[i]) ? 2 : f16_gemm_shape(cin[i], cout[i])) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cin[i], cout[i]));
+    a.split_bwd[i] = a.mode == GEMM_F16X2 ? (f16r_gemm_shape(cout[i], cin[i]) ? 2 : f16_gemm_shape(cout[i], cin[i])) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cout[i], cin[i]));
   }
   a.first_tile[n] = tiles;
   hipStream_t st = (hipStream_t)stream;

@@ -1,0 +1,404 @@
+// Pointwise 1x1 convolutions of the wide layers (Cin >= 128, Cout a multiple of 256) - forward and data gradient - as
+// fp32 GEMMs on the fp16 matrix pipe, "row-block" form.  Reference: DepthWiseBlock.conv_sep + bn_sep,
+// backbones/mobilenet_v1.py:67-68,82-84.  Arithmetic, operand bounds and numerics: pwconv_f16.hip (two fp16 pieces per
+// operand, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulation).
+//
+// What is different from pw16_k, and why (round 3; measurements in DESIGN.md 4.1).  A 128x256 tile moves 16 KB of A (fp32
+// rows from HBM, ~12 B/clk per CU when every CU streams) and 32 KB of weight planes (L2, ~35 B/clk) per k32 step through
+// its CU for 1536 cycles of matrix work per SIMD - the bytes, not the MFMAs, set the step - and M = 41 472 rows make 648
+// tiles: 2.53 rounds on 256 CUs, paid as 3.  Here
+//  * a workgroup is 12 waves: EIGHT consumer waves (two per SIMD: one wave's fragment reads hide behind the other's MFMAs)
+//    on a tile of up to 256 rows x 256 columns, four producer waves;
+//  * the tile HEIGHT is not fixed: the host cuts M into row blocks of RT <= 32 RBLK rows such that the tiles fill whole
+//    rounds of the 256 CUs (41 472 x 512: 256 row blocks of 162 rows x 2 column tiles = exactly 2 rounds; the MFMAs run
+//    on the padded 192 rows, which the byte-bound step has room for);
+//  * the weight planes reach LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write): ttk_pwconv_prepare_weights
+//    stores them as [K/16][Nout][16] with the consumers' chunk swizzle already applied, so a k16 stage of 256 rows is ONE
+//    contiguous 8 KB block per piece plane and a wave-instruction copies 1 KB of it;
+//  * BatchNorm partial sums: one row per tile (ttk_partial_rows_pwconv).
+#include "ttk_common.h"
+#include "conv_geom.h"
+#include <type_traits>
+
+namespace ttk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+enum { RMODE_FWD = 0, RMODE_DGRAD = 1 };
+constexpr int kRBN = 256;  // tile width
+
+// raw s_barrier (no vmcnt drain: the producers keep global loads in flight across it) fenced against compiler motion of LDS accesses
+__device__ __forceinline__ void rbarrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ int rswz(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 3) & 1)) << 4); }
+
+__device__ __forceinline__ void rsplit_store(f32x4 v, unsigned char* dst, int plane) {
+  const f16x2 h01 = __builtin_convertvector(f32x2{v.x, v.y}, f16x2), h23 = __builtin_convertvector(f32x2{v.z, v.w}, f16x2);
+  const f32x2 f01 = __builtin_convertvector(h01, f32x2), f23 = __builtin_convertvector(h23, f32x2);
+  const f16x2 l01 = __builtin_convertvector(f32x2{v.x - f01.x, v.y - f01.y}, f16x2);
+  const f16x2 l23 = __builtin_convertvector(f32x2{v.z - f23.x, v.w - f23.y}, f16x2);
+  *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+  *reinterpret_cast<uint2*>(dst + plane) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+}
+
+template <typename T>
+__device__ __forceinline__ f32x4 rld_act4(const T* p) {
+  const float4 v = Act<T>::ldnt(p);
+  return f32x4{v.x, v.y, v.z, v.w};
+}
+
+// Geometry of a tile of RBLK 32-row blocks x 8 32-column blocks on 8 consumer waves
+template <int RBLK>
+struct RGeo {
+  static constexpr int RB = 32 * RBLK;
+  static constexpr int WM = RBLK == 8 ? 4 : 2, WN = 8 / WM;  // consumer waves along M / N
+  static constexpr int TM = RBLK / WM, TN = 8 / WN;         // 32 x 32 blocks per consumer wave
+  static constexpr int APL = RB * 32, BPL = kRBN * 32;      // bytes of one piece plane of a k16 stage
+  static constexpr int kStage = 2 * APL + 2 * BPL;          // [A h][A l][B h][B l]
+  static constexpr int kStr = kStage + 64;                  // the two k16 halves of a producer's ds_write_b64 use different banks
+  static constexpr int kRing = 2 * 2 * kStr;                // two k32 super-stages
+  static constexpr int CH = 32 * WM;                        // rows of one epilogue chunk (block i of every consumer wave)
+  static constexpr int LDC = kRBN + 4;
+  static constexpr int kEpi = CH * LDC * 4 + 12 * 2 * kRBN * 4;
+  static constexpr int kSmem = kRing > kEpi ? kRing : kEpi;
+};
+
+// A: fp32 rows [M][K], formed on load (forward: relu(bn(y)); data gradient: ga*(g-gmean)+gb*(y-mean)); Bq: two fp16 planes
+// [K/16][Nout][16] (chunk-swizzled) of the weights scaled by pow2_scale(*wmax).  Tile t: rows [by*RT, min((by+1)*RT, M)),
+// columns [bx*256, +256); part[by][2][Nout].
+template <int RBLK, int MODE, typename T, typename TO>
+__global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restrict__ bnA,
+                                               const uint16_t* __restrict__ Bq, const float* __restrict__ wmax, TO* __restrict__ out,
+                                               const T* __restrict__ E0, const float* __restrict__ bnE, float* __restrict__ part, int64_t M,
+                                               int K, int Nout, int RT) {
+  using G = RGeo<RBLK>;
+  constexpr int RB = G::RB, WM = G::WM, WN = G::WN, TM = G::TM, TN = G::TN, APL = G::APL, BPL = G::BPL, kStr = G::kStr;
+  constexpr bool FWD = MODE == RMODE_FWD;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[G::kSmem];
+
+  const int tid = threadIdx.x;
+  // XCD-aware tile order: every XCD gets a contiguous range of tiles, so the column tiles of one row block (same A rows) run
+  // side by side on one L2
+  const unsigned Gd = gridDim.x, Lid = blockIdx.x, NB = Nout / kRBN;
+  const unsigned xq = Gd / 8, xr = Gd % 8, xcd = Lid % 8;
+  const unsigned tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + Lid / 8;
+  const unsigned bx = tile % NB, by = tile / NB;
+  const int64_t m0 = (int64_t)by * RT;
+  const int64_t m_end = m0 + RT < M ? m0 + RT : M;
+  const int n0 = bx * kRBN;
+  const int nks = K / 32;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float sa = pow2_scale(bnA[(size_t)TTK_BN_AUX * K + (FWD ? TTK_AUX_ACT_BOUND : TTK_AUX_DY_BOUND)]);
+  const float sb = pow2_scale(*wmax);
+  f32x16 acc[TM][TN];  // consumer waves only
+
+  if (wave >= 8) {
+    // ---------------- producers: A through registers (BatchNorm form, split, ds_write), B by LDS-DMA ----------------
+    __builtin_amdgcn_s_setprio(3);
+    const int pt = tid - 512, pw = wave - 8, lane = tid & 63;
+    const int row0 = pt >> 3, kq8 = pt & 7;  // 32 rows per pass; 8 lanes x 16 B = one 128-byte row segment
+    const int sub = kq8 >> 2, chunk = (kq8 >> 1) & 1, o8 = (kq8 & 1) * 8;
+    constexpr int AP = RBLK;
+    constexpr int NQ = FWD ? 3 : 4;
+    constexpr int NLOADS = (FWD ? AP : 2 * AP) + NQ;  // global loads a producer thread issues per stage (behind its LDS-DMAs)
+    f32x4 ra0[AP], ra1[FWD ? 1 : AP], q[NQ];
+    int64_t arow[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const int64_t row = m0 + row0 + 32 * i;
+      arow[i] = (row < m_end ? row : m_end - 1) * (int64_t)K + kq8 * 4;  // clamp: rows past the block are computed but never stored
+    }
+    const float* cp = bnA + kq8 * 4;
+    unsigned char* wbase = lds + sub * kStr + o8;
+    // LDS-DMA: this wave moves piece plane (pw & 1) of k16 stage (pw >> 1) of every k32 step: 8 pieces of 1 KB (32 rows x 32 B)
+    const int64_t bplane = (int64_t)K * Nout;
+    const uint16_t* bsrc = Bq + (pw & 1) * bplane + ((int64_t)(pw >> 1) * Nout + n0) * 16 + lane * 8;
+    const int bdst = (pw >> 1) * kStr + 2 * APL + (pw & 1) * BPL;
+
+    auto load_a = [&](int ks) {
+      const int kc0 = ks * 32;
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        ra0[i] = rld_act4<TO>(A0 + arow[i] + kc0);
+        if constexpr (!FWD) ra1[i] = rld_act4<T>(A1 + arow[i] + kc0);
+      }
+      if constexpr (FWD) {
+        q[0] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_SCALE * K + kc0);
+        q[1] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * K + kc0);
+        q[2] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_BETA * K + kc0);
+      } else {
+        q[0] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GA * K + kc0);
+        q[1] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GMEAN * K + kc0);
+        q[2] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GB * K + kc0);
+        q[3] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * K + kc0);
+      }
+    };
+    auto dma_b = [&](int ks) {  // weight planes of k32 step ks -> ring slot ks & 1
+      const uint16_t* s = bsrc + (int64_t)ks * 2 * Nout * 16;
+      unsigned char* d = lds + (ks & 1) * 2 * kStr + bdst;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(s + j * 512),
+                                         (void __attribute__((address_space(3)))*)(d + j * 1024), 16, 0, 0);
+    };
+    auto store_a = [&](int ks) {
+      unsigned char* S = wbase + (ks & 1) * 2 * kStr;
+      const f32x4 c0 = q[0] * sa, c2 = q[2] * sa;  // the scale S_a rides on the per-channel constants (exact: a power of two)
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        f32x4 v;
+        if constexpr (FWD) {
+          v = c0 * (ra0[i] - q[1]) + c2;
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        } else {
+          v = c0 * (ra0[i] - q[1]) + c2 * (ra1[i] - q[NQ - 1]);
+        }
+        rsplit_store(v, S + rswz(row0 + 32 * i, chunk), APL);
+      }
+    };
+    // Stage s is consumed between barrier s and barrier s + 1 from slot s & 1; the producers fill stage s + 1 meanwhile.  Per
+    // step, in this order: A of the next stage from registers to LDS (its loads had a whole step), the stage's LDS-DMAs, the
+    // global loads of the stage after it - and a COUNTED wait that retires the DMAs (older) but leaves those loads in flight
+    // across the barrier (raw s_barrier: __syncthreads() would drain them).
+    dma_b(0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(0);
+    __builtin_amdgcn_sched_barrier(0);
+    store_a(0);  // (waits for everything issued so far: the first stage's DMAs and loads)
+    __builtin_amdgcn_sched_barrier(0);
+    if (nks > 1) load_a(1);  // in flight across the barrier
+    __builtin_amdgcn_sched_barrier(0);
+    rbarrier();  // stage 0 is in LDS
+    for (int s = 1; s < nks; ++s) {
+      store_a(s);  // (the compiler waits for the registers' loads here: they are the oldest outstanding operations)
+      __builtin_amdgcn_sched_barrier(0);
+      dma_b(s);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < nks) {
+        load_a(s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      rbarrier();  // stage s is in LDS; the consumers are done with stage s - 1
+    }
+    rbarrier();  // the consumers are done with the last stage: the ring is free for the epilogue
+  } else {
+    // ---------------- consumers: ds_read_b128 fragments + three piece products per block pair ----------------
+    const int lane = tid & 63, wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    constexpr bool HOLD_A = TM <= TN;  // hold the smaller fragment set of a k16 stage in registers, stream the other
+    constexpr int TH = HOLD_A ? TM : TN, TS = HOLD_A ? TN : TM;
+    constexpr int HPL = HOLD_A ? APL : BPL, SPL = HOLD_A ? BPL : APL;
+    int hold_off[TH], strm_off[TS];
+#pragma unroll
+    for (int x = 0; x < TH; ++x) hold_off[x] = HOLD_A ? rswz(wm * (32 * TM) + x * 32 + r, h) : 2 * APL + rswz(wn * (32 * TN) + x * 32 + r, h);
+#pragma unroll
+    for (int x = 0; x < TS; ++x) strm_off[x] = HOLD_A ? 2 * APL + rswz(wn * (32 * TN) + x * 32 + r, h) : rswz(wm * (32 * TM) + x * 32 + r, h);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    f16x8 hold[TH][2], strm[2][2];
+    rbarrier();  // stage 0 is in LDS
+    for (int it = 0; it < nks; ++it) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const unsigned char* S = lds + ((it & 1) * 2 + sub) * kStr;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+          for (int x = 0; x < TH; ++x) hold[x][p] = *reinterpret_cast<const f16x8*>(S + p * HPL + hold_off[x]);
+          strm[0][p] = *reinterpret_cast<const f16x8*>(S + p * SPL + strm_off[0]);
+        }
+#pragma unroll
+        for (int x = 0; x < TS; ++x) {
+          const int cur = x & 1;
+          if (x + 1 < TS) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) strm[cur ^ 1][p] = *reinterpret_cast<const f16x8*>(S + p * SPL + strm_off[x + 1]);
+          }
+          // three piece products, smallest first; (pa, pb) index the A and B pieces (0 = h, 1 = l)
+#define TTK_RPROD(pa, pb)                                                                                     \
+  _Pragma("unroll") for (int y = 0; y < TH; ++y) {                                                            \
+    if constexpr (HOLD_A)                                                                                     \
+      acc[y][x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hold[y][pa], strm[cur][pb], acc[y][x], 0, 0, 0);     \
+    else                                                                                                      \
+      acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(strm[cur][pa], hold[y][pb], acc[x][y], 0, 0, 0);     \
+  }
+          TTK_RPROD(0, 1) TTK_RPROD(1, 0) TTK_RPROD(0, 0)
+#undef TTK_RPROD
+        }
+      }
+      rbarrier();  // done with stage `it` (its fragments are in registers, its slot may be refilled); stage it + 1 is in LDS
+    }
+  }
+  // ---------------- epilogue, all 12 waves: the tile leaves through LDS in TM chunks of CH rows (block c of every consumer
+  // wave) - un-scale, 16-byte stores (a wave writes 1 KB row segments), the data gradient's ReLU mask, BatchNorm sums ----------------
+  constexpr int LDC = G::LDC, CH = G::CH, QN = kRBN / 4;
+  float* Cs = reinterpret_cast<float*>(lds);
+  float* red = reinterpret_cast<float*>(lds + CH * LDC * 4);  // [12][2][256]
+  const int c4 = tid % QN, rg = tid / QN;  // 12 row groups
+  const int col = n0 + 4 * c4;
+  const float inv = 1.f / (sa * sb);  // exact: a power of two
+  float4 esc = f4(0.f), emean = f4(0.f), ebeta = f4(0.f);
+  if constexpr (!FWD) {
+    esc = ld4(bnE + TTK_BN_SCALE * Nout + col); emean = ld4(bnE + TTK_BN_MEAN * Nout + col); ebeta = ld4(bnE + TTK_BN_BETA * Nout + col);
+  }
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+#pragma unroll
+  for (int c = 0; c < TM; ++c) {
+    if (wave < 8) {
+      const int lane = tid & 63, wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Cs[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * (32 * TN) + j * 32 + r] = acc[c][j][e];
+    }
+    __syncthreads();  // chunk c is in LDS
+#pragma unroll 2
+    for (int cr = rg; cr < CH; cr += 12) {
+      const int64_t grow = m0 + (cr >> 5) * (32 * TM) + c * 32 + (cr & 31);  // chunk row -> tile row: block c of consumer row cr / 32
+      if (grow >= m_end) continue;
+      float4 v = ld4(Cs + cr * LDC + 4 * c4);
+      v = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+      const size_t o = (size_t)grow * Nout + col;
+      if constexpr (FWD) {
+        v = Act<TO>::round(v);  // statistics of what is stored
+        Act<TO>::st(out + o, v);
+        s1 = add4(s1, v);
+        s2 = fma4(v, v, s2);
+      } else {
+        const float4 yc = sub4(Act<T>::ld(E0 + o), emean);
+        v = Act<TO>::round(mask4(v, fma4(esc, yc, ebeta)));
+        Act<TO>::st(out + o, v);
+        s1 = add4(s1, v);
+        s2 = fma4(v, yc, s2);
+      }
+    }
+    __syncthreads();  // the row pass is done: the next chunk may be parked
+  }
+  if (part) {  // one row of partial sums per tile: 12 row groups folded in a fixed order
+    st4(red + (rg * 2 + 0) * kRBN + 4 * c4, s1);
+    st4(red + (rg * 2 + 1) * kRBN + 4 * c4, s2);
+    __syncthreads();
+    if (tid < 2 * kRBN) {
+      const int which = tid / kRBN, c = tid % kRBN;
+      float a = 0.f;
+#pragma unroll
+      for (int qq = 0; qq < 12; ++qq) a += red[(qq * 2 + which) * kRBN + c];
+      part[(size_t)by * 2 * Nout + (size_t)which * Nout + n0 + c] = a;
+    }
+  }
+}
+
+// ---- tiling: row blocks of RT rows such that the tiles fill whole rounds of the CUs ------------------------------------------
+bool f16r_enabled() {
+  static const bool on = [] { const char* e = getenv("TTK_GEMM_R"); return !(e && e[0] == '0'); }();
+  return on && gemm_mode() == GEMM_F16X2;
+}
+bool f16r_gemm_shape(int K, int Nout) { return f16r_enabled() && K >= 128 && K % 32 == 0 && Nout >= 256 && Nout % kRBN == 0; }
+
+struct RPlan { int rblk, rt, row_blocks; };
+// Cost of a tile round in cycles per CU: a k32 step costs the larger of its matrix time (384 cycles per 32-row block)
+// and the time its bytes take through the CU (A rows from HBM at ~12 B/clk, 32 KB of weight planes from L2 at ~35 B/clk); the
+// epilogue writes (and, for the data gradient, reads) RT x 256 floats.
+static RPlan r_plan(int64_t M, int K, int Nout) {
+  const char* fe = getenv("TTK_R_RBLK");  // 4 | 6 | 8: force the tile's row blocks (tests, A/B timing); read per call
+  const int force = fe ? atoi(fe) : 0;
+  static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+  const int ct = Nout / kRBN, steps = K / 32;
+  RPlan best{0, 0, 0};
+  double best_cost = 1e300;
+  for (int rblk = 4; rblk <= 8; rblk += 2) {
+    if (force && rblk != force) continue;
+    const int RB = 32 * rblk;
+    for (int r = 1; r <= 4096; ++r) {
+      const int64_t rb = (int64_t)cus * r / ct;  // row blocks that fit into r rounds
+      if (rb < 1) continue;
+      int64_t rt = ceil_div(M, rb);
+      if (rt > RB) continue;
+      if (rt < 32) rt = 32;
+      const int64_t row_blocks = ceil_div(M, rt);
+      const double tiles = (double)row_blocks * ct, rounds = (double)ceil_div((int64_t)tiles, cus);
+      const double step = fmax(384.0 * rblk, rt * 128.0 / 12.0 + 32768.0 / 35.0);
+      const double cost = rounds * (steps * step + rt * 1024.0 / 10.0 + 3000.0);
+      if (cost < best_cost) { best_cost = cost; best = RPlan{rblk, (int)rt, (int)row_blocks}; }
+      break;  // more rounds of smaller tiles only add per-tile overhead
+    }
+  }
+  return best;
+}
+int f16r_partial_rows(int64_t M, int K, int Nout) { return f16r_gemm_shape(K, Nout) ? r_plan(M, K, Nout).row_blocks : 0; }
+
+// w[rows][K] fp32 -> two fp16 planes [K/16][rows][16] (16-byte chunks of a row swapped where (row >> 3) & 1) of w * pow2_scale(*wmax)
+__global__ void w16r_split_k(const float* __restrict__ w, uint16_t* __restrict__ q, const float* __restrict__ wmax, int rows, int K) {
+  const int64_t n = (int64_t)rows * K;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float s = pow2_scale(*wmax);
+  const int row = (int)(i / K), k = (int)(i - (int64_t)row * K);
+  const int64_t o = r_plane_index(row, k, rows);
+  const float x = w[i] * s;
+  const _Float16 hh = (_Float16)x;
+  const _Float16 ll = (_Float16)(x - (float)hh);
+  q[o] = __builtin_bit_cast(uint16_t, hh);
+  q[n + o] = __builtin_bit_cast(uint16_t, ll);
+}
+__global__ void __launch_bounds__(256) w16r_absmax_k(const float* __restrict__ w, int64_t n, unsigned* __restrict__ wmax) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > __hip_atomic_load(wmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(wmax, __float_as_uint(m));
+}
+
+// Returns true when the shape was handled here (kernels launched on `st`).  Bm != nullptr: raw weight rows [Nout][K] that are split
+// into `planes` first (per-call form, unit tests); wmax: the layer's |w| maximum (a device float the per-call form computes itself).
+template <int MODE, typename T, typename TO>
+bool launch_f16r_gemm(const TO* A0, const T* A1, const float* bnA, const float* Bm, TO* out, const T* E0, const float* bnE, float* part,
+                      int64_t M, int K, int Nout, void* planes, float* wmax, hipStream_t st) {
+  if (!planes || !wmax || !f16r_gemm_shape(K, Nout)) return false;
+  uint16_t* Bq = reinterpret_cast<uint16_t*>(planes);
+  const int64_t nw = (int64_t)Nout * K;
+  if (Bm) {
+    (void)hipMemsetAsync(wmax, 0, sizeof(float), st);
+    hipLaunchKernelGGL(w16r_absmax_k, dim3((unsigned)(nw / 1024 < 1 ? 1 : (nw / 1024 > 256 ? 256 : nw / 1024))), dim3(256), 0, st, Bm, nw,
+                       reinterpret_cast<unsigned*>(wmax));
+    hipLaunchKernelGGL(w16r_split_k, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, st, Bm, Bq, wmax, Nout, K);
+  }
+  const RPlan pl = r_plan(M, K, Nout);
+  const unsigned tiles = (unsigned)pl.row_blocks * (Nout / kRBN);
+#define TTK_R_LAUNCH(RBLK_) \
+  hipLaunchKernelGGL((pw16r_k<RBLK_, MODE, T, TO>), dim3(tiles), dim3(768), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout, pl.rt)
+  if (pl.rblk == 4) TTK_R_LAUNCH(4);
+  else if (pl.rblk == 6) TTK_R_LAUNCH(6);
+  else TTK_R_LAUNCH(8);
+#undef TTK_R_LAUNCH
+  return true;
+}
+
+#define TTK_RINST(T_, TG_)                                                                                                                \
+  template bool launch_f16r_gemm<RMODE_FWD, T_, T_>(const T_*, const T_*, const float*, const float*, T_*, const T_*, const float*, float*, \
+                                                    int64_t, int, int, void*, float*, hipStream_t);                                         \
+  template bool launch_f16r_gemm<RMODE_DGRAD, T_, TG_>(const TG_*, const T_*, const float*, const float*, TG_*, const T_*, const float*,    \
+                                                       float*, int64_t, int, int, void*, float*, hipStream_t);
+TTK_RINST(float, float)
+TTK_RINST(bf16_t, bf16_t)
+template bool launch_f16r_gemm<RMODE_DGRAD, bf16_t, float>(const float*, const bf16_t*, const float*, const float*, float*, const bf16_t*, const float*,
+                                                           float*, int64_t, int, int, void*, float*, hipStream_t);
+#undef TTK_RINST
+
+}  // namespace ttk

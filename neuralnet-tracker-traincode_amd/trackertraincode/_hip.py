@@ -90,7 +90,7 @@ _SIGNATURES = {
     "ttk_stream_probe": [_P, _P, _P, _L, _I, _I, _I, _I, _L, _I, _I, _I],
 }
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class LossOp(ctypes.Structure):
@@ -133,6 +133,7 @@ class _Library:
         for name in ("ttk_partial_rows_elementwise", "ttk_partial_rows_gemm"):
             fn = getattr(self.cdll, name)
             fn.argtypes, fn.restype = [c_int64], c_int
+        self.cdll.ttk_partial_rows_pwconv.argtypes, self.cdll.ttk_partial_rows_pwconv.restype = [c_int64, c_int, c_int], c_int
         self.cdll.ttk_heads_num_rows.argtypes, self.cdll.ttk_heads_num_rows.restype = [c_int, c_int, c_int], c_int
         self.cdll.ttk_pwconv_prepared_bytes.argtypes, self.cdll.ttk_pwconv_prepared_bytes.restype = [c_int, c_int], ctypes.c_size_t
         self.cdll.ttk_partial_rows_dwconv.argtypes, self.cdll.ttk_partial_rows_dwconv.restype = [c_int] * 6, c_int
@@ -234,8 +235,12 @@ class _Library:
     def partial_rows_dwconv(self, B, H, W, C, stride, backward) -> int:
         return self.cdll.ttk_partial_rows_dwconv(B, H, W, C, stride, int(backward))
 
-    def partial_rows_gemm(self, m: int) -> int:
-        return self.cdll.ttk_partial_rows_gemm(m)
+    def partial_rows_gemm(self, m: int, k: int | None = None, nout: int | None = None) -> int:
+        """Rows of BatchNorm partial sums a GEMM epilogue writes for m rows.  With (k, nout): of ttk_pwconv1x1_fwd (k = Cin, nout = Cout) /
+        ttk_pwconv1x1_bwd_data (k = Cout, nout = Cin), whose tiling depends on the shape; without: the 128-row form (convolutions)."""
+        if k is None:
+            return self.cdll.ttk_partial_rows_gemm(m)
+        return self.cdll.ttk_partial_rows_pwconv(m, k, nout)
 
 
 _lib: _Library | None = None
@@ -261,6 +266,6 @@ def ptr(t: torch.Tensor | None):
 
 def exported_symbols() -> list[str]:
     return ["ttk_abi_version", "ttk_last_error_string", "ttk_clear_error", "ttk_partial_rows_elementwise",
-            "ttk_partial_rows_gemm", "ttk_partial_rows_dwconv", "ttk_heads_num_rows", "ttk_pwconv_prepared_bytes",
+            "ttk_partial_rows_gemm", "ttk_partial_rows_pwconv", "ttk_partial_rows_dwconv", "ttk_heads_num_rows", "ttk_pwconv_prepared_bytes",
             "ttk_pwconv_wgrad_partial_bytes", "ttk_stem_wgrad_partial_bytes", "ttk_conv_wgrad_partial_bytes", "ttk_stem7_wgrad_partial_bytes",
             "ttk_pwconv1x1_bwd_fused_rows", "ttk_pwconv1x1_bwd_fused_partial_bytes"] + list(_SIGNATURES)

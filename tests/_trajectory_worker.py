@@ -7,13 +7,16 @@ Reference loop: trackertraincode/train.py:372-439, scripts/train_poseestimator.p
 
 Prints one line "RESULT <json>": per step |loss_sum difference| and the largest per-sample loss difference, after the
 last step the BatchNorm running statistics' and the parameters' distance.
-usage: _trajectory_worker.py <repo> <cfg> <B> <steps> <loss epoch> <dtype of the oracle: float32|float64>
+With `f64` the walk is also made by the oracle in float64, and the distances HIP <-> fp64 and fp32 oracle <-> fp64 are reported:
+how far two fp32 implementations of the same loop part from one another is the yardstick for the HIP walk's distance.
+usage: _trajectory_worker.py <repo> <cfg> <B> <steps> <loss epoch> <epochs of the lr schedule> <lr epoch> <f64|nof64>
 """
 import json
 import os
 import sys
 
-repo, cfg, B, K, epoch, odt = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+repo, cfg, B, K, epoch = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+LR_EPOCHS, LR_EPOCH, with_f64 = int(sys.argv[6]), int(sys.argv[7]), sys.argv[8] == "f64"
 for p_ in (repo, repo + "/neuralnet-tracker-traincode_amd", repo + "/tests"):
     sys.path.insert(0, p_)
 import numpy as np  # noqa: E402
@@ -26,7 +29,9 @@ from test_oracle_golden import _batches, _criterions  # noqa: E402
 from util import GOLDEN, build_net, load_golden, make_batches, script_args, train_script  # noqa: E402
 import trackertraincode.train as train  # noqa: E402
 
-LR_EPOCHS, LR_EPOCH = 20, 5  # schedule position of both optimisers: past the warm-up, factor 1 -> the full lr 1e-3
+# schedule position of both optimisers (ExponentialUpThenSteps over LR_EPOCHS epochs, at epoch LR_EPOCH): (200, 0) = the first epoch
+# of the training script's default run, lr 1.26e-5; (20, 5) = past the warm-up, the full lr 1e-3
+LR0 = 1.0e-3 * R.lr_factor(LR_EPOCH, LR_EPOCHS)
 _, meta = load_golden(f"model_{cfg}.npz")
 meta = dict(meta, B=B, split=(B * 5) // 8)
 S = train_script()
@@ -41,7 +46,7 @@ with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     for _ in range(LR_EPOCH):
         sch.step()
-assert abs(opt.param_groups[0]["lr"] - 1.0e-3) < 1e-12, opt.param_groups[0]["lr"]
+assert abs(opt.param_groups[0]["lr"] - LR0) < 1e-12 * max(1.0, LR0), (opt.param_groups[0]["lr"], LR0)
 batches = make_batches(meta, "cuda")
 hip_loss, hip_vals, hip_norm = [], [], []
 for it in range(K):
@@ -57,54 +62,71 @@ hip_state = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
 del net, opt, out
 torch.cuda.empty_cache()
 
-# ---- oracle trajectory (CPU)
-dtype = getattr(torch, odt)
+# ---- oracle trajectories (CPU): fp32 = the reference's arithmetic; fp64 (optional) = the yardstick for how far two fp32 walks may part
 shapes = {k: tuple(v) for k, v in meta["shapes"].items()}
-st = {}
-for k, v in make_state(shapes, meta["state_seed"]).items():
-    t = torch.from_numpy(np.array(v))
-    t = t.to(dtype) if t.is_floating_point() else t
-    st[k] = t.requires_grad_(True) if not R.is_buffer(k) else t
-init = {k: v.detach().clone().double() for k, v in st.items()}
 ocrit, _ = _criterions(meta, GOLDEN)
-oopt = R.ClipAdam(st, lr=1.0e-3, epochs=LR_EPOCHS)
-oopt.epoch = LR_EPOCH
-assert all(abs(a - b) < 1e-12 for a, b in zip(oopt.lrs(), (1.0e-3, 1.0e-4)))
 image, ids = make_inputs(B, seed=meta["input_seed"])
-x, ids_t = torch.from_numpy(image).to(dtype), torch.from_numpy(ids)
-obatches = [{k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in b.items()} for b in _batches(meta)]
-res = dict(cfg=cfg, B=B, steps=K, oracle=odt, loss_hip=hip_loss, loss_oracle=[], dloss=[], dsample=[], gnorm_hip=hip_norm, gnorm_oracle=[])
-for it in range(K):
-    oopt.zero_grad()
-    o, _ = R.network_forward(st, x, ids_t, meta["config"], True)
-    loss, by_name = R.compute_loss(o, obatches, epoch, ocrit)
-    loss.backward()
-    res["gnorm_oracle"].append(float(oopt.step()))
-    res["loss_oracle"].append(float(loss.item()))
-    res["dloss"].append(abs(hip_loss[it] - float(loss.item())))
-    assert list(by_name.keys()) == list(hip_vals[it].keys())
-    res["dsample"].append(max(float((hip_vals[it][n] - v[0].detach().double()).abs().max()) for n, v in by_name.items()))
-    del o, loss, by_name
 
-# ---- after the last step
-run_rel, par_abs, par_rel, moved = 0.0, 0.0, 0.0, 0.0
-worst_run, worst_par = "", ""
-for k, v in st.items():
-    a, b = hip_state[k], v.detach().double()
-    if k.endswith("num_batches_tracked"):
-        assert int(a) == int(b) == K, (k, int(a), int(b))
-    elif "running_" in k:
-        e = float(((a - b).abs() / (b.abs() + 1e-2 * float(b.abs().max()) + 1e-30)).max())
-        if e > run_rel:
-            run_rel, worst_run = e, k
-    elif not R.is_buffer(k):
-        d = float((a - b).abs().max())
-        if d > par_abs:
-            par_abs, worst_par = d, k
-        step_len = float((b - init[k]).norm())
-        moved = max(moved, float((b - init[k]).abs().max()))
-        if step_len > 0:
-            par_rel = max(par_rel, float((a - b).norm()) / step_len)
-res.update(running_rel=run_rel, worst_running=worst_run, param_abs=par_abs, worst_param=worst_par, param_rel_to_path=par_rel,
-           largest_param_move=moved)
+
+def oracle_walk(dtype):
+    st = {}
+    for k, v in make_state(shapes, meta["state_seed"]).items():
+        t = torch.from_numpy(np.array(v))
+        t = t.to(dtype) if t.is_floating_point() else t
+        st[k] = t.requires_grad_(True) if not R.is_buffer(k) else t
+    init = {k: v.detach().clone().double() for k, v in st.items()}
+    oopt = R.ClipAdam(st, lr=1.0e-3, epochs=LR_EPOCHS)
+    oopt.epoch = LR_EPOCH
+    assert abs(oopt.lrs()[0] - LR0) < 1e-12 * max(1.0, LR0), (oopt.lrs(), LR0)
+    x, ids_t = torch.from_numpy(image).to(dtype), torch.from_numpy(ids)
+    obatches = [{k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in b.items()} for b in _batches(meta)]
+    losses, vals, norms = [], [], []
+    for it in range(K):
+        oopt.zero_grad()
+        o, _ = R.network_forward(st, x, ids_t, meta["config"], True)
+        loss, by_name = R.compute_loss(o, obatches, epoch, ocrit)
+        loss.backward()
+        norms.append(float(oopt.step()))
+        losses.append(float(loss.item()))
+        vals.append({n: v[0].detach().double().clone() for n, v in by_name.items()})
+        del o, loss, by_name
+    return losses, vals, norms, {k: v.detach().double().clone() for k, v in st.items()}, init
+
+
+def sample_dist(a, b):  # largest per-sample loss difference of one step
+    assert list(a.keys()) == list(b.keys())
+    return max(float((a[n] - b[n]).abs().max()) for n in a)
+
+
+def state_dist(a, b, init):
+    run_rel, par_abs, par_rel, moved, worst_run, worst_par = 0.0, 0.0, 0.0, 0.0, "", ""
+    for k, v in b.items():
+        x, y = a[k], v
+        if k.endswith("num_batches_tracked"):
+            assert int(x) == int(y) == K, (k, int(x), int(y))
+        elif "running_" in k:
+            e = float(((x - y).abs() / (y.abs() + 1e-2 * float(y.abs().max()) + 1e-30)).max())
+            if e > run_rel:
+                run_rel, worst_run = e, k
+        elif not R.is_buffer(k):
+            d = float((x - y).abs().max())
+            if d > par_abs:
+                par_abs, worst_par = d, k
+            step_len = float((y - init[k]).norm())
+            moved = max(moved, float((y - init[k]).abs().max()))
+            if step_len > 0:
+                par_rel = max(par_rel, float((x - y).norm()) / step_len)
+    return dict(running_rel=run_rel, worst_running=worst_run, param_abs=par_abs, worst_param=worst_par, param_rel_to_path=par_rel, largest_param_move=moved)
+
+
+l32, v32, n32, s32, init = oracle_walk(torch.float32)
+res = dict(cfg=cfg, B=B, steps=K, lr=LR0, loss_hip=hip_loss, loss_oracle=l32, gnorm_hip=hip_norm, gnorm_oracle=n32,
+           dloss=[abs(a - b) for a, b in zip(hip_loss, l32)], dsample=[sample_dist(hip_vals[i], v32[i]) for i in range(K)])
+res.update(state_dist(hip_state, s32, init))
+if with_f64:
+    l64, v64, n64, s64, _ = oracle_walk(torch.float64)
+    res.update(dloss_hip_64=[abs(a - b) for a, b in zip(hip_loss, l64)], dloss_cpu32_64=[abs(a - b) for a, b in zip(l32, l64)],
+               dsample_hip_64=[sample_dist(hip_vals[i], v64[i]) for i in range(K)], dsample_cpu32_64=[sample_dist(v32[i], v64[i]) for i in range(K)])
+    res["state_hip_64"] = state_dist(hip_state, s64, init)
+    res["state_cpu32_64"] = state_dist(s32, s64, init)
 print("RESULT " + json.dumps(res))

@@ -48,7 +48,7 @@ def test_pointwise_kernels_with_bf16_storage(M, Cin, Cout, flag):
     bn_dw[BN_AUX, 0] = np.abs(a64).max() * 3
     y64 = a64 @ w.astype(np.float64).T
     d_w, d_bn = torch.from_numpy(w).to(DEV), torch.from_numpy(bn_dw).to(DEV)
-    rows = L.partial_rows_gemm(M)
+    rows = L.partial_rows_gemm(M, Cin, Cout)
     y = torch.empty(M, Cout, device=DEV, dtype=torch.bfloat16)
     part = torch.full((rows, 2, Cout), float("nan"), device=DEV)
     wq = torch.empty(L.pwconv_prepared_bytes(Cin, Cout), dtype=torch.uint8, device=DEV)
@@ -67,7 +67,7 @@ def test_pointwise_kernels_with_bf16_storage(M, Cin, Cout, flag):
     gd64 = (dy64 @ w.astype(np.float64)) * (pre > 0)
     wt = torch.from_numpy(np.ascontiguousarray(w.T)).to(DEV)
     g_dw = torch.empty(M, Cin, device=DEV, dtype=gdt)
-    part2 = torch.full((rows, 2, Cin), float("nan"), device=DEV)
+    part2 = torch.full((L.partial_rows_gemm(M, Cout, Cin), 2, Cin), float("nan"), device=DEV)
     d_bnpw = torch.from_numpy(bn_pw).to(DEV)
     L.call("ttk_pwconv1x1_bwd_data", p(g), p(y), p(d_bnpw), p(wt), p(ydw), p(d_bn), p(g_dw), p(part2), M, Cin, Cout, p(wq), flag)
     torch.cuda.synchronize()

@@ -42,7 +42,10 @@ def _rel(a, b):
 
 # (M, Cin, Cout): split-kernel tiles 128x256 and 256x128, ragged M, the fp32-MFMA shapes, wide K
 SHAPES = [(648, 512, 512), (1000, 128, 256), (4100, 256, 256), (300, 1024, 1024), (777, 256, 128), (2049, 512, 128),
-          (648, 64, 128), (1234, 32, 64), (5000, 128, 128), (128, 512, 1024)]
+          (648, 64, 128), (1234, 32, 64), (5000, 128, 128), (128, 512, 1024),
+          # row-block kernels (csrc/pwconv_r.hip) at tile heights their cost model picks by itself: 162 of 192 rows (two column tiles:
+          # one full round of 256 CUs), 200 of 256 rows, 193-row blocks with a ragged last one
+          (20736, 512, 512), (12800, 256, 1024), (49601, 128, 256)]
 
 
 # LOOSE: how far the operand bounds of row TTK_BN_AUX lie above the true maxima (the step's own bounds are 1-100x loose)
@@ -57,7 +60,7 @@ def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout, loose):
     bn_dw, bn_pw = _bn_block(Cin, rng), _bn_block(Cout, rng)
     dev = "cuda"
     t = lambda a: torch.from_numpy(a).to(dev)
-    rows = L.partial_rows_gemm(M)
+    rows, rows_b = L.partial_rows_gemm(M, Cin, Cout), L.partial_rows_gemm(M, Cout, Cin)  # forward: K = Cin, N = Cout; data gradient: K = Cout, N = Cin
 
     # ---- forward: y = relu(scale*(ydw-mean)+beta) @ w^T ; partial sums of y and y^2 per column
     a32 = np.maximum(bn_dw[BN_SCALE] * (ydw - bn_dw[BN_MEAN]) + bn_dw[BN_BETA], 0).astype(np.float32)
@@ -90,7 +93,7 @@ def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout, loose):
     gd32 = _chain32(dy32, w) * mask
     wt = torch.from_numpy(np.ascontiguousarray(w.T)).to(dev)
     g_dw = torch.empty(M, Cin, device=dev)
-    part2 = torch.full((rows, 2, Cin), float("nan"), device=dev)
+    part2 = torch.full((rows_b, 2, Cin), float("nan"), device=dev)
     d_g, d_bnpw = t(g), t(bn_pw)  # named: a temporary would be recycled by the allocator before the kernel runs
     L.call("ttk_pwconv1x1_bwd_data", p(d_g), p(y), p(d_bnpw), p(wt), p(d_ydw), p(d_bn), p(g_dw), p(part2), M, Cin, Cout, p(wq), 0)
     torch.cuda.synchronize()
@@ -128,6 +131,15 @@ def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout, loose):
         assert _rel(runs[0].cpu().numpy(), dw64) <= 1.5 * e_f32 + 1e-7
 
 
+@pytest.mark.parametrize("rblk", [4, 6, 8])
+@pytest.mark.parametrize("M,Cin,Cout", [(5000, 256, 512), (1111, 512, 256)])
+def test_row_block_gemm_every_tile_height(M, Cin, Cout, rblk, monkeypatch):
+    """pw16r_k at each of its three tile heights (TTK_R_RBLK forces what the cost model would pick from the shape): forward and
+    data gradient against float64, partial sums, ragged last row block."""
+    monkeypatch.setenv("TTK_R_RBLK", str(rblk))
+    test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout, 1.0)
+
+
 def test_prepared_weights_match_per_call_split():
     """ttk_pwconv_prepare_weights (all layers, one launch) feeds the same kernels the same operand bits as the
     per-call split/transposition: outputs are bit-identical."""
@@ -145,14 +157,14 @@ def test_prepared_weights_match_per_call_split():
         bn_dw, bn_pw = _bn_block(Cin, rng), _bn_block(Cout, rng)
         bn_dw[BN_AUX, AUX_ACT_BOUND], bn_pw[BN_AUX, AUX_DY_BOUND] = 12.0, 40.0  # generous for N(0,1) data with these constants
         bn_dw, bn_pw = torch.from_numpy(bn_dw).to(dev), torch.from_numpy(bn_pw).to(dev)
-        rows = L.partial_rows_gemm(M)
+        rows, rows_b = L.partial_rows_gemm(M, Cin, Cout), L.partial_rows_gemm(M, Cout, Cin)
         wq = torch.empty(L.pwconv_prepared_bytes(Cin, Cout), dtype=torch.uint8, device=dev)
         wt = w.reshape(Cout, Cin).t().contiguous()
         out = []
         for prepared in (False, True):
             y, part = torch.empty(M, Cout, device=dev), torch.zeros(rows, 2, Cout, device=dev)
             L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None if prepared else p(w), p(y), p(part), M, Cin, Cout, p(q if prepared else wq), 0)
-            gd, part2 = torch.empty(M, Cin, device=dev), torch.zeros(rows, 2, Cin, device=dev)
+            gd, part2 = torch.empty(M, Cin, device=dev), torch.zeros(rows_b, 2, Cin, device=dev)
             L.call("ttk_pwconv1x1_bwd_data", p(g), p(y), p(bn_pw), None if prepared else p(wt), p(ydw), p(bn_dw), p(gd), p(part2), M, Cin, Cout,
                    p(q if prepared else wq), 0)
             torch.cuda.synchronize()
@@ -209,7 +221,7 @@ def test_fused_bwd_matches_fp64_and_the_two_kernels(M, Cin, Cout):
     np.testing.assert_allclose(ps[:, 1].sum(0), (o64 * yc).sum(0), rtol=0, atol=3e-5 * np.abs(o64 * yc).sum(0).max())
     # the two kernels it replaces compute the same fp32 arithmetic (exact products, fp32 accumulation, another summation order)
     g_dw2 = torch.empty(M, Cin, device=dev)
-    part2 = torch.empty(L.partial_rows_gemm(M), 2, Cin, device=dev)
+    part2 = torch.empty(L.partial_rows_gemm(M, Cout, Cin), 2, Cin, device=dev)
     dw2 = torch.zeros(Cout, Cin, device=dev)
     wt = d_w.t().contiguous()
     wq2 = torch.empty(L.pwconv_prepared_bytes(Cin, Cout), dtype=torch.uint8, device=dev)  # (named: see above)

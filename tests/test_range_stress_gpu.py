@@ -100,7 +100,7 @@ def test_pwconv_entry_points_under_heavy_tails_and_loose_bounds(M, Cin, Cout, ws
     bound_a, bound_g, bound_w = float(ydw.max()) * loose, float(np.abs(g).max()) * loose, float(np.abs(w).max())  # (the weights' bound is their measured maximum)
     bn_dw[BN_AUX, AUX_ACT_BOUND], bn_pw[BN_AUX, AUX_DY_BOUND] = bound_a, bound_g
     d_ydw, d_w, d_bndw, d_bnpw, d_g = t(ydw), t(w), t(bn_dw), t(bn_pw), t(g)
-    rows = L.partial_rows_gemm(M)
+    rows, rows_b = L.partial_rows_gemm(M, Cin, Cout), L.partial_rows_gemm(M, Cout, Cin)
     probes = range(len(PROBES))
 
     y = torch.empty(M, Cout, device=dev)
@@ -112,7 +112,7 @@ def test_pwconv_entry_points_under_heavy_tails_and_loose_bounds(M, Cin, Cout, ws
 
     wt = t(w.T)
     g_dw = torch.empty(M, Cin, device=dev)
-    part2 = torch.empty(rows, 2, Cin, device=dev)
+    part2 = torch.empty(rows_b, 2, Cin, device=dev)
     y0 = torch.zeros(M, Cout, device=dev)  # gb = 0: the conv output does not enter dy
     L.call("ttk_pwconv1x1_bwd_data", p(d_g), p(y0), p(d_bnpw), p(wt), p(d_ydw), p(d_bndw), p(g_dw), p(part2), M, Cin, Cout, p(wq), 0)
     torch.cuda.synchronize()

@@ -3,15 +3,25 @@
 Every other parity test is ONE step; this one walks five optimiser steps of the real loop at BASELINE config 2's batch
 (B = 256): forward -> multi-task loss -> backward -> global-norm clip -> Adam -> the NEXT forward with the updated weights and
 BatchNorm running statistics, on the HIP path (TTK_DETERMINISTIC=1: fixed-order weight-gradient reductions, so the walk is
-reproducible) and on the oracle (fp32 torch CPU kernels = the reference's arithmetic) from identical weights and inputs,
-at the full learning rate 1e-3 (variance heads 1e-4).  Reference: trackertraincode/train.py:372-439,
-scripts/train_poseestimator.py:147-167,442-454.
+reproducible) and on the oracle (fp32 torch CPU kernels = the reference's arithmetic) from identical weights and inputs.
+Reference: trackertraincode/train.py:372-439, scripts/train_poseestimator.py:147-167,442-454.
 
-Criteria: every step's loss_sum and every per-sample loss within 1e-3; BatchNorm running statistics after the last step
-within 2e-4 (relative, with a floor of 1 % of the tensor's largest entry); the gradient norm Adam clipped by within 1e-3
-relative.  The parameter drift is REPORTED and bounded loosely: Adam's first updates are lr * g / (|g| + eps) = +-lr for
-every element, so an element whose gradient is rounding noise around zero moves by +-lr per step in either fp32
-implementation - the bound is K * 2 * lr per element, the typical distance is printed."""
+What "parity" can mean over several steps.  Adam's first updates are lr * g / (|g| + eps): +-lr for EVERY element whose gradient is
+above eps, a fraction of it below.  An element whose gradient is rounding noise around zero therefore moves differently in ANY
+two fp32 implementations of the loop, the difference (<= 2 lr per element and step) changes single samples' losses at the next
+forward by far more than the 1e-3 that holds on identical weights, and the walks part chaotically from there (measured: the
+oracle's own fp32 walk against its float64 walk, B = 256, lr 1e-3: per-sample losses 9e-2 apart after ONE update, 1.2 after three).
+So the yardstick is measured in the same run - fp32 oracle walk vs float64 oracle walk - and the HIP walk is held to it:
+
+ * step 0 (identical weights): loss_sum within 1e-4 and every per-sample loss within 1e-3 of the fp32 oracle - the single-step bar;
+ * every later step t: the HIP walk's distance to the float64 walk (loss_sum, largest per-sample loss difference) is at most
+   3 x the largest distance the fp32 oracle walk has shown up to step t, + 1e-3;
+ * after step 5: BatchNorm running statistics and parameters likewise (3 x the fp32 oracle's distance + 2e-4 / + 1e-3 of the path walked),
+   parameters never further than 5 * 2 * lr from the float64 walk's.
+
+Two schedule positions: the first steps of the training script's default run (ExponentialUpThenSteps over 200 epochs, epoch 0:
+lr 1.26e-5 - there loss_sum must ALSO stay within 1e-3 of the fp32 oracle at every step, measured 3e-5) and the full learning
+rate 1e-3 past the warm-up.  All distances are printed."""
 import json
 import os
 import subprocess
@@ -21,29 +31,58 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-K, LR = 5, 1.0e-3
+K = 5
 
 
-def _walk(cfg, B, epoch, oracle_dtype="float32"):
+def _walk(cfg, B, epoch, lr_epochs, lr_epoch, f64):
     env = dict(os.environ, TTK_DETERMINISTIC="1")
-    out = subprocess.run([sys.executable, os.path.join(REPO, "tests", "_trajectory_worker.py"), REPO, cfg, str(B), str(K), str(epoch), oracle_dtype],
-                         env=env, capture_output=True, text=True, timeout=1500)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tests", "_trajectory_worker.py"), REPO, cfg, str(B), str(K), str(epoch), str(lr_epochs), str(lr_epoch),
+                          "f64" if f64 else "nof64"], env=env, capture_output=True, text=True, timeout=2400)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
     return json.loads(line[len("RESULT "):])
 
 
-@pytest.mark.parametrize("cfg,epoch", [("default", 150), ("full", 150)])
-def test_five_step_trajectory_matches_oracle(cfg, epoch):
-    r = _walk(cfg, 256, epoch)
-    print(f"cfg={cfg} B=256: loss hip {['%.6f' % x for x in r['loss_hip']]} oracle {['%.6f' % x for x in r['loss_oracle']]}; "
-          f"|dloss| {['%.1e' % x for x in r['dloss']]}; per-sample {['%.1e' % x for x in r['dsample']]}; running stats {r['running_rel']:.1e} "
-          f"({r['worst_running']}); parameter drift max {r['param_abs']:.1e} ({r['worst_param']}), {r['param_rel_to_path']:.1e} of the path walked "
-          f"(largest move {r['largest_param_move']:.1e})")
+def _fmt(xs):
+    return "[" + " ".join("%.1e" % x for x in xs) + "]"
+
+
+def _report(r):
+    print(f"cfg={r['cfg']} B={r['B']} lr={r['lr']:.3g}: loss hip {['%.6f' % x for x in r['loss_hip']]} oracle {['%.6f' % x for x in r['loss_oracle']]}; "
+          f"|dloss| {_fmt(r['dloss'])}; per-sample {_fmt(r['dsample'])}; running stats {r['running_rel']:.1e} ({r['worst_running']}); "
+          f"parameter drift max {r['param_abs']:.1e} ({r['worst_param']}), {r['param_rel_to_path']:.1e} of the path walked (largest move {r['largest_param_move']:.1e})")
+
+
+def _check_against_yardstick(r):
+    h, c = r["state_hip_64"], r["state_cpu32_64"]
+    print(f"  against the float64 walk: per-sample hip {_fmt(r['dsample_hip_64'])} cpu32 {_fmt(r['dsample_cpu32_64'])}; loss_sum hip {_fmt(r['dloss_hip_64'])} "
+          f"cpu32 {_fmt(r['dloss_cpu32_64'])}; running stats hip {h['running_rel']:.1e} cpu32 {c['running_rel']:.1e}; parameters hip {h['param_abs']:.1e} / "
+          f"{h['param_rel_to_path']:.1e} of the path, cpu32 {c['param_abs']:.1e} / {c['param_rel_to_path']:.1e}")
     assert r["loss_hip"][-1] < r["loss_hip"][0]  # the walk goes downhill on a fixed batch
+    assert r["dloss"][0] < 1e-4 and r["dsample"][0] < 1e-3  # identical weights: the single-step criterion
+    assert abs(r["gnorm_hip"][0] - r["gnorm_oracle"][0]) < 1e-3 * r["gnorm_oracle"][0]
+    for it in range(K):
+        yard_s, yard_l = max(r["dsample_cpu32_64"][:it + 1]), max(r["dloss_cpu32_64"][:it + 1])
+        assert r["dsample_hip_64"][it] <= 3 * yard_s + 1e-3, (it, r["dsample_hip_64"], r["dsample_cpu32_64"])
+        assert r["dloss_hip_64"][it] <= 3 * yard_l + 1e-3, (it, r["dloss_hip_64"], r["dloss_cpu32_64"])
+    assert h["running_rel"] <= 3 * c["running_rel"] + 2e-4, (h, c)
+    assert h["param_rel_to_path"] <= 3 * c["param_rel_to_path"] + 1e-3, (h, c)
+    assert h["param_abs"] <= K * 2 * r["lr"] * 1.01, h
+
+
+@pytest.mark.parametrize("cfg", ["default", "full"])
+def test_first_five_steps_of_the_default_schedule(cfg):
+    r = _walk(cfg, 256, 150, 200, 0, True)
+    _report(r)
+    assert abs(r["lr"] - 1.2589e-5) < 1e-8
+    _check_against_yardstick(r)
     for it in range(K):
         assert r["dloss"][it] < 1e-3, (it, r["dloss"])
-        assert r["dsample"][it] < 1e-3, (it, r["dsample"])
-        assert abs(r["gnorm_hip"][it] - r["gnorm_oracle"][it]) < 1e-3 * r["gnorm_oracle"][it], (it, r["gnorm_hip"], r["gnorm_oracle"])
-    assert r["running_rel"] < 2e-4, (r["running_rel"], r["worst_running"])
-    assert r["param_abs"] <= K * 2 * LR * 1.01, (r["param_abs"], r["worst_param"])
+
+
+@pytest.mark.parametrize("cfg", ["default", "full"])
+def test_five_steps_at_the_full_learning_rate(cfg):
+    r = _walk(cfg, 256, 150, 20, 5, True)
+    _report(r)
+    assert abs(r["lr"] - 1.0e-3) < 1e-12
+    _check_against_yardstick(r)
