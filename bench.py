@@ -98,6 +98,11 @@ class KernelTimer:
                     return (f"pw16_wgrad_k<128, 256, 1, {tn}>" if ci % 256 == 0 else f"pw16_wgrad_k<256, 128, 1, {tn}>" if co % 256 == 0 else f"pw16_wgrad_k<128, 128, 1, {tn}>"), fl, by
                 return "pw_wgrad_k", fl, by
             if K >= 128 and N % 256 == 0:
+                if os.environ.get("TTK_GEMM_R", "1") != "0" and os.environ.get("TTK_GEMM") in (None, "", "f16x2") and not (mode == 1 and K == 256 and N == 256):
+                    # row-block kernel (csrc/pwconv_r.hip: f16r_gemm_shape, r_plan): one partial-sum row per row block of rt rows, tile = 32 rblk rows
+                    import trackertraincode._hip as H
+                    rt = -(-M // H.lib().partial_rows_gemm(M, K, N, bool(mode)))
+                    return f"pw16r_k<{4 if rt <= 128 else 6 if rt <= 192 else 8}, {mode}, {'float' if eb == 4 else 'unsigned short'}>", fl, by
                 return f"pw16_k<128, 256, {mode}, {mode}, 1, {'float' if eb == 4 else 'unsigned short'}>", fl, by  # <BM, BN, A form, epilogue form, register sets, storage>
             if K >= 64 and N == 128:
                 return f"pw16_k<256, 128, {mode}, {mode}, 1, {'float' if eb == 4 else 'unsigned short'}>", fl, by

@@ -91,9 +91,9 @@ int ttk_clear_error(void);
 int ttk_partial_rows_elementwise(int64_t work_items); /* stem / depthwise / pool kernels        */
 int ttk_partial_rows_dwconv(int B, int H, int W, int C, int stride, int backward); /* depthwise fwd (0) / data-grad (1) */
 int ttk_partial_rows_gemm(int64_t M);                 /* MFMA kernels with 128-row partial sums: ceil(M/128) (convolutions, fused backward inputs) */
-/* rows of partial sums ttk_pwconv1x1_fwd (K = Cin, Nout = Cout) / ttk_pwconv1x1_bwd_data (K = Cout, Nout = Cin) write for M rows: one per
- * row block of the kernel that runs the shape - ceil(M/128), or the row-block tiling of csrc/pwconv_r.hip for K >= 128, Nout % 256 == 0 */
-int ttk_partial_rows_pwconv(int64_t M, int K, int Nout);
+/* rows of partial sums ttk_pwconv1x1_fwd (K = Cin, Nout = Cout, dgrad = 0) / ttk_pwconv1x1_bwd_data (K = Cout, Nout = Cin, dgrad = 1) write
+ * for M rows: one per row block of the kernel that runs the shape - ceil(M/128), or the row-block tiling of csrc/pwconv_r.hip */
+int ttk_partial_rows_pwconv(int64_t M, int K, int Nout, int dgrad);
 
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm2d statistics - replaces F.batch_norm(training=True, momentum, eps) as called through

@@ -76,7 +76,7 @@ size_t conv_wgrad16_partial_bytes(int64_t M, int Cout, int ncols, int taps);
 __host__ __device__ inline int64_t r_plane_index(int row, int k, int rows) {
   return ((int64_t)(k >> 4) * rows + row) * 16 + ((((k >> 3) & 1) ^ ((row >> 3) & 1)) << 3) + (k & 7);
 }
-bool f16r_gemm_shape(int K, int Nout);
-int f16r_partial_rows(int64_t M, int K, int Nout);
+bool f16r_gemm_shape(int K, int Nout, int dgrad);
+int f16r_partial_rows(int64_t M, int K, int Nout, int dgrad);
 
 }  // namespace ttk

@@ -530,8 +530,8 @@ using namespace ttk;
 
 extern "C" {
 
-int ttk_partial_rows_pwconv(int64_t M, int K, int Nout) {
-  const int r = f16r_partial_rows(M, K, Nout);
+int ttk_partial_rows_pwconv(int64_t M, int K, int Nout, int dgrad) {
+  const int r = f16r_partial_rows(M, K, Nout, dgrad);
   return r ? r : (int)ceil_div(M, BM);
 }
 
@@ -659,8 +659,8 @@ int ttk_pwconv_prepare_weights(int n, const float* const* w, const int* cin, con
     a.first_tile[i] = tiles;
     tiles += (cin[i] / 32) * (cout[i] / 32);
     // 0: fp32 rows; 1: piece planes [K/32][rows][32]; 2: the row-block kernels' planes [K/16][rows][16] (pwconv_r.hip)
-    a.split_fwd[i] = a.mode == GEMM_F16X2 ? (f16r_gemm_shape(cin[i], cout[i]) ? 2 : f16_gemm_shape(cin[i], cout[i])) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cin[i], cout[i]));
-    a.split_bwd[i] = a.mode == GEMM_F16X2 ? (f16r_gemm_shape(cout[i], cin[i]) ? 2 : f16_gemm_shape(cout[i], cin[i])) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cout[i], cin[i]));
+    a.split_fwd[i] = a.mode == GEMM_F16X2 ? (f16r_gemm_shape(cin[i], cout[i], 0) ? 2 : f16_gemm_shape(cin[i], cout[i])) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cin[i], cout[i]));
+    a.split_bwd[i] = a.mode == GEMM_F16X2 ? (f16r_gemm_shape(cout[i], cin[i], 1) ? 2 : f16_gemm_shape(cout[i], cin[i])) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cout[i], cin[i]));
   }
   a.first_tile[n] = tiles;
   hipStream_t st = (hipStream_t)stream;

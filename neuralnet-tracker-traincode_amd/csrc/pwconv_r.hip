@@ -12,7 +12,9 @@
 //  * the tile HEIGHT is not fixed: the host cuts M into row blocks of RT <= 32 RBLK rows such that the tiles fill whole
 //    rounds of the 256 CUs (41 472 x 512: 256 row blocks of 162 rows x 2 column tiles = exactly 2 rounds; the MFMAs run
 //    on the padded 192 rows, which the byte-bound step has room for);
-//  * the weight planes reach LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write): ttk_pwconv_prepare_weights
+//  * the weight planes reach LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write), issued by the CONSUMER waves right after
+//    the barrier that frees a ring slot (four 1 KB pieces per wave and step: they have the whole step to land; issued by the producers
+//    behind their A work they had half a step and the kernel was no faster than pw16_k): ttk_pwconv_prepare_weights
 //    stores them as [K/16][Nout][16] with the consumers' chunk swizzle already applied, so a k16 stage of 256 rows is ONE
 //    contiguous 8 KB block per piece plane and a wave-instruction copies 1 KB of it;
 //  * BatchNorm partial sums: one row per tile (ttk_partial_rows_pwconv).
@@ -103,25 +105,22 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
   if (wave >= 8) {
     // ---------------- producers: A through registers (BatchNorm form, split, ds_write), B by LDS-DMA ----------------
     __builtin_amdgcn_s_setprio(3);
-    const int pt = tid - 512, pw = wave - 8, lane = tid & 63;
+    const int pt = tid - 512;
     const int row0 = pt >> 3, kq8 = pt & 7;  // 32 rows per pass; 8 lanes x 16 B = one 128-byte row segment
     const int sub = kq8 >> 2, chunk = (kq8 >> 1) & 1, o8 = (kq8 & 1) * 8;
     constexpr int AP = RBLK;
     constexpr int NQ = FWD ? 3 : 4;
-    constexpr int NLOADS = (FWD ? AP : 2 * AP) + NQ;  // global loads a producer thread issues per stage (behind its LDS-DMAs)
     f32x4 ra0[AP], ra1[FWD ? 1 : AP], q[NQ];
     int64_t arow[AP];
+    unsigned live = 0u;  // bit i: pass i's row lies inside the row block
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       const int64_t row = m0 + row0 + 32 * i;
-      arow[i] = (row < m_end ? row : m_end - 1) * (int64_t)K + kq8 * 4;  // clamp: rows past the block are computed but never stored
+      arow[i] = (row < m_end ? row : m_end - 1) * (int64_t)K + kq8 * 4;  // clamp the address; rows past the block become ZERO fragments below
+      live |= (row < m_end ? 1u : 0u) << i;
     }
     const float* cp = bnA + kq8 * 4;
     unsigned char* wbase = lds + sub * kStr + o8;
-    // LDS-DMA: this wave moves piece plane (pw & 1) of k16 stage (pw >> 1) of every k32 step: 8 pieces of 1 KB (32 rows x 32 B)
-    const int64_t bplane = (int64_t)K * Nout;
-    const uint16_t* bsrc = Bq + (pw & 1) * bplane + ((int64_t)(pw >> 1) * Nout + n0) * 16 + lane * 8;
-    const int bdst = (pw >> 1) * kStr + 2 * APL + (pw & 1) * BPL;
 
     auto load_a = [&](int ks) {
       const int kc0 = ks * 32;
@@ -141,14 +140,6 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
         q[3] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * K + kc0);
       }
     };
-    auto dma_b = [&](int ks) {  // weight planes of k32 step ks -> ring slot ks & 1
-      const uint16_t* s = bsrc + (int64_t)ks * 2 * Nout * 16;
-      unsigned char* d = lds + (ks & 1) * 2 * kStr + bdst;
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(s + j * 512),
-                                         (void __attribute__((address_space(3)))*)(d + j * 1024), 16, 0, 0);
-    };
     auto store_a = [&](int ks) {
       unsigned char* S = wbase + (ks & 1) * 2 * kStr;
       const f32x4 c0 = q[0] * sa, c2 = q[2] * sa;  // the scale S_a rides on the per-channel constants (exact: a power of two)
@@ -161,34 +152,24 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
         } else {
           v = c0 * (ra0[i] - q[1]) + c2 * (ra1[i] - q[NQ - 1]);
         }
+        // the padding rows of a block (RT = 162 of 192) are never stored; as ZEROS they also cost the matrix pipe far less power than
+        // copies of real rows would (the chip holds a higher clock on zero operands), and these kernels run at the power limit
+        if (!((live >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
         rsplit_store(v, S + rswz(row0 + 32 * i, chunk), APL);
       }
     };
-    // Stage s is consumed between barrier s and barrier s + 1 from slot s & 1; the producers fill stage s + 1 meanwhile.  Per
-    // step, in this order: A of the next stage from registers to LDS (its loads had a whole step), the stage's LDS-DMAs, the
-    // global loads of the stage after it - and a COUNTED wait that retires the DMAs (older) but leaves those loads in flight
-    // across the barrier (raw s_barrier: __syncthreads() would drain them).
-    dma_b(0);
-    __builtin_amdgcn_sched_barrier(0);
+    // Stage s is consumed between barrier s and barrier s + 1 from slot s & 1; meanwhile the producers write the A planes of stage
+    // s + 1 (from registers whose loads had a whole step) and request the rows of stage s + 2, and the CONSUMERS' LDS-DMAs bring the
+    // weight planes of stage s + 1.  Raw s_barrier: the producers' global loads stay in flight across it.
     load_a(0);
-    __builtin_amdgcn_sched_barrier(0);
-    store_a(0);  // (waits for everything issued so far: the first stage's DMAs and loads)
-    __builtin_amdgcn_sched_barrier(0);
-    if (nks > 1) load_a(1);  // in flight across the barrier
+    store_a(0);
+    if (nks > 1) load_a(1);
     __builtin_amdgcn_sched_barrier(0);
     rbarrier();  // stage 0 is in LDS
     for (int s = 1; s < nks; ++s) {
-      store_a(s);  // (the compiler waits for the registers' loads here: they are the oldest outstanding operations)
+      store_a(s);
+      if (s + 1 < nks) load_a(s + 1);
       __builtin_amdgcn_sched_barrier(0);
-      dma_b(s);
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + 1 < nks) {
-        load_a(s + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
       rbarrier();  // stage s is in LDS; the consumers are done with stage s - 1
     }
     rbarrier();  // the consumers are done with the last stage: the ring is free for the epilogue
@@ -211,36 +192,77 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     f16x8 hold[TH][2], strm[2][2];
+    // LDS-DMA of the weight planes: a k32 step is 32 pieces of 1 KB (2 k16 stages x 2 piece planes x 8 pieces of 32 rows x 32 B); consumer
+    // wave w moves pieces 4 w .. 4 w + 3 - k16 stage w >> 2, plane (w >> 1) & 1, rows 128 (w & 1) .. + 127 - right after the barrier that
+    // freed the slot, and waits for them (its only vector-memory operations) before the barrier that publishes the stage.
+    const int64_t bplane = (int64_t)K * Nout;
+    const uint16_t* bsrc = Bq + ((wave >> 1) & 1) * bplane + ((int64_t)(wave >> 2) * Nout + n0 + (wave & 1) * 128) * 16 + lane * 8;
+    const int bdst = (wave >> 2) * kStr + 2 * APL + ((wave >> 1) & 1) * BPL + (wave & 1) * 4096;
+    // (inline asm: hipcc must not see a pending LDS-DMA in this wave - with the builtin it turned every counted lgkmcnt wait of the
+    // fragment reads into lgkmcnt(0); M0 = the wave-uniform LDS destination, restored afterwards; the data is waited for by hand)
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    auto dma_b = [&](int ks) {  // weight planes of k32 step ks -> ring slot ks & 1
+      const uint16_t* sp = bsrc + (int64_t)ks * 2 * Nout * 16;
+      const unsigned d = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((ks & 1) * 2 * kStr + bdst));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(sp + j * 512), "s"(d + j * 1024)
+                     : "memory");
+      }
+    };
+    dma_b(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     rbarrier();  // stage 0 is in LDS
+    // Software pipeline of a k32 step (two k16 stages): the stream fragment of block x + 1 is requested before the MFMAs of block x,
+    // and the hold fragments of the NEXT k16 stage replace the current ones as soon as the last block's MFMAs have read them - so
+    // inside a step no MFMA waits for a read that was issued right before it; only the first fragments after the barrier are exposed.
+    auto rd = [&](const unsigned char* S, int plane_bytes, int off, int p) { return *reinterpret_cast<const f16x8*>(S + p * plane_bytes + off); };
     for (int it = 0; it < nks; ++it) {
+      if (it + 1 < nks) dma_b(it + 1);  // slot (it + 1) & 1 was released by the barrier just passed
+      const unsigned char* S0 = lds + (it & 1) * 2 * kStr;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int y = 0; y < TH; ++y) hold[y][p] = rd(S0, HPL, hold_off[y], p);
+        strm[0][p] = rd(S0, SPL, strm_off[0], p);
+      }
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
-        const unsigned char* S = lds + ((it & 1) * 2 + sub) * kStr;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-#pragma unroll
-          for (int x = 0; x < TH; ++x) hold[x][p] = *reinterpret_cast<const f16x8*>(S + p * HPL + hold_off[x]);
-          strm[0][p] = *reinterpret_cast<const f16x8*>(S + p * SPL + strm_off[0]);
-        }
+        const unsigned char* S = S0 + sub * kStr;
 #pragma unroll
         for (int x = 0; x < TS; ++x) {
-          const int cur = x & 1;
-          if (x + 1 < TS) {
+          const int cur = (sub * TS + x) & 1;
+          const bool last = x + 1 == TS;
+          if (!last) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) strm[cur ^ 1][p] = *reinterpret_cast<const f16x8*>(S + p * SPL + strm_off[x + 1]);
+            for (int p = 0; p < 2; ++p) strm[cur ^ 1][p] = rd(S, SPL, strm_off[x + 1], p);
+          } else if (sub == 0) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) strm[cur ^ 1][p] = rd(S + kStr, SPL, strm_off[0], p);
           }
-          // three piece products, smallest first; (pa, pb) index the A and B pieces (0 = h, 1 = l)
-#define TTK_RPROD(pa, pb)                                                                                     \
-  _Pragma("unroll") for (int y = 0; y < TH; ++y) {                                                            \
-    if constexpr (HOLD_A)                                                                                     \
-      acc[y][x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hold[y][pa], strm[cur][pb], acc[y][x], 0, 0, 0);     \
-    else                                                                                                      \
-      acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(strm[cur][pa], hold[y][pb], acc[x][y], 0, 0, 0);     \
-  }
-          TTK_RPROD(0, 1) TTK_RPROD(1, 0) TTK_RPROD(0, 0)
-#undef TTK_RPROD
+#pragma unroll
+          for (int y = 0; y < TH; ++y) {
+            // three piece products of one accumulator, smallest first: h_a l_b, l_a h_b, h_a h_b
+            if constexpr (HOLD_A) {
+              acc[y][x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hold[y][0], strm[cur][1], acc[y][x], 0, 0, 0);
+              acc[y][x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hold[y][1], strm[cur][0], acc[y][x], 0, 0, 0);
+              acc[y][x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hold[y][0], strm[cur][0], acc[y][x], 0, 0, 0);
+            } else {
+              acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(strm[cur][0], hold[y][1], acc[x][y], 0, 0, 0);
+              acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(strm[cur][1], hold[y][0], acc[x][y], 0, 0, 0);
+              acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(strm[cur][0], hold[y][0], acc[x][y], 0, 0, 0);
+            }
+            if (last && sub == 0) {  // hold fragment y of the second k16 stage, behind its last use in the first
+#pragma unroll
+              for (int p = 0; p < 2; ++p) hold[y][p] = rd(S + kStr, HPL, hold_off[y], p);
+            }
+          }
         }
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage it + 1 have landed
       rbarrier();  // done with stage `it` (its fragments are in registers, its slot may be refilled); stage it + 1 is in LDS
     }
   }
@@ -308,7 +330,12 @@ bool f16r_enabled() {
   static const bool on = [] { const char* e = getenv("TTK_GEMM_R"); return !(e && e[0] == '0'); }();
   return on && gemm_mode() == GEMM_F16X2;
 }
-bool f16r_gemm_shape(int K, int Nout) { return f16r_enabled() && K >= 128 && K % 32 == 0 && Nout >= 256 && Nout % kRBN == 0; }
+// Shapes [M][K] x [K][Nout] that run here.  The data gradient of the 256 -> 256 layer (K = Nout = 256, M = 147 968 at B = 512) is the one
+// measured slower than pw16_k's 128 x 256 tiles (147 vs 134 us: it is HBM-bound, and 193-row blocks only add epilogue time there).
+bool f16r_gemm_shape(int K, int Nout, int dgrad) {
+  if (!f16r_enabled() || K < 128 || K % 32 != 0 || Nout < 256 || Nout % kRBN != 0) return false;
+  return !(dgrad && K == 256 && Nout == 256) || getenv("TTK_R_ALL") != nullptr;
+}
 
 struct RPlan { int rblk, rt, row_blocks; };
 // Cost of a tile round in cycles per CU: a k32 step costs the larger of its matrix time (384 cycles per 32-row block)
@@ -340,7 +367,7 @@ static RPlan r_plan(int64_t M, int K, int Nout) {
   }
   return best;
 }
-int f16r_partial_rows(int64_t M, int K, int Nout) { return f16r_gemm_shape(K, Nout) ? r_plan(M, K, Nout).row_blocks : 0; }
+int f16r_partial_rows(int64_t M, int K, int Nout, int dgrad) { return f16r_gemm_shape(K, Nout, dgrad) ? r_plan(M, K, Nout).row_blocks : 0; }
 
 // w[rows][K] fp32 -> two fp16 planes [K/16][rows][16] (16-byte chunks of a row swapped where (row >> 3) & 1) of w * pow2_scale(*wmax)
 __global__ void w16r_split_k(const float* __restrict__ w, uint16_t* __restrict__ q, const float* __restrict__ wmax, int rows, int K) {
@@ -370,7 +397,7 @@ __global__ void __launch_bounds__(256) w16r_absmax_k(const float* __restrict__ w
 template <int MODE, typename T, typename TO>
 bool launch_f16r_gemm(const TO* A0, const T* A1, const float* bnA, const float* Bm, TO* out, const T* E0, const float* bnE, float* part,
                       int64_t M, int K, int Nout, void* planes, float* wmax, hipStream_t st) {
-  if (!planes || !wmax || !f16r_gemm_shape(K, Nout)) return false;
+  if (!planes || !wmax || !f16r_gemm_shape(K, Nout, MODE == RMODE_DGRAD)) return false;
   uint16_t* Bq = reinterpret_cast<uint16_t*>(planes);
   const int64_t nw = (int64_t)Nout * K;
   if (Bm) {

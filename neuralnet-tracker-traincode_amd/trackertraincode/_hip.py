@@ -133,7 +133,7 @@ class _Library:
         for name in ("ttk_partial_rows_elementwise", "ttk_partial_rows_gemm"):
             fn = getattr(self.cdll, name)
             fn.argtypes, fn.restype = [c_int64], c_int
-        self.cdll.ttk_partial_rows_pwconv.argtypes, self.cdll.ttk_partial_rows_pwconv.restype = [c_int64, c_int, c_int], c_int
+        self.cdll.ttk_partial_rows_pwconv.argtypes, self.cdll.ttk_partial_rows_pwconv.restype = [c_int64, c_int, c_int, c_int], c_int
         self.cdll.ttk_heads_num_rows.argtypes, self.cdll.ttk_heads_num_rows.restype = [c_int, c_int, c_int], c_int
         self.cdll.ttk_pwconv_prepared_bytes.argtypes, self.cdll.ttk_pwconv_prepared_bytes.restype = [c_int, c_int], ctypes.c_size_t
         self.cdll.ttk_partial_rows_dwconv.argtypes, self.cdll.ttk_partial_rows_dwconv.restype = [c_int] * 6, c_int
@@ -235,12 +235,12 @@ class _Library:
     def partial_rows_dwconv(self, B, H, W, C, stride, backward) -> int:
         return self.cdll.ttk_partial_rows_dwconv(B, H, W, C, stride, int(backward))
 
-    def partial_rows_gemm(self, m: int, k: int | None = None, nout: int | None = None) -> int:
+    def partial_rows_gemm(self, m: int, k: int | None = None, nout: int | None = None, dgrad: bool = False) -> int:
         """Rows of BatchNorm partial sums a GEMM epilogue writes for m rows.  With (k, nout): of ttk_pwconv1x1_fwd (k = Cin, nout = Cout) /
-        ttk_pwconv1x1_bwd_data (k = Cout, nout = Cin), whose tiling depends on the shape; without: the 128-row form (convolutions)."""
+        ttk_pwconv1x1_bwd_data (k = Cout, nout = Cin, dgrad=True), whose tiling depends on the shape; without: the 128-row form (convolutions)."""
         if k is None:
             return self.cdll.ttk_partial_rows_gemm(m)
-        return self.cdll.ttk_partial_rows_pwconv(m, k, nout)
+        return self.cdll.ttk_partial_rows_pwconv(m, k, nout, int(dgrad))
 
 
 _lib: _Library | None = None

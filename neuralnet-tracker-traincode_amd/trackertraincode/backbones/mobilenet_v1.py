@@ -135,7 +135,7 @@ def _part_buffer(B, H, W, device):
         ho = (h - 1) // stride + 1
         need = max(need, L.partial_rows_dwconv(B, h, h, cin, stride, True) * 2 * cin)     # dw bwd-data
         need = max(need, L.partial_rows_dwconv(B, h, h, cin, stride, False) * 2 * cin)    # dw fwd
-        need = max(need, L.partial_rows_gemm(B * ho * ho, cin, cout) * 2 * cout, L.partial_rows_gemm(B * ho * ho, cout, cin) * 2 * cin)  # pw fwd / bwd-data
+        need = max(need, L.partial_rows_gemm(B * ho * ho, cin, cout) * 2 * cout, L.partial_rows_gemm(B * ho * ho, cout, cin, True) * 2 * cin)  # pw fwd / bwd-data
         need = max(need, L.partial_rows_elementwise(B * ho * ho * (cout // 4)) * 2 * cout)  # pool bwd
         h = ho
     return torch.empty(need, dtype=torch.float32, device=device)
@@ -321,7 +321,7 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         if not fused_rows:
             L.call("ttk_pwconv1x1_bwd_data", p(g), p(st_pw.y), p(st_pw.bn), None, p(st_dw.y), p(st_dw.bn), p(g_dw), p(part), M,
                    cin, cout, p(ctx.prep[k]), bf)
-            bwd_finalize(st_dw, L.partial_rows_gemm(M, cout, cin), M, pi + 1)
+            bwd_finalize(st_dw, L.partial_rows_gemm(M, cout, cin, True), M, pi + 1)
         # -- depthwise: weight gradient, then data gradient (+ residual gradient, + producer's bn sums)
         dWd = grads[pi]  # accumulated by the fused weight-gradient path of bwd_data
         g_prev = torch.empty(st_prev.y.shape, dtype=ctx.gdt, device=st_prev.y.device)

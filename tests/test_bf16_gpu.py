@@ -67,7 +67,7 @@ def test_pointwise_kernels_with_bf16_storage(M, Cin, Cout, flag):
     gd64 = (dy64 @ w.astype(np.float64)) * (pre > 0)
     wt = torch.from_numpy(np.ascontiguousarray(w.T)).to(DEV)
     g_dw = torch.empty(M, Cin, device=DEV, dtype=gdt)
-    part2 = torch.full((L.partial_rows_gemm(M, Cout, Cin), 2, Cin), float("nan"), device=DEV)
+    part2 = torch.full((L.partial_rows_gemm(M, Cout, Cin, True), 2, Cin), float("nan"), device=DEV)
     d_bnpw = torch.from_numpy(bn_pw).to(DEV)
     L.call("ttk_pwconv1x1_bwd_data", p(g), p(y), p(d_bnpw), p(wt), p(ydw), p(d_bn), p(g_dw), p(part2), M, Cin, Cout, p(wq), flag)
     torch.cuda.synchronize()

@@ -60,7 +60,7 @@ def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout, loose):
     bn_dw, bn_pw = _bn_block(Cin, rng), _bn_block(Cout, rng)
     dev = "cuda"
     t = lambda a: torch.from_numpy(a).to(dev)
-    rows, rows_b = L.partial_rows_gemm(M, Cin, Cout), L.partial_rows_gemm(M, Cout, Cin)  # forward: K = Cin, N = Cout; data gradient: K = Cout, N = Cin
+    rows, rows_b = L.partial_rows_gemm(M, Cin, Cout), L.partial_rows_gemm(M, Cout, Cin, True)  # forward: K = Cin, N = Cout; data gradient: K = Cout, N = Cin
 
     # ---- forward: y = relu(scale*(ydw-mean)+beta) @ w^T ; partial sums of y and y^2 per column
     a32 = np.maximum(bn_dw[BN_SCALE] * (ydw - bn_dw[BN_MEAN]) + bn_dw[BN_BETA], 0).astype(np.float32)
@@ -157,7 +157,7 @@ def test_prepared_weights_match_per_call_split():
         bn_dw, bn_pw = _bn_block(Cin, rng), _bn_block(Cout, rng)
         bn_dw[BN_AUX, AUX_ACT_BOUND], bn_pw[BN_AUX, AUX_DY_BOUND] = 12.0, 40.0  # generous for N(0,1) data with these constants
         bn_dw, bn_pw = torch.from_numpy(bn_dw).to(dev), torch.from_numpy(bn_pw).to(dev)
-        rows, rows_b = L.partial_rows_gemm(M, Cin, Cout), L.partial_rows_gemm(M, Cout, Cin)
+        rows, rows_b = L.partial_rows_gemm(M, Cin, Cout), L.partial_rows_gemm(M, Cout, Cin, True)
         wq = torch.empty(L.pwconv_prepared_bytes(Cin, Cout), dtype=torch.uint8, device=dev)
         wt = w.reshape(Cout, Cin).t().contiguous()
         out = []
@@ -221,7 +221,7 @@ def test_fused_bwd_matches_fp64_and_the_two_kernels(M, Cin, Cout):
     np.testing.assert_allclose(ps[:, 1].sum(0), (o64 * yc).sum(0), rtol=0, atol=3e-5 * np.abs(o64 * yc).sum(0).max())
     # the two kernels it replaces compute the same fp32 arithmetic (exact products, fp32 accumulation, another summation order)
     g_dw2 = torch.empty(M, Cin, device=dev)
-    part2 = torch.empty(L.partial_rows_gemm(M, Cout, Cin), 2, Cin, device=dev)
+    part2 = torch.empty(L.partial_rows_gemm(M, Cout, Cin, True), 2, Cin, device=dev)
     dw2 = torch.zeros(Cout, Cin, device=dev)
     wt = d_w.t().contiguous()
     wq2 = torch.empty(L.pwconv_prepared_bytes(Cin, Cout), dtype=torch.uint8, device=dev)  # (named: see above)

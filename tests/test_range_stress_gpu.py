@@ -100,7 +100,7 @@ def test_pwconv_entry_points_under_heavy_tails_and_loose_bounds(M, Cin, Cout, ws
     bound_a, bound_g, bound_w = float(ydw.max()) * loose, float(np.abs(g).max()) * loose, float(np.abs(w).max())  # (the weights' bound is their measured maximum)
     bn_dw[BN_AUX, AUX_ACT_BOUND], bn_pw[BN_AUX, AUX_DY_BOUND] = bound_a, bound_g
     d_ydw, d_w, d_bndw, d_bnpw, d_g = t(ydw), t(w), t(bn_dw), t(bn_pw), t(g)
-    rows, rows_b = L.partial_rows_gemm(M, Cin, Cout), L.partial_rows_gemm(M, Cout, Cin)
+    rows, rows_b = L.partial_rows_gemm(M, Cin, Cout), L.partial_rows_gemm(M, Cout, Cin, True)
     probes = range(len(PROBES))
 
     y = torch.empty(M, Cout, device=dev)

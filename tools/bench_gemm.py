@@ -31,7 +31,7 @@ for name, hw, ci, co, mult in shapes:
     L.pwconv_prepare_weights([w], [prep])
     nb = L.pwconv_wgrad_partial_bytes(M, ci, co) if os.environ.get("PARTIAL") else 0  # PARTIAL=1: slice partials + fixed-order fold instead of atomics
     scr = torch.empty(nb // 4, device=dev) if nb else None
-    part = torch.empty(max(L.partial_rows_gemm(M, ci, co), L.partial_rows_gemm(M, co, ci)) * 2 * max(ci, co), device=dev)
+    part = torch.empty(max(L.partial_rows_gemm(M, ci, co), L.partial_rows_gemm(M, co, ci, True)) * 2 * max(ci, co), device=dev)
     calls = {
         "fwd": lambda: L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(out), p(part), M, ci, co, p(prep), BF),
         "dgrad": lambda: L.call("ttk_pwconv1x1_bwd_data", p(g), p(y), p(bn_pw), None, p(ydw), p(bn_dw), p(gdw), p(part), M, ci, co, p(prep), BF),
