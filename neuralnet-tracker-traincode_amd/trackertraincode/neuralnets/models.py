@@ -241,17 +241,25 @@ class NetworkWithPointHead(nn.Module):
         outs = _hipops.HeadsFn.apply(feat, coord_convention_id, unc, pt, off, r6, kp, ke, self.local_pose_offset.p,
                                      self.local_pose_offset_kpts.p if pt else None, *self._linear_stack())
         roi, coord, rot, qu = outs[:4]
+        # key order of the reference's dict (:345-372; it is ExportModel's output order): with the local pose offset "rot" and "coord" are
+        # popped and re-inserted behind the heads' other keys, without it they stay where posnet / quatnet put them
         out: Dict[str, Tensor] = {"roi": roi}
         k = 4
         if unc:
             out["roi_scales"] = self.boxnet.scales()[None, :].expand_as(roi)
+        if not off:
+            out["coord"] = coord
+        if unc:
             out["coord_scales"] = outs[k]
             k += 2
         out["unnormalized_6drepr" if r6 else "unnormalized_quat"] = qu
+        if not off:
+            out["rot"] = Mat33Repr(rot) if r6 else QuatRepr(rot)
         if unc:
             out["pose_scales_tril"] = outs[5]
-        out["rot"] = Mat33Repr(rot) if r6 else QuatRepr(rot)
-        out["coord"] = coord
+        if off:
+            out["rot"] = Mat33Repr(rot) if r6 else QuatRepr(rot)
+            out["coord"] = coord
         if pt:
             out["pt3d_68"], out["shapeparam"] = outs[k], outs[k + 1]
             if unc:
@@ -266,7 +274,9 @@ class NetworkWithPointHead(nn.Module):
         out.update(self.quatnet(zs.pop()))
         hidden_rot, hidden_coord = out["rot"], out["coord"]
         if self.use_local_pose_offset:
-            out["rot"], out["coord"] = self.local_pose_offset(hidden_rot, hidden_coord, set_id=coord_convention_id)
+            # (pop + re-insert as the reference does, :352-356: "rot" and "coord" move behind the heads' other keys - the key ORDER of
+            # the eval-mode dict is the output order of scripts/export_model.py's ExportModel)
+            out["rot"], out["coord"] = self.local_pose_offset(out.pop("rot"), out.pop("coord"), set_id=coord_convention_id)
         if self.enable_point_head:
             rots, coords = out["rot"], out["coord"]
             if self.use_local_pose_offset:
