@@ -115,6 +115,34 @@ def create_net(args):
     )
 
 
+def parse_dataset_definition(arg: str):
+    """CLI dataset specification <name1>[:<weight1>]+<name2>[:<weight2>]+... -> (ids in first-seen order, {id: weight}) with the reference's
+    names (:60-94; the reference returns the ids as list(frozenset(...)), i.e. in hash order - the loaders sort them by their own table)."""
+    Id = trackertraincode.pipelines.Id
+    dsmap = {"300wlp": Id._300WLP, "synface": Id.SYNFACE, "aflw2k": Id.AFLW2k3d, "biwi": Id.BIWI, "wider": Id.WIDER, "repro_300_wlp": Id.REPO_300WLP,
+             "repro_300_wlp_woextra": Id.REPO_300WLP_WO_EXTRA, "wflw_lp": Id.WFLW_LP, "lapa_megaface_lp": Id.LAPA_MEGAFACE_LP,
+             "panoptic": Id.PANOPTIC_CMU, "replicantface": Id.REPLICANT_FACE}
+    splitted = arg.split("+")
+    unknown = [s.split(":")[0] for s in splitted if s.split(":")[0] not in dsmap]
+    if unknown:
+        raise ValueError(f"unknown dataset(s) {unknown}; available: synthetic, {', '.join(dsmap)}")
+    dataset_weights = {dsmap[k]: float(v) for k, v in (tuple(s.split(":")) for s in splitted if ":" in s)}
+    dsids = list(dict.fromkeys(dsmap[s.split(":")[0]] for s in splitted))
+    return dsids, dataset_weights
+
+
+def setup_datasets(args, device, rank=0):
+    """(train_loader, test_loader, size) - reference :66-78.  "synthetic": seeded synthetic crops; otherwise dataset ids read from the
+    converted shards under $DATADIR (trackertraincode.pipelines.make_pose_estimation_loaders)."""
+    common = dict(inputsize=args.input_size, batchsize=args.batchsize, device=device, seed=1234 + rank, enable_image_aug=args.with_image_aug,
+                  rotation_aug_angle=args.rotation_aug_angle, roi_override=args.roi_override)
+    if args.ds == "synthetic":
+        return trackertraincode.pipelines.make_pose_estimation_loaders(datasets="synthetic", **common)
+    ids, weights = parse_dataset_definition(args.ds)
+    return trackertraincode.pipelines.make_pose_estimation_loaders(datasets=ids, dataset_weights=weights,
+                                                                   use_weights_as_sampling_frequency=args.ds_weight_are_sampling_frequencies, **common)
+
+
 def make_parser():
     p = argparse.ArgumentParser(description="Trains the model")
     p.add_argument("--backbone", default="mobilenetv1")
@@ -156,35 +184,34 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
-    train_loader, _, _ = trackertraincode.pipelines.make_pose_estimation_loaders(
-        inputsize=args.input_size, batchsize=args.batchsize, datasets=args.ds, device=device, seed=1234 + rank)
+    train_loader, test_loader, _ = setup_datasets(args, device, rank)
     net = create_net(args).to(device)
     parallel.broadcast_module_state(net)  # every replica starts from rank 0's weights
-    train_crit, _ = setup_losses(args, net)
+    train_crit, test_crit = setup_losses(args, net)
     optimizer, scheduler = create_optimizer(net, args)
-    callbacks = [train.SwaCallback(start_epoch=args.epochs * 2 // 3)] if (args.swa and rank == 0) else []
-    reducer, grad_sync = None, None
+    out_dir = join(args.outdir, net.name)
+    # ModelCheckpoint(monitor="val_loss", filename="best", save_last=True) of the reference (:423-431): rank 0 writes best.ckpt / last.ckpt
+    callbacks = [train.CheckpointCallback(out_dir)] if rank == 0 else []
+    if args.swa and rank == 0:
+        callbacks.append(train.SwaCallback(start_epoch=args.epochs * 2 // 3))
+    reducer = None
     if world > 1:
         reducer = parallel.GradAllReduce()
         parallel.install(reducer)                  # gradient arenas are all-reduced in place while backward runs
         optimizer.grad_scale = reducer.grad_scale  # 1/world inside the fused clip+Adam kernel
-        params = list(net.parameters())
-        grad_sync = lambda model: reducer.finish(params)
-
-    def report(epoch, out):
-        pass
 
     try:
-        train.fit(net, train_loader, train_crit, optimizer, scheduler, epochs=args.epochs, callbacks=callbacks, on_step=report,
-                  grad_sync=grad_sync)
+        train.fit(net, train_loader, train_crit, optimizer, scheduler, epochs=args.epochs, callbacks=callbacks,
+                  val_loader=test_loader if rank == 0 else None, val_criterions=test_crit, reducer=reducer)
     finally:
         parallel.install(None)
     if rank == 0:
-        out_dir = join(args.outdir, net.name)
         os.makedirs(out_dir, exist_ok=True)
-        models.save_model(net.to("cpu"), join(out_dir, "last.ckpt"))
+        if not os.path.exists(join(out_dir, "last.ckpt")):  # (no validation epoch ran)
+            models.save_model(net.to("cpu"), join(out_dir, "last.ckpt"))
         for cb in callbacks:
-            cb.on_train_end(out_dir)
+            if hasattr(cb, "on_train_end"):
+                cb.on_train_end(out_dir)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

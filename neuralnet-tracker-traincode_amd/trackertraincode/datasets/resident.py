@@ -101,3 +101,26 @@ class ResidentLoader:
                 b["image"] = img
                 out.append(b)
             yield out
+
+
+class ResidentEvalLoader:
+    """The test loader of the reference (pipelines.py:543-552: PostprocessingLoader over the eval-transformed datasets, ONE Batch per
+    iteration, no shuffling) over frames resident in HBM: deterministic FocusRoi crop (enlargement 1.1, no shift, no rotation:
+    pipelines.py:330-339 stage "eval"), label bookkeeping and whitening on the GPU."""
+
+    def __init__(self, datasets: Sequence[ResidentFrames], batchsize: int, new_size: int = 129, extension_factor: float = 1.1):
+        from ..datatransformation.batch.geometric import NoRoiRandomization
+
+        self.datasets, self.batchsize = list(datasets), int(batchsize)
+        self._crop = GpuFocusRoiAugment(new_size=new_size, make_params=NoRoiRandomization(extension_factor), whiten=True)
+
+    def __len__(self):
+        return sum((len(d) + self.batchsize - 1) // self.batchsize for d in self.datasets)
+
+    def __iter__(self) -> Iterator[Batch]:
+        for ds in self.datasets:
+            for lo in range(0, len(ds), self.batchsize):
+                data = {k: v[lo:lo + self.batchsize] for k, v in ds.fields.items()}
+                n = int(data["image"].shape[0])
+                meta = Metadata(tuple(data["image"].shape[-2:][::-1]), n, ds.tag, None, {k: c for k, c in _CATEGORIES.items() if k in data})
+                yield self._crop(Batch(meta, data))

@@ -134,6 +134,19 @@ class GradAllReduce:
     def begin_step(self):
         self.collectives = 0
 
+    def abort(self):
+        """Backward raised: wait for the collectives already issued (they work in place on gradient arenas that are about to be
+        freed) and forget the step."""
+        for w in self._works:
+            try:
+                w.wait()
+            except Exception:  # noqa: BLE001 - the original exception is the one to report
+                pass
+        self._works.clear()
+        self._done.clear()
+        self._entries.clear()
+        self._open = None
+
 
 def install(reducer: GradAllReduce | None):
     """Point the backbones' and the fused heads' gradient-ready hooks at `reducer` (None: remove them)."""

@@ -4,8 +4,8 @@ In scope for the MI355X path: the `Tag` / `Id` vocabularies and the contract of
 `make_pose_estimation_loaders` (train loader yields `list[Batch]`, one Batch per Tag, images already
 on the device, f32 [n,1,129,129] in about [-0.5, 0.5]).  The reference's dataset constructors read
 unpublished / multi-GB HDF5 files through h5py + OpenCV in worker processes (pipelines.py:399-500) and
-are out of scope; `SyntheticPoseLoader` provides the same contract from
-seeded tensors for benchmarks and tests.
+are replaced by .npz shards decoded once into HBM-resident frames (datasets/shards.py, datasets/resident.py; SURVEY.md §8 f2);
+`SyntheticPoseLoader` provides the same contract from seeded tensors for benchmarks and tests.
 """
 from __future__ import annotations
 
@@ -130,11 +130,41 @@ class SyntheticPoseLoader:
             yield batches
 
 
+# The pose datasets of the reference that carry what the pose-estimator step trains on (pipelines.py:120-300, 399-453): file (as an .npz
+# shard converted by oracle/tools/h5_to_npz.py), task Tag, default sampling weight, and the frame range of the train split.
+_POSE_SHARDS = {
+    Id.REPO_300WLP: ("reproduction_300wlp-v12", Tag.POSE_WITH_LANDMARKS, 60_000.0, None),
+    Id.REPO_300WLP_WO_EXTRA: ("reproduction_300wlp_simple", Tag.POSE_WITH_LANDMARKS, 60_000.0, None),
+    Id._300WLP: ("300wlp", Tag.POSE_WITH_LANDMARKS_3D_AND_2D, 60_000.0, None),
+    Id.WFLW_LP: ("wflw_augmented_v4", Tag.POSE_WITH_LANDMARKS, 40_000.0, None),
+    Id.LAPA_MEGAFACE_LP: ("lapa-megaface-augmented-v2", Tag.POSE_WITH_LANDMARKS, 10_000.0, None),
+    Id.REPLICANT_FACE: ("replicant-face-v4-wider-100k", Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS, 10_000.0, None),
+    Id.BIWI: ("biwi-v3", Tag.ONLY_POSE, 1_000.0, None),
+    Id.AFLW2k3d: ("aflw2k", Tag.POSE_WITH_LANDMARKS, 1_000.0, (400, None)),  # frames 400.. train, 0..399 test (:266-271)
+}
+_TEST_SHARD = ("aflw2k", Tag.POSE_WITH_LANDMARKS, (0, 400))  # the validation set of every run (:455-456)
+
+
+def _slice_frames(frames, lo, hi):
+    from .datasets.resident import ResidentFrames
+
+    return ResidentFrames(frames.tag, {k: v[lo:hi] for k, v in frames.fields.items()})
+
+
 def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights=None, use_weights_as_sampling_frequency=True,
-                                 enable_image_aug=True, rotation_aug_angle=30.0, roi_override="original", device="cuda", seed=1234):
-    """Signature of the reference (pipelines.py:359-369) plus `seed` (data-parallel replicas draw different streams).
-    `datasets` may be the string "synthetic" (or a list of (Tag, weight) pairs) to obtain seeded synthetic loaders with
-    the reference's contract; real dataset ids need the HDF5 pipeline, which this package does not contain."""
+                                 enable_image_aug=True, rotation_aug_angle=30.0, roi_override="original", device="cuda", seed=1234,
+                                 datadir=None, steps_per_epoch=None):
+    """Signature of the reference (pipelines.py:359-369) plus `seed` (data-parallel replicas draw different streams), `datadir` and
+    `steps_per_epoch`.  `datasets`:
+
+      * "synthetic" (or a list of (Tag, weight) pairs): seeded synthetic loaders with the reference's contract;
+      * a sequence of `Id`s: the reference's datasets from `datadir` (default $DATADIR) holding one `<name>.npz` shard per HDF5 file
+        (oracle/tools/h5_to_npz.py converts them in the build container; datasets/shards.py decodes the JPEGs once).  The decoded frames
+        live in HBM; per step the weighted concat draw of the reference (datasets/randomized.py), the random focus-ROI crop / warp and
+        the intensity augmentation run on the GPU (datasets/resident.py).  The test loader is the deterministic crop of the first 400
+        AFLW2000-3D frames, as in the reference.  `roi_override` other than "original" (landmark-derived boxes) and the 1 % flip / 90
+        degree rotation (:376) are not built.
+    """
     if datasets == "synthetic":
         datasets = [(Tag.POSE_WITH_LANDMARKS, 11.0), (Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS, 1.0)]
     if isinstance(datasets, (list, tuple)) and datasets and isinstance(datasets[0], tuple) and isinstance(datasets[0][0], Tag):
@@ -143,8 +173,58 @@ def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights
         test = SyntheticPoseLoader(batchsize, [(Tag.POSE_WITH_LANDMARKS, 1.0)], device=device, seed=4321, inputsize=inputsize,
                                    steps_per_epoch=max(1, 400 // batchsize))
         return train, test, len(train) * batchsize
-    raise NotImplementedError(
-        "make_pose_estimation_loaders: the HDF5 dataset readers of the reference (h5py/OpenCV worker "
-        "pipeline, $DATADIR) are outside the hot path this package implements; pass datasets='synthetic' "
-        "or feed list[Batch] from your own loader"
-    )
+    if not (isinstance(datasets, (list, tuple)) and datasets and all(isinstance(d, Id) for d in datasets)):
+        raise ValueError('datasets: "synthetic", a list of (Tag, weight) pairs, or a sequence of pipelines.Id')
+    if roi_override != "original":
+        raise NotImplementedError('roi_override: only "original" (the stored face boxes) is built; the landmark-derived boxes of '
+                                  "PutRoiFromLandmarks (pipelines.py:341-356) are not")
+    import os
+
+    from .datasets.resident import ResidentEvalLoader, ResidentLoader
+    from .datasets.shards import load_resident_frames
+    from .datatransformation.gpu import GpuFocusRoiAugment
+
+    datadir = datadir or os.environ.get("DATADIR")
+    if not datadir:
+        raise RuntimeError("make_pose_estimation_loaders: set $DATADIR (or pass datadir=) to the directory of converted .npz shards")
+    unsupported = [d for d in datasets if d not in _POSE_SHARDS]
+    if unsupported:
+        raise NotImplementedError(f"datasets {unsupported}: landmark-only / face-detection / segmentation sets are outside the pose-estimator "
+                                  f"path this package implements (supported: {sorted(d.name for d in _POSE_SHARDS)})")
+    if len([d for d in datasets if d in (Id._300WLP, Id.REPO_300WLP, Id.REPO_300WLP_WO_EXTRA)]) > 1:
+        raise ValueError("at most one 300W-LP variant (reference :435-438)")
+    cache: dict = {}
+
+    def shard(name, tag):
+        path = os.path.join(datadir, name + ".npz")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not found: convert {name}.h5 with `/opt/conda/bin/python3.9 oracle/tools/h5_to_npz.py --dataset "
+                                    f"{name}.h5 {path}` (h5py lives in the build container's conda interpreter only)")
+        if path not in cache:
+            cache[path] = load_resident_frames(path, tag, device)
+        return cache[path]
+
+    dataset_weights = dataset_weights or {}
+    train_sets, weights = [], []
+    for d in datasets:
+        name, tag, default_w, rng = _POSE_SHARDS[d]
+        frames = shard(name, tag)
+        if rng is not None:
+            frames = _slice_frames(frames, rng[0], rng[1])
+        train_sets.append(frames)
+        weights.append(float(dataset_weights.get(d, default_w)))
+    total = sum(len(t) for t in train_sets)
+    if use_weights_as_sampling_frequency:
+        freqs = [w / sum(weights) for w in weights]
+    else:  # the weights scale the losses instead (`dataset_weight` field, reference :475-485); every dataset is drawn equally often
+        wmax = max(weights)
+        for t, w in zip(train_sets, weights):
+            t.fields["dataset_weight"] = torch.full((len(t),), w / wmax, dtype=torch.float32, device=device)
+        freqs = [1.0 / len(weights)] * len(weights)
+    augs = make_image_augmentations(torch.Generator().manual_seed(99 + seed)) if enable_image_aug else None
+    crop = GpuFocusRoiAugment(new_size=inputsize, rotation_aug_angle=rotation_aug_angle, extension_factor=1.1, whiten=not augs)
+    steps = steps_per_epoch if steps_per_epoch is not None else (10 * 1024) // batchsize  # Trainer(limit_train_batches=...), train_poseestimator.py:447
+    train = ResidentLoader(train_sets, freqs, batchsize, steps, seed=seed, crop=crop, image_augmentations=augs)
+    tname, ttag, (lo, hi) = _TEST_SHARD
+    test = ResidentEvalLoader([_slice_frames(shard(tname, ttag), lo, hi)], batchsize * 2, new_size=inputsize)
+    return train, test, total

@@ -566,20 +566,95 @@ class GraphedTrainStep:
         return self._out
 
 
+@torch.no_grad()
+def validate(model: nn.Module, val_loader, val_criterions) -> float:
+    """One validation epoch with LitModel.validation_step's arithmetic (scripts/train_poseestimator.py:332-338) and Lightning's
+    epoch reduction of `self.log("val_loss", ..., on_epoch=True, batch_size=n)`: per batch the SUM over samples and terms of
+    value * weight (not a mean), per epoch the batch-size-weighted mean of those sums.  The model runs in eval mode without
+    coord_convention_id; the criterions receive the BATCH INDEX as their step (the reference's quirk: weights that ramp with the
+    epoch ramp with the batch index here)."""
+    was_training = model.training
+    model.eval()
+    total, count = None, 0
+    try:
+        for batch_idx, batch in enumerate(val_loader):
+            pred = model(batch["image"])
+            crit = val_criterions[batch.meta.tag] if isinstance(val_criterions, dict) else val_criterions
+            values = crit.evaluate(pred, batch, batch_idx)
+            val_loss = torch.cat([(lv.val * lv.weight).reshape(-1) for lv in values]).sum()
+            n = int(batch.meta.batchsize)
+            total = val_loss * n if total is None else total + val_loss * n
+            count += n
+    finally:
+        model.train(was_training)
+    if count == 0:
+        raise ValueError("empty validation loader")
+    return float(total.item()) / count
+
+
+class CheckpointCallback:
+    """ModelCheckpoint(save_top_k=1, save_last=True, monitor="val_loss", filename="best") of the reference's training script
+    (:423-431) followed by its final re-save in the plain format (:460-465): after every validation epoch `last.ckpt` is written,
+    and `best.ckpt` whenever the monitored value reaches a new minimum - both with `save_model` (state dict + constructor
+    arguments, loadable by `models.load_model`)."""
+
+    def __init__(self, dirpath: str):
+        self.dirpath = dirpath
+        self.best_value = math.inf
+        self.best_epoch = -1
+        self.history: list[float] = []
+
+    @property
+    def best_model_path(self):
+        return os.path.join(self.dirpath, "best.ckpt")
+
+    @property
+    def last_model_path(self):
+        return os.path.join(self.dirpath, "last.ckpt")
+
+    def _save(self, model, path):
+        import copy
+
+        os.makedirs(self.dirpath, exist_ok=True)
+        save_model(copy.deepcopy(model).to("cpu"), path)
+
+    def on_validation_end(self, epoch: int, model: nn.Module, val_loss: float):
+        self.history.append(val_loss)
+        self._save(model, self.last_model_path)
+        if val_loss < self.best_value:
+            self.best_value, self.best_epoch = val_loss, epoch
+            self._save(model, self.best_model_path)
+
+
 def fit(model: nn.Module, train_loader, criterions, optimizer, scheduler=None, epochs=1, callbacks=(), on_step=None,
-        grad_sync=None):
-    """Epoch loop with Lightning's ordering.  `grad_sync(model)`, if given, runs between backward and the
-    optimiser step (data-parallel: GradAllReduce.finish - waits for the in-place all-reduces that ran during backward).
+        grad_sync=None, val_loader=None, val_criterions=None, reducer=None):
+    """Epoch loop with Lightning's ordering: per step zero_grad -> forward -> loss -> backward -> (gradient exchange) -> clip + Adam;
+    per epoch the scheduler step, then - when `val_loader` is given - a validation epoch (`validate`) whose value goes to the
+    callbacks' `on_validation_end(epoch, model, val_loss)` (CheckpointCallback: best.ckpt / last.ckpt), then `on_train_epoch_end`.
+    Data-parallel replicas pass their `parallel.GradAllReduce` as `reducer`: `begin_step()` before the step, `finish()` between
+    backward and the optimiser (it waits for the in-place all-reduces that ran during backward), and - should backward raise -
+    `abort()` so that no collective is left in flight on gradient memory that is about to be freed.  `grad_sync(model)` is the
+    older hook form of the same (runs between backward and the optimiser step).
     Gradients are dropped (set_to_none) before every step: the arena views autograd installs are the exchange buffers."""
     for cb in callbacks:
         if hasattr(cb, "on_train_start"):
             cb.on_train_start(model)
     model.train()
+    params = list(model.parameters()) if reducer is not None else None
     for epoch in range(epochs):
         for batches in train_loader:
             optimizer.zero_grad(set_to_none=True)
+            if reducer is not None:
+                reducer.begin_step()
             out = training_step(model, batches, epoch, criterions)
-            out["loss"].backward()
+            try:
+                out["loss"].backward()
+            except BaseException:
+                if reducer is not None:
+                    reducer.abort()
+                raise
+            if reducer is not None:
+                reducer.finish(params)
             if grad_sync is not None:
                 grad_sync(model)
             optimizer.step()
@@ -587,6 +662,11 @@ def fit(model: nn.Module, train_loader, criterions, optimizer, scheduler=None, e
                 on_step(epoch, out)
         if scheduler is not None:
             scheduler.step()
+        if val_loader is not None:
+            val_loss = validate(model, val_loader, val_criterions if val_criterions is not None else criterions)
+            for cb in callbacks:
+                if hasattr(cb, "on_validation_end"):
+                    cb.on_validation_end(epoch, model, val_loss)
         for cb in callbacks:
             if hasattr(cb, "on_train_epoch_end"):
                 cb.on_train_epoch_end(epoch, model)
