@@ -25,10 +25,13 @@
 
 namespace ttk {
 
-constexpr int kSlab = 32;            // channels per tile (the kernels shift by 5 where they index LDS pixels)
-constexpr int kSlabQuads = kSlab / 4;
-constexpr int kPixSlots = kBlock / kSlabQuads;  // 32 pixels in flight per pass
-constexpr int kLdsPixBudget = 368;   // (rows) x (W+2) pixels of 128 B each: <= 47 KB -> 3 workgroups per CU (560 -> 2 per CU measured slower)
+// Channels per tile ("slab").  A workgroup touches one SL * 4-byte piece per pixel, the pieces 4 C bytes apart: what the memory system
+// delivers for that shape depends on the piece (tools/stream_sweep.py, profiles/r03_stream_sweep.txt: 5:1 read:write mix at C = 512 -
+// 128-byte pieces 4.9 TB/s, 256-byte pieces 5.5 TB/s, linear 6.2 TB/s).  The kernels are templated on it; what they measured with
+// 64-channel slabs is at dw_tiling().
+constexpr int kLdsPixBudget32 = 368;   // (rows) x (W+2) pixels of 128 B each: <= 47 KB -> 3 workgroups per CU (560 -> 2 per CU measured slower)
+__host__ __device__ constexpr int lds_pix_budget(int SL) { return kLdsPixBudget32 * 32 / SL; }
+__host__ __device__ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 constexpr int kMaxDwBlocks = 768;   // 3 workgroups per CU x 256 CUs: one resident wave of persistent workgroups
 // staging elements per thread and iteration (forward): their loads are in flight together, and the bytes in flight per CU are
 // what these kernels' throughput follows.  Six fit the 168-register budget of three workgroups per CU when the layer has no
@@ -36,6 +39,7 @@ constexpr int kMaxDwBlocks = 768;   // 3 workgroups per CU x 256 CUs: one reside
 constexpr int kFwdUSkip = 4, kFwdUPlain = TTK_DW_FWD_U, kFwdUPlain2 = TTK_DW_FWD_U2;
 
 struct DwTiling {
+  int SL;                             // channels per slab: 32 | 64
   int R, nbands, nslabs, grid, rows;  // rows = partial rows = grid / nslabs
   int NI;                             // images per tile (> 1 only when one band covers the image: the 9x9 and 5x5 layers)
   int stage_rows;                     // LDS rows of one image's stage
@@ -46,8 +50,8 @@ constexpr int kColTileMinW = 48;  // images at least this wide (the 65x65 layer)
 constexpr int kColTile = 17;      // 19 x 19 staged pixels for 17 x 17 results: halo 1.25x instead of 1.7x for 3-row bands
 
 // band height on the grid the kernel iterates (forward: output rows; backward: input rows)
-__host__ __device__ inline int dw_band_rows(int Hgrid, int Wstage, int stride, bool backward) {
-  const int stage_rows = kLdsPixBudget / (Wstage + 2);  // LDS rows we can afford
+__host__ __device__ inline int dw_band_rows(int Hgrid, int Wstage, int stride, bool backward, int SL = 32) {
+  const int stage_rows = lds_pix_budget(SL) / (Wstage + 2);  // LDS rows we can afford
   int R;
   if (!backward) R = (stage_rows - 3) / stride + 1;      // needs (R-1)*S+3 input rows
   else R = (stride == 1) ? stage_rows - 2 : 2 * (stage_rows - 2);  // needs <= R/S+2 output rows
@@ -56,9 +60,10 @@ __host__ __device__ inline int dw_band_rows(int Hgrid, int Wstage, int stride, b
   return R;
 }
 
-inline DwTiling dw_tiling(int B, int H, int W, int C, int stride, bool backward) {
+inline DwTiling dw_tiling_sl(int B, int H, int W, int C, int stride, bool backward, int SL) {
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   DwTiling t;
+  t.SL = SL;
   t.NCT = 1;
   t.TW = Wo;
   if (stride == 1 && W >= kColTileMinW) {
@@ -66,9 +71,9 @@ inline DwTiling dw_tiling(int B, int H, int W, int C, int stride, bool backward)
     t.TW = (W + t.NCT - 1) / t.NCT;
   }
   const int Wtile = t.NCT > 1 ? t.TW : (backward ? Wo : W);
-  t.R = backward ? dw_band_rows(H, Wtile, stride, true) : dw_band_rows(Ho, Wtile, stride, false);
+  t.R = backward ? dw_band_rows(H, Wtile, stride, true, SL) : dw_band_rows(Ho, Wtile, stride, false, SL);
   t.nbands = ((backward ? H : Ho) + t.R - 1) / t.R;
-  t.nslabs = C / kSlab;
+  t.nslabs = C / SL;
   t.stage_rows = backward ? (stride == 1 ? t.R + 2 : t.R / 2 + 2) : (t.R - 1) * stride + 3;
   // Small images: one tile = several whole images side by side in LDS (each with its own zero border).  A 5x5 image
   // is 49 staged pixels - a fraction of one pass of the 256 threads between two barriers; seven of them fill the
@@ -76,7 +81,7 @@ inline DwTiling dw_tiling(int B, int H, int W, int C, int stride, bool backward)
   t.NI = 1;
   if (t.nbands == 1 && t.NCT == 1) {
     const int per_image = t.stage_rows * ((backward ? Wo : W) + 2);
-    t.NI = kLdsPixBudget / per_image;
+    t.NI = lds_pix_budget(SL) / per_image;
     if (t.NI > B) t.NI = B;
     if (t.NI < 1) t.NI = 1;
   }
@@ -87,6 +92,16 @@ inline DwTiling dw_tiling(int B, int H, int W, int C, int stride, bool backward)
   t.rows = (int)rows;
   t.grid = t.rows * t.nslabs;
   return t;
+}
+
+inline DwTiling dw_tiling(int B, int H, int W, int C, int stride, bool backward) {
+  // 64-channel slabs are built and tested (TTK_DW_SLAB=64) but NOT the default: measured on the C >= 512 layers at B = 512 the forward
+  // kernels did not change (59 us) and the backward kernels lost 5-10 % (97 -> 102-108 us, 65 -> 72 us) - with half the pixels per LDS
+  // stage a tile is one 9x9 image instead of three, and the per-tile barriers and latencies outweigh what 256-byte pieces gain at the
+  // memory (the 32-channel kernels already run above the streaming probe's rate for their piece size).
+  static const int force = [] { const char* e = getenv("TTK_DW_SLAB"); return e ? atoi(e) : 0; }();
+  if (force == 64 && C >= 64) return dw_tiling_sl(B, H, W, C, stride, backward, 64);
+  return dw_tiling_sl(B, H, W, C, stride, backward, 32);
 }
 
 // n / d for the tile-local pixel indices (0 <= n < 2^20, 1 <= d < 2^12) in four VALU operations: (n + 0.5) / d is at least 0.5 / d
@@ -113,10 +128,11 @@ struct SlabWeights {  // w[c][tap] of 4 consecutive channels
   __device__ __forceinline__ float4 tap(int t) const { return make_float4(v[t], v[9 + t], v[18 + t], v[27 + t]); }
 };
 
-// fold over the 32 pixel slots of the block: lanes 8 apart own the same quad
+// fold over the pixel slots of the block that sit in one wave: lanes SL / 4 apart own the same quad
+template <int SL>
 __device__ __forceinline__ float4 slab_wave_fold(float4 v) {
 #pragma unroll
-  for (int off = kSlabQuads; off < kWave; off <<= 1) {
+  for (int off = SL / 4; off < kWave; off <<= 1) {
     v.x += __shfl_xor(v.x, off); v.y += __shfl_xor(v.y, off);
     v.z += __shfl_xor(v.z, off); v.w += __shfl_xor(v.w, off);
   }
@@ -139,9 +155,10 @@ __device__ __forceinline__ double shfl_xor_d(double v, int off) {
   hi = __shfl_xor(hi, off);
   return __hiloint2double(hi, lo);
 }
+template <int SL>
 __device__ __forceinline__ D4 slab_wave_fold_d(D4 v) {
 #pragma unroll
-  for (int off = kSlabQuads; off < kWave; off <<= 1) {
+  for (int off = SL / 4; off < kWave; off <<= 1) {
     v.x += shfl_xor_d(v.x, off); v.y += shfl_xor_d(v.y, off);
     v.z += shfl_xor_d(v.z, off); v.w += shfl_xor_d(v.w, off);
   }
@@ -149,23 +166,24 @@ __device__ __forceinline__ D4 slab_wave_fold_d(D4 v) {
 }
 
 // writes part_row[0][slab columns] = sum s1, part_row[1][slab columns] = sum s2 (fixed wave order)
+template <int SL>
 __device__ __forceinline__ void slab_partials(D4 s1, D4 s2, int q, int C, int c_slab, float* part_row, float* red_f) {
-  double* red = reinterpret_cast<double*>(red_f);  // [4 waves][2][32] doubles
-  s1 = slab_wave_fold_d(s1);
-  s2 = slab_wave_fold_d(s2);
+  double* red = reinterpret_cast<double*>(red_f);  // [4 waves][2][SL] doubles
+  s1 = slab_wave_fold_d<SL>(s1);
+  s2 = slab_wave_fold_d<SL>(s2);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   __syncthreads();
-  if (lane < kSlabQuads) {
-    double* d = red + (wv * 2 + 0) * kSlab + 4 * q;
+  if (lane < SL / 4) {
+    double* d = red + (wv * 2 + 0) * SL + 4 * q;
     d[0] = s1.x; d[1] = s1.y; d[2] = s1.z; d[3] = s1.w;
-    d = red + (wv * 2 + 1) * kSlab + 4 * q;
+    d = red + (wv * 2 + 1) * SL + 4 * q;
     d[0] = s2.x; d[1] = s2.y; d[2] = s2.z; d[3] = s2.w;
   }
   __syncthreads();
-  if (threadIdx.x < 2 * kSlab) {
-    const int which = threadIdx.x / kSlab, c = threadIdx.x % kSlab;
+  if (threadIdx.x < 2 * SL) {
+    const int which = threadIdx.x / SL, c = threadIdx.x % SL;
     double a = 0.0;
-    for (int w = 0; w < kBlock / kWave; ++w) a += red[(w * 2 + which) * kSlab + c];
+    for (int w = 0; w < kBlock / kWave; ++w) a += red[(w * 2 + which) * SL + c];
     part_row[(size_t)which * C + c_slab + c] = (float)a;
   }
 }
@@ -173,15 +191,16 @@ __device__ __forceinline__ void slab_partials(D4 s1, D4 s2, int q, int C, int c_
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-template <int S, typename T, bool SKIP>
+template <int S, typename T, bool SKIP, int SL>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3)))
 dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
                                                           const T* __restrict__ skip_prev, T* __restrict__ a_out,
                                                           const float* __restrict__ w, T* __restrict__ y,
                                                           float* __restrict__ part, int B, int H, int W, int C, int Ho, int Wo,
                                                           int R, int nbands, int nslabs, int NI, int NCT, int TW) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [NI][stage_rows][tile width + 2][32] + reduction scratch
-  const int tid = threadIdx.x, q = tid & (kSlabQuads - 1), slot = tid >> 3;
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [NI][stage_rows][tile width + 2][SL] + reduction scratch
+  constexpr int kSlab = SL, kSlabQuads = SL / 4, kPixSlots = kBlock / kSlabQuads, kQs = ilog2(kSlabQuads), kPs = ilog2(SL);
+  const int tid = threadIdx.x, q = tid & (kSlabQuads - 1), slot = tid >> kQs;
   const int slab = blockIdx.x % nslabs, c0 = slab * kSlab + 4 * q;
   const int cshift = __builtin_ctz((unsigned)C);  // C is a power of two
   SlabWeights wr;
@@ -223,7 +242,7 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
 #pragma unroll
       for (int u = 0; u < kFwdU; ++u) {
         const int ee = e + u * kBlock;
-        const unsigned pxa = (unsigned)ee >> 3;              // pixel slot in LDS over all images of the tile
+        const unsigned pxa = (unsigned)ee >> kQs;            // pixel slot in LDS over all images of the tile
         const unsigned img = NI > 1 ? dPI.div(pxa) : 0u, px = NI > 1 ? pxa - __umul24(img, PI) : pxa;
         const unsigned prow = dWp.div(px);
         const int col = (int)(px - __umul24(prow, (unsigned)Wp)) - 1 + cx0, row = i0 + (int)prow;
@@ -257,7 +276,7 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
       const unsigned img = NI > 1 ? dnp.div((unsigned)p) : 0u, pp = NI > 1 ? (unsigned)p - __umul24(img, npix1) : (unsigned)p;
       const unsigned prow = dtw.div(pp);
       const int ho = o0 + (int)prow, wl = (int)(pp - __umul24(prow, (unsigned)tw)), wo = cx0 + wl;
-      const float* base = lds + ((__umul24(img, PI) + __umul24(prow * S, (unsigned)Wp) + (unsigned)(wl * S)) << 5) + 4 * q;  // tap (0,0): row ho*S-1, col wo*S-1
+      const float* base = lds + ((__umul24(img, PI) + __umul24(prow * S, (unsigned)Wp) + (unsigned)(wl * S)) << kPs) + 4 * q;  // tap (0,0): row ho*S-1, col wo*S-1
       float4 acc = f4(0.f);
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
@@ -271,14 +290,14 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
   }
   if (part) {
     const int stage = NI * ((R - 1) * S + 3) * (NCT > 1 ? TW + 2 : W + 2) * kSlab;
-    slab_partials(s1, s2, q, C, slab * kSlab, part + (size_t)(blockIdx.x / nslabs) * 2 * C, lds + stage);
+    slab_partials<SL>(s1, s2, q, C, slab * kSlab, part + (size_t)(blockIdx.x / nslabs) * 2 * C, lds + stage);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // data gradient (+ fused weight gradient)
 // ---------------------------------------------------------------------------------------------
-template <int S, typename T, typename TG>
+template <int S, typename T, typename TG, int SL>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3)))  // <= 168 VGPRs: 3 workgroups per CU, as the LDS tile allows
 dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
                                                           const float* __restrict__ bn_dw, const float* __restrict__ w,
@@ -288,8 +307,9 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
                                                           TG* __restrict__ g_prev, float* __restrict__ part,
                                                           float* __restrict__ dwgrad, float* __restrict__ dw_partial, int B, int H, int W, int C, int Ho, int Wo,
                                                           int R, int nbands, int nslabs, int stage_floats, int NI, int NCT, int TW) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // dy[NI][stage_rows][Wo+2][32] + reduction scratch
-  const int tid = threadIdx.x, q = tid & (kSlabQuads - 1), slot = tid >> 3;
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // dy[NI][stage_rows][Wo+2][SL] + reduction scratch
+  constexpr int kSlab = SL, kSlabQuads = SL / 4, kPixSlots = kBlock / kSlabQuads, kQs = ilog2(kSlabQuads), kPs = ilog2(SL);
+  const int tid = threadIdx.x, q = tid & (kSlabQuads - 1), slot = tid >> kQs;
   const int slab = blockIdx.x % nslabs, c0 = slab * kSlab + 4 * q;
   // the filter taps of this thread's channel quad live in LDS (wt[tap][32 channels], after the reduction scratch):
   // 36 fewer VGPRs, which pays for handling two pixels per iteration below
@@ -341,7 +361,7 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
 #pragma unroll
       for (int u = 0; u < kBwdU; ++u) {
         const int ee = e + u * kBlock;
-        const unsigned pxa = (unsigned)ee >> 3;
+        const unsigned pxa = (unsigned)ee >> kQs;
         const unsigned img = NI > 1 ? dPI.div(pxa) : 0u, px = NI > 1 ? pxa - __umul24(img, PI) : pxa;
         const unsigned prow = dWp.div(px);
         const int col = (int)(px - __umul24(prow, (unsigned)Wp)) - 1 + cx0, row = ho_lo + (int)prow;
@@ -354,7 +374,7 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
       for (int u = 0; u < kBwdU; ++u) {
         const int ee = e + u * kBlock;
         if (ee >= nstage) break;
-        st4(lds + (size_t)(ee >> 3) * kSlab + 4 * q, in[u] ? bg.dy(gv[u], yv[u]) : f4(0.f));
+        st4(lds + (size_t)(ee >> kQs) * kSlab + 4 * q, in[u] ? bg.dy(gv[u], yv[u]) : f4(0.f));
       }
     }
     __syncthreads();
@@ -383,7 +403,7 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
       for (int half = 0; half < 2; ++half) {
         if (half == 1 && !hasb) break;
         const int hi = half ? hiB : hiA, wi = half ? wiB : wiA;
-        const float* dyimg = lds + (__umul24(half ? imgB : imgA, PI) << 5);
+        const float* dyimg = lds + (__umul24(half ? imgB : imgA, PI) << kPs);
         const float4 yp = half ? ypB : ypA, raw = half ? rawB : rawA, sg = half ? sgB : sgA;
         float4 a;
         if (a_in) a = raw;
@@ -400,7 +420,7 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
             const int tw = wi + 1 - kw;  // -1 .. W
             if (S == 2 && (tw & 1)) continue;
             const int wo = (S == 1) ? tw : (tw >> 1);  // -1 or Wo hit the zero padding columns (S=1); always inside for S=2
-            const float4 dy = ld4(dyimg + ((__mul24(ho - ho_lo, Wp) + wo - cx0 + 1) << 5) + 4 * q);
+            const float4 dy = ld4(dyimg + ((__mul24(ho - ho_lo, Wp) + wo - cx0 + 1) << kPs) + 4 * q);
             G = fma4(dy, ld4(wt + (kh * 3 + kw) * kSlab + 4 * q), G);
             wacc[kh * 3 + kw] = fma4(dy, a, wacc[kh * 3 + kw]);
           }
@@ -421,13 +441,13 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
     unsigned* slot = reinterpret_cast<unsigned*>(bn_prev + (size_t)TTK_BN_AUX * C + TTK_AUX_GMAX);
     if (__float_as_uint(gmx) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, __float_as_uint(gmx));
   }
-  if (part) slab_partials(s1, s2, q, C, slab * kSlab, part + (size_t)(blockIdx.x / nslabs) * 2 * C, red);
+  if (part) slab_partials<SL>(s1, s2, q, C, slab * kSlab, part + (size_t)(blockIdx.x / nslabs) * 2 * C, red);
   if (dwgrad) {
     __syncthreads();
     const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const float4 v = slab_wave_fold(wacc[t]);
+      const float4 v = slab_wave_fold<SL>(wacc[t]);
       if (lane < kSlabQuads) st4(red + ((size_t)wv * 9 + t) * kSlab + 4 * q, v);
     }
     __syncthreads();
@@ -469,14 +489,16 @@ int ttk_dwconv3x3_fwd(const void* yprev, const float* bn_prev, const void* skip_
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const DwTiling t = dw_tiling(B, H, W, C, stride, false);
   TTK_REQUIRE((int64_t)((B + t.NI - 1) / t.NI) * t.nbands * t.NCT < ((int64_t)1 << 31), "dwconv3x3_fwd: too many tiles for 32-bit indexing");
-  const size_t stage = (size_t)t.NI * t.stage_rows * ((t.NCT > 1 ? t.TW : W) + 2) * kSlab;
-  const size_t sm = (stage + 16 * kSlab) * sizeof(float);  // + [4][2][32] doubles of reduction scratch
-#define TTK_DW_FWD(S_, SK_)                                                                                                        \
-  hipLaunchKernelGGL((dw_fwd_tiled_k<S_, ActT, SK_>), dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, (const ActT*)yprev, bn_prev, \
+  const size_t stage = (size_t)t.NI * t.stage_rows * ((t.NCT > 1 ? t.TW : W) + 2) * t.SL;
+  const size_t sm = (stage + 16 * t.SL) * sizeof(float);  // + [4][2][SL] doubles of reduction scratch
+#define TTK_DW_FWD_SL(S_, SK_, SL_)                                                                                                     \
+  hipLaunchKernelGGL((dw_fwd_tiled_k<S_, ActT, SK_, SL_>), dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, (const ActT*)yprev, bn_prev, \
                      (const ActT*)skip_prev, (ActT*)a_out, w, (ActT*)y, part, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI, t.NCT, t.TW)
+#define TTK_DW_FWD(S_, SK_) do { if (t.SL == 64) TTK_DW_FWD_SL(S_, SK_, 64); else TTK_DW_FWD_SL(S_, SK_, 32); } while (0)
   TTK_ACT_DISPATCH(act_bf16, if (stride == 1) { if (skip_prev) TTK_DW_FWD(1, true); else TTK_DW_FWD(1, false); }
                              else { if (skip_prev) TTK_DW_FWD(2, true); else TTK_DW_FWD(2, false); });
 #undef TTK_DW_FWD
+#undef TTK_DW_FWD_SL
   TTK_LAUNCH_CHECK("dwconv3x3_fwd");
 }
 
@@ -490,17 +512,19 @@ int ttk_dwconv3x3_bwd_data(const void* g_dw, const void* y_dw, const float* bn_d
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const DwTiling t = dw_tiling(B, H, W, C, stride, true);
   TTK_REQUIRE((int64_t)((B + t.NI - 1) / t.NI) * t.nbands * t.NCT < ((int64_t)1 << 31), "dwconv3x3_bwd_data: too many tiles for 32-bit indexing");
-  const size_t stage = (size_t)t.NI * t.stage_rows * ((t.NCT > 1 ? t.TW : Wo) + 2) * kSlab;
-  const size_t sm = (stage + 4 * 9 * kSlab + 9 * kSlab) * sizeof(float);  // stage + reduction scratch + filter taps
+  const size_t stage = (size_t)t.NI * t.stage_rows * ((t.NCT > 1 ? t.TW : Wo) + 2) * t.SL;
+  const size_t sm = (stage + 4 * 9 * t.SL + 9 * t.SL) * sizeof(float);  // stage + reduction scratch + filter taps
   hipStream_t st = (hipStream_t)stream;
   if (!dw) dw_partial = nullptr;
   if (dw && !dw_accumulate && !dw_partial) hipLaunchKernelGGL(zero_fill_k, dim3((9 * C + 255) / 256), dim3(256), 0, st, dw, (int64_t)9 * C);
-#define TTK_DW_BWD(S_)                                                                                                              \
-  hipLaunchKernelGGL((dw_bwd_tiled_k<S_, ActT, GradT>), dim3(t.grid), dim3(kBlock), sm, st, (const GradT*)g_dw, (const ActT*)y_dw, bn_dw, w, \
+#define TTK_DW_BWD(S_) do { if (t.SL == 64) TTK_DW_BWD_SL(S_, 64); else TTK_DW_BWD_SL(S_, 32); } while (0)
+#define TTK_DW_BWD_SL(S_, SL_)                                                                                                      \
+  hipLaunchKernelGGL((dw_bwd_tiled_k<S_, ActT, GradT, SL_>), dim3(t.grid), dim3(kBlock), sm, st, (const GradT*)g_dw, (const ActT*)y_dw, bn_dw, w, \
                      (const GradT*)skip_grad, (const ActT*)yprev, bn_prev, (const ActT*)skip_prev, (const ActT*)a_in, (GradT*)g_prev, part,  \
                      dw, dw_partial, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage, t.NI, t.NCT, t.TW)
   TTK_ACT_DISPATCH(act_bf16, if (stride == 1) TTK_DW_BWD(1); else TTK_DW_BWD(2));
 #undef TTK_DW_BWD
+#undef TTK_DW_BWD_SL
   if (dw_partial) launch_fold_partials(dw_partial, t.rows, (int64_t)9 * C, dw, dw_accumulate, st);
   TTK_LAUNCH_CHECK("dwconv3x3_bwd_data");
 }
