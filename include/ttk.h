@@ -42,7 +42,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 15
+#define TTK_ABI_VERSION 16
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -194,8 +194,11 @@ int ttk_pwconv1x1_bwd_data(const void* g, const void* y, const float* bn_pw, con
  * partial == NULL: the M dimension is split over workgroups that add atomically (fp32 atomics: the result depends on
  * the order the hardware commits them).  partial = scratch of ttk_pwconv_wgrad_partial_bytes(M, Cin, Cout) (0 = this
  * shape / GEMM mode has no such form): every slice of M stores its tile and a second kernel adds the slices to dw in a
- * fixed order - bitwise reproducible. */
+ * fixed order - bitwise reproducible.  For Cin, Cout multiples of 256 the slice form is also the FASTER one (256 x 256 tiles with transposed
+ * LDS reads, csrc/pwconv_r.hip): ttk_pwconv_wgrad_scratch_bytes says how much scratch the default mode wants to be handed as `partial`
+ * for a shape (0: none, the atomic form runs). */
 size_t ttk_pwconv_wgrad_partial_bytes(int64_t M, int Cin, int Cout);
+size_t ttk_pwconv_wgrad_scratch_bytes(int64_t M, int Cin, int Cout);
 int ttk_pwconv1x1_bwd_weight(const void* g, const void* y, const float* bn_pw, const void* ydw,
                              const float* bn_dw, float* dw, float* partial, int64_t M, int Cin, int Cout,
                              int act_bf16, ttk_stream_t stream);

@@ -378,6 +378,13 @@ template <int MODE, typename T, typename TO>
 bool launch_f16r_gemm(const TO* A0, const T* A1, const float* bnA, const float* Bm, TO* out, const T* E0, const float* bnE, float* part,
                       int64_t M, int K, int Nout, void* planes, float* wmax, hipStream_t st);
 
+// pwconv_r.hip: weight gradient of the layers with Cin, Cout multiples of 256 on 256 x 256 tiles with transposed LDS fragment reads; always
+// reduces through `partial` (scratch of f16t_wgrad_scratch_bytes) and a fixed-order fold
+template <typename T, typename TG>
+bool launch_f16t_wgrad(const TG* g, const T* y, const float* bn_pw, const T* ydw, const float* bn_dw, float* dw, float* partial, int64_t M,
+                       int Cin, int Cout, hipStream_t st);
+size_t f16t_wgrad_scratch_bytes(int64_t M, int Cin, int Cout);
+
 // pwconv_split.hip: the same shapes on the bf16 pipe with exact 3-piece splits (six products; TTK_GEMM=bf16x3, and the
 // implicit-GEMM convolutions of the ResNet18 variant)
 #ifdef TTK_WITH_BF16X3
@@ -581,9 +588,16 @@ static void fp32_wgrad_plan(int64_t M, int Cin, int Cout, int& bn, int& bk, int&
   slices = ceil_div(M, rows);
 }
 
+size_t ttk_pwconv_wgrad_scratch_bytes(int64_t M, int Cin, int Cout) {
+  if (!pw_shape_ok(M, Cin, Cout) || gemm_mode() != GEMM_F16X2) return 0;
+  return f16t_wgrad_scratch_bytes(M, Cin, Cout);
+}
+
 size_t ttk_pwconv_wgrad_partial_bytes(int64_t M, int Cin, int Cout) {
   if (!pw_shape_ok(M, Cin, Cout)) return 0;
   if (gemm_mode() == GEMM_F16X2) {
+    const size_t t = f16t_wgrad_scratch_bytes(M, Cin, Cout);
+    if (t) return t;
     const size_t b = f16_wgrad_partial_bytes(M, Cin, Cout);
     if (b) return b;
   } else if (gemm_mode() == GEMM_BF16X3 && Cin >= 128 && Cout >= 128 && (int64_t)Cin * Cout >= 128 * 256) {
@@ -602,6 +616,9 @@ int ttk_pwconv1x1_bwd_weight(const void* g, const void* y, const float* bn_pw, c
   TTK_REQUIRE(!(act_bf16 && gemm_mode() == GEMM_BF16X3), "pwconv1x1_bwd_weight: bf16 activations need TTK_GEMM=f16x2 (default) or f32mfma");
   if (gemm_mode() == GEMM_F16X2) {
     bool done = false;
+    TTK_ACT_DISPATCH(act_bf16, done = launch_f16t_wgrad<ActT, GradT>((const GradT*)g, (const ActT*)y, bn_pw, (const ActT*)ydw, bn_dw, dw, partial, M, Cin, Cout,
+                                                              (hipStream_t)stream));
+    if (done) { TTK_LAUNCH_CHECK("pwconv1x1_bwd_weight"); }
     TTK_ACT_DISPATCH(act_bf16, done = launch_f16_wgrad<ActT, GradT>((const GradT*)g, (const ActT*)y, bn_pw, (const ActT*)ydw, bn_dw, dw, partial, M, Cin, Cout,
                                                              (hipStream_t)stream));
     if (done) { TTK_LAUNCH_CHECK("pwconv1x1_bwd_weight"); }

@@ -325,6 +325,235 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient  dW[co][ci] += sum_m dy[m][co] * a[m][ci]  of the layers with Cin and Cout multiples of 256, 256 x 256 tiles.
+//
+// The contraction runs over the pixels m, so an MFMA fragment needs 8 CONSECUTIVE m of one channel, while memory has the channels
+// contiguous.  pw16_wgrad_k transposes in registers (4 rows x 4 channels per thread) and scatters 8-byte pieces into channel-major LDS
+// rows - 2-way bank conflicts on every store (SQ_LDS_BANK_CONFLICT = a third of its LDS cycles) and a 128 x 256 tile per CU, i.e.
+// every slice of dy is formed by two workgroups and every slice of a by four.  Here
+//  * the producers store what they load: LDS holds the piece planes in the tensors' own [m][channel] order (8-byte pieces, lanes side by
+//    side: conflict-free), and the CONSUMERS read their fragments transposed with ds_read_b64_tr_b16 (a 4 m x 16 channel block per
+//    16-lane group, column-major into the lanes: the fragment of 32x32x16 is two such reads); rows are padded from 512 to 576 bytes so
+//    that the four rows of a block fall into four different 64-byte bank windows;
+//  * the tile is 256 x 256 on eight consumer waves (64 x 128 each): dy is formed twice (not per 128 output channels), a twice instead of
+//    four times;
+//  * every workgroup stores its tile to partial[slice][Cout][Cin] and wgrad_fold_k adds the slices in a fixed order: 64 MB of float
+//    atomics per launch would take 50 us at the chip's 1.3 TB/s atomic rate, the plain stores and the fold take about half - and the
+//    result is bitwise reproducible in every mode.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTRow = 576;                       // bytes of one m-row of a piece plane: 256 channels x 2 B + 64 B (bank windows)
+constexpr int kTPlane = 16 * kTRow;              // one piece plane of one operand of a k16 stage
+constexpr int kTStage = 4 * kTPlane;             // [dy h][dy l][a h][a l]
+constexpr int kTRing = 2 * 2 * kTStage;          // two k32 super-stages
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x8 tr_frag(const unsigned char* plane, int off) {
+  // rows 8h .. 8h+3 and 8h+4 .. 8h+7 of the stage (the lane's address already holds 8h + q): element j = 4 t + q' of the fragment
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + off));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + off + 4 * kTRow));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(f16x8, v);
+}
+__device__ __forceinline__ void tsplit_store(f32x4 v, unsigned char* dst) {  // 4 consecutive channels of one m-row: h at dst, l at dst + kTPlane
+  const f16x2 h01 = __builtin_convertvector(f32x2{v.x, v.y}, f16x2), h23 = __builtin_convertvector(f32x2{v.z, v.w}, f16x2);
+  const f32x2 f01 = __builtin_convertvector(h01, f32x2), f23 = __builtin_convertvector(h23, f32x2);
+  const f16x2 l01 = __builtin_convertvector(f32x2{v.x - f01.x, v.y - f01.y}, f16x2);
+  const f16x2 l23 = __builtin_convertvector(f32x2{v.z - f23.x, v.w - f23.y}, f16x2);
+  *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+  *reinterpret_cast<uint2*>(dst + kTPlane) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+}
+
+// G, Y: [M][Cout] (gradient w.r.t. the BatchNorm output, raw conv output), X: [M][Cin] (raw depthwise output); partial[slice][Cout][Cin]
+template <typename T, typename TG>
+__global__ void __launch_bounds__(768) pw16t_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __restrict__ bn_pw,
+                                                     const T* __restrict__ X, const float* __restrict__ bn_x, float* __restrict__ partial,
+                                                     int64_t M, int Cin, int Cout, int64_t rows_per_slice) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kTRing];
+  const int tid = threadIdx.x;
+  // XCD-aware order: every XCD gets whole slices (the tiles of a slice read the same rows of g, y and x)
+  const unsigned NT = (Cout / 256) * (Cin / 256), NG = gridDim.x, Lid = blockIdx.x;
+  const unsigned xq = NG / 8, xr = NG % 8, xcd = Lid % 8;
+  const unsigned logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + Lid / 8;
+  const unsigned tile = logical % NT, slice = logical / NT;
+  const int tiles_k = Cin / 256;
+  const int n0 = (tile / tiles_k) * 256, k0 = (tile % tiles_k) * 256;  // first output channel / input channel of the tile
+  const int64_t m_begin = (int64_t)slice * rows_per_slice;
+  const int64_t m_end = (m_begin + rows_per_slice < M) ? m_begin + rows_per_slice : M;
+  const int nks = m_begin < m_end ? (int)((m_end - m_begin + 31) / 32) : 0;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float sa = pow2_scale(bn_pw[(size_t)TTK_BN_AUX * Cout + TTK_AUX_DY_BOUND]);
+  const float sb = pow2_scale(bn_x[(size_t)TTK_BN_AUX * Cin + TTK_AUX_ACT_BOUND]);
+  f32x16 acc[2][4];  // consumer waves: 64 output channels x 128 input channels
+
+  if (wave >= 8) {
+    // ---------------- producers: wave w owns rows 8 w .. 8 w + 7 of every k32 step, lane = channel quad ----------------
+    __builtin_amdgcn_s_setprio(3);
+    const int pw = wave - 8, quad = tid & 63;
+    const int ca = n0 + 4 * quad, cb = k0 + 4 * quad;
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GA * Cout + ca) * sa;
+    const f32x4 gb = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GB * Cout + ca) * sa;
+    const f32x4 gmean = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GMEAN * Cout + ca);
+    const f32x4 ymean = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_MEAN * Cout + ca);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_SCALE * Cin + cb) * sb;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_MEAN * Cin + cb);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_BETA * Cin + cb) * sb;
+    f32x4 rg[8], ry[8], rx[8];
+    const int64_t r0 = m_begin + 8 * pw;
+    // LDS: k16 stage (pw >> 1) of the step, rows 8 (pw & 1) .. + 7
+    unsigned char* wdy = lds + (pw >> 1) * kTStage + (8 * (pw & 1)) * kTRow + quad * 8;
+    unsigned char* wx = wdy + 2 * kTPlane;
+    auto load_row = [&](int ks, int i) {
+      int64_t row = r0 + (int64_t)ks * 32 + i;
+      row = row < m_end ? row : m_end - 1;  // (rows past the slice are zeroed when they are stored)
+      rg[i] = rld_act4<TG>(G + row * Cout + ca);
+      ry[i] = rld_act4<T>(Y + row * Cout + ca);
+      rx[i] = rld_act4<T>(X + row * Cin + cb);
+    };
+    auto store = [&](int ks) {  // the eight rows of step ks: BatchNorm backward / BatchNorm + ReLU, split, to LDS
+      unsigned char* dy = wdy + (ks & 1) * 2 * kTStage;
+      unsigned char* xx = wx + (ks & 1) * 2 * kTStage;
+      const int64_t row0 = r0 + (int64_t)ks * 32;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool live = row0 + i < m_end;  // rows past the slice contribute nothing
+        f32x4 v = ga * (rg[i] - gmean) + gb * (ry[i] - ymean);
+        f32x4 a = sc * (rx[i] - mu) + be;
+        a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+        if (!live) { v = f32x4{0.f, 0.f, 0.f, 0.f}; a = v; }
+        tsplit_store(v, dy + i * kTRow);
+        tsplit_store(a, xx + i * kTRow);
+      }
+    };
+    if (nks > 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) load_row(0, i);
+      for (int s = 0; s < nks; ++s) {
+        store(s);
+        if (s + 1 < nks) {  // in flight across the barrier; waited for by the next store
+#pragma unroll
+          for (int i = 0; i < 8; ++i) load_row(s + 1, i);
+        }
+        rbarrier();  // stage s is in LDS; the consumers are done with stage s - 1
+      }
+      rbarrier();
+    }
+  } else {
+    // ---------------- consumers: transposed fragment reads + three piece products per block pair ----------------
+    const int lane = tid & 63, wm = wave >> 1, wn = wave & 1;
+    const int grp = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3, h = grp >> 1;
+    // this lane's address inside a plane for the 32-channel block that starts at channel `c32`: row 8h + q, channels c32 + 16 (grp & 1) + 4 p
+    const int lane_off = (8 * h + q) * kTRow + (16 * (grp & 1) + 4 * p4) * 2;
+    int aoff[2], boff[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) aoff[i] = lane_off + (wm * 64 + i * 32) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) boff[j] = 2 * kTPlane + lane_off + (wn * 128 + j * 32) * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    if (nks > 0) {
+      rbarrier();  // stage 0 is in LDS
+      for (int it = 0; it < nks; ++it) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          const unsigned char* S = lds + ((it & 1) * 2 + sub) * kTStage;
+          f16x8 a[2][2], b[2][2];
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i][pl] = tr_frag(S + pl * kTPlane, aoff[i]);
+            b[0][pl] = tr_frag(S + pl * kTPlane, boff[0]);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int cur = j & 1;
+            if (j + 1 < 4) {
+#pragma unroll
+              for (int pl = 0; pl < 2; ++pl) b[cur ^ 1][pl] = tr_frag(S + pl * kTPlane, boff[j + 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[cur][1], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[cur][0], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[cur][0], acc[i][j], 0, 0, 0);
+            }
+          }
+        }
+        rbarrier();  // done with stage `it`; stage it + 1 is in LDS
+      }
+    }
+    // ---- the tile of this slice: plain stores (lanes = 32 consecutive input channels: 128-byte segments)
+    const float inv = 1.f / (sa * sb);
+    const int r = lane & 31, hh = lane >> 5;
+    float* dst = partial + (size_t)slice * Cout * Cin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = n0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          const int col = k0 + wn * 128 + j * 32 + r;
+          dst[(size_t)row * Cin + col] = acc[i][j][e] * inv;
+        }
+  }
+}
+
+// dW[i] += partial[0][i] + partial[1][i] + ... (fixed order: bitwise reproducible); 16 B per lane
+__global__ void __launch_bounds__(256) wgrad_fold_k(const float* __restrict__ partial, float* __restrict__ dW, int64_t n, int slices) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 a = ld4(dW + i);
+  for (int s = 0; s < slices; ++s) a = add4(a, ld4nt(partial + (size_t)s * n + i));
+  st4(dW + i, a);
+}
+
+bool f16t_wgrad_shape(int Cin, int Cout) {
+  // measured at B = 512 (profiles/r03_wgrad_transposed.txt): ahead of the row-fragment kernel only on the 1024 x 1024 layer, so
+  // that is the default; TTK_WGRAD_T=1 takes every shape the tile divides, TTK_WGRAD_T=0 none
+  static const int mode = [] { const char* e = getenv("TTK_WGRAD_T"); return e ? (e[0] == '0' ? 0 : 2) : 1; }();
+  if (mode == 0 || gemm_mode() != GEMM_F16X2 || Cin < 256 || Cout < 256 || Cin % 256 || Cout % 256) return false;
+  return mode == 2 || (Cin == 1024 && Cout == 1024);
+}
+static void t_wgrad_plan(int64_t M, int Cin, int Cout, int& tiles, int64_t& slices, int64_t& rows) {
+  tiles = (Cout / 256) * (Cin / 256);
+  slices = 256 / tiles;
+  if (slices < 1) slices = 1;
+  const int64_t max_slices = ceil_div(M, 64);
+  if (slices > max_slices) slices = max_slices;
+  rows = ceil_div(ceil_div(M, slices), 32) * 32;
+  slices = ceil_div(M, rows);
+}
+size_t f16t_wgrad_scratch_bytes(int64_t M, int Cin, int Cout) {
+  if (!f16t_wgrad_shape(Cin, Cout)) return 0;
+  int tiles;
+  int64_t slices, rows;
+  t_wgrad_plan(M, Cin, Cout, tiles, slices, rows);
+  return (size_t)slices * Cin * Cout * sizeof(float);
+}
+template <typename T, typename TG>
+bool launch_f16t_wgrad(const TG* g, const T* y, const float* bn_pw, const T* ydw, const float* bn_dw, float* dw, float* partial, int64_t M,
+                       int Cin, int Cout, hipStream_t st) {
+  if (!partial || !f16t_wgrad_shape(Cin, Cout)) return false;
+  int tiles;
+  int64_t slices, rows;
+  t_wgrad_plan(M, Cin, Cout, tiles, slices, rows);
+  hipLaunchKernelGGL((pw16t_wgrad_k<T, TG>), dim3((unsigned)(tiles * slices)), dim3(768), 0, st, g, y, bn_pw, ydw, bn_dw, partial, M, Cin, Cout, rows);
+  const int64_t n = (int64_t)Cin * Cout;
+  hipLaunchKernelGGL(wgrad_fold_k, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, st, partial, dw, n, (int)slices);
+  return true;
+}
+template bool launch_f16t_wgrad<float, float>(const float*, const float*, const float*, const float*, const float*, float*, float*, int64_t, int, int, hipStream_t);
+template bool launch_f16t_wgrad<bf16_t, bf16_t>(const bf16_t*, const bf16_t*, const float*, const bf16_t*, const float*, float*, float*, int64_t, int, int,
+                                                hipStream_t);
+template bool launch_f16t_wgrad<bf16_t, float>(const float*, const bf16_t*, const float*, const bf16_t*, const float*, float*, float*, int64_t, int, int,
+                                               hipStream_t);
+
 // ---- tiling: row blocks of RT rows such that the tiles fill whole rounds of the CUs ------------------------------------------
 bool f16r_enabled() {
   static const bool on = [] { const char* e = getenv("TTK_GEMM_R"); return !(e && e[0] == '0'); }();

@@ -90,7 +90,7 @@ _SIGNATURES = {
     "ttk_stream_probe": [_P, _P, _P, _L, _I, _I, _I, _I, _L, _I, _I, _I],
 }
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class LossOp(ctypes.Structure):
@@ -138,6 +138,7 @@ class _Library:
         self.cdll.ttk_pwconv_prepared_bytes.argtypes, self.cdll.ttk_pwconv_prepared_bytes.restype = [c_int, c_int], ctypes.c_size_t
         self.cdll.ttk_partial_rows_dwconv.argtypes, self.cdll.ttk_partial_rows_dwconv.restype = [c_int] * 6, c_int
         self.cdll.ttk_pwconv_wgrad_partial_bytes.argtypes, self.cdll.ttk_pwconv_wgrad_partial_bytes.restype = [c_int64, c_int, c_int], ctypes.c_size_t
+        self.cdll.ttk_pwconv_wgrad_scratch_bytes.argtypes, self.cdll.ttk_pwconv_wgrad_scratch_bytes.restype = [c_int64, c_int, c_int], ctypes.c_size_t
         self.cdll.ttk_conv_wgrad_partial_bytes.argtypes, self.cdll.ttk_conv_wgrad_partial_bytes.restype = [c_int] * 9, ctypes.c_size_t
         self.cdll.ttk_pwconv1x1_bwd_fused_rows.argtypes, self.cdll.ttk_pwconv1x1_bwd_fused_rows.restype = [c_int64, c_int, c_int], c_int
         self.cdll.ttk_pwconv1x1_bwd_fused_partial_bytes.argtypes, self.cdll.ttk_pwconv1x1_bwd_fused_partial_bytes.restype = [c_int64, c_int, c_int], ctypes.c_size_t
@@ -199,6 +200,10 @@ class _Library:
     def pwconv_wgrad_partial_bytes(self, m: int, cin: int, cout: int) -> int:
         """Scratch bytes of the deterministic (fixed-order) weight-gradient reduction; 0 = this shape has none."""
         return self.cdll.ttk_pwconv_wgrad_partial_bytes(m, cin, cout)
+
+    def pwconv_wgrad_scratch_bytes(self, m: int, cin: int, cout: int) -> int:
+        """Scratch bytes ttk_pwconv1x1_bwd_weight wants as `partial` in the DEFAULT mode (0: the shape runs its atomic form)."""
+        return self.cdll.ttk_pwconv_wgrad_scratch_bytes(m, cin, cout)
 
     def conv_prepare_weights(self, weights, w_fwd, w_bwd):
         """ttk_conv_prepare_weights: `weights[i]` [Cout, Cin, k, k] fp32, `w_fwd[i]` / `w_bwd[i]` int16 buffers of 3 * numel
@@ -267,5 +272,5 @@ def ptr(t: torch.Tensor | None):
 def exported_symbols() -> list[str]:
     return ["ttk_abi_version", "ttk_last_error_string", "ttk_clear_error", "ttk_partial_rows_elementwise",
             "ttk_partial_rows_gemm", "ttk_partial_rows_pwconv", "ttk_partial_rows_dwconv", "ttk_heads_num_rows", "ttk_pwconv_prepared_bytes",
-            "ttk_pwconv_wgrad_partial_bytes", "ttk_stem_wgrad_partial_bytes", "ttk_conv_wgrad_partial_bytes", "ttk_stem7_wgrad_partial_bytes",
+            "ttk_pwconv_wgrad_partial_bytes", "ttk_pwconv_wgrad_scratch_bytes", "ttk_stem_wgrad_partial_bytes", "ttk_conv_wgrad_partial_bytes", "ttk_stem7_wgrad_partial_bytes",
             "ttk_pwconv1x1_bwd_fused_rows", "ttk_pwconv1x1_bwd_fused_partial_bytes"] + list(_SIGNATURES)

@@ -281,6 +281,11 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         need = max(need, max(L.cdll.ttk_pwconv1x1_bwd_fused_partial_bytes(B * d[2] * d[3], d[4], d[5]) for d in ctx.dims))
         need = max(need, max(L.partial_rows_dwconv(B, d[0], d[1], d[4], d[6], True) * 9 * d[4] * 4 for d in ctx.dims))
         wg_scratch = torch.empty(need // 4, dtype=torch.float32, device=gfeat.device)
+    # the weight gradient of the wide pointwise layers (Cin, Cout multiples of 256) always reduces slice partials in a fixed order
+    # (csrc/pwconv_r.hip: faster than float atomics for 256 x 256 tiles): its scratch, in every mode
+    pw_need = max([L.pwconv_wgrad_scratch_bytes(B * d[2] * d[3], d[4], d[5]) for d in ctx.dims] + [0])
+    pw_scratch = wg_scratch if (wg_scratch is not None and wg_scratch.numel() * 4 >= pw_need) else (
+        torch.empty(pw_need // 4, dtype=torch.float32, device=gfeat.device) if pw_need else None)
     keep = []
 
     g = torch.empty(last.y.shape, dtype=ctx.gdt, device=last.y.device)
@@ -311,13 +316,15 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
             ev.record(main)  # g, bn_pw backward constants and the zeroed dW are ready
             side.wait_event(ev)
             with torch.cuda.stream(side):
-                L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW), None, M, cin, cout, bf)
+                L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW),
+                       p(pw_scratch) if L.pwconv_wgrad_scratch_bytes(M, cin, cout) else None, M, cin, cout, bf)
                 if grad_ready_hook is not None:
                     done = torch.cuda.Event()
                     done.record(side)
             keep.append(g)  # main must not recycle g's memory while the side stream still reads it
         else:
-            L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW), p(wg_scratch), M, cin, cout, bf)
+            L.call("ttk_pwconv1x1_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(dW),
+                   p(wg_scratch) if wg_scratch is not None else (p(pw_scratch) if L.pwconv_wgrad_scratch_bytes(M, cin, cout) else None), M, cin, cout, bf)
         if not fused_rows:
             L.call("ttk_pwconv1x1_bwd_data", p(g), p(st_pw.y), p(st_pw.bn), None, p(st_dw.y), p(st_dw.bn), p(g_dw), p(part), M,
                    cin, cout, p(ctx.prep[k]), bf)

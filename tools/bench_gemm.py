@@ -29,7 +29,7 @@ for name, hw, ci, co, mult in shapes:
     out, gdw, dW = torch.empty(M, co, device=dev, dtype=ADT), torch.empty(M, ci, device=dev, dtype=ADT), torch.zeros(co, ci, device=dev)
     prep = torch.empty(L.pwconv_prepared_bytes(ci, co), dtype=torch.uint8, device=dev)
     L.pwconv_prepare_weights([w], [prep])
-    nb = L.pwconv_wgrad_partial_bytes(M, ci, co) if os.environ.get("PARTIAL") else 0  # PARTIAL=1: slice partials + fixed-order fold instead of atomics
+    nb = L.pwconv_wgrad_partial_bytes(M, ci, co) if os.environ.get("PARTIAL") else L.pwconv_wgrad_scratch_bytes(M, ci, co)  # PARTIAL=1: slice partials + fixed-order fold everywhere
     scr = torch.empty(nb // 4, device=dev) if nb else None
     part = torch.empty(max(L.partial_rows_gemm(M, ci, co), L.partial_rows_gemm(M, co, ci, True)) * 2 * max(ci, co), device=dev)
     calls = {
