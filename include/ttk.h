@@ -42,7 +42,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 16
+#define TTK_ABI_VERSION 17
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -102,8 +102,16 @@ int ttk_partial_rows_pwconv(int64_t M, int K, int Nout, int dgrad);
  * num_batches_tracked (int64 scalar on the device, may be NULL) is incremented.
  * ------------------------------------------------------------------------------------------- */
 /* `part` is scratch: when part_rows > 1280 the finalize kernels first fold it IN PLACE to 1024 rows.
- * Writes rows SCALE, BETA, MEAN, RSTD of bn and raises bn[TTK_BN_AUX][TTK_AUX_ACT_BOUND]. */
-int ttk_bn_fwd_finalize(float* part, int part_rows, int C, int64_t count,
+ * Writes rows SCALE, BETA, MEAN, RSTD of bn and raises bn[TTK_BN_AUX][TTK_AUX_ACT_BOUND].
+ *
+ * The statistics PIVOT.  Every forward producer below (ttk_stem_fwd, ttk_dwconv3x3_fwd, ttk_pwconv1x1_fwd, ttk_conv_fwd,
+ * ttk_stem7_fwd) takes `pivot` (float[C] on the device, or NULL = zeros) and leaves in `part` the sums of (y - pivot) and
+ * (y - pivot)^2; the finalisation given the SAME pivot forms mean = pivot + S1/n and var = S2/n - (S1/n)^2.  The partial rows are
+ * fp32, so without a pivot a channel whose mean is k standard deviations from zero loses ~k^2 * 2^-24 of its variance to
+ * cancellation (13 sigma: 1e-5 relative); with the layer's running_mean as the pivot - what the host passes; the finalisation
+ * reads it before it writes the update, so pivot may alias running_mean - k is the distance between the batch mean and the
+ * running mean instead. */
+int ttk_bn_fwd_finalize(float* part, const float* pivot, int part_rows, int C, int64_t count,
                         const float* gamma, const float* beta,
                         float* running_mean, float* running_var, int64_t* num_batches_tracked,
                         float momentum, float eps, float* bn, ttk_stream_t stream);
@@ -124,14 +132,14 @@ int ttk_bn_bwd_frozen(float* bn, int C, ttk_stream_t stream);
 /* Forward half: after ttk_bn_eval_prepare, raise bn[TTK_BN_AUX][TTK_AUX_ACT_BOUND] to a bound of relu(scale*(y-mean)+beta) over
  * this batch from the producer's partial sums (as ttk_bn_fwd_finalize does for batch statistics), so that the fp16 GEMMs of the
  * backward pass scale their operands; nothing else of bn is written. */
-int ttk_bn_frozen_bound(float* part, int part_rows, int C, int64_t count, float* bn, ttk_stream_t stream);
+int ttk_bn_frozen_bound(float* part, const float* pivot, int part_rows, int C, int64_t count, float* bn, ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stem: nn.Conv2d(1, 32, 5, stride 2, pad 2, bias=False)  - mobilenet_v1.py:122-124,161.
  * x[B][H][W] -> y[B][Ho][Wo][32], Ho = (H+1)/2.  w is the reference's weight (32,1,5,5) as is.
  * part may be NULL (eval).
  * ------------------------------------------------------------------------------------------- */
-int ttk_stem_fwd(const float* x, const float* w, void* y, float* part, int B, int H, int W,
+int ttk_stem_fwd(const float* x, const float* w, void* y, float* part, const float* pivot, int B, int H, int W,
                  int act_bf16, ttk_stream_t stream);
 /* dW[32][25] (+)= sum dy * x, dy formed on load from (g, y, bn = the stem's BatchNorm block). */
 /* partial (nullable): scratch of ttk_stem_wgrad_partial_bytes() - the workgroups store their partial sums there and a
@@ -150,8 +158,8 @@ int ttk_stem_bwd_weight(const void* g, const void* y, const float* bn, const flo
  * (mobilenet_v1.py:70,86-88).  w is the reference's weight (C,1,3,3) as is.
  * ------------------------------------------------------------------------------------------- */
 int ttk_dwconv3x3_fwd(const void* yprev, const float* bn_prev, const void* skip_prev, void* a_out,
-                      const float* w, void* y, float* part, int B, int H, int W, int C, int stride,
-                      int act_bf16, ttk_stream_t stream);
+                      const float* w, void* y, float* part, const float* pivot, int B, int H, int W, int C,
+                      int stride, int act_bf16, ttk_stream_t stream);
 /* Gradient w.r.t. the block input, masked by relu and handed to the producer's BatchNorm:
  *   G      = convT3x3(dy_dw) (+ skip_grad)        dy_dw formed on load from (g_dw, y_dw, bn_dw)
  *   g_prev = G * [a_in > 0]                        -> written, with partials sum(g_prev), sum(g_prev*(yprev-mean))
@@ -183,7 +191,7 @@ int ttk_dwconv3x3_bwd_weight(const float* g_dw, const float* y_dw, const float* 
  * wsplit (forward and data gradient): scratch of ttk_pwconv_prepared_bytes(Cin, Cout) for the split weight operand,
  * or a block that ttk_pwconv_prepare_weights filled (then w / wt == NULL); NULL selects the fp32 MFMA kernels.
  * ------------------------------------------------------------------------------------------- */
-int ttk_pwconv1x1_fwd(const void* ydw, const float* bn_dw, const float* w, void* y, float* part,
+int ttk_pwconv1x1_fwd(const void* ydw, const float* bn_dw, const float* w, void* y, float* part, const float* pivot,
                       int64_t M, int Cin, int Cout, void* wsplit, int act_bf16, ttk_stream_t stream);
 /* g_dw[M][Cin] = (dy[M][Cout] . w[Cout][Cin]) * [bn_dw(ydw) > 0],  dy formed on load from (g, y, bn_pw);
  * wt = w transposed ([Cin][Cout], ttk_transpose).  partials: sum(g_dw), sum(g_dw*(ydw-mean)). */
@@ -273,8 +281,8 @@ int ttk_conv_weight_repack(const float* w, void* w_fwd, void* w_bwd, int Cout, i
 /* the same for n <= 24 weight tensors (square kernels of size ksize[i] in {1,3}) in two launches: a training step's 19 */
 int ttk_conv_prepare_weights(int n, const float* const* w, void* const* w_fwd, void* const* w_bwd, const int* cout,
                              const int* cin, const int* ksize, ttk_stream_t stream);
-int ttk_conv_fwd(const float* a_in, const float* a_bound, const void* w_fwd, float* y, float* part, int B, int H, int W,
-                 int Cin, int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream);
+int ttk_conv_fwd(const float* a_in, const float* a_bound, const void* w_fwd, float* y, float* part, const float* pivot, int B, int H,
+                 int W, int Cin, int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream);
 int ttk_conv_bwd_data(const float* g, const float* y, const float* bn, const void* w_bwd, const float* mask_y,
                       float* mask_bn, float* g_in, float* part, int B, int H, int W, int Cin, int Cout,
                       int KH, int KW, int stride, int pad, ttk_stream_t stream);
@@ -304,7 +312,7 @@ int ttk_conv_bwd_weight(const float* g, const float* y, const float* bn, const f
  *                          downsample BatchNorm; rows of both = ttk_partial_rows_elementwise(rows*C/4).  Raises
  *                          TTK_AUX_GMAX of bn (and bnd) to max |gs|.
  * ------------------------------------------------------------------------------------------- */
-int ttk_stem7_fwd(const float* x, const float* w, float* y, float* part, int B, int H, int W, ttk_stream_t stream);
+int ttk_stem7_fwd(const float* x, const float* w, float* y, float* part, const float* pivot, int B, int H, int W, ttk_stream_t stream);
 size_t ttk_stem7_wgrad_partial_bytes(int B, int H, int W);
 int ttk_stem7_bwd_weight(const float* g, const float* y, const float* bn, const float* x, float* dw, float* partial, int B,
                          int H, int W, ttk_stream_t stream);

@@ -16,7 +16,11 @@ void set_error(const char* fmt, ...) {
 }
 
 // block = 32 channels x 32 row-lanes (1024 threads); each thread strides over the partial rows, 4 loads in flight.
-__global__ void __launch_bounds__(1024) bn_fwd_finalize_k(const float* __restrict__ part, int rows, int C, double inv_count,
+// The partial sums are those of y - pivot[c] (pivot == nullptr: of y): mean = pivot + S1/n, var = S2/n - (S1/n)^2.  With the running
+// mean as the pivot the cancellation in the variance is that of a batch whose mean is (running_mean_of_the_batches - pivot), not of
+// one whose mean is |mean| / sigma standard deviations from zero.  pivot may alias rmean: the owning thread reads it before it
+// writes the update.
+__global__ void __launch_bounds__(1024) bn_fwd_finalize_k(const float* __restrict__ part, const float* pivot, int rows, int C, double inv_count,
                                                           double unbias, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ rmean,
                                                           float* __restrict__ rvar, int64_t* nbt, float momentum, float eps,
@@ -38,8 +42,9 @@ __global__ void __launch_bounds__(1024) bn_fwd_finalize_k(const float* __restric
   float bound = 0.f;
   if (rl == 0 && c < C) {
     for (int i = 1; i < 32; ++i) { a += sm[0][i][cl]; b += sm[1][i][cl]; }
-    const double mean = a * inv_count;
-    double var = b * inv_count - mean * mean;  // biased variance, used for normalisation
+    const double shifted = a * inv_count;
+    const double mean = shifted + (pivot ? (double)pivot[c] : 0.0);
+    double var = b * inv_count - shifted * shifted;  // biased variance, used for normalisation
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
     const double sc = (double)gamma[c] * rstd;
@@ -47,7 +52,7 @@ __global__ void __launch_bounds__(1024) bn_fwd_finalize_k(const float* __restric
     bn[TTK_BN_BETA * C + c] = beta[c];
     bn[TTK_BN_MEAN * C + c] = (float)mean;
     bn[TTK_BN_RSTD * C + c] = (float)rstd;
-    if (rmean) {
+    if (rmean) {  // (after the read of pivot[c] above)
       rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mean);
       rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * var * unbias);
     }
@@ -148,7 +153,7 @@ __global__ void __launch_bounds__(256) bn_bwd_frozen_k(float* __restrict__ bn, i
 // Forward half of the frozen mode: the constants come from the running statistics (bn_eval_prepare_k), but the fp16 GEMMs still
 // want a bound of relu(scale*(y - mean_run) + beta) over THIS batch.  From the batch sums (mean_b, var_b):
 //   |scale*(y - mean_run) + beta| <= |scale| * (sqrt(count * var_b) + |mean_b - mean_run|) + |beta|     (Cauchy-Schwarz, as above)
-__global__ void __launch_bounds__(1024) bn_frozen_bound_k(const float* __restrict__ part, int rows, int C, double inv_count,
+__global__ void __launch_bounds__(1024) bn_frozen_bound_k(const float* __restrict__ part, const float* __restrict__ pivot, int rows, int C, double inv_count,
                                                           float* __restrict__ bn) {
   __shared__ double sm[2][32][32];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
@@ -167,8 +172,9 @@ __global__ void __launch_bounds__(1024) bn_frozen_bound_k(const float* __restric
   float bound = 0.f;
   if (rl == 0 && c < C) {
     for (int i = 1; i < 32; ++i) { a += sm[0][i][cl]; b += sm[1][i][cl]; }
-    const double mean = a * inv_count;
-    double var = b * inv_count - mean * mean;
+    const double shifted = a * inv_count;
+    const double mean = shifted + (pivot ? (double)pivot[c] : 0.0);
+    double var = b * inv_count - shifted * shifted;
     if (var < 0.0) var = 0.0;
     const double dev = sqrt((var + 1.0e-6 * (b * inv_count)) / inv_count);
     bound = (float)(fabs((double)bn[TTK_BN_SCALE * C + c]) * (dev + fabs(mean - (double)bn[TTK_BN_MEAN * C + c])) + fabs((double)bn[TTK_BN_BETA * C + c])) * 1.0001f;
@@ -220,7 +226,7 @@ const char* ttk_last_error_string(void) { return ttk::g_err; }
 int ttk_partial_rows_elementwise(int64_t work_items) { return elementwise_grid(work_items); }
 int ttk_partial_rows_gemm(int64_t M) { return (int)ceil_div(M, TTK_GEMM_BLOCK_M); }
 
-int ttk_bn_fwd_finalize(float* part, int part_rows, int C, int64_t count, const float* gamma, const float* beta,
+int ttk_bn_fwd_finalize(float* part, const float* pivot, int part_rows, int C, int64_t count, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
                         float* bn, ttk_stream_t stream) {
   TTK_REQUIRE(part && gamma && beta && bn, "bn_fwd_finalize: null pointer");
@@ -228,7 +234,7 @@ int ttk_bn_fwd_finalize(float* part, int part_rows, int C, int64_t count, const 
   TTK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_fwd_finalize: running_mean/var must both be given");
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
   part_rows = fold_if_needed(part, part_rows, C, (hipStream_t)stream);
-  hipLaunchKernelGGL(bn_fwd_finalize_k, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, part_rows, C,
+  hipLaunchKernelGGL(bn_fwd_finalize_k, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, pivot, part_rows, C,
                      1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                      bn);
   TTK_LAUNCH_CHECK("bn_fwd_finalize");
@@ -254,10 +260,10 @@ int ttk_bn_bwd_finalize(float* part, int part_rows, int C, int64_t count, const 
   TTK_LAUNCH_CHECK("bn_bwd_finalize");
 }
 
-int ttk_bn_frozen_bound(float* part, int part_rows, int C, int64_t count, float* bn, ttk_stream_t stream) {
+int ttk_bn_frozen_bound(float* part, const float* pivot, int part_rows, int C, int64_t count, float* bn, ttk_stream_t stream) {
   TTK_REQUIRE(part && bn && C > 0 && part_rows > 0 && count > 0, "bn_frozen_bound: bad arguments");
   part_rows = fold_if_needed(part, part_rows, C, (hipStream_t)stream);
-  hipLaunchKernelGGL(bn_frozen_bound_k, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, part_rows, C, 1.0 / (double)count, bn);
+  hipLaunchKernelGGL(bn_frozen_bound_k, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, pivot, part_rows, C, 1.0 / (double)count, bn);
   TTK_LAUNCH_CHECK("bn_frozen_bound");
 }
 

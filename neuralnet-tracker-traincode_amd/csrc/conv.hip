@@ -221,8 +221,8 @@ int ttk_conv_prepare_weights(int n, const float* const* w, void* const* w_fwd, v
   TTK_LAUNCH_CHECK("conv_prepare_weights");
 }
 
-int ttk_conv_fwd(const float* a_in, const float* a_bound, const void* w_fwd, float* y, float* part, int B, int H, int W, int Cin, int Cout,
-                 int KH, int KW, int stride, int pad, ttk_stream_t stream) {
+int ttk_conv_fwd(const float* a_in, const float* a_bound, const void* w_fwd, float* y, float* part, const float* pivot, int B, int H, int W,
+                 int Cin, int Cout, int KH, int KW, int stride, int pad, ttk_stream_t stream) {
   TTK_REQUIRE(a_in && a_bound && w_fwd && y, "conv_fwd: null pointer");
   TTK_REQUIRE(conv_shape_ok(B, H, W, Cin, Cout, KH, KW, stride, pad), "conv_fwd: unsupported shape B=%d H=%d W=%d Cin=%d Cout=%d k=%d s=%d p=%d", B, H, W, Cin, Cout, KH, stride, pad);
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
@@ -231,8 +231,8 @@ int ttk_conv_fwd(const float* a_in, const float* a_bound, const void* w_fwd, flo
   const int K = KH * KW * Cin;
   const bool ok = gemm_mode() == GEMM_F16X2
                       ? launch_conv_gemm16(AMODE_PLAIN, EMODE_STATS, a_in, nullptr, nullptr, a_bound, wq, (const float*)(wq + 2 * (size_t)K * Cout), y,
-                                           nullptr, nullptr, part, (int64_t)B * Ho * Wo, K, Cout, geo, (hipStream_t)stream)
-                      : launch_conv_gemm(AMODE_PLAIN, EMODE_STATS, a_in, nullptr, nullptr, wq, y, nullptr, nullptr, part, (int64_t)B * Ho * Wo, K,
+                                           nullptr, const_cast<float*>(pivot), part, (int64_t)B * Ho * Wo, K, Cout, geo, (hipStream_t)stream)
+                      : launch_conv_gemm(AMODE_PLAIN, EMODE_STATS, a_in, nullptr, nullptr, wq, y, nullptr, pivot, part, (int64_t)B * Ho * Wo, K,
                                          Cout, geo, (hipStream_t)stream);
   TTK_REQUIRE(ok, "conv_fwd: no kernel for this shape");
   TTK_LAUNCH_CHECK("conv_fwd");

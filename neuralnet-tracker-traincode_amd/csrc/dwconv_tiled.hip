@@ -196,8 +196,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 
 dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
                                                           const T* __restrict__ skip_prev, T* __restrict__ a_out,
                                                           const float* __restrict__ w, T* __restrict__ y,
-                                                          float* __restrict__ part, int B, int H, int W, int C, int Ho, int Wo,
-                                                          int R, int nbands, int nslabs, int NI, int NCT, int TW) {
+                                                          float* __restrict__ part, const float* __restrict__ pivot, int B, int H, int W, int C,
+                                                          int Ho, int Wo, int R, int nbands, int nslabs, int NI, int NCT, int TW) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [NI][stage_rows][tile width + 2][SL] + reduction scratch
   constexpr int kSlab = SL, kSlabQuads = SL / 4, kPixSlots = kBlock / kSlabQuads, kQs = ilog2(kSlabQuads), kPs = ilog2(SL);
   const int tid = threadIdx.x, q = tid & (kSlabQuads - 1), slot = tid >> kQs;
@@ -206,6 +206,7 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
   SlabWeights wr;
   wr.load(w, c0);
   const BnApply4 bn = BnApply4::load(bn_prev, C, c0);
+  const float4 pv = pivot ? ld4(pivot + c0) : f4(0.f);  // the partial sums are those of y - pivot (ttk.h)
   D4 s1{0.0, 0.0, 0.0, 0.0}, s2{0.0, 0.0, 0.0, 0.0};
   const unsigned tiles = (unsigned)((B + NI - 1) / NI) * nbands * NCT;  // (< 2^31: checked by the host)
   for (unsigned t = blockIdx.x / nslabs; t < tiles; t += gridDim.x / nslabs) {
@@ -284,6 +285,7 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
         for (int kw = 0; kw < 3; ++kw) acc = fma4(ld4(base + ((size_t)kh * Wp + kw) * kSlab), wr.tap(kh * 3 + kw), acc);
       acc = Act<T>::round(acc);  // statistics of what is stored
       Act<T>::st(youttile + ((__umul24(__umul24(img, (unsigned)Ho) + (unsigned)ho, (unsigned)Wo) + (unsigned)wo) << cshift) + 4 * q, acc);
+      acc = sub4(acc, pv);
       s1.add(acc);
       s2.addmul(acc, acc);
     }
@@ -482,7 +484,7 @@ int ttk_partial_rows_dwconv(int B, int H, int W, int C, int stride, int backward
 }
 
 int ttk_dwconv3x3_fwd(const void* yprev, const float* bn_prev, const void* skip_prev, void* a_out, const float* w, void* y,
-                      float* part, int B, int H, int W, int C, int stride, int act_bf16, ttk_stream_t stream) {
+                      float* part, const float* pivot, int B, int H, int W, int C, int stride, int act_bf16, ttk_stream_t stream) {
   TTK_REQUIRE(yprev && bn_prev && w && y, "dwconv3x3_fwd: null pointer");
   TTK_REQUIRE(dw_shape_ok2(B, H, W, C, stride), "dwconv3x3_fwd: unsupported shape B=%d H=%d W=%d C=%d stride=%d (C: power of two in 32..1024, W <= 256)", B, H, W, C, stride);
   TTK_REQUIRE(!(a_out && stride != 1), "dwconv3x3_fwd: a_out requires stride 1");
@@ -493,7 +495,7 @@ int ttk_dwconv3x3_fwd(const void* yprev, const float* bn_prev, const void* skip_
   const size_t sm = (stage + 16 * t.SL) * sizeof(float);  // + [4][2][SL] doubles of reduction scratch
 #define TTK_DW_FWD_SL(S_, SK_, SL_)                                                                                                     \
   hipLaunchKernelGGL((dw_fwd_tiled_k<S_, ActT, SK_, SL_>), dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, (const ActT*)yprev, bn_prev, \
-                     (const ActT*)skip_prev, (ActT*)a_out, w, (ActT*)y, part, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI, t.NCT, t.TW)
+                     (const ActT*)skip_prev, (ActT*)a_out, w, (ActT*)y, part, pivot, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI, t.NCT, t.TW)
 #define TTK_DW_FWD(S_, SK_) do { if (t.SL == 64) TTK_DW_FWD_SL(S_, SK_, 64); else TTK_DW_FWD_SL(S_, SK_, 32); } while (0)
   TTK_ACT_DISPATCH(act_bf16, if (stride == 1) { if (skip_prev) TTK_DW_FWD(1, true); else TTK_DW_FWD(1, false); }
                              else { if (skip_prev) TTK_DW_FWD(2, true); else TTK_DW_FWD(2, false); });

@@ -178,6 +178,9 @@ pw_gemm_k(const TO* __restrict__ A0, const T* __restrict__ A1,
   if constexpr (MODE == MODE_DGRAD) {
     esc = ld4(bnE + TTK_BN_SCALE * Nout + col); emean = ld4(bnE + TTK_BN_MEAN * Nout + col); ebeta = ld4(bnE + TTK_BN_BETA * Nout + col);
   }
+  if constexpr (MODE == MODE_FWD) {
+    if (bnE) emean = ld4(bnE + col);  // forward: bnE is the statistics pivot [Nout] (ttk.h), the sums are those of y - pivot
+  }
   float4 s1 = f4(0.f), s2 = f4(0.f);
 #pragma unroll 4
   for (int row = rg; row < BM; row += RG) {
@@ -188,6 +191,7 @@ pw_gemm_k(const TO* __restrict__ A0, const T* __restrict__ A1,
     if constexpr (MODE == MODE_FWD) {
       v = Act<TO>::round(v);  // statistics of what is stored
       Act<TO>::st(out + o, v);
+      v = sub4(v, emean);
       s1 = add4(s1, v);
       s2 = fma4(v, v, s2);
     } else {
@@ -542,8 +546,8 @@ int ttk_partial_rows_pwconv(int64_t M, int K, int Nout, int dgrad) {
   return r ? r : (int)ceil_div(M, BM);
 }
 
-int ttk_pwconv1x1_fwd(const void* ydw, const float* bn_dw, const float* w, void* y, float* part, int64_t M, int Cin, int Cout,
-                      void* wsplit, int act_bf16, ttk_stream_t stream) {
+int ttk_pwconv1x1_fwd(const void* ydw, const float* bn_dw, const float* w, void* y, float* part, const float* pivot, int64_t M, int Cin,
+                      int Cout, void* wsplit, int act_bf16, ttk_stream_t stream) {
   TTK_REQUIRE(ydw && bn_dw && y && (w || wsplit), "pwconv1x1_fwd: null pointer");
   TTK_REQUIRE(pw_shape_ok(M, Cin, Cout), "pwconv1x1_fwd: unsupported shape M=%lld Cin=%d Cout=%d (channels: powers of two in 32..1024)", (long long)M, Cin, Cout);
   TTK_REQUIRE(ceil_div(M, BM) <= 65535, "pwconv1x1_fwd: M=%lld too large for one launch", (long long)M);
@@ -551,7 +555,7 @@ int ttk_pwconv1x1_fwd(const void* ydw, const float* bn_dw, const float* w, void*
   const size_t n = (size_t)Cin * Cout;
   float* hdr = ws ? reinterpret_cast<float*>(ws + prep_hdr_offset(n)) : nullptr;
   bool ok = false;
-  TTK_ACT_DISPATCH(act_bf16, ok = launch_gemm<MODE_FWD, ActT, ActT>((const ActT*)ydw, nullptr, bn_dw, w, (ActT*)y, nullptr, nullptr, part, M, Cin, Cout, ws,
+  TTK_ACT_DISPATCH(act_bf16, ok = launch_gemm<MODE_FWD, ActT, ActT>((const ActT*)ydw, nullptr, bn_dw, w, (ActT*)y, nullptr, pivot, part, M, Cin, Cout, ws,
                                                               hdr, (hipStream_t)stream));
   TTK_REQUIRE(ok, "pwconv1x1_fwd: bf16 activations need TTK_GEMM=f16x2 (default) or f32mfma");
   TTK_LAUNCH_CHECK("pwconv1x1_fwd");

@@ -432,6 +432,8 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
   float4 esc = f4(0.f), emean = f4(0.f), ebeta = f4(0.f);
   if constexpr (EMODE == EMODE_MASK) {
     esc = ld4(bnE + TTK_BN_SCALE * Nout + col); emean = ld4(bnE + TTK_BN_MEAN * Nout + col); ebeta = ld4(bnE + TTK_BN_BETA * Nout + col);
+  } else if constexpr (EMODE == EMODE_STATS) {
+    if (bnE) emean = ld4(bnE + col);  // forward: bnE is the statistics pivot [Nout] (ttk.h), the sums are those of y - pivot
   }
   float4 s1 = f4(0.f), s2 = f4(0.f);
   float vmx = 0.f;
@@ -452,6 +454,7 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
     } else if constexpr (EMODE == EMODE_STATS) {
       v = Act<TO>::round(v);  // statistics of what is stored
       Act<TO>::st(out + o, v);
+      v = sub4(v, emean);
       s1 = add4(s1, v);
       s2 = fma4(v, v, s2);
     } else {

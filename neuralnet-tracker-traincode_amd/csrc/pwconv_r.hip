@@ -277,6 +277,8 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
   float4 esc = f4(0.f), emean = f4(0.f), ebeta = f4(0.f);
   if constexpr (!FWD) {
     esc = ld4(bnE + TTK_BN_SCALE * Nout + col); emean = ld4(bnE + TTK_BN_MEAN * Nout + col); ebeta = ld4(bnE + TTK_BN_BETA * Nout + col);
+  } else {
+    if (bnE) emean = ld4(bnE + col);  // forward: bnE is the statistics pivot [Nout] (ttk.h), the sums are those of y - pivot
   }
   float4 s1 = f4(0.f), s2 = f4(0.f);
 #pragma unroll
@@ -299,6 +301,7 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
       if constexpr (FWD) {
         v = Act<TO>::round(v);  // statistics of what is stored
         Act<TO>::st(out + o, v);
+        v = sub4(v, emean);
         s1 = add4(s1, v);
         s2 = fma4(v, v, s2);
       } else {

@@ -341,6 +341,9 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
   if constexpr (EMODE == EMODE_MASK) {
     esc = ld4(bnE + TTK_BN_SCALE * Nout + col); emean = ld4(bnE + TTK_BN_MEAN * Nout + col); ebeta = ld4(bnE + TTK_BN_BETA * Nout + col);
   }
+  if constexpr (EMODE == EMODE_STATS) {
+    if (bnE) emean = ld4(bnE + col);  // forward: bnE is the statistics pivot [Nout]
+  }
   float4 s1 = f4(0.f), s2 = f4(0.f);
 #pragma unroll 4
   for (int i = 0; i < 128 / RGH; ++i) {
@@ -353,6 +356,7 @@ pw_split_k(const float* __restrict__ A0, const float* __restrict__ A1, const flo
       st4(out + o, v);
     } else if constexpr (EMODE == EMODE_STATS) {
       st4(out + o, v);
+      v = sub4(v, emean);
       s1 = add4(s1, v);
       s2 = fma4(v, v, s2);
     } else {

@@ -17,8 +17,8 @@ constexpr int kS7Wp = 192;    // stem7_fwd_mfma_k: row pitch of a wave's input p
 // thread = TWO horizontally adjacent output pixels x 32 channels (same scheme as stem.hip, see there): the filter
 // bank of this channel half sits in LDS as wt[tap][c] and is read with wave-uniform (broadcast) ds_read_b128.
 __global__ void __launch_bounds__(kBlock) stem7_fwd_k(const float* __restrict__ x, const float* __restrict__ w,
-                                                       float* __restrict__ y, float* __restrict__ part, int B, int H, int W,
-                                                       int Ho, int Wo) {
+                                                       float* __restrict__ y, float* __restrict__ part, const float* __restrict__ pivot,
+                                                       int B, int H, int W, int Ho, int Wo) {
   __shared__ __attribute__((aligned(16))) float wt[kS7K * kS7K][kS7Half];
   __shared__ float red[kBlock / kWave][2 * kS7Half];
   const int cbase = blockIdx.y * kS7Half;
@@ -61,7 +61,9 @@ __global__ void __launch_bounds__(kBlock) stem7_fwd_k(const float* __restrict__ 
           a1 = fma4(f4(xin[kh][kw + 2]), wq, a1);
         }
       st4(y0 + 4 * c4, a0);
-      if (second) st4(y0 + kS7C + 4 * c4, a1);
+      const float4 pv = pivot ? ld4(pivot + cbase + 4 * c4) : f4(0.f);  // the sums are those of y - pivot
+      a0 = sub4(a0, pv);
+      if (second) { st4(y0 + kS7C + 4 * c4, a1); a1 = sub4(a1, pv); }
       else a1 = f4(0.f);
       s1[4 * c4 + 0] += a0.x + a1.x; s1[4 * c4 + 1] += a0.y + a1.y; s1[4 * c4 + 2] += a0.z + a1.z; s1[4 * c4 + 3] += a0.w + a1.w;
       s2[4 * c4 + 0] = fmaf(a0.x, a0.x, fmaf(a1.x, a1.x, s2[4 * c4 + 0]));
@@ -97,8 +99,8 @@ __global__ void __launch_bounds__(kBlock) stem7_fwd_k(const float* __restrict__ 
 // rows held in registers.  Wave-private LDS: no workgroup barrier in the loop; groups go round-robin over all waves.
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 __global__ void __launch_bounds__(kBlock) stem7_fwd_mfma_k(const float* __restrict__ x, const float* __restrict__ w,
-                                                            float* __restrict__ y, float* __restrict__ part, int B, int H, int W,
-                                                            int Ho, int Wo, int PR, int wave_floats) {
+                                                            float* __restrict__ y, float* __restrict__ part, const float* __restrict__ pivot,
+                                                            int B, int H, int W, int Ho, int Wo, int PR, int wave_floats) {
   extern __shared__ __attribute__((aligned(16))) float smem7[];
   __shared__ float red[kBlock / kWave][2 * kS7C];
   constexpr int kTaps = kS7K * kS7K, kSteps = (kTaps + 1) / 2;  // 49 taps, 25 MFMAs (the 50th tap has zero weights)
@@ -123,6 +125,7 @@ __global__ void __launch_bounds__(kBlock) stem7_fwd_mfma_k(const float* __restri
   const int hw = Ho * Wo, gpi = (hw + 31) / 32;  // 32-pixel groups per image
   const int groups = B * gpi, nwaves = (int)gridDim.x * (kBlock / kWave);  // (the host checks B * gpi < 2^31)
   const int c4 = lane & 15, prow = lane >> 4;  // output pass: 16 lanes x float4 = one pixel's 64 channels, 4 pixels per instruction
+  const float4 pv = pivot ? ld4(pivot + 4 * c4) : f4(0.f);  // the sums are those of y - pivot
   float4 s1 = f4(0.f), s2 = f4(0.f);
   // The input rows of a group are fetched into registers one group ahead (27 independent loads in flight under the
   // previous group's MFMAs and output pass; a load -> LDS-write loop paid one memory latency per element, 13 us per group).
@@ -191,8 +194,9 @@ __global__ void __launch_bounds__(kBlock) stem7_fwd_mfma_k(const float* __restri
     for (int i = 0; i < 8; ++i) {
       const int row = prow + 4 * i;
       if (p0 + row < hw) {
-        const float4 v = ld4(patch + row * kLdo + 4 * c4);
+        float4 v = ld4(patch + row * kLdo + 4 * c4);
         st4(yg + (size_t)row * kS7C + 4 * c4, v);
+        v = sub4(v, pv);
         s1 = add4(s1, v);
         s2 = fma4(v, v, s2);
       }
@@ -563,7 +567,7 @@ using namespace ttk;
 
 extern "C" {
 
-int ttk_stem7_fwd(const float* x, const float* w, float* y, float* part, int B, int H, int W, ttk_stream_t stream) {
+int ttk_stem7_fwd(const float* x, const float* w, float* y, float* part, const float* pivot, int B, int H, int W, ttk_stream_t stream) {
   TTK_REQUIRE(x && w && y, "stem7_fwd: null pointer");
   TTK_REQUIRE(B > 0 && H > 6 && W > 6, "stem7_fwd: bad shape B=%d H=%d W=%d", B, H, W);
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
@@ -574,11 +578,11 @@ int ttk_stem7_fwd(const float* x, const float* w, float* y, float* part, int B, 
   const size_t smem = (size_t)(kBlock / kWave) * wave_floats * sizeof(float);
   static const bool valu = getenv("TTK_STEM7_VALU") != nullptr;  // the previous kernel (A/B timing)
   if (!valu && smem <= 60 * 1024 && W + 7 <= kS7Wp && (int64_t)B * ((Ho * Wo + 31) / 32) < ((int64_t)1 << 30))
-    hipLaunchKernelGGL(stem7_fwd_mfma_k, dim3(elementwise_grid(items)), dim3(kBlock), smem, (hipStream_t)stream, x, w, y, part, B, H, W, Ho, Wo,
-                       PR, wave_floats);
+    hipLaunchKernelGGL(stem7_fwd_mfma_k, dim3(elementwise_grid(items)), dim3(kBlock), smem, (hipStream_t)stream, x, w, y, part, pivot, B, H, W,
+                       Ho, Wo, PR, wave_floats);
   else
     hipLaunchKernelGGL(stem7_fwd_k, dim3(elementwise_grid(items), kS7C / kS7Half), dim3(kBlock), 0, (hipStream_t)stream, x, w, y, part,
-                       B, H, W, Ho, Wo);
+                       pivot, B, H, W, Ho, Wo);
   TTK_LAUNCH_CHECK("stem7_fwd");
 }
 

@@ -18,8 +18,8 @@ constexpr int kStemQuads = kStemC / 4;
 // a scalar-register filter bank does not work either (800 SGPRs: the compiler spills them through
 // v_writelane/v_readlane).  BatchNorm partial sums stay in registers over the grid-stride loop.
 __global__ void __launch_bounds__(kBlock) stem_fwd_k(const float* __restrict__ x, const float* __restrict__ w,
-                                                      float* __restrict__ y, float* __restrict__ part, int B, int H,
-                                                      int W, int Ho, int Wo) {
+                                                      float* __restrict__ y, float* __restrict__ part, const float* __restrict__ pivot,
+                                                      int B, int H, int W, int Ho, int Wo) {
   __shared__ __attribute__((aligned(16))) float wt[25][kStemC];
   __shared__ float red[kBlock / kWave][2 * kStemC];
   for (int i = threadIdx.x; i < 25 * kStemC; i += kBlock) wt[i % 25][i / 25] = w[i];  // w[c][tap] -> wt[tap][c]
@@ -60,7 +60,9 @@ __global__ void __launch_bounds__(kBlock) stem_fwd_k(const float* __restrict__ x
           a1 = fma4(f4(xin[kh][kw + 2]), wq, a1);
         }
       st4(y0 + 4 * c4, a0);
-      if (second) st4(y0 + kStemC + 4 * c4, a1);
+      const float4 pv = pivot ? ld4(pivot + 4 * c4) : f4(0.f);  // the sums are those of y - pivot
+      a0 = sub4(a0, pv);
+      if (second) { st4(y0 + kStemC + 4 * c4, a1); a1 = sub4(a1, pv); }
       else a1 = f4(0.f);
       s1[4 * c4 + 0] += a0.x + a1.x; s1[4 * c4 + 1] += a0.y + a1.y; s1[4 * c4 + 2] += a0.z + a1.z; s1[4 * c4 + 3] += a0.w + a1.w;
       s2[4 * c4 + 0] = fmaf(a0.x, a0.x, fmaf(a1.x, a1.x, s2[4 * c4 + 0]));
@@ -168,12 +170,13 @@ __device__ __forceinline__ float stem_patch(const float* __restrict__ x, int n, 
 
 template <typename T>
 __global__ void __launch_bounds__(kBlock) stem_fwd_mfma_k(const float* __restrict__ x, const float* __restrict__ w,
-                                                           T* __restrict__ y, float* __restrict__ part, int B, int H,
-                                                           int W, int Ho, int Wo) {
+                                                           T* __restrict__ y, float* __restrict__ part, const float* __restrict__ pivot,
+                                                           int B, int H, int W, int Ho, int Wo) {
   __shared__ float red[kBlock / kWave][2 * kStemC];
   constexpr int kTileLd = 36;  // floats per pixel row of the transposition tile (16-byte aligned rows, conflict-free b128 reads)
   __shared__ __attribute__((aligned(16))) float tile[kBlock / kWave][32 * kTileLd];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, hk = lane >> 5;
+  const float pv = pivot ? pivot[r] : 0.f;  // the sums are those of y - pivot
   float bw[13];  // B fragments: w[c = r][tap = 2j + hk]
 #pragma unroll
   for (int j = 0; j < 13; ++j) bw[j] = (2 * j + hk < 25) ? w[r * 25 + 2 * j + hk] : 0.f;
@@ -216,8 +219,9 @@ __global__ void __launch_bounds__(kBlock) stem_fwd_mfma_k(const float* __restric
         const int row = (e & 3) + 8 * (e >> 2) + 4 * hk;
         tw[row * kTileLd + r] = acc[e];
         if (t * 32 + row < P) {
-          s1 += acc[e];
-          s2 = fmaf(acc[e], acc[e], s2);
+          const float d = acc[e] - pv;
+          s1 += d;
+          s2 = fmaf(d, d, s2);
         }
       }
       __builtin_amdgcn_wave_barrier();  // wave-private: LDS executes a wave's accesses in order
@@ -235,7 +239,7 @@ __global__ void __launch_bounds__(kBlock) stem_fwd_mfma_k(const float* __restric
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * hk;
         if (t * 32 + row < P) {
-          const float v = Act<T>::st1(yt + (size_t)row * kStemC, acc[e]);  // 32 lanes = one pixel; statistics of the stored value
+          const float v = Act<T>::st1(yt + (size_t)row * kStemC, acc[e]) - pv;  // 32 lanes = one pixel; statistics of the stored value
           s1 += v;
           s2 = fmaf(v, v, s2);
         }
@@ -262,7 +266,8 @@ __global__ void __launch_bounds__(kBlock) stem_fwd_mfma_k(const float* __restric
 constexpr int kFwBand = 13;  // 65 = 5 x 13 output rows
 template <typename T>
 __global__ void __launch_bounds__(kBlock) stem_fwd_band_k(const float* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
-                                                           float* __restrict__ part, int B, int H, int W, int Ho, int Wo, int nbands) {
+                                                           float* __restrict__ part, const float* __restrict__ pivot, int B, int H, int W, int Ho,
+                                                           int Wo, int nbands) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   __shared__ float red[kBlock / kWave][2 * kStemC];
   constexpr int kTileLd = 36;
@@ -270,6 +275,7 @@ __global__ void __launch_bounds__(kBlock) stem_fwd_band_k(const float* __restric
   float* xs = sm;                                  // [xrows][Wp]
   float* tiles = sm + ((xrows * Wp + 3) & ~3);     // [4 waves][32][kTileLd]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, hk = lane >> 5;
+  const float pv = pivot ? pivot[r] : 0.f;  // the sums are those of y - pivot
   float bw[13];
   int toff[13];  // LDS offset of this lane's tap 2j + hk inside a patch
 #pragma unroll
@@ -311,8 +317,9 @@ __global__ void __launch_bounds__(kBlock) stem_fwd_band_k(const float* __restric
           const int row = (e & 3) + 8 * (e >> 2) + 4 * hk;
           tw[row * kTileLd + r] = acc[e];
           if (p0 + row < npix) {
-            s1 += acc[e];
-            s2 = fmaf(acc[e], acc[e], s2);
+            const float d = acc[e] - pv;
+            s1 += d;
+            s2 = fmaf(d, d, s2);
           }
         }
         __builtin_amdgcn_wave_barrier();  // wave-private tile: LDS executes a wave's accesses in order
@@ -330,7 +337,7 @@ __global__ void __launch_bounds__(kBlock) stem_fwd_band_k(const float* __restric
         for (int e = 0; e < 16; ++e) {
           const int row = (e & 3) + 8 * (e >> 2) + 4 * hk;
           if (p0 + row < npix) {
-            const float v = Act<T>::st1(yt + (size_t)row * kStemC, acc[e]);  // statistics of the stored value
+            const float v = Act<T>::st1(yt + (size_t)row * kStemC, acc[e]) - pv;  // statistics of the stored value
             s1 += v;
             s2 = fmaf(v, v, s2);
           }
@@ -458,7 +465,8 @@ using namespace ttk;
 
 extern "C" {
 
-int ttk_stem_fwd(const float* x, const float* w, void* y, float* part, int B, int H, int W, int act_bf16, ttk_stream_t stream) {
+int ttk_stem_fwd(const float* x, const float* w, void* y, float* part, const float* pivot, int B, int H, int W, int act_bf16,
+                 ttk_stream_t stream) {
   TTK_REQUIRE(x && w && y, "stem_fwd: null pointer");
   TTK_REQUIRE(B > 0 && H > 4 && W > 4, "stem_fwd: bad shape B=%d H=%d W=%d", B, H, W);
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
@@ -467,7 +475,8 @@ int ttk_stem_fwd(const float* x, const float* w, void* y, float* part, int B, in
   TTK_REQUIRE(!(scalar && act_bf16), "stem_fwd: TTK_STEM=scalar has no bf16-storage form");
   TTK_REQUIRE((int64_t)B * Ho * Wo < (int64_t)1 << 31, "stem_fwd: too many output pixels for 32-bit indexing");
   if (scalar)  // TTK_STEM=scalar: the VALU kernels (A/B timing)
-    hipLaunchKernelGGL(stem_fwd_k, dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, x, w, (float*)y, part, B, H, W, Ho, Wo);
+    hipLaunchKernelGGL(stem_fwd_k, dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, x, w, (float*)y, part, pivot, B, H, W, Ho,
+                       Wo);
   else {
     // input band in LDS (TTK_STEM=gather: the kernel that gathers its patches from global memory; also for images too wide for LDS)
     static const bool gather = [] { const char* e = getenv("TTK_STEM"); return e && strcmp(e, "gather") == 0; }();
@@ -475,10 +484,10 @@ int ttk_stem_fwd(const float* x, const float* w, void* y, float* part, int B, in
     const int nbands = (Ho + kFwBand - 1) / kFwBand;
     if (!gather && sm <= 64 * 1024)
       TTK_ACT_DISPATCH(act_bf16, hipLaunchKernelGGL((stem_fwd_band_k<ActT>), dim3(elementwise_grid(items)), dim3(kBlock), sm, (hipStream_t)stream, x, w,
-                                                    (ActT*)y, part, B, H, W, Ho, Wo, nbands));
+                                                    (ActT*)y, part, pivot, B, H, W, Ho, Wo, nbands));
     else
       TTK_ACT_DISPATCH(act_bf16, hipLaunchKernelGGL((stem_fwd_mfma_k<ActT>), dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, x, w,
-                                                    (ActT*)y, part, B, H, W, Ho, Wo));
+                                                    (ActT*)y, part, pivot, B, H, W, Ho, Wo));
   }
   TTK_LAUNCH_CHECK("stem_fwd");
 }

@@ -18,17 +18,17 @@ _P, _I, _L, _F, _D = c_void_p, c_int, c_int64, c_float, c_double
 
 # name -> argument types (the trailing stream pointer is added automatically)
 _SIGNATURES = {
-    "ttk_bn_fwd_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _F, _F, _P],
+    "ttk_bn_fwd_finalize": [_P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _F, _F, _P],
     "ttk_bn_bwd_frozen": [_P, _I],
-    "ttk_bn_frozen_bound": [_P, _I, _I, _L, _P],
+    "ttk_bn_frozen_bound": [_P, _P, _I, _I, _L, _P],
     "ttk_bn_eval_prepare": [_P, _P, _P, _P, _F, _I, _P],
     "ttk_bn_bwd_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _I],
-    "ttk_stem_fwd": [_P, _P, _P, _P, _I, _I, _I, _I],
+    "ttk_stem_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
     "ttk_stem_bwd_weight": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I],
-    "ttk_dwconv3x3_fwd": [_P] * 7 + [_I] * 6,
+    "ttk_dwconv3x3_fwd": [_P] * 8 + [_I] * 6,
     "ttk_dwconv3x3_bwd_data": [_P] * 12 + [_I, _P] + [_I] * 6,
     "ttk_dwconv3x3_bwd_weight": [_P] * 8 + [_I] * 6,
-    "ttk_pwconv1x1_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _I],
+    "ttk_pwconv1x1_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _I],
     "ttk_pwconv1x1_bwd_data": [_P] * 8 + [_L, _I, _I, _P, _I],
     "ttk_pwconv1x1_bwd_weight": [_P] * 7 + [_L, _I, _I, _I],
     "ttk_pwconv_prepare_weights": [_I, _P, _P, _P, _P],
@@ -37,7 +37,7 @@ _SIGNATURES = {
     "ttk_avgpool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I],
     "ttk_avgpool_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
     "ttk_bn_act": [_P, _P, _P, _P, _L, _I],
-    "ttk_stem7_fwd": [_P, _P, _P, _P, _I, _I, _I],
+    "ttk_stem7_fwd": [_P, _P, _P, _P, _P, _I, _I, _I],
     "ttk_stem7_bwd_weight": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
     "ttk_maxpool3x3s2_fwd": [_P, _P, _P, _P, _I, _I, _I, _I],
     "ttk_maxpool3x3s2_bwd": [_P] * 7 + [_I] * 4,
@@ -46,7 +46,7 @@ _SIGNATURES = {
     "ttk_bn_bwd_apply": [_P, _P, _P, _P, _L, _I],
     "ttk_conv_weight_repack": [_P, _P, _P, _I, _I, _I, _I],
     "ttk_conv_prepare_weights": [_I, _P, _P, _P, _P, _P, _P],
-    "ttk_conv_fwd": [_P, _P, _P, _P, _P] + [_I] * 9,
+    "ttk_conv_fwd": [_P, _P, _P, _P, _P, _P] + [_I] * 9,
     "ttk_conv_bwd_data": [_P] * 8 + [_I] * 9,
     "ttk_conv_bwd_weight": [_P] * 7 + [_I] * 9,
     "ttk_heads_fwd": [_P] * 8 + [_I] * 7 + [_P] * 9,
@@ -90,7 +90,13 @@ _SIGNATURES = {
     "ttk_stream_probe": [_P, _P, _P, _L, _I, _I, _I, _I, _L, _I, _I, _I],
 }
 
-ABI_VERSION = 16
+ABI_VERSION = 17
+
+
+def bn_pivot() -> bool:
+    """Whether the backbones hand the running mean to the forward producers as the statistics pivot (include/ttk.h; TTK_BN_PIVOT=0:
+    plain sums of y and y^2, the A/B of tests/test_bn_pivot_gpu.py)."""
+    return os.environ.get("TTK_BN_PIVOT", "1") != "0"
 
 
 class LossOp(ctypes.Structure):

@@ -164,15 +164,20 @@ def _forward_impl(x, params, buffers, momentum, eps, training, act_dtype=torch.f
     ctx.bf, ctx.gdt = bf, grad_dtype
     bns = _BnArena([32] + [c for _, cin, cout, _ in _BLOCKS for c in (cin, cout)], dev)
 
+    def pivot(bi):
+        """The statistics pivot of BatchNorm `bi` (include/ttk.h): its running mean - the producer sums y - pivot, the finalisation adds
+        it back (and only then updates the running mean)."""
+        return p(buffers[3 * bi]) if (_hip.bn_pivot() and (training or frozen)) else None
+
     def finalize(bn, rows, C, count, gamma, beta, bi):
         rm, rv, nbt = buffers[3 * bi], buffers[3 * bi + 1], buffers[3 * bi + 2]
         if training:
-            L.call("ttk_bn_fwd_finalize", p(part), rows, C, count, p(gamma), p(beta), p(rm), p(rv), p(nbt),
+            L.call("ttk_bn_fwd_finalize", p(part), pivot(bi), rows, C, count, p(gamma), p(beta), p(rm), p(rv), p(nbt),
                    float(momentum), float(eps), p(bn))
         else:
             L.call("ttk_bn_eval_prepare", p(gamma), p(beta), p(rm), p(rv), float(eps), C, p(bn))
             if frozen:  # a backward pass follows: its fp16 GEMMs want the activation bound of this batch
-                L.call("ttk_bn_frozen_bound", p(part), rows, C, count, p(bn))
+                L.call("ttk_bn_frozen_bound", p(part), pivot(bi), rows, C, count, p(bn))
 
     part_arg = p(part) if (training or frozen) else None
     # forward and data-gradient weight operands of all 13 pointwise convs, one launch
@@ -183,7 +188,7 @@ def _forward_impl(x, params, buffers, momentum, eps, training, act_dtype=torch.f
     L.pwconv_prepare_weights(w_pws, ctx.prep)
     # ---- stem (reference :122-126,161-163)
     y0 = torch.empty((B, Ho, Wo, 32), dtype=act_dtype, device=dev)
-    L.call("ttk_stem_fwd", p(x), p(params[0]), p(y0), part_arg, B, H, W, bf)
+    L.call("ttk_stem_fwd", p(x), p(params[0]), p(y0), part_arg, pivot(0), B, H, W, bf)
     bn = bns.take(32)
     finalize(bn, L.partial_rows_elementwise(B * Ho * Wo * 8), 32, B * Ho * Wo, params[1], params[2], 0)
     prev = _Stage(y0, bn, None)
@@ -197,13 +202,13 @@ def _forward_impl(x, params, buffers, momentum, eps, training, act_dtype=torch.f
         ho, wo = (h - 1) // stride + 1, (w_ - 1) // stride + 1
         a_in = torch.empty_like(prev.y) if has_skip else None
         ydw = torch.empty((B, ho, wo, cin), dtype=act_dtype, device=dev)
-        L.call("ttk_dwconv3x3_fwd", p(prev.y), p(prev.bn), p(prev.skip), p(a_in), p(w_dw), p(ydw), part_arg, B, h, w_, cin,
+        L.call("ttk_dwconv3x3_fwd", p(prev.y), p(prev.bn), p(prev.skip), p(a_in), p(w_dw), p(ydw), part_arg, pivot(bi), B, h, w_, cin,
                stride, bf)
         bn_dw = bns.take(cin)
         finalize(bn_dw, L.partial_rows_dwconv(B, h, w_, cin, stride, False), cin, B * ho * wo, g_dw, b_dw, bi)
         ypw = torch.empty((B, ho, wo, cout), dtype=act_dtype, device=dev)
         M = B * ho * wo
-        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(ypw), part_arg, M, cin, cout, p(ctx.prep[len(ctx.dims)]), bf)
+        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(ypw), part_arg, pivot(bi + 1), M, cin, cout, p(ctx.prep[len(ctx.dims)]), bf)
         bn_pw = bns.take(cout)
         finalize(bn_pw, L.partial_rows_gemm(M, cin, cout), cout, M, g_pw, b_pw, bi + 1)
         bi += 2

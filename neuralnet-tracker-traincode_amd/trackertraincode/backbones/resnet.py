@@ -101,11 +101,16 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
     _bn_work = lambda C, _dev: arena.take(C)
     bound = lambda bn: p(bn[_BN_AUX])  # device float: bound of the activation formed from this BatchNorm
 
+    def pivot():
+        """Statistics pivot (include/ttk.h) of the BatchNorm the NEXT finalize() call handles: its running mean, before the update."""
+        return p(buffers[3 * bi[0]]) if (training and _hip.bn_pivot()) else None
+
     def finalize(bn, rows, C, count, gamma, beta, scratch=None):
         rm, rv, nbt = buffers[3 * bi[0]: 3 * bi[0] + 3]
+        pv = pivot()
         bi[0] += 1
         if training:
-            L.call("ttk_bn_fwd_finalize", p(scratch if scratch is not None else part), rows, C, count, p(gamma), p(beta), p(rm), p(rv),
+            L.call("ttk_bn_fwd_finalize", p(scratch if scratch is not None else part), pv, rows, C, count, p(gamma), p(beta), p(rm), p(rv),
                    p(nbt), float(momentum), float(eps), p(bn))
         else:  # eval: constants from the running statistics, the partial sums the kernels wrote are ignored
             L.call("ttk_bn_eval_prepare", p(gamma), p(beta), p(rm), p(rv), float(eps), C, p(bn))
@@ -113,7 +118,7 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
     # ---- stem 7x7/s2 + bn + relu + maxpool 3x3/s2 (reference resnet.py:63-66; torchvision ResNet.forward)
     Ho = (H - 1) // 2 + 1
     c.y0 = new(B, Ho, Ho, 64)
-    L.call("ttk_stem7_fwd", p(x), p(params[0]), p(c.y0), p(part), B, H, W)
+    L.call("ttk_stem7_fwd", p(x), p(params[0]), p(c.y0), p(part), pivot(), B, H, W)
     c.bn0 = _bn_work(64, dev)
     finalize(c.bn0, L.partial_rows_elementwise(B * Ho * Ho * 16), 64, B * Ho * Ho, params[1], params[2])
     h = (Ho - 1) // 2 + 1
@@ -152,13 +157,13 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
         w2f, k.w2b = next(wops)
         wdf, k.wdb = next(wops) if has_ds else (None, None)
         k.y1 = new(B, ho, ho, planes)
-        L.call("ttk_conv_fwd", p(a_in), bound(a_bn), p(w1f), p(k.y1), p(part), B, h, h, cin, planes, 3, 3, stride, 1)
+        L.call("ttk_conv_fwd", p(a_in), bound(a_bn), p(w1f), p(k.y1), p(part), pivot(), B, h, h, cin, planes, 3, 3, stride, 1)
         k.bn1 = _bn_work(planes, dev)
         finalize(k.bn1, L.partial_rows_gemm(M), planes, M, g1, b1)
         k.a_mid = new(B, ho, ho, planes)
         L.call("ttk_bn_add_act", p(k.y1), p(k.bn1), None, None, p(k.a_mid), None, int(not training), M, planes)
         k.y2 = new(B, ho, ho, planes)
-        L.call("ttk_conv_fwd", p(k.a_mid), bound(k.bn1), p(w2f), p(k.y2), p(part), B, ho, ho, planes, planes, 3, 3, 1, 1)
+        L.call("ttk_conv_fwd", p(k.a_mid), bound(k.bn1), p(w2f), p(k.y2), p(part), pivot(), B, ho, ho, planes, planes, 3, 3, 1, 1)
         k.bn2 = _bn_work(planes, dev)
         finalize(k.bn2, L.partial_rows_gemm(M), planes, M, g2, b2)
         k.yd = k.bnd = None
@@ -166,7 +171,7 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
             wd, gd, bd = params[pi:pi + 3]
             pi += 3
             k.yd = new(B, ho, ho, planes)
-            L.call("ttk_conv_fwd", p(a_in), bound(a_bn), p(wdf), p(k.yd), p(part), B, h, h, cin, planes, 1, 1, stride, 0)
+            L.call("ttk_conv_fwd", p(a_in), bound(a_bn), p(wdf), p(k.yd), p(part), pivot(), B, h, h, cin, planes, 1, 1, stride, 0)
             k.bnd = _bn_work(planes, dev)
             finalize(k.bnd, L.partial_rows_gemm(M), planes, M, gd, bd)
         last = bidx == len(_PLAN) - 1

@@ -120,13 +120,13 @@ def test_entry_points_reject_bad_arguments():
     L, p = H.lib(), H.ptr
     t = torch.zeros(64, device="cuda")
     with pytest.raises(RuntimeError, match="pwconv1x1_fwd"):
-        L.call("ttk_pwconv1x1_fwd", p(t), p(t), p(t), p(t), p(t), 100, 48, 64, None, 0)  # 48 channels: not a power of two
+        L.call("ttk_pwconv1x1_fwd", p(t), p(t), p(t), p(t), p(t), None, 100, 48, 64, None, 0)  # 48 channels: not a power of two
     with pytest.raises(RuntimeError, match="null pointer"):
-        L.call("ttk_pwconv1x1_fwd", None, p(t), p(t), p(t), p(t), 100, 32, 64, None, 0)
+        L.call("ttk_pwconv1x1_fwd", None, p(t), p(t), p(t), p(t), None, 100, 32, 64, None, 0)
     with pytest.raises(RuntimeError, match="dwconv3x3_fwd"):
-        L.call("ttk_dwconv3x3_fwd", p(t), p(t), None, None, p(t), p(t), None, 1, 8, 8, 32, 3, 0)  # stride 3
+        L.call("ttk_dwconv3x3_fwd", p(t), p(t), None, None, p(t), p(t), None, None, 1, 8, 8, 32, 3, 0)  # stride 3
     with pytest.raises(RuntimeError, match="conv_fwd"):
-        L.call("ttk_conv_fwd", p(t), p(t), p(t), p(t), p(t), 1, 8, 8, 64, 64, 5, 5, 1, 2)  # 5x5 is not a ResNet18 conv
+        L.call("ttk_conv_fwd", p(t), p(t), p(t), p(t), p(t), None, 1, 8, 8, 64, 64, 5, 5, 1, 2)  # 5x5 is not a ResNet18 conv
     with pytest.raises(RuntimeError, match="heads_fwd"):
         L.call("ttk_heads_fwd", p(t), p(t), p(t), None, None, None, None, None, 4, 1024, 7, 0, 0, 0, 0, p(t), p(t), p(t), p(t), p(t), None, None,
                None, None)  # NZ does not match the configuration

@@ -52,7 +52,7 @@ def test_pointwise_kernels_with_bf16_storage(M, Cin, Cout, flag):
     y = torch.empty(M, Cout, device=DEV, dtype=torch.bfloat16)
     part = torch.full((rows, 2, Cout), float("nan"), device=DEV)
     wq = torch.empty(L.pwconv_prepared_bytes(Cin, Cout), dtype=torch.uint8, device=DEV)
-    L.call("ttk_pwconv1x1_fwd", p(ydw), p(d_bn), p(d_w), p(y), p(part), M, Cin, Cout, p(wq), flag)
+    L.call("ttk_pwconv1x1_fwd", p(ydw), p(d_bn), p(d_w), p(y), p(part), None, M, Cin, Cout, p(wq), flag)
     torch.cuda.synchronize()
     assert _rel(f64(y), y64) < 3e-3  # bf16 rounding of the outputs: 2^-9 per element
     ps, ys = part.cpu().numpy().astype(np.float64), f64(y)

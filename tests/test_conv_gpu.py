@@ -61,12 +61,14 @@ def test_conv_fwd_bwd_data_bwd_weight(B, H, Cin, Cout, k, stride):
     rows = L.partial_rows_gemm(M)
     y = torch.empty(B, Ho, Ho, Cout, device=dev)
     part = torch.full((rows, 2, Cout), float("nan"), device=dev)
-    L.call("ttk_conv_fwd", p(d_a), p(a_bound), p(w_f), p(y), p(part), B, H, W, Cin, Cout, k, k, stride, pad)
+    piv = rng.normal(0, 0.5, Cout).astype(np.float32)  # statistics pivot (include/ttk.h)
+    d_piv = t(piv)
+    L.call("ttk_conv_fwd", p(d_a), p(a_bound), p(w_f), p(y), p(part), p(d_piv), B, H, W, Cin, Cout, k, k, stride, pad)
     torch.cuda.synchronize()
     assert _rel(y.cpu().numpy(), y_ref) < 1.5e-6
     ps = part.cpu().numpy().astype(np.float64)
     assert np.isfinite(ps).all()
-    flat = y_ref.reshape(-1, Cout)
+    flat = y_ref.reshape(-1, Cout) - piv.astype(np.float64)
     np.testing.assert_allclose(ps[:, 0].sum(0), flat.sum(0), rtol=0, atol=3e-5 * np.abs(flat).sum(0).max())
     np.testing.assert_allclose(ps[:, 1].sum(0), (flat ** 2).sum(0), rtol=3e-5)
 

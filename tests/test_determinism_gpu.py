@@ -70,7 +70,9 @@ for m in net.modules():  # (zero-initialised residual BatchNorms would silence m
         torch.nn.init.uniform_(m.weight, 0.5, 1.5)
 x = torch.randn(24, 1, 129, 129, device="cuda")
 G = torch.randn(24, 512, device="cuda")
+start = {k: v.clone() for k, v in net.state_dict().items()}
 for rep in range(2):
+    net.load_state_dict(start)  # the same running statistics: they are the pivot of the BatchNorm sums (include/ttk.h), i.e. part of the input
     net.zero_grad(set_to_none=True)
     feat, _ = net(x)
     (feat * G).sum().backward()
@@ -86,7 +88,7 @@ for rep in range(2):
 def test_resnet18_deterministic_mode_is_bitwise_reproducible():
     """The ResNet18 variant: the 3x3 convolutions' weight gradients always fold slice partials in a fixed order; under
     TTK_DETERMINISTIC=1 the 1x1 shortcut convolutions and the 7x7 stem do too - forward and every gradient are then bitwise
-    equal from run to run (in one process and between two)."""
+    equal from run to run (in one process - from the same parameters AND buffers - and between two)."""
     env = dict(os.environ, TTK_DETERMINISTIC="1")
     hashes = []
     for _ in range(2):

@@ -66,7 +66,9 @@ def test_dwconv_fwd_and_bwd_against_float64(B, H, W, C, stride, skip):
     y = torch.full((B, Ho, Wo, C), float("nan"), device="cuda")
     rows = L.partial_rows_dwconv(B, H, W, C, stride, False)
     part = torch.full((rows, 2, C), float("nan"), device="cuda")
-    L.call("ttk_dwconv3x3_fwd", p(d_yprev), p(d_bnp), p(d_skip), p(a_out), p(d_w), p(y), p(part), B, H, W, C, stride, 0)
+    piv = (torch.randn(C, generator=torch.Generator().manual_seed(C)) * 0.5).float()  # statistics pivot (include/ttk.h)
+    d_piv = piv.cuda()
+    L.call("ttk_dwconv3x3_fwd", p(d_yprev), p(d_bnp), p(d_skip), p(a_out), p(d_w), p(y), p(part), p(d_piv), B, H, W, C, stride, 0)
     torch.cuda.synchronize()
     assert torch.isfinite(y).all() and torch.isfinite(part).all()
     scale = y_ref.abs().max().item()
@@ -74,8 +76,9 @@ def test_dwconv_fwd_and_bwd_against_float64(B, H, W, C, stride, skip):
     if want_a:
         assert (a_out.cpu().double() - a_in).abs().max().item() <= 1e-6 * max(a_in.abs().max().item(), 1.0)
     ps = part.cpu().double().sum(0)
-    assert torch.allclose(ps[0], y_ref.sum((0, 1, 2)), rtol=0, atol=2e-5 * y_ref.abs().sum((0, 1, 2)).max().item())
-    assert torch.allclose(ps[1], (y_ref ** 2).sum((0, 1, 2)), rtol=2e-5, atol=1e-12)
+    ys = y_ref - piv.double()
+    assert torch.allclose(ps[0], ys.sum((0, 1, 2)), rtol=0, atol=2e-5 * ys.abs().sum((0, 1, 2)).max().item())
+    assert torch.allclose(ps[1], (ys ** 2).sum((0, 1, 2)), rtol=2e-5, atol=1e-12)
 
     # ---------------- data gradient (+ fused weight gradient), block input recomputed and materialised
     g_dw, y_dw = rnd(B, Ho, Wo, C).to(torch.float32).double(), y.cpu().double()
@@ -135,12 +138,15 @@ def test_stem_fwd_and_weight_gradient_against_float64(B, H, W):
     y = torch.full((B, Ho, Wo, 32), float("nan"), device="cuda")
     rows = L.partial_rows_elementwise(B * Ho * Wo * 8)
     part = torch.full((rows, 2, 32), float("nan"), device="cuda")
-    L.call("ttk_stem_fwd", p(d_x), p(d_w), p(y), p(part), B, H, W, 0)
+    piv = (torch.randn(32, generator=g) * 0.1).float()  # statistics pivot (include/ttk.h)
+    d_piv = piv.cuda()
+    L.call("ttk_stem_fwd", p(d_x), p(d_w), p(y), p(part), p(d_piv), B, H, W, 0)
     torch.cuda.synchronize()
     assert (y.cpu().double() - y_ref).abs().max().item() <= 3e-6 * y_ref.abs().max().item()
     ps = part.cpu().double().sum(0)
-    assert torch.allclose(ps[0], y_ref.sum((0, 1, 2)), rtol=0, atol=2e-5 * y_ref.abs().sum((0, 1, 2)).max().item())
-    assert torch.allclose(ps[1], (y_ref ** 2).sum((0, 1, 2)), rtol=2e-5)
+    ys = y_ref - piv.double()
+    assert torch.allclose(ps[0], ys.sum((0, 1, 2)), rtol=0, atol=2e-5 * ys.abs().sum((0, 1, 2)).max().item())
+    assert torch.allclose(ps[1], (ys ** 2).sum((0, 1, 2)), rtol=2e-5)
     bn = _bn(32, g).float().double()
     gr = torch.randn(B, Ho, Wo, 32, generator=g).float().double()
     yv = y.cpu().double()

@@ -71,15 +71,18 @@ def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout, loose):
     y = torch.empty(M, Cout, device=dev)
     part = torch.full((rows, 2, Cout), float("nan"), device=dev)
     wq = torch.empty(L.pwconv_prepared_bytes(Cin, Cout), dtype=torch.uint8, device=dev)  # scratch for the split weight operand
-    L.call("ttk_pwconv1x1_fwd", p(d_ydw), p(d_bn), p(d_w), p(y), p(part), M, Cin, Cout, p(wq), 0)
+    piv = rng.normal(0, 0.5, Cout).astype(np.float32)  # statistics pivot (include/ttk.h): the partial sums are those of y - pivot
+    d_piv = t(piv)
+    L.call("ttk_pwconv1x1_fwd", p(d_ydw), p(d_bn), p(d_w), p(y), p(part), p(d_piv), M, Cin, Cout, p(wq), 0)
     torch.cuda.synchronize()
     e_hip, e_f32 = _rel(y.cpu().numpy(), y64), _rel(y32, y64)
     print(f"fwd   M={M} K={Cin} N={Cout}: hip {e_hip:.2e}  fp32 chain {e_f32:.2e}")
     assert e_hip <= 1.5 * e_f32 + 1e-7, (e_hip, e_f32)
     ps = part.cpu().numpy().astype(np.float64)
     assert np.isfinite(ps).all()
-    np.testing.assert_allclose(ps[:, 0].sum(0), y64.sum(0), rtol=0, atol=2e-5 * np.abs(y64).sum(0).max())
-    np.testing.assert_allclose(ps[:, 1].sum(0), (y64 ** 2).sum(0), rtol=2e-5)
+    ys = y64 - piv.astype(np.float64)
+    np.testing.assert_allclose(ps[:, 0].sum(0), ys.sum(0), rtol=0, atol=2e-5 * np.abs(ys).sum(0).max())
+    np.testing.assert_allclose(ps[:, 1].sum(0), (ys ** 2).sum(0), rtol=2e-5)
 
     # ---- data gradient: g_dw = (dy @ w) * [bn_dw(ydw) > 0], dy = ga*(g-gmean) + gb*(y-mean_pw)
     g = rng.normal(0, 1, (M, Cout)).astype(np.float32)
@@ -163,7 +166,7 @@ def test_prepared_weights_match_per_call_split():
         out = []
         for prepared in (False, True):
             y, part = torch.empty(M, Cout, device=dev), torch.zeros(rows, 2, Cout, device=dev)
-            L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None if prepared else p(w), p(y), p(part), M, Cin, Cout, p(q if prepared else wq), 0)
+            L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None if prepared else p(w), p(y), p(part), None, M, Cin, Cout, p(q if prepared else wq), 0)
             gd, part2 = torch.empty(M, Cin, device=dev), torch.zeros(rows_b, 2, Cin, device=dev)
             L.call("ttk_pwconv1x1_bwd_data", p(g), p(y), p(bn_pw), None if prepared else p(wt), p(ydw), p(bn_dw), p(gd), p(part2), M, Cin, Cout,
                    p(q if prepared else wq), 0)
@@ -172,7 +175,7 @@ def test_prepared_weights_match_per_call_split():
         for a, b in zip(*out):
             assert torch.equal(a, b), (M, Cin, Cout)
     with pytest.raises(RuntimeError, match="null pointer"):
-        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(y), None, M, Cin, Cout, None, 0)
+        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(y), None, None, M, Cin, Cout, None, 0)
 
 
 @pytest.mark.parametrize("M,Cin,Cout", [(64 * 300 + 17, 32, 64), (64 * 1100 + 63, 32, 64), (64 * 200 + 1, 64, 128), (64 * 700 + 40, 64, 128), (50, 64, 128),

@@ -106,7 +106,7 @@ def test_pwconv_entry_points_under_heavy_tails_and_loose_bounds(M, Cin, Cout, ws
     y = torch.empty(M, Cout, device=dev)
     part = torch.empty(rows, 2, Cout, device=dev)
     wq = torch.empty(L.pwconv_prepared_bytes(Cin, Cout), dtype=torch.uint8, device=dev)
-    L.call("ttk_pwconv1x1_fwd", p(d_ydw), p(d_bndw), p(d_w), p(y), p(part), M, Cin, Cout, p(wq), 0)
+    L.call("ttk_pwconv1x1_fwd", p(d_ydw), p(d_bndw), p(d_w), p(y), p(part), None, M, Cin, Cout, p(wq), 0)
     torch.cuda.synchronize()
     _check("fwd", y.cpu().numpy(), ydw, np.ascontiguousarray(w.T), bound_a, bound_w, loose, probes)
 
@@ -162,7 +162,7 @@ def test_conv_entry_points_under_heavy_tails_and_loose_bounds(loose):
     M = B * H * H
     y = torch.empty(B, H, H, Cout, device=dev)
     part = torch.empty(L.partial_rows_gemm(M), 2, Cout, device=dev)
-    L.call("ttk_conv_fwd", p(d_a), p(a_bound), p(w_f), p(y), p(part), B, H, H, Cin, Cout, k, k, stride, pad)
+    L.call("ttk_conv_fwd", p(d_a), p(a_bound), p(w_f), p(y), p(part), None, B, H, H, Cin, Cout, k, k, stride, pad)
     torch.cuda.synchronize()
     conv = lambda x, ww: F.conv2d(x, ww, stride=stride, padding=pad)
     judge("fwd", y.cpu().numpy(), nhwc(conv(a64, w64)), nhwc(conv(a32, w32)), nhwc(conv(fa, w64.abs()) + conv(a64.abs(), fw)))

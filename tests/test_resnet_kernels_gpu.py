@@ -54,11 +54,13 @@ def test_stem7(B, H):
     d_x, d_w = t(x), t(w)
     y = torch.empty(B, Ho, Ho, 64, device=dev)
     part = torch.full((rows, 2, 64), float("nan"), device=dev)
-    L.call("ttk_stem7_fwd", p(d_x), p(d_w), p(y), p(part), B, H, H)
+    piv = rng.normal(0, 0.1, 64).astype(np.float32)  # statistics pivot (include/ttk.h)
+    d_piv = t(piv)
+    L.call("ttk_stem7_fwd", p(d_x), p(d_w), p(y), p(part), p(d_piv), B, H, H)
     torch.cuda.synchronize()
     assert _rel(y.cpu().numpy(), y_ref) < 1e-6
     ps = part.cpu().numpy().astype(np.float64)
-    flat = y_ref.reshape(-1, 64)
+    flat = y_ref.reshape(-1, 64) - piv.astype(np.float64)
     np.testing.assert_allclose(ps[:, 0].sum(0), flat.sum(0), rtol=0, atol=3e-5 * np.abs(flat).sum(0).max())
     np.testing.assert_allclose(ps[:, 1].sum(0), (flat ** 2).sum(0), rtol=3e-5)
     g = rng.normal(0, 1, (B, Ho, Ho, 64)).astype(np.float32)

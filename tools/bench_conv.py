@@ -40,7 +40,7 @@ for name, hw, ci, co, k, s, mult in shapes:
     out, gin, dw = torch.empty(B, ho, ho, co, device=dev), torch.empty(B, hw, hw, ci, device=dev), torch.zeros(co, ci, k, k, device=dev)
     part = torch.empty(max(L.partial_rows_gemm(M), L.partial_rows_gemm(B * hw * hw)) * 2 * max(ci, co), device=dev)
     calls = {
-        "fwd": lambda: L.call("ttk_conv_fwd", p(a), p(a_bound), p(wf), p(out), p(part), B, hw, hw, ci, co, k, k, s, pad),
+        "fwd": lambda: L.call("ttk_conv_fwd", p(a), p(a_bound), p(wf), p(out), p(part), None, B, hw, hw, ci, co, k, k, s, pad),
         "dy": lambda: L.call("ttk_bn_bwd_apply", p(g), p(y), p(bn), p(dy), M, co),
         "dgrad": lambda: L.call("ttk_conv_bwd_data", p(dy), yp, p(bn), p(wb), None, None, p(gin), None, B, hw, hw, ci, co, k, k, s, pad),
         "dgrad_m": lambda: L.call("ttk_conv_bwd_data", p(dy), yp, p(bn), p(wb), p(a), p(mbn), p(gin), p(part), B, hw, hw, ci, co, k, k, s, pad),

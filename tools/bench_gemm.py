@@ -33,7 +33,7 @@ for name, hw, ci, co, mult in shapes:
     scr = torch.empty(nb // 4, device=dev) if nb else None
     part = torch.empty(max(L.partial_rows_gemm(M, ci, co), L.partial_rows_gemm(M, co, ci, True)) * 2 * max(ci, co), device=dev)
     calls = {
-        "fwd": lambda: L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(out), p(part), M, ci, co, p(prep), BF),
+        "fwd": lambda: L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(out), p(part), None, M, ci, co, p(prep), BF),
         "dgrad": lambda: L.call("ttk_pwconv1x1_bwd_data", p(g), p(y), p(bn_pw), None, p(ydw), p(bn_dw), p(gdw), p(part), M, ci, co, p(prep), BF),
         "wgrad": lambda: L.call("ttk_pwconv1x1_bwd_weight", p(g), p(y), p(bn_pw), p(ydw), p(bn_dw), p(dW), p(scr), M, ci, co, BF),
     }

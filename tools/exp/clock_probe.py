@@ -15,7 +15,7 @@ for (M, ci, co) in [(41472, 512, 512), (12800, 1024, 1024), (147968, 256, 256)]:
     rows = L.partial_rows_gemm(M)
     part = torch.zeros(rows * 2 * co + 64, device=dev)
     for _ in range(200):  # sustained load: the clock settles
-        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn), None, p(out), p(part), M, ci, co, p(prep), 0)
+        L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn), None, p(out), p(part), None, M, ci, co, p(prep), 0)
     torch.cuda.synchronize()
     c, t, n, bw, pl, tb, ta = part[rows * 2 * co: rows * 2 * co + 7].tolist()
     print(f"M={M} K={ci} N={co}: main loop {c:.0f} cycles / {n:.0f} steps = {c / n:.0f} cycles per k32 step; {t * 10:.0f} ns -> clock {c / (t * 10):.3f} GHz; "

@@ -5,10 +5,10 @@ L, p = H.lib(), H.ptr
 B = 512
 x = torch.randn(B, 1, 129, 129, device="cuda"); w = torch.randn(64, 1, 7, 7, device="cuda") * 0.1
 y = torch.empty(B, 65, 65, 64, device="cuda"); part = torch.empty(L.partial_rows_elementwise(B * 65 * 65 * 16), 2, 64, device="cuda")
-for _ in range(3): L.call("ttk_stem7_fwd", p(x), p(w), p(y), p(part), B, 129, 129)
+for _ in range(3): L.call("ttk_stem7_fwd", p(x), p(w), p(y), p(part), None, B, 129, 129)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(10): L.call("ttk_stem7_fwd", p(x), p(w), p(y), p(part), B, 129, 129)
+for _ in range(10): L.call("ttk_stem7_fwd", p(x), p(w), p(y), p(part), None, B, 129, 129)
 e1.record(); torch.cuda.synchronize()
 print("stem7_fwd us", e0.elapsed_time(e1) * 100)
 ref = torch.nn.functional.conv2d(x[:4].double().cpu(), w.double().cpu(), stride=2, padding=3).permute(0, 2, 3, 1)

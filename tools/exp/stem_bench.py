@@ -13,7 +13,7 @@ def run(fn, name):
     for _ in range(10): fn()
     e1.record(); torch.cuda.synchronize()
     print(name, "us", round(e0.elapsed_time(e1) * 100, 1))
-run(lambda: L.call("ttk_stem_fwd", p(x), p(w), p(y), p(part), B, 129, 129, 0), "stem_fwd")
+run(lambda: L.call("ttk_stem_fwd", p(x), p(w), p(y), p(part), None, B, 129, 129, 0), "stem_fwd")
 ref = torch.nn.functional.conv2d(x[:4].double().cpu(), w.double().cpu(), stride=2, padding=2).permute(0, 2, 3, 1)
 print("rel err", float((y[:4].cpu().double() - ref).norm() / ref.norm()))
 g = torch.randn(B, 65, 65, 32, device="cuda") * 1e-3
