@@ -17,8 +17,15 @@
  *  - return value: 0 = ok; negative = argument/shape error detected on the host before any launch;
  *    positive = hipError_t of the failed launch.  ttk_last_error_string() describes the last error
  *    of the calling thread.
- *  - activations are fp32 "channels-last": y[n][h][w][c].  The network input x[B][1][H][W] is the
- *    reference's NCHW tensor (C = 1, so the two layouts coincide).
+ *  - Activation layout.  The network input x[B][1][H][W] is the reference's NCHW tensor.  Every activation-sized tensor of the
+ *    MobileNet path (raw conv outputs y, materialised block inputs, their gradients) is stored as CHANNEL BLOCKS of 32:
+ *        [C / 32][M][32],  M = B*H*W pixels in (n, h, w) order;  element (m, c) at ((c >> 5) * M + m) * 32 + (c & 31)
+ *    (C = 32: plain channels-last).  A depthwise workgroup's 32-channel slab and a GEMM's k32 step are then contiguous runs of
+ *    pixels x 128 bytes; over channels-last rows the same kernels touched 128-byte pieces of 4C-byte rows and streamed 10-20 %
+ *    slower (profiles/r03_stream_sweep.txt).  These tensors only travel from kernel to kernel; ttk_bn_act hands out a plain
+ *    channels-last copy (MobileNet's intermediate feature maps), ttk_avgpool_fwd the [B][C] features.
+ *    The ResNet18 entry points (ttk_conv_*, ttk_stem7_*, ttk_maxpool_*, ttk_bn_add_act, ttk_bn_bwd_apply) keep channels-last rows
+ *    y[n][h][w][c]; ttk_avgpool_* serve both (TTK_LAYOUT_ROWS).
  *  - training-mode BatchNorm is split in three: the producing conv writes its RAW output y and
  *    per-workgroup partial sums  part[row][0][c] = sum(y), part[row][1][c] = sum(y*y);
  *    ttk_bn_fwd_finalize folds them (fp64) into the layer's constant block bn[TTK_BN_ROWS][C]
@@ -42,7 +49,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 17
+#define TTK_ABI_VERSION 18
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -78,6 +85,9 @@ enum { TTK_AUX_ACT_BOUND = 0, TTK_AUX_DY_BOUND = 1, TTK_AUX_GMAX = 2 };
  * arithmetic, statistics, weights and weight gradients are fp32 in every mode. */
 #define TTK_STORE_ACT_BF16 1
 #define TTK_STORE_GRAD_BF16 2
+/* The two entry points both backbones share (ttk_avgpool_fwd / ttk_avgpool_bwd) take this bit in the same argument: their
+ * activation tensors are channels-last rows [pixels][C] (the ResNet18 path) instead of channel blocks (see "Activation layout"). */
+#define TTK_LAYOUT_ROWS 4
 #define TTK_MAX_PARTIAL_ROWS_ELEMENTWISE 1024
 #define TTK_GEMM_BLOCK_M 128
 
@@ -165,7 +175,7 @@ int ttk_dwconv3x3_fwd(const void* yprev, const float* bn_prev, const void* skip_
  *   g_prev = G * [a_in > 0]                        -> written, with partials sum(g_prev), sum(g_prev*(yprev-mean))
  * a_in (nullable): materialised block input; if NULL it is recomputed from yprev/bn_prev/skip_prev.
  * dw (nullable): FUSED weight gradient dW[C][9] (+)= sum dy_dw * a_in(taps) - every (dy, a_in) pair it
- * needs is already in registers here, so the standalone kernel below is only kept for unit tests.
+ * needs is already in registers here.
  * Raises bn_prev[TTK_BN_AUX][TTK_AUX_GMAX] to max |g_prev| (the bound the previous block's GEMMs scale by).
  * dw_partial (nullable): scratch of ttk_partial_rows_dwconv(.., 1) * 9 * C floats - the fused weight gradient is then
  * folded from per-workgroup rows in a fixed order (bitwise reproducible) instead of fp32 atomics. */
@@ -174,11 +184,6 @@ int ttk_dwconv3x3_bwd_data(const void* g_dw, const void* y_dw, const float* bn_d
                            const void* skip_prev, const void* a_in, void* g_prev, float* part,
                            float* dw, int dw_accumulate, float* dw_partial, int B, int H, int W, int C,
                            int stride, int act_bf16, ttk_stream_t stream);
-/* dW[C][9] (+)= sum dy_dw * a_in(taps) (standalone form). */
-int ttk_dwconv3x3_bwd_weight(const float* g_dw, const float* y_dw, const float* bn_dw,
-                             const float* yprev, const float* bn_prev, const float* skip_prev,
-                             const float* a_in, float* dw, int accumulate, int B, int H, int W, int C,
-                             int stride, ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pointwise 1x1 conv = GEMM on the matrix cores - DepthWiseBlock.conv_sep, mobilenet_v1.py:67,82.
@@ -243,8 +248,8 @@ int ttk_avgpool_fwd(const void* y, const float* bn, const void* skip, float* fea
  * bn[TTK_BN_AUX][TTK_AUX_GMAX] to max |g|. */
 int ttk_avgpool_bwd(const float* gfeat, const void* y, float* bn, const void* skip, void* g,
                     float* part, int B, int HW, int C, int act_bf16, ttk_stream_t stream);
-/* a[.][C] = max(bn(y) (+ skip), 0): materialises a post-activation tensor (the `intermediates` list
- * MobileNet.forward returns, mobilenet_v1.py:165-186). */
+/* a[rows][C] = max(bn(y) (+ skip), 0): materialises a post-activation tensor (the `intermediates` list
+ * MobileNet.forward returns, mobilenet_v1.py:165-186).  y, skip: channel blocks; a: plain channels-last rows. */
 int ttk_bn_act(const float* y, const float* bn, const float* skip, float* a, int64_t rows, int C,
                ttk_stream_t stream);
 

@@ -36,32 +36,19 @@ inline int gemm_mode() {
   static const int mode = [] {
     const char* e = getenv("TTK_GEMM");
     if (e && strcmp(e, "f32mfma") == 0) return (int)GEMM_F32;
-#ifdef TTK_WITH_BF16X3
-    if (e && strcmp(e, "bf16x3") == 0) return (int)GEMM_BF16X3;
-#else
     if (e && strcmp(e, "bf16x3") == 0)
-      fprintf(stderr, "libttk_hip: TTK_GEMM=bf16x3 needs a build with `make WITH_BF16X3=1` (csrc/pwconv_split.hip is not part of the default build); "
-                      "using the fp16 kernels\n");
-#endif
+      fprintf(stderr, "libttk_hip: TTK_GEMM=bf16x3 (round 1's six-product bf16 split, csrc/pwconv_split.hip) was removed in round 3 - it is in the "
+                      "git history before the channel-block activation layout; using the fp16 kernels\n");
     return (int)GEMM_F16X2;
   }();
   return mode;
 }
 
-// Round 1's six-product bf16 split (csrc/pwconv_split.hip) is kept for A/B timing and numerics comparisons only and is NOT part of
-// the default build: `make WITH_BF16X3=1` compiles it and makes TTK_GEMM=bf16x3 selectable.
-#ifdef TTK_WITH_BF16X3
-bool launch_conv_gemm(int amode, int emode, const float* A0, const float* A1, const float* bnA, const uint16_t* Bm, float* out,
-                      const float* E0, const float* bnE, float* part, int64_t M, int K, int Nout, const ConvGeom& geo,
-                      hipStream_t st);
-
-bool launch_conv_wgrad(const float* g, const float* y, const float* bn, const float* a_in, float* dw, int64_t M, int Cout,
-                       int taps, const ConvGeom& geo, hipStream_t st);
-#else
+// Round 1's six-product bf16 split (csrc/pwconv_split.hip, TTK_GEMM=bf16x3) was removed in round 3; gemm_mode() never returns
+// GEMM_BF16X3 and these never launch.
 inline bool launch_conv_gemm(int, int, const float*, const float*, const float*, const uint16_t*, float*, const float*, const float*, float*, int64_t,
                              int, int, const ConvGeom&, hipStream_t) { return false; }
 inline bool launch_conv_wgrad(const float*, const float*, const float*, const float*, float*, int64_t, int, int, const ConvGeom&, hipStream_t) { return false; }
-#endif
 
 // fp16-pipe forms (pwconv_f16.hip): Bq = two fp16 planes scaled by pow2_scale(*wmax); a_bound = bound of a plain A operand
 bool launch_conv_gemm16(int amode, int emode, const float* A0, const float* A1, const float* bnA, const float* a_bound, const uint16_t* Bq,

@@ -95,13 +95,10 @@ inline DwTiling dw_tiling_sl(int B, int H, int W, int C, int stride, bool backwa
 }
 
 inline DwTiling dw_tiling(int B, int H, int W, int C, int stride, bool backward) {
-  // 64-channel slabs are built and tested (TTK_DW_SLAB=64) but NOT the default: measured on the C >= 512 layers at B = 512 the forward
-  // kernels did not change (59 us) and the backward kernels lost 5-10 % (97 -> 102-108 us, 65 -> 72 us) - with half the pixels per LDS
-  // stage a tile is one 9x9 image instead of three, and the per-tile barriers and latencies outweigh what 256-byte pieces gain at the
-  // memory (the 32-channel kernels already run above the streaming probe's rate for their piece size).
-  static const int force = [] { const char* e = getenv("TTK_DW_SLAB"); return e ? atoi(e) : 0; }();
-  if (force == 64 && C >= 64) return dw_tiling_sl(B, H, W, C, stride, backward, 64);
-  return dw_tiling_sl(B, H, W, C, stride, backward, 32);
+  // A slab is one 32-channel block of the activation layout.  (Round 3 also measured 64-channel slabs over the channels-last layout
+  // of that time: forward unchanged, backward 5-10 % slower - half the pixels per LDS stage; the kernels keep SL as a template
+  // parameter for that history, only SL = kCB is instantiated.)
+  return dw_tiling_sl(B, H, W, C, stride, backward, kCB);
 }
 
 // n / d for the tile-local pixel indices (0 <= n < 2^20, 1 <= d < 2^12) in four VALU operations: (n + 0.5) / d is at least 0.5 / d
@@ -202,7 +199,8 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
   constexpr int kSlab = SL, kSlabQuads = SL / 4, kPixSlots = kBlock / kSlabQuads, kQs = ilog2(kSlabQuads), kPs = ilog2(SL);
   const int tid = threadIdx.x, q = tid & (kSlabQuads - 1), slot = tid >> kQs;
   const int slab = blockIdx.x % nslabs, c0 = slab * kSlab + 4 * q;
-  const int cshift = __builtin_ctz((unsigned)C);  // C is a power of two
+  static_assert(SL == kCB, "a slab is one channel block of the activation layout");
+  constexpr int cshift = 5;  // pixels of a channel block are 32 elements apart (ttk_common.h act_off)
   SlabWeights wr;
   wr.load(w, c0);
   const BnApply4 bn = BnApply4::load(bn_prev, C, c0);
@@ -224,7 +222,8 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
     // full-rate instruction; the 32-bit / 64-bit integer multiplies of the size_t form run at a quarter of that rate, and at
     // ten per staged element they were a third of these VALU-bound kernels' issue slots)
     // (the bases are uniform over the workgroup - scalar registers; the lane's channel quad rides in the 32-bit offset)
-    const size_t tin = (size_t)n0 * H * W * C + slab * kSlab, tout = (size_t)n0 * Ho * Wo * C + slab * kSlab;
+    // channel block `slab` of the input / output tensor, first pixel of image n0: everything this tile touches is one contiguous run
+    const size_t tin = ((size_t)slab * B * H * W + (size_t)n0 * H * W) * kCB, tout = ((size_t)slab * B * Ho * Wo + (size_t)n0 * Ho * Wo) * kCB;
     const T* ytile = yprev + tin;
     const T* sktile = SKIP ? skip_prev + tin : nullptr;
     T* aotile = a_out ? a_out + tin : nullptr;
@@ -321,7 +320,8 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
     for (int t = 0; t < 9; ++t)
       st4(wt + t * kSlab + 4 * q, make_float4(w[(size_t)(c0 + 0) * 9 + t], w[(size_t)(c0 + 1) * 9 + t], w[(size_t)(c0 + 2) * 9 + t], w[(size_t)(c0 + 3) * 9 + t]));
   }
-  const int cshift = __builtin_ctz((unsigned)C);  // C is a power of two
+  static_assert(SL == kCB, "a slab is one channel block of the activation layout");
+  constexpr int cshift = 5;  // pixels of a channel block are 32 elements apart (ttk_common.h act_off)
   const BnApply4 bnp = BnApply4::load(bn_prev, C, c0);
   const BnGrad4 bg = BnGrad4::load(bn_dw, C, c0);
   D4 s1{0.0, 0.0, 0.0, 0.0}, s2{0.0, 0.0, 0.0, 0.0};
@@ -344,7 +344,8 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
     const unsigned PI = (unsigned)(nrows * Wp);  // staged pixels per image
     const TileDiv dPI(PI), dWp((unsigned)Wp), dtw((unsigned)tw);
     // one 64-bit base per tile and tensor, 32-bit element offsets from 24-bit multiplies (see the forward kernel)
-    const size_t tdy = (size_t)n0 * Ho * Wo * C + slab * kSlab, tin = (size_t)n0 * H * W * C + slab * kSlab;  // uniform: scalar registers
+    // channel block `slab`, first pixel of image n0 (uniform: scalar registers)
+    const size_t tdy = ((size_t)slab * B * Ho * Wo + (size_t)n0 * Ho * Wo) * kCB, tin = ((size_t)slab * B * H * W + (size_t)n0 * H * W) * kCB;
     const TG* gtile = g_dw + tdy;
     const T* ydtile = y_dw + tdy;
     const T* yptile = yprev + tin;
@@ -496,7 +497,7 @@ int ttk_dwconv3x3_fwd(const void* yprev, const float* bn_prev, const void* skip_
 #define TTK_DW_FWD_SL(S_, SK_, SL_)                                                                                                     \
   hipLaunchKernelGGL((dw_fwd_tiled_k<S_, ActT, SK_, SL_>), dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, (const ActT*)yprev, bn_prev, \
                      (const ActT*)skip_prev, (ActT*)a_out, w, (ActT*)y, part, pivot, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI, t.NCT, t.TW)
-#define TTK_DW_FWD(S_, SK_) do { if (t.SL == 64) TTK_DW_FWD_SL(S_, SK_, 64); else TTK_DW_FWD_SL(S_, SK_, 32); } while (0)
+#define TTK_DW_FWD(S_, SK_) TTK_DW_FWD_SL(S_, SK_, kCB)
   TTK_ACT_DISPATCH(act_bf16, if (stride == 1) { if (skip_prev) TTK_DW_FWD(1, true); else TTK_DW_FWD(1, false); }
                              else { if (skip_prev) TTK_DW_FWD(2, true); else TTK_DW_FWD(2, false); });
 #undef TTK_DW_FWD
@@ -519,7 +520,7 @@ int ttk_dwconv3x3_bwd_data(const void* g_dw, const void* y_dw, const float* bn_d
   hipStream_t st = (hipStream_t)stream;
   if (!dw) dw_partial = nullptr;
   if (dw && !dw_accumulate && !dw_partial) hipLaunchKernelGGL(zero_fill_k, dim3((9 * C + 255) / 256), dim3(256), 0, st, dw, (int64_t)9 * C);
-#define TTK_DW_BWD(S_) do { if (t.SL == 64) TTK_DW_BWD_SL(S_, 64); else TTK_DW_BWD_SL(S_, 32); } while (0)
+#define TTK_DW_BWD(S_) TTK_DW_BWD_SL(S_, kCB)
 #define TTK_DW_BWD_SL(S_, SL_)                                                                                                      \
   hipLaunchKernelGGL((dw_bwd_tiled_k<S_, ActT, GradT, SL_>), dim3(t.grid), dim3(kBlock), sm, st, (const GradT*)g_dw, (const ActT*)y_dw, bn_dw, w, \
                      (const GradT*)skip_grad, (const ActT*)yprev, bn_prev, (const ActT*)skip_prev, (const ActT*)a_in, (GradT*)g_prev, part,  \

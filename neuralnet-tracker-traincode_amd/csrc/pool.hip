@@ -9,7 +9,7 @@ namespace ttk {
 template <typename T>
 __global__ void __launch_bounds__(kBlock) avgpool_fwd_k(const T* __restrict__ y, const float* __restrict__ bnp,
                                                          const T* __restrict__ skip,
-                                                         float* __restrict__ feat, int B, int HW, int C) {
+                                                         float* __restrict__ feat, int B, int HW, int C, int rows_layout) {
   const int quads = C >> 2;
   const int64_t items = (int64_t)B * quads;
   const float inv = 1.0f / (float)HW;
@@ -19,7 +19,8 @@ __global__ void __launch_bounds__(kBlock) avgpool_fwd_k(const T* __restrict__ y,
     const BnApply4 bn = BnApply4::load(bnp, C, 4 * c4);
     float4 s = f4(0.f);
     for (int p = 0; p < HW; ++p) {
-      const size_t off = ((size_t)n * HW + p) * C + 4 * c4;
+      const int64_t m = (int64_t)n * HW + p;
+      const size_t off = rows_layout ? (size_t)m * C + 4 * c4 : act_off(m, 4 * c4, (int64_t)B * HW);  // channels-last rows (ResNet18) | channel blocks
       s = add4(s, skip ? bn.act(Act<T>::ld(y + off), Act<T>::ld(skip + off)) : bn.act(Act<T>::ld(y + off)));
     }
     st4(feat + (size_t)n * C + 4 * c4, make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv));
@@ -30,7 +31,7 @@ __global__ void __launch_bounds__(kBlock) avgpool_fwd_k(const T* __restrict__ y,
 template <typename T, typename TG>
 __global__ void __launch_bounds__(kBlock) avgpool_bwd_k(const float* __restrict__ gfeat, const T* __restrict__ y,
                                                          float* __restrict__ bnp, const T* __restrict__ skip, TG* __restrict__ g,
-                                                         float* __restrict__ part, int B, int HW, int C, int qshift) {
+                                                         float* __restrict__ part, int B, int HW, int C, int qshift, int rows_layout) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int quads = C >> 2;
   const int c4 = threadIdx.x & (quads - 1);
@@ -41,7 +42,7 @@ __global__ void __launch_bounds__(kBlock) avgpool_bwd_k(const float* __restrict_
   float gmx = 0.f;  // max |g| (ttk.h, TTK_AUX_GMAX)
   for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * kBlock) {
     const int n = (int)((unsigned)(idx >> qshift) / (unsigned)HW);  // 32-bit division (the host checks that B * HW fits)
-    const size_t off = (size_t)idx << 2;
+    const size_t off = rows_layout ? (size_t)idx << 2 : act_off(idx >> qshift, 4 * c4, (int64_t)B * HW);  // channels-last rows (ResNet18) | channel blocks
     const float4 yv = Act<T>::ld(y + off);
     const float4 a = skip ? bn.act(yv, Act<T>::ld(skip + off)) : bn.act(yv);
     float4 gv = ld4(gfeat + (size_t)n * C + 4 * c4);
@@ -78,7 +79,7 @@ int ttk_avgpool_fwd(const void* y, const float* bn, const void* skip, float* fea
   TTK_REQUIRE(B > 0 && HW > 0 && C >= 32 && C <= 1024 && (C & (C - 1)) == 0, "avgpool_fwd: unsupported shape B=%d HW=%d C=%d", B, HW, C);
   const int64_t items = (int64_t)B * (C / 4);
   TTK_ACT_DISPATCH(act_bf16, hipLaunchKernelGGL((avgpool_fwd_k<ActT>), dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream,
-                                                (const ActT*)y, bn, (const ActT*)skip, feat, B, HW, C));
+                                                (const ActT*)y, bn, (const ActT*)skip, feat, B, HW, C, (act_bf16 & TTK_LAYOUT_ROWS) != 0));
   TTK_LAUNCH_CHECK("avgpool_fwd");
 }
 
@@ -90,7 +91,7 @@ int ttk_avgpool_bwd(const float* gfeat, const void* y, float* bn, const void* sk
   const int qs = log2i_(C / 4);
   const int64_t items = ((int64_t)B * HW) << qs;
   TTK_ACT_DISPATCH(act_bf16, hipLaunchKernelGGL((avgpool_bwd_k<ActT, GradT>), dim3(elementwise_grid(items)), dim3(kBlock), 2 * (size_t)C * sizeof(float),
-                                                (hipStream_t)stream, gfeat, (const ActT*)y, bn, (const ActT*)skip, (GradT*)g, part, B, HW, C, qs));
+                                                (hipStream_t)stream, gfeat, (const ActT*)y, bn, (const ActT*)skip, (GradT*)g, part, B, HW, C, qs, (act_bf16 & TTK_LAYOUT_ROWS) != 0));
   TTK_LAUNCH_CHECK("avgpool_bwd");
 }
 

@@ -126,14 +126,14 @@ __global__ void __launch_bounds__(512) pw_bwd_fused_k(const float* __restrict__ 
       for (int i = 0; i < NY; ++i) {
         const int64_t row = m0 + (pt + 256 * i) / QY;
         const int64_t rcl = row < M ? row : M - 1;
-        rg[i] = ld4nt(g + rcl * COUT + 4 * cy);
-        ry[i] = ld4nt(y + rcl * COUT + 4 * cy);
+        rg[i] = ld4nt(g + act_off(rcl, 4 * cy, M));  // activations: channel blocks (ttk_common.h)
+        ry[i] = ld4nt(y + act_off(rcl, 4 * cy, M));
       }
 #pragma unroll
       for (int i = 0; i < NC; ++i) {
         const int64_t row = m0 + (pt + 256 * i) / QC;
         const int64_t rcl = row < M ? row : M - 1;
-        rc[i] = ld4(ydw + rcl * CIN + 4 * cc);  // (read again by the depthwise backward: cached)
+        rc[i] = ld4(ydw + act_off(rcl, 4 * cc, M));  // (read again by the depthwise backward: cached)
       }
     };
     auto store = [&](int t, int st) {
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(512) pw_bwd_fused_k(const float* __restrict__ 
             const float yc = Yc[row * LDC + col];
             const float out = fmaf(dsc[j], yc, dbe[j]) > 0.f ? acc[e] : 0.f;  // ReLU mask of bn_dw
             if (m0 + row < M) {
-              g_dw[(size_t)(m0 + row) * CIN + col] = out;  // 32 lanes = 128 contiguous bytes
+              g_dw[act_off(m0 + row, col, M)] = out;  // 32 lanes = 128 contiguous bytes (one row of channel block nt)
               s1[j] += out;
               s2[j] = fmaf(out, yc, s2[j]);
             }
@@ -353,10 +353,10 @@ pw_bwd_fused16_k(const float* __restrict__ g, const float* __restrict__ y, const
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int64_t row = r0 + i < M ? r0 + i : M - 1;
-        const float4 a = ld4nt(g + row * COUT + 4 * cq), b = ld4nt(y + row * COUT + 4 * cq);
+        const float4 a = ld4nt(g + act_off(row, 4 * cq, M)), b = ld4nt(y + act_off(row, 4 * cq, M));  // activations: channel blocks (ttk_common.h)
         rg[i] = fz32x4{a.x, a.y, a.z, a.w}; ry[i] = fz32x4{b.x, b.y, b.z, b.w};
         if (a_on) {
-          const float4 c = ld4(ydw + row * CIN + 4 * cqa);
+          const float4 c = ld4(ydw + act_off(row, 4 * cqa, M));
           rc[i] = fz32x4{c.x, c.y, c.z, c.w};
         }
       }
@@ -501,7 +501,7 @@ pw_bwd_fused16_k(const float* __restrict__ g, const float* __restrict__ y, const
           const float yc = Yc[row * kLdc + ci_dg];
           const float out = fmaf(dsc, yc, dbe) > 0.f ? acc[e] * inv_dg : 0.f;
           if (m0 + row < M) {
-            g_dw[(size_t)(m0 + row) * CIN + ci_dg] = out;
+            g_dw[act_off(m0 + row, ci_dg, M)] = out;
             s1 += out;
             s2 = fmaf(out, yc, s2);
           }

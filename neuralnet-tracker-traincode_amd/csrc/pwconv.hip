@@ -25,6 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = TTK_GEMM_BLOCK_M;  // 128 rows of M per workgroup
 constexpr int BKT = 32;               // contraction slice per LDS stage
+static_assert(BKT == kCB, "one LDS stage = one channel block of the A operand");
 constexpr int LDP = BKT + 4;          // padded LDS row (floats)
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
@@ -88,8 +89,9 @@ pw_gemm_k(const TO* __restrict__ A0, const T* __restrict__ A1,
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
       const int64_t row = m0 + p * ROWS_PER_PASS + lrow;
-      ra0[p] = (row < M) ? Act<TO>::ldnt(A0 + row * K + k0) : f4(0.f);
-      if constexpr (MODE == MODE_DGRAD) ra1[p] = (row < M) ? Act<T>::ldnt(A1 + row * K + k0) : f4(0.f);
+      const size_t ao = ((size_t)kt * M + row) * kCB + kq;  // channel block kt of the A operand (BKT == kCB), row `row`
+      ra0[p] = (row < M) ? Act<TO>::ldnt(A0 + ao) : f4(0.f);
+      if constexpr (MODE == MODE_DGRAD) ra1[p] = (row < M) ? Act<T>::ldnt(A1 + ao) : f4(0.f);
     }
 #pragma unroll
     for (int p = 0; p < B_PASSES; ++p) {
@@ -187,7 +189,7 @@ pw_gemm_k(const TO* __restrict__ A0, const T* __restrict__ A1,
     const int64_t grow = m0 + row;
     if (grow >= M) break;
     float4 v = ld4(Cs + row * LDC + 4 * c4);
-    const size_t o = (size_t)grow * Nout + col;
+    const size_t o = act_off(grow, col, M);
     if constexpr (MODE == MODE_FWD) {
       v = Act<TO>::round(v);  // statistics of what is stored
       Act<TO>::st(out + o, v);
@@ -270,8 +272,8 @@ __global__ void __launch_bounds__(kBlock) pw_wgrad_k(const TG* __restrict__ G, c
       const int row = f / (BN / 4), q = f % (BN / 4);
       const int64_t m = ms + row;
       if (row < MS && m < m_end) {
-        rg[p] = Act<TG>::ldnt(G + m * Cout + n0 + 4 * q);
-        ry[p] = Act<T>::ldnt(Y + m * Cout + n0 + 4 * q);
+        rg[p] = Act<TG>::ldnt(G + act_off(m, n0 + 4 * q, M));
+        ry[p] = Act<T>::ldnt(Y + act_off(m, n0 + 4 * q, M));
       } else {
         rg[p] = f4(0.f);
         ry[p] = f4(0.f);
@@ -282,7 +284,7 @@ __global__ void __launch_bounds__(kBlock) pw_wgrad_k(const TG* __restrict__ G, c
       const int f = p * kBlock + tid;
       const int row = f / (BK / 4), q = f % (BK / 4);
       const int64_t m = ms + row;
-      ra[p] = (row < MS && m < m_end) ? Act<T>::ldnt(Ydw + m * Cin + k0 + 4 * q) : f4(0.f);
+      ra[p] = (row < MS && m < m_end) ? Act<T>::ldnt(Ydw + act_off(m, k0 + 4 * q, M)) : f4(0.f);
     }
   };
   auto store_stage = [&](int64_t ms, int buf) {
@@ -389,24 +391,12 @@ bool launch_f16t_wgrad(const TG* g, const T* y, const float* bn_pw, const T* ydw
                        int Cin, int Cout, hipStream_t st);
 size_t f16t_wgrad_scratch_bytes(int64_t M, int Cin, int Cout);
 
-// pwconv_split.hip: the same shapes on the bf16 pipe with exact 3-piece splits (six products; TTK_GEMM=bf16x3, and the
-// implicit-GEMM convolutions of the ResNet18 variant)
-#ifdef TTK_WITH_BF16X3
-template <int MODE>
-bool launch_split_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0,
-                       const float* bnE, float* part, int64_t M, int K, int Nout, void* wsplit, hipStream_t st);
-
-bool split_gemm_shape(int K, int Nout);
-
-bool launch_split_wgrad(const float* g, const float* y, const float* bn_pw, const float* ydw, const float* bn_dw, float* dw,
-                        int64_t M, int Cin, int Cout, hipStream_t st);
-#else  // not built (conv_geom.h): gemm_mode() never returns GEMM_BF16X3
+// (round 1's bf16 x 3 split kernels were removed in round 3: gemm_mode() never returns GEMM_BF16X3, these never launch)
 template <int MODE>
 inline bool launch_split_gemm(const float*, const float*, const float*, const float*, float*, const float*, const float*, float*, int64_t, int, int, void*,
                               hipStream_t) { return false; }
 inline bool split_gemm_shape(int, int) { return false; }
 inline bool launch_split_wgrad(const float*, const float*, const float*, const float*, const float*, float*, int64_t, int, int, hipStream_t) { return false; }
-#endif
 
 // Layout of a prepared weight block of n = Cin*Cout elements.  fp16 / fp32 modes: [forward operand 4n][data-gradient
 // operand 4n][header: |w| maximum] - an operand is two fp16 planes or, for the shapes that stay on the fp32 kernels,

@@ -245,7 +245,7 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
         int64_t row = m0 + row0 + 32 * i;
-        arow[i] = (row < M ? row : M - 1) * (int64_t)K + kq8 * 4;  // clamp: rows past M are computed but never stored
+        arow[i] = (row < M ? row : M - 1) * (int64_t)kCB + kq8 * 4;  // inside a channel block (ttk_common.h act_off); clamp: rows past M are computed but never stored
       }
     } else {
       const int hw = Hc * Wc;
@@ -281,8 +281,8 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
       if constexpr (!GATHER) {
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
-          ra0[set][i] = ld_act4<TO>(A0 + arow[i] + kc0);
-          if constexpr (AMODE == AMODE_BNGRAD) ra1[set][i] = ld_act4<T>(A1 + arow[i] + kc0);
+          ra0[set][i] = ld_act4<TO>(A0 + arow[i] + (size_t)ks * act_block_stride(M));  // k32 step ks = channel block ks
+          if constexpr (AMODE == AMODE_BNGRAD) ra1[set][i] = ld_act4<T>(A1 + arow[i] + (size_t)ks * act_block_stride(M));
         }
       } else {  // the taps re-read their neighbours' rows: cached loads
         const int kh = tap / geo.KW, kw = tap - kh * geo.KW;
@@ -413,7 +413,12 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
   }
   // ---- epilogue, all 8 waves: row-wise pass over the C image - un-scale, 16-byte stores (a wave writes 1 KB row
   // segments), the ReLU mask of the data gradient, and the BatchNorm partial sums of this tile's 128-row halves.
-  const int c4 = tid % QN, rg = tid / QN, half = rg / RGH, rr = rg % RGH;
+  // pointwise (channel-block outputs): 16 half-waves = BN/32 channel blocks x row phases, a half-wave = 4 consecutive rows x the 8 quads
+  // of one block (512 contiguous bytes per instruction); convolutions (channels-last rows): a row segment per wave as before
+  constexpr int NBk = BN / 32;
+  const int hw_ = tid >> 5;
+  const int c4 = GATHER ? tid % QN : (hw_ % NBk) * 8 + (tid & 7), rg = GATHER ? tid / QN : (hw_ / NBk) * 4 + ((tid >> 3) & 3);
+  const int half = rg / RGH, rr = rg % RGH;
   const int col = n0 + 4 * c4;
   // the mask operand of the data gradient is requested before the barrier: its latency hides behind the accumulator
   // writes of the consumer waves (it was 16 dependent round trips to memory inside the loop below)
@@ -422,7 +427,7 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
 #pragma unroll
     for (int i = 0; i < EI; ++i) {
       const int64_t grow = m0 + half * 128 + rr + RGH * i;
-      e0[i] = grow < M ? Act<T>::ld(E0 + (size_t)grow * Nout + col) : f4(0.f);
+      e0[i] = grow < M ? Act<T>::ld(E0 + (GATHER ? (size_t)grow * Nout + col : act_off(grow, col, M))) : f4(0.f);
     }
   }
   __syncthreads();
@@ -444,7 +449,7 @@ pw16_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restr
     if (grow >= M) break;
     float4 v = ld4(Cs + row * LDC + 4 * c4);
     v = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
-    size_t o = (size_t)grow * Nout + col;
+    size_t o = GATHER ? (size_t)grow * Nout + col : act_off(grow, col, M);  // convolutions (ResNet18): channels-last rows; pointwise: channel blocks
     if (classes) {  // class-local row -> pixel
       const int rr = (int)grow, hw = Hc * Wc, n = rr / hw, rem = rr - n * hw, ch = rem / Wc, cw = rem - ch * Wc;
       o = ((size_t)(n * geo.Hg + 2 * ch + ph) * geo.Wg + 2 * cw + pw) * Nout + col;
@@ -592,16 +597,20 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
     // Steps whose 32 rows all lie inside the slice (all but possibly the last one) take a path without row clamps and
     // zero fills.
     const int nfull = (int)((m_end - m_begin) / 32);
+    // convolutions (ResNet18): channels-last rows [M][C]; pointwise: channel blocks [C/32][M][32] (ttk_common.h act_off) - elements
+    // between consecutive rows, and the offset of channel c in row 0
+    const int64_t rsA = CONV ? (int64_t)Cout : kCB, rsX = CONV ? (int64_t)Kc : kCB;
+    auto colo = [&](int c) -> int64_t { return CONV ? (int64_t)c : (int64_t)act_off(0, c, M); };
     const TG* gp[AP];
     const T* yp[AP];
     const T* xp[BP];
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      gp[p] = G + (m_begin + 4 * mb) * Cout + ca[p];
-      yp[p] = Y + (m_begin + 4 * mb) * Cout + ca[p];
+      gp[p] = G + (m_begin + 4 * mb) * rsA + colo(ca[p]);
+      yp[p] = Y + (m_begin + 4 * mb) * rsA + colo(ca[p]);
     }
 #pragma unroll
-    for (int p = 0; p < BP; ++p) xp[p] = X + (m_begin + 4 * mb) * Kc + cb[p];
+    for (int p = 0; p < BP; ++p) xp[p] = X + (m_begin + 4 * mb) * rsX + colo(cb[p]);
     // convolutions: output pixel (pn, pho, pwo) of this thread's first row of the next step, the step increments, the
     // per-column-group offset of the tap, the rows left in the slice
     int pn = 0, pho = 0, pwo = 0, dn32 = 0, dh32 = 0, dw32 = 0, prows = 0, tapoff[BP];
@@ -636,13 +645,13 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
         return;
       }
       if (ks < nfull) {
-        const int64_t base = (int64_t)ks * 32 * Cout;
+        const int64_t base = (int64_t)ks * 32 * rsA;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int p = 0; p < AP; ++p) {
-            rg[set][p][i] = ld_act4<TG>(gp[p] + base + (int64_t)i * Cout);
-            if constexpr (!APLAIN) ry[set][p][i] = ld_act4<T>(yp[p] + base + (int64_t)i * Cout);
+            rg[set][p][i] = ld_act4<TG>(gp[p] + base + (int64_t)i * rsA);
+            if constexpr (!APLAIN) ry[set][p][i] = ld_act4<T>(yp[p] + base + (int64_t)i * rsA);
           }
         return;
       }
@@ -652,8 +661,8 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
         row = row < m_end ? row : m_end - 1;
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-          rg[set][p][i] = ld_act4<TG>(G + row * Cout + ca[p]);
-          if constexpr (!APLAIN) ry[set][p][i] = ld_act4<T>(Y + row * Cout + ca[p]);
+          rg[set][p][i] = ld_act4<TG>(G + row * rsA + colo(ca[p]));
+          if constexpr (!APLAIN) ry[set][p][i] = ld_act4<T>(Y + row * rsA + colo(ca[p]));
         }
       }
     };
@@ -700,11 +709,11 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
         return;
       }
       if (ks < nfull) {
-        const int64_t base = (int64_t)ks * 32 * Cin;
+        const int64_t base = (int64_t)ks * 32 * rsX;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int p = 0; p < BP; ++p) rx[set][p][i] = ld_act4<T>(xp[p] + base + (int64_t)i * Cin);
+          for (int p = 0; p < BP; ++p) rx[set][p][i] = ld_act4<T>(xp[p] + base + (int64_t)i * rsX);
         return;
       }
       const int64_t r0 = m_begin + (int64_t)ks * 32 + 4 * mb;
@@ -713,7 +722,7 @@ pw16_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __r
         int64_t row = r0 + i;
         row = row < m_end ? row : m_end - 1;
 #pragma unroll
-        for (int p = 0; p < BP; ++p) rx[set][p][i] = ld_act4<T>(X + row * Cin + cb[p]);
+        for (int p = 0; p < BP; ++p) rx[set][p][i] = ld_act4<T>(X + row * rsX + colo(cb[p]));
       }
     };
     auto store_a = [&](int ks, auto setc) {

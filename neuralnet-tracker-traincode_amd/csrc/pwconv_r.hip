@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       const int64_t row = m0 + row0 + 32 * i;
-      arow[i] = (row < m_end ? row : m_end - 1) * (int64_t)K + kq8 * 4;  // clamp the address; rows past the block become ZERO fragments below
+      arow[i] = (row < m_end ? row : m_end - 1) * (int64_t)kCB + kq8 * 4;  // inside a channel block (ttk_common.h act_off); clamped: rows past the block become ZERO fragments below
       live |= (row < m_end ? 1u : 0u) << i;
     }
     const float* cp = bnA + kq8 * 4;
@@ -126,8 +126,8 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
       const int kc0 = ks * 32;
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
-        ra0[i] = rld_act4<TO>(A0 + arow[i] + kc0);
-        if constexpr (!FWD) ra1[i] = rld_act4<T>(A1 + arow[i] + kc0);
+        ra0[i] = rld_act4<TO>(A0 + arow[i] + (size_t)ks * act_block_stride(M));  // k32 step ks = channel block ks: RT x 128 contiguous bytes
+        if constexpr (!FWD) ra1[i] = rld_act4<T>(A1 + arow[i] + (size_t)ks * act_block_stride(M));
       }
       if constexpr (FWD) {
         q[0] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_SCALE * K + kc0);
@@ -271,7 +271,10 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
   constexpr int LDC = G::LDC, CH = G::CH, QN = kRBN / 4;
   float* Cs = reinterpret_cast<float*>(lds);
   float* red = reinterpret_cast<float*>(lds + CH * LDC * 4);  // [12][2][256]
-  const int c4 = tid % QN, rg = tid / QN;  // 12 row groups
+  // 24 half-waves = 8 channel blocks x 3 row phases; a half-wave = 4 consecutive rows x the 8 quads of ONE channel block: 512 contiguous
+  // bytes of the output (and of the mask operand) per half-wave and instruction in the channel-block layout.  The column quad of a
+  // thread is fixed (its partial sums), its rows are rg, rg + 12, ...
+  const int hw_ = tid >> 5, c4 = (hw_ & 7) * 8 + (tid & 7), rg = (hw_ >> 3) * 4 + ((tid >> 3) & 3);  // 12 row groups
   const int col = n0 + 4 * c4;
   const float inv = 1.f / (sa * sb);  // exact: a power of two
   float4 esc = f4(0.f), emean = f4(0.f), ebeta = f4(0.f);
@@ -297,7 +300,7 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
       if (grow >= m_end) continue;
       float4 v = ld4(Cs + cr * LDC + 4 * c4);
       v = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
-      const size_t o = (size_t)grow * Nout + col;
+      const size_t o = act_off(grow, col, M);
       if constexpr (FWD) {
         v = Act<TO>::round(v);  // statistics of what is stored
         Act<TO>::st(out + o, v);
@@ -410,9 +413,9 @@ __global__ void __launch_bounds__(768) pw16t_wgrad_k(const TG* __restrict__ G, c
     auto load_row = [&](int ks, int i) {
       int64_t row = r0 + (int64_t)ks * 32 + i;
       row = row < m_end ? row : m_end - 1;  // (rows past the slice are zeroed when they are stored)
-      rg[i] = rld_act4<TG>(G + row * Cout + ca);
-      ry[i] = rld_act4<T>(Y + row * Cout + ca);
-      rx[i] = rld_act4<T>(X + row * Cin + cb);
+      rg[i] = rld_act4<TG>(G + act_off(row, ca, M));
+      ry[i] = rld_act4<T>(Y + act_off(row, ca, M));
+      rx[i] = rld_act4<T>(X + act_off(row, cb, M));
     };
     auto store = [&](int ks) {  // the eight rows of step ks: BatchNorm backward / BatchNorm + ReLU, split, to LDS
       unsigned char* dy = wdy + (ks & 1) * 2 * kTStage;

@@ -35,6 +35,14 @@ void set_error(const char* fmt, ...);
 
 __host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Activation layout of the MobileNet path (include/ttk.h, "channel blocks"): a tensor of M pixels x C channels is stored as
+// [C / 32][M][32] - element (m, c) at ((c >> 5) * M + m) * 32 + (c & 31).  A depthwise workgroup's 32-channel slab and a GEMM's
+// k32 step are then CONTIGUOUS runs (pixels x 128 B) instead of 128-byte pieces of 4 C-byte rows: the same kernels stream 10-20 %
+// faster (profiles/r03_stream_sweep.txt: 5:1 read:write mix 4.9 TB/s in 128-byte pieces, 5.9-6.2 TB/s linear).  C = 32: plain [M][32].
+constexpr int kCB = 32;
+__host__ __device__ __forceinline__ size_t act_off(int64_t m, int c, int64_t M) { return ((size_t)(c >> 5) * (size_t)M + (size_t)m) * kCB + (c & (kCB - 1)); }
+__host__ __device__ __forceinline__ size_t act_block_stride(int64_t M) { return (size_t)M * kCB; }  // elements between channel blocks
+
 inline int elementwise_grid(int64_t items) {
   int64_t g = ceil_div(items, kBlock);
   if (g > TTK_MAX_PARTIAL_ROWS_ELEMENTWISE) g = TTK_MAX_PARTIAL_ROWS_ELEMENTWISE;

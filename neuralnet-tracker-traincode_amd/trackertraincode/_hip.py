@@ -27,7 +27,6 @@ _SIGNATURES = {
     "ttk_stem_bwd_weight": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I],
     "ttk_dwconv3x3_fwd": [_P] * 8 + [_I] * 6,
     "ttk_dwconv3x3_bwd_data": [_P] * 12 + [_I, _P] + [_I] * 6,
-    "ttk_dwconv3x3_bwd_weight": [_P] * 8 + [_I] * 6,
     "ttk_pwconv1x1_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _I],
     "ttk_pwconv1x1_bwd_data": [_P] * 8 + [_L, _I, _I, _P, _I],
     "ttk_pwconv1x1_bwd_weight": [_P] * 7 + [_L, _I, _I, _I],
@@ -90,7 +89,7 @@ _SIGNATURES = {
     "ttk_stream_probe": [_P, _P, _P, _L, _I, _I, _I, _I, _L, _I, _I, _I],
 }
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 def bn_pivot() -> bool:
@@ -273,6 +272,27 @@ def ptr(t: torch.Tensor | None):
     if not t.is_contiguous():
         raise RuntimeError("HIP entry point received a non-contiguous tensor")
     return t.data_ptr()
+
+
+CHANNEL_BLOCK = 32  # kCB of csrc/ttk_common.h
+
+
+def to_blocks(t: torch.Tensor) -> torch.Tensor:
+    """Channels-last values [..., C] -> the storage order of the MobileNet kernels' activation tensors (include/ttk.h, "Activation
+    layout": channel blocks [C/32][pixels][32]).  The result keeps the nominal shape of `t`; only its memory order differs.  Host code
+    never needs this - activations are produced and consumed by kernels - tests and tools do."""
+    C = t.shape[-1]
+    if C <= CHANNEL_BLOCK:
+        return t.contiguous()
+    return t.reshape(-1, C // CHANNEL_BLOCK, CHANNEL_BLOCK).transpose(0, 1).contiguous().view(t.shape)
+
+
+def from_blocks(t: torch.Tensor) -> torch.Tensor:
+    """Inverse of `to_blocks`: a tensor whose memory holds channel blocks -> the channels-last values, same nominal shape."""
+    C = t.shape[-1]
+    if C <= CHANNEL_BLOCK:
+        return t
+    return t.reshape(C // CHANNEL_BLOCK, -1, CHANNEL_BLOCK).transpose(0, 1).reshape(t.shape)
 
 
 def exported_symbols() -> list[str]:

@@ -50,6 +50,7 @@ class BasicBlock(nn.Module):
 
 _MATERIALISE_DY = os.environ.get("TTK_GEMM") != "bf16x3"
 _DETERMINISTIC = os.environ.get("TTK_DETERMINISTIC", "0") != "0"  # bitwise reproducible steps (tests/test_determinism_gpu.py)
+_LAYOUT_ROWS = 4  # TTK_LAYOUT_ROWS (include/ttk.h): this backbone keeps its activations channels-last, [pixels][C]
 _BN_AUX = 7  # TTK_BN_AUX: [0] = TTK_AUX_ACT_BOUND of the activation this BatchNorm forms
 
 
@@ -187,7 +188,7 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
     k = c.blocks[-1]
     assert k.yd is None, "the pooled block has an identity shortcut in ResNet18"
     feat = new(B, cin)
-    L.call("ttk_avgpool_fwd", p(k.y2), p(k.bn2), p(k.a_in), p(feat), B, h * h, cin, 0)
+    L.call("ttk_avgpool_fwd", p(k.y2), p(k.bn2), p(k.a_in), p(feat), B, h * h, cin, _LAYOUT_ROWS)
     return feat, c
 
 
@@ -249,7 +250,7 @@ def _backward_impl(c: _Ctx, gfeat, params):
     k = c.blocks[-1]
     C, hw = k.cout, k.ho * k.ho
     gs = new(B, k.ho, k.ho, C)
-    L.call("ttk_avgpool_bwd", p(gfeat), p(k.y2), p(k.bn2), p(k.a_in), p(gs), p(part), B, hw, C, 0)
+    L.call("ttk_avgpool_bwd", p(gfeat), p(k.y2), p(k.bn2), p(k.a_in), p(gs), p(part), B, hw, C, _LAYOUT_ROWS)
     rows_gs = L.partial_rows_elementwise(B * hw * (C // 4))
     for bidx in range(len(_PLAN) - 1, -1, -1):
         k = c.blocks[bidx]

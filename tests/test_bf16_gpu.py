@@ -37,10 +37,10 @@ def test_pointwise_kernels_with_bf16_storage(M, Cin, Cout, flag):
     import trackertraincode._hip as H
     L, p = H.lib(), H.ptr
     rng = np.random.default_rng(M + Cin + Cout)
-    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(DEV).to(torch.bfloat16)
+    bf = lambda a: H.to_blocks(torch.from_numpy(a.astype(np.float32)).to(DEV).to(torch.bfloat16))  # activations: channel blocks (include/ttk.h)
     gdt = torch.bfloat16 if flag == 3 else torch.float32  # storage of the gradient tensors
-    gr = lambda a: torch.from_numpy(a.astype(np.float32)).to(DEV).to(gdt)
-    f64 = lambda t: t.float().cpu().numpy().astype(np.float64)
+    gr = lambda a: H.to_blocks(torch.from_numpy(a.astype(np.float32)).to(DEV).to(gdt))
+    f64 = lambda t: H.from_blocks(t).float().cpu().numpy().astype(np.float64)
     ydw = bf(rng.normal(0, 1, (M, Cin)))
     w = (rng.normal(0, 1, (Cout, Cin)) * np.sqrt(2.0 / Cout)).astype(np.float32)
     bn_dw, bn_pw = _bn_block(Cin, rng), _bn_block(Cout, rng)

@@ -18,10 +18,15 @@ BN_SCALE, BN_BETA, BN_MEAN, BN_RSTD, BN_GA, BN_GB, BN_GMEAN, BN_AUX = range(8)
 MOMENTUM, EPS = 0.1, 1e-5
 
 
-def _finalize_and_check(L, p, y, part_fn, C, label):
+def _H():
+    import trackertraincode._hip as H
+    return H
+
+
+def _finalize_and_check(L, p, y, part_fn, C, label, rows_layout=False):
     """`part_fn(pivot_or_None)` runs the producer and returns its partial rows; `y` is what it stored ([..., C], on the GPU)."""
     dev = y.device
-    y64 = y.detach().double().reshape(-1, C).cpu()
+    y64 = (y if rows_layout else _H().from_blocks(y)).detach().double().reshape(-1, C).cpu()
     n = y64.shape[0]
     mean, var = y64.mean(0), y64.var(0, unbiased=False)
     ratio = (mean.abs() / var.sqrt()).numpy()
@@ -74,7 +79,7 @@ def test_pointwise_producer(M, Cin, Cout):
     a_max = float(np.maximum(ydw, 0).max())
     bn_dw[BN_AUX, 0] = max(a_max, 1.0)
     t = lambda a: torch.from_numpy(a).to(dev)
-    d_ydw, d_bn, d_w = t(ydw), t(bn_dw), t(w)
+    d_ydw, d_bn, d_w = _H().to_blocks(t(ydw)), t(bn_dw), t(w)
     y = torch.empty(M, Cout, device=dev)
     wq = torch.empty(L.pwconv_prepared_bytes(Cin, Cout), dtype=torch.uint8, device=dev)
     rows = L.partial_rows_gemm(M, Cin, Cout)
@@ -102,7 +107,7 @@ def test_depthwise_producer(B, H, C, stride):
     w = torch.zeros(C, 1, 3, 3)
     w[:, 0, 1, 1] = torch.rand(C, generator=g) + 0.5       # y = w * a_in
     Ho = (H - 1) // stride + 1
-    d_yprev, d_bn, d_w = yprev.to(dev), bn_prev.to(dev), w.to(dev)
+    d_yprev, d_bn, d_w = _H().to_blocks(yprev.to(dev)), bn_prev.to(dev), w.to(dev)
     y = torch.empty(B, Ho, Ho, C, device=dev)
     rows = L.partial_rows_dwconv(B, H, H, C, stride, False)
 
@@ -141,7 +146,7 @@ def test_resnet_conv_and_stem_producers():
         return part
 
     run(None)
-    _finalize_and_check(L, p, y, run, Cout, "conv3x3 64->64")
+    _finalize_and_check(L, p, y, run, Cout, "conv3x3 64->64", rows_layout=True)
 
     # the two stems: a bright image (0.8 + noise) under filters whose taps share a sign
     for name, C, k, args in (("ttk_stem_fwd", 32, 5, (0,)), ("ttk_stem7_fwd", 64, 7, ())):
@@ -163,7 +168,7 @@ def test_resnet_conv_and_stem_producers():
         if float((y64.mean(0).abs() / y64.std(0)).max()) <= 10:  # the zero padding at the border dominates sigma
             print(name, "border-dominated sigma: ratio", float((y64.mean(0).abs() / y64.std(0)).max()))
             continue
-        _finalize_and_check(L, p, ys, run_s, C, name)
+        _finalize_and_check(L, p, ys, run_s, C, name, rows_layout=True)
 
 
 def test_backbone_running_statistics_track_the_float64_oracle_over_steps():

@@ -60,7 +60,9 @@ def test_dwconv_fwd_and_bwd_against_float64(B, H, W, C, stride, skip):
     pre = bn_prev[SCALE] * (yprev - bn_prev[MEAN]) + bn_prev[BETA] + (skp if skip else 0.0)
     a_in = pre.clamp_min(0.0)
     y_ref = F.conv2d(_nchw(a_in), w, stride=stride, padding=1, groups=C).permute(0, 2, 3, 1)
-    d_yprev, d_skip, d_w, d_bnp = f32(yprev), f32(skp), f32(w), f32(bn_prev)
+    blk = lambda t: None if t is None else hip.to_blocks(f32(t))  # activations travel as channel blocks (include/ttk.h)
+    unblk = lambda t: hip.from_blocks(t).cpu().double()
+    d_yprev, d_skip, d_w, d_bnp = blk(yprev), blk(skp), f32(w), f32(bn_prev)
     want_a = skip and stride == 1
     a_out = torch.full((B, H, W, C), float("nan"), device="cuda") if want_a else None
     y = torch.full((B, Ho, Wo, C), float("nan"), device="cuda")
@@ -72,16 +74,16 @@ def test_dwconv_fwd_and_bwd_against_float64(B, H, W, C, stride, skip):
     torch.cuda.synchronize()
     assert torch.isfinite(y).all() and torch.isfinite(part).all()
     scale = y_ref.abs().max().item()
-    assert (y.cpu().double() - y_ref).abs().max().item() <= 3e-6 * scale
+    assert (unblk(y) - y_ref).abs().max().item() <= 3e-6 * scale
     if want_a:
-        assert (a_out.cpu().double() - a_in).abs().max().item() <= 1e-6 * max(a_in.abs().max().item(), 1.0)
+        assert (unblk(a_out) - a_in).abs().max().item() <= 1e-6 * max(a_in.abs().max().item(), 1.0)
     ps = part.cpu().double().sum(0)
     ys = y_ref - piv.double()
     assert torch.allclose(ps[0], ys.sum((0, 1, 2)), rtol=0, atol=2e-5 * ys.abs().sum((0, 1, 2)).max().item())
     assert torch.allclose(ps[1], (ys ** 2).sum((0, 1, 2)), rtol=2e-5, atol=1e-12)
 
     # ---------------- data gradient (+ fused weight gradient), block input recomputed and materialised
-    g_dw, y_dw = rnd(B, Ho, Wo, C).to(torch.float32).double(), y.cpu().double()
+    g_dw, y_dw = rnd(B, Ho, Wo, C).to(torch.float32).double(), unblk(y)
     sg = rnd(B, H, W, C).to(torch.float32).double() if (skip and stride == 1) else None
     dy = bn_dw[GA] * (g_dw - bn_dw[GMEAN]) + bn_dw[GB] * (y_dw - bn_dw[MEAN])
     a_leaf = a_in.clone().requires_grad_(True)
@@ -92,7 +94,7 @@ def test_dwconv_fwd_and_bwd_against_float64(B, H, W, C, stride, skip):
     margin = pre.abs() > 1e-4  # entries whose relu mask could flip with rounding are left out
     gp_ref = G * (pre > 0)
     dw_ref = w_leaf.grad.reshape(C, 9)
-    d_g, d_y, d_bnd, d_sg = f32(g_dw), f32(y_dw), f32(bn_dw), f32(sg)
+    d_g, d_y, d_bnd, d_sg = blk(g_dw), y, f32(bn_dw), blk(sg)
     rows_b = L.partial_rows_dwconv(B, H, W, C, stride, True)
     for materialised in ((False, True) if want_a else (False,)):
         g_prev = torch.full((B, H, W, C), float("nan"), device="cuda")
@@ -112,7 +114,7 @@ def test_dwconv_fwd_and_bwd_against_float64(B, H, W, C, stride, skip):
             det.append(dwd)
         assert torch.equal(det[0], det[1])
         assert (det[0].cpu().double() - dw_ref).abs().max().item() <= 3e-5 * dw_ref.abs().max().item()
-        got = g_prev.cpu().double()
+        got = unblk(g_prev)
         assert torch.isfinite(got).all() and torch.isfinite(part_b).all()
         sc = gp_ref.abs().max().item()
         assert ((got - gp_ref) * margin).abs().max().item() <= 5e-6 * sc, (materialised,)

@@ -67,7 +67,7 @@ def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout, loose):
     bn_dw[BN_AUX, AUX_ACT_BOUND] = np.abs(a32).max() * loose
     y64 = a32.astype(np.float64) @ w.astype(np.float64).T
     y32 = _chain32(a32, np.ascontiguousarray(w.T))
-    d_ydw, d_w, d_bn = t(ydw), t(w), t(bn_dw)
+    d_ydw, d_w, d_bn = H.to_blocks(t(ydw)), t(w), t(bn_dw)  # activations travel as channel blocks (include/ttk.h)
     y = torch.empty(M, Cout, device=dev)
     part = torch.full((rows, 2, Cout), float("nan"), device=dev)
     wq = torch.empty(L.pwconv_prepared_bytes(Cin, Cout), dtype=torch.uint8, device=dev)  # scratch for the split weight operand
@@ -75,7 +75,7 @@ def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout, loose):
     d_piv = t(piv)
     L.call("ttk_pwconv1x1_fwd", p(d_ydw), p(d_bn), p(d_w), p(y), p(part), p(d_piv), M, Cin, Cout, p(wq), 0)
     torch.cuda.synchronize()
-    e_hip, e_f32 = _rel(y.cpu().numpy(), y64), _rel(y32, y64)
+    e_hip, e_f32 = _rel(H.from_blocks(y).cpu().numpy(), y64), _rel(y32, y64)
     print(f"fwd   M={M} K={Cin} N={Cout}: hip {e_hip:.2e}  fp32 chain {e_f32:.2e}")
     assert e_hip <= 1.5 * e_f32 + 1e-7, (e_hip, e_f32)
     ps = part.cpu().numpy().astype(np.float64)
@@ -86,7 +86,7 @@ def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout, loose):
 
     # ---- data gradient: g_dw = (dy @ w) * [bn_dw(ydw) > 0], dy = ga*(g-gmean) + gb*(y-mean_pw)
     g = rng.normal(0, 1, (M, Cout)).astype(np.float32)
-    yv = y.cpu().numpy()
+    yv = H.from_blocks(y).cpu().numpy()
     dy32 = (bn_pw[BN_GA] * (g - bn_pw[BN_GMEAN]) + bn_pw[BN_GB] * (yv - bn_pw[BN_MEAN])).astype(np.float32)
     bn_pw[BN_AUX, AUX_DY_BOUND] = np.abs(dy32).max() * loose
     pre = bn_dw[BN_SCALE] * (ydw - bn_dw[BN_MEAN]) + bn_dw[BN_BETA]
@@ -97,10 +97,10 @@ def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout, loose):
     wt = torch.from_numpy(np.ascontiguousarray(w.T)).to(dev)
     g_dw = torch.empty(M, Cin, device=dev)
     part2 = torch.full((rows_b, 2, Cin), float("nan"), device=dev)
-    d_g, d_bnpw = t(g), t(bn_pw)  # named: a temporary would be recycled by the allocator before the kernel runs
+    d_g, d_bnpw = H.to_blocks(t(g)), t(bn_pw)  # named: a temporary would be recycled by the allocator before the kernel runs
     L.call("ttk_pwconv1x1_bwd_data", p(d_g), p(y), p(d_bnpw), p(wt), p(d_ydw), p(d_bn), p(g_dw), p(part2), M, Cin, Cout, p(wq), 0)
     torch.cuda.synchronize()
-    out = g_dw.cpu().numpy()
+    out = H.from_blocks(g_dw).cpu().numpy()
     e_hip, e_f32 = _rel(out * safe, gd64 * safe), _rel(gd32 * safe, gd64 * safe)
     print(f"dgrad M={M} K={Cout} N={Cin}: hip {e_hip:.2e}  fp32 chain {e_f32:.2e}")
     assert e_hip <= 1.5 * e_f32 + 1e-7, (e_hip, e_f32)
@@ -198,7 +198,7 @@ def test_fused_bwd_matches_fp64_and_the_two_kernels(M, Cin, Cout):
     dw_ref = dy.T @ np.maximum(pre, 0)
     dev = "cuda"
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    d_g, d_y, d_ydw, d_w, d_bnpw, d_bndw = t(g), t(y), t(ydw), t(w), t(bn_pw), t(bn_dw)
+    d_g, d_y, d_ydw, d_w, d_bnpw, d_bndw = Hh.to_blocks(t(g)), Hh.to_blocks(t(y)), Hh.to_blocks(t(ydw)), t(w), t(bn_pw), t(bn_dw)  # activations: channel blocks
     prep = None
     if Cin >= 64:  # the fp16-pipe forms: prepared weight block (planes / |w| maximum) and the operand bounds of row TTK_BN_AUX (1.7x loose, as the step's are)
         prep = torch.empty(L.pwconv_prepared_bytes(Cin, Cout), dtype=torch.uint8, device=dev)
@@ -213,7 +213,7 @@ def test_fused_bwd_matches_fp64_and_the_two_kernels(M, Cin, Cout):
     L.call("ttk_pwconv1x1_bwd_fused", p(d_g), p(d_y), p(d_bnpw), p(d_w), p(prep), p(d_ydw), p(d_bndw), p(g_dw), p(dw), None, p(part), M, Cin, Cout)
     torch.cuda.synchronize()
     safe = np.abs(pre) > 1e-4  # a pre-activation within rounding of zero may fall on either side of the ReLU
-    out = g_dw.cpu().numpy()
+    out = Hh.from_blocks(g_dw).cpu().numpy()
     assert np.isfinite(out).all()
     tol = 2e-6 if Cin < 64 else 3e-6  # fp32 MFMA (exact products) | fp16 split (an fp32 fma chain's accuracy)
     assert _rel(out * safe, gdw_ref * safe) < tol
@@ -231,7 +231,7 @@ def test_fused_bwd_matches_fp64_and_the_two_kernels(M, Cin, Cout):
     L.call("ttk_pwconv1x1_bwd_data", p(d_g), p(d_y), p(d_bnpw), p(wt), p(d_ydw), p(d_bndw), p(g_dw2), p(part2), M, Cin, Cout, p(wq2), 0)
     L.call("ttk_pwconv1x1_bwd_weight", p(d_g), p(d_y), p(d_bnpw), p(d_ydw), p(d_bndw), p(dw2), None, M, Cin, Cout, 0)
     torch.cuda.synchronize()
-    assert _rel(out * safe, g_dw2.cpu().numpy() * safe) < tol and _rel(dw.cpu().numpy(), dw2.cpu().numpy()) < tol
+    assert _rel(out * safe, Hh.from_blocks(g_dw2).cpu().numpy() * safe) < tol and _rel(dw.cpu().numpy(), dw2.cpu().numpy()) < tol
     # deterministic form
     nb = L.cdll.ttk_pwconv1x1_bwd_fused_partial_bytes(M, Cin, Cout)
     scratch = torch.full((nb // 4,), float("nan"), device=dev)

@@ -99,7 +99,7 @@ def test_pwconv_entry_points_under_heavy_tails_and_loose_bounds(M, Cin, Cout, ws
     bn_dw[BN_SCALE], bn_dw[BN_RSTD], bn_pw[BN_GA], bn_pw[BN_SCALE], bn_pw[BN_RSTD] = 1.0, 1.0, 1.0, 1.0, 1.0
     bound_a, bound_g, bound_w = float(ydw.max()) * loose, float(np.abs(g).max()) * loose, float(np.abs(w).max())  # (the weights' bound is their measured maximum)
     bn_dw[BN_AUX, AUX_ACT_BOUND], bn_pw[BN_AUX, AUX_DY_BOUND] = bound_a, bound_g
-    d_ydw, d_w, d_bndw, d_bnpw, d_g = t(ydw), t(w), t(bn_dw), t(bn_pw), t(g)
+    d_ydw, d_w, d_bndw, d_bnpw, d_g = H.to_blocks(t(ydw)), t(w), t(bn_dw), t(bn_pw), H.to_blocks(t(g))  # activations: channel blocks (include/ttk.h)
     rows, rows_b = L.partial_rows_gemm(M, Cin, Cout), L.partial_rows_gemm(M, Cout, Cin, True)
     probes = range(len(PROBES))
 
@@ -108,7 +108,7 @@ def test_pwconv_entry_points_under_heavy_tails_and_loose_bounds(M, Cin, Cout, ws
     wq = torch.empty(L.pwconv_prepared_bytes(Cin, Cout), dtype=torch.uint8, device=dev)
     L.call("ttk_pwconv1x1_fwd", p(d_ydw), p(d_bndw), p(d_w), p(y), p(part), None, M, Cin, Cout, p(wq), 0)
     torch.cuda.synchronize()
-    _check("fwd", y.cpu().numpy(), ydw, np.ascontiguousarray(w.T), bound_a, bound_w, loose, probes)
+    _check("fwd", H.from_blocks(y).cpu().numpy(), ydw, np.ascontiguousarray(w.T), bound_a, bound_w, loose, probes)
 
     wt = t(w.T)
     g_dw = torch.empty(M, Cin, device=dev)
@@ -116,7 +116,7 @@ def test_pwconv_entry_points_under_heavy_tails_and_loose_bounds(M, Cin, Cout, ws
     y0 = torch.zeros(M, Cout, device=dev)  # gb = 0: the conv output does not enter dy
     L.call("ttk_pwconv1x1_bwd_data", p(d_g), p(y0), p(d_bnpw), p(wt), p(d_ydw), p(d_bndw), p(g_dw), p(part2), M, Cin, Cout, p(wq), 0)
     torch.cuda.synchronize()
-    _check("dgrad", g_dw.cpu().numpy(), g, w, bound_g, bound_w, loose, probes)  # (ydw > 0 everywhere: the ReLU mask is all ones)
+    _check("dgrad", H.from_blocks(g_dw).cpu().numpy(), g, w, bound_g, bound_w, loose, probes)  # (ydw > 0 everywhere: the ReLU mask is all ones)
 
     dW = torch.zeros(Cout, Cin, device=dev)
     L.call("ttk_pwconv1x1_bwd_weight", p(d_g), p(y0), p(d_bnpw), p(d_ydw), p(d_bndw), p(dW), None, M, Cin, Cout, 0)
