@@ -93,10 +93,13 @@ class KernelTimer:
                 K, N, mode, by = co, ci, 1, eb * (2 * M * co + 2 * M * ci) + 4 * ci * co
             else:
                 by = eb * (2 * M * co + M * ci) + 4 * ci * co
-                t_mode = os.environ.get("TTK_WGRAD_T")  # csrc/pwconv_r.hip f16t_wgrad_shape: default = the 1024 x 1024 layer only
-                t_shape = ci % 256 == 0 and co % 256 == 0 and (t_mode is None and ci == co == 1024 or t_mode not in (None, "0"))
-                if t_shape and os.environ.get("TTK_GEMM") in (None, "", "f16x2"):
-                    return f"pw16t_wgrad_k<{'float' if eb == 4 else 'unsigned short'}>", fl, by  # csrc/pwconv_r.hip: 256 x 256 tiles, transposed LDS reads
+                t_mode = os.environ.get("TTK_WGRAD_T", "u")[:1]  # csrc/pwconv_r.hip f16t_wgrad_shape: 0 | t (256 x 256 tiles) | u (128 x 256, default)
+                if t_mode != "0" and ci % 256 == 0 and ci >= 256 and os.environ.get("TTK_GEMM") in (None, "", "f16x2"):
+                    ty = "float" if eb == 4 else "unsigned short"
+                    if t_mode == "t" and co % 256 == 0:
+                        return f"pw16t_wgrad_k<{ty}>", fl, by  # 256 x 256 tiles, transposed LDS reads
+                    if t_mode != "t" and co % 128 == 0 and not (ci == 256 and co == 256):
+                        return f"pw16u_wgrad_k<{ty}>", fl, by  # 128 x 256 tiles, eight producer waves with two register sets
                 if ci >= 128 and co >= 128 and (ci % 256 == 0 or co % 256 == 0 or (ci == 128 and co == 128)):
                     tn = "float" if eb == 4 else "unsigned short"
                     return (f"pw16_wgrad_k<128, 256, 1, {tn}>" if ci % 256 == 0 else f"pw16_wgrad_k<256, 128, 1, {tn}>" if co % 256 == 0 else f"pw16_wgrad_k<128, 128, 1, {tn}>"), fl, by

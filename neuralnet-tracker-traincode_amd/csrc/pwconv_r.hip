@@ -510,6 +510,173 @@ __global__ void __launch_bounds__(768) pw16t_wgrad_k(const TG* __restrict__ G, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same weight gradient with the roles turned round: 128 (Cout) x 256 (Cin) tiles, FOUR consumer waves (64 x 128 each, one per
+// SIMD) and EIGHT producer waves with TWO register sets.  Both earlier forms wait for memory in their producers: the loads of a k32
+// step are issued, waited for (a round trip under load: 3-4 000 cycles), converted, and only then are the next ones issued - the
+// matrix pipe (1 536 cycles per step) idles two thirds of the time (SQ_WAIT_INST_ANY 59 %).  With eight producer waves a lane holds
+// 8 loads (128 B) per step instead of 24, so two steps fit into registers: the loads of steps s + 1 and s + 2 are in flight while
+// step s is converted.  LDS layout, transposed fragment reads and the partial-tile + fold epilogue are those of pw16t_wgrad_k.
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename TG>
+__global__ void __launch_bounds__(768) pw16u_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __restrict__ bn_pw,
+                                                     const T* __restrict__ X, const float* __restrict__ bn_x, float* __restrict__ partial,
+                                                     int64_t M, int Cin, int Cout, int64_t rows_per_slice) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kTRing];
+  const int tid = threadIdx.x;
+  // XCD-aware order: every XCD gets whole slices (the tiles of a slice read the same rows of g, y and x)
+  const unsigned NT = (Cout / 128) * (Cin / 256), NG = gridDim.x, Lid = blockIdx.x;
+  const unsigned xq = NG / 8, xr = NG % 8, xcd = Lid % 8;
+  const unsigned logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + Lid / 8;
+  const unsigned tile = logical % NT, slice = logical / NT;
+  const int tiles_k = Cin / 256;
+  const int n0 = (tile / tiles_k) * 128, k0 = (tile % tiles_k) * 256;  // first output channel / input channel of the tile
+  const int64_t m_begin = (int64_t)slice * rows_per_slice;
+  const int64_t m_end = (m_begin + rows_per_slice < M) ? m_begin + rows_per_slice : M;
+  const int nks = m_begin < m_end ? (int)((m_end - m_begin + 31) / 32) : 0;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float sa = pow2_scale(bn_pw[(size_t)TTK_BN_AUX * Cout + TTK_AUX_DY_BOUND]);
+  const float sb = pow2_scale(bn_x[(size_t)TTK_BN_AUX * Cin + TTK_AUX_ACT_BOUND]);
+
+  if (wave >= 4) {
+    // ---------------- producers: wave w owns rows 4 w .. 4 w + 3 of every k32 step.  Lane l: the x quad l (all four rows) and the dy
+    // quad l & 31 (rows 2 (l >> 5), + 1)
+    __builtin_amdgcn_s_setprio(3);
+    const int pw = wave - 4, lane = tid & 63;
+    const int qa = lane & 31, ra = 2 * (lane >> 5);
+    const int ca = n0 + 4 * qa, cb = k0 + 4 * lane;
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GA * Cout + ca) * sa;
+    const f32x4 gb = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GB * Cout + ca) * sa;
+    const f32x4 gmean = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_GMEAN * Cout + ca);
+    const f32x4 ymean = *reinterpret_cast<const f32x4*>(bn_pw + TTK_BN_MEAN * Cout + ca);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_SCALE * Cin + cb) * sb;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_MEAN * Cin + cb);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(bn_x + TTK_BN_BETA * Cin + cb) * sb;
+    f32x4 rg[2][2], ry[2][2], rx[2][4];
+    const int64_t r0 = m_begin + 4 * pw;
+    const size_t oa = act_off(0, ca, M), ob = act_off(0, cb, M);  // channel block of this lane's quads; rows are kCB elements apart
+    // LDS: k16 stage (pw >> 2) of the step, rows 4 (pw & 3) .. + 3 of that stage
+    unsigned char* wbase = lds + (pw >> 2) * kTStage + (4 * (pw & 3)) * kTRow;
+    unsigned char* wdy = wbase + ra * kTRow + qa * 8;
+    unsigned char* wx = wbase + 2 * kTPlane + lane * 8;
+    auto load = [&](int ks, auto setc) {
+      constexpr int set = decltype(setc)::value;
+      const int64_t rb = r0 + (int64_t)ks * 32;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int64_t row = rb + i;
+        row = row < m_end ? row : m_end - 1;  // (rows past the slice are zeroed when they are stored)
+        rx[set][i] = rld_act4<T>(X + ob + (size_t)row * kCB);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int64_t row = rb + ra + j;
+        row = row < m_end ? row : m_end - 1;
+        rg[set][j] = rld_act4<TG>(G + oa + (size_t)row * kCB);
+        ry[set][j] = rld_act4<T>(Y + oa + (size_t)row * kCB);
+      }
+    };
+    auto store = [&](int ks, auto setc) {  // BatchNorm backward / BatchNorm + ReLU, split, to LDS
+      constexpr int set = decltype(setc)::value;
+      unsigned char* dy = wdy + (ks & 1) * 2 * kTStage;
+      unsigned char* xx = wx + (ks & 1) * 2 * kTStage;
+      const int64_t rb = r0 + (int64_t)ks * 32;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x4 v = ga * (rg[set][j] - gmean) + gb * (ry[set][j] - ymean);
+        if (!(rb + ra + j < m_end)) v = f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the slice contribute nothing
+        tsplit_store(v, dy + j * kTRow);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 a = sc * (rx[set][i] - mu) + be;
+        a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+        if (!(rb + i < m_end)) a = f32x4{0.f, 0.f, 0.f, 0.f};
+        tsplit_store(a, xx + i * kTRow);
+      }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    if (nks > 0) {
+      load(0, S0{});
+      if (nks > 1) load(1, S1{});
+      for (int s = 0; s < nks; s += 2) {
+        store(s, S0{});                       // (waits for the loads of step s only: those of s + 1 stay in flight)
+        if (s + 2 < nks) load(s + 2, S0{});
+        rbarrier();                           // stage s is in LDS; the consumers are done with stage s - 1
+        if (s + 1 < nks) {
+          store(s + 1, S1{});
+          if (s + 3 < nks) load(s + 3, S1{});
+          rbarrier();
+        }
+      }
+      rbarrier();
+    }
+  } else {
+    // ---------------- consumers: transposed fragment reads + three piece products per block pair (as pw16t_wgrad_k) ----------------
+    f32x16 acc[2][4];  // 64 output channels x 128 input channels
+    const int lane = tid & 63, wm = wave >> 1, wn = wave & 1;
+    const int grp = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3, h = grp >> 1;
+    const int lane_off = (8 * h + q) * kTRow + (16 * (grp & 1) + 4 * p4) * 2;
+    int aoff[2], boff[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) aoff[i] = lane_off + (wm * 64 + i * 32) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) boff[j] = 2 * kTPlane + lane_off + (wn * 128 + j * 32) * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    if (nks > 0) {
+      rbarrier();  // stage 0 is in LDS
+      for (int it = 0; it < nks; ++it) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          const unsigned char* S = lds + ((it & 1) * 2 + sub) * kTStage;
+          f16x8 a[2][2], b[2][2];
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i][pl] = tr_frag(S + pl * kTPlane, aoff[i]);
+            b[0][pl] = tr_frag(S + pl * kTPlane, boff[0]);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int cur = j & 1;
+            if (j + 1 < 4) {
+#pragma unroll
+              for (int pl = 0; pl < 2; ++pl) b[cur ^ 1][pl] = tr_frag(S + pl * kTPlane, boff[j + 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[cur][1], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[cur][0], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[cur][0], acc[i][j], 0, 0, 0);
+            }
+          }
+        }
+        rbarrier();  // done with stage `it`; stage it + 1 is in LDS
+      }
+    }
+    // ---- the tile of this slice: plain stores (lanes = 32 consecutive input channels: 128-byte segments)
+    const float inv = 1.f / (sa * sb);
+    const int r = lane & 31, hh = lane >> 5;
+    float* dst = partial + (size_t)slice * Cout * Cin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = n0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          const int col = k0 + wn * 128 + j * 32 + r;
+          dst[(size_t)row * Cin + col] = acc[i][j][e] * inv;
+        }
+  }
+}
+
 // dW[i] += partial[0][i] + partial[1][i] + ... (fixed order: bitwise reproducible); 16 B per lane
 __global__ void __launch_bounds__(256) wgrad_fold_k(const float* __restrict__ partial, float* __restrict__ dW, int64_t n, int slices) {
   const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -519,15 +686,22 @@ __global__ void __launch_bounds__(256) wgrad_fold_k(const float* __restrict__ pa
   st4(dW + i, a);
 }
 
+// TTK_WGRAD_T: 0 = neither transposed-read kernel; t = pw16t_wgrad_k (256 x 256 tiles) where its tile divides the shape;
+// u (default) = pw16u_wgrad_k (128 x 256 tiles, eight producer waves) where its tile divides the shape
+static int t_wgrad_mode() {
+  static const int mode = [] { const char* e = getenv("TTK_WGRAD_T"); return !e ? 2 : (e[0] == '0' ? 0 : (e[0] == 't' ? 1 : 2)); }();
+  return mode;
+}
+static bool t_wgrad_wide(int Cin, int Cout) { return t_wgrad_mode() == 1 && Cin % 256 == 0 && Cout % 256 == 0; }
 bool f16t_wgrad_shape(int Cin, int Cout) {
-  // measured at B = 512 (profiles/r03_wgrad_transposed.txt): ahead of the row-fragment kernel only on the 1024 x 1024 layer, so
-  // that is the default; TTK_WGRAD_T=1 takes every shape the tile divides, TTK_WGRAD_T=0 none
-  static const int mode = [] { const char* e = getenv("TTK_WGRAD_T"); return e ? (e[0] == '0' ? 0 : 2) : 1; }();
-  if (mode == 0 || gemm_mode() != GEMM_F16X2 || Cin < 256 || Cout < 256 || Cin % 256 || Cout % 256) return false;
-  return mode == 2 || (Cin == 1024 && Cout == 1024);
+  if (t_wgrad_mode() == 0 || gemm_mode() != GEMM_F16X2 || Cin < 256 || Cin % 256) return false;
+  if (t_wgrad_mode() == 1) return Cout >= 256 && Cout % 256 == 0;
+  // 256 x 256 (M = 147 968 at B = 512) is HBM-bound and has two tiles only - 128 slices of partial tiles: measured 126 us against
+  // 121 us of pw16_wgrad_k; the others gain 9-20 % (profiles/r03_wgrad_transposed.txt)
+  return Cout >= 128 && Cout % 128 == 0 && !(Cin == 256 && Cout == 256);
 }
 static void t_wgrad_plan(int64_t M, int Cin, int Cout, int& tiles, int64_t& slices, int64_t& rows) {
-  tiles = (Cout / 256) * (Cin / 256);
+  tiles = (Cout / (t_wgrad_wide(Cin, Cout) ? 256 : 128)) * (Cin / 256);
   slices = 256 / tiles;
   if (slices < 1) slices = 1;
   const int64_t max_slices = ceil_div(M, 64);
@@ -549,7 +723,10 @@ bool launch_f16t_wgrad(const TG* g, const T* y, const float* bn_pw, const T* ydw
   int tiles;
   int64_t slices, rows;
   t_wgrad_plan(M, Cin, Cout, tiles, slices, rows);
-  hipLaunchKernelGGL((pw16t_wgrad_k<T, TG>), dim3((unsigned)(tiles * slices)), dim3(768), 0, st, g, y, bn_pw, ydw, bn_dw, partial, M, Cin, Cout, rows);
+  if (t_wgrad_wide(Cin, Cout))
+    hipLaunchKernelGGL((pw16t_wgrad_k<T, TG>), dim3((unsigned)(tiles * slices)), dim3(768), 0, st, g, y, bn_pw, ydw, bn_dw, partial, M, Cin, Cout, rows);
+  else
+    hipLaunchKernelGGL((pw16u_wgrad_k<T, TG>), dim3((unsigned)(tiles * slices)), dim3(768), 0, st, g, y, bn_pw, ydw, bn_dw, partial, M, Cin, Cout, rows);
   const int64_t n = (int64_t)Cin * Cout;
   hipLaunchKernelGGL(wgrad_fold_k, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, st, partial, dw, n, (int)slices);
   return true;
