@@ -165,6 +165,8 @@ def make_parser():
     # not a flag of the reference (it trains in fp32 only): storage of the backbone's activations in HBM
     p.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16-all"],
                    help="bf16: activations cross HBM as bfloat16, their gradients stay fp32; bf16-all: both bfloat16 (statistics / accumulation / weights fp32)")
+    p.add_argument("--graph-steps", default=False, action="store_true",
+                   help="single GPU: replay one captured hipGraph per training step instead of ~150 eager launches (train.GraphedTrainStep)")
     return p
 
 
@@ -202,7 +204,8 @@ def main():
 
     try:
         train.fit(net, train_loader, train_crit, optimizer, scheduler, epochs=args.epochs, callbacks=callbacks,
-                  val_loader=test_loader if rank == 0 else None, val_criterions=test_crit, reducer=reducer)
+                  val_loader=test_loader if rank == 0 else None, val_criterions=test_crit, reducer=reducer,
+                  graphed=bool(getattr(args, "graph_steps", False)) and reducer is None)
     finally:
         parallel.install(None)
     if rank == 0:

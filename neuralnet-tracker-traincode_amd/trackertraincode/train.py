@@ -652,7 +652,7 @@ class CheckpointCallback:
 
 
 def fit(model: nn.Module, train_loader, criterions, optimizer, scheduler=None, epochs=1, callbacks=(), on_step=None,
-        grad_sync=None, val_loader=None, val_criterions=None, reducer=None):
+        grad_sync=None, val_loader=None, val_criterions=None, reducer=None, graphed=False):
     """Epoch loop with Lightning's ordering: per step zero_grad -> forward -> loss -> backward -> (gradient exchange) -> clip + Adam;
     per epoch the scheduler step, then - when `val_loader` is given - a validation epoch (`validate`) whose value goes to the
     callbacks' `on_validation_end(epoch, model, val_loss)` (CheckpointCallback: best.ckpt / last.ckpt), then `on_train_epoch_end`.
@@ -660,7 +660,14 @@ def fit(model: nn.Module, train_loader, criterions, optimizer, scheduler=None, e
     backward and the optimiser (it waits for the in-place all-reduces that ran during backward), and - should backward raise -
     `abort()` so that no collective is left in flight on gradient memory that is about to be freed.  `grad_sync(model)` is the
     older hook form of the same (runs between backward and the optimiser step).
-    Gradients are dropped (set_to_none) before every step: the arena views autograd installs are the exchange buffers."""
+    Gradients are dropped (set_to_none) before every step: the arena views autograd installs are the exchange buffers.
+    `graphed=True` (single replica, ClipAdam): every step is a replay of ONE captured hipGraph (`GraphedTrainStep`; re-captured when the
+    sub-batch layout or the epoch's loss weights change); `on_step` then receives the graph's static output tensors."""
+    stepper = None
+    if graphed:
+        if reducer is not None or grad_sync is not None:
+            raise ValueError("graphed steps are single-replica (collectives inside a captured graph are untested on this stack)")
+        stepper = GraphedTrainStep(model, criterions, optimizer)
     for cb in callbacks:
         if hasattr(cb, "on_train_start"):
             cb.on_train_start(model)
@@ -668,6 +675,11 @@ def fit(model: nn.Module, train_loader, criterions, optimizer, scheduler=None, e
     params = list(model.parameters()) if reducer is not None else None
     for epoch in range(epochs):
         for batches in train_loader:
+            if stepper is not None:
+                out = stepper.run(batches, epoch)
+                if on_step is not None:
+                    on_step(epoch, out)
+                continue
             optimizer.zero_grad(set_to_none=True)
             if reducer is not None:
                 reducer.begin_step()

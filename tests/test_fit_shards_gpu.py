@@ -27,7 +27,8 @@ def _datadir(tmp_path):
     return str(d)
 
 
-def test_fit_from_shards_with_validation_and_best_checkpoint(tmp_path, monkeypatch):
+@pytest.mark.parametrize("graphed", [False, True])  # eager launches | every step a replay of one captured hipGraph (train.GraphedTrainStep)
+def test_fit_from_shards_with_validation_and_best_checkpoint(tmp_path, monkeypatch, graphed):
     import trackertraincode.pipelines as P
     import trackertraincode.train as train
     from oracle import refmodel as R
@@ -71,7 +72,7 @@ def test_fit_from_shards_with_validation_and_best_checkpoint(tmp_path, monkeypat
         def on_validation_end(self, epoch, model, val_loss):
             seen.append((epoch, val_loss, model.training))
 
-    train.fit(net, train_loader, train_crit, opt, sch, epochs=2, callbacks=[ck, Spy()], val_loader=test_loader, val_criterions=test_crit)
+    train.fit(net, train_loader, train_crit, opt, sch, epochs=2, callbacks=[ck, Spy()], val_loader=test_loader, val_criterions=test_crit, graphed=graphed)
     assert [e for e, _, _ in seen] == [0, 1] and all(np.isfinite(v) and v > 0 for _, v, _ in seen) and all(t for _, _, t in seen)  # back in train mode
     assert ck.history == [v for _, v, _ in seen] and ck.best_value == min(ck.history) and ck.best_epoch == int(np.argmin(ck.history))
     assert os.path.exists(ck.best_model_path) and os.path.exists(ck.last_model_path)
