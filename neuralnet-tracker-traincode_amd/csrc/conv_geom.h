@@ -50,6 +50,11 @@ inline bool launch_conv_gemm(int, int, const float*, const float*, const float*,
                              int, int, const ConvGeom&, hipStream_t) { return false; }
 inline bool launch_conv_wgrad(const float*, const float*, const float*, const float*, float*, int64_t, int, int, const ConvGeom&, hipStream_t) { return false; }
 
+// Layout of a prepared weight block of n = Cin * Cout elements (ttk_pwconv_prepare_weights): [forward operand][data-gradient operand]
+// [header: |w| maximum ...].  Every reader of the block takes the offsets from here.
+inline size_t prep_bwd_offset(size_t n) { return 4 * n; }
+inline size_t prep_hdr_offset(size_t n) { return 8 * n; }
+
 // fp16-pipe forms (pwconv_f16.hip): Bq = two fp16 planes scaled by pow2_scale(*wmax); a_bound = bound of a plain A operand
 bool launch_conv_gemm16(int amode, int emode, const float* A0, const float* A1, const float* bnA, const float* a_bound, const uint16_t* Bq,
                         const float* wmax, float* out, const float* E0, float* bnE, float* part, int64_t M, int K, int Nout,

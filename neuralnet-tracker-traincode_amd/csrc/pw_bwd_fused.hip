@@ -568,8 +568,8 @@ int ttk_pwconv1x1_bwd_fused(const float* g, const float* y, const float* bn_pw, 
     // prepared block (ttk_pwconv_prepare_weights, fp16 mode): [forward planes 4n][data-gradient planes 4n][|w| maximum]
     const size_t n = (size_t)Cin * Cout;
     const unsigned char* ws = static_cast<const unsigned char*>(wsplit);
-    const uint16_t* wq = reinterpret_cast<const uint16_t*>(ws + 4 * n);
-    const float* wmx = reinterpret_cast<const float*>(ws + 8 * n);
+    const uint16_t* wq = reinterpret_cast<const uint16_t*>(ws + prep_bwd_offset(n));
+    const float* wmx = reinterpret_cast<const float*>(ws + prep_hdr_offset(n));
     if (Cin == 128)
       hipLaunchKernelGGL((pw_bwd_fused16_k<128, 128>), dim3(grid), dim3(512), 0, st, g, y, bn_pw, wq, w, wmx, ydw, bn_dw, g_dw, dw, partial, part, M, ntiles);
     else

@@ -401,8 +401,7 @@ inline bool launch_split_wgrad(const float*, const float*, const float*, const f
 // Layout of a prepared weight block of n = Cin*Cout elements.  fp16 / fp32 modes: [forward operand 4n][data-gradient
 // operand 4n][header: |w| maximum] - an operand is two fp16 planes or, for the shapes that stay on the fp32 kernels,
 // the fp32 rows; bf16 mode: [forward 6n][data gradient 6n].
-static size_t prep_bwd_offset(size_t n) { return gemm_mode() == GEMM_BF16X3 ? 6 * n : 4 * n; }
-static size_t prep_hdr_offset(size_t n) { return gemm_mode() == GEMM_BF16X3 ? 12 * n : 8 * n; }
+// (prep_bwd_offset / prep_hdr_offset: conv_geom.h - shared with the fused backward kernels of pw_bwd_fused.hip)
 
 template <int MODE, typename T, typename TO>
 static bool launch_gemm(const TO* A0, const T* A1, const float* bnA, const float* Bm, TO* out, const T* E0,

@@ -167,7 +167,7 @@ def _forward_impl(x, params, buffers, momentum, eps, training, act_dtype=torch.f
     def pivot(bi):
         """The statistics pivot of BatchNorm `bi` (include/ttk.h): its running mean - the producer sums y - pivot, the finalisation adds
         it back (and only then updates the running mean)."""
-        return p(buffers[3 * bi]) if (_hip.bn_pivot() and (training or frozen)) else None
+        return p(buffers[3 * bi]) if _hip.bn_pivot() else None
 
     def finalize(bn, rows, C, count, gamma, beta, bi):
         rm, rv, nbt = buffers[3 * bi], buffers[3 * bi + 1], buffers[3 * bi + 2]
@@ -176,10 +176,12 @@ def _forward_impl(x, params, buffers, momentum, eps, training, act_dtype=torch.f
                    float(momentum), float(eps), p(bn))
         else:
             L.call("ttk_bn_eval_prepare", p(gamma), p(beta), p(rm), p(rv), float(eps), C, p(bn))
-            if frozen:  # a backward pass follows: its fp16 GEMMs want the activation bound of this batch
-                L.call("ttk_bn_frozen_bound", p(part), pivot(bi), rows, C, count, p(bn))
+            # eval-mode statistics: the fp16-split GEMMs (forward here; the backward too when the convolutions train with frozen
+            # statistics) still scale their operands by a bound of THIS batch's activations, from the producers' partial sums - without
+            # it the pieces are unscaled: values above 65 504 overflow, small activations fall into fp16's subnormal range
+            L.call("ttk_bn_frozen_bound", p(part), pivot(bi), rows, C, count, p(bn))
 
-    part_arg = p(part) if (training or frozen) else None
+    part_arg = p(part)
     # forward and data-gradient weight operands of all 13 pointwise convs, one launch
     w_pws = [params[3 + 6 * k + 3] for k in range(len(_BLOCKS))]
     sizes = [L.pwconv_prepared_bytes(cin, cout) for _, cin, cout, _ in _BLOCKS]

@@ -214,6 +214,8 @@ class HeadsFn(Function):
         dwcat, dbcat = arena[:NZ * F].view(NZ, F), arena[NZ * F:NZ * F + NZ]
         dP = arena[NZ * F + NZ:NZ * F + NZ + 32].view(8, 4) if Pc is not None else None
         dPk = arena[NZ * F + NZ + 32:NZ * F + NZ + 64].view(8, 4) if Pkc is not None else None
+        if (dP is None) != (dPk is None):
+            arena[NZ * F + NZ:].zero_()  # one table only: the other slot lies inside the range the data-parallel hook announces (merged lo..hi)
         _call("ttk_heads_bwd", _p(feat), _p(wcat), _p(z), _p(ids32), _p(Pc), _p(Pkc), _p(kp), _p(ke), B, F, NZ, int(unc), int(pt),
               int(use_offset), int(rot6d), _p(g_roi), _p(g_coord), _p(g_rot), _p(g_qu), _p(g_Lc), _p(g_Lr), _p(g_pts), _p(g_shp), _p(dz),
               _p(dprow), _p(dfeat), _p(dwcat), _p(dbcat), _p(dP), _p(dPk))
