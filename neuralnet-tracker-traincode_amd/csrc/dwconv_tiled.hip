@@ -7,7 +7,8 @@
 // stages the operand of the stencil ONCE in LDS - already transformed (forward: a_in = relu(bn(y_prev)
 // (+skip)); backward: dy = ga*(g-gmean)+gb*(y-mean)) - with one zero column of padding left and right,
 // and reads the 9 taps with ds_read_b128 (8 lanes x 16 B = the 128-byte channel slab of one pixel;
-// 8 consecutive pixels of a row = 1 KiB contiguous: conflict-free).
+// 8 consecutive pixels of a row = 1 KiB contiguous: conflict-free).  In global memory the tensors are channel blocks
+// [C/32][pixels][32] (ttk_common.h): the slab of a tile row is contiguous there too.
 //
 // Workgroups are persistent over tiles of ONE channel slab, so per-channel BatchNorm partial sums and
 // the fused depthwise weight gradient accumulate in registers across tiles and leave the block once
@@ -25,10 +26,10 @@
 
 namespace ttk {
 
-// Channels per tile ("slab").  A workgroup touches one SL * 4-byte piece per pixel, the pieces 4 C bytes apart: what the memory system
-// delivers for that shape depends on the piece (tools/stream_sweep.py, profiles/r03_stream_sweep.txt: 5:1 read:write mix at C = 512 -
-// 128-byte pieces 4.9 TB/s, 256-byte pieces 5.5 TB/s, linear 6.2 TB/s).  The kernels are templated on it; what they measured with
-// 64-channel slabs is at dw_tiling().
+// Channels per tile ("slab") = one channel block of the activation layout (ttk_common.h act_off): the pixels of a slab are 128 bytes
+// apart, a tile row is one contiguous run.  (Over channels-last rows a workgroup touched one 128-byte piece per pixel, 4 C bytes
+// apart: tools/stream_sweep.py, profiles/r03_stream_sweep.txt - 5:1 read:write mix at C = 512: 128-byte pieces 4.9 TB/s, 256-byte
+// pieces 5.5, linear 6.2.  What 64-channel slabs measured there is at dw_tiling().)
 constexpr int kLdsPixBudget32 = 368;   // (rows) x (W+2) pixels of 128 B each: <= 47 KB -> 3 workgroups per CU (560 -> 2 per CU measured slower)
 __host__ __device__ constexpr int lds_pix_budget(int SL) { return kLdsPixBudget32 * 32 / SL; }
 __host__ __device__ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }

@@ -7,8 +7,9 @@ forward and backward launch the HIP kernels of ../../csrc through the C-ABI (inc
 
     stem 5x5 s2 -> 13 x (depthwise 3x3 -> pointwise 1x1 on fp32 MFMA) -> global average pool
 
-Data layout in HBM: activations are fp32 channels-last (`[B, H, W, C]`; exposed to PyTorch as NCHW
-tensors with channels_last strides).  Every conv writes its RAW output once, BatchNorm statistics
+Data layout in HBM: activations are fp32 in channel blocks of 32, `[C/32][B*H*W][32]` (include/ttk.h, "Activation layout"): the
+tensors below are allocated with the nominal shape `[B, H, W, C]` but only ever travel from kernel to kernel; what PyTorch sees
+(the pooled features, the intermediate maps through ttk_bn_act) is plain.  Every conv writes its RAW output once, BatchNorm statistics
 come out of the conv's epilogue, and BN + ReLU (+ residual) are applied by the consumer while
 loading (forward) - backward mirrors this with three per-channel coefficients (see include/ttk.h).
 
@@ -482,7 +483,7 @@ class MobileNet(nn.Module):
                 st = c.stages[2 * k + 2]
                 a = torch.empty_like(st.y)
                 L.call("ttk_bn_act", p(st.y), p(st.bn), p(st.skip), p(a), a.numel() // a.shape[-1], a.shape[-1])
-                outs.append(a.permute(0, 3, 1, 2))  # NCHW view of the channels-last buffer
+                outs.append(a.permute(0, 3, 1, 2))  # NCHW view of the channels-last copy ttk_bn_act wrote
         return outs
 
     def _forward_torch(self, x):
