@@ -1,6 +1,8 @@
 // Stem convolution 5x5, stride 2, pad 2, 1 -> 32 channels (backbones/mobilenet_v1.py:122-124,161)
 // and its weight gradient.  HBM-bound: the output (B*65*65*32 floats) dominates; the 129x129 input
 // plane is read through L1/L2 (each pixel is touched by <= 9 outputs x 8 lanes).
+#include <stdint.h>
+
 #include "ttk_common.h"
 #include <cstdlib>
 #include <cstring>
@@ -263,15 +265,15 @@ __global__ void __launch_bounds__(kBlock) stem_fwd_mfma_k(const float* __restric
 // 2 kFwBand + 3 input rows it touches once with coalesced loads (two zero columns left and right, zero rows outside the image:
 // no bounds tests at the taps), and its waves take the band's pixels 32 at a time - the patch fragments are LDS reads instead
 // of 13 strided 4-byte global gathers per lane (timing-only builds of stem_fwd_mfma_k: 99 us with them, 62 without).
-constexpr int kFwBand = 13;  // 65 = 5 x 13 output rows
+constexpr int kFwBand = 13;  // LDS is sized for bands of up to 13 output rows (65 = 5 x 13); the launch picks the height, see stem_band_rows()
 template <typename T>
 __global__ void __launch_bounds__(kBlock) stem_fwd_band_k(const float* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
                                                            float* __restrict__ part, const float* __restrict__ pivot, int B, int H, int W, int Ho,
-                                                           int Wo, int nbands) {
+                                                           int Wo, int nbands, int band_rows) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   __shared__ float red[kBlock / kWave][2 * kStemC];
   constexpr int kTileLd = 36;
-  const int Wp = W + 4, xrows = 2 * kFwBand + 3;
+  const int Wp = W + 4, xrows = 2 * kFwBand + 3;  // (layout of the LDS carve-up: the staged rows of a band are 2 band_rows + 3 <= xrows)
   float* xs = sm;                                  // [xrows][Wp]
   float* tiles = sm + ((xrows * Wp + 3) & ~3);     // [4 waves][32][kTileLd]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, hk = lane >> 5;
@@ -288,12 +290,20 @@ __global__ void __launch_bounds__(kBlock) stem_fwd_band_k(const float* __restric
   float s1 = 0.f, s2 = 0.f;
   for (int bt = blockIdx.x; bt < B * nbands; bt += gridDim.x) {
     const int n = bt / nbands, band = bt - n * nbands;
-    const int ho0 = band * kFwBand, ho1 = min(ho0 + kFwBand, Ho), hi0 = 2 * ho0 - 2;
+    const int ho0 = band * band_rows, ho1 = min(ho0 + band_rows, Ho), hi0 = 2 * ho0 - 2;
     const int nrows = 2 * (ho1 - ho0) + 3;
     __syncthreads();  // the previous band's readers are done with xs
-    for (int i = threadIdx.x; i < nrows * Wp; i += kBlock) {
-      const int rr = i / Wp, cc = i - rr * Wp, hi = hi0 + rr, wi = cc - 2;
-      xs[i] = (hi >= 0 && hi < H && wi >= 0 && wi < W) ? x[((size_t)n * H + hi) * W + wi] : 0.f;
+    // eight loads per thread in flight: one by one this loop was a chain of ~15 memory round trips between two barriers
+    for (int i0 = threadIdx.x; i0 < nrows * Wp; i0 += 8 * kBlock) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * kBlock, rr = i / Wp, cc = i - rr * Wp, hi = hi0 + rr, wi = cc - 2;
+        v[u] = (i < nrows * Wp && hi >= 0 && hi < H && wi >= 0 && wi < W) ? x[((size_t)n * H + hi) * W + wi] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * kBlock < nrows * Wp) xs[i0 + u * kBlock] = v[u];
     }
     __syncthreads();
     const int npix = (ho1 - ho0) * Wo;
@@ -362,14 +372,14 @@ __global__ void __launch_bounds__(kBlock) stem_fwd_band_k(const float* __restric
 // LDS (zero outside the image), so the patch fragments are LDS reads; dy is loaded with 16-byte loads (512 B per
 // wave-load instead of the fragment layout's 4 bytes per lane - the dword version was texture-addresser bound at
 // 255 us), formed in registers and turned into fragment order through a wave-private LDS tile.
-constexpr int kWgBand = 13;   // 65 = 5 x 13 output rows
+constexpr int kWgBand = 13;   // LDS is sized for bands of up to 13 output rows; the launch picks the height (stem_band_rows)
 constexpr int kWgChunk = 32;  // pixels per wave iteration = 16 MFMA k-pairs (four 16-byte loads per lane and tensor in flight)
 
 template <typename T, typename TG>
 __global__ void __launch_bounds__(kBlock) stem_wgrad_mfma_k(const TG* __restrict__ g, const T* __restrict__ y,
                                                              const float* __restrict__ bn, const float* __restrict__ x,
                                                              float* __restrict__ dw, float* __restrict__ partial, int B, int H, int W, int Ho, int Wo,
-                                                             int nbands) {
+                                                             int nbands, int band_rows) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int xrows = 2 * kWgBand + 3;
   float* xs = sm;                                         // [xrows][W]
@@ -386,12 +396,20 @@ __global__ void __launch_bounds__(kBlock) stem_wgrad_mfma_k(const TG* __restrict
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   for (int t = blockIdx.x; t < B * nbands; t += gridDim.x) {
     const int n = t / nbands, band = t - n * nbands;
-    const int ho0 = band * kWgBand, ho1 = min(ho0 + kWgBand, Ho);
+    const int ho0 = band * band_rows, ho1 = min(ho0 + band_rows, Ho);
     const int hi0 = 2 * ho0 - 2;
     __syncthreads();  // previous band's readers are done with xs
-    for (int i = threadIdx.x; i < xrows * W; i += kBlock) {
-      const int rr = i / W, cc = i - rr * W, hi = hi0 + rr;
-      xs[i] = (hi >= 0 && hi < H) ? x[((size_t)n * H + hi) * W + cc] : 0.f;
+    // eight loads per thread in flight (see stem_fwd_band_k)
+    for (int i0 = threadIdx.x; i0 < xrows * W; i0 += 8 * kBlock) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * kBlock, rr = i / W, cc = i - rr * W, hi = hi0 + rr;
+        v[u] = (i < xrows * W && hi >= 0 && hi < H) ? x[((size_t)n * H + hi) * W + cc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * kBlock < xrows * W) xs[i0 + u * kBlock] = v[u];
     }
     __syncthreads();
     const int npix = (ho1 - ho0) * Wo;
@@ -461,6 +479,20 @@ __global__ void zero_k(float* p, int n) {
 
 }  // namespace ttk
 
+// Band height (output rows per tile) for `grid` persistent workgroups: the workgroup with the most tiles sets the kernel's time, so pick
+// the height that minimises ceil(tiles / grid) * rows - at B = 512, Ho = 65: 11 rows = 6 bands = 3 072 tiles = 3 per workgroup of 1 024
+// (13 rows: 2 560 tiles, 3 for half of the workgroups and 2 for the rest: 39 rows against 33).
+static int stem_band_rows(int B, int Ho, int grid, int max_rows) {
+  int best = max_rows < Ho ? max_rows : Ho;
+  int64_t best_cost = INT64_MAX;
+  for (int r = (max_rows < Ho ? max_rows : Ho); r >= 6 && r >= 1; --r) {
+    const int64_t tiles = (int64_t)B * ((Ho + r - 1) / r);
+    const int64_t cost = ttk::ceil_div(tiles, grid) * r;
+    if (cost < best_cost) { best_cost = cost; best = r; }
+  }
+  return best;
+}
+
 using namespace ttk;
 
 extern "C" {
@@ -481,10 +513,11 @@ int ttk_stem_fwd(const float* x, const float* w, void* y, float* part, const flo
     // input band in LDS (TTK_STEM=gather: the kernel that gathers its patches from global memory; also for images too wide for LDS)
     static const bool gather = [] { const char* e = getenv("TTK_STEM"); return e && strcmp(e, "gather") == 0; }();
     const size_t sm = ((size_t)(((2 * kFwBand + 3) * (W + 4) + 3) & ~3) + (kBlock / kWave) * 32 * 36) * sizeof(float);
-    const int nbands = (Ho + kFwBand - 1) / kFwBand;
+    const int band_rows = kFwBand < Ho ? kFwBand : Ho;  // (balanced 11-row bands measured no better here: 74.9 vs 71.1 us - more halo rows per output row)
+    const int nbands = (Ho + band_rows - 1) / band_rows;
     if (!gather && sm <= 64 * 1024)
       TTK_ACT_DISPATCH(act_bf16, hipLaunchKernelGGL((stem_fwd_band_k<ActT>), dim3(elementwise_grid(items)), dim3(kBlock), sm, (hipStream_t)stream, x, w,
-                                                    (ActT*)y, part, pivot, B, H, W, Ho, Wo, nbands));
+                                                    (ActT*)y, part, pivot, B, H, W, Ho, Wo, nbands, band_rows));
     else
       TTK_ACT_DISPATCH(act_bf16, hipLaunchKernelGGL((stem_fwd_mfma_k<ActT>), dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, x, w,
                                                     (ActT*)y, part, pivot, B, H, W, Ho, Wo));
@@ -509,12 +542,16 @@ int ttk_stem_bwd_weight(const void* g, const void* y, const float* bn, const flo
     if (grid > 512) grid = 512;
     hipLaunchKernelGGL(stem_bwd_weight_k, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, (const float*)g, (const float*)y, bn, x, dw, B, H, W, Ho, Wo);
   } else {
-    const int nbands = (Ho + kWgBand - 1) / kWgBand;
-    grid = B * nbands < 1024 ? B * nbands : 1024;
+    // three workgroups fit a CU (44 KB of LDS each): 768 persistent workgroups are all resident - with 1 024 the last quarter only
+    // started when the first finished, five tile times for 2.5 tiles per workgroup
+    const int resident = 3 * 256;
+    const int band_rows = stem_band_rows(B, Ho, resident, kWgBand);
+    const int nbands = (Ho + band_rows - 1) / band_rows;
+    grid = B * nbands < resident ? B * nbands : resident;
     const size_t sm = ((size_t)(2 * kWgBand + 3) * W + (kBlock / kWave) * (kWgChunk * kStemC + kStemC * 25)) * sizeof(float);
     TTK_REQUIRE(sm <= 64 * 1024, "stem_bwd_weight: image too wide for the LDS band (W=%d)", W);
     TTK_ACT_DISPATCH(act_bf16, hipLaunchKernelGGL((stem_wgrad_mfma_k<ActT, GradT>), dim3(grid), dim3(kBlock), sm, (hipStream_t)stream, (const GradT*)g,
-                                                  (const ActT*)y, bn, x, dw, partial, B, H, W, Ho, Wo, nbands));
+                                                  (const ActT*)y, bn, x, dw, partial, B, H, W, Ho, Wo, nbands, band_rows));
     if (partial) launch_fold_partials(partial, grid, 25 * kStemC, dw, accumulate, (hipStream_t)stream);
   }
   TTK_LAUNCH_CHECK("stem_bwd_weight");
