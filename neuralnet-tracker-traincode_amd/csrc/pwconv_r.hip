@@ -660,7 +660,8 @@ __global__ void __launch_bounds__(768) pw16u_wgrad_k(const TG* __restrict__ G, c
         rbarrier();  // done with stage `it`; stage it + 1 is in LDS
       }
     }
-    // ---- the tile of this slice: plain stores (lanes = 32 consecutive input channels: 128-byte segments)
+    // ---- the tile of this slice: plain stores (lanes = 32 consecutive input channels: 128-byte segments; an LDS-staged form with
+    // 16-byte lanes and 1 KB rows per wave measured the same: 84.6 vs 83.9 us)
     const float inv = 1.f / (sa * sb);
     const int r = lane & 31, hh = lane >> 5;
     float* dst = partial + (size_t)slice * Cout * Cin;
@@ -682,7 +683,15 @@ __global__ void __launch_bounds__(256) wgrad_fold_k(const float* __restrict__ pa
   const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   float4 a = ld4(dW + i);
-  for (int s = 0; s < slices; ++s) a = add4(a, ld4nt(partial + (size_t)s * n + i));
+  int s = 0;
+  for (; s + 8 <= slices; s += 8) {  // eight loads in flight; the sum keeps its order (bitwise reproducible)
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ld4nt(partial + (size_t)(s + u) * n + i);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a = add4(a, v[u]);
+  }
+  for (; s < slices; ++s) a = add4(a, ld4nt(partial + (size_t)s * n + i));
   st4(dW + i, a);
 }
 
