@@ -22,6 +22,16 @@
 #include "conv_geom.h"
 #include <type_traits>
 
+// TTK_M_NOPK=1 (experiment builds): this file's kernels without packed fp32 instructions.  Measured (profiles/r04_rowblock_gemm_variants.txt):
+// pw16m_k 5 % SLOWER (forward 87.8 vs 82.9 us, data gradient 103 vs 96) - beside MFMAs the NUMBER of vector instructions is what costs.
+#ifndef TTK_M_NOPK
+#define TTK_M_NOPK 0
+#endif
+#if TTK_M_NOPK && defined(__HIP_DEVICE_COMPILE__)
+// every function of this translation unit (kernels, their lambdas, the inline helpers): same target features, so everything still inlines
+#pragma clang attribute push(__attribute__((target("no-packed-fp32-ops"))), apply_to = function)
+#endif
+
 namespace ttk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -31,6 +41,69 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 enum { RMODE_FWD = 0, RMODE_DGRAD = 1 };
+// Experiment builds only (tools/exp/build_variants.sh; the product is built with all of them at their defaults):
+//   TTK_R_DBG   timing-only bits, results wrong by construction: 1 no A loads | 2 no LDS-DMA | 4 no MFMAs | 8 no epilogue |
+//               16 the data gradient's epilogue does not read its mask operand | 32 the producers store their rows unconverted |
+//               64 the producers store nothing (barriers only) | 128 the consumers read no fragments (MFMAs on stale registers)
+//   TTK_R_PPRIO / TTK_R_CPRIO   s_setprio of the producer / consumer waves
+#ifndef TTK_R_DBG
+#define TTK_R_DBG 0
+#endif
+#ifndef TTK_R_PPRIO
+#define TTK_R_PPRIO 3
+#endif
+#ifndef TTK_R_CPRIO
+#define TTK_R_CPRIO 0
+#endif
+//   TTK_R_SETS  register sets of the producers' A rows: 2 (default) = the rows of step s + 2 are requested before step s + 1 is
+//               converted; 1 = round 3's schedule (rows requested one step ahead, after the conversion)
+#ifndef TTK_R_SETS
+#define TTK_R_SETS 2
+#endif
+//   TTK_R_GPS_F / TTK_R_NSLOT_F, TTK_R_GPS_D / TTK_R_NSLOT_D   groups per step and register slots of the producers' pipeline
+//               (forward / data gradient; see pw16r_k)
+//   TTK_R_MERGED 1 (default) = pw16m_k (eight waves that convert and multiply) for the data gradient, 2 = for the forward too,
+//                0 = pw16r_k (eight MFMA + four producer waves) everywhere
+//   TTK_M_FENCE  1 = a scheduling fence behind every conversion part of pw16m_k
+#ifndef TTK_R_MERGED
+#define TTK_R_MERGED 1
+#endif
+#ifndef TTK_M_FENCE
+#define TTK_M_FENCE 1
+#endif
+//   TTK_M_MIX    1 (default) = low pieces by v_fma_mix, 0 = convert back, subtract, convert
+#ifndef TTK_M_MIX
+#define TTK_M_MIX 1
+#endif
+
+#ifndef TTK_R_GPS_F
+#define TTK_R_GPS_F 1
+#endif
+#ifndef TTK_R_NSLOT_F
+#define TTK_R_NSLOT_F 2
+#endif
+#ifndef TTK_R_GPS_D
+#define TTK_R_GPS_D 2
+#endif
+#ifndef TTK_R_NSLOT_D
+#define TTK_R_NSLOT_D 3
+#endif
+template <int N, typename F, int I = 0>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, F, I + 1>(static_cast<F&&>(f));
+  }
+}
+constexpr int kRDbg = TTK_R_DBG;
+__device__ __forceinline__ f32x16 rmfma(f16x8 a, f16x8 b, f32x16 c) {
+  if constexpr (kRDbg & 4) {
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+  } else {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+}
 constexpr int kRBN = 256;  // tile width
 
 // raw s_barrier (no vmcnt drain: the producers keep global loads in flight across it) fenced against compiler motion of LDS accesses
@@ -39,6 +112,20 @@ __device__ __forceinline__ void rbarrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
+
+#if defined(TTK_R_STAMP)
+// Experiment builds only (tools/exp): cycle accounting per wave.  A stamp is s_memtime behind the lgkmcnt(0) a barrier needs anyway.
+__device__ unsigned long long g_r_stamps[2048 * 12 * 8];
+#define TTK_STAMP(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")
+#define TTK_RSTAMP(t) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")
+__device__ __forceinline__ void rbarrier_s(unsigned long long& wait) {
+  unsigned long long a, b;
+  TTK_STAMP(a);
+  __builtin_amdgcn_s_barrier();
+  TTK_STAMP(b);
+  wait += b - a;
+}
+#endif
 
 __device__ __forceinline__ int rswz(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 3) & 1)) << 4); }
 
@@ -51,10 +138,40 @@ __device__ __forceinline__ void rsplit_store(f32x4 v, unsigned char* dst, int pl
   *reinterpret_cast<uint2*>(dst + plane) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
 }
 
+// Low piece l = fp16(x - h) of two values whose high pieces are the halves of `h`: v_fma_mixlo/hi_f16 take the fp16 half as a source
+// of an fp32 fma and round the result to fp16 once - the value of (cvt_f32_f16, subtract, cvt_pk_f16_f32) in two instructions
+// instead of three and a half.  (Vector instructions of an MFMA wave are not free: they cost the matrix pipe a few cycles each.)
+__device__ __forceinline__ unsigned rlow2(unsigned h, float x0, float x1) {
+  unsigned l;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(l)
+      : "v"(h), "v"(x0), "v"(x1));
+  return l;
+}
 template <typename T>
 __device__ __forceinline__ f32x4 rld_act4(const T* p) {
   const float4 v = Act<T>::ldnt(p);
   return f32x4{v.x, v.y, v.z, v.w};
+}
+// The producers' row loads as BUFFER loads: a wave-uniform descriptor (rebuilt per k32 step: scalar work) + one 32-bit byte offset
+// per lane.  As global loads hipcc kept a 64-bit address pair per (row pass, tensor) in registers across the loop - 24 VGPRs of the
+// data gradient's producers, which is what made a second set of rows spill.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rbuf(const T* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, 0x7fffffff, 0x00020000);
+}
+template <typename T>
+__device__ __forceinline__ f32x4 rbuf_ld4(__amdgpu_buffer_rsrc_t r, unsigned elem_off) {  // 4 consecutive elements, streaming (nt)
+  if constexpr (Act<T>::kBf16) {
+    const u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(r, elem_off * 2u, 0, 2);
+    const float4 v = Act<bf16_t>::widen(make_uint2(u.x, u.y));
+    return f32x4{v.x, v.y, v.z, v.w};
+  } else {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, elem_off * 4u, 0, 2));
+  }
 }
 
 // Geometry of a tile of RBLK 32-row blocks x 8 32-column blocks on 8 consumer waves
@@ -70,8 +187,118 @@ struct RGeo {
   static constexpr int CH = 32 * WM;                        // rows of one epilogue chunk (block i of every consumer wave)
   static constexpr int LDC = kRBN + 4;
   static constexpr int kEpi = CH * LDC * 4 + 12 * 2 * kRBN * 4;
-  static constexpr int kSmem = kRing > kEpi ? kRing : kEpi;
+  static constexpr int kCst = 4 * 1024 * 4;                 // per-channel constants of the A operand: [4][K <= 1024] floats behind the ring (main loop only)
+  static constexpr int kSmem = kRing + kCst > kEpi ? kRing + kCst : kEpi;
 };
+
+// ---------------- epilogue of a tile, all NW waves: the tile leaves through LDS in TM chunks of CH rows (block c of every MFMA wave) -
+// un-scale, 16-byte stores (a wave writes 1 KB row segments), the data gradient's ReLU mask, BatchNorm sums ----------------
+template <int RBLK, int MODE, int NW, typename T, typename TO, typename Acc>
+__device__ __forceinline__ void r_epilogue(unsigned char* lds, Acc& acc, TO* __restrict__ out, const T* __restrict__ E0, const float* __restrict__ bnE,
+                                           float* __restrict__ part, int64_t M, int Nout, int64_t m0, int64_t m_end, int n0, unsigned by, float sa, float sb) {
+  using G = RGeo<RBLK>;
+  constexpr int WM = G::WM, WN = G::WN, TM = G::TM, TN = G::TN;
+  constexpr bool FWD = MODE == RMODE_FWD;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int LDC = G::LDC, CH = G::CH;
+  float* Cs = reinterpret_cast<float*>(lds);
+  float* red = reinterpret_cast<float*>(lds + CH * LDC * 4);  // [NW][2][256]
+  // 2 NW half-waves = 8 channel blocks x NW / 4 row phases; a half-wave = 4 consecutive rows x the 8 quads of ONE channel block: 512
+  // contiguous bytes of the output (and of the mask operand) per half-wave and instruction in the channel-block layout.  The column
+  // quad of a thread is fixed (its partial sums), its rows are rg, rg + NW, ...
+  const int hw_ = tid >> 5, c4 = (hw_ & 7) * 8 + (tid & 7), rg = (hw_ >> 3) * 4 + ((tid >> 3) & 3);  // NW row groups
+  const int col = n0 + 4 * c4;
+  const float inv = 1.f / (sa * sb);  // exact: a power of two
+  float4 esc = f4(0.f), emean = f4(0.f), ebeta = f4(0.f);
+  if constexpr (!FWD) {
+    esc = ld4(bnE + TTK_BN_SCALE * Nout + col); emean = ld4(bnE + TTK_BN_MEAN * Nout + col); ebeta = ld4(bnE + TTK_BN_BETA * Nout + col);
+  } else {
+    if (bnE) emean = ld4(bnE + col);  // forward: bnE is the statistics pivot [Nout] (ttk.h), the sums are those of y - pivot
+  }
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+  if constexpr (kRDbg & 8) {
+    if (wave < 8) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+    }
+  } else {
+  // The data gradient's mask operand (raw depthwise output) is requested one group of rows ahead into the other of two register
+  // buffers: a chunk's later groups and the next chunk's first group while the current group is processed (the registers of the
+  // accumulators already parked are free by then), the tile's first group right after chunk 0 is parked.  Requested inside the
+  // row loop, two rows at a time, every round trip was exposed: 23 000 cycles per tile against the forward's 9 600
+  // (profiles/r04_rowblock_stamps.txt).
+  constexpr int NRG = NW == 12 ? 6 : 8, NGRP = (CH + NW * NRG - 1) / (NW * NRG);  // rows per thread and group; groups per chunk
+  float4 ev[2][NRG];
+  auto tile_row = [&](int c, int cr) -> int64_t { return m0 + (cr >> 5) * (32 * TM) + c * 32 + (cr & 31); };  // chunk row -> tile row: block c of consumer row cr / 32
+  auto e_load = [&](auto idxc) {  // group idx = c * NGRP + g -> buffer idx & 1
+    constexpr int idx = decltype(idxc)::value, c = idx / NGRP, g = idx % NGRP;
+    if constexpr (!FWD && idx < TM * NGRP) {
+#pragma unroll
+      for (int u = 0; u < NRG; ++u) {
+        const int cr = rg + NW * (g * NRG + u);
+        const int64_t grow = tile_row(c, cr);
+        ev[idx & 1][u] = f4(0.f);
+        if constexpr (!(kRDbg & 16))
+          if (cr < CH && grow < m_end) ev[idx & 1][u] = Act<T>::ld(E0 + act_off(grow, col, M));
+      }
+    }
+  };
+  static_for<TM>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    if (wave < 8) {
+      const int lane = tid & 63, wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Cs[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * (32 * TN) + j * 32 + r] = acc[c][j][e];
+    }
+    if constexpr (c == 0) e_load(std::integral_constant<int, 0>{});
+    __syncthreads();  // chunk c is in LDS
+    static_for<NGRP>([&](auto gc) {
+      constexpr int g = decltype(gc)::value, idx = c * NGRP + g;
+      e_load(std::integral_constant<int, idx + 1>{});
+#pragma unroll
+      for (int u = 0; u < NRG; ++u) {
+        const int cr = rg + NW * (g * NRG + u);
+        const int64_t grow = tile_row(c, cr);
+        if (cr >= CH || grow >= m_end) continue;
+        float4 v = ld4(Cs + cr * LDC + 4 * c4);
+        v = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+        const size_t o = act_off(grow, col, M);
+        if constexpr (FWD) {
+          v = Act<TO>::round(v);  // statistics of what is stored
+          Act<TO>::st(out + o, v);
+          v = sub4(v, emean);
+          s1 = add4(s1, v);
+          s2 = fma4(v, v, s2);
+        } else {
+          const float4 yc = sub4(ev[idx & 1][u], emean);
+          v = Act<TO>::round(mask4(v, fma4(esc, yc, ebeta)));
+          Act<TO>::st(out + o, v);
+          s1 = add4(s1, v);
+          s2 = fma4(v, yc, s2);
+        }
+      }
+    });
+    __syncthreads();  // the row pass is done: the next chunk may be parked
+  });
+  }
+  if (part) {  // one row of partial sums per tile: NW row groups folded in a fixed order
+    st4(red + (rg * 2 + 0) * kRBN + 4 * c4, s1);
+    st4(red + (rg * 2 + 1) * kRBN + 4 * c4, s2);
+    __syncthreads();
+    if (tid < 2 * kRBN) {
+      const int which = tid / kRBN, c = tid % kRBN;
+      float a = 0.f;
+#pragma unroll
+      for (int qq = 0; qq < NW; ++qq) a += red[(qq * 2 + which) * kRBN + c];
+      part[(size_t)by * 2 * Nout + (size_t)which * Nout + n0 + c] = a;
+    }
+  }
+}
 
 // A: fp32 rows [M][K], formed on load (forward: relu(bn(y)); data gradient: ga*(g-gmean)+gb*(y-mean)); Bq: two fp16 planes
 // [K/16][Nout][16] (chunk-swizzled) of the weights scaled by pow2_scale(*wmax).  Tile t: rows [by*RT, min((by+1)*RT, M)),
@@ -101,80 +328,155 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
   const float sa = pow2_scale(bnA[(size_t)TTK_BN_AUX * K + (FWD ? TTK_AUX_ACT_BOUND : TTK_AUX_DY_BOUND)]);
   const float sb = pow2_scale(*wmax);
   f32x16 acc[TM][TN];  // consumer waves only
+  // per-channel constants of the A operand, once per tile: [scale S_a | mean | beta S_a] (forward), [ga S_a | gmean | gb S_a | mean] (data gradient)
+  float* cst = reinterpret_cast<float*>(lds + G::kRing);
+  {
+    constexpr int NQ = FWD ? 3 : 4;
+    for (int i = tid * 4; i < NQ * K; i += 768 * 4) {
+      const int j = i / K, c = i - j * K;
+      const int row = FWD ? (j == 0 ? TTK_BN_SCALE : (j == 1 ? TTK_BN_MEAN : TTK_BN_BETA)) : (j == 0 ? TTK_BN_GA : (j == 1 ? TTK_BN_GMEAN : (j == 2 ? TTK_BN_GB : TTK_BN_MEAN)));
+      float4 v = ld4(bnA + (size_t)row * K + c);
+      if (j == 0 || j == 2) v = make_float4(v.x * sa, v.y * sa, v.z * sa, v.w * sa);
+      st4(cst + i, v);
+    }
+    __syncthreads();
+  }
+#if defined(TTK_R_STAMP)
+  unsigned long long st_t0, st_r0, st_wait = 0, st_aux = 0, st_loop0 = 0, st_loop1 = 0, st_x, st_y;
+  TTK_STAMP(st_t0);
+  TTK_RSTAMP(st_r0);
+#define TTK_RB() rbarrier_s(st_wait)
+#else
+#define TTK_RB() rbarrier()
+#endif
 
   if (wave >= 8) {
     // ---------------- producers: A through registers (BatchNorm form, split, ds_write), B by LDS-DMA ----------------
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(TTK_R_PPRIO);
     const int pt = tid - 512;
     const int row0 = pt >> 3, kq8 = pt & 7;  // 32 rows per pass; 8 lanes x 16 B = one 128-byte row segment
     const int sub = kq8 >> 2, chunk = (kq8 >> 1) & 1, o8 = (kq8 & 1) * 8;
     constexpr int AP = RBLK;
-    constexpr int NQ = FWD ? 3 : 4;
-    f32x4 ra0[AP], ra1[FWD ? 1 : AP], q[NQ];
-    int64_t arow[AP];
+    // The producers' pipeline works in GROUPS of G = AP / GPS row passes of a k32 step; NSLOT register slots of one group rotate:
+    // group n is converted from slot n % NSLOT and group n + NSLOT is requested into the slot that has just been freed.
+    // With ONE set of a whole step (GPS = 1, NSLOT = 1: round 3) a row is requested when the producer finishes its part of step s
+    // and needed when step s + 1 begins - its latency budget is the producers' barrier wait, so the loop settles at (memory
+    // latency + conversion + issue) per step: 3 700 cycles measured against 2 304 of matrix work, the consumers waiting 1 000 at
+    // the barrier of every step (profiles/r04_rowblock_stamps.txt).  The forward keeps two whole sets (budget: two steps); the data
+    // gradient, whose rows are two tensors, three half sets (72 registers at RBLK = 6; budget: a step and a half).
+    constexpr int GPS = TTK_R_SETS == 1 ? 1 : (FWD ? TTK_R_GPS_F : TTK_R_GPS_D);
+    constexpr int NSLOT = TTK_R_SETS == 1 ? 1 : (FWD ? TTK_R_NSLOT_F : TTK_R_NSLOT_D);
+    static_assert(AP % GPS == 0 && (GPS & (GPS - 1)) == 0, "groups per step: a power of two that divides the row passes");
+    constexpr int G = AP / GPS;
+    constexpr int UNR = NSLOT % GPS == 0 ? NSLOT : (GPS % NSLOT == 0 ? GPS : NSLOT * GPS);  // groups per unrolled round: slot and half are compile-time
+    f32x4 ra0[NSLOT][G] = {}, ra1[NSLOT][FWD ? 1 : G] = {};
     unsigned live = 0u;  // bit i: pass i's row lies inside the row block
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      const int64_t row = m0 + row0 + 32 * i;
-      arow[i] = (row < m_end ? row : m_end - 1) * (int64_t)kCB + kq8 * 4;  // inside a channel block (ttk_common.h act_off); clamped: rows past the block become ZERO fragments below
-      live |= (row < m_end ? 1u : 0u) << i;
-    }
-    const float* cp = bnA + kq8 * 4;
+    for (int i = 0; i < AP; ++i) live |= (m0 + row0 + 32 * i < m_end ? 1u : 0u) << i;
+    // element offset of pass 0 inside the tile's run of a channel block (ttk_common.h act_off); pass i is 32 rows = 32 kCB elements
+    // further; rows past the block read pass 0's address (always inside: RT >= 32) and become ZERO fragments below
+    const unsigned aoff0 = (unsigned)(row0 * kCB + kq8 * 4);
+    const float* cq = cst + kq8 * 4;
     unsigned char* wbase = lds + sub * kStr + o8;
+    const int NG = nks * GPS;
 
-    auto load_a = [&](int ks) {
-      const int kc0 = ks * 32;
+    auto load_g = [&](int ks, auto hfc, auto slotc) {  // rows of group hf of step ks -> slot
+      constexpr int slot = decltype(slotc)::value, hf = decltype(hfc)::value;
+      // k32 step ks = channel block ks: the tile's RT x 128 contiguous bytes
+      const __amdgpu_buffer_rsrc_t r0 = rbuf(A0 + ((size_t)ks * act_block_stride(M) + (size_t)m0 * kCB));
+      const __amdgpu_buffer_rsrc_t r1 = rbuf((FWD ? (const T*)nullptr : A1) + ((size_t)ks * act_block_stride(M) + (size_t)m0 * kCB));
 #pragma unroll
-      for (int i = 0; i < AP; ++i) {
-        ra0[i] = rld_act4<TO>(A0 + arow[i] + (size_t)ks * act_block_stride(M));  // k32 step ks = channel block ks: RT x 128 contiguous bytes
-        if constexpr (!FWD) ra1[i] = rld_act4<T>(A1 + arow[i] + (size_t)ks * act_block_stride(M));
-      }
-      if constexpr (FWD) {
-        q[0] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_SCALE * K + kc0);
-        q[1] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * K + kc0);
-        q[2] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_BETA * K + kc0);
-      } else {
-        q[0] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GA * K + kc0);
-        q[1] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GMEAN * K + kc0);
-        q[2] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_GB * K + kc0);
-        q[3] = *reinterpret_cast<const f32x4*>(cp + TTK_BN_MEAN * K + kc0);
+      for (int u = 0; u < G; ++u) {
+        const int i = hf * G + u;
+        if constexpr (kRDbg & 1) {
+          f32x4 t0 = ra0[slot][u], t1 = ra1[slot][FWD ? 0 : u];  // (copies: clang rejects captured arrays as asm operands in this lambda)
+          asm volatile("" : "+v"(t0), "+v"(t1));
+          ra0[slot][u] = t0;
+          ra1[slot][FWD ? 0 : u] = t1;
+        } else {
+          const unsigned o = ((live >> i) & 1u) ? aoff0 + (unsigned)(i * 32 * kCB) : aoff0;
+          ra0[slot][u] = rbuf_ld4<TO>(r0, o);
+          if constexpr (!FWD) ra1[slot][u] = rbuf_ld4<T>(r1, o);
+        }
       }
     };
-    auto store_a = [&](int ks) {
+    auto conv_g = [&](int ks, auto hfc, auto slotc) {  // BatchNorm form, split, ds_write of group hf of step ks
+      constexpr int slot = decltype(slotc)::value, hf = decltype(hfc)::value;
       unsigned char* S = wbase + (ks & 1) * 2 * kStr;
-      const f32x4 c0 = q[0] * sa, c2 = q[2] * sa;  // the scale S_a rides on the per-channel constants (exact: a power of two)
+      // this step's per-channel constants from LDS (staged once per tile with S_a already folded in: exact, a power of two)
+      const float* cs = cq + ks * 32;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs), q1 = *reinterpret_cast<const f32x4*>(cs + K), c2 = *reinterpret_cast<const f32x4*>(cs + 2 * K);
+      f32x4 q3 = c2;
+      if constexpr (!FWD) q3 = *reinterpret_cast<const f32x4*>(cs + 3 * K);
 #pragma unroll
-      for (int i = 0; i < AP; ++i) {
+      for (int u = 0; u < G; ++u) {
+        const int i = hf * G + u;
         f32x4 v;
         if constexpr (FWD) {
-          v = c0 * (ra0[i] - q[1]) + c2;
+          v = c0 * (ra0[slot][u] - q1) + c2;
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         } else {
-          v = c0 * (ra0[i] - q[1]) + c2 * (ra1[i] - q[NQ - 1]);
+          v = c0 * (ra0[slot][u] - q1) + c2 * (ra1[slot][u] - q3);
         }
         // the padding rows of a block (RT = 162 of 192) are never stored; as ZEROS they also cost the matrix pipe far less power than
         // copies of real rows would (the chip holds a higher clock on zero operands), and these kernels run at the power limit
         if (!((live >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (kRDbg & 64) {
+          const f32x4 t0 = v;
+          asm volatile("" ::"v"(t0));
+        } else if constexpr (kRDbg & 32) {
+          unsigned char* dst = S + rswz(row0 + 32 * i, chunk);
+          const f32x4 w = ra0[slot][u];
+          *reinterpret_cast<uint2*>(dst) = make_uint2(__float_as_uint(w.x), __float_as_uint(w.y));
+          *reinterpret_cast<uint2*>(dst + APL) = make_uint2(__float_as_uint(w.z), __float_as_uint(w.w));
+        } else
         rsplit_store(v, S + rswz(row0 + 32 * i, chunk), APL);
       }
     };
     // Stage s is consumed between barrier s and barrier s + 1 from slot s & 1; meanwhile the producers write the A planes of stage
-    // s + 1 (from registers whose loads had a whole step) and request the rows of stage s + 2, and the CONSUMERS' LDS-DMAs bring the
-    // weight planes of stage s + 1.  Raw s_barrier: the producers' global loads stay in flight across it.
-    load_a(0);
-    store_a(0);
-    if (nks > 1) load_a(1);
-    __builtin_amdgcn_sched_barrier(0);
-    rbarrier();  // stage 0 is in LDS
-    for (int s = 1; s < nks; ++s) {
-      store_a(s);
-      if (s + 1 < nks) load_a(s + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      rbarrier();  // stage s is in LDS; the consumers are done with stage s - 1
+    // s + 1 and the CONSUMERS' LDS-DMAs bring its weight planes.  Raw s_barrier: the producers' global loads stay in flight across it.
+    static_for<NSLOT>([&](auto dc) {
+      constexpr int d = decltype(dc)::value;
+      if (d < NG) load_g(d / GPS, std::integral_constant<int, d % GPS>{}, dc);
+    });
+    for (int n0 = 0; n0 < NG; n0 += UNR) {
+      static_for<UNR>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        using HF = std::integral_constant<int, d % GPS>;
+        using SL = std::integral_constant<int, d % NSLOT>;
+        const int n = n0 + d;
+        if (n < NG) {
+#if defined(TTK_R_STAMP)
+          TTK_STAMP(st_x);
+#endif
+          conv_g(n / GPS, HF{}, SL{});
+#if defined(TTK_R_STAMP)
+          __builtin_amdgcn_sched_barrier(0);
+          TTK_STAMP(st_y);
+          if (n >= GPS) st_aux += st_y - st_x;
+#endif
+          // (UNR is a multiple of GPS and of NSLOT, so group n + NSLOT has half (d + NSLOT) % GPS and goes to slot d % NSLOT)
+          if (n + NSLOT < NG) load_g((n + NSLOT) / GPS, std::integral_constant<int, (d + NSLOT) % GPS>{}, SL{});
+          if constexpr (d % GPS == GPS - 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            TTK_RB();  // stage n / GPS is in LDS; the consumers are done with the stage before it
+#if defined(TTK_R_STAMP)
+            if (n / GPS == 0) {
+              TTK_STAMP(st_loop0);
+              st_wait = 0;
+            }
+#endif
+          }
+        }
+      });
     }
-    rbarrier();  // the consumers are done with the last stage: the ring is free for the epilogue
+    TTK_RB();  // the consumers are done with the last stage: the ring is free for the epilogue
+#if defined(TTK_R_STAMP)
+    TTK_STAMP(st_loop1);
+#endif
   } else {
     // ---------------- consumers: ds_read_b128 fragments + three piece products per block pair ----------------
+    if constexpr (TTK_R_CPRIO != 0) __builtin_amdgcn_s_setprio(TTK_R_CPRIO);
     const int lane = tid & 63, wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
     constexpr bool HOLD_A = TM <= TN;  // hold the smaller fragment set of a k16 stage in registers, stream the other
@@ -191,7 +493,7 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    f16x8 hold[TH][2], strm[2][2];
+    f16x8 hold[TH][2] = {}, strm[2][2] = {};
     // LDS-DMA of the weight planes: a k32 step is 32 pieces of 1 KB (2 k16 stages x 2 piece planes x 8 pieces of 32 rows x 32 B); consumer
     // wave w moves pieces 4 w .. 4 w + 3 - k16 stage w >> 2, plane (w >> 1) & 1, rows 128 (w & 1) .. + 127 - right after the barrier that
     // freed the slot, and waits for them (its only vector-memory operations) before the barrier that publishes the stage.
@@ -202,6 +504,7 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
     // fragment reads into lgkmcnt(0); M0 = the wave-uniform LDS destination, restored afterwards; the data is waited for by hand)
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     auto dma_b = [&](int ks) {  // weight planes of k32 step ks -> ring slot ks & 1
+      if constexpr (kRDbg & 2) return;
       const uint16_t* sp = bsrc + (int64_t)ks * 2 * Nout * 16;
       const unsigned d = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((ks & 1) * 2 * kStr + bdst));
 #pragma unroll
@@ -215,11 +518,23 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
     };
     dma_b(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    rbarrier();  // stage 0 is in LDS
+    TTK_RB();  // stage 0 is in LDS
+#if defined(TTK_R_STAMP)
+    TTK_STAMP(st_loop0);
+    st_wait = 0;
+#endif
     // Software pipeline of a k32 step (two k16 stages): the stream fragment of block x + 1 is requested before the MFMAs of block x,
     // and the hold fragments of the NEXT k16 stage replace the current ones as soon as the last block's MFMAs have read them - so
     // inside a step no MFMA waits for a read that was issued right before it; only the first fragments after the barrier are exposed.
-    auto rd = [&](const unsigned char* S, int plane_bytes, int off, int p) { return *reinterpret_cast<const f16x8*>(S + p * plane_bytes + off); };
+    auto rd = [&](const unsigned char* S, int plane_bytes, int off, int p) {
+      if constexpr (kRDbg & 128) {
+        f16x8 z = hold[0][0];
+        asm volatile("" : "+v"(z));
+        return z;
+      } else {
+        return *reinterpret_cast<const f16x8*>(S + p * plane_bytes + off);
+      }
+    };
     for (int it = 0; it < nks; ++it) {
       if (it + 1 < nks) dma_b(it + 1);  // slot (it + 1) & 1 was released by the barrier just passed
       const unsigned char* S0 = lds + (it & 1) * 2 * kStr;
@@ -247,13 +562,13 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
           for (int y = 0; y < TH; ++y) {
             // three piece products of one accumulator, smallest first: h_a l_b, l_a h_b, h_a h_b
             if constexpr (HOLD_A) {
-              acc[y][x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hold[y][0], strm[cur][1], acc[y][x], 0, 0, 0);
-              acc[y][x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hold[y][1], strm[cur][0], acc[y][x], 0, 0, 0);
-              acc[y][x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hold[y][0], strm[cur][0], acc[y][x], 0, 0, 0);
+              acc[y][x] = rmfma(hold[y][0], strm[cur][1], acc[y][x]);
+              acc[y][x] = rmfma(hold[y][1], strm[cur][0], acc[y][x]);
+              acc[y][x] = rmfma(hold[y][0], strm[cur][0], acc[y][x]);
             } else {
-              acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(strm[cur][0], hold[y][1], acc[x][y], 0, 0, 0);
-              acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(strm[cur][1], hold[y][0], acc[x][y], 0, 0, 0);
-              acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(strm[cur][0], hold[y][0], acc[x][y], 0, 0, 0);
+              acc[x][y] = rmfma(strm[cur][0], hold[y][1], acc[x][y]);
+              acc[x][y] = rmfma(strm[cur][1], hold[y][0], acc[x][y]);
+              acc[x][y] = rmfma(strm[cur][0], hold[y][0], acc[x][y]);
             }
             if (last && sub == 0) {  // hold fragment y of the second k16 stage, behind its last use in the first
 #pragma unroll
@@ -262,73 +577,366 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
           }
         }
       }
+#if defined(TTK_R_STAMP)
+      TTK_STAMP(st_x);
+#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage it + 1 have landed
-      rbarrier();  // done with stage `it` (its fragments are in registers, its slot may be refilled); stage it + 1 is in LDS
+#if defined(TTK_R_STAMP)
+      TTK_STAMP(st_y);
+      st_aux += st_y - st_x;
+#endif
+      TTK_RB();  // done with stage `it` (its fragments are in registers, its slot may be refilled); stage it + 1 is in LDS
+    }
+#if defined(TTK_R_STAMP)
+    TTK_STAMP(st_loop1);
+#endif
+  }
+#undef TTK_RB
+  r_epilogue<RBLK, MODE, 12, T, TO>(lds, acc, out, E0, bnE, part, M, Nout, m0, m_end, n0, by, sa, sb);
+#if defined(TTK_R_STAMP)
+  {
+    unsigned long long st_t1, st_r1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TTK_STAMP(st_t1);
+    TTK_RSTAMP(st_r1);
+    if ((tid & 63) == 0 && blockIdx.x < 2048) {
+      unsigned long long* d = g_r_stamps + ((size_t)blockIdx.x * 12 + wave) * 8;
+      d[0] = st_loop0 - st_t0; d[1] = st_loop1 - st_loop0; d[2] = st_t1 - st_loop1; d[3] = st_wait; d[4] = st_aux; d[5] = st_r1 - st_r0; d[6] = st_t1 - st_t0;
+      d[7] = st_r0;
     }
   }
-  // ---------------- epilogue, all 12 waves: the tile leaves through LDS in TM chunks of CH rows (block c of every consumer
-  // wave) - un-scale, 16-byte stores (a wave writes 1 KB row segments), the data gradient's ReLU mask, BatchNorm sums ----------------
-  constexpr int LDC = G::LDC, CH = G::CH, QN = kRBN / 4;
-  float* Cs = reinterpret_cast<float*>(lds);
-  float* red = reinterpret_cast<float*>(lds + CH * LDC * 4);  // [12][2][256]
-  // 24 half-waves = 8 channel blocks x 3 row phases; a half-wave = 4 consecutive rows x the 8 quads of ONE channel block: 512 contiguous
-  // bytes of the output (and of the mask operand) per half-wave and instruction in the channel-block layout.  The column quad of a
-  // thread is fixed (its partial sums), its rows are rg, rg + 12, ...
-  const int hw_ = tid >> 5, c4 = (hw_ & 7) * 8 + (tid & 7), rg = (hw_ >> 3) * 4 + ((tid >> 3) & 3);  // 12 row groups
-  const int col = n0 + 4 * c4;
-  const float inv = 1.f / (sa * sb);  // exact: a power of two
-  float4 esc = f4(0.f), emean = f4(0.f), ebeta = f4(0.f);
-  if constexpr (!FWD) {
-    esc = ld4(bnE + TTK_BN_SCALE * Nout + col); emean = ld4(bnE + TTK_BN_MEAN * Nout + col); ebeta = ld4(bnE + TTK_BN_BETA * Nout + col);
-  } else {
-    if (bnE) emean = ld4(bnE + col);  // forward: bnE is the statistics pivot [Nout] (ttk.h), the sums are those of y - pivot
-  }
-  float4 s1 = f4(0.f), s2 = f4(0.f);
-#pragma unroll
-  for (int c = 0; c < TM; ++c) {
-    if (wave < 8) {
-      const int lane = tid & 63, wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) Cs[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * (32 * TN) + j * 32 + r] = acc[c][j][e];
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// pw16m_k (round 4): the same tiles, LDS ring, LDS-DMA weight planes, arithmetic and epilogue as pw16r_k on EIGHT waves that each do
+// both jobs - every wave owns its 32 x 32 blocks of the tile AND converts 1 / 8 of the A rows of the next stage, the conversion cut
+// into RBLK parts that sit between its own MFMAs.
+//
+// Why (profiles/r04_rowblock_stamps.txt, r04_rowblock_gemm_timing_variants.txt): in pw16r_k a SIMD runs two MFMA waves and one
+// producer wave.  With the matrix pipe kept busy by the two, the third wave's vector instructions are issued at about one per MFMA
+// slot (the ~60 instructions of a step's BatchNorm form alone took 2 275 cycles beside the MFMAs, 370 without them; s_setprio
+// changes nothing), so the conversion of a stage stretches over the whole step, the producers reach the barrier last and the MFMA
+// waves wait 700-1 200 cycles per step for them: 3 700 cycles per k32 step against 2 304 of matrix work.  A second set of rows in
+// flight did not help - the rows were there, the instructions were not issued.  Vector instructions of the wave that issues the
+// MFMAs do overlap them (a handful per MFMA), so the conversion moves into the MFMA waves' own streams.
+// ---------------------------------------------------------------------------------------------
+template <int RBLK>
+struct MGeo {
+  using G = RGeo<RBLK>;
+  static constexpr int NW = 8;
+  static constexpr int kEpi = G::CH * G::LDC * 4 + NW * 2 * kRBN * 4;
+  static constexpr int kSmem = G::kRing + G::kCst > kEpi ? G::kRing + G::kCst : kEpi;
+};
+
+template <int RBLK, int MODE, typename T, typename TO>
+__global__ void __launch_bounds__(512) pw16m_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restrict__ bnA,
+                                               const uint16_t* __restrict__ Bq, const float* __restrict__ wmax, TO* __restrict__ out,
+                                               const T* __restrict__ E0, const float* __restrict__ bnE, float* __restrict__ part, int64_t M,
+                                               int K, int Nout, int RT) {
+  using G = RGeo<RBLK>;
+  constexpr int RB = G::RB, WM = G::WM, WN = G::WN, TM = G::TM, TN = G::TN, APL = G::APL, BPL = G::BPL, kStr = G::kStr;
+  constexpr bool FWD = MODE == RMODE_FWD;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[MGeo<RBLK>::kSmem];
+
+  const int tid = threadIdx.x;
+  // XCD-aware tile order (as pw16r_k): the column tiles of one row block run side by side on one L2
+  const unsigned Gd = gridDim.x, Lid = blockIdx.x, NB = Nout / kRBN;
+  const unsigned xq = Gd / 8, xr = Gd % 8, xcd = Lid % 8;
+  const unsigned tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + Lid / 8;
+  const unsigned bx = tile % NB, by = tile / NB;
+  const int64_t m0 = (int64_t)by * RT;
+  const int64_t m_end = m0 + RT < M ? m0 + RT : M;
+  const int n0 = bx * kRBN;
+  const int nks = K / 32;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float sa = pow2_scale(bnA[(size_t)TTK_BN_AUX * K + (FWD ? TTK_AUX_ACT_BOUND : TTK_AUX_DY_BOUND)]);
+  const float sb = pow2_scale(*wmax);
+  f32x16 acc[TM][TN];
+  // per-channel constants of the A operand, once per tile: [scale S_a | mean | beta S_a] (forward), [ga S_a | gmean | gb S_a | mean] (data gradient)
+  float* cst = reinterpret_cast<float*>(lds + G::kRing);
+  {
+    constexpr int NQ = FWD ? 3 : 4;
+    for (int i = tid * 4; i < NQ * K; i += 512 * 4) {
+      const int j = i / K, c = i - j * K;
+      const int row = FWD ? (j == 0 ? TTK_BN_SCALE : (j == 1 ? TTK_BN_MEAN : TTK_BN_BETA)) : (j == 0 ? TTK_BN_GA : (j == 1 ? TTK_BN_GMEAN : (j == 2 ? TTK_BN_GB : TTK_BN_MEAN)));
+      float4 v = ld4(bnA + (size_t)row * K + c);
+      if (j == 0 || j == 2) v = make_float4(v.x * sa, v.y * sa, v.z * sa, v.w * sa);
+      st4(cst + i, v);
     }
-    __syncthreads();  // chunk c is in LDS
-#pragma unroll 2
-    for (int cr = rg; cr < CH; cr += 12) {
-      const int64_t grow = m0 + (cr >> 5) * (32 * TM) + c * 32 + (cr & 31);  // chunk row -> tile row: block c of consumer row cr / 32
-      if (grow >= m_end) continue;
-      float4 v = ld4(Cs + cr * LDC + 4 * c4);
-      v = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
-      const size_t o = act_off(grow, col, M);
-      if constexpr (FWD) {
-        v = Act<TO>::round(v);  // statistics of what is stored
-        Act<TO>::st(out + o, v);
-        v = sub4(v, emean);
-        s1 = add4(s1, v);
-        s2 = fma4(v, v, s2);
+    __syncthreads();
+  }
+
+  // ---- this thread's share of the A operand: 16 bytes (4 channels of the k32 step) of rows row0, row0 + 64, ... ----
+  const int row0 = tid >> 3, kq8 = tid & 7;  // 64 rows per pass; 8 lanes x 16 B = one 128-byte row segment
+  const int sub_ = kq8 >> 2, chunk = (kq8 >> 1) & 1, o8 = (kq8 & 1) * 8;
+  constexpr int AP = RB / 64;                 // row passes per stage
+  constexpr int NA = AP * (FWD ? 1 : 2);      // vector-memory loads per thread and stage
+  f32x4 ra0[2][AP] = {}, ra1[2][FWD ? 1 : AP] = {};
+  unsigned live = 0u;  // bit u: pass u's row lies inside the row block
+#pragma unroll
+  for (int u = 0; u < AP; ++u) live |= (m0 + row0 + 64 * u < m_end ? 1u : 0u) << u;
+  // element offset of pass 0 inside the tile's run of a channel block; rows past the block (pass 0 too: RT may be 32) read row 0 of
+  // the tile and become ZERO fragments (which also cost the matrix pipe less power than copies of real rows would)
+  const unsigned aoff0 = (unsigned)(row0 * kCB + kq8 * 4);
+  const float* cq = cst + kq8 * 4;
+  // LDS destination of pass u in ring slot s: ((row >> 3) & 1 is that of row0: the passes are 64 rows apart)
+  unsigned char* wbase = lds + sub_ * kStr + o8 + rswz(row0, chunk);
+
+  auto load_a = [&](int ks, auto setc) {  // rows of stage ks -> register set
+    constexpr int set = decltype(setc)::value;
+    const __amdgpu_buffer_rsrc_t r0 = rbuf(A0 + ((size_t)ks * act_block_stride(M) + (size_t)m0 * kCB));
+    const __amdgpu_buffer_rsrc_t r1 = rbuf((FWD ? (const T*)nullptr : A1) + ((size_t)ks * act_block_stride(M) + (size_t)m0 * kCB));
+#pragma unroll
+    for (int u = 0; u < AP; ++u) {
+      if constexpr (kRDbg & 1) {
+        f32x4 t0 = ra0[set][u], t1 = ra1[set][FWD ? 0 : u];
+        asm volatile("" : "+v"(t0), "+v"(t1));
+        ra0[set][u] = t0;
+        ra1[set][FWD ? 0 : u] = t1;
       } else {
-        const float4 yc = sub4(Act<T>::ld(E0 + o), emean);
-        v = Act<TO>::round(mask4(v, fma4(esc, yc, ebeta)));
-        Act<TO>::st(out + o, v);
-        s1 = add4(s1, v);
-        s2 = fma4(v, yc, s2);
+        const unsigned o = ((live >> u) & 1u) ? aoff0 + (unsigned)(u * 64 * kCB) : (unsigned)(kq8 * 4);
+        ra0[set][u] = rbuf_ld4<TO>(r0, o);
+        if constexpr (!FWD) ra1[set][u] = rbuf_ld4<T>(r1, o);
       }
     }
-    __syncthreads();  // the row pass is done: the next chunk may be parked
-  }
-  if (part) {  // one row of partial sums per tile: 12 row groups folded in a fixed order
-    st4(red + (rg * 2 + 0) * kRBN + 4 * c4, s1);
-    st4(red + (rg * 2 + 1) * kRBN + 4 * c4, s2);
-    __syncthreads();
-    if (tid < 2 * kRBN) {
-      const int which = tid / kRBN, c = tid % kRBN;
-      float a = 0.f;
+  };
+  // Conversion of one row pass in two parts (a part sits behind every second MFMA triple): part 0 = BatchNorm form + high pieces, part 1
+  // = low pieces + the two ds_write_b64.  `pv`, `ph` carry a pass from part 0 to part 1.
+  f32x4 cc0 = {}, cq1 = {}, cc2 = {}, cq3 = {};  // the stage's per-channel constants (from LDS, S_a folded in)
+  f32x4 pv = {};
+  uint2 ph = make_uint2(0u, 0u);
+  auto conv_consts = [&](int ks) {
+    const float* cs = cq + ks * 32;
+    cc0 = *reinterpret_cast<const f32x4*>(cs); cq1 = *reinterpret_cast<const f32x4*>(cs + K); cc2 = *reinterpret_cast<const f32x4*>(cs + 2 * K);
+    if constexpr (!FWD) cq3 = *reinterpret_cast<const f32x4*>(cs + 3 * K);
+  };
+  int conv_ks = 0;
+  auto conv_part = [&](auto setc, auto slotc, auto ppc) {
+    constexpr int set = decltype(setc)::value, slot = decltype(slotc)::value, pp = decltype(ppc)::value, u = pp >> 1;
+    if constexpr ((pp & 1) == 0) {
+      // (the data gradient re-reads its four constant quads per row pass: held through the step they cost 16 registers and the
+      // kernel spilled inside its loop)
+      if constexpr (!FWD) conv_consts(conv_ks);
+      f32x4 v;
+      if constexpr (FWD) {
+        v = cc0 * (ra0[set][u] - cq1) + cc2;
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      } else {
+        v = cc0 * (ra0[set][u] - cq1) + cc2 * (ra1[set][u] - cq3);
+      }
+      if (m0 + 64 * u + 63 >= m_end) {  // (uniform: only the pass that holds the end of the row block masks its rows)
+        if (!((live >> u) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      const f16x2 h01 = __builtin_convertvector(f32x2{v.x, v.y}, f16x2), h23 = __builtin_convertvector(f32x2{v.z, v.w}, f16x2);
+      pv = v;
+      ph = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+    } else {
+#if TTK_M_MIX
+      const unsigned l01 = rlow2(ph.x, pv.x, pv.y), l23 = rlow2(ph.y, pv.z, pv.w);
+#else
+      const f32x2 f01 = __builtin_convertvector(__builtin_bit_cast(f16x2, ph.x), f32x2), f23 = __builtin_convertvector(__builtin_bit_cast(f16x2, ph.y), f32x2);
+      const unsigned l01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{pv.x - f01.x, pv.y - f01.y}, f16x2));
+      const unsigned l23 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{pv.z - f23.x, pv.w - f23.y}, f16x2));
+#endif
+      unsigned char* dst = wbase + slot * 2 * kStr + u * 64 * 32;
+      if constexpr (!(kRDbg & 64)) {
+        *reinterpret_cast<uint2*>(dst) = ph;
+        *reinterpret_cast<uint2*>(dst + APL) = make_uint2(l01, l23);
+      } else {
+        asm volatile("" ::"v"(l01), "v"(l23));
+      }
+    }
+  };
+
+  // ---- this wave's blocks of the tile ----
+  const int lane = tid & 63, wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  constexpr bool HOLD_A = TM <= TN;  // hold the smaller fragment set of a k16 stage in registers, stream the other
+  constexpr int TH = HOLD_A ? TM : TN, TS = HOLD_A ? TN : TM;
+  constexpr int HPL = HOLD_A ? APL : BPL, SPL = HOLD_A ? BPL : APL;
+  static_assert(2 * TS * TH == 2 * RBLK && 2 * AP == RBLK, "one conversion part behind every second MFMA triple");
+  int hold_off[TH], strm_off[TS];
 #pragma unroll
-      for (int qq = 0; qq < 12; ++qq) a += red[(qq * 2 + which) * kRBN + c];
-      part[(size_t)by * 2 * Nout + (size_t)which * Nout + n0 + c] = a;
+  for (int x = 0; x < TH; ++x) hold_off[x] = HOLD_A ? rswz(wm * (32 * TM) + x * 32 + r, h) : 2 * APL + rswz(wn * (32 * TN) + x * 32 + r, h);
+#pragma unroll
+  for (int x = 0; x < TS; ++x) strm_off[x] = HOLD_A ? 2 * APL + rswz(wn * (32 * TN) + x * 32 + r, h) : rswz(wm * (32 * TM) + x * 32 + r, h);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  f16x8 hold[TH][2] = {}, strm[2][2] = {};
+  // LDS-DMA of the weight planes (as pw16r_k): wave w moves pieces 4 w .. 4 w + 3 of a k32 step - k16 stage w >> 2, plane (w >> 1) & 1,
+  // rows 128 (w & 1) .. + 127 - right after the barrier that freed the slot, and waits for them before the barrier that publishes it.
+  const int64_t bplane = (int64_t)K * Nout;
+  const uint16_t* bsrc = Bq + ((wave >> 1) & 1) * bplane + ((int64_t)(wave >> 2) * Nout + n0 + (wave & 1) * 128) * 16 + lane * 8;
+  const int bdst = (wave >> 2) * kStr + 2 * APL + ((wave >> 1) & 1) * BPL + (wave & 1) * 4096;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  auto dma_b = [&](int ks, int slot) {  // weight planes of k32 step ks -> ring slot
+    if constexpr (kRDbg & 2) return;
+    const uint16_t* sp = bsrc + (int64_t)ks * 2 * Nout * 16;
+    const unsigned d = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * 2 * kStr + bdst));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(sp + j * 512), "s"(d + j * 1024)
+                   : "memory");
+    }
+  };
+  auto rd = [&](const unsigned char* S, int plane_bytes, int off, int p) {
+    if constexpr (kRDbg & 128) {
+      f16x8 z = hold[0][0];
+      asm volatile("" : "+v"(z));
+      return z;
+    } else {
+      return *reinterpret_cast<const f16x8*>(S + p * plane_bytes + off);
+    }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+
+#if defined(TTK_R_STAMP)
+  unsigned long long st_t0, st_r0, st_wait = 0, st_aux = 0, st_loop0 = 0, st_loop1 = 0, st_x, st_y;
+  TTK_STAMP(st_t0);
+  TTK_RSTAMP(st_r0);
+#define TTK_RB() rbarrier_s(st_wait)
+#else
+#define TTK_RB() rbarrier()
+#endif
+  // ---- prologue: stage 0 into ring slot 0 (nothing to hide it under), the rows of stages 1 and 2 requested ----
+  load_a(0, P0{});
+  if (nks > 1) load_a(1, P1{});
+  dma_b(0, 0);
+  conv_consts(0);
+  conv_ks = 0;
+  static_for<RBLK>([&](auto ppc) { conv_part(P0{}, P0{}, ppc); });
+  if (nks > 2) {
+    load_a(2, P0{});
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");  // everything older than the rows of stage 2: the pieces of stage 0 have landed
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  TTK_RB();  // stage 0 is in LDS
+#if defined(TTK_R_STAMP)
+  TTK_STAMP(st_loop0);
+  st_wait = 0;
+#endif
+
+  // One k32 step: MFMAs on stage `it` (ring slot PAR = it & 1) with, when CONV, the conversion of stage it + 1 (register set and ring
+  // slot PAR ^ 1) between them; then the rows of stage it + 3 are requested into the set just freed.  Vector-memory order of a step:
+  // [4 LDS-DMA pieces of stage it + 1] ... [NA rows of stage it + 3], so "all but the NA youngest" = the pieces have landed.
+  auto step = [&](int it, auto parc, auto convc) {
+    constexpr int PAR = decltype(parc)::value;
+    constexpr bool CONV = decltype(convc)::value != 0;
+    using SN = std::integral_constant<int, PAR ^ 1>;
+    const unsigned char* S0 = lds + PAR * 2 * kStr;
+    if constexpr (CONV) {
+      dma_b(it + 1, PAR ^ 1);  // that slot was released by the barrier just passed
+      conv_ks = it + 1;
+      if constexpr (FWD) conv_consts(it + 1);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int y = 0; y < TH; ++y) hold[y][p] = rd(S0, HPL, hold_off[y], p);
+      strm[0][p] = rd(S0, SPL, strm_off[0], p);
+    }
+    // software pipeline of the fragment reads as in pw16r_k: the stream fragment of block x + 1 is requested before the MFMAs of
+    // block x, the hold fragments of the second k16 stage replace the first's behind their last use
+    static_for<2>([&](auto subc) {
+      constexpr int sub = decltype(subc)::value;
+      const unsigned char* S = S0 + sub * kStr;
+      static_for<TS>([&](auto xc) {
+        constexpr int x = decltype(xc)::value;
+        constexpr int cur = (sub * TS + x) & 1;
+        constexpr bool last = x + 1 == TS;
+        if constexpr (!last) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) strm[cur ^ 1][p] = rd(S, SPL, strm_off[x + 1], p);
+        } else if constexpr (sub == 0) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) strm[cur ^ 1][p] = rd(S + kStr, SPL, strm_off[0], p);
+        }
+        static_for<TH>([&](auto yc) {
+          constexpr int y = decltype(yc)::value;
+          // three piece products of one accumulator, smallest first: h_a l_b, l_a h_b, h_a h_b
+          if constexpr (HOLD_A) {
+            acc[y][x] = rmfma(hold[y][0], strm[cur][1], acc[y][x]);
+            acc[y][x] = rmfma(hold[y][1], strm[cur][0], acc[y][x]);
+            acc[y][x] = rmfma(hold[y][0], strm[cur][0], acc[y][x]);
+          } else {
+            acc[x][y] = rmfma(strm[cur][0], hold[y][1], acc[x][y]);
+            acc[x][y] = rmfma(strm[cur][1], hold[y][0], acc[x][y]);
+            acc[x][y] = rmfma(strm[cur][0], hold[y][0], acc[x][y]);
+          }
+          if constexpr (last && sub == 0) {  // hold fragment y of the second k16 stage, behind its last use in the first
+#pragma unroll
+            for (int p = 0; p < 2; ++p) hold[y][p] = rd(S + kStr, HPL, hold_off[y], p);
+          }
+          constexpr int q = (sub * TS + x) * TH + y;  // MFMA triple of the step
+          if constexpr (CONV && (q & 1) == 1) {
+            conv_part(SN{}, SN{}, std::integral_constant<int, (q >> 1)>{});
+#if TTK_M_FENCE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+          }
+        });
+      });
+    });
+#if defined(TTK_R_STAMP)
+    TTK_STAMP(st_x);
+#endif
+    if constexpr (CONV) {
+      if (it + 3 < nks) {
+        load_a(it + 3, SN{});
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");  // the pieces of stage it + 1 have landed
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+#if defined(TTK_R_STAMP)
+    TTK_STAMP(st_y);
+    st_aux += st_y - st_x;
+#endif
+    TTK_RB();  // done with stage `it` (its fragments are in registers, its slot may be refilled); stage it + 1 is in LDS
+  };
+  // (one loop body of two converting steps and a tail: with the step variants inside the loop hipcc kept two copies of the accumulators)
+  int it = 0;
+  for (; it + 2 < nks; it += 2) {
+    step(it, P0{}, P1{});
+    step(it + 1, P1{}, P1{});
+  }
+  if (it + 1 < nks) {
+    step(it, P0{}, P1{});
+    step(it + 1, P1{}, P0{});
+  } else {
+    step(it, P0{}, P0{});
+  }
+#if defined(TTK_R_STAMP)
+  TTK_STAMP(st_loop1);
+#endif
+#undef TTK_RB
+  r_epilogue<RBLK, MODE, 8, T, TO>(lds, acc, out, E0, bnE, part, M, Nout, m0, m_end, n0, by, sa, sb);
+#if defined(TTK_R_STAMP)
+  {
+    unsigned long long st_t1, st_r1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TTK_STAMP(st_t1);
+    TTK_RSTAMP(st_r1);
+    if ((tid & 63) == 0 && blockIdx.x < 2048) {
+      unsigned long long* d = g_r_stamps + ((size_t)blockIdx.x * 12 + wave) * 8;
+      d[0] = st_loop0 - st_t0; d[1] = st_loop1 - st_loop0; d[2] = st_t1 - st_loop1; d[3] = st_wait; d[4] = st_aux; d[5] = st_r1 - st_r0; d[6] = st_t1 - st_t0;
+      d[7] = st_r0;
+      if (wave == 0)  // (the stamp reader expects twelve waves: rows 8..11 repeat wave 0)
+        for (int w = 8; w < 12; ++w)
+          for (int i = 0; i < 8; ++i) g_r_stamps[((size_t)blockIdx.x * 12 + w) * 8 + i] = d[i];
     }
   }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -754,7 +1362,7 @@ bool f16r_enabled() {
 // Shapes [M][K] x [K][Nout] that run here.  The data gradient of the 256 -> 256 layer (K = Nout = 256, M = 147 968 at B = 512) is the one
 // measured slower than pw16_k's 128 x 256 tiles (147 vs 134 us: it is HBM-bound, and 193-row blocks only add epilogue time there).
 bool f16r_gemm_shape(int K, int Nout, int dgrad) {
-  if (!f16r_enabled() || K < 128 || K % 32 != 0 || Nout < 256 || Nout % kRBN != 0) return false;
+  if (!f16r_enabled() || K < 128 || K > 1024 || K % 32 != 0 || Nout < 256 || Nout % kRBN != 0) return false;
   return !(dgrad && K == 256 && Nout == 256) || getenv("TTK_R_ALL") != nullptr;
 }
 
@@ -829,12 +1437,21 @@ bool launch_f16r_gemm(const TO* A0, const T* A1, const float* bnA, const float* 
   }
   const RPlan pl = r_plan(M, K, Nout);
   const unsigned tiles = (unsigned)pl.row_blocks * (Nout / kRBN);
+#define TTK_M_LAUNCH(RBLK_) \
+  hipLaunchKernelGGL((pw16m_k<RBLK_, MODE, T, TO>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout, pl.rt)
 #define TTK_R_LAUNCH(RBLK_) \
   hipLaunchKernelGGL((pw16r_k<RBLK_, MODE, T, TO>), dim3(tiles), dim3(768), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout, pl.rt)
-  if (pl.rblk == 4) TTK_R_LAUNCH(4);
+  // Which form runs what, from same-box runs of the whole step (profiles/r04_rowblock_gemm_variants.txt): the eight-wave form takes the
+  // data gradient (two tensors to convert per element: 0.617 vs 0.644 ms per step), the twelve-wave form keeps the forward (0.478 vs
+  // 0.485) and the 256-row tiles (128 accumulator registers + two sets of rows do not fit the eight-wave form's 256).
+  const bool merged = TTK_R_MERGED == 2 || (TTK_R_MERGED == 1 && MODE == RMODE_DGRAD);
+  if (merged && pl.rblk == 4) TTK_M_LAUNCH(4);
+  else if (merged && pl.rblk == 6) TTK_M_LAUNCH(6);
+  else if (pl.rblk == 4) TTK_R_LAUNCH(4);
   else if (pl.rblk == 6) TTK_R_LAUNCH(6);
   else TTK_R_LAUNCH(8);
 #undef TTK_R_LAUNCH
+#undef TTK_M_LAUNCH
   return true;
 }
 
@@ -850,3 +1467,13 @@ template bool launch_f16r_gemm<RMODE_DGRAD, bf16_t, float>(const float*, const b
 #undef TTK_RINST
 
 }  // namespace ttk
+
+#if defined(TTK_R_STAMP)
+extern "C" int ttk_debug_read_r_stamps(void* host_dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ttk::g_r_stamps), bytes < sizeof(ttk::g_r_stamps) ? bytes : sizeof(ttk::g_r_stamps));
+}
+#endif
+
+#if TTK_M_NOPK && defined(__HIP_DEVICE_COMPILE__)
+#pragma clang attribute pop
+#endif
