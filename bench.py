@@ -16,6 +16,7 @@ configs 3 and 2 the same way.  Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -76,7 +77,8 @@ class KernelTimer:
     @staticmethod
     def work(name, a):
         """(kernel name as rocprofv3 prints it, flops, algorithmic bytes) of one call; fp32 = 4 B/element.
-        Mirrors the dispatch rules of csrc/pwconv.hip + pwconv_split.hip + dwconv_tiled.hip."""
+        Mirrors the dispatch rules of csrc/pwconv.hip + pwconv_f16.hip + pwconv_r.hip + dwconv_tiled.hip (the A/B environment switches
+        mentioned below exist in experiment builds of the library only)."""
         ints = [x for x in a if isinstance(x, int) and not isinstance(x, bool)]
         eb = KernelTimer.act_bytes
         if name == "ttk_pwconv1x1_bwd_fused":  # first two pointwise layers: weight + data gradient, operands read once (HBM-bound)
@@ -107,9 +109,11 @@ class KernelTimer:
             if K >= 128 and N % 256 == 0:
                 if os.environ.get("TTK_GEMM_R", "1") != "0" and os.environ.get("TTK_GEMM") in (None, "", "f16x2") and not (mode == 1 and K == 256 and N == 256):
                     # row-block kernel (csrc/pwconv_r.hip: f16r_gemm_shape, r_plan): one partial-sum row per row block of rt rows, tile = 32 rblk rows
+                    # (round 4: the data gradient's 128- and 192-row tiles run the eight-wave form pw16m_k)
                     import trackertraincode._hip as H
-                    rt = -(-M // H.lib().partial_rows_gemm(M, K, N, bool(mode)))
-                    return f"pw16r_k<{4 if rt <= 128 else 6 if rt <= 192 else 8}, {mode}, {'float' if eb == 4 else 'unsigned short'}>", fl, by
+                    rblk = H.lib().cdll.ttk_pwconv_tile_rows(M, K, N, mode) // 32
+                    kern = "pw16m_k" if (mode == 1 and rblk in (4, 6)) else "pw16r_k"
+                    return f"{kern}<{rblk}, {mode}, {'float' if eb == 4 else 'unsigned short'}>", fl, by
                 return f"pw16_k<128, 256, {mode}, {mode}, 1, {'float' if eb == 4 else 'unsigned short'}>", fl, by  # <BM, BN, A form, epilogue form, register sets, storage>
             if K >= 64 and N == 128:
                 return f"pw16_k<256, 128, {mode}, {mode}, 1, {'float' if eb == 4 else 'unsigned short'}>", fl, by
@@ -451,7 +455,21 @@ def main():
             # roofline pass.  Depthwise kernels are HBM-bound; pw_split_k runs 6 bf16 MFMA products per fp32 product,
             # so its fp32-equivalent ceiling is the dense bf16 peak / 6; pw_gemm_k / pw_wgrad_k (the early, HBM-bound
             # pointwise layers) are fp32 MFMA kernels priced against HBM.
-            traffic = json.load(open(args.traffic_json))["kernels"] if args.traffic_json else {}
+            # counter traffic: --traffic-json, else the newest profiles/r*_pmc_traffic.json whose csrc_sha256 stamp (tools/build_id.py)
+            # equals this tree's - counters of another build are never attached
+            traffic, traffic_src = {}, None
+            cands = [args.traffic_json] if args.traffic_json else sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True)
+            sys.path.insert(0, os.path.join(REPO, "tools"))
+            from build_id import csrc_sha256
+            tree = csrc_sha256()
+            for c in cands:
+                try:
+                    d = json.load(open(c))
+                except (OSError, ValueError):
+                    continue
+                if d.get("csrc_sha256") == tree or (args.traffic_json and "csrc_sha256" not in d):
+                    traffic, traffic_src = d["kernels"], os.path.relpath(c, REPO)
+                    break
 
             def roofline_of(k):
                 v = ks[k]
@@ -473,7 +491,7 @@ def main():
             roof = roofline_of(order[0])
             roof["peak_note"] = ("HBM3E spec 8 TB/s (6.3 TB/s achievable per the MI355X guide)" if roof["bound"] == "hbm"
                                  else "fp32-equivalent: 2500 TF dense 16-bit MFMA / piece products per fp32 product (3: fp16 x 2 split, 6: bf16 x 3 split)")
-            roof["traffic_source"] = (args.traffic_json + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build)") if args.traffic_json else None
+            roof["traffic_source"] = (traffic_src + f" (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; csrc_sha256 {tree[:16]} = this build)") if traffic_src else None
             roof["pass"] = f"{roof_steps} extra steps after the timed region, HIP events around each conv call, single stream"
             top5 = [roofline_of(k) for k in order[:6]]
         dominant = roof["kernel"] if roof else None

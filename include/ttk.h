@@ -49,7 +49,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 18
+#define TTK_ABI_VERSION 19
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -104,6 +104,9 @@ int ttk_partial_rows_gemm(int64_t M);                 /* MFMA kernels with 128-r
 /* rows of partial sums ttk_pwconv1x1_fwd (K = Cin, Nout = Cout, dgrad = 0) / ttk_pwconv1x1_bwd_data (K = Cout, Nout = Cin, dgrad = 1) write
  * for M rows: one per row block of the kernel that runs the shape - ceil(M/128), or the row-block tiling of csrc/pwconv_r.hip */
 int ttk_partial_rows_pwconv(int64_t M, int K, int Nout, int dgrad);
+/* rows of the MFMA tile that runs the shape: 128, 192 or 256 for the row-block kernels of csrc/pwconv_r.hip (chosen per (M, K, Nout) by their
+ * cost model so that the tiles fill whole rounds of the CUs), 0 for every other kernel.  ABI 19; a query for tests and tools. */
+int ttk_pwconv_tile_rows(int64_t M, int K, int Nout, int dgrad);
 
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm2d statistics - replaces F.batch_norm(training=True, momentum, eps) as called through

@@ -34,7 +34,7 @@ struct ConvGeom {
 enum { GEMM_F16X2 = 0, GEMM_BF16X3 = 1, GEMM_F32 = 2 };
 inline int gemm_mode() {
   static const int mode = [] {
-    const char* e = getenv("TTK_GEMM");
+    const char* e = exp_env("TTK_GEMM");
     if (e && strcmp(e, "f32mfma") == 0) return (int)GEMM_F32;
     if (e && strcmp(e, "bf16x3") == 0)
       fprintf(stderr, "libttk_hip: TTK_GEMM=bf16x3 (round 1's six-product bf16 split, csrc/pwconv_split.hip) was removed in round 3 - it is in the "
@@ -70,5 +70,6 @@ __host__ __device__ inline int64_t r_plane_index(int row, int k, int rows) {
 }
 bool f16r_gemm_shape(int K, int Nout, int dgrad);
 int f16r_partial_rows(int64_t M, int K, int Nout, int dgrad);
+int f16r_tile_rows(int64_t M, int K, int Nout, int dgrad);
 
 }  // namespace ttk

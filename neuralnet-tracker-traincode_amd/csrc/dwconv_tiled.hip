@@ -67,7 +67,7 @@ inline DwTiling dw_tiling_sl(int B, int H, int W, int C, int stride, bool backwa
   t.SL = SL;
   t.NCT = 1;
   t.TW = Wo;
-  static const int col_tile = [] { const char* e = getenv("TTK_DW_COLTILE"); return e ? atoi(e) : kColTile; }();  // (experiments)
+  static const int col_tile = [] { const char* e = exp_env("TTK_DW_COLTILE"); return e ? atoi(e) : kColTile; }();  // (experiments)
   if (stride == 1 && W >= kColTileMinW && col_tile < W) {
     t.NCT = (W + col_tile - 1) / col_tile;
     t.TW = (W + t.NCT - 1) / t.NCT;

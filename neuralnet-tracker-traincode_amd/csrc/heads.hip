@@ -346,7 +346,7 @@ int ttk_heads_bwd(const float* feat, const float* wcat, const float* z, const in
   hipLaunchKernelGGL(heads_bwd_feat_k, dim3((unsigned)ceil_div(nf > nw ? nf : nw, kBlock)), dim3(kBlock), 0, st, dz, wcat, dfeat, dwcat, dbcat, B, F,
                      NZ);
   // TTK_DETERMINISTIC=1: one chunk of samples per weight instead of B/64 chunks that add atomically (fixed summation order)
-  static const bool det = [] { const char* e = getenv("TTK_DETERMINISTIC"); return e && e[0] != '0'; }();
+  const bool det = deterministic_mode();
   hipLaunchKernelGGL(heads_bwd_weight_k, dim3((unsigned)ceil_div(nw, kBlock), det ? 1u : (unsigned)ceil_div(B, 64)), dim3(kBlock), 0, st, dz,
                      feat, dwcat, dbcat, B, F, NZ);
   if (use_offset && (dP || dPk)) hipLaunchKernelGGL(heads_bwd_offset_k, dim3(64), dim3(kBlock), 0, st, dprow, ids, dP, dPk, B);

@@ -531,7 +531,7 @@ pw_bwd_fused16_k(const float* __restrict__ g, const float* __restrict__ y, const
 
 // 128 -> 128 always runs on the fp16 pipe; 64 -> 128 too when the prepared block holds fp16 planes (default TTK_GEMM mode), else
 // on fp32 MFMA from the raw weights
-static bool fused_f16(int Cin) { return Cin == 128 || (Cin == 64 && gemm_mode() == GEMM_F16X2 && !getenv("TTK_FUSED_FP32")); }
+static bool fused_f16(int Cin) { return Cin == 128 || (Cin == 64 && gemm_mode() == GEMM_F16X2 && !exp_env("TTK_FUSED_FP32")); }
 static bool fused_shape(int Cin, int Cout) {
   // (the 128 -> 128 form reads the fp16 planes of the prepared weight block: default TTK_GEMM mode only)
   return (Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 128) || (Cin == 128 && Cout == 128 && gemm_mode() == GEMM_F16X2);

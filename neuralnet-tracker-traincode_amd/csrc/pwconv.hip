@@ -534,6 +534,7 @@ int ttk_partial_rows_pwconv(int64_t M, int K, int Nout, int dgrad) {
   const int r = f16r_partial_rows(M, K, Nout, dgrad);
   return r ? r : (int)ceil_div(M, BM);
 }
+int ttk_pwconv_tile_rows(int64_t M, int K, int Nout, int dgrad) { return f16r_tile_rows(M, K, Nout, dgrad); }
 
 int ttk_pwconv1x1_fwd(const void* ydw, const float* bn_dw, const float* w, void* y, float* part, const float* pivot, int64_t M, int Cin,
                       int Cout, void* wsplit, int act_bf16, ttk_stream_t stream) {

@@ -983,10 +983,6 @@ static void conv_wgrad_plan(int64_t M, int Cout, int ncols, int& tiles, int64_t&
   tiles = (int)(ceil_div(Cout, Cout <= 64 ? 64 : 128) * ceil_div(ncols, conv_wgrad_bn(Cout, ncols)));
   wgrad_slices(M, tiles, slices, rows, conv_wgrad_bn(Cout, ncols) == 192 ? 512 : 256);  // 64x192 tiles: two workgroups per CU
 }
-static bool deterministic_mode() {
-  static const bool det = [] { const char* e = getenv("TTK_DETERMINISTIC"); return e && e[0] != '0'; }();
-  return det;
-}
 size_t conv_wgrad16_partial_bytes(int64_t M, int Cout, int ncols, int taps) {
   // 1x1: the atomics are coalesced ([co][ci] = the GEMM's layout) and measured faster than the fold - unless a fixed summation
   // order is asked for (TTK_DETERMINISTIC=1)
@@ -1066,7 +1062,7 @@ bool launch_conv_gemm16(int amode, int emode, const float* A0, const float* A1, 
     return true;                                                   \
   } while (0)
   if (Nout % 64 != 0 || geo.Kc % 32 != 0) return false;
-  static const bool narrow = !getenv("TTK_CONV_WIDE64");  // 64 output channels: 128x64 tiles, two workgroups per CU (default) | 256x64
+  static const bool narrow = !exp_env("TTK_CONV_WIDE64");  // 64 output channels: 128x64 tiles, two workgroups per CU (default) | 256x64
   if (amode == AMODE_PLAIN && emode == EMODE_STATS) TTK_CONV_TILES(AMODE_PLAIN, EMODE_STATS);
   if (amode == AMODE_BNGRAD && emode == EMODE_MASK) TTK_CONV_TILES(AMODE_BNGRAD, EMODE_MASK);
   if (amode == AMODE_BNGRAD && emode == EMODE_PLAIN) TTK_CONV_TILES(AMODE_BNGRAD, EMODE_PLAIN);

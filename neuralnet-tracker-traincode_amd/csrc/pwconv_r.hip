@@ -979,6 +979,7 @@ __device__ __forceinline__ void tsplit_store(f32x4 v, unsigned char* dst) {  // 
   *reinterpret_cast<uint2*>(dst + kTPlane) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
 }
 
+#if defined(TTK_EXPERIMENTS)  // (pw16t_wgrad_k is selectable by TTK_WGRAD_T=t only: ahead of pw16u_wgrad_k on no shape but 1024 x 1024, and there by 5 %)
 // G, Y: [M][Cout] (gradient w.r.t. the BatchNorm output, raw conv output), X: [M][Cin] (raw depthwise output); partial[slice][Cout][Cin]
 template <typename T, typename TG>
 __global__ void __launch_bounds__(768) pw16t_wgrad_k(const TG* __restrict__ G, const T* __restrict__ Y, const float* __restrict__ bn_pw,
@@ -1117,6 +1118,8 @@ __global__ void __launch_bounds__(768) pw16t_wgrad_k(const TG* __restrict__ G, c
         }
   }
 }
+
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // The same weight gradient with the roles turned round: 128 (Cout) x 256 (Cin) tiles, FOUR consumer waves (64 x 128 each, one per
@@ -1306,7 +1309,7 @@ __global__ void __launch_bounds__(256) wgrad_fold_k(const float* __restrict__ pa
 // TTK_WGRAD_T: 0 = neither transposed-read kernel; t = pw16t_wgrad_k (256 x 256 tiles) where its tile divides the shape;
 // u (default) = pw16u_wgrad_k (128 x 256 tiles, eight producer waves) where its tile divides the shape
 static int t_wgrad_mode() {
-  static const int mode = [] { const char* e = getenv("TTK_WGRAD_T"); return !e ? 2 : (e[0] == '0' ? 0 : (e[0] == 't' ? 1 : 2)); }();
+  static const int mode = [] { const char* e = exp_env("TTK_WGRAD_T"); return !e ? 2 : (e[0] == '0' ? 0 : (e[0] == 't' ? 1 : 2)); }();
   return mode;
 }
 static bool t_wgrad_wide(int Cin, int Cout) { return t_wgrad_mode() == 1 && Cin % 256 == 0 && Cout % 256 == 0; }
@@ -1340,9 +1343,11 @@ bool launch_f16t_wgrad(const TG* g, const T* y, const float* bn_pw, const T* ydw
   int tiles;
   int64_t slices, rows;
   t_wgrad_plan(M, Cin, Cout, tiles, slices, rows);
+#if defined(TTK_EXPERIMENTS)
   if (t_wgrad_wide(Cin, Cout))
     hipLaunchKernelGGL((pw16t_wgrad_k<T, TG>), dim3((unsigned)(tiles * slices)), dim3(768), 0, st, g, y, bn_pw, ydw, bn_dw, partial, M, Cin, Cout, rows);
   else
+#endif
     hipLaunchKernelGGL((pw16u_wgrad_k<T, TG>), dim3((unsigned)(tiles * slices)), dim3(768), 0, st, g, y, bn_pw, ydw, bn_dw, partial, M, Cin, Cout, rows);
   const int64_t n = (int64_t)Cin * Cout;
   hipLaunchKernelGGL(wgrad_fold_k, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, st, partial, dw, n, (int)slices);
@@ -1356,14 +1361,14 @@ template bool launch_f16t_wgrad<bf16_t, float>(const float*, const bf16_t*, cons
 
 // ---- tiling: row blocks of RT rows such that the tiles fill whole rounds of the CUs ------------------------------------------
 bool f16r_enabled() {
-  static const bool on = [] { const char* e = getenv("TTK_GEMM_R"); return !(e && e[0] == '0'); }();
+  static const bool on = [] { const char* e = exp_env("TTK_GEMM_R"); return !(e && e[0] == '0'); }();
   return on && gemm_mode() == GEMM_F16X2;
 }
 // Shapes [M][K] x [K][Nout] that run here.  The data gradient of the 256 -> 256 layer (K = Nout = 256, M = 147 968 at B = 512) is the one
 // measured slower than pw16_k's 128 x 256 tiles (147 vs 134 us: it is HBM-bound, and 193-row blocks only add epilogue time there).
 bool f16r_gemm_shape(int K, int Nout, int dgrad) {
   if (!f16r_enabled() || K < 128 || K > 1024 || K % 32 != 0 || Nout < 256 || Nout % kRBN != 0) return false;
-  return !(dgrad && K == 256 && Nout == 256) || getenv("TTK_R_ALL") != nullptr;
+  return !(dgrad && K == 256 && Nout == 256) || exp_env("TTK_R_ALL") != nullptr;
 }
 
 struct RPlan { int rblk, rt, row_blocks; };
@@ -1371,8 +1376,9 @@ struct RPlan { int rblk, rt, row_blocks; };
 // and the time its bytes take through the CU (A rows from HBM at ~12 B/clk, 32 KB of weight planes from L2 at ~35 B/clk); the
 // epilogue writes (and, for the data gradient, reads) RT x 256 floats.
 static RPlan r_plan(int64_t M, int K, int Nout) {
-  const char* fe = getenv("TTK_R_RBLK");  // 4 | 6 | 8: force the tile's row blocks (tests, A/B timing); read per call
-  const int force = fe ? atoi(fe) : 0;
+  const char* fe = exp_env("TTK_R_RBLK");  // experiment builds: 4 | 6 | 8 forces the tile's row blocks (anything else is ignored)
+  int force = fe ? atoi(fe) : 0;
+  if (force != 4 && force != 6 && force != 8) force = 0;
   static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
   const int ct = Nout / kRBN, steps = K / 32;
   RPlan best{0, 0, 0};
@@ -1394,9 +1400,14 @@ static RPlan r_plan(int64_t M, int K, int Nout) {
       break;  // more rounds of smaller tiles only add per-tile overhead
     }
   }
+  if (best.rblk == 0) {  // (M beyond 4 096 rounds of full tiles: full-height tiles, as many rounds as it takes - never an empty grid)
+    const int rblk = force ? force : 8;
+    best = RPlan{rblk, 32 * rblk, (int)ceil_div(M, 32 * rblk)};
+  }
   return best;
 }
 int f16r_partial_rows(int64_t M, int K, int Nout, int dgrad) { return f16r_gemm_shape(K, Nout, dgrad) ? r_plan(M, K, Nout).row_blocks : 0; }
+int f16r_tile_rows(int64_t M, int K, int Nout, int dgrad) { return f16r_gemm_shape(K, Nout, dgrad) ? 32 * r_plan(M, K, Nout).rblk : 0; }
 
 // w[rows][K] fp32 -> two fp16 planes [K/16][rows][16] (16-byte chunks of a row swapped where (row >> 3) & 1) of w * pow2_scale(*wmax)
 __global__ void w16r_split_k(const float* __restrict__ w, uint16_t* __restrict__ q, const float* __restrict__ wmax, int rows, int K) {

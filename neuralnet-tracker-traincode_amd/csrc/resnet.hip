@@ -576,7 +576,7 @@ int ttk_stem7_fwd(const float* x, const float* w, float* y, float* part, const f
   const int prows = (PR + 8) / 9 * 9;               // staged in rounds of 9
   const int wave_floats = prows * kS7Wp > 32 * (kS7C + 4) ? prows * kS7Wp : 32 * (kS7C + 4);
   const size_t smem = (size_t)(kBlock / kWave) * wave_floats * sizeof(float);
-  static const bool valu = getenv("TTK_STEM7_VALU") != nullptr;  // the previous kernel (A/B timing)
+  static const bool valu = exp_env("TTK_STEM7_VALU") != nullptr;  // the previous kernel (A/B timing)
   if (!valu && smem <= 60 * 1024 && W + 7 <= kS7Wp && (int64_t)B * ((Ho * Wo + 31) / 32) < ((int64_t)1 << 30))
     hipLaunchKernelGGL(stem7_fwd_mfma_k, dim3(elementwise_grid(items)), dim3(kBlock), smem, (hipStream_t)stream, x, w, y, part, pivot, B, H, W,
                        Ho, Wo, PR, wave_floats);
@@ -602,7 +602,7 @@ int ttk_stem7_bwd_weight(const float* g, const float* y, const float* bn, const 
   size_t smem = (size_t)(kBlock / kWave) * wave_floats * sizeof(float);
   const size_t red_bytes = (size_t)(kBlock / kWave) * kS7C * kS7K * kS7K * sizeof(float);
   if (smem < red_bytes) smem = red_bytes;
-  static const bool valu = getenv("TTK_STEM7_VALU") != nullptr;  // the previous kernels (A/B timing)
+  static const bool valu = exp_env("TTK_STEM7_VALU") != nullptr;  // the previous kernels (A/B timing)
   if (!valu && smem <= 64 * 1024 && W + 7 <= 192 && (int64_t)B * ((Ho * Wo + 31) / 32) < ((int64_t)1 << 30)) {
     const int grid = stem_wgrad_grid(B, Ho);
     hipLaunchKernelGGL(stem7_wgrad_mfma_k, dim3(grid), dim3(kBlock), smem, (hipStream_t)stream, g, y, bn, x, dw, partial, B, H, W, Ho, Wo, PR,

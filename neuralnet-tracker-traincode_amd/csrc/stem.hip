@@ -12,6 +12,7 @@ namespace ttk {
 constexpr int kStemC = 32;
 constexpr int kStemQuads = kStemC / 4;
 
+#if defined(TTK_EXPERIMENTS)  // round 1's VALU kernels: selectable by TTK_STEM=scalar only (A/B timing)
 // thread = TWO horizontally adjacent output pixels, all 32 channels.  The filter bank sits in LDS as
 // wt[tap][c]; a ds_read_b128 at a wave-uniform address is a broadcast and hands every lane the weights of 4
 // channels for one tap, which feed 8 FMAs (2 pixels x 4 channels).  35 coalesced input loads (5 rows x 7
@@ -149,6 +150,7 @@ __global__ void __launch_bounds__(kBlock) stem_bwd_weight_k(const float* __restr
   }
   for (int i = threadIdx.x; i < 25 * kStemC; i += kBlock) atomicAdd(dw + i, acc_s[i % 25][i / 25]);  // dw[c][tap]
 }
+#endif  // TTK_EXPERIMENTS
 
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -503,15 +505,18 @@ int ttk_stem_fwd(const float* x, const float* w, void* y, float* part, const flo
   TTK_REQUIRE(B > 0 && H > 4 && W > 4, "stem_fwd: bad shape B=%d H=%d W=%d", B, H, W);
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int64_t items = (int64_t)B * Ho * Wo * kStemQuads;  // sizes the partial rows (ttk_partial_rows_elementwise)
-  static const bool scalar = [] { const char* e = getenv("TTK_STEM"); return e && strcmp(e, "scalar") == 0; }();
+  static const bool scalar = [] { const char* e = exp_env("TTK_STEM"); return e && strcmp(e, "scalar") == 0; }();
   TTK_REQUIRE(!(scalar && act_bf16), "stem_fwd: TTK_STEM=scalar has no bf16-storage form");
   TTK_REQUIRE((int64_t)B * Ho * Wo < (int64_t)1 << 31, "stem_fwd: too many output pixels for 32-bit indexing");
+#if defined(TTK_EXPERIMENTS)
   if (scalar)  // TTK_STEM=scalar: the VALU kernels (A/B timing)
     hipLaunchKernelGGL(stem_fwd_k, dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, x, w, (float*)y, part, pivot, B, H, W, Ho,
                        Wo);
-  else {
+  else
+#endif
+  {
     // input band in LDS (TTK_STEM=gather: the kernel that gathers its patches from global memory; also for images too wide for LDS)
-    static const bool gather = [] { const char* e = getenv("TTK_STEM"); return e && strcmp(e, "gather") == 0; }();
+    static const bool gather = [] { const char* e = exp_env("TTK_STEM"); return e && strcmp(e, "gather") == 0; }();
     const size_t sm = ((size_t)(((2 * kFwBand + 3) * (W + 4) + 3) & ~3) + (kBlock / kWave) * 32 * 36) * sizeof(float);
     const int band_rows = kFwBand < Ho ? kFwBand : Ho;  // (balanced 11-row bands measured no better here: 74.9 vs 71.1 us - more halo rows per output row)
     const int nbands = (Ho + band_rows - 1) / band_rows;
@@ -534,14 +539,17 @@ int ttk_stem_bwd_weight(const void* g, const void* y, const float* bn, const flo
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int64_t items = (int64_t)B * Ho * Wo * kStemQuads;
   int grid = elementwise_grid(items);
-  static const bool scalar = [] { const char* e = getenv("TTK_STEM"); return e && strcmp(e, "scalar") == 0; }();
+  static const bool scalar = [] { const char* e = exp_env("TTK_STEM"); return e && strcmp(e, "scalar") == 0; }();
   TTK_REQUIRE(!(scalar && act_bf16), "stem_bwd_weight: TTK_STEM=scalar has no bf16-storage form");
   if (scalar) partial = nullptr;
   if (!accumulate && !partial) hipLaunchKernelGGL(zero_k, dim3(4), dim3(256), 0, (hipStream_t)stream, dw, 25 * kStemC);
+#if defined(TTK_EXPERIMENTS)
   if (scalar) {
     if (grid > 512) grid = 512;
     hipLaunchKernelGGL(stem_bwd_weight_k, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, (const float*)g, (const float*)y, bn, x, dw, B, H, W, Ho, Wo);
-  } else {
+  } else
+#endif
+  {
     // three workgroups fit a CU (44 KB of LDS each): 768 persistent workgroups are all resident - with 1 024 the last quarter only
     // started when the first finished, five tile times for 2.5 tiles per workgroup
     const int resident = 3 * 256;

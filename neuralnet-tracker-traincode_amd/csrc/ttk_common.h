@@ -35,6 +35,20 @@ void set_error(const char* fmt, ...);
 
 __host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Environment switches.  The PRODUCT library reads exactly one variable, TTK_DETERMINISTIC (a documented mode: DESIGN.md 4.8).  Every
+// A/B switch (kernel selection, forced tilings: TTK_GEMM, TTK_GEMM_R, TTK_R_RBLK, TTK_R_ALL, TTK_WGRAD_T, TTK_STEM, TTK_STEM7_VALU,
+// TTK_FUSED_FP32, TTK_CONV_WIDE64, TTK_DW_COLTILE) exists only in experiment builds (-DTTK_EXPERIMENTS: tools/exp/build_variants.sh);
+// in the product exp_env() is a constant and the branches behind it fold away.
+#if defined(TTK_EXPERIMENTS)
+inline const char* exp_env(const char* name) { return getenv(name); }
+#else
+inline const char* exp_env(const char*) { return nullptr; }
+#endif
+inline bool deterministic_mode() {
+  static const bool det = [] { const char* e = getenv("TTK_DETERMINISTIC"); return e && e[0] != '0'; }();
+  return det;
+}
+
 // Activation layout of the MobileNet path (include/ttk.h, "channel blocks"): a tensor of M pixels x C channels is stored as
 // [C / 32][M][32] - element (m, c) at ((c >> 5) * M + m) * 32 + (c & 31).  A depthwise workgroup's 32-channel slab and a GEMM's
 // k32 step are then CONTIGUOUS runs (pixels x 128 B) instead of 128-byte pieces of 4 C-byte rows: the same kernels stream 10-20 %

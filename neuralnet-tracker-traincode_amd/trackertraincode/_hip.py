@@ -89,7 +89,7 @@ _SIGNATURES = {
     "ttk_stream_probe": [_P, _P, _P, _L, _I, _I, _I, _I, _L, _I, _I, _I],
 }
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 def bn_pivot() -> bool:
@@ -139,6 +139,7 @@ class _Library:
             fn = getattr(self.cdll, name)
             fn.argtypes, fn.restype = [c_int64], c_int
         self.cdll.ttk_partial_rows_pwconv.argtypes, self.cdll.ttk_partial_rows_pwconv.restype = [c_int64, c_int, c_int, c_int], c_int
+        self.cdll.ttk_pwconv_tile_rows.argtypes, self.cdll.ttk_pwconv_tile_rows.restype = [c_int64, c_int, c_int, c_int], c_int
         self.cdll.ttk_heads_num_rows.argtypes, self.cdll.ttk_heads_num_rows.restype = [c_int, c_int, c_int], c_int
         self.cdll.ttk_pwconv_prepared_bytes.argtypes, self.cdll.ttk_pwconv_prepared_bytes.restype = [c_int, c_int], ctypes.c_size_t
         self.cdll.ttk_partial_rows_dwconv.argtypes, self.cdll.ttk_partial_rows_dwconv.restype = [c_int] * 6, c_int
@@ -157,19 +158,25 @@ class _Library:
             fn.restype = c_int
             self._fns[name] = fn
 
-    def call(self, name: str, *args):
-        stream = torch.cuda.current_stream().cuda_stream
-        # a stale error of an unrelated earlier HIP call must not be blamed on this launch - but it must not vanish either
+    def clear_stale_error(self, where: str = "") -> int:
+        """Drops (and reports once) a HIP error that an EARLIER, unrelated call of the process left pending - entry points report launch
+        failures through the sticky per-thread hipGetLastError().  Called when the library is loaded and once per training / evaluation
+        step (train.training_step, eval.Predictor), not before every launch: that was a second ctypes round trip in front of each of the
+        ~160 launches of a step (round 3: host_enqueue_ms_per_step 3.2)."""
         stale = self._clear()
         if stale and not self._stale_reported:
             self._stale_reported = True
             import warnings
-            warnings.warn(f"a HIP error (hipError_t {stale}) from an earlier launch was pending when {name} was called; it was NOT raised by {name}",
-                          RuntimeWarning, stacklevel=2)
-        rc = self._fns[name](*args, stream)
+            warnings.warn(f"a HIP error (hipError_t {stale}) from an earlier launch was pending{' at ' + where if where else ''}; it was dropped, "
+                          "not raised", RuntimeWarning, stacklevel=2)
+        return stale
+
+    def call(self, name: str, *args):
+        rc = self._fns[name](*args, torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             msg = self.cdll.ttk_last_error_string().decode(errors="replace")
-            raise RuntimeError(f"{name} failed (code {rc}): {msg}")
+            hint = "" if rc < 0 else " (a positive code is a hipError_t read from the sticky hipGetLastError(): an earlier launch of this step may have left it)"
+            raise RuntimeError(f"{name} failed (code {rc}): {msg}{hint}")
 
     def loss_batch(self, ops):
         """ttk_loss_batch: `ops` = [(entry point name, argument tuple as for call()), ...], mutually independent; one launch
@@ -260,6 +267,8 @@ def lib() -> _Library:
     global _lib
     if _lib is None:
         _lib = _Library()
+        if torch.cuda.is_available():
+            _lib.clear_stale_error("library load")
     return _lib
 
 
@@ -297,6 +306,6 @@ def from_blocks(t: torch.Tensor) -> torch.Tensor:
 
 def exported_symbols() -> list[str]:
     return ["ttk_abi_version", "ttk_last_error_string", "ttk_clear_error", "ttk_partial_rows_elementwise",
-            "ttk_partial_rows_gemm", "ttk_partial_rows_pwconv", "ttk_partial_rows_dwconv", "ttk_heads_num_rows", "ttk_pwconv_prepared_bytes",
+            "ttk_partial_rows_gemm", "ttk_partial_rows_pwconv", "ttk_pwconv_tile_rows", "ttk_partial_rows_dwconv", "ttk_heads_num_rows", "ttk_pwconv_prepared_bytes",
             "ttk_pwconv_wgrad_partial_bytes", "ttk_pwconv_wgrad_scratch_bytes", "ttk_stem_wgrad_partial_bytes", "ttk_conv_wgrad_partial_bytes", "ttk_stem7_wgrad_partial_bytes",
             "ttk_pwconv1x1_bwd_fused_rows", "ttk_pwconv1x1_bwd_fused_partial_bytes"] + list(_SIGNATURES)

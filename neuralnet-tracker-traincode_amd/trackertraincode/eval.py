@@ -17,7 +17,7 @@ import numpy as np
 import torch
 from torch import Tensor
 
-from . import utils
+from . import _hip, utils
 from .datasets.batch import Batch, Metadata
 from .datatransformation.batch.geometric import NoRoiRandomization
 from .datatransformation.gpu import GpuFocusRoiAugment
@@ -74,6 +74,8 @@ class Predictor:
 
     @torch.no_grad()
     def predict_batch(self, images, rois: Tensor) -> Batch:
+        if self._device.type == "cuda":
+            _hip.lib().clear_stale_error("the start of an evaluation batch")
         crop = self.crop_batch(images, rois)
         preds = self._net(crop["image"])
         N = self.input_resolution

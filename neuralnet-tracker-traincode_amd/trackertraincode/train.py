@@ -484,6 +484,8 @@ def _concat_rows(tensors):
 
 def training_step(model: nn.Module, batches: List[Batch], epoch: int, criterions):
     """LitModel.training_step (scripts/train_poseestimator.py:310-330) without the logging."""
+    if batches[0]["image"].is_cuda:
+        _hip.lib().clear_stale_error("the start of a training step")  # once per step (the launches themselves no longer do it)
     inputs = _concat_rows([b["image"] for b in batches])
     ids = _concat_rows([b["coord_convention_id"] for b in batches])
     preds = model(inputs, ids)

@@ -134,13 +134,28 @@ def test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout, loose):
         assert _rel(runs[0].cpu().numpy(), dw64) <= 1.5 * e_f32 + 1e-7
 
 
-@pytest.mark.parametrize("rblk", [4, 6, 8])
-@pytest.mark.parametrize("M,Cin,Cout", [(5000, 256, 512), (1111, 512, 256)])
-def test_row_block_gemm_every_tile_height(M, Cin, Cout, rblk, monkeypatch):
-    """pw16r_k at each of its three tile heights (TTK_R_RBLK forces what the cost model would pick from the shape): forward and
-    data gradient against float64, partial sums, ragged last row block."""
-    monkeypatch.setenv("TTK_R_RBLK", str(rblk))
-    test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout, 1.0)
+@pytest.mark.parametrize("tile_rows", [128, 192, 256])
+@pytest.mark.parametrize("Cin,Cout", [(256, 512), (512, 256)])
+def test_row_block_gemm_every_tile_height(Cin, Cout, tile_rows):
+    """The row-block GEMMs (pw16r_k / pw16m_k) at each of their three tile heights: forward and data gradient against float64, partial
+    sums, ragged last row block.  The cost model picks the height from (M, K, Nout); ttk_pwconv_tile_rows (ABI 19) reports it, and the
+    test searches an M for which BOTH directions run the wanted height (the product library has no switch that forces one)."""
+    import trackertraincode._hip as H
+    L = H.lib()
+    found = None
+    for M in list(range(1000, 20000, 37)) + list(range(20000, 120000, 997)):
+        if L.cdll.ttk_pwconv_tile_rows(M, Cin, Cout, 0) == tile_rows and L.cdll.ttk_pwconv_tile_rows(M, Cout, Cin, 1) == tile_rows:
+            found = M
+            break
+    if found is None:  # the two directions need not agree on one M: take one M per direction
+        ms = []
+        for dgrad, (k, n) in enumerate(((Cin, Cout), (Cout, Cin))):
+            ms.append(next((M for M in list(range(1000, 20000, 37)) + list(range(20000, 120000, 997)) if L.cdll.ttk_pwconv_tile_rows(M, k, n, dgrad) == tile_rows), None))
+        assert all(m is not None for m in ms), f"no M in the searched range runs {tile_rows}-row tiles for {Cin}->{Cout}: {ms}"
+        for M in sorted(set(ms)):
+            test_pwconv_fwd_bwd_data_bwd_weight(M, Cin, Cout, 1.0)
+    else:
+        test_pwconv_fwd_bwd_data_bwd_weight(found, Cin, Cout, 1.0)
 
 
 def test_prepared_weights_match_per_call_split():

@@ -8,7 +8,7 @@ C=$R/neuralnet-tracker-traincode_amd/csrc
 O=$R/tools/exp/_build
 mkdir -p $O
 make -C $C -j8 > /dev/null
-FLAGS="-O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable"
+FLAGS="-O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable -DTTK_EXPERIMENTS"  # (the A/B environment switches of the recompiled file exist in experiment builds only)
 pids=()
 while [ $# -ge 3 ]; do
   name=$1; src=$2; defs=$3; shift 3

@@ -45,7 +45,13 @@ for k in sorted(set(fetch) | set(write)):
         _, rd = l2["TCP_TCC_READ_REQ_sum"].get(k, [0, 0.0])
         out[k].update(l2_hit_rate=hit / max(hit + miss, 1.0), l2_hits_per_launch=hit / max(nh, 1), l2_misses_per_launch=miss / max(nh, 1),
                       l1_read_requests_to_l2_per_launch=rd / max(nh, 1))
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --serial-streams`, "
-                     "KB -> bytes, FETCH_SIZE doubled (gfx950 wide-read rule)", "kernels": out}, open(sys.argv[3], "w"), indent=1)
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from build_id import csrc_sha256  # noqa: E402
+
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 1 --no-graph`, "
+                     "KB -> bytes, FETCH_SIZE doubled (gfx950 wide-read rule)",
+           "csrc_sha256": csrc_sha256(),  # the kernel sources these counters belong to (tools/build_id.py); bench.py checks it
+           "kernels": out}, open(sys.argv[3], "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["bytes_per_launch"] * kv[1]["launches"])[:12]:
     print(f"{k:40s} n={v['launches']:4d}  {v['bytes_per_launch']/1e6:9.1f} MB/launch")
