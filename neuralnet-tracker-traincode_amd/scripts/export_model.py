@@ -156,6 +156,10 @@ def convert_posemodel_onnx(net: nn.Module, filename, for_opentrack=True, quantiz
     if quantize:
         raise NotImplementedError("post-training quantisation (torch.ao over 20 training batches, reference :53-113) is not built: it needs the "
                                   "HDF5 training sets; see SURVEY.md §8 f4")
+    if fp16:
+        # (round-3 advisor finding: the flag used to change only the file name and the contract - an fp32 graph labelled fp16)
+        raise NotImplementedError("fp16 conversion (onnxconverter_common.float16 + onnxsim + an onnxruntime comparison, reference :243-279) is not "
+                                  "built: the image has none of the three packages; export fp32 and convert where they are installed")
     net = net.to("cpu")
     net.load_state_dict(clear_denormals(net.state_dict()))
     wrapped = ModelForOpenTrack(net) if for_opentrack else ExportModel(net)

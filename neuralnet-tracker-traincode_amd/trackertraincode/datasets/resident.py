@@ -93,8 +93,14 @@ class ResidentLoader:
                 by_tag.setdefault(ds.tag, []).append(Batch(meta, data))
             out = []
             for parts in by_tag.values():
-                b = parts[0] if len(parts) == 1 else Batch.Collation._collate_group(parts)
-                b = self._crop(b, generator=self._gen)
+                if len({p.meta.image_wh for p in parts}) == 1:
+                    b = parts[0] if len(parts) == 1 else Batch.Collation._collate_group(parts)
+                    b = self._crop(b, generator=self._gen)
+                else:
+                    # datasets of one Tag whose frames differ in size (every shard is padded to its OWN largest frame): the source frames
+                    # cannot be stacked, the 129 x 129 crops can - crop each dataset's part, collate the crops (the reference crops
+                    # per sample before its collation, datatransformation/loader.py:24-58)
+                    b = Batch.Collation._collate_group([self._crop(p, generator=self._gen) for p in parts])
                 img = b["image"]
                 for aug in self._augs:
                     img = aug.apply(img, aug.sample_params(img.shape[0], self._gen))
@@ -108,11 +114,13 @@ class ResidentEvalLoader:
     iteration, no shuffling) over frames resident in HBM: deterministic FocusRoi crop (enlargement 1.1, no shift, no rotation:
     pipelines.py:330-339 stage "eval"), label bookkeeping and whitening on the GPU."""
 
-    def __init__(self, datasets: Sequence[ResidentFrames], batchsize: int, new_size: int = 129, extension_factor: float = 1.1):
+    def __init__(self, datasets: Sequence[ResidentFrames], batchsize: int, new_size: int = 129, extension_factor: float = 1.1,
+                 roi_from_landmarks: bool = False):
         from ..datatransformation.batch.geometric import NoRoiRandomization
 
         self.datasets, self.batchsize = list(datasets), int(batchsize)
-        self._crop = GpuFocusRoiAugment(new_size=new_size, make_params=NoRoiRandomization(extension_factor), whiten=True)
+        self._crop = GpuFocusRoiAugment(new_size=new_size, make_params=NoRoiRandomization(extension_factor), whiten=True,
+                                        roi_from_landmarks=roi_from_landmarks)
 
     def __len__(self):
         return sum((len(d) + self.batchsize - 1) // self.batchsize for d in self.datasets)

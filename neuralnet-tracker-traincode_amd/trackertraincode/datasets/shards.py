@@ -23,7 +23,17 @@ import torch
 
 from .resident import ResidentFrames
 
-_NAME_MAP = {"rois": "roi", "coords": "coord", "quats": "pose", "pt3d_68": "pt3d_68", "shapeparams": "shapeparam"}  # dshdf5pose.py:34-46
+# dshdf5pose.py:33-46 (its whitelist :168-180 also names semseg / seg_image, which no pose dataset of the training script carries)
+_NAME_MAP = {"rois": "roi", "coords": "coord", "quats": "pose", "pt3d_68": "pt3d_68", "pt2d_68": "pt2d_68", "shapeparams": "shapeparam", "hasface": "hasface"}
+
+
+def _to_grey(im: np.ndarray) -> np.ndarray:
+    """Raw frames with a colour axis -> grey with the luma weights the JPEG path uses (PIL "L" = ITU-R 601: 299/587/114 per mille,
+    what cv2.imdecode(..., IMREAD_GRAYSCALE) of the reference computes too), rounded to nearest."""
+    if im.ndim == 2:
+        return np.asarray(im, dtype=np.uint8)
+    rgb = np.asarray(im[..., :3], dtype=np.float32)
+    return np.clip(np.rint(rgb @ np.array([0.299, 0.587, 0.114], np.float32)), 0, 255).astype(np.uint8)
 
 
 def _decode_grey(blob: bytes) -> np.ndarray:
@@ -42,7 +52,7 @@ def decode_pose_shard(path: str, half_pixel_offset: bool = True) -> dict:
         frames = [_decode_grey(blob[offs[i]:offs[i + 1]].tobytes()) for i in range(len(lengths))]
     elif "images" in d.files:
         imgs = d["images"]
-        frames = [np.asarray(im if im.ndim == 2 else im[..., 0], dtype=np.uint8) for im in imgs]
+        frames = [_to_grey(im) for im in imgs]
     else:
         raise ValueError(f"{path}: neither image_bytes/image_lengths nor images")
     H, W = max(f.shape[0] for f in frames), max(f.shape[1] for f in frames)
@@ -58,9 +68,10 @@ def decode_pose_shard(path: str, half_pixel_offset: bool = True) -> dict:
         if "coord" in out:
             out["coord"] = out["coord"].copy()
             out["coord"][:, :2] += 0.5
-        if "pt3d_68" in out:
-            out["pt3d_68"] = out["pt3d_68"].copy()
-            out["pt3d_68"][..., :2] += 0.5
+        for k in ("pt3d_68", "pt2d_68"):
+            if k in out:
+                out[k] = out[k].copy()
+                out[k][..., :2] += 0.5
     n = {len(v) for v in out.values()}
     if len(n) != 1:
         raise ValueError(f"{path}: fields of different lengths")

@@ -78,10 +78,15 @@ class Predictor:
             _hip.lib().clear_stale_error("the start of an evaluation batch")
         crop = self.crop_batch(images, rois)
         preds = self._net(crop["image"])
-        N = self.input_resolution
-        # image pixels -> crop pixels -> [-1, 1]: invert the whole chain for the predictions (reference :199-206:
-        # unnormalize_batch, then the stored image_backtransform)
-        to_norm = position_normalization(N, N).to(self._device) @ Affine2d(crop["image_transform"])
+        return self.to_image_coordinates(preds, crop["image_transform"], self.input_resolution)
+
+    @staticmethod
+    def to_image_coordinates(preds, image_transform: Tensor, N: int) -> Batch:
+        """Predictions in the crop's [-1, 1] coordinates -> image pixels (reference :199-206: unnormalize_batch, then the
+        image_backtransform that FocusRoi stored = the inverse of the crop's point transform).  `image_transform`: [B, 2, 3] image pixels ->
+        crop pixels.  Pinned to the reference by tests/golden/eval.npz (oracle/tools/gen_golden_eval.py)."""
+        # image pixels -> crop pixels -> [-1, 1]: invert the whole chain for the predictions
+        to_norm = position_normalization(N, N).to(image_transform.device) @ Affine2d(image_transform)
         back = to_norm.inv()
         cats = {"coord": FieldCategory.xys, "pose": FieldCategory.quat, "pt3d_68": FieldCategory.points, "roi": FieldCategory.roi}
         out = {}
@@ -92,7 +97,7 @@ class Predictor:
         for k in ("coord_scales", "pose_scales_tril", "shapeparam", "unnormalized_quat"):
             if k in preds:
                 out[k] = preds[k]
-        meta = Metadata(N, rois.shape[0], categories=dict(cats))
+        meta = Metadata(N, int(image_transform.shape[0]), categories=dict(cats))
         return Batch(meta, out)
 
     def evaluate(self, metric, samples, batchsize: int = 128):

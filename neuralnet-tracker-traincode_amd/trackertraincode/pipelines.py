@@ -162,8 +162,11 @@ def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights
         (oracle/tools/h5_to_npz.py converts them in the build container; datasets/shards.py decodes the JPEGs once).  The decoded frames
         live in HBM; per step the weighted concat draw of the reference (datasets/randomized.py), the random focus-ROI crop / warp and
         the intensity augmentation run on the GPU (datasets/resident.py).  The test loader is the deterministic crop of the first 400
-        AFLW2000-3D frames, as in the reference.  `roi_override` other than "original" (landmark-derived boxes) and the 1 % flip / 90
-        degree rotation (:376) are not built.
+        AFLW2000-3D frames, as in the reference.  Behind the crop every sample is mirrored with probability 1/2 and turned by +-90
+        degrees with probability 0.5 % each (`horizontal_flip_and_rot_90(0.01)`, :373-377), composed into the crop's warp.
+        `roi_override`: "original" (stored face boxes, crop enlargement 1.1) or "landmarks" (boxes = xy extent of pt3d_68 in front of and
+        behind the crop, enlargement 1.2; :329-350).  "extent_to_forehead" needs the vertices of the full BFM head model, a blob the
+        reference's repository does not carry: it raises.
     """
     if datasets == "synthetic":
         datasets = [(Tag.POSE_WITH_LANDMARKS, 11.0), (Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS, 1.0)]
@@ -175,9 +178,13 @@ def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights
         return train, test, len(train) * batchsize
     if not (isinstance(datasets, (list, tuple)) and datasets and all(isinstance(d, Id) for d in datasets)):
         raise ValueError('datasets: "synthetic", a list of (Tag, weight) pairs, or a sequence of pipelines.Id')
-    if roi_override != "original":
-        raise NotImplementedError('roi_override: only "original" (the stored face boxes) is built; the landmark-derived boxes of '
-                                  "PutRoiFromLandmarks (pipelines.py:341-356) are not")
+    if roi_override not in ("original", "landmarks", "extent_to_forehead"):
+        raise ValueError(f"roi_override: got {roi_override!r}")  # (the reference asserts, :330)
+    if roi_override == "extent_to_forehead":
+        raise NotImplementedError('roi_override="extent_to_forehead": PutRoiFromLandmarks(extend_to_forehead=True) takes the extent of the posed '
+                                  "BFM head's VERTICES (batch/misc.py:18-21); the reference's bfm_noneck_v3.pkl is a missing blob, so there is "
+                                  'nothing to build or to pin against; "original" and "landmarks" are built')
+    extension_factor = {"original": 1.1, "landmarks": 1.2}[roi_override]  # :333
     import os
 
     from .datasets.resident import ResidentEvalLoader, ResidentLoader
@@ -222,9 +229,11 @@ def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights
             t.fields["dataset_weight"] = torch.full((len(t),), w / wmax, dtype=torch.float32, device=device)
         freqs = [1.0 / len(weights)] * len(weights)
     augs = make_image_augmentations(torch.Generator().manual_seed(99 + seed)) if enable_image_aug else None
-    crop = GpuFocusRoiAugment(new_size=inputsize, rotation_aug_angle=rotation_aug_angle, extension_factor=1.1, whiten=not augs)
+    crop = GpuFocusRoiAugment(new_size=inputsize, rotation_aug_angle=rotation_aug_angle, extension_factor=extension_factor, whiten=not augs,
+                              flip_rot_p=0.01, roi_from_landmarks=roi_override == "landmarks")
     steps = steps_per_epoch if steps_per_epoch is not None else (10 * 1024) // batchsize  # Trainer(limit_train_batches=...), train_poseestimator.py:447
     train = ResidentLoader(train_sets, freqs, batchsize, steps, seed=seed, crop=crop, image_augmentations=augs)
     tname, ttag, (lo, hi) = _TEST_SHARD
-    test = ResidentEvalLoader([_slice_frames(shard(tname, ttag), lo, hi)], batchsize * 2, new_size=inputsize)
+    test = ResidentEvalLoader([_slice_frames(shard(tname, ttag), lo, hi)], batchsize * 2, new_size=inputsize, extension_factor=extension_factor,
+                              roi_from_landmarks=roi_override == "landmarks")
     return train, test, total

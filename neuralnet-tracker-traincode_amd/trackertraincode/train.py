@@ -526,6 +526,8 @@ class GraphedTrainStep:
         self._static: list[Batch] = []
         self._out = None
         self.captures = 0
+        self._miss_streak = 0      # consecutive steps whose signature differed from the captured one
+        self.eager_only = False    # set once re-capturing is seen to happen step after step
 
     def _signature(self, batches, epoch):
         layout = tuple((str(b.meta.tag), b.meta.batchsize, tuple((k, tuple(v.shape), str(v.dtype)) for k, v in b.items()))
@@ -559,8 +561,20 @@ class GraphedTrainStep:
     def run(self, batches: List[Batch], epoch: int):
         """One training step.  Returns {"loss", "mt_losses"}; when replayed these are the graph's static output
         tensors (overwritten by the next call)."""
+        if self.eager_only:
+            return self._eager(batches, epoch)
         sig = self._signature(batches, epoch)
         if sig != self._sig:
+            # A loader that mixes datasets of several Tags draws the per-Tag sub-batch sizes anew every step (ResidentLoader): the signature
+            # then changes almost every step and each step would run eagerly AND re-capture (synchronise, capture, a new private pool) -
+            # far slower than eager.  Three misses in a row: stay eager for the rest of the run (round-3 advisor finding).
+            self._miss_streak += 1
+            if self._miss_streak >= 3 and self.captures >= 2:
+                import warnings
+                warnings.warn("GraphedTrainStep: the sub-batch layout changed on three consecutive steps (per-Tag batch sizes vary from step to "
+                              "step?) - a captured graph would be re-captured every step; running eagerly from here on", RuntimeWarning, stacklevel=2)
+                self.eager_only, self.graph, self._static, self._out = True, None, [], None
+                return self._eager(batches, epoch)
             # first step with this layout: run it eagerly (lazy initialisation, table building, stream creation happen
             # here and the step counts), then capture for the following steps
             out = self._eager(batches, epoch)
@@ -587,6 +601,7 @@ class GraphedTrainStep:
                     d.copy_(v, non_blocking=True)
         if fdst:
             _hip.lib().multi_copy(fsrc, fdst)
+        self._miss_streak = 0
         self.optimizer.before_graph_replay()
         self.graph.replay()
         self.optimizer.after_graph_replay()

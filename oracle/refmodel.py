@@ -415,7 +415,10 @@ def heads_forward(st, f: Tensor, set_id: Tensor | None, *, enable_point_head: bo
 
 def network_forward(st, x: Tensor, set_id: Tensor | None, cfg: dict, training: bool, momentum=0.1):
     assert x.shape[2] == 129 and x.shape[3] == 129  # models.py:341
-    f, _ = mobilenet_forward(st, x, training, momentum)
+    if cfg.get("config", "mobilenetv1") == "resnet18":  # models.py:221-222 (create_pose_estimator_backbone): ResNetBackbone, 512 features
+        f, _ = resnet18_forward(st, x, training, momentum, prefix="convnet.")
+    else:
+        f, _ = mobilenet_forward(st, x, training, momentum)
     return heads_forward(
         st, f, set_id, enable_point_head=cfg["enable_point_head"],
         enable_uncertainty=cfg["enable_uncertainty"],

@@ -34,7 +34,7 @@ def convert_pose_dataset(src, dst):
             d["image_bytes"] = np.concatenate(blobs)
         else:
             d["images"] = imgs[...]
-        for k in ["coords", "quats", "rois", "pt3d_68", "shapeparams"]:
+        for k in ["coords", "quats", "rois", "pt3d_68", "pt2d_68", "shapeparams", "hasface"]:  # the reader's label whitelist (dshdf5pose.py:168-180)
             if k in f:
                 d[k] = f[k][...]
         np.savez(dst, **d)

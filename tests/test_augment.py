@@ -95,3 +95,71 @@ def test_hip_augment_matches_reference_golden():
     np.testing.assert_allclose(pose[0].cpu().numpy(), G["flip_pose"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(coord[0].cpu().numpy(), G["flip_coord"], rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(roi[0].cpu().numpy(), G["flip_roi"], rtol=1e-5, atol=1e-4)
+
+
+GF = dict(np.load(os.path.join(GOLDEN, "augment_fliprot.npz"))) if os.path.exists(os.path.join(GOLDEN, "augment_fliprot.npz")) else None
+
+
+def test_fliprot_table_matches_reference_composition():
+    """The six (rot_dir, do_flip) point transforms of GpuFocusRoiAugment are exact quarter turns / mirrors of the 129-pixel crop (the
+    reference composes them from range remaps and a rotation by +-pi/2, batch/geometric.py:241-251; cos(pi/2) leaves 4e-8)."""
+    from trackertraincode.datatransformation import GpuFocusRoiAugment
+
+    T = GpuFocusRoiAugment(N, flip_rot_p=0.01).fliprot_table().numpy()
+    assert T.shape == (6, 3, 3)
+    np.testing.assert_allclose(T[2], np.eye(3), atol=1e-6)                                   # rot 0, no flip
+    np.testing.assert_allclose(T[3], [[-1, 0, N], [0, 1, 0], [0, 0, 1]], atol=1e-4)          # mirror x -> N - x
+    for code in range(6):
+        assert abs(abs(np.linalg.det(T[code][:2, :2])) - 1) < 1e-5
+        assert (np.linalg.det(T[code][:2, :2]) < 0) == bool(code & 1)
+    # the draw: mirrored half of the time, turned 1 % of the time
+    aug = GpuFocusRoiAugment(N, flip_rot_p=0.01)
+    codes = aug.draw_fliprot(200000, torch.Generator().manual_seed(3))
+    assert abs(float((codes % 2 == 1).float().mean()) - 0.5) < 0.01
+    assert abs(float((codes // 2 != 1).float().mean()) - 0.01) < 0.002 and abs(float((codes // 2 == 0).float().mean()) - 0.005) < 0.0015
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("code", range(6))
+def test_hip_flip_and_rot90_matches_reference_golden(code):
+    """horizontal_flip_and_rot_90 behind the crop (reference batch/geometric.py:234-267, every one of its six draws forced in the golden):
+    here the mirror / quarter turn is composed onto the crop's transform, so ONE warp produces the permuted crop and the labels see the
+    composed transform."""
+    from trackertraincode.datasets.batch import Batch, Metadata
+    from trackertraincode.datatransformation import GpuFocusRoiAugment
+    from trackertraincode.datatransformation.batch.geometric import RoiFocusRandomizationParameters
+
+    dev = "cuda"
+    b = int(GF["sample"])
+    t = lambda k: torch.from_numpy(G[k][b:b + 1]).to(dev)
+    batch = Batch(Metadata(96, 1, tag="x"), image=t("image"), roi=t("roi"), coord=t("coord"), pose=t("pose"), pt3d_68=t("pt3d_68"))
+    params = RoiFocusRandomizationParameters(t("scales"), t("angles"), t("translations"))
+    out = GpuFocusRoiAugment(N, whiten=True, flip_rot_p=0.01)(batch, params=params, fliprot_codes=torch.tensor([code]))
+    crop = (out["image"].cpu().numpy()[0] + 0.5) * 256.0
+    # the reference permutes the pixels of ITS crop; here the source is re-sampled at the permuted pixel centres: the same bilinear taps
+    np.testing.assert_allclose(crop, GF[f"image_{code}"], atol=6e-2)
+    if code == 2:
+        np.testing.assert_allclose(crop, G["crop"][b], atol=5e-2)
+    for k in ("coord", "pose", "roi", "pt3d_68"):
+        np.testing.assert_allclose(out[k].cpu().numpy()[0], GF[f"{k}_{code}"], rtol=1e-4, atol=3e-5, err_msg=f"{k} code {code}")
+
+
+@pytest.mark.gpu
+def test_hip_roi_from_landmarks_matches_reference_golden():
+    """roi_override="landmarks" (pipelines.py:343-350): PutRoiFromLandmarks in front of the deterministic 1.2x crop and behind it."""
+    from trackertraincode.datasets.batch import Batch, Metadata
+    from trackertraincode.datatransformation import GpuFocusRoiAugment
+    from trackertraincode.datatransformation.batch.geometric import NoRoiRandomization
+
+    dev = "cuda"
+    t = lambda k: torch.from_numpy(G[k]).to(dev)
+    B = G["roi"].shape[0]
+    batch = Batch(Metadata(96, B, tag="x"), image=t("image"), roi=t("roi"), coord=t("coord"), pose=t("pose"), pt3d_68=t("pt3d_68"))
+    out = GpuFocusRoiAugment(N, whiten=True, make_params=NoRoiRandomization(1.2), roi_from_landmarks=True)(batch)
+    assert np.array_equal(out.view_roi.cpu().numpy(), GF["lm_view_roi"])  # INTEGER: bit-exact
+    np.testing.assert_allclose(out.transform.cpu().numpy(), GF["lm_tr"], rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(out["roi"].cpu().numpy(), GF["lm_roi_after"], rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(out["pt3d_68"].cpu().numpy(), GF["lm_pt3d_68_after"], rtol=1e-4, atol=3e-5)
+    # the box in front of the crop: xy extent of the landmarks
+    xy = G["pt3d_68"][..., :2]
+    np.testing.assert_allclose(np.concatenate([xy.min(1), xy.max(1)], -1), GF["lm_roi_before"], rtol=0, atol=0)

@@ -209,3 +209,59 @@ def test_resident_loader_feeds_training_step():
     out = train.training_step(net, steps[0], 0, crit)
     out["loss"].backward()
     assert torch.isfinite(out["loss"]) and all(torch.isfinite(q.grad).all() for q in net.parameters() if q.grad is not None)
+
+
+@pytest.mark.gpu
+def test_resident_loader_same_tag_datasets_of_different_frame_sizes():
+    """The reference's baseline mix (--ds repro_300_wlp+lapa_megaface_lp:20000+wflw_lp) has three datasets of ONE Tag; decoded shards are
+    padded to their own largest frame, so the parts of a step cannot be stacked before the crop (round-3 advisor finding: torch.cat
+    raised).  Each part is cropped on its own and the 129 x 129 crops are collated per Tag; every sample still equals the crop its own
+    dataset would produce alone (deterministic crop: no roi randomisation, no intensity augmentation)."""
+    from trackertraincode.datasets.resident import ResidentFrames, ResidentLoader
+    from trackertraincode.datatransformation.batch.geometric import NoRoiRandomization
+    from trackertraincode.datatransformation.gpu import GpuFocusRoiAugment
+    from trackertraincode.pipelines import Tag
+
+    g = torch.Generator().manual_seed(4)
+    dev = "cuda"
+
+    def frames(n, h, w):
+        f = {"image": torch.randint(0, 256, (n, 1, h, w), generator=g, dtype=torch.uint8),
+             "roi": torch.tensor([10.0, 12.0, min(w, h) - 8.0, min(w, h) - 6.0]) + torch.rand(n, 4, generator=g) * 3,
+             "coord": torch.cat((w / 2 + torch.randn(n, 2, generator=g), 20 + torch.rand(n, 1, generator=g)), -1),
+             "pose": torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=-1),
+             "pt3d_68": w / 2 + 8 * torch.randn(n, 68, 3, generator=g),
+             "coord_convention_id": torch.zeros(n, dtype=torch.int32),
+             "index": torch.arange(n, dtype=torch.int32)}
+        return ResidentFrames(Tag.POSE_WITH_LANDMARKS, {k: v.to(dev) for k, v in f.items()})
+
+    sets = [frames(40, 64, 64), frames(30, 96, 80), frames(20, 72, 112)]
+    crop = GpuFocusRoiAugment(make_params=NoRoiRandomization(1.1), whiten=True)
+    loader = ResidentLoader(sets, [2.0, 1.0, 1.0], batchsize=48, steps_per_epoch=3, seed=2, crop=crop)
+    seen = 0
+    for batches, plan in zip(loader, _replay_draws(sets, [2.0, 1.0, 1.0], 48, 3, seed=2)):
+        assert len(batches) == 1 and batches[0].meta.batchsize == 48  # one Tag -> one Batch
+        b = batches[0]
+        assert b["image"].shape == (48, 1, 129, 129)
+        # the same frames through the crop of their own dataset alone, in the loader's order (datasets in first-seen order of the draw)
+        lo = 0
+        for d, idx in plan:
+            sel = torch.from_numpy(idx).to(dev)
+            data = {k: v.index_select(0, sel) for k, v in sets[d].fields.items()}
+            from trackertraincode.datasets.batch import Batch, Metadata
+            from trackertraincode.datasets.resident import _CATEGORIES
+            ref = crop(Batch(Metadata(tuple(data["image"].shape[-2:][::-1]), len(idx), sets[d].tag, None, {k: c for k, c in _CATEGORIES.items() if k in data}), data))
+            n = len(idx)
+            for k in ("image", "coord", "pose", "pt3d_68", "roi", "index"):
+                assert torch.equal(b[k][lo:lo + n], ref[k]), (k, d)
+            lo += n
+            seen += n
+        assert lo == 48
+    assert seen == 3 * 48
+
+
+def _replay_draws(sets, weights, batchsize, steps, seed):
+    """The (dataset, frame indices) plan of a ResidentLoader with the same seed (its draw() is deterministic)."""
+    from trackertraincode.datasets.resident import ResidentLoader
+    twin = ResidentLoader(sets, weights, batchsize=batchsize, steps_per_epoch=steps, seed=seed)
+    return [twin.draw() for _ in range(steps)]

@@ -64,27 +64,20 @@ def _one_fwd_bwd(B, seed, sd):
 
 
 @pytest.mark.parametrize("B", [3, 8])
-def test_resnet18_train_fwd_bwd_matches_oracle(B):
-    """Forward: as close to the fp64 oracle as the fp32 CPU oracle is (factor 3 + 2e-5).  Gradients: a ReLU / max-pool
-    decision whose pre-activation lies within rounding of zero legitimately differs between two fp32 evaluations, and ONE
-    flipped element of a [B,5,5,512] tensor shifts the gradient of every layer upstream by ~1/sqrt(elements) ~ 5e-3
-    relative at these tiny batches (measured: the fp32 CPU oracle, the bf16x3 and the fp16x2 GEMM paths each flip on
-    different seeds).  So the strict criterion (every parameter gradient within max(3 x the fp32 CPU oracle's distance,
-    1e-4) of fp64) is looked for on up to four inputs, every input must stay inside the flip-sized bound 3e-2 for its worst
-    parameter, and - when all four flipped - 5e-3 for its median parameter (the arithmetic itself is held to 1.5e-6 per
-    kernel in test_conv_gpu.py)."""
+def test_resnet18_train_fwd_bwd_matches_oracle_parity_unpinned(B):
+    """Small batches, ONE input (no retry over inputs).  Forward: as close to the fp64 oracle as the fp32 CPU oracle is (factor 3 +
+    2e-5).  Gradients: held to max(3 x the fp32 CPU oracle's distance to fp64, 1e-4) per parameter - with explicit accounting for what a
+    small batch cannot avoid: a ReLU / max-pool decision whose pre-activation lies within rounding of zero legitimately differs between
+    two fp32 evaluations, and ONE flipped element of a [B,5,5,512] tensor shifts the gradient of every layer upstream by
+    ~1/sqrt(elements) ~ 5e-3 relative at B = 8.  A parameter that misses the strict bound is a "flip" and must (a) stay inside the
+    flip-sized bound 3e-2, and (b) belong to a run in which the TYPICAL (median) parameter still meets 5e-3; the flips are printed.
+    The arithmetic itself is held to 1.5e-6 per kernel in test_conv_gpu.py; B = 512 (below) has no flip allowance beyond single BatchNorm
+    channels.  "parity unpinned": the oracle restates torchvision's BasicBlock (module docstring)."""
     sd = make_state(R.resnet18_state_shapes(), seed=0)
-    strict, report = 0, []
-    for seed in (7, 8, 9, 10):
-        ok, worst, median, bad = _one_fwd_bwd(B, seed, sd)
-        report.append((seed, worst, median, bad[:3]))
-        assert worst < 3e-2, report
-        strict += ok
-        if strict:
-            break
-    # (the weight gradients' fp32 atomics make the borderline decisions differ from run to run: with four inputs that all flip
-    # - seen about once in nine runs at B = 8 - the flip-sized bound on the typical parameter still has to hold on every one)
-    assert strict >= 1 or all(m < 5e-3 for _, _, m, _ in report), f"no input met the strict gradient criterion: {report}"
+    ok, worst, median, bad = _one_fwd_bwd(B, 7, sd)
+    print(f"resnet18 B={B}: worst gradient rel {worst:.1e}, median {median:.1e}, parameters beyond the strict bound: {[(k, f'{a:.1e}', f'{b:.1e}') for k, a, b in bad]}")
+    assert worst < 3e-2, (worst, bad[:4])
+    assert ok or median < 5e-3, (median, bad[:4])
 
 
 def test_resnet18_at_benchmark_size_matches_oracle():
@@ -154,6 +147,118 @@ def test_resnet18_at_benchmark_size_matches_oracle():
         print("single-decision channels:", flips)
     assert len(flips) <= 4, flips
     print(f"resnet18 B={B}: features rel {e_feat:.1e}, worst gradient rel {worst[0]:.1e} ({worst[1]})")
+    assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("cfg", ["default", "full"])
+def test_resnet18_pose_network_whole_step_at_benchmark_size_parity_unpinned(cfg):
+    """BASELINE config 3 as a WHOLE step: NetworkWithPointHead(config="resnet18") at B = 512 through the backbone, the heads, the multi-task
+    losses, backward, the global-norm clip and Adam, against the oracle (resnet18_forward + heads_forward + compute_loss + ClipAdam) on
+    identical weights and inputs, with the criterion of tests/test_fullsize_gpu.py: loss_sum and every per-sample loss within 1e-3,
+    features 1e-4 relative, BatchNorm running statistics 2e-4, every parameter gradient as close to the fp64 oracle as the fp32 CPU path
+    is (3 x its error + 1e-5; a BatchNorm vector may exceed it through at most two single-ReLU-decision channels, printed), the global
+    gradient norm 1e-3 relative and the parameters after the fused clip + Adam step within 2 lr of the oracle's.  "parity unpinned":
+    torchvision is absent from the image and not vendored by the reference - the oracle restates BasicBlock (backbones/resnet.py:52-104,
+    neuralnets/models.py:218-232)."""
+    import gc
+    import itertools
+    import os
+
+    import trackertraincode.train as train
+    from trackertraincode.neuralnets.models import NetworkWithPointHead
+    from test_oracle_golden import _batches, _criterions
+    from util import GOLDEN, load_golden, make_batches, script_args, train_script
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    B, epoch = 512, 150
+    _, meta = load_golden(f"model_{cfg}.npz")
+    meta = dict(meta, B=B, split=(B * 5) // 8)
+    meta["config"] = dict(meta["config"], config="resnet18")
+    S = train_script()
+    net = NetworkWithPointHead(**meta["config"])
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = make_state(shapes, meta["state_seed"])
+    # zero_init_residual (resnet.py:101) would make half of every block's gradients trivially zero: unit BatchNorm weights instead
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    net = net.cuda().train()
+    crit, _ = S.setup_losses(script_args(meta["flags"]), net)
+    opt, _ = S.create_optimizer(net, script_args(meta["flags"], epochs=20))
+    lr = opt.param_groups[0]["lr"]
+    batches = make_batches(meta, "cuda")
+    out = train.training_step(net, batches, epoch, crit)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    hip_loss = out["loss"].item()
+    hip_vals = {k: v.detach().cpu() for k, v in out["mt_losses"].items()}
+    hip_grads = {k: (None if p.grad is None else p.grad.detach().cpu().clone()) for k, p in net.named_parameters()}
+    opt.step()
+    torch.cuda.synchronize()
+    hip_norm = float(opt.last_grad_norm.item())
+    hip_state = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    del net, out, opt
+    torch.cuda.empty_cache()
+
+    image, ids = make_inputs(B, seed=meta["input_seed"])
+    ocrit, _ = _criterions(meta, GOLDEN)
+
+    def oracle(dtype, step):
+        st = {}
+        for k, v in sd.items():
+            t = torch.from_numpy(np.array(v))
+            t = t.to(dtype) if t.is_floating_point() else t
+            st[k] = t.requires_grad_(True) if not R.is_buffer(k) else t
+        obatches = [{k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in b.items()} for b in _batches(meta)]
+        o, feat = R.network_forward(st, torch.from_numpy(image).to(dtype), torch.from_numpy(ids), meta["config"], True)
+        loss, by_name = R.compute_loss(o, obatches, epoch, ocrit)
+        loss.backward()
+        res = dict(loss=float(loss.item()), by_name={k: v[0].detach().clone() for k, v in by_name.items()},
+                   grads={k: (None if v.grad is None else v.grad.clone()) for k, v in st.items() if not R.is_buffer(k)},
+                   running={k: v.detach().clone() for k, v in st.items() if "running_" in k})
+        if step:
+            oopt = R.ClipAdam(st, lr=1.0e-3, epochs=20)
+            res["gnorm"] = float(oopt.step())
+            res["lr"] = oopt.lrs()[0]
+            res["after"] = {k: v.detach().clone() for k, v in st.items() if not R.is_buffer(k)}
+        del st, o, feat, loss, by_name
+        gc.collect()
+        return res
+
+    o32 = oracle(torch.float32, True)
+    assert abs(lr - o32["lr"]) < 1e-12
+    assert abs(hip_loss - o32["loss"]) < 1e-3, (hip_loss, o32["loss"])
+    assert list(hip_vals.keys()) == list(o32["by_name"].keys())
+    for n, v in o32["by_name"].items():
+        np.testing.assert_allclose(hip_vals[n].numpy(), v.numpy(), rtol=1e-3, atol=1e-3, err_msg=n)
+    for k, v in o32["running"].items():
+        np.testing.assert_allclose(hip_state[k].numpy(), v.numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+    assert abs(hip_norm - o32["gnorm"]) < 1e-3 * o32["gnorm"], (hip_norm, o32["gnorm"])
+    worst_move = max(float((hip_state[k].double() - v.double()).abs().max()) for k, v in o32["after"].items())
+    assert worst_move <= 2.02 * lr, (worst_move, lr)
+    o64 = oracle(torch.float64, False)
+    bad, flips, worst = [], [], (0.0, "")
+    for k, g in hip_grads.items():
+        g64 = o64["grads"][k]
+        if g64 is None:
+            assert g is None or float(g.abs().max()) == 0.0, k
+            continue
+        e_hip, e_cpu = _rel(g, g64), _rel(o32["grads"][k], g64)
+        if e_hip > worst[0]:
+            worst = (e_hip, k)
+        if e_hip > 3 * e_cpu + 1e-5:
+            dev = (g.double() - g64.double()).reshape(g.shape[0], -1).pow(2).sum(1)
+            top = torch.topk(dev, min(2, dev.numel())).indices
+            rest = dev.clone()
+            rest[top] = 0.0
+            e_rest = (rest.sum().sqrt() / g64.double().norm()).item()
+            if g.dim() == 1 and e_rest <= 3 * e_cpu + 1e-5:
+                flips.append((k, [int(i) for i in top], f"hip {e_hip:.2e} -> {e_rest:.2e} without them", f"cpu32 {e_cpu:.2e}"))
+            else:
+                bad.append((k, f"hip {e_hip:.2e}", f"cpu32 {e_cpu:.2e}"))
+    if flips:
+        print("single-decision channels:", flips)
+    print(f"resnet18 pose network cfg={cfg} B={B}: loss {hip_loss:.6f} (oracle {o32['loss']:.6f}), grad norm {hip_norm:.4f} ({o32['gnorm']:.4f}), "
+          f"worst gradient rel {worst[0]:.1e} ({worst[1]}), largest parameter distance after the step {worst_move / lr:.2f} lr")
+    assert len(flips) <= 4, flips
     assert not bad, bad[:8]
 
 
