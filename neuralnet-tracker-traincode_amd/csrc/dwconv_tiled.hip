@@ -45,7 +45,12 @@ struct DwTiling {
   int NI;                             // images per tile (> 1 only when one band covers the image: the 9x9 and 5x5 layers)
   int stage_rows;                     // LDS rows of one image's stage
   int NCT, TW;                        // column tiles per band and their width (stride 1, wide images); else 1, full width
+  int carry;                          // forward only: a workgroup walks CONSECUTIVE bands of an image and keeps their shared rows in LDS
 };
+#ifndef TTK_DW_CARRY
+#define TTK_DW_CARRY 1
+#endif
+constexpr int kCarryRegs = 5;  // float4 registers per thread that hand the shared rows from one band to the next
 
 constexpr int kColTileMinW = 48;  // images at least this wide (the 65x65 layer) are tiled in columns too
 constexpr int kColTile = 17;      // 19 x 19 staged pixels for 17 x 17 results: halo 1.25x instead of 1.7x for 3-row bands
@@ -68,7 +73,12 @@ inline DwTiling dw_tiling_sl(int B, int H, int W, int C, int stride, bool backwa
   t.NCT = 1;
   t.TW = Wo;
   static const int col_tile = [] { const char* e = exp_env("TTK_DW_COLTILE"); return e ? atoi(e) : kColTile; }();  // (experiments)
-  if (stride == 1 && W >= kColTileMinW && col_tile < W) {
+  // Forward, images of several full-width bands (65 x 65, 33 x 33): the 3 - stride input rows two neighbouring bands share are staged
+  // ONCE - a workgroup takes a contiguous run of bands and carries those rows over in LDS - so the tensor is read exactly once
+  // (column tiles of 17 x 17 results staged 19 x 19 = 1.25 x; full-width bands without the carry 5 rows for 3 = 1.67 x; PMC of
+  // round 3: 480 MB for 404 on the stride-1 kernel, 833 for 696 on the stride-2 65 x 65 x 64 layer).
+  t.carry = TTK_DW_CARRY && !backward && (3 - stride) * (W + 2) * (SL / 4) <= kCarryRegs * kBlock;
+  if (!t.carry && stride == 1 && W >= kColTileMinW && col_tile < W) {
     t.NCT = (W + col_tile - 1) / col_tile;
     t.TW = (W + t.NCT - 1) / t.NCT;
   }
@@ -81,6 +91,7 @@ inline DwTiling dw_tiling_sl(int B, int H, int W, int C, int stride, bool backwa
   // is 49 staged pixels - a fraction of one pass of the 256 threads between two barriers; seven of them fill the
   // stage buffer, the lanes and the memory pipeline.
   t.NI = 1;
+  if (t.nbands == 1) t.carry = 0;
   if (t.nbands == 1 && t.NCT == 1) {
     const int per_image = t.stage_rows * ((backward ? Wo : W) + 2);
     t.NI = lds_pix_budget(SL) / per_image;
@@ -190,13 +201,13 @@ __device__ __forceinline__ void slab_partials(D4 s1, D4 s2, int q, int C, int c_
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-template <int S, typename T, bool SKIP, int SL>
+template <int S, typename T, bool SKIP, int SL, bool CARRY>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3)))
 dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
                                                           const T* __restrict__ skip_prev, T* __restrict__ a_out,
                                                           const float* __restrict__ w, T* __restrict__ y,
                                                           float* __restrict__ part, const float* __restrict__ pivot, int B, int H, int W, int C,
-                                                          int Ho, int Wo, int R, int nbands, int nslabs, int NI, int NCT, int TW) {
+                                                          int Ho, int Wo, int R, int nbands, int nslabs, int NI_, int NCT_, int TW) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [NI][stage_rows][tile width + 2][SL] + reduction scratch
   constexpr int kSlab = SL, kSlabQuads = SL / 4, kPixSlots = kBlock / kSlabQuads, kQs = ilog2(kSlabQuads), kPs = ilog2(SL);
   const int tid = threadIdx.x, q = tid & (kSlabQuads - 1), slot = tid >> kQs;
@@ -208,8 +219,18 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
   const BnApply4 bn = BnApply4::load(bn_prev, C, c0);
   const float4 pv = pivot ? ld4(pivot + c0) : f4(0.f);  // the partial sums are those of y - pivot (ttk.h)
   D4 s1{0.0, 0.0, 0.0, 0.0}, s2{0.0, 0.0, 0.0, 0.0};
+  const int NI = CARRY ? 1 : NI_, NCT = CARRY ? 1 : NCT_;  // (carry mode: one image per tile, full-width bands - constants for the compiler)
+  constexpr bool carry = CARRY;
   const unsigned tiles = (unsigned)((B + NI - 1) / NI) * nbands * NCT;  // (< 2^31: checked by the host)
-  for (unsigned t = blockIdx.x / nslabs; t < tiles; t += gridDim.x / nslabs) {
+  // Tile order.  Default: workgroup r of a slab takes tiles r, r + rows, ...  Carry mode (full-width bands of a several-band image, NI =
+  // NCT = 1): a CONTIGUOUS run of tiles, i.e. consecutive bands of an image, whose 3 - S shared input rows go from one band's stage to
+  // the next through registers instead of being read again.
+  const unsigned wgs = gridDim.x / nslabs, wg = blockIdx.x / nslabs;
+  const unsigned t_begin = carry ? (unsigned)((uint64_t)tiles * wg / wgs) : wg, t_end = carry ? (unsigned)((uint64_t)tiles * (wg + 1) / wgs) : tiles;
+  const unsigned t_step = carry ? 1u : wgs;
+  int prev_img = -1, prev_band = -2, prev_nrows = 0;
+  constexpr int OV = 3 - S;  // input rows two neighbouring bands share
+  for (unsigned t = t_begin; t < t_end; t += t_step) {
     const unsigned tb = t / (unsigned)NCT, ti = tb / (unsigned)nbands;
     const int ct = (int)(t - tb * NCT), band = (int)(tb - ti * nbands), n0 = (int)ti * NI;  // NI > 1 implies one tile per image
     const int nimg = min(NI, B - n0);
@@ -230,12 +251,31 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
     const T* sktile = SKIP ? skip_prev + tin : nullptr;
     T* aotile = a_out ? a_out + tin : nullptr;
     T* youttile = y + tout;
-    __syncthreads();  // previous tile's readers are done
-    // ---- stage: a_in rows i0 .. i0+nrows-1, columns -1 .. W (zero outside the image) of nimg images.  Several
+    // carry mode: rows i0 .. i0 + OV - 1 of this band are the last OV staged rows of the previous one
+    const int ov = (carry && (int)ti == prev_img && band == prev_band + 1) ? OV : 0;
+    // a materialised block input (a_out) is stored by whoever STAGES a row: the row below this band too when the next band will take it over
+    const int own_hi = (carry && t + 1 < t_end && band + 1 < nbands) ? i0 + nrows : o1;
+    float4 cr[kCarryRegs];
+    const int ncopy = ov * Wp * kSlabQuads;
+    if (ov) {
+      const float* src = lds + (size_t)(prev_nrows - OV) * Wp * kSlab;
+#pragma unroll
+      for (int u = 0; u < kCarryRegs; ++u)
+        if (tid + u * kBlock < ncopy) cr[u] = ld4(src + (size_t)(tid + u * kBlock) * 4);
+    }
+    prev_img = (int)ti; prev_band = band; prev_nrows = nrows;
+    __syncthreads();  // previous tile's readers are done (and the rows to carry over are in registers)
+    if (ov) {
+#pragma unroll
+      for (int u = 0; u < kCarryRegs; ++u)
+        if (tid + u * kBlock < ncopy) st4(lds + (size_t)(tid + u * kBlock) * 4, cr[u]);
+    }
+    // ---- stage: a_in rows i0 + ov .. i0+nrows-1, columns -1 .. W (zero outside the image) of nimg images.  Several
     // elements per thread and iteration so that their loads are in flight together (the staging phase is where this
     // kernel touches HBM).
-    const int nstage = nimg * (int)PI * kSlabQuads;
-    constexpr int kFwdU = SKIP ? kFwdUSkip : (S == 2 ? kFwdUPlain2 : kFwdUPlain);
+    const int nstage = nimg * ((int)PI - ov * Wp) * kSlabQuads;
+    const unsigned ovpix = (unsigned)(ov * Wp);
+    constexpr int kFwdU = SKIP ? kFwdUSkip : (S == 2 ? kFwdUPlain2 : (CARRY ? kFwdUPlain - 1 : kFwdUPlain));  // (carry mode holds five more float4 across the barrier)
     for (int e = tid; e < nstage; e += kFwdU * kBlock) {
       float4 yv[kFwdU], sk[SKIP ? kFwdU : 1];
       unsigned off[kFwdU];
@@ -244,12 +284,12 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
 #pragma unroll
       for (int u = 0; u < kFwdU; ++u) {
         const int ee = e + u * kBlock;
-        const unsigned pxa = (unsigned)ee >> kQs;            // pixel slot in LDS over all images of the tile
+        const unsigned pxa = ((unsigned)ee >> kQs) + ovpix;  // pixel slot in LDS over all images of the tile (carry mode: behind the rows taken over)
         const unsigned img = NI > 1 ? dPI.div(pxa) : 0u, px = NI > 1 ? pxa - __umul24(img, PI) : pxa;
         const unsigned prow = dWp.div(px);
         const int col = (int)(px - __umul24(prow, (unsigned)Wp)) - 1 + cx0, row = i0 + (int)prow;
         pxs[u] = (int)pxa;
-        rows[u] = (row >= o0 && row < o1 && col >= cx0 && col < cx0 + tw) ? 1 : 0;  // the one tile this input pixel belongs to
+        rows[u] = (row >= o0 && row < own_hi && col >= cx0 && col < cx0 + tw) ? 1 : 0;  // the one tile this input pixel belongs to
         in[u] = ee < nstage && row >= 0 && row < H && col >= 0 && col < W;
         off[u] = in[u] ? ((__umul24(__umul24(img, (unsigned)H) + (unsigned)row, (unsigned)W) + (unsigned)col) << cshift) + 4 * q : 0u;  // qq == q: kBlock is a multiple of 8
         yv[u] = in[u] ? Act<T>::ldnt(ytile + off[u]) : f4(0.f);
@@ -496,10 +536,10 @@ int ttk_dwconv3x3_fwd(const void* yprev, const float* bn_prev, const void* skip_
   TTK_REQUIRE((int64_t)((B + t.NI - 1) / t.NI) * t.nbands * t.NCT < ((int64_t)1 << 31), "dwconv3x3_fwd: too many tiles for 32-bit indexing");
   const size_t stage = (size_t)t.NI * t.stage_rows * ((t.NCT > 1 ? t.TW : W) + 2) * t.SL;
   const size_t sm = (stage + 16 * t.SL) * sizeof(float);  // + [4][2][SL] doubles of reduction scratch
-#define TTK_DW_FWD_SL(S_, SK_, SL_)                                                                                                     \
-  hipLaunchKernelGGL((dw_fwd_tiled_k<S_, ActT, SK_, SL_>), dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, (const ActT*)yprev, bn_prev, \
+#define TTK_DW_FWD_SL(S_, SK_, SL_, CY_)                                                                                                     \
+  hipLaunchKernelGGL((dw_fwd_tiled_k<S_, ActT, SK_, SL_, CY_>), dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, (const ActT*)yprev, bn_prev, \
                      (const ActT*)skip_prev, (ActT*)a_out, w, (ActT*)y, part, pivot, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI, t.NCT, t.TW)
-#define TTK_DW_FWD(S_, SK_) TTK_DW_FWD_SL(S_, SK_, kCB)
+#define TTK_DW_FWD(S_, SK_) do { if (t.carry) TTK_DW_FWD_SL(S_, SK_, kCB, true); else TTK_DW_FWD_SL(S_, SK_, kCB, false); } while (0)
   TTK_ACT_DISPATCH(act_bf16, if (stride == 1) { if (skip_prev) TTK_DW_FWD(1, true); else TTK_DW_FWD(1, false); }
                              else { if (skip_prev) TTK_DW_FWD(2, true); else TTK_DW_FWD(2, false); });
 #undef TTK_DW_FWD

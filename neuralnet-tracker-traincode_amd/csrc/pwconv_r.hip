@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
 #pragma unroll
     for (int i = 0; i < AP; ++i) live |= (m0 + row0 + 32 * i < m_end ? 1u : 0u) << i;
     // element offset of pass 0 inside the tile's run of a channel block (ttk_common.h act_off); pass i is 32 rows = 32 kCB elements
-    // further; rows past the block read pass 0's address (always inside: RT >= 32) and become ZERO fragments below
+    // further; rows past the block (the tensor's last tile may hold fewer than 32) read row 0 of the tile and become ZERO fragments below
     const unsigned aoff0 = (unsigned)(row0 * kCB + kq8 * 4);
     const float* cq = cst + kq8 * 4;
     unsigned char* wbase = lds + sub * kStr + o8;
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(768) pw16r_k(const TO* __restrict__ A0, const 
           ra0[slot][u] = t0;
           ra1[slot][FWD ? 0 : u] = t1;
         } else {
-          const unsigned o = ((live >> i) & 1u) ? aoff0 + (unsigned)(i * 32 * kCB) : aoff0;
+          const unsigned o = ((live >> i) & 1u) ? aoff0 + (unsigned)(i * 32 * kCB) : (unsigned)(kq8 * 4);  // (dead rows - pass 0's too - read row 0 of the tile)
           ra0[slot][u] = rbuf_ld4<TO>(r0, o);
           if constexpr (!FWD) ra1[slot][u] = rbuf_ld4<T>(r1, o);
         }

@@ -38,7 +38,13 @@ SHAPES = [(4, 9, 9, 64, 1, True),     # 3 images per tile, ragged last tile
           (2, 33, 33, 64, 2, False),  # stride 2, odd size
           (3, 10, 12, 32, 2, False),  # stride 2, even sizes
           (6, 9, 9, 128, 2, False),   # stride 2, several images per tile
-          (1, 17, 17, 256, 1, True)]
+          (1, 17, 17, 256, 1, True),
+          # more bands than resident workgroups: a workgroup of the forward walks CONSECUTIVE bands of an image and carries their
+          # shared input rows over in LDS (round 4), across image boundaries too; a_out rows are stored by whoever stages them
+          (40, 65, 65, 32, 1, True),
+          (40, 65, 65, 32, 2, False),
+          (100, 33, 33, 64, 1, True),
+          (90, 33, 33, 64, 2, False)]
 
 
 @pytest.mark.parametrize("B,H,W,C,stride,skip", SHAPES)

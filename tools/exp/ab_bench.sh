@@ -8,7 +8,7 @@ for rep in 1 2; do
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 k = d['kernels_ms_per_step']
-print('$v', round(d['value']), 'crops/s', d['ms_per_step'], 'ms', {n: k[n] for n in k if n.startswith('pw16')})" >> $O/ab.txt
+print('$v', round(d['value']), 'crops/s', d['ms_per_step'], 'ms', {n: k[n] for n in k if n.startswith('dw_') or n.startswith('pw16m')})" >> $O/ab.txt
   done
 done
 cat $O/ab.txt
