@@ -22,6 +22,7 @@ for leg in mn:B512 256:B256 rn:resnet18_B512 bf:B512_bf16; do
 done
 python tools/pmc_summary.py $(find $OUT/pmc_f -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_w -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json $(find $OUT/pmc_l2 -name "*counter_collection.csv" | head -1) > /dev/null
 rm -rf $OUT/prof_mn $OUT/prof_256 $OUT/prof_rn $OUT/prof_bf $OUT/pmc_f $OUT/pmc_w $OUT/pmc_l2
+# (the summary carries the csrc_sha256 of this tree; bench.py also finds it by itself once it is copied to profiles/r0N_pmc_traffic.json)
 python3 bench.py --steps 30 --warmup 5 --traffic-json $OUT/pmc_traffic.json > $OUT/bench_B512.json 2>/dev/null
 python3 bench.py --batch 256 --steps 30 --warmup 5 > $OUT/bench_B256.json 2>/dev/null
 python3 bench.py --backbone resnet18 --steps 20 --warmup 5 > $OUT/bench_resnet18_B512.json 2>/dev/null
