@@ -193,7 +193,7 @@ struct RGeo {
 
 // ---------------- epilogue of a tile, all NW waves: the tile leaves through LDS in TM chunks of CH rows (block c of every MFMA wave) -
 // un-scale, 16-byte stores (a wave writes 1 KB row segments), the data gradient's ReLU mask, BatchNorm sums ----------------
-template <int RBLK, int MODE, int NW, typename T, typename TO, typename Acc>
+template <int RBLK, int MODE, int NW, typename T, typename TO, typename Acc, bool M16 = false>
 __device__ __forceinline__ void r_epilogue(unsigned char* lds, Acc& acc, TO* __restrict__ out, const T* __restrict__ E0, const float* __restrict__ bnE,
                                            float* __restrict__ part, int64_t M, int Nout, int64_t m0, int64_t m_end, int n0, unsigned by, float sa, float sb) {
   using G = RGeo<RBLK>;
@@ -250,10 +250,20 @@ __device__ __forceinline__ void r_epilogue(unsigned char* lds, Acc& acc, TO* __r
     constexpr int c = decltype(cc)::value;
     if (wave < 8) {
       const int lane = tid & 63, wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+      if constexpr (M16) {  // acc[2 TM][2 TN] of 16 x 16 blocks (four registers: row 4 (lane >> 4) + i, column lane & 15)
+        const int r16 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+          for (int j = 0; j < 2 * TN; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Cs[(wm * 32 + s_ * 16 + 4 * g4 + i) * LDC + wn * (32 * TN) + j * 16 + r16] = acc[2 * c + s_][j][i];
+      } else {
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) Cs[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * (32 * TN) + j * 32 + r] = acc[c][j][e];
+      }
     }
     if constexpr (c == 0) e_load(std::integral_constant<int, 0>{});
     __syncthreads();  // chunk c is in LDS
@@ -629,7 +639,14 @@ struct MGeo {
   static constexpr int kSmem = G::kRing + G::kCst > kEpi ? G::kRing + G::kCst : kEpi;
 };
 
-template <int RBLK, int MODE, typename T, typename TO>
+#ifndef TTK_M_M16
+#define TTK_M_M16 1
+#endif
+// M16 (default): the products on v_mfma_f32_16x16x32_f16 - a k32 step in ONE instruction per 16 x 16 block, same LDS image, same fragment
+// reads, same cycles per flop as 32x32x16 - for two reasons: the 16-row blocks that lie wholly behind the end of the row block are
+// skipped (RT = 162 of a 192-row tile: the last of the twelve, i.e. 8 % of the matrix work), and the guide measures the 16 x 16 shape at a
+// higher clock under the power limit.  Measured: data gradient of 512 x 512 99.9 -> 97.2 us before the skip (profiles/r04_rowblock_gemm_variants.txt)
+template <int RBLK, int MODE, typename T, typename TO, bool M16>
 __global__ void __launch_bounds__(512) pw16m_k(const TO* __restrict__ A0, const T* __restrict__ A1, const float* __restrict__ bnA,
                                                const uint16_t* __restrict__ Bq, const float* __restrict__ wmax, TO* __restrict__ out,
                                                const T* __restrict__ E0, const float* __restrict__ bnE, float* __restrict__ part, int64_t M,
@@ -652,7 +669,8 @@ __global__ void __launch_bounds__(512) pw16m_k(const TO* __restrict__ A0, const 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float sa = pow2_scale(bnA[(size_t)TTK_BN_AUX * K + (FWD ? TTK_AUX_ACT_BOUND : TTK_AUX_DY_BOUND)]);
   const float sb = pow2_scale(*wmax);
-  f32x16 acc[TM][TN];
+  f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
+  f32x4 acc16[M16 ? 2 * TM : 1][M16 ? 2 * TN : 1];
   // per-channel constants of the A operand, once per tile: [scale S_a | mean | beta S_a] (forward), [ga S_a | gmean | gb S_a | mean] (data gradient)
   float* cst = reinterpret_cast<float*>(lds + G::kRing);
   {
@@ -761,13 +779,30 @@ __global__ void __launch_bounds__(512) pw16m_k(const TO* __restrict__ A0, const 
   for (int x = 0; x < TH; ++x) hold_off[x] = HOLD_A ? rswz(wm * (32 * TM) + x * 32 + r, h) : 2 * APL + rswz(wn * (32 * TN) + x * 32 + r, h);
 #pragma unroll
   for (int x = 0; x < TS; ++x) strm_off[x] = HOLD_A ? 2 * APL + rswz(wn * (32 * TN) + x * 32 + r, h) : rswz(wm * (32 * TM) + x * 32 + r, h);
+  if constexpr (!M16) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * TN; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   f16x8 hold[TH][2] = {}, strm[2][2] = {};
+  // 16 x 16 x 32 fragments: lane l holds row l & 15, k = 8 (l >> 4) .. + 7 of the k32 step: k16 stage (l >> 5), 16-byte chunk (l >> 4) & 1
+  int a16_off[M16 ? 2 * TM : 1], b16_off[M16 ? 2 * TN : 1];
+  const int live_rows16 = (int)(m_end - m0) - wm * (32 * TM);  // rows of this wave's strip inside the row block
+  if constexpr (M16) {
+    const int r16 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i) a16_off[i] = (g4 >> 1) * kStr + rswz(wm * (32 * TM) + i * 16 + r16, g4 & 1);
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j) b16_off[j] = (g4 >> 1) * kStr + 2 * APL + rswz(wn * (32 * TN) + j * 16 + r16, g4 & 1);
+  }
   // LDS-DMA of the weight planes (as pw16r_k): wave w moves pieces 4 w .. 4 w + 3 of a k32 step - k16 stage w >> 2, plane (w >> 1) & 1,
   // rows 128 (w & 1) .. + 127 - right after the barrier that freed the slot, and waits for them before the barrier that publishes it.
   const int64_t bplane = (int64_t)K * Nout;
@@ -839,6 +874,43 @@ __global__ void __launch_bounds__(512) pw16m_k(const TO* __restrict__ A0, const 
       conv_ks = it + 1;
       if constexpr (FWD) conv_consts(it + 1);
     }
+    if constexpr (M16) {
+      // hold the B fragments of the step (2 TN blocks x 2 pieces), stream the A fragments one 16-row block ahead
+      f16x8 hb[2 * TN][2], sa16[2][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j) hb[j][p] = rd(S0, BPL, b16_off[j], p);
+        sa16[0][p] = rd(S0, APL, a16_off[0], p);
+      }
+      static_for<2 * TM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, cur = i & 1;
+        if constexpr (i + 1 < 2 * TM) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) sa16[cur ^ 1][p] = rd(S0, APL, a16_off[i + 1], p);
+        }
+        const bool blk_live = i * 16 < live_rows16;  // (uniform) a 16-row block wholly behind the end of the row block holds zeros: no products
+        static_for<2 * TN>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if constexpr (kRDbg & 4) {
+            asm volatile("" ::"v"(sa16[cur][0]), "v"(hb[j][0]));
+          } else {
+            if (blk_live) {
+              acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sa16[cur][0], hb[j][1], acc16[i][j], 0, 0, 0);
+              acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sa16[cur][1], hb[j][0], acc16[i][j], 0, 0, 0);
+              acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sa16[cur][0], hb[j][0], acc16[i][j], 0, 0, 0);
+            }
+          }
+          constexpr int q = i * (2 * TN) + j;  // MFMA triple of the step: 4 RBLK of them, a conversion part behind every fourth
+          if constexpr (CONV && (q & 3) == 3) {
+            conv_part(SN{}, SN{}, std::integral_constant<int, (q >> 2)>{});
+#if TTK_M_FENCE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+          }
+        });
+      });
+    } else {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
 #pragma unroll
@@ -887,6 +959,7 @@ __global__ void __launch_bounds__(512) pw16m_k(const TO* __restrict__ A0, const 
         });
       });
     });
+    }
 #if defined(TTK_R_STAMP)
     TTK_STAMP(st_x);
 #endif
@@ -920,7 +993,8 @@ __global__ void __launch_bounds__(512) pw16m_k(const TO* __restrict__ A0, const 
   TTK_STAMP(st_loop1);
 #endif
 #undef TTK_RB
-  r_epilogue<RBLK, MODE, 8, T, TO>(lds, acc, out, E0, bnE, part, M, Nout, m0, m_end, n0, by, sa, sb);
+  if constexpr (M16) r_epilogue<RBLK, MODE, 8, T, TO, decltype(acc16), true>(lds, acc16, out, E0, bnE, part, M, Nout, m0, m_end, n0, by, sa, sb);
+  else r_epilogue<RBLK, MODE, 8, T, TO>(lds, acc, out, E0, bnE, part, M, Nout, m0, m_end, n0, by, sa, sb);
 #if defined(TTK_R_STAMP)
   {
     unsigned long long st_t1, st_r1;
@@ -1449,7 +1523,7 @@ bool launch_f16r_gemm(const TO* A0, const T* A1, const float* bnA, const float* 
   const RPlan pl = r_plan(M, K, Nout);
   const unsigned tiles = (unsigned)pl.row_blocks * (Nout / kRBN);
 #define TTK_M_LAUNCH(RBLK_) \
-  hipLaunchKernelGGL((pw16m_k<RBLK_, MODE, T, TO>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout, pl.rt)
+  hipLaunchKernelGGL((pw16m_k<RBLK_, MODE, T, TO, (TTK_M_M16 != 0)>), dim3(tiles), dim3(512), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout, pl.rt)
 #define TTK_R_LAUNCH(RBLK_) \
   hipLaunchKernelGGL((pw16r_k<RBLK_, MODE, T, TO>), dim3(tiles), dim3(768), 0, st, A0, A1, bnA, Bq, wmax, out, E0, bnE, part, M, K, Nout, pl.rt)
   // Which form runs what, from same-box runs of the whole step (profiles/r04_rowblock_gemm_variants.txt): the eight-wave form takes the
