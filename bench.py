@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="crops per GPU")
     ap.add_argument("--backbone", default="mobilenetv1", choices=["mobilenetv1", "resnet18"])
+    ap.add_argument("--blurpool", action="store_true", help="the training script's --blurpool: BlurPool2D + stride-1 depthwise conv in the strided MobileNet blocks")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16-all"],
                     help="BASELINE config 5's storage variant (separate line, dtype bf16; mobilenetv1 only): bf16 = activations bf16 in HBM, their "
                     "gradients fp32; bf16-all = both bf16")
@@ -205,7 +206,7 @@ def build_step(args, device):
 
     torch.manual_seed(0)
     net = NetworkWithPointHead(enable_point_head=True, enable_uncertainty=False, config=args.backbone,
-                               backbone_args={"use_blurpool": False})
+                               backbone_args={"use_blurpool": args.blurpool})
     g = torch.Generator().manual_seed(7)  # synthetic 3DMM keypoint basis (the real blob is not in the reference)
     net.landmarks.deformablekeypoints.set_basis(torch.randn(68, 3, generator=g) * 0.5, torch.randn(50, 68, 3, generator=g) * 0.05)
     net = net.to(device).train()
@@ -276,7 +277,11 @@ def cpu_baseline(args):
     n = args.cpu_threads or min(os.cpu_count() or 1, 32)
     torch.set_num_threads(n)
     B = args.cpu_batch
-    shapes = R.state_shapes(True, False)
+    if args.backbone == "resnet18":  # the heads on 512 features + the ResNet-18 backbone under "convnet."
+        heads = {k: v for k, v in R.state_shapes(True, False, num_features=512).items() if not k.startswith("convnet.")}
+        shapes = {**R.resnet18_state_shapes(prefix="convnet."), **heads}
+    else:
+        shapes = R.state_shapes(True, False, use_blurpool=args.blurpool)
     st = R.state_from_numpy(make_state(shapes, 0))
     image, ids = make_inputs(B, seed=1, structured=False)
     lab = make_labels(B, seed=1)
@@ -284,7 +289,7 @@ def cpu_baseline(args):
     crit, _ = R.setup_losses(with_pointhead=True, with_nll_loss=False, gmm=gmm)
     batch = [dict(tag="POSE_WITH_LANDMARKS", n=B, **{k: torch.from_numpy(v) for k, v in lab.items() if k != "dataset_weight"})]
     x, idt = torch.from_numpy(image), torch.from_numpy(ids)
-    cfg = dict(enable_point_head=True, enable_uncertainty=False)
+    cfg = dict(enable_point_head=True, enable_uncertainty=False, config=args.backbone)
 
     def step():
         for v in st.values():
@@ -500,7 +505,7 @@ def main():
             "metric": f"face-crops/sec fwd+bwd @ batch {args.batch}", "value": crops, "unit": "crops/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
-            "config": {"workload": f"NetworkWithPointHead({args.backbone}, point head on, NLL off = training-script defaults): "
+            "config": {"workload": f"NetworkWithPointHead({args.backbone}{', --blurpool' if args.blurpool else ''}, point head on, NLL off = training-script defaults): "
                                    "zero_grad + fwd + multi-task loss + bwd" + (" + RCCL grad all-reduce overlapped with bwd" if world > 1 else "") + " + fused clip/Adam step",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "input": "129x129x1 f32",
                        "parallelism": f"dp{world}"},

@@ -28,6 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _hip
+from ..neuralnets.modelcomponents import BlurPool2D
 
 __all__ = ["MobileNet", "DepthWiseBlock"]
 
@@ -53,20 +54,27 @@ class DepthWiseBlock(nn.Module):
         assert stride in (1, 2)
         self.inplanes, self.planes = inplanes, planes = int(inplanes), int(planes)
         self.stride = stride
-        if stride == 2 and use_blurpool:
-            raise NotImplementedError(
-                "use_blurpool=True (kornia BlurPool2D before strided depthwise convs) is not built: "
-                "off in every BASELINE config, parity unpinned (SURVEY.md §8c)"
-            )
         if stochastic_depth:
             raise NotImplementedError("stochastic_depth is never enabled by the reference's pose estimator")
-        self.conv_dw = nn.Conv2d(inplanes, inplanes, kernel_size=3, padding=1, stride=stride, groups=inplanes, bias=False)
+        self.blurpool = stride == 2 and bool(use_blurpool)
+        if self.blurpool:  # reference :43-55: blur + downsample, then the depthwise conv at stride 1 (state-dict names conv_dw.0.kernel, conv_dw.1.weight)
+            self.conv_dw = nn.Sequential(
+                BlurPool2D(kernel_size=3, stride=2, channels=inplanes),
+                nn.Conv2d(inplanes, inplanes, kernel_size=3, padding=1, stride=1, groups=inplanes, bias=False),
+            )
+        else:
+            self.conv_dw = nn.Conv2d(inplanes, inplanes, kernel_size=3, padding=1, stride=stride, groups=inplanes, bias=False)
         self.bn_dw = NormalizationLayer(inplanes, momentum=momentum)
         self.conv_sep = nn.Conv2d(inplanes, planes, kernel_size=1, stride=1, padding=0, bias=False)
         self.bn_sep = NormalizationLayer(planes, momentum=momentum)
         self.relu = nn.ReLU(inplace=True)
         self.skip_connection = not (stride != 1 or inplanes != planes)
         self.stochastic_depth = None
+
+    @property
+    def dw_weight(self):
+        """The trainable depthwise weight [C,1,3,3] (conv_dw.weight, or conv_dw.1.weight behind a BlurPool2D)."""
+        return self.conv_dw[1].weight if self.blurpool else self.conv_dw.weight
 
     def forward(self, x):  # eval/export path in plain torch ops (CPU); training goes through MobileNet
         out = self.relu(self.bn_dw(self.conv_dw(x)))
@@ -126,7 +134,7 @@ class _Stage(NamedTuple):
     skip: torch.Tensor | None  # residual input added before the ReLU of this stage's output
 
 
-def _part_buffer(B, H, W, device):
+def _part_buffer(B, H, W, device, blur=False):
     """One scratch buffer large enough for every layer's [rows][2][C] partial sums."""
     L = _hip.lib()
     need = 0
@@ -136,6 +144,8 @@ def _part_buffer(B, H, W, device):
         ho = (h - 1) // stride + 1
         need = max(need, L.partial_rows_dwconv(B, h, h, cin, stride, True) * 2 * cin)     # dw bwd-data
         need = max(need, L.partial_rows_dwconv(B, h, h, cin, stride, False) * 2 * cin)    # dw fwd
+        if blur and stride == 2:  # the stride-1 depthwise conv behind the blur
+            need = max(need, L.partial_rows_dwconv(B, ho, ho, cin, 1, False) * 2 * cin, L.partial_rows_dwconv(B, ho, ho, cin, 1, True) * 2 * cin)
         need = max(need, L.partial_rows_gemm(B * ho * ho, cin, cout) * 2 * cout, L.partial_rows_gemm(B * ho * ho, cout, cin, True) * 2 * cin)  # pw fwd / bwd-data
         need = max(need, L.partial_rows_elementwise(B * ho * ho * (cout // 4)) * 2 * cout)  # pool bwd
         h = ho
@@ -144,21 +154,40 @@ def _part_buffer(B, H, W, device):
 
 class _Ctx:
     """Everything one forward pass leaves behind for its backward."""
-    __slots__ = ("x", "stages", "a_in", "part", "dims", "pool_skip", "wparams", "HW", "B", "prep", "bf", "gdt", "frozen")
+    __slots__ = ("x", "stages", "a_in", "part", "dims", "pool_skip", "wparams", "HW", "B", "prep", "bf", "gdt", "frozen", "blur")
 
 
-def _forward_impl(x, params, buffers, momentum, eps, training, act_dtype=torch.float32, grad_dtype=torch.float32, frozen=False):
+_IDENTITY_BN: dict = {}
+
+
+def _identity_bn(C, device):
+    """A fresh constant block of the identity map (scale = rstd = 1, beta = mean = 0): the blurred tensor of a BlurPool block has
+    no BatchNorm of its own, but every consumer forms its input as relu(bn(y)) on load - relu(t) = t for a blur of
+    non-negative activations.  The backward rows (ga, gb, gmean) are written by ttk_bn_bwd_frozen."""
+    key = (device.type, device.index, C)
+    if key not in _IDENTITY_BN:
+        t = torch.zeros((_BN_ROWS, C), dtype=torch.float32, device=device)
+        t[0] = 1.0
+        t[3] = 1.0
+        _IDENTITY_BN[key] = t
+    return _IDENTITY_BN[key].clone()
+
+
+def _forward_impl(x, params, buffers, momentum, eps, training, act_dtype=torch.float32, grad_dtype=torch.float32, frozen=False, blur=None):
     """Launches the forward kernels.  `params`: flat list [conv1.w, bn1.w, bn1.b, (dw.w, bn_dw.w,
     bn_dw.b, pw.w, bn_sep.w, bn_sep.b) x 13]; `buffers`: flat list of (running_mean, running_var,
-    num_batches_tracked) per BN in the same order."""
+    num_batches_tracked) per BN in the same order; `blur`: per block, the BlurPool2D kernel as a depthwise weight
+    [Cin,1,3,3] (use_blurpool, strided blocks) or None."""
     L = _hip.lib()
     p = _hip.ptr
     dev = x.device
     B, _, H, W = x.shape
     Ho, Wo = (H + 1) // 2, (W + 1) // 2
-    part = _part_buffer(B, H, W, dev)
+    blur = list(blur) if blur is not None else [None] * len(_BLOCKS)
+    part = _part_buffer(B, H, W, dev, any(b is not None for b in blur))
     ctx = _Ctx()
     ctx.x, ctx.part, ctx.B = x, part, B
+    ctx.blur = []
     ctx.frozen = frozen  # backward through eval-mode BatchNorm: the fixed affine map (ttk_bn_bwd_frozen)
     ctx.stages, ctx.a_in, ctx.dims = [], [], []
     bf = int(act_dtype == torch.bfloat16) | (2 if grad_dtype == torch.bfloat16 else 0)  # TTK_STORE_* bits
@@ -205,10 +234,24 @@ def _forward_impl(x, params, buffers, momentum, eps, training, act_dtype=torch.f
         ho, wo = (h - 1) // stride + 1, (w_ - 1) // stride + 1
         a_in = torch.empty_like(prev.y) if has_skip else None
         ydw = torch.empty((B, ho, wo, cin), dtype=act_dtype, device=dev)
-        L.call("ttk_dwconv3x3_fwd", p(prev.y), p(prev.bn), p(prev.skip), p(a_in), p(w_dw), p(ydw), part_arg, pivot(bi), B, h, w_, cin,
-               stride, bf)
+        k = len(ctx.dims)
+        if blur[k] is not None:
+            # reference :43-55 - BlurPool2D (binomial 3x3, stride 2) then the depthwise conv at stride 1: two launches of the
+            # same depthwise kernel; the blurred tensor crosses HBM once with the identity constant block (its partial sums
+            # are written to the scratch rows and overwritten by the next launch)
+            t = torch.empty((B, ho, wo, cin), dtype=act_dtype, device=dev)
+            L.call("ttk_dwconv3x3_fwd", p(prev.y), p(prev.bn), p(prev.skip), None, p(blur[k]), p(t), part_arg, None, B, h, w_, cin, stride, bf)
+            st_t = _Stage(t, _identity_bn(cin, dev), None)
+            L.call("ttk_dwconv3x3_fwd", p(t), p(st_t.bn), None, None, p(w_dw), p(ydw), part_arg, pivot(bi), B, ho, wo, cin, 1, bf)
+            dw_rows = L.partial_rows_dwconv(B, ho, wo, cin, 1, False)
+            ctx.blur.append((st_t, blur[k]))
+        else:
+            L.call("ttk_dwconv3x3_fwd", p(prev.y), p(prev.bn), p(prev.skip), p(a_in), p(w_dw), p(ydw), part_arg, pivot(bi), B, h, w_, cin,
+                   stride, bf)
+            dw_rows = L.partial_rows_dwconv(B, h, w_, cin, stride, False)
+            ctx.blur.append(None)
         bn_dw = bns.take(cin)
-        finalize(bn_dw, L.partial_rows_dwconv(B, h, w_, cin, stride, False), cin, B * ho * wo, g_dw, b_dw, bi)
+        finalize(bn_dw, dw_rows, cin, B * ho * wo, g_dw, b_dw, bi)
         ypw = torch.empty((B, ho, wo, cout), dtype=act_dtype, device=dev)
         M = B * ho * wo
         L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(ypw), part_arg, pivot(bi + 1), M, cin, cout, p(ctx.prep[len(ctx.dims)]), bf)
@@ -288,6 +331,7 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         need = max(need, L.cdll.ttk_stem_wgrad_partial_bytes())
         need = max(need, max(L.cdll.ttk_pwconv1x1_bwd_fused_partial_bytes(B * d[2] * d[3], d[4], d[5]) for d in ctx.dims))
         need = max(need, max(L.partial_rows_dwconv(B, d[0], d[1], d[4], d[6], True) * 9 * d[4] * 4 for d in ctx.dims))
+        need = max([need] + [L.partial_rows_dwconv(B, d[2], d[3], d[4], 1, True) * 9 * d[4] * 4 for d, bl in zip(ctx.dims, ctx.blur) if bl is not None])
         wg_scratch = torch.empty(need // 4, dtype=torch.float32, device=gfeat.device)
     # the weight gradient of the wide pointwise layers (Cin, Cout multiples of 256) always reduces slice partials in a fixed order
     # (csrc/pwconv_r.hip: faster than float atomics for 256 x 256 tiles): its scratch, in every mode
@@ -340,8 +384,20 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         # -- depthwise: weight gradient, then data gradient (+ residual gradient, + producer's bn sums)
         dWd = grads[pi]  # accumulated by the fused weight-gradient path of bwd_data
         g_prev = torch.empty(st_prev.y.shape, dtype=ctx.gdt, device=st_prev.y.device)
-        L.call("ttk_dwconv3x3_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), p(g) if has_skip else None, p(st_prev.y),
-               p(st_prev.bn), p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 1, p(wg_scratch), B, h, w_, cin, stride, bf)
+        if ctx.blur[k] is not None:
+            # BlurPool block: through the stride-1 conv to the blurred tensor (its "BatchNorm" is the identity: ga = 1, gb = gmean = 0;
+            # the mask [t > 0] only drops gradient that the producer's own mask drops as well - t = 0 means every tap was 0), then
+            # through the fixed blur kernel (no weight gradient) to the block input
+            st_t, w_blur = ctx.blur[k]
+            g_t = torch.empty(st_t.y.shape, dtype=ctx.gdt, device=st_t.y.device)
+            L.call("ttk_dwconv3x3_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), None, p(st_t.y), p(st_t.bn), None, None, p(g_t),
+                   p(part), p(dWd), 1, p(wg_scratch), B, ho, wo, cin, 1, bf)
+            L.call("ttk_bn_bwd_frozen", p(st_t.bn), cin)
+            L.call("ttk_dwconv3x3_bwd_data", p(g_t), p(st_t.y), p(st_t.bn), p(w_blur), None, p(st_prev.y), p(st_prev.bn), p(st_prev.skip),
+                   None, p(g_prev), p(part), None, 0, None, B, h, w_, cin, stride, bf)
+        else:
+            L.call("ttk_dwconv3x3_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), p(g) if has_skip else None, p(st_prev.y),
+                   p(st_prev.bn), p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 1, p(wg_scratch), B, h, w_, cin, stride, bf)
         bwd_finalize(st_prev, L.partial_rows_dwconv(B, h, w_, cin, stride, True), B * h * w_, pi - 2 if k > 0 else 1)
         g = g_prev
         if grad_ready_hook is not None:  # this block's conv + bn_dw gradients and its own bn_sep gradients are final
@@ -363,8 +419,9 @@ class _MobileNetFn(torch.autograd.Function):
     """One autograd node for the whole backbone: saves raw conv outputs + BN constants."""
 
     @staticmethod
-    def forward(ctx, x, momentum, eps, buffers, frozen, *params):
-        feat, c = _forward_impl(x, params, buffers, momentum, eps, training=not frozen, act_dtype=_ACT_DTYPE, grad_dtype=_GRAD_DTYPE, frozen=frozen)
+    def forward(ctx, x, momentum, eps, buffers, frozen, blur, *params):
+        feat, c = _forward_impl(x, params, buffers, momentum, eps, training=not frozen, act_dtype=_ACT_DTYPE, grad_dtype=_GRAD_DTYPE, frozen=frozen,
+                                blur=blur)
         ctx.c = c
         ctx.nparams = len(params)
         ctx.save_for_backward(*params)
@@ -375,7 +432,7 @@ class _MobileNetFn(torch.autograd.Function):
         params = ctx.saved_tensors
         grads = _backward_impl(ctx.c, gfeat.contiguous(), params)
         ctx.c = None
-        return (None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, *grads)
 
 
 class MobileNet(nn.Module):
@@ -392,6 +449,7 @@ class MobileNet(nn.Module):
         def block(inplanes, planes, stride=1):
             return DepthWiseBlock(inplanes, planes, stride=stride, momentum=momentum, use_blurpool=use_blurpool)
 
+        self.use_blurpool = bool(use_blurpool)
         self.conv1 = nn.Conv2d(input_channel, 32, kernel_size=5, stride=2, padding=2, bias=False)
         self.bn1 = NormalizationLayer(32, momentum=momentum)
         self.relu = ActivationFunc(inplace=True)
@@ -421,8 +479,14 @@ class MobileNet(nn.Module):
         ps = [self.conv1.weight, self.bn1.weight, self.bn1.bias]
         for name, *_ in _BLOCKS:
             b = getattr(self, name)
-            ps += [b.conv_dw.weight, b.bn_dw.weight, b.bn_dw.bias, b.conv_sep.weight, b.bn_sep.weight, b.bn_sep.bias]
+            ps += [b.dw_weight, b.bn_dw.weight, b.bn_dw.bias, b.conv_sep.weight, b.bn_sep.weight, b.bn_sep.bias]
         return ps
+
+    def _blur_weights(self):
+        """Per block: the BlurPool2D kernel as a depthwise weight (use_blurpool, strided blocks) or None."""
+        if not self.use_blurpool:
+            return None
+        return [getattr(self, name).conv_dw[0].depthwise_weight() if getattr(self, name).blurpool else None for name, *_ in _BLOCKS]
 
     def _flat_buffers(self):
         out = []
@@ -447,7 +511,7 @@ class MobileNet(nn.Module):
         x = x.contiguous()
         bn_training = [bn.training for bn in self._bns()]
         if self.training and all(bn_training):
-            return _MobileNetFn.apply(x, momentum, eps, self._flat_buffers(), False, *self._flat_params())
+            return _MobileNetFn.apply(x, momentum, eps, self._flat_buffers(), False, self._blur_weights(), *self._flat_params())
         if any(bn_training):
             raise NotImplementedError("mixed train/eval BatchNorm layers are not supported by the fused backbone")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._flat_params()):
@@ -456,8 +520,8 @@ class MobileNet(nn.Module):
             if any(p.requires_grad for bn in self._bns() for p in bn.parameters()):
                 raise NotImplementedError("eval-mode BatchNorm layers with trainable weight / bias are not built: freeze them "
                                           "(modelcomponents.freeze_norm_stats) or put the layers in training mode")
-            return _MobileNetFn.apply(x, momentum, eps, self._flat_buffers(), True, *self._flat_params())
-        feat, _ = _forward_impl(x, [q.detach() for q in self._flat_params()], self._flat_buffers(), momentum, eps, False)
+            return _MobileNetFn.apply(x, momentum, eps, self._flat_buffers(), True, self._blur_weights(), *self._flat_params())
+        feat, _ = _forward_impl(x, [q.detach() for q in self._flat_params()], self._flat_buffers(), momentum, eps, False, blur=self._blur_weights())
         return feat
 
     def forward(self, x):
@@ -475,7 +539,7 @@ class MobileNet(nn.Module):
         momentum, eps = self._check(x)
         bufs = [b.clone() for b in self._flat_buffers()]  # do not double-update running statistics
         training = self.training
-        _, c = _forward_impl(x.contiguous(), [q.detach() for q in self._flat_params()], bufs, momentum, eps, training)
+        _, c = _forward_impl(x.contiguous(), [q.detach() for q in self._flat_params()], bufs, momentum, eps, training, blur=self._blur_weights())
         L, p = _hip.lib(), _hip.ptr
         outs = []
         for k, (name, *_r) in enumerate(_BLOCKS):

@@ -6,6 +6,7 @@ and provide the plain-torch form used for CPU eval/export and by evaluation scri
 """
 from __future__ import annotations
 
+import math
 import os
 from typing import Optional, Type
 
@@ -24,6 +25,33 @@ def set_bn_momentum(model: nn.Module, momentum):
     for m in model.modules():
         if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
             m.momentum = momentum
+
+
+class BlurPool2D(nn.Module):
+    """Blur + downsample (reference :187-205: kornia's blur pooling with an explicit channel count): a depthwise
+    convolution with the normalised binomial kernel (kernel_size 3: outer([1,2,1],[1,2,1]) / 16), zero padding
+    (kernel_size - 1) // 2 and the given stride.  Owns the reference's buffer `kernel` [k, k]; `depthwise_weight()` is the
+    same kernel as a [C,1,k,k] depthwise weight - the form csrc/dwconv_tiled.hip's kernels take on the MI355X (the strided
+    MobileNet blocks run the blur as one more 3x3 depthwise launch, backbones/mobilenet_v1.py).  `forward` is the plain
+    torch form for CPU eval / export."""
+
+    def __init__(self, kernel_size: int, channels: int, stride: int = 2):
+        super().__init__()
+        if not isinstance(kernel_size, int):
+            if kernel_size[0] != kernel_size[1]:
+                raise NotImplementedError("BlurPool2D: square kernels only")
+            kernel_size = int(kernel_size[0])
+        self.kernel_size, self.stride, self.channels = kernel_size, stride, channels
+        row = torch.tensor([float(math.comb(kernel_size - 1, i)) for i in range(kernel_size)], dtype=torch.float32)
+        k = row[:, None] * row[None, :]
+        self.register_buffer("kernel", k / k.sum())
+
+    def depthwise_weight(self) -> Tensor:
+        return self.kernel.repeat((self.channels, 1, 1, 1)).contiguous()
+
+    def forward(self, input: Tensor) -> Tensor:
+        return nn.functional.conv2d(input, self.depthwise_weight(), None, stride=self.stride,
+                                    padding=(self.kernel_size - 1) // 2, groups=self.channels)
 
 
 def freeze_norm_stats(m: nn.Module):

@@ -37,9 +37,10 @@ INTERMEDIATE_AFTER = ("dw2_1", "dw3_1", "dw4_1", "dw5_5", "dw6")  # mobilenet_v1
 # =============================================================================================
 # state handling
 # =============================================================================================
-def state_shapes(enable_point_head=True, enable_uncertainty=False, num_features=1024, enable_6drot=False) -> dict:
+def state_shapes(enable_point_head=True, enable_uncertainty=False, num_features=1024, enable_6drot=False, use_blurpool=False) -> dict:
     """Key -> shape inventory of NetworkWithPointHead("mobilenetv1") (SURVEY.md Appendix C;
-    neuralnets/models.py:262-307, backbones/mobilenet_v1.py:122-140)."""
+    neuralnets/models.py:262-307, backbones/mobilenet_v1.py:122-140).  use_blurpool: the strided blocks hold
+    conv_dw = Sequential(BlurPool2D, Conv2d) (mobilenet_v1.py:43-55): buffer conv_dw.0.kernel, weight conv_dw.1.weight."""
     s: dict[str, tuple] = {}
 
     def bn(prefix, c):
@@ -51,8 +52,12 @@ def state_shapes(enable_point_head=True, enable_uncertainty=False, num_features=
 
     s["convnet.conv1.weight"] = (32, 1, 5, 5)
     bn("convnet.bn1", 32)
-    for name, cin, cout, _ in MOBILENET_BLOCKS:
-        s[f"convnet.{name}.conv_dw.weight"] = (cin, 1, 3, 3)
+    for name, cin, cout, stride in MOBILENET_BLOCKS:
+        if use_blurpool and stride == 2:
+            s[f"convnet.{name}.conv_dw.0.kernel"] = (3, 3)
+            s[f"convnet.{name}.conv_dw.1.weight"] = (cin, 1, 3, 3)
+        else:
+            s[f"convnet.{name}.conv_dw.weight"] = (cin, 1, 3, 3)
         bn(f"convnet.{name}.bn_dw", cin)
         s[f"convnet.{name}.conv_sep.weight"] = (cout, cin, 1, 1)
         bn(f"convnet.{name}.bn_sep", cout)
@@ -88,7 +93,7 @@ def state_shapes(enable_point_head=True, enable_uncertainty=False, num_features=
     return s
 
 
-BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked", "min_diag", "keypts", "keyeigvecs")
+BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked", "min_diag", "keypts", "keyeigvecs", "kernel")
 
 
 def is_buffer(key: str) -> bool:
@@ -255,7 +260,17 @@ def mobilenet_forward(st, x: Tensor, training: bool, momentum: float = 0.1, pref
     inter = []
     for name, cin, cout, stride in MOBILENET_BLOCKS:
         b = p + name
-        y = F.conv2d(a, st[b + ".conv_dw.weight"], None, stride=stride, padding=1, groups=cin)
+        if b + ".conv_dw.0.kernel" in st:
+            # use_blurpool (mobilenet_v1.py:43-55; modelcomponents.py:187-205): BlurPool2D = kornia's _blur_pool_by_kernel2d
+            # (kornia is a requirements.txt dependency without a pinned version, absent from this image; its published form:
+            # conv2d with the binomial kernel repeated per channel, zero padding (k-1)//2, the stride, groups = C), then the
+            # depthwise conv at stride 1
+            t = F.conv2d(a, st[b + ".conv_dw.0.kernel"].repeat(cin, 1, 1, 1), None, stride=stride, padding=1, groups=cin)
+            if want_raw is not None:
+                want_raw[name + ".blur"] = t
+            y = F.conv2d(t, st[b + ".conv_dw.1.weight"], None, stride=1, padding=1, groups=cin)
+        else:
+            y = F.conv2d(a, st[b + ".conv_dw.weight"], None, stride=stride, padding=1, groups=cin)
         if want_raw is not None:
             want_raw[name + ".dw"] = y
         h = F.relu(_bn(y, st, b + ".bn_dw", training, momentum))

@@ -86,6 +86,14 @@ CONFIGS = {
              backbone_args={"use_blurpool": False}, enable_6drot=True),
         dict(with_pointhead=True, with_nll_loss=True, rampup_nll_losses=True, enable_6drot=True),
     ),
+    # --blurpool (scripts/train_poseestimator.py:294,402): BlurPool2D(3, stride 2) + stride-1 depthwise conv in the four
+    # strided blocks (backbones/mobilenet_v1.py:43-55).  The two kornia helpers behind BlurPool2D (kornia is absent here) are
+    # the restatements in ref_shims.py: binomial 3x3 kernel / 16, conv2d(padding 1, stride 2, groups C).
+    "blurpool": (
+        dict(enable_point_head=True, enable_uncertainty=False, config="mobilenetv1",
+             backbone_args={"use_blurpool": True}),
+        dict(with_pointhead=True, with_nll_loss=False, rampup_nll_losses=False, with_blurpool=True),
+    ),
 }
 
 

@@ -13,12 +13,12 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SCRIPT = r"""
-import sys, hashlib
+import os, sys, hashlib
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/neuralnet-tracker-traincode_amd"); sys.path.insert(0, sys.argv[1] + "/tests")
 import torch
 from util import build_net, load_golden, make_batches, script_args, train_script
 import trackertraincode.train as train
-d, meta = load_golden("model_full.npz")
+d, meta = load_golden(os.environ.get("TTK_TEST_GOLDEN", "model_full.npz"))
 meta = dict(meta, B=96, split=60)
 S = train_script()
 net = build_net(meta, "cuda").train()
@@ -41,8 +41,8 @@ print("STATE", h.hexdigest())
 """
 
 
-def _run(det):
-    env = dict(os.environ, TTK_DETERMINISTIC="1" if det else "0")
+def _run(det, golden="model_full.npz"):
+    env = dict(os.environ, TTK_DETERMINISTIC="1" if det else "0", TTK_TEST_GOLDEN=golden)
     out = subprocess.run([sys.executable, "-c", SCRIPT, REPO], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = {l.split()[0]: l.split()[1:] for l in out.stdout.splitlines() if l.startswith(("LOSSES", "STATE"))}
@@ -83,6 +83,13 @@ for rep in range(2):
         h.update(p_.grad.cpu().numpy().tobytes())
     print("HASH", h.hexdigest())
 """
+
+
+def test_blurpool_deterministic_mode_is_bitwise_reproducible():
+    """--blurpool: the extra depthwise launches (blur, stride-1 conv behind it) fold their weight gradient in the same fixed order."""
+    l1, s1 = _run(True, "model_blurpool.npz")
+    l2, s2 = _run(True, "model_blurpool.npz")
+    assert l1 == l2 and s1 == s2
 
 
 def test_resnet18_deterministic_mode_is_bitwise_reproducible():

@@ -72,11 +72,11 @@ def _check(net, sd, forward, F, B, prefix):
     return n
 
 
-@pytest.mark.parametrize("B", [3, 8])
-def test_mobilenet_frozen_batchnorm_backward(B):
+@pytest.mark.parametrize("B,blur", [(3, False), (8, False), (8, True)])
+def test_mobilenet_frozen_batchnorm_backward(B, blur):
     from trackertraincode.backbones.mobilenet_v1 import MobileNet
-    shapes = {k: v for k, v in R.state_shapes(False, False).items() if k.startswith("convnet.")}
-    net = MobileNet(num_classes=None).cuda()
+    shapes = {k: v for k, v in R.state_shapes(False, False, use_blurpool=blur).items() if k.startswith("convnet.")}
+    net = MobileNet(num_classes=None, use_blurpool=blur).cuda()
     assert _check(net, _state(shapes, 2), R.mobilenet_forward, 1024, B, "convnet.") == 27
 
 

@@ -42,7 +42,21 @@ def test_state_dict_inventory(unc, pt):
     assert net.name == "NetworkWithPointHead_mobilenetv1" and net.input_resolution == 129 and net.input_resolutions == (129,)
 
 
-@pytest.mark.parametrize("cfg", ["full", "posonly"])
+def test_state_dict_inventory_blurpool():
+    """--blurpool: conv_dw becomes Sequential(BlurPool2D, Conv2d) in the four strided blocks (reference mobilenet_v1.py:43-55)."""
+    from trackertraincode.neuralnets.models import NetworkWithPointHead
+
+    _, meta = load_golden("model_blurpool.npz")
+    net = NetworkWithPointHead(**meta["config"])
+    mine = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    ref = {k: tuple(v) for k, v in meta["shapes"].items()}
+    assert list(mine) == list(ref) and mine == ref
+    assert net.get_config()["backbone_args"] == {"use_blurpool": True}
+    k = net.convnet.dw2_2.conv_dw[0].kernel
+    assert torch.equal(k, torch.tensor([[1., 2., 1.], [2., 4., 2.], [1., 2., 1.]]) / 16.0)
+
+
+@pytest.mark.parametrize("cfg", ["full", "posonly", "blurpool"])
 def test_cpu_eval_export_path_matches_reference_golden(cfg):
     d, meta = load_golden(f"model_{cfg}.npz")
     cal = {k[len("calib/"):]: d[k] for k in d.files if k.startswith("calib/")}

@@ -22,7 +22,7 @@ def _val(v):
     return (v.value if hasattr(v, "value") else v).detach().cpu().numpy()
 
 
-@pytest.mark.parametrize("cfg", ["full", "default", "posonly", "rot6d"])
+@pytest.mark.parametrize("cfg", ["full", "default", "posonly", "rot6d", "blurpool"])
 def test_train_step_matches_reference_golden(cfg):
     import trackertraincode.train as train
 
@@ -87,7 +87,7 @@ def test_dataset_weight_and_validation_paths():
     assert abs(val_loss.item() - float(d["val/val_loss"])) < 5e-3
 
 
-@pytest.mark.parametrize("cfg", ["full", "default", "posonly", "rot6d"])
+@pytest.mark.parametrize("cfg", ["full", "default", "posonly", "rot6d", "blurpool"])
 def test_eval_forward_matches_reference_golden(cfg):
     d, meta = load_golden(f"model_{cfg}.npz")
     cal = {k[len("calib/"):]: d[k] for k in d.files if k.startswith("calib/")}

@@ -11,7 +11,7 @@ from oracle import refmodel as R
 from oracle.synth import digest_close, make_grads, make_inputs, make_labels, make_state
 
 torch.set_num_threads(min(8, os.cpu_count() or 1))
-CFGS = ["full", "default", "posonly", "rot6d"]
+CFGS = ["full", "default", "posonly", "rot6d", "blurpool"]
 
 
 def _load(golden_dir, name):
@@ -45,7 +45,8 @@ def _criterions(meta, golden_dir):
 def test_state_inventory_matches_reference(cfg, golden_dir):
     d, meta = _load(golden_dir, f"model_{cfg}.npz")
     mine = R.state_shapes(meta["config"]["enable_point_head"], meta["config"]["enable_uncertainty"],
-                          enable_6drot=meta["config"].get("enable_6drot", False))
+                          enable_6drot=meta["config"].get("enable_6drot", False),
+                          use_blurpool=meta["config"]["backbone_args"]["use_blurpool"])
     ref = {k: tuple(v) for k, v in meta["shapes"].items()}
     assert list(mine.keys()) == list(ref.keys())  # same names, same order (checkpoint surface)
     assert mine == ref
