@@ -49,7 +49,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 19
+#define TTK_ABI_VERSION 20
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -421,6 +421,21 @@ int ttk_loss_nllcoord_fwd(const float* c, const float* t, const float* L, int n,
 int ttk_loss_nllcoord_bwd(const float* c, const float* t, const float* L, const float* gv, int n, float* gc, float* gL, ttk_stream_t stream);
 int ttk_loss_normal_fwd(const float* mu, const float* sigma, const float* x, int n, int per, int points, int dim, float chin, float eye, float* v, ttk_stream_t stream);
 int ttk_loss_normal_bwd(const float* mu, const float* sigma, const float* x, const float* gv, int n, int per, int points, int dim, float chin, float eye, float* gmu, float* gsigma, ttk_stream_t stream);
+/* The non-default kinds of the reference's loss switches (single launches, not part of ttk_loss_batch):
+ *   laplace       the `normal` entry points with Laplace(mu, b) in place of Normal(mu, sigma) - DISTRIBUTION_CLASS_MAP["laplace"],
+ *                 negloglikelihood.py:68-69 (CoordPoseNLLLoss, BoxNLLLoss, Points3dNLLLoss, ShapeParamsNLLLoss)
+ *   elem          v[s] = sum_d colw[d] * f(p[s][d] - t[s][d]) over rows of D floats, f by kind: TTK_ELEM_L2 e^2, TTK_ELEM_L1 |e|,
+ *                 TTK_ELEM_SMOOTH_L1 (|e| < beta ? e^2 / (2 beta) : |e| - beta / 2) - LOSS_OBJECT_MAP, losses.py:16-21 (the reference's
+ *                 smooth_l1 has beta = 0.01).  colw[D] (device) carries each loss class's reduction: 1/Dc inside a column window
+ *                 (PoseXYLoss, PoseSizeLoss, BoxLoss), point weight / 68 on the first `dim` coordinates of a landmark (Points3dLoss).
+ *   rot_geodesic  smooth_l1(|rotation_delta(q, t)|, beta = 1 degree) / pi - smooth_geodesic_distance, losses.py:24-32 */
+enum { TTK_ELEM_L2 = 0, TTK_ELEM_L1 = 1, TTK_ELEM_SMOOTH_L1 = 2 };
+int ttk_loss_laplace_fwd(const float* mu, const float* b, const float* x, int n, int per, int points, int dim, float chin, float eye, float* v, ttk_stream_t stream);
+int ttk_loss_laplace_bwd(const float* mu, const float* b, const float* x, const float* gv, int n, int per, int points, int dim, float chin, float eye, float* gmu, float* gb, ttk_stream_t stream);
+int ttk_loss_elem_fwd(const float* p, const float* t, const float* colw, int n, int D, int kind, float beta, float* v, ttk_stream_t stream);
+int ttk_loss_elem_bwd(const float* p, const float* t, const float* colw, const float* gv, int n, int D, int kind, float beta, float* gp, ttk_stream_t stream);
+int ttk_loss_rot_geodesic_fwd(const float* q, const float* t, int n, float* v, ttk_stream_t stream);
+int ttk_loss_rot_geodesic_bwd(const float* q, const float* t, const float* gv, int n, float* gq, ttk_stream_t stream);
 int ttk_loss_gmm_fwd(const float* x, const double* ck, const double* mu, const double* sinv, int K, double fudge, int n, float* v, double* post, ttk_stream_t stream);
 int ttk_loss_gmm_bwd(const float* x, const double* mu, const double* sinv, const double* post, int K, double fudge, const float* gv, int n, float* gx, ttk_stream_t stream);
 

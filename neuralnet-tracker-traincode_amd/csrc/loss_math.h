@@ -147,6 +147,47 @@ TTK_HD void nllcoord_loss_bwd(const float c[3], const float t[3], const float L[
   gc[0] = -gd[0]; gc[1] = -gd[1]; gc[2] = -gd[2];
 }
 
+// ---- smooth_geodesic_distance (losses.py:24-32): smooth_l1(|rotation_delta(q, t)|, 0, beta = 1 degree) / pi ---------------
+TTK_HD float smooth_geodesic_loss(const float q[4], const float t[4]) {
+  const RotDelta d = rotation_delta(q, t);
+  const float th = sqrtf(d.r[0] * d.r[0] + d.r[1] * d.r[1] + d.r[2] * d.r[2]);
+  const float beta = 3.14159265358979323846f / 180.f;
+  return (th < beta ? 0.5f * th * th / beta : th - 0.5f * beta) / 3.14159265358979323846f;
+}
+TTK_HD void smooth_geodesic_loss_bwd(const float q[4], const float t[4], float gv, float gq[4]) {
+  const RotDelta d = rotation_delta(q, t);
+  const float th = sqrtf(d.r[0] * d.r[0] + d.r[1] * d.r[1] + d.r[2] * d.r[2]);
+  const float beta = 3.14159265358979323846f / 180.f;
+  const float gth = (th < beta ? th / beta : 1.f) / 3.14159265358979323846f * gv;
+  const float f = th > 0.f ? gth / th : 0.f;  // d|r|/dr = r / |r| (0 at r = 0, torch's norm subgradient)
+  const float gr[3] = {f * d.r[0], f * d.r[1], f * d.r[2]};
+  rotation_delta_bwd(q, t, d, gr, gq);
+}
+
+// ---- elementwise distance kinds of LOSS_OBJECT_MAP (losses.py:16-21): MSELoss, L1Loss, SmoothL1Loss(beta) ------------------
+enum { kElemL2 = 0, kElemL1 = 1, kElemSmoothL1 = 2 };
+TTK_HD float elem_loss(int kind, float e, float beta) {
+  const float a = fabsf(e);
+  if (kind == kElemL2) return e * e;
+  if (kind == kElemL1) return a;
+  return a < beta ? 0.5f * e * e / beta : a - 0.5f * beta;
+}
+TTK_HD float elem_loss_d(int kind, float e, float beta) {
+  const float sg = e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f);
+  if (kind == kElemL2) return 2.f * e;
+  if (kind == kElemL1) return sg;
+  return fabsf(e) < beta ? e / beta : sg;
+}
+
+// ---- -Laplace(mu, b).log_prob(x), one element (negloglikelihood.py:68-69, DISTRIBUTION_CLASS_MAP["laplace"]) --------------
+TTK_HD float laplace_nll(float mu, float b, float x) { return logf(2.f * b) + fabsf(x - mu) / b; }
+TTK_HD void laplace_nll_bwd(float mu, float b, float x, float g, float& gmu, float& gb) {
+  const float d = x - mu, ib = 1.f / b;
+  const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+  gmu = -sg * ib * g;
+  gb = (ib - fabsf(d) * ib * ib) * g;
+}
+
 // ---- -Normal(mu, sigma).log_prob(x), one element ----------------------------------------------------
 TTK_HD float normal_nll(float mu, float sigma, float x) {
   const float d = x - mu;

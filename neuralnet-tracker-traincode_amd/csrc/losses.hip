@@ -110,6 +110,35 @@ __device__ __forceinline__ void loss_mse_cols_bwd_body(const float* p, const flo
   gp[i] = (d >= 0 && d < Dc) ? 2.f * (p[i] - t[i]) * gv[i / Dt] / (float)Dc : 0.f;
 }
 
+// The non-default kinds of the reference's loss switches (losses.py:16-38): v[s] = sum_d colw[d] * f_kind(p[s][d] - t[s][d]) over rows of
+// D floats.  The host folds the reduction of each loss class into colw (mean over a column window: 1/Dc inside, 0 outside; landmarks:
+// point weight / 68 on the first `dim` coordinates of each point).
+__device__ __forceinline__ void loss_elem_fwd_body(const float* p, const float* t, const float* colw, int n, int D, int kind, float beta, float* v) {
+  TTK_WAVE_SAMPLE(n);
+  float acc = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float w = colw[d];
+    if (w != 0.f) acc = fmaf(w, lm::elem_loss(kind, p[(size_t)s * D + d] - t[(size_t)s * D + d], beta), acc);
+  }
+  acc = wave_sum_f(acc);
+  if (lane == 0) v[s] = acc;
+}
+__device__ __forceinline__ void loss_elem_bwd_body(const float* p, const float* t, const float* colw, const float* gv, int n, int D, int kind, float beta,
+                                                   float* gp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * D) return;
+  const float w = colw[i % D];
+  gp[i] = w != 0.f ? w * lm::elem_loss_d(kind, p[i] - t[i], beta) * gv[i / D] : 0.f;
+}
+__device__ __forceinline__ void loss_rot_geodesic_fwd_body(const float* q, const float* t, int n, float* v) {
+  TTK_SAMPLE_INDEX(n);
+  v[s] = lm::smooth_geodesic_loss(q + 4 * s, t + 4 * s);
+}
+__device__ __forceinline__ void loss_rot_geodesic_bwd_body(const float* q, const float* t, const float* gv, int n, float* gq) {
+  TTK_SAMPLE_INDEX(n);
+  lm::smooth_geodesic_loss_bwd(q + 4 * s, t + 4 * s, gv[s], gq + 4 * s);
+}
+
 // ---- loss bookkeeping of one training step in single launches (train.py default_compute_loss) ---------------------
 constexpr int kMaxSeg = 32;
 struct CopySegs {
@@ -204,6 +233,7 @@ __device__ __forceinline__ void loss_nllcoord_bwd_body(const float* c, const flo
 }
 // -mean over `per` elements of w * Normal(mu, sigma).log_prob(x); elements laid out [n][rows][3] with
 // only the first `dim` of every 3 used when rows3 != 0 (points), else plain [n][per].
+template <bool LAPLACE = false>
 __device__ __forceinline__ void loss_normal_fwd_body(const float* mu, const float* sg, const float* x, int n, int per, int points, int dim,
                                   float chin, float eye, float* v) {
   TTK_WAVE_SAMPLE(n);
@@ -213,7 +243,7 @@ __device__ __forceinline__ void loss_normal_fwd_body(const float* mu, const floa
       float a = 0.f;
       for (int d = 0; d < dim; ++d) {
         const size_t o = ((size_t)s * 68 + k) * 3 + d;
-        a += lm::normal_nll(mu[o], sg[o], x[o]);
+        a += LAPLACE ? lm::laplace_nll(mu[o], sg[o], x[o]) : lm::normal_nll(mu[o], sg[o], x[o]);
       }
       acc = fmaf(lm::point_weight(k, chin, eye), a, acc);
     }
@@ -222,12 +252,13 @@ __device__ __forceinline__ void loss_normal_fwd_body(const float* mu, const floa
   } else {
     for (int d = lane; d < per; d += 64) {
       const size_t o = (size_t)s * per + d;
-      acc += lm::normal_nll(mu[o], sg[o], x[o]);
+      acc += LAPLACE ? lm::laplace_nll(mu[o], sg[o], x[o]) : lm::normal_nll(mu[o], sg[o], x[o]);
     }
     acc = wave_sum_f(acc);
     if (lane == 0) v[s] = acc / (float)per;
   }
 }
+template <bool LAPLACE = false>
 __device__ __forceinline__ void loss_normal_bwd_body(const float* mu, const float* sg, const float* x, const float* gv, int n, int per,
                                   int points, int dim, float chin, float eye, float* gmu, float* gsg) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -242,7 +273,10 @@ __device__ __forceinline__ void loss_normal_bwd_body(const float* mu, const floa
     w = 1.f / (float)per;
   }
   float a = 0.f, b = 0.f;
-  if (w != 0.f) lm::normal_nll_bwd(mu[i], sg[i], x[i], w * gv[s], a, b);
+  if (w != 0.f) {
+    if (LAPLACE) lm::laplace_nll_bwd(mu[i], sg[i], x[i], w * gv[s], a, b);
+    else lm::normal_nll_bwd(mu[i], sg[i], x[i], w * gv[s], a, b);
+  }
   gmu[i] = a;
   gsg[i] = b;
 }
@@ -302,6 +336,12 @@ __global__ void loss_nllcoord_fwd_k(const float* c, const float* t, const float*
 __global__ void loss_nllcoord_bwd_k(const float* c, const float* t, const float* L, const float* gv, int n, float* gc, float* gL) { loss_nllcoord_bwd_body(c, t, L, gv, n, gc, gL); }
 __global__ void loss_normal_fwd_k(const float* mu, const float* sg, const float* x, int n, int per, int points, int dim, float chin, float eye, float* v) { loss_normal_fwd_body(mu, sg, x, n, per, points, dim, chin, eye, v); }
 __global__ void loss_normal_bwd_k(const float* mu, const float* sg, const float* x, const float* gv, int n, int per, int points, int dim, float chin, float eye, float* gmu, float* gsg) { loss_normal_bwd_body(mu, sg, x, gv, n, per, points, dim, chin, eye, gmu, gsg); }
+__global__ void loss_laplace_fwd_k(const float* mu, const float* sg, const float* x, int n, int per, int points, int dim, float chin, float eye, float* v) { loss_normal_fwd_body<true>(mu, sg, x, n, per, points, dim, chin, eye, v); }
+__global__ void loss_laplace_bwd_k(const float* mu, const float* sg, const float* x, const float* gv, int n, int per, int points, int dim, float chin, float eye, float* gmu, float* gsg) { loss_normal_bwd_body<true>(mu, sg, x, gv, n, per, points, dim, chin, eye, gmu, gsg); }
+__global__ void loss_elem_fwd_k(const float* p, const float* t, const float* colw, int n, int D, int kind, float beta, float* v) { loss_elem_fwd_body(p, t, colw, n, D, kind, beta, v); }
+__global__ void loss_elem_bwd_k(const float* p, const float* t, const float* colw, const float* gv, int n, int D, int kind, float beta, float* gp) { loss_elem_bwd_body(p, t, colw, gv, n, D, kind, beta, gp); }
+__global__ void loss_rot_geodesic_fwd_k(const float* q, const float* t, int n, float* v) { loss_rot_geodesic_fwd_body(q, t, n, v); }
+__global__ void loss_rot_geodesic_bwd_k(const float* q, const float* t, const float* gv, int n, float* gq) { loss_rot_geodesic_bwd_body(q, t, gv, n, gq); }
 __global__ void loss_gmm_fwd_k(const float* x, const double* ck, const double* mu, const double* sinv, int K, double fudge, int n, float* v, double* post) { loss_gmm_fwd_body(x, ck, mu, sinv, K, fudge, n, v, post); }
 __global__ void loss_gmm_bwd_k(const float* x, const double* mu, const double* sinv, const double* post, int K, double fudge, const float* gv, int n, float* gx) { loss_gmm_bwd_body(x, mu, sinv, post, K, fudge, gv, n, gx); }
 
@@ -532,6 +572,40 @@ int ttk_loss_normal_bwd(const float* mu, const float* sigma, const float* x, con
   const int total = n * (points ? 204 : per);
   hipLaunchKernelGGL(loss_normal_bwd_k, TTK_GRID(total), mu, sigma, x, gv, n, per, points, dim, chin, eye, gmu, gsigma);
   TTK_LAUNCH_CHECK("loss_normal_bwd");
+}
+int ttk_loss_laplace_fwd(const float* mu, const float* b, const float* x, int n, int per, int points, int dim, float chin, float eye,
+                         float* v, ttk_stream_t stream) {
+  TTK_REQUIRE(mu && b && x && v && n > 0 && (points ? (dim == 2 || dim == 3) : per > 0), "loss_laplace_fwd: bad arguments");
+  hipLaunchKernelGGL(loss_laplace_fwd_k, TTK_GRID(n * 64), mu, b, x, n, per, points, dim, chin, eye, v);
+  TTK_LAUNCH_CHECK("loss_laplace_fwd");
+}
+int ttk_loss_laplace_bwd(const float* mu, const float* b, const float* x, const float* gv, int n, int per, int points, int dim,
+                         float chin, float eye, float* gmu, float* gb, ttk_stream_t stream) {
+  TTK_REQUIRE(mu && b && x && gv && gmu && gb && n > 0, "loss_laplace_bwd: bad arguments");
+  const int total = n * (points ? 204 : per);
+  hipLaunchKernelGGL(loss_laplace_bwd_k, TTK_GRID(total), mu, b, x, gv, n, per, points, dim, chin, eye, gmu, gb);
+  TTK_LAUNCH_CHECK("loss_laplace_bwd");
+}
+int ttk_loss_elem_fwd(const float* p, const float* t, const float* colw, int n, int D, int kind, float beta, float* v, ttk_stream_t stream) {
+  TTK_REQUIRE(p && t && colw && v && n > 0 && D > 0 && kind >= 0 && kind <= 2 && (kind != 2 || beta > 0.f), "loss_elem_fwd: bad arguments");
+  hipLaunchKernelGGL(loss_elem_fwd_k, TTK_GRID(n * 64), p, t, colw, n, D, kind, beta, v);
+  TTK_LAUNCH_CHECK("loss_elem_fwd");
+}
+int ttk_loss_elem_bwd(const float* p, const float* t, const float* colw, const float* gv, int n, int D, int kind, float beta, float* gp,
+                      ttk_stream_t stream) {
+  TTK_REQUIRE(p && t && colw && gv && gp && n > 0 && D > 0 && kind >= 0 && kind <= 2 && (kind != 2 || beta > 0.f), "loss_elem_bwd: bad arguments");
+  hipLaunchKernelGGL(loss_elem_bwd_k, TTK_GRID(n * D), p, t, colw, gv, n, D, kind, beta, gp);
+  TTK_LAUNCH_CHECK("loss_elem_bwd");
+}
+int ttk_loss_rot_geodesic_fwd(const float* q, const float* t, int n, float* v, ttk_stream_t stream) {
+  TTK_REQUIRE(q && t && v && n > 0, "loss_rot_geodesic_fwd: bad arguments");
+  hipLaunchKernelGGL(loss_rot_geodesic_fwd_k, TTK_GRID(n), q, t, n, v);
+  TTK_LAUNCH_CHECK("loss_rot_geodesic_fwd");
+}
+int ttk_loss_rot_geodesic_bwd(const float* q, const float* t, const float* gv, int n, float* gq, ttk_stream_t stream) {
+  TTK_REQUIRE(q && t && gv && gq && n > 0, "loss_rot_geodesic_bwd: bad arguments");
+  hipLaunchKernelGGL(loss_rot_geodesic_bwd_k, TTK_GRID(n), q, t, gv, n, gq);
+  TTK_LAUNCH_CHECK("loss_rot_geodesic_bwd");
 }
 int ttk_loss_gmm_fwd(const float* x, const double* ck, const double* mu, const double* sinv, int K, double fudge, int n,
                      float* v, double* post, ttk_stream_t stream) {

@@ -77,6 +77,12 @@ _SIGNATURES = {
     "ttk_loss_nllcoord_bwd": [_P, _P, _P, _P, _I, _P, _P],
     "ttk_loss_normal_fwd": [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P],
     "ttk_loss_normal_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P],
+    "ttk_loss_laplace_fwd": [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P],
+    "ttk_loss_laplace_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P],
+    "ttk_loss_elem_fwd": [_P, _P, _P, _I, _I, _I, _F, _P],
+    "ttk_loss_elem_bwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "ttk_loss_rot_geodesic_fwd": [_P, _P, _I, _P],
+    "ttk_loss_rot_geodesic_bwd": [_P, _P, _P, _I, _P],
     "ttk_loss_gmm_fwd": [_P, _P, _P, _P, _I, _D, _I, _P, _P],
     "ttk_loss_gmm_bwd": [_P, _P, _P, _P, _I, _D, _P, _I, _P],
     "ttk_loss_batch": [_I, _P],
@@ -89,7 +95,7 @@ _SIGNATURES = {
     "ttk_stream_probe": [_P, _P, _P, _L, _I, _I, _I, _I, _L, _I, _I, _I],
 }
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 def bn_pivot() -> bool:

@@ -542,28 +542,95 @@ class NllCoordFn(Function):
         return gc, None, gL
 
 
+def _dist_nll_fwd(sym, ctx, mu, sigma, x, points, dim, chin, eye):
+    mu, sigma, x = _f32c(mu), _f32c(sigma), _f32c(x)
+    n = mu.shape[0]
+    per = mu[0].numel()
+    v = _vec(n, mu)
+    cfg = (n, per, int(points), int(dim), float(chin), float(eye))
+    _call(sym + "_fwd", _p(mu), _p(sigma), _p(x), *cfg, _p(v))
+    ctx.save_for_backward(mu, sigma, x)
+    ctx.cfg = cfg
+    return v
+
+
+def _dist_nll_bwd(sym, ctx, gv):
+    mu, sigma, x = ctx.saved_tensors
+    gmu, gsg = torch.empty_like(mu), torch.empty_like(sigma)
+    _call(sym + "_bwd", _p(mu), _p(sigma), _p(x), _p(_f32c(gv)), *ctx.cfg, _p(gmu), _p(gsg))
+    return gmu, gsg, None, None, None, None, None
+
+
 class NormalNllFn(Function):
     """-mean Normal(mu, sigma).log_prob(x).  points=False: tensors [n, D]; points=True: [n, 68, 3] with the
     first `dim` coordinates and the chin/eye point weights."""
 
     @staticmethod
     def forward(ctx, mu, sigma, x, points, dim, chin, eye):
-        mu, sigma, x = _f32c(mu), _f32c(sigma), _f32c(x)
-        n = mu.shape[0]
-        per = mu[0].numel()
-        v = _vec(n, mu)
-        cfg = (n, per, int(points), int(dim), float(chin), float(eye))
-        _call("ttk_loss_normal_fwd", _p(mu), _p(sigma), _p(x), *cfg, _p(v))
-        ctx.save_for_backward(mu, sigma, x)
-        ctx.cfg = cfg
+        return _dist_nll_fwd("ttk_loss_normal", ctx, mu, sigma, x, points, dim, chin, eye)
+
+    @staticmethod
+    def backward(ctx, gv):
+        return _dist_nll_bwd("ttk_loss_normal", ctx, gv)
+
+
+class LaplaceNllFn(Function):
+    """-mean Laplace(mu, b).log_prob(x) with NormalNllFn's layouts (distribution="laplace", reference negloglikelihood.py:68-69)."""
+
+    @staticmethod
+    def forward(ctx, mu, b, x, points, dim, chin, eye):
+        return _dist_nll_fwd("ttk_loss_laplace", ctx, mu, b, x, points, dim, chin, eye)
+
+    @staticmethod
+    def backward(ctx, gv):
+        return _dist_nll_bwd("ttk_loss_laplace", ctx, gv)
+
+
+ELEM_KINDS = {"l2": 0, "l1": 1, "smooth_l1": 2}  # TTK_ELEM_*; LOSS_OBJECT_MAP of the reference's losses.py:16-21
+SMOOTH_L1_BETA = 0.01                             # torch.nn.SmoothL1Loss(beta=0.01) there
+
+
+class ElemLossFn(Function):
+    """v[s] = sum_d colw[d] * f_kind(p[s, d] - t[s, d]); p, t: [n, ...] flattened to rows, colw: device vector of the row length."""
+
+    @staticmethod
+    def forward(ctx, p, t, colw, kind):
+        shape = p.shape
+        p, t = _f32c(p).reshape(shape[0], -1), _f32c(t).reshape(shape[0], -1)
+        n, D = p.shape
+        assert colw.numel() == D and colw.is_cuda and colw.dtype == torch.float32
+        v = _vec(n, p)
+        _call("ttk_loss_elem_fwd", _p(p), _p(t), _p(colw), n, D, int(kind), SMOOTH_L1_BETA, _p(v))
+        ctx.save_for_backward(p, t, colw)
+        ctx.cfg = (shape, int(kind))
         return v
 
     @staticmethod
     def backward(ctx, gv):
-        mu, sigma, x = ctx.saved_tensors
-        gmu, gsg = torch.empty_like(mu), torch.empty_like(sigma)
-        _call("ttk_loss_normal_bwd", _p(mu), _p(sigma), _p(x), _p(_f32c(gv)), *ctx.cfg, _p(gmu), _p(gsg))
-        return gmu, gsg, None, None, None, None, None
+        p, t, colw = ctx.saved_tensors
+        shape, kind = ctx.cfg
+        gp = torch.empty_like(p)
+        _call("ttk_loss_elem_bwd", _p(p), _p(t), _p(colw), _p(_f32c(gv)), p.shape[0], p.shape[1], kind, SMOOTH_L1_BETA, _p(gp))
+        return gp.view(shape), None, None, None
+
+
+class RotGeodesicFn(Function):
+    """smooth_geodesic_distance of the reference's losses.py:24-32."""
+
+    @staticmethod
+    def forward(ctx, q, t):
+        q, t = _f32c(q), _f32c(t)
+        v = _vec(q.shape[0], q)
+        _call("ttk_loss_rot_geodesic_fwd", _p(q), _p(t), q.shape[0], _p(v))
+        ctx.save_for_backward(q, t)
+        return v
+
+    @staticmethod
+    def backward(ctx, gv):
+        q, t = ctx.saved_tensors
+        gq = torch.empty_like(q)
+        _call("ttk_loss_rot_geodesic_bwd", _p(q), _p(t), _p(_f32c(gv)), q.shape[0], _p(gq))
+        return gq, None
 
 
 class GmmNllFn(Function):

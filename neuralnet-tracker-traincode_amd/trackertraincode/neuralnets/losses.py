@@ -13,13 +13,35 @@ from . import _hipops
 from ..facemodel import keypoints68 as kpts68
 from .modelcomponents import FACEMODEL_DIR, GaussianMixture
 
-SimpleLossSwitch = Literal["l2", "smooth_l1"]
+SimpleLossSwitch = Literal["l2", "l1", "smooth_l1"]
 SimpleRotLossSwitch = Literal["approx_distance", "smooth_geodesic"]
 
 
-def _l2_only(kind):
-    if kind != "l2":
-        raise NotImplementedError(f"loss={kind!r}: only 'l2' is built (the training script uses nothing else)")
+def _check_kind(kind):
+    """The keys of the reference's LOSS_OBJECT_MAP (:16-21): MSELoss, L1Loss, SmoothL1Loss(beta=0.01), all reduction="none"."""
+    if kind not in _hipops.ELEM_KINDS:
+        raise KeyError(kind)
+    return kind
+
+
+class _ColumnWeights:
+    """Device copies of the per-column weight vector of a non-"l2" loss (ttk_loss_elem: v = sum_d colw[d] f(p_d - t_d)), one per device."""
+
+    def __init__(self, values):
+        self._host = torch.as_tensor(values, dtype=torch.float32).contiguous()
+        self._dev = {}
+
+    def on(self, device):
+        key = (device.type, device.index)
+        if key not in self._dev:
+            self._dev[key] = self._host.to(device)
+        return self._dev[key]
+
+
+def _window_weights(D, c0, nc):
+    w = np.zeros((D,), dtype=np.float32)
+    w[c0:c0 + nc] = 1.0 / nc  # .mean(dim=-1) over the window
+    return w
 
 
 def point_weights(chin_weight=1.0, eye_weight=0.0) -> torch.Tensor:
@@ -33,31 +55,38 @@ def point_weights(chin_weight=1.0, eye_weight=0.0) -> torch.Tensor:
 
 class QuatPoseLoss:
     def __init__(self, loss: SimpleRotLossSwitch, prefix=""):
-        if loss != "approx_distance":
-            raise NotImplementedError("only the 'approx_distance' rotation loss is built (scripts/train_poseestimator.py:172)")
+        # reference :35-39: "approx_distance" = torchquaternion.distance, "smooth_geodesic" = smooth_geodesic_distance (:24-32)
+        self._fn = {"approx_distance": _hipops.RotLossFn, "smooth_geodesic": _hipops.RotGeodesicFn}[loss]
         self._prefix = prefix
 
     def __call__(self, pred, sample):
         quat = pred[self._prefix + "rot"]
-        return _hipops.apply(_hipops.RotLossFn, quat.value if hasattr(quat, "value") else quat, sample["pose"])
+        return _hipops.apply(self._fn, quat.value if hasattr(quat, "value") else quat, sample["pose"])
 
 
-class PoseSizeLoss:
+class _CoordWindowLoss:
+    """loss_obj(coord[..., window], target[..., window]) averaged over the window (reference :67-88)."""
+
+    _c0, _nc = 0, 3
+
     def __init__(self, loss: SimpleLossSwitch, prefix=""):
-        _l2_only(loss)
+        self._kind = _check_kind(loss)
         self._prefix = prefix
+        self._colw = _ColumnWeights(_window_weights(3, self._c0, self._nc))
 
     def __call__(self, pred, sample):
-        return _hipops.mse_cols(pred[self._prefix + "coord"], sample["coord"], 2, 1)
+        p, t = pred[self._prefix + "coord"], sample["coord"]
+        if self._kind == "l2":
+            return _hipops.mse_cols(p, t, self._c0, self._nc)
+        return _hipops.apply(_hipops.ElemLossFn, p, t, self._colw.on(p.device), _hipops.ELEM_KINDS[self._kind])
 
 
-class PoseXYLoss:
-    def __init__(self, loss: SimpleLossSwitch, prefix=""):
-        _l2_only(loss)
-        self._prefix = prefix
+class PoseSizeLoss(_CoordWindowLoss):
+    _c0, _nc = 2, 1
 
-    def __call__(self, pred, sample):
-        return _hipops.mse_cols(pred[self._prefix + "coord"], sample["coord"], 0, 2)
+
+class PoseXYLoss(_CoordWindowLoss):
+    _c0, _nc = 0, 2
 
 
 class ShapeParameterLoss:
@@ -101,15 +130,20 @@ class QuaternionNormalizationSoftConstraint:
 class Points3dLoss(nn.Module):
     def __init__(self, loss: SimpleLossSwitch, pointdimension: int = 3, chin_weight=1.0, eye_weights=0.0, prefix=""):
         super().__init__()
-        _l2_only(loss)
+        self._kind = _check_kind(loss)
         assert pointdimension in (2, 3)
         self._prefix, self.pointdimension = prefix, pointdimension
         self.chin_weight, self.eye_weights = float(chin_weight), float(eye_weights)
         self.register_buffer("pointweights", point_weights(chin_weight, eye_weights))
+        # mean_p w_p sum_{d < dim} f(.) as one weight per (point, coordinate)
+        w = (self.pointweights[:, None] / 68.0) * torch.tensor([1.0, 1.0, 1.0 if pointdimension == 3 else 0.0])
+        self._colw = _ColumnWeights(w.reshape(-1))
 
     def _eval_on_points(self, pred, target):
         assert target.shape == pred.shape, f"Mismatch {target.shape} vs {pred.shape}"
         assert target.shape[1] == 68 and target.shape[2] == 3
+        if self._kind != "l2":
+            return _hipops.apply(_hipops.ElemLossFn, pred, target, self._colw.on(pred.device), _hipops.ELEM_KINDS[self._kind])
         return _hipops.apply(_hipops.PointsLossFn, pred, target, self.pointdimension, self.chin_weight, self.eye_weights)
 
     def forward(self, pred, sample):
@@ -118,11 +152,15 @@ class Points3dLoss(nn.Module):
 
 class BoxLoss:
     def __init__(self, loss: SimpleLossSwitch, dataname="roi"):
-        _l2_only(loss)
+        self._kind = _check_kind(loss)
         self.dataname = dataname
+        self._colw = _ColumnWeights(_window_weights(4, 0, 4))
 
     def __call__(self, pred, sample):
-        return _hipops.apply(_hipops.MseRowsFn, pred[self.dataname], sample[self.dataname])
+        p, t = pred[self.dataname], sample[self.dataname]
+        if self._kind != "l2":
+            return _hipops.apply(_hipops.ElemLossFn, p, t, self._colw.on(p.device), _hipops.ELEM_KINDS[self._kind])
+        return _hipops.apply(_hipops.MseRowsFn, p, t)
 
 
 class Rot6dReprLoss:

@@ -20,9 +20,9 @@ inv_make_positive = inv_smoothclip0
 SimpleDistributionSwitch = Literal["gaussian", "laplace"]
 
 
-def _gaussian_only(distribution):
-    if distribution != "gaussian":
-        raise NotImplementedError(f"distribution={distribution!r}: only 'gaussian' is built (the only one the training script uses)")
+def _dist_fn(distribution):
+    """DISTRIBUTION_CLASS_MAP of the reference (:68-69): Normal or Laplace, both parameterised (location, scale)."""
+    return {"gaussian": _hipops.NormalNllFn, "laplace": _hipops.LaplaceNllFn}[distribution]
 
 
 class Neck(nn.Module):
@@ -111,7 +111,7 @@ class CoordPoseNLLLoss(nn.Module):
 
     def __init__(self, xy_weight: float, head_size_weight: float, distribution: SimpleDistributionSwitch = "gaussian"):
         super().__init__()
-        _gaussian_only(distribution)
+        self._fn = _dist_fn(distribution)
         self._w = (xy_weight / 2.0, xy_weight / 2.0, float(head_size_weight))  # host copy: no device read per step
         self.register_buffer("weights", torch.as_tensor(self._w, dtype=torch.float32))
 
@@ -120,7 +120,7 @@ class CoordPoseNLLLoss(nn.Module):
         if sigma.shape != mu.shape:
             raise ValueError(f"CoordPoseNLLLoss: coord_scales {tuple(sigma.shape)} must be per-coordinate like coord {tuple(mu.shape)}")
         # -mean_d w_d log N(x_d; mu_d, sigma_d): one single-column launch of the Normal kernel per coordinate
-        terms = [_hipops.NormalNllFn.apply(mu[:, d:d + 1], sigma[:, d:d + 1], x[:, d:d + 1], False, 0, 1.0, 1.0) for d in range(3)]
+        terms = [self._fn.apply(mu[:, d:d + 1], sigma[:, d:d + 1], x[:, d:d + 1], False, 0, 1.0, 1.0) for d in range(3)]
         return (terms[0] * self._w[0] + terms[1] * self._w[1] + terms[2] * self._w[2]) / 3.0
 
 
@@ -149,34 +149,34 @@ class CorrelatedCoordPoseNLLLoss(nn.Module):
 class BoxNLLLoss(nn.Module):
     def __init__(self, dataname="roi", distribution: SimpleDistributionSwitch = "gaussian"):
         super().__init__()
-        _gaussian_only(distribution)
+        self._fn = _dist_fn(distribution)
         self.dataname = dataname
 
     def __call__(self, pred, sample):
-        return _hipops.apply(_hipops.NormalNllFn, pred[self.dataname], pred[self.dataname + "_scales"], sample[self.dataname], False, 0, 1.0, 1.0)
+        return _hipops.apply(self._fn, pred[self.dataname], pred[self.dataname + "_scales"], sample[self.dataname], False, 0, 1.0, 1.0)
 
 
 class Points3dNLLLoss(nn.Module):
     def __init__(self, chin_weight, eye_weight, pointdimension: int = 3, distribution: SimpleDistributionSwitch = "gaussian"):
         super().__init__()
-        _gaussian_only(distribution)
+        self._fn = _dist_fn(distribution)
         from .losses import point_weights
 
         self.register_buffer("pointweights", point_weights(chin_weight, eye_weight))
         self.chin_weight, self.eye_weight, self.pointdimension = float(chin_weight), float(eye_weight), pointdimension
 
     def __call__(self, preds, sample):
-        return _hipops.apply(_hipops.NormalNllFn, preds["pt3d_68"], preds["pt3d_68_scales"], sample["pt3d_68"], True,
+        return _hipops.apply(self._fn, preds["pt3d_68"], preds["pt3d_68_scales"], sample["pt3d_68"], True,
                                          self.pointdimension, self.chin_weight, self.eye_weight)
 
 
 class ShapeParamsNLLLoss(nn.Module):
     def __init__(self, distribution: SimpleDistributionSwitch = "gaussian"):
         super().__init__()
-        _gaussian_only(distribution)
+        self._fn = _dist_fn(distribution)
 
     def __call__(self, preds, sample):
-        return _hipops.apply(_hipops.NormalNllFn, preds["shapeparam"], preds["shapeparam_scales"], sample["shapeparam"], False, 0, 1.0, 1.0)
+        return _hipops.apply(self._fn, preds["shapeparam"], preds["shapeparam_scales"], sample["shapeparam"], False, 0, 1.0, 1.0)
 
 
 class QuatPoseNLLLoss(nn.Module):

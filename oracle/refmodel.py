@@ -554,6 +554,68 @@ def loss_nllpoints3d(p, s, dim=3):  # negloglikelihood.py:145-166
     return (-point_weights().to(lp.device)[None, :, None] * lp).mean(dim=(-2, -1))
 
 
+# ---- the non-default kinds of the loss switches (unused by the training script; pinned by tests/golden/loss_kinds.npz) ----------------
+def elem_distance(kind: str, p: Tensor, t: Tensor) -> Tensor:
+    """LOSS_OBJECT_MAP, losses.py:16-21: MSELoss / L1Loss / SmoothL1Loss(beta=0.01), reduction="none"."""
+    e = p - t
+    if kind == "l2":
+        return e.square()
+    if kind == "l1":
+        return e.abs()
+    assert kind == "smooth_l1"
+    beta = 0.01
+    return torch.where(e.abs() < beta, 0.5 * e.square() / beta, e.abs() - 0.5 * beta)
+
+
+def loss_xy_kind(p, s, kind):  # losses.py:79-88
+    return elem_distance(kind, p["coord"][..., :2], s["coord"][..., :2]).mean(-1)
+
+
+def loss_sz_kind(p, s, kind):  # losses.py:67-76
+    return elem_distance(kind, p["coord"][..., 2], s["coord"][..., 2])
+
+
+def loss_box_kind(p, s, kind):  # losses.py:163-173
+    return elem_distance(kind, p["roi"], s["roi"]).mean(-1)
+
+
+def loss_points3d_kind(p, s, kind, dim=3, chin=0.8, eye=0.0):  # losses.py:128-160
+    d = elem_distance(kind, p["pt3d_68"][..., :dim], s["pt3d_68"][..., :dim]).sum(-1)
+    return (d * point_weights(chin, eye).to(d.device)[None, :]).mean(-1)
+
+
+def loss_rot_smooth_geodesic(p, s):  # losses.py:24-32: smooth_l1(|rotation_delta|, 0, beta = 1 degree) / pi; torchquaternion.py:233-236
+    th = rotation_delta(p["rot"], s["pose"]).norm(dim=-1)
+    beta = math.pi / 180.0
+    return torch.where(th < beta, 0.5 * th.square() / beta, th - 0.5 * beta) / math.pi
+
+
+def _laplace_logprob(x, mu, b):  # torch.distributions.Laplace.log_prob
+    return -(2 * b).log() - (x - mu).abs() / b
+
+
+def _dist_logprob(distribution):
+    return {"gaussian": _normal_logprob, "laplace": _laplace_logprob}[distribution]
+
+
+def loss_nllcoord_indep(p, s, xy_weight, size_weight, distribution="gaussian"):  # negloglikelihood.py:72-97
+    w = torch.tensor([xy_weight / 2.0, xy_weight / 2.0, size_weight], dtype=p["coord"].dtype)
+    return -(_dist_logprob(distribution)(s["coord"], p["coord"], p["coord_scales"]) * w[None, :]).mean(-1)
+
+
+def loss_nllbox_dist(p, s, distribution):  # negloglikelihood.py:129-142
+    return -_dist_logprob(distribution)(s["roi"], p["roi"], p["roi_scales"]).mean(-1)
+
+
+def loss_nllpoints3d_dist(p, s, distribution, dim=3, chin=0.8, eye=0.0):  # negloglikelihood.py:145-166
+    lp = _dist_logprob(distribution)(s["pt3d_68"][..., :dim], p["pt3d_68"][..., :dim], p["pt3d_68_scales"][..., :dim])
+    return (-point_weights(chin, eye).to(lp.device)[None, :, None] * lp).mean(dim=(-2, -1))
+
+
+def loss_nllshape_dist(p, s, distribution):  # negloglikelihood.py:169-177
+    return -_dist_logprob(distribution)(s["shapeparam"], p["shapeparam"], p["shapeparam_scales"]).mean(-1)
+
+
 # ---------------------------------------------------------------------------------------------
 # criterion tables  (scripts/train_poseestimator.py:170-285)
 # ---------------------------------------------------------------------------------------------

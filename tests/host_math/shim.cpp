@@ -101,6 +101,16 @@ void lm_nllcoord(int n, const float* c, const float* t, const float* L, const fl
 void lm_normal(int n, const float* mu, const float* sg, const float* x, float* v, float* gmu, float* gsg) {
   for (int s = 0; s < n; ++s) { v[s] = lm::normal_nll(mu[s], sg[s], x[s]); lm::normal_nll_bwd(mu[s], sg[s], x[s], 1.f, gmu[s], gsg[s]); }
 }
+// the non-default loss kinds: elementwise distance kinds, Laplace NLL, smooth geodesic distance
+void lm_elem(int n, int kind, float beta, const float* p, const float* t, float* v, float* d) {
+  for (int s = 0; s < n; ++s) { v[s] = lm::elem_loss(kind, p[s] - t[s], beta); d[s] = lm::elem_loss_d(kind, p[s] - t[s], beta); }
+}
+void lm_laplace(int n, const float* mu, const float* b, const float* x, float* v, float* gmu, float* gb) {
+  for (int s = 0; s < n; ++s) { v[s] = lm::laplace_nll(mu[s], b[s], x[s]); lm::laplace_nll_bwd(mu[s], b[s], x[s], 1.f, gmu[s], gb[s]); }
+}
+void lm_rot_geodesic(int n, const float* q, const float* t, const float* gv, float* v, float* gq) {
+  for (int s = 0; s < n; ++s) { v[s] = lm::smooth_geodesic_loss(q + 4 * s, t + 4 * s); lm::smooth_geodesic_loss_bwd(q + 4 * s, t + 4 * s, gv[s], gq + 4 * s); }
+}
 void lm_gmm(int n, const float* x, const double* ck, const double* mu, const double* sinv, int K, double fudge, float* v,
             double* post) {
   for (int s = 0; s < n; ++s) v[s] = (float)lm::gmm_nll(x + 50 * s, ck, mu, sinv, K, fudge, post + K * s);
