@@ -64,6 +64,12 @@ def decode_pose_shard(path: str, half_pixel_offset: bool = True) -> dict:
         if src in d.files:
             v = np.asarray(d[src])
             out[dst] = v.astype(np.float32) if v.dtype.kind == "f" else v
+    # who is in a frame (reference dshdf5pose.py:221-236): from the sequence boundaries, else the stored array
+    if "sequence_starts" in d.files:
+        starts = np.asarray(d["sequence_starts"]).astype(np.int32)
+        out["individual"] = np.concatenate([np.full(b - a, i, dtype=np.int32) for i, (a, b) in enumerate(zip(starts[:-1], starts[1:]))])
+    elif "individual" in d.files:
+        out["individual"] = np.asarray(d["individual"]).astype(np.int32)
     if half_pixel_offset:
         if "coord" in out:
             out["coord"] = out["coord"].copy()

@@ -2,3 +2,4 @@ from .geometric import (GeneralFocusRoi, MakeRoiRandomizationParameters, NoRoiRa
                         RoiFocusRandomizationParameters)
 from .intensity import (KorniaImageDistortions, OnlyClip, RandomBrightness, RandomContrast, RandomEqualize,  # noqa: F401
                         RandomGamma, RandomGaussianBlur, RandomGaussianNoise, RandomGaussianNoiseWithClipping, RandomPosterize)
+from .misc import PutRoiFromLandmarks, head_extent_roi  # noqa: F401

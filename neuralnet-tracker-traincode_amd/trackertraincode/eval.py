@@ -106,6 +106,7 @@ class Predictor:
             images = [s["image"] for s in chunk]
             keys = [k for k in chunk[0] if k != "image"]
             targets = Batch(Metadata(0, len(chunk)), {k: torch.stack([torch.as_tensor(s[k]) for s in chunk]).to(self._device) for k in keys})
+            targets["image_hw"] = torch.as_tensor([tuple(im.shape[:2]) for im in images])  # what AlignedRotationErrorMetric("perspective") reads
             preds = self.predict_batch(images, targets["roi"])
             metric.update(preds, targets)
         return metric.compute()
@@ -228,3 +229,98 @@ def pose_error_table(euler_errors: Tensor, geodesic: Tensor) -> dict:
     mae = e.mean(0)
     return {"pitch": float(mae[0]), "yaw": float(mae[1]), "roll": float(mae[2]), "mae": float(mae.mean()),
             "geodesic": float(geodesic.detach().cpu().numpy().mean() * utils.rad2deg)}
+
+
+# ---------------------------------------------------------------------------------------------
+# rotation errors after an alignment of the predictions (reference :443-600; scripts/evaluate_pose_network.py --alignment-scheme)
+# ---------------------------------------------------------------------------------------------
+def compute_mean_rotation(rots, tol=0.0001, max_iter=100000):
+    """Karcher mean of scipy Rotations inside the ball of radius pi/2 (the OPAL paper's evaluator, reference :447-459): start at the first
+    one, move along the mean tangent vector until it is shorter than `tol`."""
+    from scipy.spatial.transform import Rotation
+
+    rots = rots[rots.magnitude() < np.pi / 2]
+    mean = rots[0]
+    for _ in range(max_iter):
+        step = np.mean((mean.inv() * rots).as_rotvec(), axis=0)
+        if np.linalg.norm(step) < tol:
+            break
+        mean = mean * Rotation.from_rotvec(step)
+    return mean
+
+
+def compute_opal_paper_alignment(pose_pred: Tensor, pose_target: Tensor, cluster_ids) -> Tensor:
+    """Predictions with the mean offset to the labels removed, separately for every cluster id (the recorded individuals of Biwi):
+    P <- P * mean(T^-1 P)^-1 (reference :462-482).  CPU tensors."""
+    from scipy.spatial.transform import Rotation
+
+    assert pose_pred.device.type == "cpu" and pose_target.device.type == "cpu"
+    cluster_ids = np.asarray(cluster_ids)
+    out = torch.empty_like(pose_pred)
+    for cid in np.unique(cluster_ids):
+        mask = cluster_ids == cid
+        pred, target = Rotation.from_quat(pose_pred[mask].numpy()), Rotation.from_quat(pose_target[mask].numpy())
+        offset = compute_mean_rotation(target.inv() * pred)
+        out[torch.from_numpy(mask)] = torch.from_numpy((pred * offset.inv()).as_quat()).to(pose_pred.dtype)
+    return out
+
+
+class PerspectiveCorrector:
+    """The network sees a face off the optical axis under the angle of its viewing ray; this rotates the predicted pose from the ray's frame
+    into the camera frame (reference :485-544).  `fov`: horizontal field of view in degrees."""
+
+    def __init__(self, fov):
+        self._fov = fov
+        self.f = 1.0 / np.tan(fov * np.pi / 180.0 * 0.5)
+
+    def corrected_rotation(self, image_sizes: Tensor, coord: Tensor, pose: Tensor) -> Tensor:
+        """image_sizes [B, 2] = (width, height); coord [B, 3] in pixels; pose [B, 4]."""
+        half = 0.5 * image_sizes
+        xy = (coord[..., :2] - half) / half[0]  # (the reference divides by the FIRST row's half size: all images of a set share one size)
+        ray = torch.cat([xy, torch.as_tensor(self.f, device=xy.device, dtype=xy.dtype).expand_as(xy[..., :1])], dim=-1)
+        return torchquaternion.mult(torchquaternion.from_matrix(self._make_look_at_matrix(ray)), pose)
+
+    @staticmethod
+    def _make_look_at_matrix(pos: Tensor) -> Tensor:
+        """Columns x, y, z with z along `pos` and x kept horizontal."""
+        z = pos / torch.norm(pos, dim=-1, keepdim=True)
+        x = torch.cross(*torch.broadcast_tensors(pos.new_tensor([0.0, 1.0, 0.0]), z), dim=-1)
+        x = x / torch.norm(x, dim=-1, keepdim=True)
+        y = torch.cross(z, x, dim=-1)
+        y = y / torch.norm(x, dim=-1, keepdim=True)  # (x is already unit length: the reference's normalisation of y is a no-op)
+        return torch.stack([x, y, z], dim=-1)
+
+
+class AlignedRotationErrorMetric:
+    """Euler-angle or geodesic errors after `correction_mode` "perspective" (needs the image sizes: targets["image_hw"] [B, 2] as
+    Predictor.evaluate provides it, or targets["image"] as a list of [H, W(, C)] frames) or "opal23" (needs targets["individual"]) -
+    reference :547-600."""
+
+    def __init__(self, error_mode, correction_mode, fov=None):
+        assert error_mode in ("euler", "geo") and correction_mode in ("perspective", "opal23")
+        self._error_mode, self._correction_mode, self._fov = error_mode, correction_mode, fov
+        self.reset()
+
+    def reset(self):
+        self.image_sizes, self.target_quats, self.pred_quats, self.pred_coord, self.individual = [], [], [], [], []
+
+    def update(self, preds: Batch, targets: Batch) -> None:
+        self.target_quats.append(targets["pose"].cpu())
+        self.pred_quats.append(preds["pose"].cpu())
+        self.pred_coord.append(preds["coord"].cpu())
+        if self._correction_mode == "perspective":
+            hw = targets["image_hw"] if "image_hw" in targets else torch.as_tensor([tuple(t.shape[:2]) for t in targets["image"]])
+            self.image_sizes.append(torch.as_tensor(hw).cpu())  # (h, w)
+        else:
+            self.individual.append(torch.as_tensor(targets["individual"]).cpu())
+
+    def compute(self) -> Tensor:
+        target, pred, coord = torch.cat(self.target_quats), torch.cat(self.pred_quats), torch.cat(self.pred_coord)
+        if self._correction_mode == "perspective":
+            wh = torch.flip(torch.cat(self.image_sizes), dims=(-1,))
+            pred = PerspectiveCorrector(self._fov).corrected_rotation(wh, coord, pred)
+        else:
+            pred = compute_opal_paper_alignment(pred, target, torch.cat(self.individual).numpy())
+        if self._error_mode == "euler":
+            return _aflw3d_euler_errors(pred, target)
+        return torchquaternion.geodesicdistance(pred, target)

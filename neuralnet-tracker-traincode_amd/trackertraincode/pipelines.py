@@ -12,8 +12,10 @@ from __future__ import annotations
 import enum
 from typing import Iterator, Sequence
 
+import numpy as np
 import torch
 
+from . import utils
 from .datasets.batch import Batch, Metadata
 
 
@@ -145,6 +147,95 @@ _POSE_SHARDS = {
 _TEST_SHARD = ("aflw2k", Tag.POSE_WITH_LANDMARKS, (0, 400))  # the validation set of every run (:455-456)
 
 
+# ---------------------------------------------------------------------------------------------
+# validation sets of the evaluation script (reference :170-271, 557-636)
+# ---------------------------------------------------------------------------------------------
+# name -> (shard file, "filter").  The sets the reference builds from pose datasets with stored frames; the panoptic / replicant-face
+# variants with a train/test split or a random subset are not listed.
+_VALIDATION_SHARDS = {
+    "aflw2k3d": ("aflw2k", "no_extreme_poses"),
+    "aflw2k3d_closedeyes": ("aflw2k3d-closedeyes", "no_extreme_poses"),
+    "aflw2k3d_grimaces": ("aflw2k", "grimaces"),
+    "biwi": ("biwi-v3", None),
+    "myself": ("myself", None),
+    "myself_yaw": ("myself-yaw", None),
+    "repro_300_wlp": ("reproduction_300wlp-v12", None),
+    "wflw_lp": ("wflw_augmented_v4", None),
+    "lapa_megaface_lp": ("lapa-megaface-augmented-v2", None),
+    "replicantface": ("replicant-face-v4-eval-10k", None),
+    "replicantface-stability": ("replicant-face-stability-test-wider", None),
+}
+# frames of AFLW2000-3D's first 400 (the test split) with strong facial expressions (reference :208-263)
+_AFLW2K_GRIMACES = (39, 236, 0, 129, 164, 356, 359, 256, 136, 375, 226, 392, 119, 366, 293, 56, 305, 303, 397, 10, 11, 96, 173, 124, 115, 153, 337,
+                    29, 121, 266, 387, 122, 8, 59, 108, 380, 187, 192, 353, 257, 162, 363, 331, 14, 163)
+
+
+def indices_without_extreme_poses(quats, coords):
+    """Frames whose AFLW-convention pitch, yaw and roll all stay below 99 degrees and whose size is not negative (reference :170-185)."""
+    from scipy.spatial.transform import Rotation
+
+    pyr = np.asarray([utils.inv_aflw_rotation_conversion(r) for r in Rotation.from_quat(np.asarray(quats))])
+    ok = (np.abs(pyr) < np.pi * 99.0 / 180.0).all(axis=1) & (np.asarray(coords)[:, -1] >= 0.0)
+    return np.nonzero(ok)[0]
+
+
+class ValidationSamples:
+    """Single labelled frames for `eval.Predictor.evaluate` (the reference's SampleBySampleLoader over make_validation_dataset): dicts with
+    "image" (uint8 [H, W], unpadded), the labels as CPU tensors, "index" and - where the file knows it - "individual"."""
+
+    def __init__(self, shard: dict, indices, put_roi):
+        self._shard, self._indices, self._put_roi = shard, np.asarray(indices), put_roi
+
+    def __len__(self):
+        return len(self._indices)
+
+    def __iter__(self):
+        for i in self._indices:
+            w, h = (int(v) for v in self._shard["image_size"][i])
+            s = {k: torch.from_numpy(np.asarray(v[i])) for k, v in self._shard.items() if k not in ("image", "image_size")}
+            s["image"] = torch.from_numpy(self._shard["image"][i, 0, :h, :w])
+            s["index"] = torch.tensor(int(i), dtype=torch.int32)
+            yield self._put_roi(s)
+
+
+def make_validation_dataset(name, order=None, use_head_roi=True, datadir=None, headmodel=None) -> ValidationSamples:
+    """Reference :557-606.  Every sample gets the half-pixel offset (datasets/shards.py) and `PutRoiFromLandmarks(extend_to_forehead=
+    use_head_roi)`: use_head_roi=True - the reference's default, "(H_roi)" in its tables - needs the BFM head mesh (facemodel/bfm.py;
+    FileNotFoundError without the blob), use_head_roi=False ("(F_roi)") takes the landmarks' extent."""
+    import os
+
+    from .datasets.shards import decode_pose_shard
+    from .datatransformation.batch.misc import PutRoiFromLandmarks
+
+    if name not in _VALIDATION_SHARDS:
+        raise ValueError(f"unknown validation set {name!r} (known: {sorted(_VALIDATION_SHARDS)})")
+    fname, rule = _VALIDATION_SHARDS[name]
+    datadir = datadir or os.environ.get("DATADIR")
+    if not datadir:
+        raise RuntimeError("make_validation_dataset: set $DATADIR (or pass datadir=) to the directory of converted .npz shards")
+    path = os.path.join(datadir, fname + ".npz")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} not found: convert {fname}.h5 with oracle/tools/h5_to_npz.py --dataset")
+    shard = decode_pose_shard(path)
+    n = len(shard["image"])
+    if rule == "no_extreme_poses":
+        indices = indices_without_extreme_poses(shard["pose"], shard["coord"])
+    elif rule == "grimaces":
+        indices = np.asarray(_AFLW2K_GRIMACES)
+    else:
+        indices = np.arange(n)
+    if order is not None:
+        indices = indices[np.asarray(order)]
+    return ValidationSamples(shard, indices, PutRoiFromLandmarks(extend_to_forehead=use_head_roi, headmodel=headmodel))
+
+
+def make_validation_loader(name, order=None, use_head_roi=True, return_single_samples=True, datadir=None, headmodel=None):
+    """Reference :608-636 with return_single_samples=True, the form the evaluation script uses (frames of a set differ in size)."""
+    if not return_single_samples:
+        raise NotImplementedError("batched validation loaders: use make_pose_estimation_loaders' test loader (HBM-resident, cropped on the GPU)")
+    return make_validation_dataset(name, order, use_head_roi, datadir, headmodel)
+
+
 def _slice_frames(frames, lo, hi):
     from .datasets.resident import ResidentFrames
 
@@ -153,7 +244,7 @@ def _slice_frames(frames, lo, hi):
 
 def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights=None, use_weights_as_sampling_frequency=True,
                                  enable_image_aug=True, rotation_aug_angle=30.0, roi_override="original", device="cuda", seed=1234,
-                                 datadir=None, steps_per_epoch=None):
+                                 datadir=None, steps_per_epoch=None, headmodel=None):
     """Signature of the reference (pipelines.py:359-369) plus `seed` (data-parallel replicas draw different streams), `datadir` and
     `steps_per_epoch`.  `datasets`:
 
@@ -165,8 +256,10 @@ def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights
         AFLW2000-3D frames, as in the reference.  Behind the crop every sample is mirrored with probability 1/2 and turned by +-90
         degrees with probability 0.5 % each (`horizontal_flip_and_rot_90(0.01)`, :373-377), composed into the crop's warp.
         `roi_override`: "original" (stored face boxes, crop enlargement 1.1) or "landmarks" (boxes = xy extent of pt3d_68 in front of and
-        behind the crop, enlargement 1.2; :329-350).  "extent_to_forehead" needs the vertices of the full BFM head model, a blob the
-        reference's repository does not carry: it raises.
+        behind the crop, enlargement 1.2; :329-350) or "extent_to_forehead" (boxes = xy extent of the posed BFM head mesh in front of the
+        crop only, enlargement 1.1; :351-356 - computed once per resident frame set, since they depend on the labels alone).  The last one
+        needs the vertices of the full BFM head model, a blob neither the reference's repository nor this package carries
+        (facemodel/bfm.py): FileNotFoundError without it.
     """
     if datasets == "synthetic":
         datasets = [(Tag.POSE_WITH_LANDMARKS, 11.0), (Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS, 1.0)]
@@ -180,11 +273,12 @@ def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights
         raise ValueError('datasets: "synthetic", a list of (Tag, weight) pairs, or a sequence of pipelines.Id')
     if roi_override not in ("original", "landmarks", "extent_to_forehead"):
         raise ValueError(f"roi_override: got {roi_override!r}")  # (the reference asserts, :330)
+    head_roi = None
     if roi_override == "extent_to_forehead":
-        raise NotImplementedError('roi_override="extent_to_forehead": PutRoiFromLandmarks(extend_to_forehead=True) takes the extent of the posed '
-                                  "BFM head's VERTICES (batch/misc.py:18-21); the reference's bfm_noneck_v3.pkl is a missing blob, so there is "
-                                  'nothing to build or to pin against; "original" and "landmarks" are built')
-    extension_factor = {"original": 1.1, "landmarks": 1.2}[roi_override]  # :333
+        from .datatransformation.batch.misc import PutRoiFromLandmarks
+
+        head_roi = PutRoiFromLandmarks(extend_to_forehead=True, headmodel=headmodel)  # FileNotFoundError when the BFM blob is absent
+    extension_factor = {"original": 1.1, "extent_to_forehead": 1.1, "landmarks": 1.2}[roi_override]  # :333
     import os
 
     from .datasets.resident import ResidentEvalLoader, ResidentLoader
@@ -209,6 +303,8 @@ def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights
                                     f"{name}.h5 {path}` (h5py lives in the build container's conda interpreter only)")
         if path not in cache:
             cache[path] = load_resident_frames(path, tag, device)
+            if head_roi is not None:
+                head_roi(cache[path].fields)  # frames with landmarks get the forehead box; the others keep their stored one
         return cache[path]
 
     dataset_weights = dataset_weights or {}

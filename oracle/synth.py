@@ -184,3 +184,24 @@ def digest_close(d_expected: np.ndarray, a, rtol: float, atol: float, rtol_sampl
     err_n = abs(d[0] - d_expected[0])
     ok_n = err_n <= atol * math.sqrt(d_expected[3]) + rtol * d_expected[0]
     return bool(ok_s and ok_n), f"sample err {err_s:.3e} (rms {scale:.3e}), norm err {err_n:.3e} of {d_expected[0]:.3e}"
+
+
+# ---------------------------------------------------------------------------------------------
+# A seeded synthetic blob in the format of the reference's missing bfm_noneck_v3.pkl / tri.pkl (3DDFA_V2): test input for
+# facemodel/bfm.py.  V must exceed the hard-coded eye-contour vertex indices (14 327).
+# ---------------------------------------------------------------------------------------------
+def write_synthetic_bfm_blob(folder: str, V: int = 14400, n_shp: int = 42, n_exp: int = 11, seed: int = 515) -> None:
+    import os
+    import pickle
+
+    rng = np.random.default_rng(seed)
+    u = (rng.standard_normal((3 * V, 1)) * 4.0e4 + np.tile([0.0, 2.6e4, 9.0e4], V)[:, None]).astype(np.float64)  # the loader casts to f32
+    w_shp = (rng.standard_normal((3 * V, n_shp)) * 3.0e-4).astype(np.float64)
+    w_exp = (rng.standard_normal((3 * V, n_exp)) * 40.0).astype(np.float64)
+    kp = rng.permutation(V)[:68].astype(np.int64)
+    keypoints = (3 * kp[:, None] + np.arange(3)[None, :]).reshape(-1)
+    tri = rng.integers(0, V, (3, 64)).astype(np.int64)
+    with open(os.path.join(folder, "bfm_noneck_v3.pkl"), "wb") as f:
+        pickle.dump({"u": u, "w_shp": w_shp, "w_exp": w_exp, "keypoints": keypoints}, f)
+    with open(os.path.join(folder, "tri.pkl"), "wb") as f:
+        pickle.dump(tri, f)

@@ -37,6 +37,9 @@ def convert_pose_dataset(src, dst):
         for k in ["coords", "quats", "rois", "pt3d_68", "pt2d_68", "shapeparams", "hasface"]:  # the reader's label whitelist (dshdf5pose.py:168-180)
             if k in f:
                 d[k] = f[k][...]
+        for k in ["sequence_starts", "individual"]:  # who is in a frame (dshdf5pose.py:221-228): the "opal23" alignment of the evaluation needs it
+            if k in f:
+                d[k] = f[k][...]
         np.savez(dst, **d)
         print(dst, {k: (v.shape, v.dtype) for k, v in d.items()})
 

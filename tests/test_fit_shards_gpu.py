@@ -99,3 +99,33 @@ def test_fit_from_shards_with_validation_and_best_checkpoint(tmp_path, monkeypat
         total += float(torch.cat([v.reshape(-1) for v in vals]).sum()) * b.meta.batchsize
         count += b.meta.batchsize
     assert abs(total / count - val_gpu) <= 2e-3 * abs(val_gpu), (total / count, val_gpu)
+
+
+def test_roi_override_extent_to_forehead(tmp_path, monkeypatch):
+    """roi_override="extent_to_forehead" (reference pipelines.py:351-356): the crop is taken around the xy extent of the posed BFM head mesh.
+    With a synthetic blob of the missing files' format (the arithmetic is pinned in tests/test_bfm.py); without any blob: FileNotFoundError."""
+    import trackertraincode.pipelines as P
+    from oracle.synth import write_synthetic_bfm_blob
+    from trackertraincode.datatransformation.batch import head_extent_roi
+    from trackertraincode.facemodel.bfm import BFMModel, ScaledBfmModule
+
+    datadir = _datadir(tmp_path)
+    monkeypatch.setitem(P._POSE_SHARDS, P.Id.AFLW2k3d, ("aflw2k", P.Tag.POSE_WITH_LANDMARKS, 1000.0, (8, None)))
+    monkeypatch.setattr(P, "_TEST_SHARD", ("aflw2k", P.Tag.POSE_WITH_LANDMARKS, (0, 8)))
+    have_blob = os.path.exists(os.path.join(os.path.dirname(P.__file__), "facemodel", "bfm_noneck_v3.pkl"))
+    if not have_blob:
+        with pytest.raises(FileNotFoundError, match="bfm_noneck_v3"):
+            P.make_pose_estimation_loaders(129, 8, [P.Id.AFLW2k3d], device="cuda", datadir=datadir, roi_override="extent_to_forehead")
+    blob = tmp_path / "bfm"
+    blob.mkdir()
+    write_synthetic_bfm_blob(str(blob))
+    mesh = ScaledBfmModule(BFMModel(folder=str(blob)))
+    _, test_o, _ = P.make_pose_estimation_loaders(129, 8, [P.Id.AFLW2k3d], device="cuda", datadir=datadir, enable_image_aug=False)
+    _, test_h, _ = P.make_pose_estimation_loaders(129, 8, [P.Id.AFLW2k3d], device="cuda", datadir=datadir, enable_image_aug=False,
+                                                  roi_override="extent_to_forehead", headmodel=mesh)
+    fo, fh = test_o.datasets[0].fields, test_h.datasets[0].fields
+    want = head_extent_roi(mesh.vertices.cuda(), fo["coord"], fo["pose"])
+    assert torch.allclose(fh["roi"], want) and not torch.allclose(fh["roi"], fo["roi"])
+    bo, bh = next(iter(test_o)), next(iter(test_h))
+    # the synthetic mesh is a point cloud of about +-2 head sizes: its box is larger than the face box, so the same head fills less of the crop
+    assert float((bh["coord"][:, 2] / bo["coord"][:, 2]).max()) < 1.0
