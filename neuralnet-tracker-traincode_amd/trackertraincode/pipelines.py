@@ -244,7 +244,7 @@ def _slice_frames(frames, lo, hi):
 
 def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights=None, use_weights_as_sampling_frequency=True,
                                  enable_image_aug=True, rotation_aug_angle=30.0, roi_override="original", device="cuda", seed=1234,
-                                 datadir=None, steps_per_epoch=None, headmodel=None):
+                                 datadir=None, steps_per_epoch=None, headmodel=None, frames_on="auto", hbm_budget_bytes=None):
     """Signature of the reference (pipelines.py:359-369) plus `seed` (data-parallel replicas draw different streams), `datadir` and
     `steps_per_epoch`.  `datasets`:
 
@@ -260,6 +260,9 @@ def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights
         crop only, enlargement 1.1; :351-356 - computed once per resident frame set, since they depend on the labels alone).  The last one
         needs the vertices of the full BFM head model, a blob neither the reference's repository nor this package carries
         (facemodel/bfm.py): FileNotFoundError without it.
+        `frames_on`: "device" (decoded frames live in HBM), "host" (pinned host memory, gathered and copied per step on a side stream, one
+        step ahead: datasets/resident.py) or "auto": in HBM while the decoded shards stay within `hbm_budget_bytes` (default: half of
+        the device's memory), the largest datasets on the host beyond that.
     """
     if datasets == "synthetic":
         datasets = [(Tag.POSE_WITH_LANDMARKS, 11.0), (Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS, 1.0)]
@@ -294,7 +297,13 @@ def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights
                                   f"path this package implements (supported: {sorted(d.name for d in _POSE_SHARDS)})")
     if len([d for d in datasets if d in (Id._300WLP, Id.REPO_300WLP, Id.REPO_300WLP_WO_EXTRA)]) > 1:
         raise ValueError("at most one 300W-LP variant (reference :435-438)")
+    if frames_on not in ("auto", "device", "host"):
+        raise ValueError(f"frames_on: got {frames_on!r}")
     cache: dict = {}
+    budget = hbm_budget_bytes
+    if budget is None and frames_on == "auto":
+        budget = torch.cuda.get_device_properties(device).total_memory // 2 if str(device).startswith("cuda") else 0
+    on_device_bytes = [0]
 
     def shard(name, tag):
         path = os.path.join(datadir, name + ".npz")
@@ -302,7 +311,12 @@ def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights
             raise FileNotFoundError(f"{path} not found: convert {name}.h5 with `/opt/conda/bin/python3.9 oracle/tools/h5_to_npz.py --dataset "
                                     f"{name}.h5 {path}` (h5py lives in the build container's conda interpreter only)")
         if path not in cache:
-            cache[path] = load_resident_frames(path, tag, device)
+            frames = load_resident_frames(path, tag, "cpu")
+            if frames_on == "device" or (frames_on == "auto" and on_device_bytes[0] + frames.nbytes() <= budget):
+                on_device_bytes[0] += frames.nbytes()
+                cache[path] = frames.to(device)
+            else:  # beyond the HBM budget (or asked for): pinned host memory, streamed per step
+                cache[path] = frames.to_host()
             if head_roi is not None:
                 head_roi(cache[path].fields)  # frames with landmarks get the forehead box; the others keep their stored one
         return cache[path]
