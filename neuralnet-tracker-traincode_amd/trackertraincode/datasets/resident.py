@@ -52,7 +52,8 @@ class ResidentFrames:
 
     @property
     def on_host(self) -> bool:
-        return self.fields["image"].device.type == "cpu"
+        """Frames in host memory that a GPU consumes (without a GPU the loaders' draw plan can still be exercised on CPU tensors)."""
+        return self.fields["image"].device.type == "cpu" and torch.cuda.is_available()
 
     def to(self, device) -> "ResidentFrames":
         return ResidentFrames(self.tag, {k: v.to(device) for k, v in self.fields.items()})
@@ -72,7 +73,7 @@ def _device_of(datasets, device):
     for d in datasets:
         if not d.on_host:
             return d.fields["image"].device
-    return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
 
 
 class _HostGather:
