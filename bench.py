@@ -461,9 +461,12 @@ def main():
             # so its fp32-equivalent ceiling is the dense bf16 peak / 6; pw_gemm_k / pw_wgrad_k (the early, HBM-bound
             # pointwise layers) are fp32 MFMA kernels priced against HBM.
             # counter traffic: --traffic-json, else the newest profiles/r*_pmc_traffic.json whose csrc_sha256 stamp (tools/build_id.py)
-            # equals this tree's - counters of another build are never attached
+            # equals this tree's - counters of another build are never attached, and the committed summaries (tools/profile_round.sh: the
+            # default workload) only to the default workload: per-launch bytes of B = 512 say nothing about another batch size or network
             traffic, traffic_src = {}, None
-            cands = [args.traffic_json] if args.traffic_json else sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True)
+            default_workload = args.batch == 512 and args.backbone == "mobilenetv1" and args.precision == "fp32" and not args.blurpool
+            cands = [args.traffic_json] if args.traffic_json else (
+                sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True) if default_workload else [])
             sys.path.insert(0, os.path.join(REPO, "tools"))
             from build_id import csrc_sha256
             tree = csrc_sha256()
@@ -486,9 +489,11 @@ def main():
                 else:
                     ach, peak, unit = v["flops"] / sec / 1e12, PEAK_BF16_MFMA_TFLOPS / products, "TFLOP/s"
                 # the labels of work() are prefixes of the profiler's kernel names (trailing template arguments omitted)
-                tr = traffic.get(k) or next((v_ for k_, v_ in traffic.items() if k_.startswith(k.rstrip(">"))), None)
+                # (one label can cover several instantiations - dw_fwd_tiled_k<1, float, SKIP, 32, CARRY>: their launch-weighted mean)
+                trs = [traffic[k]] if k in traffic else [v_ for k_, v_ in traffic.items() if k_.startswith(k.rstrip(">"))]
+                tr_bytes = (sum(t["bytes_per_launch"] * t["launches"] for t in trs) / sum(t["launches"] for t in trs)) if trs else None
                 return {"bound": "hbm" if hbm else "mfma", "kernel": k, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                        "traffic": tr["bytes_per_launch"] if tr else None, "algorithmic_bytes_per_launch": v["bytes"] / launches,
+                        "traffic": tr_bytes, "algorithmic_bytes_per_launch": v["bytes"] / launches,
                         "flops_per_launch": v["flops"] / launches, "launch_avg_us": v["ms"] / launches * 1e3,
                         "launches_per_step": v["calls_per_step"], "ms_per_step": v["ms_per_step"]}
 

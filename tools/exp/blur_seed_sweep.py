@@ -10,8 +10,8 @@ from oracle.synth import make_inputs
 from trackertraincode.backbones.mobilenet_v1 import MobileNet
 
 for blur in (False, True):
-    for seed in range(7, 13):
-        B = 3
+    for seed in (7, 7, 7, 8, 9, 10):
+        B = int(sys.argv[1]) if len(sys.argv) > 1 else 3
         sd = T._backbone_state(blur=blur)
         image, _ = make_inputs(B, seed=seed)
         G = np.random.default_rng(5).standard_normal((B, 1024)).astype(np.float32)
