@@ -340,7 +340,16 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
 // ---------------------------------------------------------------------------------------------
 // data gradient (+ fused weight gradient)
 // ---------------------------------------------------------------------------------------------
-template <int S, typename T, typename TG, int SL>
+// LEAN: the block has no residual operands (a_in, skip_prev, skip_grad all null: the strided blocks and dw2_1).  Then the second phase
+// reads one tensor only (yprev) and two pixels per iteration keep 8 KB per workgroup in flight: LEAN handles kLeanPix pixels per
+// iteration with the registers the three absent operands would take.
+#ifndef TTK_DW_BWD_LEAN_PIX
+#define TTK_DW_BWD_LEAN_PIX 4   // stride 1 (168 registers: the cap)
+#endif
+#ifndef TTK_DW_BWD_LEAN_PIX2
+#define TTK_DW_BWD_LEAN_PIX2 4  // stride 2 (6 measured slower: 276 vs 263 us on the 65 x 65 x 64 layer)
+#endif
+template <int S, typename T, typename TG, int SL, bool LEAN>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3)))  // <= 168 VGPRs: 3 workgroups per CU, as the LDS tile allows
 dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
                                                           const float* __restrict__ bn_dw, const float* __restrict__ w,
@@ -426,33 +435,46 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
     const unsigned npix1 = (unsigned)((r1 - r0) * tw);  // input pixels per image
     const int npix = nimg * (int)npix1;
     const TileDiv dnp(npix1);
-    // two pixels per thread and iteration: their (up to six) global loads are issued back to back before either
-    // pixel's LDS taps are read
-    for (int p = slot; p < npix; p += 2 * kPixSlots) {
-      const int pb = p + kPixSlots;
-      const bool hasb = pb < npix;
-      const unsigned imgA = NI > 1 ? dnp.div((unsigned)p) : 0u, ppA = NI > 1 ? (unsigned)p - __umul24(imgA, npix1) : (unsigned)p;
-      const unsigned imgB = (NI > 1 && hasb) ? dnp.div((unsigned)pb) : imgA;
-      const unsigned ppB = hasb ? ((NI > 1) ? (unsigned)pb - __umul24(imgB, npix1) : (unsigned)pb) : ppA;
-      const unsigned prA = dtw.div(ppA), prB = dtw.div(ppB);
-      const int hiA = r0 + (int)prA, wiA = cx0 + (int)(ppA - __umul24(prA, (unsigned)tw));
-      const int hiB = r0 + (int)prB, wiB = cx0 + (int)(ppB - __umul24(prB, (unsigned)tw));
-      const unsigned offA = ((__umul24(__umul24(imgA, (unsigned)H) + (unsigned)hiA, (unsigned)W) + (unsigned)wiA) << cshift) + 4 * q;
-      const unsigned offB = ((__umul24(__umul24(imgB, (unsigned)H) + (unsigned)hiB, (unsigned)W) + (unsigned)wiB) << cshift) + 4 * q;
-      const float4 ypA = Act<T>::ldnt(yptile + offA), ypB = Act<T>::ldnt(yptile + offB);
-      float4 rawA = f4(0.f), rawB = f4(0.f), sgA = f4(0.f), sgB = f4(0.f);
-      if (a_in) { rawA = Act<T>::ldnt(aitile + offA); rawB = Act<T>::ldnt(aitile + offB); }
-      else if (skip_prev) { rawA = Act<T>::ldnt(sktile + offA); rawB = Act<T>::ldnt(sktile + offB); }
-      if (skip_grad) { sgA = Act<TG>::ldnt(sgtile + offA); sgB = Act<TG>::ldnt(sgtile + offB); }
+    // NP pixels per thread and iteration: their (up to 3 NP) global loads are issued back to back before any pixel's LDS taps are read
+    constexpr int NP = LEAN ? (S == 2 ? TTK_DW_BWD_LEAN_PIX2 : TTK_DW_BWD_LEAN_PIX) : 2;
+    for (int p = slot; p < npix; p += NP * kPixSlots) {
+      bool has[NP];
+      unsigned imgs[NP], offs[NP];
+      int his[NP], wis[NP];
+      float4 yps[NP], raws[NP], sgs[NP];
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        if (half == 1 && !hasb) break;
-        const int hi = half ? hiB : hiA, wi = half ? wiB : wiA;
-        const float* dyimg = lds + (__umul24(half ? imgB : imgA, PI) << kPs);
-        const float4 yp = half ? ypB : ypA, raw = half ? rawB : rawA, sg = half ? sgB : sgA;
+      for (int j = 0; j < NP; ++j) {
+        const int pj = p + j * kPixSlots;
+        has[j] = pj < npix;
+        const unsigned pq = has[j] ? (unsigned)pj : (unsigned)p;  // absent pixels repeat the first one's (valid) address
+        imgs[j] = NI > 1 ? dnp.div(pq) : 0u;
+        const unsigned pp = NI > 1 ? pq - __umul24(imgs[j], npix1) : pq;
+        const unsigned pr = dtw.div(pp);
+        his[j] = r0 + (int)pr;
+        wis[j] = cx0 + (int)(pp - __umul24(pr, (unsigned)tw));
+        offs[j] = ((__umul24(__umul24(imgs[j], (unsigned)H) + (unsigned)his[j], (unsigned)W) + (unsigned)wis[j]) << cshift) + 4 * q;
+      }
+#pragma unroll
+      for (int j = 0; j < NP; ++j) yps[j] = Act<T>::ldnt(yptile + offs[j]);
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        raws[j] = f4(0.f);
+        sgs[j] = f4(0.f);
+        if (!LEAN) {
+          if (a_in) raws[j] = Act<T>::ldnt(aitile + offs[j]);
+          else if (skip_prev) raws[j] = Act<T>::ldnt(sktile + offs[j]);
+          if (skip_grad) sgs[j] = Act<TG>::ldnt(sgtile + offs[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        if (j > 0 && !has[j]) break;
+        const int hi = his[j], wi = wis[j];
+        const float* dyimg = lds + (__umul24(imgs[j], PI) << kPs);
+        const float4 yp = yps[j], raw = raws[j], sg = sgs[j];
         float4 a;
-        if (a_in) a = raw;
-        else a = skip_prev ? bnp.act(yp, raw) : bnp.act(yp);
+        if (!LEAN && a_in) a = raw;
+        else a = (!LEAN && skip_prev) ? bnp.act(yp, raw) : bnp.act(yp);
         float4 G = f4(0.f);
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
@@ -470,9 +492,9 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
             wacc[kh * 3 + kw] = fma4(dy, a, wacc[kh * 3 + kw]);
           }
         }
-        if (skip_grad) G = add4(G, sg);
+        if (!LEAN && skip_grad) G = add4(G, sg);
         const float4 gp = Act<TG>::round(mask4(G, a));  // sums and maximum of what is stored
-        Act<TG>::st(gptile + (half ? offB : offA), gp);
+        Act<TG>::st(gptile + offs[j], gp);
         gmx = fmaxf(fmaxf(gmx, fmaxf(fabsf(gp.x), fabsf(gp.y))), fmaxf(fabsf(gp.z), fabsf(gp.w)));
         s1.add(gp);
         s2.addmul(gp, sub4(yp, bnp.mean));
@@ -563,11 +585,15 @@ int ttk_dwconv3x3_bwd_data(const void* g_dw, const void* y_dw, const float* bn_d
   if (!dw) dw_partial = nullptr;
   if (dw && !dw_accumulate && !dw_partial) hipLaunchKernelGGL(zero_fill_k, dim3((9 * C + 255) / 256), dim3(256), 0, st, dw, (int64_t)9 * C);
 #define TTK_DW_BWD(S_) TTK_DW_BWD_SL(S_, kCB)
-#define TTK_DW_BWD_SL(S_, SL_)                                                                                                      \
-  hipLaunchKernelGGL((dw_bwd_tiled_k<S_, ActT, GradT, SL_>), dim3(t.grid), dim3(kBlock), sm, st, (const GradT*)g_dw, (const ActT*)y_dw, bn_dw, w, \
+#define TTK_DW_BWD_SL(S_, SL_) \
+  TTK_DW_BWD_L(S_, SL_, true); else TTK_DW_BWD_L(S_, SL_, false)
+#define TTK_DW_BWD_L(S_, SL_, LEAN_)                                                                                                      \
+  hipLaunchKernelGGL((dw_bwd_tiled_k<S_, ActT, GradT, SL_, LEAN_>), dim3(t.grid), dim3(kBlock), sm, st, (const GradT*)g_dw, (const ActT*)y_dw, bn_dw, w, \
                      (const GradT*)skip_grad, (const ActT*)yprev, bn_prev, (const ActT*)skip_prev, (const ActT*)a_in, (GradT*)g_prev, part,  \
                      dw, dw_partial, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage, t.NI, t.NCT, t.TW)
-  TTK_ACT_DISPATCH(act_bf16, if (stride == 1) TTK_DW_BWD(1); else TTK_DW_BWD(2));
+  const bool lean = !a_in && !skip_prev && !skip_grad;
+  TTK_ACT_DISPATCH(act_bf16, if (stride == 1) { if (lean) TTK_DW_BWD(1); } else { if (lean) TTK_DW_BWD(2); });
+#undef TTK_DW_BWD_L
 #undef TTK_DW_BWD
 #undef TTK_DW_BWD_SL
   if (dw_partial) launch_fold_partials(dw_partial, t.rows, (int64_t)9 * C, dw, dw_accumulate, st);
