@@ -157,7 +157,8 @@ def report(net_filename, data_name, roi_config: RoiConfig, args, builder: TableB
         rmse_size=np.sqrt(np.average(np.square(e_size))) * 100.0,
         unweighted_nme_3d=np.average(uw_nme_3d) if uw_nme_3d is not None else None,
         nme_2d=results.get("nme_2d"),
-        data_aux_string=" / " + str(roi_config),
+        # (a bare .npz is evaluated with the boxes it stores: neither the head-mesh nor the landmark extent is substituted)
+        data_aux_string=" / " + (f"(stored)ROI{roi_config.expansion_factor:0.1f}" if data_name.endswith(".npz") else str(roi_config)),
     )
 
 

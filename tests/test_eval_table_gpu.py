@@ -71,6 +71,6 @@ def test_script_tables(tmp_path, capsys):
     # text form, alignment schemes, a bare .npz as data
     S.main([ck, "--ds", os.path.join(GOLDEN, "aflw2kmini.npz"), "--roi-expansion", "1.2", "--alignment-scheme", "perspective"])
     text = capsys.readouterr().out
-    assert "| Data" in text and "(H_roi)ROI1.2" in text and "Geodesic°" in text
+    assert "| Data" in text and "(stored)ROI1.2" in text and "Geodesic°" in text
     with pytest.raises(NotImplementedError):
         S.main([ck, "--vis", "rot"])
