@@ -50,6 +50,9 @@ def parse():
                     "gradients fp32; bf16-all = both bf16")
     ap.add_argument("--traffic-json", default=None, help="rocprofv3 PMC summary (tools/pmc_summary.py) taken with THIS build; "
                     "fills roofline.traffic (null without it)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (the measurement); gloo with --share-gpu: "
+                    "a dry run of the multi-rank code path on a one-GPU box (tests/test_bench_dp_dryrun_gpu.py) - its rate is not a result")
+    ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses device 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-copy-probe", action="store_true", help="skip the same-process streaming probe (copy_probe object)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-call HIP-event instrumentation (roofline = null)")
@@ -321,10 +324,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if (args.dist_backend != "nccl") != args.share_gpu:
+        raise SystemExit("--dist-backend gloo and --share-gpu belong together (dry run of the multi-rank path on one GPU)")
+    local = 0 if args.share_gpu else local
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     import trackertraincode._hip as H
@@ -511,7 +520,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": f"NetworkWithPointHead({args.backbone}{', --blurpool' if args.blurpool else ''}, point head on, NLL off = training-script defaults): "
-                                   "zero_grad + fwd + multi-task loss + bwd" + (" + RCCL grad all-reduce overlapped with bwd" if world > 1 else "") + " + fused clip/Adam step",
+                                   "zero_grad + fwd + multi-task loss + bwd" + ((" + RCCL grad all-reduce overlapped with bwd" if args.dist_backend == "nccl" else " + gloo grad all-reduce, ranks SHARING one GPU (dry run, not a result)") if world > 1 else "") + " + fused clip/Adam step",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "input": "129x129x1 f32",
                        "parallelism": f"dp{world}"},
             "roofline": roof,
