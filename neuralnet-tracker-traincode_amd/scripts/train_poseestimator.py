@@ -180,12 +180,18 @@ def main():
 
     mobilenet_v1.set_activation_dtype(args.precision)
     world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    # TTK_DRYRUN_SHARE_GPU=1: every rank on device 0 with gloo instead of RCCL - a dry run of the multi-rank wiring on a one-GPU box
+    # (tests/test_train_script_dp_dryrun_gpu.py); RCCL needs one device per rank
+    share_gpu = os.environ.get("TTK_DRYRUN_SHARE_GPU", "0") != "0"
+    device = torch.device("cuda", 0 if share_gpu else int(os.environ.get("LOCAL_RANK", 0)))
     torch.cuda.set_device(device)
     if world > 1:  # before anything else touches the GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     train_loader, test_loader, _ = setup_datasets(args, device, rank)
     net = create_net(args).to(device)
     parallel.broadcast_module_state(net)  # every replica starts from rank 0's weights

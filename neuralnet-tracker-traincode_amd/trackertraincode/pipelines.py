@@ -106,7 +106,11 @@ class SyntheticPoseLoader:
     loader returned by make_pose_estimation_loaders, reference :534-554)."""
 
     def __init__(self, batchsize: int, tags_and_weights: Sequence[tuple[Tag, float]], device="cuda", seed=1234, inputsize=129,
-                 steps_per_epoch: int | None = None, image_augmentations=None):
+                 steps_per_epoch: int | None = None, image_augmentations=None, single_batch: bool = False):
+        # single_batch: the contract of the TEST loader instead (reference :543-552: one Batch per iteration, not a list) - one Tag only
+        if single_batch and len(tags_and_weights) != 1:
+            raise ValueError("single_batch: one Tag")
+        self._single = single_batch
         self._augs = image_augmentations  # containers from make_image_augmentations (images are un-whitened for them)
         total = sum(w for _, w in tags_and_weights)
         counts = [int(batchsize * w / total) for _, w in tags_and_weights]
@@ -129,7 +133,7 @@ class SyntheticPoseLoader:
                     for aug in self._augs:
                         img = aug.apply(img, aug.sample_params(img.shape[0]))
                     b["image"] = img
-            yield batches
+            yield batches[0] if self._single else batches
 
 
 # The pose datasets of the reference that carry what the pose-estimator step trains on (pipelines.py:120-300, 399-453): file (as an .npz
@@ -270,7 +274,7 @@ def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights
         augs = make_image_augmentations(torch.Generator().manual_seed(99 + seed)) if enable_image_aug and str(device).startswith("cuda") else None
         train = SyntheticPoseLoader(batchsize, datasets, device=device, seed=seed, inputsize=inputsize, image_augmentations=augs)
         test = SyntheticPoseLoader(batchsize, [(Tag.POSE_WITH_LANDMARKS, 1.0)], device=device, seed=4321, inputsize=inputsize,
-                                   steps_per_epoch=max(1, 400 // batchsize))
+                                   steps_per_epoch=max(1, 400 // batchsize), single_batch=True)
         return train, test, len(train) * batchsize
     if not (isinstance(datasets, (list, tuple)) and datasets and all(isinstance(d, Id) for d in datasets)):
         raise ValueError('datasets: "synthetic", a list of (Tag, weight) pairs, or a sequence of pipelines.Id')

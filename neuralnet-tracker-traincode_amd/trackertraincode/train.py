@@ -620,6 +620,9 @@ def validate(model: nn.Module, val_loader, val_criterions) -> float:
     total, count = None, 0
     try:
         for batch_idx, batch in enumerate(val_loader):
+            if isinstance(batch, (list, tuple)):
+                raise TypeError("validate: the validation loader yields ONE Batch per iteration (reference pipelines.py:543-552), got a list - "
+                                "train loaders yield lists")
             pred = model(batch["image"])
             crit = val_criterions[batch.meta.tag] if isinstance(val_criterions, dict) else val_criterions
             values = crit.evaluate(pred, batch, batch_idx)
