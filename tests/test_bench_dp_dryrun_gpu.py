@@ -13,17 +13,18 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_sharing_the_gpu():
+@pytest.mark.parametrize("extra", [[], ["--backbone", "resnet18"], ["--precision", "bf16"], ["--blurpool"]], ids=["default", "resnet18", "bf16", "blurpool"])
+def test_two_ranks_sharing_the_gpu(extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29571",
            os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "64", "--dist-backend", "gloo", "--share-gpu",
-           "--no-cpu-baseline", "--no-copy-probe"]
+           "--no-cpu-baseline", "--no-copy-probe", *extra]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]  # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak" and d["dtype"] == ("bf16" if "bf16" in extra else "f32")
     assert d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2" and "dry run" in d["config"]["workload"]
     assert d["value"] > 0 and abs(d["value"] - 128 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     assert d["roofline"] is not None and d["roofline"]["traffic"] is None  # B = 64 per rank: not the default workload, no counters attached
