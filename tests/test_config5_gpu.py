@@ -1,85 +1,98 @@
-"""BASELINE config 5 on the one GPU this pool offers: the multi-task mix (three dataset kinds with different label sets) drawn by the
-weighted sampler, random focus-ROI crop + affine warp + label bookkeeping + mirror / quarter turns + intensity augmentation on the GPU,
-NLL losses with their ramp, clip + Adam - with bf16 activation storage, at 512 crops per step, through train.fit().  (The 8-GPU part of
-the configuration - RCCL all-reduce - is covered by tests/test_parallel_*.py and test_dp2_gpu.py.)  The bf16 run is held to the fp32 run
-of the same data: same draws, same augmentation parameters; per-step losses within the bf16-storage tolerance measured in
-tests/test_bf16_gpu.py for single steps, loosened for the parameter drift of the preceding steps."""
+"""BASELINE config 5, fp32 leg, at full size on one GPU: 512 crops per step drawn from four HBM-resident uint8 datasets of
+192x192 frames with the reference's sampling weights 60 000 : 40 000 : 10 000 : 10 000 (pipelines.py:399-453), random
+view ROIs / angles (batch/geometric.py:63-84), GPU warp to 129x129 + label bookkeeping - every sample checked against the
+CPU oracle (oracle/augment.py, pinned to the reference by tests/golden/augment.npz): view_roi BIT-EXACT (integer
+bookkeeping), transforms, all labels, and the warped pixels."""
 import numpy as np
 import pytest
 import torch
 
-from util import script_args, train_script
+from oracle import augment as A
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda"
+N = 129
 
 
-def _frames(tag, n, size, seed, with_pts, with_shape):
-    from trackertraincode.datasets.resident import ResidentFrames
-
-    g = torch.Generator().manual_seed(seed)
-    S = size
-    f = {
-        "image": torch.randint(0, 255, (n, 1, S, S), dtype=torch.uint8, generator=g),
-        "roi": torch.tensor([[0.25 * S, 0.25 * S, 0.75 * S, 0.75 * S]]).repeat(n, 1) + torch.randn(n, 4, generator=g) * 3,
-        "coord": torch.cat([torch.full((n, 2), 0.5 * S) + torch.randn(n, 2, generator=g) * 4, torch.full((n, 1), 0.22 * S)], -1),
-        "pose": torch.nn.functional.normalize(torch.cat([torch.randn(n, 3, generator=g) * 0.3, torch.ones(n, 1)], -1), dim=-1),
-        "coord_convention_id": torch.full((n,), seed % 3, dtype=torch.int32),
-    }
-    if with_pts:
-        f["pt3d_68"] = torch.cat([torch.rand(n, 68, 2, generator=g) * 0.4 * S + 0.3 * S, torch.randn(n, 68, 1, generator=g) * 10], -1)
+def _dataset(tag, n, seed, with_shape):
+    g = np.random.default_rng(seed)
+    img = g.integers(0, 256, (n, 1, 192, 192), dtype=np.uint8)
+    yy, xx = np.mgrid[0:192, 0:192]
+    img = (0.5 * img + 0.5 * (127 + 100 * np.sin(xx[None, None] * g.uniform(0.02, 0.2, (n, 1, 1, 1)) + yy[None, None] * g.uniform(0.02, 0.2, (n, 1, 1, 1))))).astype(np.uint8)
+    c = g.uniform(60, 132, (n, 2))
+    half = g.uniform(25, 60, (n, 2))
+    roi = np.concatenate([c - half, c + half], -1).astype(np.float32)  # face boxes in pixels
+    pose = g.standard_normal((n, 4)).astype(np.float32)
+    pose /= np.linalg.norm(pose, axis=-1, keepdims=True)
+    coord = np.concatenate([c, half.mean(-1, keepdims=True)], -1).astype(np.float32)
+    pts = np.concatenate([c[:, None, :] + g.standard_normal((n, 68, 2)) * half[:, None, :] * 0.5, g.standard_normal((n, 68, 1)) * 20], -1).astype(np.float32)
+    f = {"image": img, "roi": roi, "pose": pose, "coord": coord, "pt3d_68": pts, "frame_id": np.arange(n, dtype=np.int64) + 1000000 * seed}
     if with_shape:
-        f["shapeparam"] = torch.randn(n, 50, generator=g) * 0.5
-    return ResidentFrames(tag, {k: v.cuda() for k, v in f.items()})
+        f["shapeparam"] = (g.standard_normal((n, 50)) * 0.5).astype(np.float32)
+    return tag, f
 
 
-def _run(mode, steps=4, B=512):
-    import trackertraincode.backbones.mobilenet_v1 as MB
-    import trackertraincode.train as train
-    from trackertraincode.datasets.resident import ResidentLoader
-    from trackertraincode.datatransformation.gpu import GpuFocusRoiAugment
-    from trackertraincode.pipelines import Tag, make_image_augmentations
+class _RecordingParams:
+    """MakeRoiRandomizationParameters that keeps what it drew, in call order (one call per output sub-batch)."""
 
-    S = train_script()
-    sets = [_frames(Tag.POSE_WITH_LANDMARKS, 700, 160, 1, True, True), _frames(Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS, 300, 128, 2, True, False),
-            _frames(Tag.ONLY_POSE, 300, 192, 3, False, False)]
-    augs = make_image_augmentations(torch.Generator().manual_seed(100))
-    crop = GpuFocusRoiAugment(new_size=129, rotation_aug_angle=30.0, extension_factor=1.1, whiten=False, flip_rot_p=0.01)
-    loader = ResidentLoader(sets, [0.6, 0.2, 0.2], B, steps, seed=9, crop=crop, image_augmentations=augs)
-    flags = dict(with_pointhead=True, with_nll_loss=True, rampup_nll_losses=True)
-    args = script_args(flags, epochs=2)
-    torch.manual_seed(0)
-    net = S.create_net(args).cuda()
-    g = torch.Generator().manual_seed(7)
-    net.landmarks.deformablekeypoints.set_basis(torch.randn(68, 3, generator=g) * 0.5, torch.randn(50, 68, 3, generator=g) * 0.05)
-    crit, _ = S.setup_losses(args, net)
-    opt, sch = S.create_optimizer(net, args)
-    losses, tags = [], []
+    def __init__(self):
+        from trackertraincode.datatransformation.batch.geometric import MakeRoiRandomizationParameters
 
-    def on_step(epoch, out):
-        losses.append(float(out["loss"].detach()))
+        self.inner, self.calls = MakeRoiRandomizationParameters(30.0, 1.1), []
 
-    MB.set_activation_dtype(mode)
-    try:
-        torch.manual_seed(3)  # the noise augmentation draws from the global device generator
-        train.fit(net, loader, crit, opt, sch, epochs=1, on_step=on_step)
-        torch.cuda.synchronize()
-    finally:
-        MB.set_activation_dtype("fp32")
-    first = next(iter(ResidentLoader(sets, [0.6, 0.2, 0.2], B, 1, seed=9, crop=crop, image_augmentations=None)))
-    return losses, [b.meta.tag for b in first], [int(b["image"].shape[0]) for b in first], net
+    def __call__(self, B, generator=None, device="cpu"):
+        p = self.inner(B, generator=generator, device=device)
+        self.calls.append(p)
+        return p
 
 
-def test_multitask_mix_with_bf16_storage_tracks_fp32():
+def test_multitask_mix_through_resident_loader_matches_oracle_per_sample():
+    from trackertraincode.datasets.resident import ResidentFrames, ResidentLoader
+    from trackertraincode.datatransformation import GpuFocusRoiAugment
     from trackertraincode.pipelines import Tag
 
-    l32, tags, sizes, net32 = _run("fp32")
-    l16, _, _, net16 = _run("bf16")
-    assert set(tags) == {Tag.POSE_WITH_LANDMARKS, Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS, Tag.ONLY_POSE} and sum(sizes) == 512
-    assert len(l32) == len(l16) == 4 and all(np.isfinite(l32)) and all(np.isfinite(l16))
-    print("fp32 losses", l32, "bf16 losses", l16)
-    assert abs(l16[0] - l32[0]) <= 2e-3 * abs(l32[0])  # first step: the same parameters, bf16 rounding of the stored activations only
-    for a, b in zip(l32[1:], l16[1:]):
-        assert abs(b - a) <= 1e-1 * abs(a)  # later steps (measured 0.5 %, 1.5 %, 4.2 %): Adam's first updates amplify the gradients' bf16 noise
-    assert all(torch.isfinite(p).all() for p in net16.parameters())
-    moved = [float((p16 - p32).abs().max()) for p16, p32 in zip(net16.parameters(), net32.parameters())]
-    assert max(moved) > 0.0  # the two runs are not the same run
+    specs = [_dataset(Tag.POSE_WITH_LANDMARKS, 600, 1, True), _dataset(Tag.POSE_WITH_LANDMARKS, 400, 2, True),
+             _dataset(Tag.POSE_WITH_LANDMARKS, 100, 3, True), _dataset(Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS, 100, 4, False)]
+    src = {}
+    for _, f in specs:
+        for i, fid in enumerate(f["frame_id"]):
+            src[int(fid)] = (f, i)
+    frames = [ResidentFrames(tag, {k: torch.from_numpy(v).to(DEV) for k, v in f.items()}) for tag, f in specs]
+    rec = _RecordingParams()
+    loader = ResidentLoader(frames, [60000.0, 40000.0, 10000.0, 10000.0], batchsize=512, steps_per_epoch=1, seed=11,
+                            crop=GpuFocusRoiAugment(N, whiten=True, make_params=rec))
+    (batches,) = list(loader)
+    assert sum(b.meta.batchsize for b in batches) == 512 and len(batches) == 2  # split by Tag
+    assert {b.meta.tag for b in batches} == {Tag.POSE_WITH_LANDMARKS, Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS}
+    assert len(rec.calls) == len(batches)
+    nm = A.normalization(N)
+    checked_pixels = 0
+    for b, prm in zip(batches, rec.calls):
+        n = b.meta.batchsize
+        assert b["image"].shape == (n, 1, N, N) and b["image"].dtype == torch.float32
+        fid = b["frame_id"].cpu().numpy()
+        rows = [src[int(x)] for x in fid]
+        gather = lambda k: np.stack([f[k][i] for f, i in rows])
+        scales, angles, trans = (t.cpu().numpy() for t in (prm.scales, prm.angles, prm.translations))
+        # ---- INTEGER bookkeeping: bit-exact for every sample
+        view = A.round_view_roi(A.compute_view_roi(gather("roi"), scales, trans, 0.3))
+        assert np.array_equal(b.view_roi.cpu().numpy(), view)
+        tr = A.crop_transform(view, angles.astype(np.float64), N)
+        np.testing.assert_allclose(b.transform.cpu().numpy(), tr, rtol=2e-5, atol=2e-4)
+        # ---- labels: crop transform, then pixel -> [-1,1] (normalize_batch)
+        full = np.einsum("ij,bjk->bik", nm[:, :2].astype(np.float64), tr.astype(np.float64))
+        full[:, :, 2] += nm[:, 2]
+        full = full.astype(np.float32)
+        np.testing.assert_allclose(b["coord"].cpu().numpy(), A.transform_coord(full, gather("coord")), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(b["pose"].cpu().numpy(), A.transform_rot(full, gather("pose")), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(b["roi"].cpu().numpy(), A.transform_roi(full, gather("roi")), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(b["pt3d_68"].cpu().numpy(), A.transform_keypoints(full, gather("pt3d_68")), rtol=1e-4, atol=3e-5)
+        if "shapeparam" in b:
+            assert np.array_equal(b["shapeparam"].cpu().numpy(), gather("shapeparam"))  # passes through untouched
+        # ---- pixels: every 8th sample against the numpy bilinear warp (grey levels; fp32 gather arithmetic)
+        crop = (b["image"].cpu().numpy()[:, 0] + 0.5) * 256.0
+        imgs = gather("image")[:, 0].astype(np.float32)
+        for i in range(0, n, 8):
+            np.testing.assert_allclose(crop[i], A.warp_bilinear(imgs[i], tr[i], N), atol=6e-2)
+            checked_pixels += 1
+    assert checked_pixels >= 60
