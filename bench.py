@@ -44,7 +44,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="crops per GPU")
     ap.add_argument("--backbone", default="mobilenetv1", choices=["mobilenetv1", "resnet18"])
-    ap.add_argument("--blurpool", action="store_true", help="the training script's --blurpool: BlurPool2D + stride-1 depthwise conv in the strided MobileNet blocks")
+    ap.add_argument("--blurpool", action="store_true", help="the training script's --blurpool: BlurPool2D + stride-1 depthwise conv in the strided MobileNet blocks (ResNet18: in front of every "
+                    "block's first convolution and in the max-pool's place)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16-all"],
                     help="BASELINE config 5's storage variant (separate line, dtype bf16; mobilenetv1 only): bf16 = activations bf16 in HBM, their "
                     "gradients fp32; bf16-all = both bf16")
@@ -282,7 +283,7 @@ def cpu_baseline(args):
     B = args.cpu_batch
     if args.backbone == "resnet18":  # the heads on 512 features + the ResNet-18 backbone under "convnet."
         heads = {k: v for k, v in R.state_shapes(True, False, num_features=512).items() if not k.startswith("convnet.")}
-        shapes = {**R.resnet18_state_shapes(prefix="convnet."), **heads}
+        shapes = {**R.resnet18_state_shapes(prefix="convnet.", use_blurpool=args.blurpool), **heads}
     else:
         shapes = R.state_shapes(True, False, use_blurpool=args.blurpool)
     st = R.state_from_numpy(make_state(shapes, 0))

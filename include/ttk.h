@@ -49,7 +49,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 20
+#define TTK_ABI_VERSION 21
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -331,6 +331,12 @@ int ttk_maxpool3x3s2_bwd(const float* ga, const float* gb, const unsigned char* 
 int ttk_bn_add_act(const float* y, float* bn, const float* res, const float* res_bn, float* a, const float* res_bound,
                    int measure, int64_t rows, int C, ttk_stream_t stream);
 int ttk_bn_bwd_apply(const float* g, const float* y, const float* bn, void* dy, int64_t rows, int C, ttk_stream_t stream);
+/* BlurPool2D of the ResNet18 variant's use_blurpool (backbones/resnet.py:31-49,63-66; neuralnets/modelcomponents.py:187-205) on
+ * channels-last rows: t[B][Ho][Wo][C] = depthwise 3x3 of a[B][H][W][C] with the binomial kernel [1 2 1]^T [1 2 1] / 16, zero padding 1,
+ * stride 1 | 2 (Ho = (H-1)/stride + 1); C % 4 == 0.  ttk_blur3x3_bwd: g[B][H][W][C] = the transposed map of (ga + gb) (gb nullable) -
+ * the gradient w.r.t. a.  max |t| <= max |a|: the a_bound of a is a valid bound of t. */
+int ttk_blur3x3_fwd(const float* a, float* t, int B, int H, int W, int C, int stride, ttk_stream_t stream);
+int ttk_blur3x3_bwd(const float* ga, const float* gb, float* g, int B, int H, int W, int C, int stride, ttk_stream_t stream);
 int ttk_residual_bwd(const float* ga, const float* gb, const float* a, const float* y, float* bn, const float* yd,
                      float* bnd, float* gs, float* part, float* partd, int64_t rows, int C, ttk_stream_t stream);
 

@@ -561,6 +561,78 @@ __global__ void __launch_bounds__(kEwBlock) residual_bwd_k(const float* __restri
 
 static bool ew_shape_ok(int64_t rows, int C) { return rows > 0 && C >= 32 && C <= 1024 && (C & (C - 1)) == 0; }
 
+
+// ---- BlurPool2D on channels-last rows (reference neuralnets/modelcomponents.py:187-205: the ResNet variant's use_blurpool,
+// backbones/resnet.py:31-49,63-66): depthwise 3x3 with the binomial kernel [1 2 1]^T [1 2 1] / 16, zero padding 1, stride 1 | 2.
+// One thread = one pixel x 4 channels; HBM-bound and small beside the dense convolutions around it.
+__device__ __forceinline__ float blur_tap(int k) { return k == 1 ? 0.5f : 0.25f; }  // separable: (1/4, 1/2, 1/4) per axis
+
+__global__ void __launch_bounds__(kBlock) blur3x3_fwd_k(const float* __restrict__ a, float* __restrict__ t, int B, int H, int W, int Ho, int Wo,
+                                                        int C, int stride) {
+  const int cq = C / 4;
+  const int64_t items = (int64_t)B * Ho * Wo * cq;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < items; i += (int64_t)gridDim.x * kBlock) {
+    const int q = (int)(i % cq);
+    int64_t px = i / cq;
+    const int wo = (int)(px % Wo);
+    px /= Wo;
+    const int ho = (int)(px % Ho), n = (int)(px / Ho);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hi = ho * stride + kh - 1;
+      if (hi < 0 || hi >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int wi = wo * stride + kw - 1;
+        if (wi < 0 || wi >= W) continue;
+        const float wgt = blur_tap(kh) * blur_tap(kw);
+        const float4 v = ld4(a + (((int64_t)n * H + hi) * W + wi) * C + 4 * q);
+        acc.x = fmaf(wgt, v.x, acc.x); acc.y = fmaf(wgt, v.y, acc.y); acc.z = fmaf(wgt, v.z, acc.z); acc.w = fmaf(wgt, v.w, acc.w);
+      }
+    }
+    st4(t + i * 4, acc);
+  }
+}
+
+// g[n][hi][wi] = sum over (ho, wo, kh, kw) with ho*stride + kh - 1 = hi, wo*stride + kw - 1 = wi of w[kh][kw] * (ga + gb)[n][ho][wo]
+__global__ void __launch_bounds__(kBlock) blur3x3_bwd_k(const float* __restrict__ ga, const float* __restrict__ gb, float* __restrict__ g, int B,
+                                                        int H, int W, int Ho, int Wo, int C, int stride) {
+  const int cq = C / 4;
+  const int64_t items = (int64_t)B * H * W * cq;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < items; i += (int64_t)gridDim.x * kBlock) {
+    const int q = (int)(i % cq);
+    int64_t px = i / cq;
+    const int wi = (int)(px % W);
+    px /= W;
+    const int hi = (int)(px % H), n = (int)(px / H);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int th = hi + 1 - kh;
+      if (th < 0 || th % stride != 0) continue;
+      const int ho = th / stride;
+      if (ho >= Ho) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int tw = wi + 1 - kw;
+        if (tw < 0 || tw % stride != 0) continue;
+        const int wo = tw / stride;
+        if (wo >= Wo) continue;
+        const float wgt = blur_tap(kh) * blur_tap(kw);
+        const int64_t o = (((int64_t)n * Ho + ho) * Wo + wo) * C + 4 * q;
+        float4 v = ld4(ga + o);
+        if (gb) {
+          const float4 u = ld4(gb + o);
+          v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        acc.x = fmaf(wgt, v.x, acc.x); acc.y = fmaf(wgt, v.y, acc.y); acc.z = fmaf(wgt, v.z, acc.z); acc.w = fmaf(wgt, v.w, acc.w);
+      }
+    }
+    st4(g + i * 4, acc);
+  }
+}
+
 }  // namespace ttk
 
 using namespace ttk;
@@ -637,6 +709,26 @@ int ttk_maxpool3x3s2_bwd(const float* ga, const float* gb, const unsigned char* 
   hipLaunchKernelGGL(maxpool_bwd_k, dim3(elementwise_grid(items)), dim3(1024), 2 * (size_t)C * sizeof(float), (hipStream_t)stream,
                      ga, gb, idx, y, bn, g, part, B, H, W, Ho, Wo, C);
   TTK_LAUNCH_CHECK("maxpool3x3s2_bwd");
+}
+
+int ttk_blur3x3_fwd(const float* a, float* t, int B, int H, int W, int C, int stride, ttk_stream_t stream) {
+  TTK_REQUIRE(a && t, "blur3x3_fwd: null pointer");
+  TTK_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2), "blur3x3_fwd: unsupported shape");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  int64_t grid = ceil_div((int64_t)B * Ho * Wo * (C / 4), kBlock);
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(blur3x3_fwd_k, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, a, t, B, H, W, Ho, Wo, C, stride);
+  TTK_LAUNCH_CHECK("blur3x3_fwd");
+}
+
+int ttk_blur3x3_bwd(const float* ga, const float* gb, float* g, int B, int H, int W, int C, int stride, ttk_stream_t stream) {
+  TTK_REQUIRE(ga && g, "blur3x3_bwd: null pointer");
+  TTK_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2), "blur3x3_bwd: unsupported shape");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  int64_t grid = ceil_div((int64_t)B * H * W * (C / 4), kBlock);
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(blur3x3_bwd_k, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, ga, gb, g, B, H, W, Ho, Wo, C, stride);
+  TTK_LAUNCH_CHECK("blur3x3_bwd");
 }
 
 int ttk_bn_add_act(const float* y, float* bn, const float* res, const float* res_bn, float* a, const float* res_bound, int measure,

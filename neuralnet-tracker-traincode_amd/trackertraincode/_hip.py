@@ -86,6 +86,8 @@ _SIGNATURES = {
     "ttk_loss_gmm_fwd": [_P, _P, _P, _P, _I, _D, _I, _P, _P],
     "ttk_loss_gmm_bwd": [_P, _P, _P, _P, _I, _D, _P, _I, _P],
     "ttk_loss_batch": [_I, _P],
+    "ttk_blur3x3_fwd": [_P, _P, _I, _I, _I, _I, _I],
+    "ttk_blur3x3_bwd": [_P, _P, _P, _I, _I, _I, _I, _I],
     "ttk_view_roi": [_P, _P, _P, _F, _I, _P],
     "ttk_roi_transform": [_P, _P, _I, _I, _P],
     "ttk_affine_warp": [_P, _I, _I, _I, _I, _P, _P, _I, _F, _F],
@@ -95,7 +97,7 @@ _SIGNATURES = {
     "ttk_stream_probe": [_P, _P, _P, _L, _I, _I, _I, _I, _L, _I, _I, _I],
 }
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 def bn_pivot() -> bool:

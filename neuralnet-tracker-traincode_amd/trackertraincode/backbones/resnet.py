@@ -11,7 +11,9 @@ max-pool and the residual/BatchNorm elementwise passes in csrc/resnet.hip, every
 as an implicit GEMM on the fp16-split producer/consumer kernels (csrc/conv.hip, csrc/pwconv_f16.hip; operand magnitude
 bounds travel in row TTK_BN_AUX of the BatchNorm blocks, which therefore come from one zeroed arena per step).  Activations
 are channels-last and materialised (post BatchNorm/ReLU); BatchNorm statistics follow the partial-sum -> fp64 finalize
-scheme of the MobileNet backbone.  `use_blurpool=True` (reference :33-50,63-66) is not built.
+scheme of the MobileNet backbone.  `use_blurpool=True` (reference :31-49,63-66): every BasicBlock's conv1 becomes
+Sequential(BlurPool2D(stride), conv3x3(stride 1)) and the max-pool a BlurPool2D(stride 2); the blur runs as its own small kernel on the
+channels-last rows (ttk_blur3x3_fwd / _bwd), the convolutions around it are the same implicit GEMMs.
 """
 from __future__ import annotations
 
@@ -22,6 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _hip
+from ..neuralnets.modelcomponents import BlurPool2D
 
 _BN_ROWS = 8
 _PLAN = [(64, 1), (64, 1), (128, 2), (128, 1), (256, 2), (256, 1), (512, 2), (512, 1)]  # (planes, stride) per BasicBlock
@@ -31,15 +34,23 @@ class BasicBlock(nn.Module):
     """torchvision.models.resnet.BasicBlock: conv3x3-bn-relu-conv3x3-bn (+ identity | downsample) - relu."""
     expansion = 1
 
-    def __init__(self, inplanes: int, planes: int, stride: int = 1, downsample: nn.Module | None = None):
+    def __init__(self, inplanes: int, planes: int, stride: int = 1, downsample: nn.Module | None = None, use_blurpool: bool = False):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.blurpool = bool(use_blurpool)
+        if use_blurpool:  # the reference's CustomBlock (:31-49): blur (+ downsample) first, then the convolution at stride 1 - in EVERY block
+            self.conv1 = nn.Sequential(BlurPool2D(kernel_size=3, channels=inplanes, stride=stride), nn.Conv2d(inplanes, planes, 3, 1, 1, bias=False))
+        else:
+            self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
         self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = downsample
         self.stride = stride
+
+    @property
+    def conv1_weight(self):
+        return self.conv1[1].weight if self.blurpool else self.conv1.weight
 
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
@@ -63,12 +74,12 @@ def _bn_channels():
 
 
 class _Ctx:
-    __slots__ = ("x", "B", "H", "W", "y0", "bn0", "idx", "a1", "blocks", "part", "partd", "last", "frozen")
+    __slots__ = ("x", "B", "H", "W", "y0", "bn0", "idx", "a1", "blocks", "part", "partd", "last", "frozen", "blur", "a0")
 
 
 class _Blk:
     """What one BasicBlock leaves behind for backward."""
-    __slots__ = ("a_in", "a_bn", "y1", "bn1", "a_mid", "y2", "bn2", "yd", "bnd", "a_out", "h", "ho", "cin", "cout", "stride", "w1b", "w2b", "wdb")
+    __slots__ = ("a_in", "a_bn", "y1", "bn1", "a_mid", "y2", "bn2", "yd", "bnd", "a_out", "h", "ho", "cin", "cout", "stride", "w1b", "w2b", "wdb", "t")
 
 
 def _part_buffers(B, device):
@@ -83,8 +94,8 @@ def _part_buffers(B, device):
     return mk(), mk()
 
 
-def _forward_impl(x, params, buffers, momentum, eps, training=True):
-    """params: [conv1.w, bn1.w, bn1.b, then per block (conv1.w, bn1.w, bn1.b, conv2.w, bn2.w, bn2.b[, ds.w, dsbn.w, dsbn.b])];
+def _forward_impl(x, params, buffers, momentum, eps, training=True, blur=False):
+    """blur: the use_blurpool variant.  params: [conv1.w, bn1.w, bn1.b, then per block (conv1.w, bn1.w, bn1.b, conv2.w, bn2.w, bn2.b[, ds.w, dsbn.w, dsbn.b])];
     buffers: (running_mean, running_var, num_batches_tracked) per BatchNorm in the same order."""
     L, p = _hip.lib(), _hip.ptr
     dev = x.device
@@ -92,6 +103,7 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
     c = _Ctx()
     c.x, c.B, c.H, c.W = x, B, H, W
     c.frozen = not training  # backward through eval-mode BatchNorm: the fixed affine map (ttk_bn_bwd_frozen)
+    c.blur, c.a0 = bool(blur), None
     c.part, c.partd = _part_buffers(B, dev)
     part = c.part
     new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
@@ -124,8 +136,14 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
     finalize(c.bn0, L.partial_rows_elementwise(B * Ho * Ho * 16), 64, B * Ho * Ho, params[1], params[2])
     h = (Ho - 1) // 2 + 1
     c.a1 = new(B, h, h, 64)
-    c.idx = torch.empty((B, h, h, 64), dtype=torch.uint8, device=dev)
-    L.call("ttk_maxpool3x3s2_fwd", p(c.y0), p(c.bn0), p(c.a1), p(c.idx), B, Ho, Ho, 64)
+    if blur:  # reference :63-66: BlurPool2D(3, channels 64, stride 2) in the max-pool's place, behind relu(bn1(.))
+        c.idx = None
+        c.a0 = new(B, Ho, Ho, 64)
+        L.call("ttk_bn_add_act", p(c.y0), p(c.bn0), None, None, p(c.a0), None, int(not training), B * Ho * Ho, 64)
+        L.call("ttk_blur3x3_fwd", p(c.a0), p(c.a1), B, Ho, Ho, 64, 2)
+    else:
+        c.idx = torch.empty((B, h, h, 64), dtype=torch.uint8, device=dev)
+        L.call("ttk_maxpool3x3s2_fwd", p(c.y0), p(c.bn0), p(c.a1), p(c.idx), B, Ho, Ho, 64)
 
     # forward and data-gradient operands of all 19 convolution weights: one allocation, three launches
     convs, cin, pi = [], 64, 3
@@ -158,7 +176,13 @@ def _forward_impl(x, params, buffers, momentum, eps, training=True):
         w2f, k.w2b = next(wops)
         wdf, k.wdb = next(wops) if has_ds else (None, None)
         k.y1 = new(B, ho, ho, planes)
-        L.call("ttk_conv_fwd", p(a_in), bound(a_bn), p(w1f), p(k.y1), p(part), pivot(), B, h, h, cin, planes, 3, 3, stride, 1)
+        k.t = None
+        if blur:  # conv1 = Sequential(BlurPool2D(stride), conv3x3 at stride 1); a blur of a_in is bounded by a_in's bound
+            k.t = new(B, ho, ho, cin)
+            L.call("ttk_blur3x3_fwd", p(a_in), p(k.t), B, h, h, cin, stride)
+            L.call("ttk_conv_fwd", p(k.t), bound(a_bn), p(w1f), p(k.y1), p(part), pivot(), B, ho, ho, cin, planes, 3, 3, 1, 1)
+        else:
+            L.call("ttk_conv_fwd", p(a_in), bound(a_bn), p(w1f), p(k.y1), p(part), pivot(), B, h, h, cin, planes, 3, 3, stride, 1)
         k.bn1 = _bn_work(planes, dev)
         finalize(k.bn1, L.partial_rows_gemm(M), planes, M, g1, b1)
         k.a_mid = new(B, ho, ho, planes)
@@ -236,6 +260,7 @@ def _backward_impl(c: _Ctx, gfeat, params):
     need = 0
     for k in c.blocks:
         need = max(need, L.conv_wgrad_partial_bytes(B, k.h, k.h, k.cin, k.cout, 3, k.stride), L.conv_wgrad_partial_bytes(B, k.ho, k.ho, k.cout, k.cout, 3, 1),
+                   L.conv_wgrad_partial_bytes(B, k.ho, k.ho, k.cin, k.cout, 3, 1) if c.blur else 0,
                    L.conv_wgrad_partial_bytes(B, k.h, k.h, k.cin, k.cout, 1, k.stride) if k.yd is not None else 0)
     wscratch = torch.empty(need // 4, dtype=torch.float32, device=dev) if need else None
 
@@ -270,9 +295,16 @@ def _backward_impl(c: _Ctx, gfeat, params):
         bwd_finalize(k.bn1, L.partial_rows_gemm(M), C, M, pi + 1)
         # conv1: weight gradient, raw data gradient w.r.t. the block input
         dy1, y1 = through_bn(g1, k.y1, k.bn1, M, C)
-        L.call("ttk_conv_bwd_weight", p(dy1), y1, p(k.bn1), p(k.a_in), bound(k.a_bn), p(grads[pi]), p(wscratch), B, k.h, k.h, k.cin, C, 3, 3, k.stride, 1)
         g_in = new(B, k.h, k.h, k.cin)
-        L.call("ttk_conv_bwd_data", p(dy1), y1, p(k.bn1), p(k.w1b), None, None, p(g_in), None, B, k.h, k.h, k.cin, C, 3, 3, k.stride, 1)
+        if c.blur:  # the convolution saw the blurred input at stride 1; its data gradient goes back through the blur
+            L.call("ttk_conv_bwd_weight", p(dy1), y1, p(k.bn1), p(k.t), bound(k.a_bn), p(grads[pi]), p(wscratch), B, k.ho, k.ho, k.cin, C, 3, 3, 1, 1)
+            g_t = new(B, k.ho, k.ho, k.cin)
+            L.call("ttk_conv_bwd_data", p(dy1), y1, p(k.bn1), p(k.w1b), None, None, p(g_t), None, B, k.ho, k.ho, k.cin, C, 3, 3, 1, 1)
+            L.call("ttk_blur3x3_bwd", p(g_t), None, p(g_in), B, k.h, k.h, k.cin, k.stride)
+            del g_t
+        else:
+            L.call("ttk_conv_bwd_weight", p(dy1), y1, p(k.bn1), p(k.a_in), bound(k.a_bn), p(grads[pi]), p(wscratch), B, k.h, k.h, k.cin, C, 3, 3, k.stride, 1)
+            L.call("ttk_conv_bwd_data", p(dy1), y1, p(k.bn1), p(k.w1b), None, None, p(g_in), None, B, k.h, k.h, k.cin, C, 3, 3, k.stride, 1)
         del dy1
         if has_ds:
             L.call("ttk_conv_bwd_weight", p(gs), p(k.yd), p(k.bnd), p(k.a_in), bound(k.a_bn), p(grads[pi + 6]), p(wscratch), B, k.h, k.h, k.cin, C, 1, 1, k.stride, 0)
@@ -292,7 +324,12 @@ def _backward_impl(c: _Ctx, gfeat, params):
         else:
             Ho = c.y0.shape[1]
             g0 = new(B, Ho, Ho, 64)
-            L.call("ttk_maxpool3x3s2_bwd", p(g_in), p(g_sc), p(c.idx), p(c.y0), p(c.bn0), p(g0), p(part), B, Ho, Ho, 64)
+            if c.blur:  # back through the blur (both gradients of a1 summed on load), then through relu(bn1(.)) with its BatchNorm sums
+                g_a0 = new(B, Ho, Ho, 64)
+                L.call("ttk_blur3x3_bwd", p(g_in), p(g_sc), p(g_a0), B, Ho, Ho, 64, 2)
+                L.call("ttk_residual_bwd", p(g_a0), None, p(c.a0), p(c.y0), p(c.bn0), None, None, p(g0), p(part), None, B * Ho * Ho, 64)
+            else:
+                L.call("ttk_maxpool3x3s2_bwd", p(g_in), p(g_sc), p(c.idx), p(c.y0), p(c.bn0), p(g0), p(part), B, Ho, Ho, 64)
             bwd_finalize(c.bn0, L.partial_rows_elementwise(B * Ho * Ho * 16), 64, B * Ho * Ho, 1)
             sp = None
             if _DETERMINISTIC:  # workgroup partials + a fixed-order fold instead of atomics (the 3x3 convolutions always fold; the
@@ -306,8 +343,8 @@ def _backward_impl(c: _Ctx, gfeat, params):
 
 class _ResNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, momentum, eps, buffers, frozen, *params):
-        feat, c = _forward_impl(x, params, buffers, momentum, eps, training=not frozen)
+    def forward(ctx, x, momentum, eps, buffers, frozen, blur, *params):
+        feat, c = _forward_impl(x, params, buffers, momentum, eps, training=not frozen, blur=blur)
         ctx.c = c
         ctx.save_for_backward(*params)
         return feat
@@ -316,7 +353,7 @@ class _ResNetFn(torch.autograd.Function):
     def backward(ctx, gfeat):
         grads = _backward_impl(ctx.c, gfeat.contiguous(), ctx.saved_tensors)
         ctx.c = None
-        return (None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, *grads)
 
 
 class ResNetBackbone(nn.Module):
@@ -324,8 +361,7 @@ class ResNetBackbone(nn.Module):
 
     def __init__(self, use_blurpool: bool = False, zero_init_residual: bool = True):
         super().__init__()
-        if use_blurpool:
-            raise NotImplementedError("resnet18(use_blurpool=True) (reference resnet.py:33-50) is not built; the training script's default is False")
+        self.use_blurpool = bool(use_blurpool)
         stages, inplanes = [], 64
         for si in range(4):
             blocks = []
@@ -334,12 +370,13 @@ class ResNetBackbone(nn.Module):
                 ds = None
                 if stride != 1 or inplanes != planes:
                     ds = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
-                blocks.append(BasicBlock(inplanes, planes, stride, ds))
+                blocks.append(BasicBlock(inplanes, planes, stride, ds, use_blurpool=self.use_blurpool))
                 inplanes = planes
             stages.append(nn.Sequential(*blocks))
         self.layers = nn.Sequential(
             nn.Conv2d(1, 64, kernel_size=7, stride=2, padding=3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
-            nn.MaxPool2d(kernel_size=3, stride=2, padding=1), *stages, nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten())
+            BlurPool2D(kernel_size=3, channels=64, stride=2) if self.use_blurpool else nn.MaxPool2d(kernel_size=3, stride=2, padding=1),
+            *stages, nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten())
         self.num_features = 512
         # torchvision ResNet.__init__: kaiming fan_out for every conv, BatchNorm (1, 0), zero-initialised last BatchNorm of
         # each residual branch (reference passes zero_init_residual=True, resnet.py:101)
@@ -367,7 +404,7 @@ class ResNetBackbone(nn.Module):
         ps = [self.layers[0].weight, self.layers[1].weight, self.layers[1].bias]
         for si in range(4, 8):
             for blk in self.layers[si]:
-                ps += [blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias]
+                ps += [blk.conv1_weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias]
                 if blk.downsample is not None:
                     ps += [blk.downsample[0].weight, blk.downsample[1].weight, blk.downsample[1].bias]
         return ps
@@ -391,7 +428,7 @@ class ResNetBackbone(nn.Module):
             raise NotImplementedError("all BatchNorm layers must share one momentum/eps")
         bn_training = [b.training for b in bns]
         if self.training and all(bn_training):
-            return _ResNetFn.apply(x.contiguous(), moms.pop(), epss.pop(), self._flat_buffers(), False, *self._flat_params())
+            return _ResNetFn.apply(x.contiguous(), moms.pop(), epss.pop(), self._flat_buffers(), False, self.use_blurpool, *self._flat_params())
         if any(bn_training):
             raise NotImplementedError("mixed train/eval BatchNorm layers are not supported by the fused backbone")
         if torch.is_grad_enabled() and any(q.requires_grad for q in self._flat_params()):
@@ -399,9 +436,9 @@ class ResNetBackbone(nn.Module):
             if any(q.requires_grad for b in bns for q in b.parameters()):
                 raise NotImplementedError("eval-mode BatchNorm layers with trainable weight / bias are not built: freeze them "
                                           "(modelcomponents.freeze_norm_stats) or put the layers in training mode")
-            return _ResNetFn.apply(x.contiguous(), moms.pop(), epss.pop(), self._flat_buffers(), True, *self._flat_params())
+            return _ResNetFn.apply(x.contiguous(), moms.pop(), epss.pop(), self._flat_buffers(), True, self.use_blurpool, *self._flat_params())
         feat, _ = _forward_impl(x.contiguous(), [q.detach() for q in self._flat_params()], self._flat_buffers(), moms.pop(), epss.pop(),
-                                training=False)
+                                training=False, blur=self.use_blurpool)
         return feat
 
     def forward(self, x):

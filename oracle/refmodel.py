@@ -300,7 +300,9 @@ def mobilenet_forward(st, x: Tensor, training: bool, momentum: float = 0.1, pref
 RESNET18_PLAN = [(64, 1), (64, 1), (128, 2), (128, 1), (256, 2), (256, 1), (512, 2), (512, 1)]
 
 
-def resnet18_state_shapes(prefix="") -> dict:
+def resnet18_state_shapes(prefix="", use_blurpool=False) -> dict:
+    """use_blurpool (resnet.py:31-49,63-66): the reference's CustomBlock replaces conv1 by Sequential(BlurPool2D(stride), conv3x3 stride 1)
+    in every block and the max-pool by BlurPool2D(3, channels 64, stride 2): buffers `kernel` [3, 3]."""
     s = {}
 
     def bn(name, c):
@@ -309,10 +311,16 @@ def resnet18_state_shapes(prefix="") -> dict:
 
     s[prefix + "layers.0.weight"] = (64, 1, 7, 7)
     bn(prefix + "layers.1", 64)
+    if use_blurpool:
+        s[prefix + "layers.3.kernel"] = (3, 3)
     cin = 64
     for i, (planes, stride) in enumerate(RESNET18_PLAN):
         b = f"{prefix}layers.{4 + i // 2}.{i % 2}"
-        s[b + ".conv1.weight"] = (planes, cin, 3, 3)
+        if use_blurpool:
+            s[b + ".conv1.0.kernel"] = (3, 3)
+            s[b + ".conv1.1.weight"] = (planes, cin, 3, 3)
+        else:
+            s[b + ".conv1.weight"] = (planes, cin, 3, 3)
         bn(b + ".bn1", planes)
         s[b + ".conv2.weight"] = (planes, planes, 3, 3)
         bn(b + ".bn2", planes)
@@ -325,13 +333,21 @@ def resnet18_state_shapes(prefix="") -> dict:
 
 def resnet18_forward(st, x: Tensor, training: bool, momentum: float = 0.1, prefix=""):
     """[B,1,H,W] -> ([B,512], None)"""
+    def blur(a, key, stride):  # BlurPool2D (modelcomponents.py:187-205; kornia's _blur_pool_by_kernel2d restated as in mobilenet_forward)
+        c = a.shape[1]
+        return F.conv2d(a, st[key].to(a.dtype).repeat(c, 1, 1, 1), None, stride=stride, padding=1, groups=c)
+
     y = F.conv2d(x, st[prefix + "layers.0.weight"], stride=2, padding=3)
-    y = F.max_pool2d(torch.relu(_bn(y, st, prefix + "layers.1", training, momentum)), 3, 2, 1)
+    y = torch.relu(_bn(y, st, prefix + "layers.1", training, momentum))
+    y = blur(y, prefix + "layers.3.kernel", 2) if prefix + "layers.3.kernel" in st else F.max_pool2d(y, 3, 2, 1)
     cin = 64
     for i, (planes, stride) in enumerate(RESNET18_PLAN):
         b = f"{prefix}layers.{4 + i // 2}.{i % 2}"
         identity = y
-        out = F.conv2d(y, st[b + ".conv1.weight"], stride=stride, padding=1)
+        if b + ".conv1.0.kernel" in st:  # CustomBlock: blur with the block's stride, then the convolution at stride 1
+            out = F.conv2d(blur(y, b + ".conv1.0.kernel", stride), st[b + ".conv1.1.weight"], stride=1, padding=1)
+        else:
+            out = F.conv2d(y, st[b + ".conv1.weight"], stride=stride, padding=1)
         out = torch.relu(_bn(out, st, b + ".bn1", training, momentum))
         out = _bn(F.conv2d(out, st[b + ".conv2.weight"], stride=1, padding=1), st, b + ".bn2", training, momentum)
         if stride != 1 or cin != planes:

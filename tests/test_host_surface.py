@@ -42,6 +42,18 @@ def test_state_dict_inventory(unc, pt):
     assert net.name == "NetworkWithPointHead_mobilenetv1" and net.input_resolution == 129 and net.input_resolutions == (129,)
 
 
+def test_resnet18_blurpool_state_dict_inventory():
+    """resnet18(use_blurpool=True): the reference's CustomBlock / BlurPool2D key names (resnet.py:31-49,63-66) = the oracle's inventory."""
+    from trackertraincode.backbones.resnet import resnet18
+
+    net = resnet18(use_blurpool=True)
+    mine = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    ref = R.resnet18_state_shapes(use_blurpool=True)
+    assert list(mine) == list(ref) and mine == ref
+    assert "layers.3.kernel" in mine and "layers.4.0.conv1.0.kernel" in mine and "layers.7.1.conv1.1.weight" in mine
+    assert torch.equal(net.layers[3].kernel, torch.tensor([[1., 2., 1.], [2., 4., 2.], [1., 2., 1.]]) / 16.0)
+
+
 def test_state_dict_inventory_blurpool():
     """--blurpool: conv_dw becomes Sequential(BlurPool2D, Conv2d) in the four strided blocks (reference mobilenet_v1.py:43-55)."""
     from trackertraincode.neuralnets.models import NetworkWithPointHead
@@ -152,8 +164,11 @@ def test_resnet18_module_surface():
         ref, _ = R.resnet18_forward(st, x, False)
     assert inter is None and feat.shape == (2, 512)
     torch.testing.assert_close(feat, ref, rtol=1e-5, atol=1e-6)
-    with __import__("pytest").raises(NotImplementedError):
-        resnet18(use_blurpool=True)
+    blur = resnet18(use_blurpool=True).eval()  # the CPU module path of the blur variant against the oracle's restatement
+    with torch.no_grad():
+        feat_b, _ = blur(x)
+        ref_b, _ = R.resnet18_forward({k: v.clone() for k, v in blur.state_dict().items()}, x, False)
+    torch.testing.assert_close(feat_b, ref_b, rtol=1e-5, atol=1e-6)
 
 
 def test_eval_metrics_and_rotation_conventions():

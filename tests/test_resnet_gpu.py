@@ -29,7 +29,7 @@ def _run_oracle(sd, image, G, dtype):
     return feat.detach(), st
 
 
-def _one_fwd_bwd(B, seed, sd):
+def _one_fwd_bwd(B, seed, sd, blur=False):
     """-> (strictly ok?, worst relative gradient error); asserts the forward criteria."""
     from trackertraincode.backbones.resnet import resnet18
 
@@ -37,7 +37,7 @@ def _one_fwd_bwd(B, seed, sd):
     G = np.random.default_rng(5).standard_normal((B, 512)).astype(np.float32)
     f64, st64 = _run_oracle(sd, image, G, torch.float64)
     f32, st32 = _run_oracle(sd, image, G, torch.float32)
-    net = resnet18().cuda()
+    net = resnet18(use_blurpool=blur).cuda()
     net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
     net.train()
     feat, none = net(torch.from_numpy(image).cuda())
@@ -63,8 +63,8 @@ def _one_fwd_bwd(B, seed, sd):
     return not bad, max(errs), float(np.median(errs)), bad
 
 
-@pytest.mark.parametrize("B", [3, 8])
-def test_resnet18_train_fwd_bwd_matches_oracle_parity_unpinned(B):
+@pytest.mark.parametrize("B,blur", [(3, False), (8, False), (3, True), (8, True)])
+def test_resnet18_train_fwd_bwd_matches_oracle_parity_unpinned(B, blur):
     """Small batches, ONE input (no retry over inputs).  Forward: as close to the fp64 oracle as the fp32 CPU oracle is (factor 3 +
     2e-5).  Gradients: held to max(3 x the fp32 CPU oracle's distance to fp64, 1e-4) per parameter - with explicit accounting for what a
     small batch cannot avoid: a ReLU / max-pool decision whose pre-activation lies within rounding of zero legitimately differs between
@@ -73,9 +73,10 @@ def test_resnet18_train_fwd_bwd_matches_oracle_parity_unpinned(B):
     flip-sized bound 3e-2, and (b) belong to a run in which the TYPICAL (median) parameter still meets 5e-3; the flips are printed.
     The arithmetic itself is held to 1.5e-6 per kernel in test_conv_gpu.py; B = 512 (below) has no flip allowance beyond single BatchNorm
     channels.  "parity unpinned": the oracle restates torchvision's BasicBlock (module docstring)."""
-    sd = make_state(R.resnet18_state_shapes(), seed=0)
-    ok, worst, median, bad = _one_fwd_bwd(B, 7, sd)
-    print(f"resnet18 B={B}: worst gradient rel {worst:.1e}, median {median:.1e}, parameters beyond the strict bound: {[(k, f'{a:.1e}', f'{b:.1e}') for k, a, b in bad]}")
+    # blur: use_blurpool=True - BlurPool2D in front of every block's first convolution and in the max-pool's place (resnet.py:31-49,63-66)
+    sd = make_state(R.resnet18_state_shapes(use_blurpool=blur), seed=0)
+    ok, worst, median, bad = _one_fwd_bwd(B, 7, sd, blur)
+    print(f"resnet18 B={B} blur={blur}: worst gradient rel {worst:.1e}, median {median:.1e}, parameters beyond the strict bound: {[(k, f'{a:.1e}', f'{b:.1e}') for k, a, b in bad]}")
     assert worst < 3e-2, (worst, bad[:4])
     assert ok or median < 5e-3, (median, bad[:4])
 
@@ -293,3 +294,58 @@ def test_resnet18_eval_forward_matches_oracle():
     assert _rel(feat.cpu(), ref) < 2e-4
     with pytest.raises(NotImplementedError):
         net(torch.from_numpy(image).cuda())  # grad mode with trainable parameters in eval: not built
+
+
+@pytest.mark.parametrize("B,H,W,C,stride", [(3, 33, 33, 64, 1), (2, 65, 65, 64, 2), (5, 17, 17, 128, 2), (4, 9, 9, 256, 1), (2, 6, 5, 32, 2)])
+def test_blur3x3_kernels_match_torch(B, H, W, C, stride):
+    """ttk_blur3x3_fwd / _bwd on channels-last rows against conv2d with the binomial kernel and its autograd (fp64)."""
+    import trackertraincode._hip as H_
+
+    L, p = H_.lib(), H_.ptr
+    g = torch.Generator().manual_seed(B * 100 + C)
+    a = torch.randn(B, C, H, W, generator=g)
+    k = (torch.tensor([1.0, 2.0, 1.0])[:, None] * torch.tensor([1.0, 2.0, 1.0])[None, :] / 16.0).double()
+    a64 = a.double().requires_grad_(True)
+    t64 = torch.nn.functional.conv2d(a64, k.repeat(C, 1, 1, 1), None, stride=stride, padding=1, groups=C)
+    ga, gb = torch.randn(t64.shape, generator=g), torch.randn(t64.shape, generator=g)
+    t64.backward((ga + gb).double())
+    Ho, Wo = t64.shape[-2:]
+    rows = lambda x: x.permute(0, 2, 3, 1).contiguous().cuda()
+    a_r = rows(a)
+    t = torch.empty((B, Ho, Wo, C), device="cuda")
+    L.call("ttk_blur3x3_fwd", p(a_r), p(t), B, H, W, C, stride)
+    assert _rel(t.permute(0, 3, 1, 2).cpu(), t64.detach()) < 2e-7
+    gin = torch.empty((B, H, W, C), device="cuda")
+    ga_r, gb_r = rows(ga), rows(gb)  # (named: a temporary would be recycled before the launch reads it)
+    L.call("ttk_blur3x3_bwd", p(ga_r), p(gb_r), p(gin), B, H, W, C, stride)
+    assert _rel(gin.permute(0, 3, 1, 2).cpu(), a64.grad) < 3e-7
+    L.call("ttk_blur3x3_bwd", p(ga_r), None, p(gin), B, H, W, C, stride)
+    a64.grad = None
+    torch.nn.functional.conv2d(a64, k.repeat(C, 1, 1, 1), None, stride=stride, padding=1, groups=C).backward(ga.double())
+    assert _rel(gin.permute(0, 3, 1, 2).cpu(), a64.grad) < 3e-7
+
+
+def test_resnet18_blurpool_pose_step_and_eval():
+    """NetworkWithPointHead("resnet18", use_blurpool) through heads, losses and clip + Adam, and the eval-mode forward against the oracle."""
+    from trackertraincode.backbones.resnet import resnet18
+    from trackertraincode.neuralnets.models import NetworkWithPointHead
+
+    net = NetworkWithPointHead(enable_point_head=False, config="resnet18", backbone_args={"use_blurpool": True}).cuda().train()
+    assert net.get_config()["backbone_args"] == {"use_blurpool": True}
+    x = torch.rand(4, 1, 129, 129, device="cuda") - 0.5
+    out = net(x, torch.zeros(4, dtype=torch.int32, device="cuda"))
+    (out["coord"].sum() + out["roi"].sum() + out["rot"].value.sum()).backward()
+    assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in net.convnet.parameters())
+    sd = make_state(R.resnet18_state_shapes(use_blurpool=True), seed=0)
+    image, _ = make_inputs(4, seed=9)
+    st = R.state_from_numpy(sd, requires_grad=False)
+    with torch.no_grad():
+        R.resnet18_forward(st, torch.from_numpy(image), True, momentum=1.0)  # calibrate the running statistics on this batch
+        ref, _ = R.resnet18_forward(st, torch.from_numpy(image), False)
+    bb = resnet18(use_blurpool=True).cuda()
+    bb.load_state_dict({k: v.clone() for k, v in st.items()}, strict=True)
+    bb.eval()
+    with torch.no_grad():
+        feat, _ = bb(torch.from_numpy(image).cuda())
+        feat_cpu, _ = bb.cpu()(torch.from_numpy(image))  # the plain-torch module path (export)
+    assert _rel(feat.cpu(), ref) < 2e-4 and _rel(feat_cpu, ref) < 1e-5

@@ -36,6 +36,7 @@ CASES = {
                       "NetworkWithPointHead_mobilenetv1"),
     "resnet18_posonly": (["--ds", "synthetic", "--batchsize", "16", "--epochs", "1", "--backbone", "resnet18", "--no-pointhead", "--no-imgaug"],
                          "NetworkWithPointHead_resnet18"),
+    "resnet18_blurpool": (["--ds", "synthetic", "--batchsize", "16", "--epochs", "1", "--backbone", "resnet18", "--blurpool"], "NetworkWithPointHead_resnet18"),
     "blurpool_graph_bf16": (["--ds", "synthetic", "--batchsize", "32", "--epochs", "2", "--blurpool", "--graph-steps", "--precision", "bf16"],
                             "NetworkWithPointHead_mobilenetv1"),
     "shards_landmark_roi": (["--ds", "aflw2k:500", "--batchsize", "8", "--epochs", "2", "--roi-override", "landmarks", "--ds-weighting", "--raug", "20"],
