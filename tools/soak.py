@@ -17,8 +17,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--backbone", default="mobilenetv1")
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--steps", type=int, default=600)
+ap.add_argument("--blurpool", action="store_true")
 a = ap.parse_args()
-sys.argv = ["bench.py", "--backbone", a.backbone, "--batch", str(a.batch)]
+sys.argv = ["bench.py", "--backbone", a.backbone, "--batch", str(a.batch)] + (["--blurpool"] if a.blurpool else [])
 args = bench.parse()
 dev = torch.device("cuda", 0)
 net, crit, opt, batches, train = bench.build_step(args, dev)
@@ -33,7 +34,7 @@ for it in range(a.steps):
     if it % 50 == 0 or it == a.steps - 1:
         v = float(out["loss"])
         gmax = max(float(p.grad.abs().max()) for p in params if p.grad is not None)
-        print(f"step {it:4d}  loss {v:.5f}  max|grad| {gmax:.3e}", flush=True)
+        print(f"step {it:4d}  loss {v:.5f}  max|grad| {gmax:.3e}  allocated {torch.cuda.memory_allocated() / 2**20:.0f} MiB  reserved {torch.cuda.memory_reserved() / 2**20:.0f} MiB", flush=True)
         assert math.isfinite(v) and math.isfinite(gmax), "non-finite loss or gradient"
         first = v if first is None else first
         last = v
