@@ -86,3 +86,38 @@ def test_abandoned_iteration_stops_the_prefetch_thread(tmp_path, monkeypatch):
     hist = train.fit(net, tr2, crit, opt, sch, epochs=1)
     assert hist is None or True
     assert all(torch.isfinite(p).all() for p in net.parameters())
+
+
+def test_mixed_placement_three_datasets_two_sizes():
+    """Three datasets (two Tags, two frame sizes), one of them on the host, the others in HBM: the same batches as with everything in HBM."""
+    from trackertraincode.datasets.resident import ResidentFrames, ResidentLoader
+    from trackertraincode.datatransformation.gpu import GpuFocusRoiAugment
+    from trackertraincode.pipelines import Tag
+
+    def frames(tag, n, size, seed, pts):
+        g = torch.Generator().manual_seed(seed)
+        f = {"image": torch.randint(0, 255, (n, 1, size, size), dtype=torch.uint8, generator=g),
+             "roi": torch.tensor([[0.25 * size, 0.25 * size, 0.75 * size, 0.75 * size]]).repeat(n, 1) + torch.randn(n, 4, generator=g) * 2,
+             "coord": torch.cat([torch.full((n, 2), 0.5 * size), torch.full((n, 1), 0.2 * size)], -1),
+             "pose": torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=-1),
+             "coord_convention_id": torch.zeros(n, dtype=torch.int32)}
+        if pts:
+            f["pt3d_68"] = torch.rand(n, 68, 3, generator=g) * size
+            f["shapeparam"] = torch.randn(n, 50, generator=g)
+        return ResidentFrames(tag, f)
+
+    host_sets = [frames(Tag.POSE_WITH_LANDMARKS, 90, 96, 1, True), frames(Tag.POSE_WITH_LANDMARKS, 70, 128, 2, True), frames(Tag.ONLY_POSE, 50, 80, 3, False)]
+
+    def run(placement):
+        sets = [s.to("cuda") if on == "d" else s.to_host() for s, on in zip(host_sets, placement)]
+        crop = GpuFocusRoiAugment(new_size=129, rotation_aug_angle=25.0, extension_factor=1.1, whiten=True, flip_rot_p=0.01)
+        loader = ResidentLoader(sets, [0.5, 0.3, 0.2], 48, 9, seed=4, crop=crop)
+        return [[{k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()} for b in step] for step in loader]
+
+    ref, mixed, allhost = run("ddd"), run("dhd"), run("hhh")
+    for other in (mixed, allhost):
+        assert len(other) == len(ref) == 9
+        for sa, sb in zip(ref, other):
+            assert len(sa) == len(sb) == 2  # two Tags; the two landmark sets differ in frame size: cropped per set, collated
+            for x, y in zip(sa, sb):
+                _equal(x, y)
