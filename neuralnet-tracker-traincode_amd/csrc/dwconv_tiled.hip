@@ -30,10 +30,16 @@ namespace ttk {
 // apart, a tile row is one contiguous run.  (Over channels-last rows a workgroup touched one 128-byte piece per pixel, 4 C bytes
 // apart: tools/stream_sweep.py, profiles/r03_stream_sweep.txt - 5:1 read:write mix at C = 512: 128-byte pieces 4.9 TB/s, 256-byte
 // pieces 5.5, linear 6.2.  What 64-channel slabs measured there is at dw_tiling().)
-constexpr int kLdsPixBudget32 = 368;   // (rows) x (W+2) pixels of 128 B each: <= 47 KB -> 3 workgroups per CU (560 -> 2 per CU measured slower)
+#ifndef TTK_DW_LDS_PIX
+#define TTK_DW_LDS_PIX 368
+#endif
+constexpr int kLdsPixBudget32 = TTK_DW_LDS_PIX;   // (rows) x (W+2) pixels of 128 B each: <= 47 KB -> 3 workgroups per CU (560 -> 2 per CU measured slower)
 __host__ __device__ constexpr int lds_pix_budget(int SL) { return kLdsPixBudget32 * 32 / SL; }
 __host__ __device__ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
-constexpr int kMaxDwBlocks = 768;   // 3 workgroups per CU x 256 CUs: one resident wave of persistent workgroups
+#ifndef TTK_DW_WGS_PER_CU
+#define TTK_DW_WGS_PER_CU 3
+#endif
+constexpr int kMaxDwBlocks = 256 * TTK_DW_WGS_PER_CU;   // 3 workgroups per CU x 256 CUs: one resident wave of persistent workgroups
 // staging elements per thread and iteration (forward): their loads are in flight together, and the bytes in flight per CU are
 // what these kernels' throughput follows.  Six fit the 168-register budget of three workgroups per CU when the layer has no
 // residual input to load beside them (the largest layers), four otherwise.
@@ -202,7 +208,7 @@ __device__ __forceinline__ void slab_partials(D4 s1, D4 s2, int q, int C, int c_
 // forward
 // ---------------------------------------------------------------------------------------------
 template <int S, typename T, bool SKIP, int SL, bool CARRY>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TTK_DW_WGS_PER_CU, TTK_DW_WGS_PER_CU)))
 dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
                                                           const T* __restrict__ skip_prev, T* __restrict__ a_out,
                                                           const float* __restrict__ w, T* __restrict__ y,
@@ -350,7 +356,7 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
 #define TTK_DW_BWD_LEAN_PIX2 4  // stride 2 (6 measured slower: 276 vs 263 us on the 65 x 65 x 64 layer)
 #endif
 template <int S, typename T, typename TG, int SL, bool LEAN>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3)))  // <= 168 VGPRs: 3 workgroups per CU, as the LDS tile allows
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TTK_DW_WGS_PER_CU, TTK_DW_WGS_PER_CU)))  // <= 168 VGPRs: 3 workgroups per CU, as the LDS tile allows
 dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
                                                           const float* __restrict__ bn_dw, const float* __restrict__ w,
                                                           const TG* __restrict__ skip_grad,
