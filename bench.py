@@ -46,9 +46,10 @@ def parse():
     ap.add_argument("--backbone", default="mobilenetv1", choices=["mobilenetv1", "resnet18"])
     ap.add_argument("--blurpool", action="store_true", help="the training script's --blurpool: BlurPool2D + stride-1 depthwise conv in the strided MobileNet blocks (ResNet18: in front of every "
                     "block's first convolution and in the max-pool's place)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16-all"],
-                    help="BASELINE config 5's storage variant (separate line, dtype bf16; mobilenetv1 only): bf16 = activations bf16 in HBM, their "
-                    "gradients fp32; bf16-all = both bf16")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16-all", "bf16-compute"],
+                    help="BASELINE config 5's bf16 leg (separate line, dtype bf16; mobilenetv1 only): bf16-compute = activations and gradients bf16 in "
+                    "64-channel blocks, pointwise convolutions as ONE bf16 MFMA product with fp32 accumulation (csrc/bc_*.hip); bf16 / bf16-all = the "
+                    "storage-only variants of earlier rounds (activations | activations and gradients bf16 under the fp32 kernels)")
     ap.add_argument("--traffic-json", default=None, help="rocprofv3 PMC summary (tools/pmc_summary.py) taken with THIS build; "
                     "fills roofline.traffic (null without it)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (the measurement); gloo with --share-gpu: "
@@ -90,6 +91,21 @@ class KernelTimer:
             M, ci, co = ints[-3:]
             f16 = ci == 128 or (ci == 64 and os.environ.get("TTK_GEMM") not in ("f32mfma", "bf16x3") and not os.environ.get("TTK_FUSED_FP32"))  # csrc/pw_bwd_fused.hip: fused_f16
             return f"pw_bwd_fused{'16' if f16 else ''}_k<{ci}, {co}>", 4 * M * ci * co, 4 * (2 * M * co + 2 * M * ci) + 4 * ci * co
+        if name.startswith("ttk_bc_pw"):  # bf16-compute path: one bf16 product, every activation-sized tensor 2 bytes per element
+            M, ci, co = ints[-3:]
+            fl = 2 * M * ci * co
+            if name == "ttk_bc_pw_fwd":
+                return (f"bc_gemm_e_k<0, {co // 32}, {ci // 32}>" if (co <= 128 and ci <= 256) else "bc_gemm_l_k<0>"), fl, 2 * (M * ci + M * co) + 2 * ci * co
+            if name == "ttk_bc_pw_bwd_data":
+                return (f"bc_gemm_e_k<1, {ci // 32}, {co // 32}>" if (ci <= 128 and co <= 256) else "bc_gemm_l_k<1>"), fl, 2 * (2 * M * co + 2 * M * ci) + 2 * ci * co
+            tn, tk = min(co, 256) // 32, min(ci, 256) // 32
+            return f"bc_wgrad_k<{tn}, {tk}", fl, 2 * (2 * M * co + M * ci) + 4 * ci * co
+        if name in ("ttk_bc_dw_fwd", "ttk_bc_dw_bwd_data"):
+            B, H, W, C, s_ = a[-5:]
+            n_in, n_out = B * H * W * C, B * ((H - 1) // s_ + 1) * ((W - 1) // s_ + 1) * C
+            if name == "ttk_bc_dw_fwd":
+                return f"bc_dw_fwd_k<{s_}", 2 * 9 * n_out, 2 * (n_in * (1 + bool(a[2]) + bool(a[3])) + n_out)
+            return f"bc_dw_bwd_k<{s_}", 2 * 2 * 9 * n_out, 2 * (2 * n_out + n_in * (2 + bool(a[4]) + bool(a[7] or a[8])))
         if name.startswith("ttk_pwconv1x1"):
             # trailing arguments: ..., M, Cin, Cout, [scratch pointer of the split weights,] act_bf16
             M, ci, co = ints[-4:-1] if name == "ttk_pwconv1x1_bwd_weight" else ints[-5:-2]
@@ -152,7 +168,7 @@ class KernelTimer:
 
         def call(name, *args):
             # only the conv kernels (94 % of the GPU time) are bracketed, and only in the separate roofline pass
-            if not timer.enabled or not (name.startswith("ttk_pwconv1x1") or name.startswith("ttk_dwconv3x3") or name.startswith("ttk_conv_")):
+            if not timer.enabled or not (name.startswith("ttk_pwconv1x1") or name.startswith("ttk_dwconv3x3") or name.startswith("ttk_conv_") or name.startswith("ttk_bc_pw") or name.startswith("ttk_bc_dw")):
                 return orig(name, *args)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -161,7 +177,7 @@ class KernelTimer:
             kern, fl, by = timer.work(name, args)
             ints = [x for x in args if isinstance(x, int) and not isinstance(x, bool)]
             timer.records.append((kern, s, e, fl, by))
-            timer.shapes.append(tuple(ints[-3:]) if name == "ttk_pwconv1x1_bwd_fused" else tuple(ints[-5:-2]) if name in ("ttk_pwconv1x1_fwd", "ttk_pwconv1x1_bwd_data")
+            timer.shapes.append(tuple(ints[-3:]) if (name == "ttk_pwconv1x1_bwd_fused" or name.startswith("ttk_bc_pw")) else tuple(args[-5:]) if name.startswith("ttk_bc_dw") else tuple(ints[-5:-2]) if name in ("ttk_pwconv1x1_fwd", "ttk_pwconv1x1_bwd_data")
                                 else tuple(ints[-4:-1]) if name == "ttk_pwconv1x1_bwd_weight"
                                 else tuple(ints[-9:]) if name.startswith("ttk_conv_") else tuple(args[-6:-1]))
 
@@ -492,7 +508,7 @@ def main():
             def roofline_of(k):
                 v = ks[k]
                 sec, launches = v["ms"] * 1e-3, v["calls_per_step"] * roof_steps
-                products = 3 if "pw16" in k else 6 if "pw_split" in k else 0  # 16-bit MFMA products per fp32 product
+                products = 3 if "pw16" in k else 6 if "pw_split" in k else 0  # 16-bit MFMA products per fp32 product (the bf16-compute GEMMs, one product, are HBM-bound)
                 hbm = products == 0
                 if hbm:
                     ach, peak, unit = v["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s"
@@ -525,7 +541,7 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "input": "129x129x1 f32",
                        "parallelism": f"dp{world}"},
             "roofline": roof,
-            "step_roofline": ({"hbm_frac_of_8TBs": per_gpu * ALGO_BYTES_PER_CROP * (0.5 if args.precision == "bf16-all" else 1.0) / (PEAK_HBM_GBS * 1e9),
+            "step_roofline": ({"hbm_frac_of_8TBs": per_gpu * ALGO_BYTES_PER_CROP * (0.5 if args.precision in ("bf16-all", "bf16-compute") else 1.0) / (PEAK_HBM_GBS * 1e9),
                                "fp32_mfma_frac_of_157TF": per_gpu * ALGO_FLOP_PER_CROP / (PEAK_FP32_MFMA_TFLOPS * 1e12)} if args.backbone == "mobilenetv1"
                               else {"fp32_mfma_frac_of_157TF": per_gpu * 4.203e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12)}),  # 4.203 GFLOP/crop
             "enqueue": ("hipGraph replay (1 capture)" if use_graph[0] else "eager Python launches") + enqueue_note,

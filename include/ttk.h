@@ -49,7 +49,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 21
+#define TTK_ABI_VERSION 22
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -88,6 +88,8 @@ enum { TTK_AUX_ACT_BOUND = 0, TTK_AUX_DY_BOUND = 1, TTK_AUX_GMAX = 2 };
 /* The two entry points both backbones share (ttk_avgpool_fwd / ttk_avgpool_bwd) take this bit in the same argument: their
  * activation tensors are channels-last rows [pixels][C] (the ResNet18 path) instead of channel blocks (see "Activation layout"). */
 #define TTK_LAYOUT_ROWS 4
+/* ... and this one: channel blocks of 64 (the bf16-compute path below; C >= 64) instead of 32. */
+#define TTK_LAYOUT_CB64 8
 #define TTK_MAX_PARTIAL_ROWS_ELEMENTWISE 1024
 #define TTK_GEMM_BLOCK_M 128
 
@@ -255,6 +257,41 @@ int ttk_avgpool_bwd(const float* gfeat, const void* y, float* bn, const void* sk
  * MobileNet.forward returns, mobilenet_v1.py:165-186).  y, skip: channel blocks; a: plain channels-last rows. */
 int ttk_bn_act(const float* y, const float* bn, const float* skip, float* a, int64_t rows, int C,
                ttk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The bf16-COMPUTE path of the MobileNet backbone (`--precision bf16-compute`, BASELINE config 5's bf16 leg; csrc/bc_*.hip).  The
+ * reference has no such mode (it is fp32 everywhere: scripts/train_poseestimator.py:442-454 sets no precision); the entry points
+ * replace the same reference lines as their fp32 counterparts above (depthwise conv mobilenet_v1.py:57-66,78-80; pointwise conv
+ * :67,82).  Differences from the fp32 entry points:
+ *  - every activation-sized tensor AND its gradient is bfloat16 in CHANNEL BLOCKS OF 64:  [C / 64][M][64], element (m, c) at
+ *    ((c >> 6) * M + m) * 64 + (c & 63)  (C = 32: plain [M][32]) - a pixel of a block is one 128-byte line.  ttk_stem_fwd /
+ *    ttk_stem_bwd_weight (C = 32: the same bytes in either layout) serve this path with act_bf16 = TTK_STORE_ACT_BF16 |
+ *    TTK_STORE_GRAD_BF16, ttk_avgpool_* with TTK_LAYOUT_CB64 added, the ttk_bn_* finalisations unchanged;
+ *  - the pointwise products run as ONE bf16 MFMA product with fp32 accumulation: operands rounded to bf16 after the BatchNorm (+ ReLU)
+ *    / BatchNorm-backward map on load, weights rounded once per step by ttk_bc_prepare_weights (`wprep`: two images per layer,
+ *    ttk_bc_prepared_bytes); no operand bounds (row TTK_BN_AUX is not read);
+ *  - the BatchNorm maps are applied in their one-fma forms (scale*y + shift; ga*g + gb*y + c0); BatchNorm statistics come from the
+ *    values as stored; weight gradients (fp32) are reduced in a fixed order (bitwise reproducible in every mode);
+ *  - part rows: ttk_bc_partial_rows_pw(M, K, Nout) for ttk_bc_pw_fwd (K = Cin, Nout = Cout) / ttk_bc_pw_bwd_data (K = Cout,
+ *    Nout = Cin); ttk_bc_partial_rows_dw for the depthwise pair;
+ *  - ttk_bc_pw_bwd_weight needs `scratch` of ttk_bc_pw_wgrad_scratch_bytes(M, Cin, Cout) bytes and ADDS to dw.
+ * ------------------------------------------------------------------------------------------- */
+size_t ttk_bc_prepared_bytes(int Cin, int Cout);
+int ttk_bc_prepare_weights(int n, const float* const* w, const int* cin, const int* cout, void* const* prepared, ttk_stream_t stream);
+int ttk_bc_partial_rows_pw(int64_t M, int K, int Nout);
+int ttk_bc_partial_rows_dw(int B, int H, int W, int C, int stride, int backward);
+int ttk_bc_pw_fwd(const void* ydw, const float* bn_dw, const void* wprep, void* y, float* part, const float* pivot, int64_t M, int Cin,
+                  int Cout, ttk_stream_t stream);
+int ttk_bc_pw_bwd_data(const void* g, const void* y, const float* bn_pw, const void* wprep, const void* ydw, const float* bn_dw,
+                       void* g_dw, float* part, int64_t M, int Cin, int Cout, ttk_stream_t stream);
+size_t ttk_bc_pw_wgrad_scratch_bytes(int64_t M, int Cin, int Cout);
+int ttk_bc_pw_bwd_weight(const void* g, const void* y, const float* bn_pw, const void* ydw, const float* bn_dw, float* dw,
+                         float* scratch, int64_t M, int Cin, int Cout, ttk_stream_t stream);
+int ttk_bc_dw_fwd(const void* yprev, const float* bn_prev, const void* skip_prev, void* a_out, const float* w, void* y, float* part,
+                  const float* pivot, int B, int H, int W, int C, int stride, ttk_stream_t stream);
+int ttk_bc_dw_bwd_data(const void* g_dw, const void* y_dw, const float* bn_dw, const float* w, const void* skip_grad,
+                       const void* yprev, const float* bn_prev, const void* skip_prev, const void* a_in, void* g_prev, float* part,
+                       float* dw, int dw_accumulate, float* dw_partial, int B, int H, int W, int C, int stride, ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense convolutions of the ResNet18 backbone variant (backbones/resnet.py:52-104; arithmetic =

@@ -1,0 +1,79 @@
+// Shared helpers of the bf16-COMPUTE path (`--precision bf16-compute`, BASELINE config 5's bf16 leg; csrc/bc_*.hip).
+//
+// What differs from the fp32 path:
+//  * every activation-sized tensor (raw conv outputs, materialised block inputs AND their gradients) is bf16 in CHANNEL BLOCKS OF 64:
+//        [C / 64][M][64]   element (m, c) at ((c >> 6) * M + m) * 64 + (c & 63)     (C = 32: plain [M][32])
+//    so a pixel of a block is ONE 128-byte line - the unit the fp32 path's 32-channel blocks have in fp32 - and a depthwise
+//    workgroup's slab / a GEMM's k64 step are contiguous runs of pixels x 128 B;
+//  * the pointwise GEMMs multiply bf16 operands in ONE v_mfma_f32_32x32x16_bf16 product with fp32 accumulation (no fp16 split, no scale
+//    bounds, no conversion waves): the A operand is rounded to bf16 after BatchNorm + ReLU on load, the gradient operand after the
+//    BatchNorm-backward form, the weights once per step (ttk_bc_prepare_weights);
+//  * the depthwise kernels keep their LDS tiles in bf16 (a pixel of a 64-channel slab = 128 B there too) and accumulate in fp32.
+// Master weights, BatchNorm statistics (taken from the values as stored), every reduction, the weight gradients and Adam stay fp32.
+// With 8 mantissa bits in every stored tensor the one-fma forms of the BatchNorm maps (scale*y + shift; ga*g + gb*y + c0) are used:
+// their fp32 cancellation error (2^-24 of the terms) is far below the storage quantisation (2^-9) that the subtract-first forms of the
+// fp32 path protect.
+#pragma once
+#include "ttk_common.h"
+
+namespace ttk {
+namespace bc {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// channels per block of a C-channel tensor, and the element offset of (m, c)
+__host__ __device__ __forceinline__ int cbw(int C) { return C < 64 ? C : 64; }
+__host__ __device__ __forceinline__ size_t off64(int64_t m, int c, int64_t M, int C) {
+  const int w = cbw(C);
+  return ((size_t)(c / w) * (size_t)M + (size_t)m) * w + (c % w);
+}
+
+// 8 bf16 (one 16-byte chunk) <-> 8 floats
+__device__ __forceinline__ void unpack8(uint4 u, float (&f)[8]) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ unsigned pack2(float a, float b) {  // round to nearest even (v_cvt_pk_bf16_f32)
+  const ttk_bf16x2 v = __builtin_convertvector(ttk_f32x2{a, b}, ttk_bf16x2);
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+}
+__device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ uint4 ld16nt(const void* p) {
+  const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+// relu on packed bf16 pairs: a negative float has the sign bit set = a negative int16 (v_pk_max_i16)
+__device__ __forceinline__ unsigned relu_pk(unsigned v) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const s16x2 a = __builtin_bit_cast(s16x2, v), z = {0, 0};
+  const s16x2 r = __builtin_elementwise_max(a, z);
+  return __builtin_bit_cast(unsigned, r);
+}
+
+// kernels that declare more than 64 KB of dynamic LDS need the attribute once (per kernel instantiation)
+template <auto Kern>
+inline void allow_big_lds() {
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done = true;
+  }
+}
+
+// Weight image of a pointwise layer for the GEMM kernels (ttk_bc_prepare_weights): for the product out[n] = sum_k in[k] * Wimg(n, k)
+// rows n of min(K, 64) bf16 (one k64 block, 128 B; K = 32: 64 B) in [K / 64][N][row]; the 16-byte chunks of a row are stored XOR-swizzled
+// so that the MFMA operand reads (32 rows x one chunk per ds_read_b128) are bank-conflict free in LDS:
+//   chunk c (k = 8 c .. 8 c + 7 of the block) of row n sits at position c ^ swz(n)
+__host__ __device__ __forceinline__ int w_cpr(int K) { return K < 64 ? K / 8 : 8; }                  // chunks per row
+__host__ __device__ __forceinline__ int w_swz(int n, int cpr) { return cpr == 8 ? (n >> 1) & 7 : (n >> 2) & 3; }
+
+}  // namespace bc
+}  // namespace ttk

@@ -1,0 +1,566 @@
+// Pointwise 1x1 convolutions of the bf16-COMPUTE path (bc_common.h): forward and data gradient as ONE bf16 MFMA product.
+//
+//   forward  y[m][n]    = sum_k a[m][k] W[n][k]            a  = bf16(relu(scale*ydw + shift))            on load
+//   dgrad    g_dw[m][n] = sum_k dy[m][k] W[k][n] * mask    dy = bf16(ga*g + gb*y + c0), mask = [a_dw > 0]  on load / in the epilogue
+// (k = contraction channels: Cin forward, Cout data gradient; n = output channels).  Both are the same kernel: the weight image
+// (ttk_bc_prepare_weights) is the MFMA "A" operand - rows = OUTPUT CHANNELS - and the activations are the "B" operand - columns =
+// PIXELS - so that
+//   * a lane's B fragment (8 consecutive channels of one pixel) is 16 contiguous bytes of the [C/64][M][64] tensor: the waves load their
+//     fragments STRAIGHT from global memory into registers, transform them there and never stage activations in LDS;
+//   * an accumulator lane holds 4 consecutive channels of one pixel: the epilogue packs them, transposes 32 pixels x 64 channels
+//     through a wave-private 4 KB LDS tile and every lane stores 16 contiguous bytes - 1 KB per wave instruction, whole 128-byte lines.
+// BatchNorm partial sums come from the values as stored (read back from that tile).
+//
+// Two structures, chosen per shape (all of them HBM- or CU-ingest-bound with one product):
+//   bc_gemm_e_k  N <= 128 (K <= 256): the whole weight image is resident in LDS, the eight waves of a workgroup are INDEPENDENT
+//                streams over 32-pixel groups (no barrier after the prologue), the next group's loads are in flight while one is computed;
+//   bc_gemm_l_k  N a multiple of 256: tiles of <= 256 pixels x 256 channels, the weight image streamed per k64 step through a
+//                two-slot LDS ring (plain loads one step ahead + ds_write), one barrier per step.
+#include "bc_common.h"
+
+namespace ttk {
+namespace bc {
+
+constexpr int kFwd = 0, kDgrad = 1;
+
+// ---------------------------------------------------------------------------------------------
+// weight images: [img 0: forward rows = Cout, k = Cin | img 1: data gradient rows = Cin, k = Cout], bf16, swizzled chunks
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxPrep = 16;
+struct PrepTable {
+  const float* w[kMaxPrep];
+  uint4* out[kMaxPrep];
+  int cin[kMaxPrep], cout[kMaxPrep];
+  long long start[kMaxPrep + 1];  // first chunk of layer i in the flat index space
+  int n;
+};
+__global__ void __launch_bounds__(256) bc_prepare_k(PrepTable t) {
+  const long long total = t.start[t.n];
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    int l = 0;
+    while (l + 1 < t.n && idx >= t.start[l + 1]) ++l;
+    const int cin = t.cin[l], cout = t.cout[l];
+    const long long local = idx - t.start[l], per = (long long)cin * cout / 8;
+    const int img = (int)(local / per);
+    const long long cl = local - (long long)img * per;
+    const int K = img == 0 ? cin : cout, N = img == 0 ? cout : cin;
+    const int cpr = w_cpr(K);
+    const long long row = cl / cpr;
+    const int cs = (int)(cl - row * cpr);
+    const int kb = (int)(row / N), n = (int)(row - (long long)kb * N);
+    const int c = cs ^ w_swz(n, cpr);
+    const int k0 = kb * 64 + 8 * c;
+    const float* w = t.w[l];
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = img == 0 ? w[(size_t)n * cin + k0 + j] : w[(size_t)(k0 + j) * cin + n];  // W[co][ci]
+    t.out[l][local] = pack8(f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shared pieces
+// ---------------------------------------------------------------------------------------------
+// fragment of 8 channels (ch .. ch + 7 of the contraction side) from the raw 16-byte loads
+template <int MODE>
+__device__ __forceinline__ bf16x8 make_frag(uint4 r0, uint4 r1, const float* cA, int K, int ch) {
+  float a[8], c0[8], c1[8];
+  unpack8(r0, a);
+  *reinterpret_cast<float4*>(c0) = *reinterpret_cast<const float4*>(cA + ch);
+  *reinterpret_cast<float4*>(c0 + 4) = *reinterpret_cast<const float4*>(cA + ch + 4);
+  *reinterpret_cast<float4*>(c1) = *reinterpret_cast<const float4*>(cA + K + ch);
+  *reinterpret_cast<float4*>(c1 + 4) = *reinterpret_cast<const float4*>(cA + K + ch + 4);
+  uint4 p;
+  if constexpr (MODE == kFwd) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaf(c0[j], a[j], c1[j]);
+    p = pack8(v);
+    p.x = relu_pk(p.x); p.y = relu_pk(p.y); p.z = relu_pk(p.z); p.w = relu_pk(p.w);
+  } else {
+    float y[8], c2[8], v[8];
+    unpack8(r1, y);
+    *reinterpret_cast<float4*>(c2) = *reinterpret_cast<const float4*>(cA + 2 * K + ch);
+    *reinterpret_cast<float4*>(c2 + 4) = *reinterpret_cast<const float4*>(cA + 2 * K + ch + 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaf(c0[j], a[j], fmaf(c1[j], y[j], c2[j]));
+    p = pack8(v);
+  }
+  return __builtin_bit_cast(bf16x8, p);
+}
+
+// constants of the contraction side into LDS: forward scale | shift; data gradient ga | gb | c0
+template <int MODE>
+__device__ __forceinline__ void fill_cA(float* cA, const float* bnA, int K, int tid, int nthreads) {
+  for (int c = tid; c < K; c += nthreads) {
+    if constexpr (MODE == kFwd) {
+      const float sc = bnA[TTK_BN_SCALE * K + c];
+      cA[c] = sc;
+      cA[K + c] = fmaf(-sc, bnA[TTK_BN_MEAN * K + c], bnA[TTK_BN_BETA * K + c]);
+    } else {
+      const float ga = bnA[TTK_BN_GA * K + c], gb = bnA[TTK_BN_GB * K + c];
+      cA[c] = ga;
+      cA[K + c] = gb;
+      cA[2 * K + c] = -ga * bnA[TTK_BN_GMEAN * K + c] - gb * bnA[TTK_BN_MEAN * K + c];
+    }
+  }
+}
+// constants of the output side, channels n0 .. n0 + cnt - 1: forward pivot; data gradient scale | shift | mean of the mask operand's BatchNorm
+template <int MODE>
+__device__ __forceinline__ void fill_cE(float* cE, const float* pivot, const float* bnE, int Ntot, int n0, int cnt, int tid, int nthreads) {
+  for (int c = tid; c < cnt; c += nthreads) {
+    if constexpr (MODE == kFwd) {
+      cE[c] = pivot ? pivot[n0 + c] : 0.f;
+    } else {
+      const float sc = bnE[TTK_BN_SCALE * Ntot + n0 + c], mu = bnE[TTK_BN_MEAN * Ntot + n0 + c];
+      cE[c] = sc;
+      cE[cnt + c] = fmaf(-sc, mu, bnE[TTK_BN_BETA * Ntot + n0 + c]);
+      cE[2 * cnt + c] = mu;
+    }
+  }
+}
+
+// One 32-pixel x OC-channel block of a wave's accumulators -> its LDS tile -> global memory (+ statistics).
+//   acc: BPC = OC / 32 accumulator blocks (channels x pixels); stg: wave-private tile [32 px][OC] bf16, chunks XOR-swizzled by pixel
+//   ce: output-side constants of THIS block's channels ([cnt] rows apart), pix0: first pixel, pend: end of the valid pixels
+//   s1, s2: the lane's running sums for its 8 channels (lane % LPP = its 16-byte chunk of the pixel)
+template <int MODE, int OC>
+__device__ __forceinline__ void store_block(const f32x16* acc, uint4* stg, bf16_t* __restrict__ outb, const uint4* mk, const float* ce, int cnt,
+                                            int64_t pix0, int64_t pend, float (&s1)[8], float (&s2)[8]) {
+  constexpr int LPP = OC / 8, PPI = 64 / LPP, NI = 32 / PPI, BPC = OC / 32;
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  unsigned char* sb = reinterpret_cast<unsigned char*>(stg);
+#pragma unroll
+  for (int blk = 0; blk < BPC; ++blk)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const f32x16& a = acc[blk];
+      const uint2 v = make_uint2(pack2(a[4 * gq], a[4 * gq + 1]), pack2(a[4 * gq + 2], a[4 * gq + 3]));
+      const int chunk = (4 * blk + gq) ^ (r & (LPP - 1));
+      *reinterpret_cast<uint2*>(sb + r * (OC * 2) + chunk * 16 + 8 * h) = v;
+    }
+  asm volatile("" ::: "memory");  // (LDS operations of one wave complete in order: the reads below see the stores above)
+  __builtin_amdgcn_wave_barrier();
+  const int oct = lane % LPP;
+  float e0[8], e1[8], e2[8];
+  *reinterpret_cast<float4*>(e0) = *reinterpret_cast<const float4*>(ce + 8 * oct);
+  *reinterpret_cast<float4*>(e0 + 4) = *reinterpret_cast<const float4*>(ce + 8 * oct + 4);
+  if constexpr (MODE == kDgrad) {
+    *reinterpret_cast<float4*>(e1) = *reinterpret_cast<const float4*>(ce + cnt + 8 * oct);
+    *reinterpret_cast<float4*>(e1 + 4) = *reinterpret_cast<const float4*>(ce + cnt + 8 * oct + 4);
+    *reinterpret_cast<float4*>(e2) = *reinterpret_cast<const float4*>(ce + 2 * cnt + 8 * oct);
+    *reinterpret_cast<float4*>(e2 + 4) = *reinterpret_cast<const float4*>(ce + 2 * cnt + 8 * oct + 4);
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int px = PPI * i + lane / LPP;
+    uint4 u = stg[px * LPP + (oct ^ (px & (LPP - 1)))];
+    const int64_t pix = pix0 + px;
+    const bool ok = pix < pend;
+    float f[8];
+    unpack8(u, f);
+    if constexpr (MODE == kFwd) {
+      if (ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = f[j] - e0[j];
+          s1[j] += d;
+          s2[j] = fmaf(d, d, s2[j]);
+        }
+      }
+    } else {
+      float y[8];
+      unpack8(mk[i], y);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float a = fmaf(e0[j], y[j], e1[j]);
+        f[j] = a > 0.f ? f[j] : 0.f;
+      }
+      u = pack8(f);  // (the kept values are bf16 already: exact)
+      if (ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          s1[j] += f[j];
+          s2[j] = fmaf(f[j], y[j] - e2[j], s2[j]);
+        }
+      }
+    }
+    if (ok) st16(outb + (size_t)(pix - pix0) * OC + 8 * oct, u);
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------
+// resident-weight kernel: N = 32 NB <= 128 output channels, K = 32 KH <= 256 contraction channels
+// ---------------------------------------------------------------------------------------------
+template <int MODE, int NB, int KH>
+__global__ void __launch_bounds__(512) bc_gemm_e_k(const bf16_t* __restrict__ A0, const bf16_t* __restrict__ A1, const float* __restrict__ bnA,
+                                                    const uint4* __restrict__ Wimg, bf16_t* __restrict__ out, const bf16_t* __restrict__ maskY,
+                                                    const float* __restrict__ bnE, const float* __restrict__ pivot, float* __restrict__ part, int64_t M) {
+  constexpr int K = 32 * KH, N = 32 * NB, CPR = KH == 1 ? 4 : 8, SS = KH == 1 ? 2 : 4, NKB = KH == 1 ? 1 : KH / 2, CBK = KH == 1 ? 32 : 64;
+  constexpr int OC = NB == 1 ? 32 : 64, NCB = NB == 1 ? 1 : NB / 2, LPP = OC / 8, PPI = 64 / LPP, NI = 32 / PPI, BPC = OC / 32;
+  extern __shared__ uint4 lds[];
+  uint4* Wl = lds;                                             // N * K / 8 chunks
+  float* cA = reinterpret_cast<float*>(lds + N * K / 8);       // [3][K]
+  float* cE = cA + 3 * K;                                      // [3][N]
+  uint4* stg = reinterpret_cast<uint4*>(cE + 3 * N);           // 8 waves x 4 OC chunks
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  for (int i = tid; i < N * K / 8; i += 512) Wl[i] = Wimg[i];
+  fill_cA<MODE>(cA, bnA, K, tid, 512);
+  fill_cE<MODE>(cE, pivot, bnE, N, 0, N, tid, 512);
+  __syncthreads();
+
+  uint4* mystg = stg + wave * (4 * OC);
+  const int64_t groups = (M + 31) / 32, stride = (int64_t)gridDim.x * 8;
+  int64_t g = (int64_t)blockIdx.x * 8 + wave;
+  float s1[NCB][8], s2[NCB][8];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[cb][j] = s2[cb][j] = 0.f;
+  uint4 rc0[SS], rc1[SS], rn0[SS], rn1[SS];
+  auto load = [&](int64_t grp, int kb, uint4(&d0)[SS], uint4(&d1)[SS]) {
+    int64_t pix = grp * 32 + r;
+    pix = pix < M ? pix : M - 1;
+    const size_t o = ((size_t)kb * M + pix) * CBK + 8 * h;
+#pragma unroll
+    for (int s = 0; s < SS; ++s) {
+      d0[s] = ld16nt(A0 + o + 16 * s);
+      if constexpr (MODE == kDgrad) d1[s] = ld16nt(A1 + o + 16 * s);
+    }
+  };
+  // this lane's W fragment: row 32 nb + r, chunk 2 s + h (swizzled) of k64 block kb
+  const int wrow = r * CPR, wsw = w_swz(r, CPR);
+  if (g < groups) load(g, 0, rc0, rc1);
+  for (; g < groups; g += stride) {
+    const int64_t pix0 = g * 32;
+    // the mask operand of the data gradient (same positions as the outputs this lane will store): block 0 is requested here, block cb + 1
+    // when block cb is stored
+    uint4 mk[2][NI];
+    auto load_mask = [&](int cb, uint4(&d)[NI]) {
+      if constexpr (MODE == kDgrad) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          int64_t pix = pix0 + PPI * i + lane / LPP;
+          pix = pix < M ? pix : M - 1;
+          d[i] = ld16nt(maskY + ((size_t)cb * M + pix) * OC + 8 * (lane % LPP));
+        }
+      }
+    };
+    load_mask(0, mk[0]);
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
+#pragma unroll(NKB <= 2 ? NKB : 1)
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (kb + 1 < NKB) load(g, kb + 1, rn0, rn1);
+      else if (g + stride < groups) load(g + stride, 0, rn0, rn1);
+#pragma unroll
+      for (int s = 0; s < SS; ++s) {
+        const bf16x8 fr = make_frag<MODE>(rc0[s], rc1[s], cA, K, kb * 64 + 16 * s + 8 * h);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const uint4 wv = Wl[(kb * N + 32 * nb) * CPR + wrow + ((2 * s + h) ^ wsw)];
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv), fr, acc[nb], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < SS; ++s) { rc0[s] = rn0[s]; rc1[s] = rn1[s]; }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      if (cb + 1 < NCB) load_mask(cb + 1, mk[(cb + 1) & 1]);
+      store_block<MODE, OC>(acc + cb * BPC, mystg, out + ((size_t)cb * M + pix0) * OC, mk[cb & 1], cE + cb * OC, N, pix0, M, s1[cb], s2[cb]);
+    }
+  }
+  // ---- partial sums of the workgroup: lanes of one chunk, then the eight waves (fixed order)
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int off = LPP; off < 64; off <<= 1) {
+        s1[cb][j] += __shfl_xor(s1[cb][j], off);
+        s2[cb][j] += __shfl_xor(s2[cb][j], off);
+      }
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(stg);  // [8 waves][2][N]
+  if (lane < LPP) {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[(wave * 2 + 0) * N + cb * OC + 8 * lane + j] = s1[cb][j];
+        red[(wave * 2 + 1) * N + cb * OC + 8 * lane + j] = s2[cb][j];
+      }
+  }
+  __syncthreads();
+  if (part)
+    for (int i = tid; i < 2 * N; i += 512) {
+      const int which = i / N, c = i - which * N;
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += red[(w * 2 + which) * N + c];
+      part[(size_t)blockIdx.x * 2 * N + i] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// streamed-weight kernel: tiles of RT <= 256 pixels x 256 output channels; K, N multiples of 64 / 256
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(512) bc_gemm_l_k(const bf16_t* __restrict__ A0, const bf16_t* __restrict__ A1, const float* __restrict__ bnA,
+                                                    const uint4* __restrict__ Wimg, bf16_t* __restrict__ out, const bf16_t* __restrict__ maskY,
+                                                    const float* __restrict__ bnE, const float* __restrict__ pivot, float* __restrict__ part, int64_t M,
+                                                    int K, int N, int RT, int nrt, int ncol) {
+  extern __shared__ uint4 lds[];
+  uint4* ring = lds;                                            // [2][256 rows x 8 chunks]
+  uint4* stg = lds + 2 * 2048;                                  // 8 waves x 256 chunks
+  float* cE = reinterpret_cast<float*>(stg + 8 * 256);          // [3][256]
+  float* cA = cE + 3 * 256;                                     // [3][K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  // blocks b and b + 8 share an XCD (round-robin dispatch): the column tiles of one row tile sit there together, the second one finds
+  // the activation rows in that XCD's L2
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int ct = jj % ncol, rt = (jj / ncol) * 8 + xcd;
+  if (rt >= nrt) return;
+  const int n0 = ct * 256;
+  const int64_t p0 = (int64_t)rt * RT, pend = (p0 + RT < M) ? p0 + RT : M;
+  fill_cA<MODE>(cA, bnA, K, tid, 512);
+  fill_cE<MODE>(cE, pivot, bnE, N, n0, 256, tid, 512);
+  const int nkb = K / 64;
+  // this wave's pixels p0 + 32 wave + r
+  int64_t pix = p0 + 32 * wave + r;
+  pix = pix < pend ? pix : pend - 1;
+  const bool wave_live = p0 + 32 * wave < pend;
+  const size_t abase = (size_t)pix * 64 + 8 * h;
+  uint4 rc0[4], rc1[4], rn0[4], rn1[4];
+  uint4 w0, w1, w2, w3;  // the next k64 slab of this column tile (256 rows x 128 B, contiguous in the image): 4 chunks per thread
+  auto load_act = [&](int kb, uint4(&d0)[4], uint4(&d1)[4]) {
+    const size_t o = (size_t)kb * M * 64 + abase;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      d0[s] = ld16nt(A0 + o + 16 * s);
+      if constexpr (MODE == kDgrad) d1[s] = ld16nt(A1 + o + 16 * s);
+    }
+  };
+#define TTK_BC_LOAD_W(kb_)                                              \
+  do {                                                                  \
+    const uint4* src_ = Wimg + ((size_t)(kb_) * N + n0) * 8 + tid;      \
+    w0 = src_[0]; w1 = src_[512]; w2 = src_[1024]; w3 = src_[1536];     \
+  } while (0)
+#define TTK_BC_STORE_W(slot_)                                           \
+  do {                                                                  \
+    uint4* dst_ = ring + (slot_) * 2048 + tid;                          \
+    dst_[0] = w0; dst_[512] = w1; dst_[1024] = w2; dst_[1536] = w3;     \
+  } while (0)
+  TTK_BC_LOAD_W(0);
+  load_act(0, rc0, rc1);
+  TTK_BC_STORE_W(0);
+  if (nkb > 1) TTK_BC_LOAD_W(1);
+  f32x16 acc[8];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
+  const int wrow = r * 8, wsw = (r >> 1) & 7;
+  __syncthreads();
+  for (int kb = 0; kb < nkb; ++kb) {
+    if (kb + 1 < nkb) load_act(kb + 1, rn0, rn1);
+    const uint4* Ws = ring + (kb & 1) * 2048;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 fr = make_frag<MODE>(rc0[s], rc1[s], cA, K, kb * 64 + 16 * s + 8 * h);
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) {
+        const uint4 wv = Ws[nb * 256 + wrow + ((2 * s + h) ^ wsw)];
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv), fr, acc[nb], 0, 0, 0);
+      }
+    }
+    if (kb + 1 < nkb) TTK_BC_STORE_W((kb + 1) & 1);  // (that slot was last read in step kb - 1: every wave has passed the barrier since)
+    if (kb + 2 < nkb) TTK_BC_LOAD_W(kb + 2);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { rc0[s] = rn0[s]; rc1[s] = rn1[s]; }
+  }
+#undef TTK_BC_LOAD_W
+#undef TTK_BC_STORE_W
+  // ---- epilogue: four 64-channel blocks through the wave's LDS tile
+  uint4* mystg = stg + wave * 256;
+  float* red = reinterpret_cast<float*>(ring);  // [8 waves][4 blocks][2][64] (the ring is free: barrier above)
+  const int64_t wp0 = p0 + 32 * wave;
+  const int oct = lane & 7;
+  uint4 mk[2][4];
+  auto load_mask = [&](int cb, uint4(&d)[4]) {
+    if constexpr (MODE == kDgrad) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int64_t p = wp0 + 8 * i + (lane >> 3);
+        p = p < pend ? p : pend - 1;
+        d[i] = ld16nt(maskY + ((size_t)(n0 / 64 + cb) * M + p) * 64 + 8 * oct);
+      }
+    }
+  };
+  if (wave_live) load_mask(0, mk[0]);
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    if (wave_live) {
+      if (cb + 1 < 4) load_mask(cb + 1, mk[(cb + 1) & 1]);
+      store_block<MODE, 64>(acc + 2 * cb, mystg, out + ((size_t)(n0 / 64 + cb) * M + wp0) * 64, mk[cb & 1], cE + 64 * cb, 256, wp0, pend, s1, s2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+          s1[j] += __shfl_xor(s1[j], off);
+          s2[j] += __shfl_xor(s2[j], off);
+        }
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[((wave * 4 + cb) * 2 + 0) * 64 + 8 * lane + j] = s1[j];
+        red[((wave * 4 + cb) * 2 + 1) * 64 + 8 * lane + j] = s2[j];
+      }
+    }
+  }
+  __syncthreads();
+  if (part) {  // tid = which * 256 + column of the tile
+    const int which = tid >> 8, c = tid & 255, cb = c >> 6, cc = c & 63;
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) a += red[((w * 4 + cb) * 2 + which) * 64 + cc];
+    part[((size_t)rt * 2 + which) * N + n0 + c] = a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static bool pw_shape_ok(int Cin, int Cout) {
+  auto p2 = [](int v) { return v >= 32 && v <= 1024 && (v & (v - 1)) == 0; };
+  return p2(Cin) && p2(Cout);
+}
+// E: N <= 128 and K <= 256; else L needs N % 256 == 0 and K % 64 == 0
+static bool is_e(int K, int N) { return N <= 128 && K <= 256; }
+static bool is_l(int K, int N) { return N % 256 == 0 && K % 64 == 0; }
+
+struct LPlan { int RT, nrt, ncol, grid; };
+static LPlan l_plan(int64_t M, int N) {
+  LPlan p;
+  p.ncol = N / 256;
+  const int64_t t256 = ceil_div(M, 256);
+  const int64_t rounds = ceil_div(t256 * p.ncol, 256);      // rounds of the 256 CUs with full 256-pixel tiles
+  int64_t target = rounds * 256 / p.ncol;                   // row tiles that fill those rounds
+  if (target < 1) target = 1;
+  int64_t RT = ceil_div(ceil_div(M, target), 8) * 8;
+  if (RT > 256) RT = 256;
+  if (RT < 8) RT = 8;
+  p.RT = (int)RT;
+  p.nrt = (int)ceil_div(M, RT);
+  p.grid = (int)(ceil_div(p.nrt, 8) * 8 * p.ncol);
+  return p;
+}
+static int e_grid(int64_t M) {
+  const int64_t groups = ceil_div(M, 32);
+  int64_t g = ceil_div(groups, 8);
+  if (g > 256) g = 256;
+  return (int)g;
+}
+static size_t e_lds_bytes(int K, int N) {
+  const int OC = N < 64 ? 32 : 64;
+  const size_t stg = (size_t)8 * 4 * OC * 16, red = (size_t)8 * 2 * N * 4;
+  return (size_t)N * K * 2 + (size_t)3 * K * 4 + (size_t)3 * N * 4 + (stg > red ? stg : red);
+}
+static size_t l_lds_bytes(int K) { return (size_t)2 * 2048 * 16 + (size_t)8 * 256 * 16 + (size_t)3 * 256 * 4 + (size_t)3 * K * 4; }
+
+template <int MODE>
+static int launch_gemm(const bf16_t* A0, const bf16_t* A1, const float* bnA, const uint4* Wimg, bf16_t* out, const bf16_t* maskY, const float* bnE,
+                       const float* pivot, float* part, int64_t M, int K, int N, hipStream_t st) {
+  if (is_e(K, N)) {
+    const int grid = e_grid(M);
+    const size_t sm = e_lds_bytes(K, N);
+#define TTK_BC_E(NB_, KH_)                                                                                                                        \
+  if (N == 32 * NB_ && K == 32 * KH_) {                                                                                                           \
+    allow_big_lds<bc_gemm_e_k<MODE, NB_, KH_>>();                                                                                                 \
+    hipLaunchKernelGGL((bc_gemm_e_k<MODE, NB_, KH_>), dim3(grid), dim3(512), sm, st, A0, A1, bnA, Wimg, out, maskY, bnE, pivot, part, M);             \
+    return 0;                                                                                                                                     \
+  }
+    TTK_BC_E(2, 1) TTK_BC_E(4, 2) TTK_BC_E(4, 4)            // forward: 32 -> 64, 64 -> 128, 128 -> 128
+    TTK_BC_E(1, 2) TTK_BC_E(2, 4) TTK_BC_E(4, 8)            // data gradient of 32 -> 64, 64 -> 128, 128 -> 256 (and 4, 4: 128 -> 128)
+#undef TTK_BC_E
+    return -2;
+  }
+  if (!is_l(K, N)) return -2;
+  const LPlan p = l_plan(M, N);
+  allow_big_lds<bc_gemm_l_k<MODE>>();
+  hipLaunchKernelGGL((bc_gemm_l_k<MODE>), dim3(p.grid), dim3(512), l_lds_bytes(K), st, A0, A1, bnA, Wimg, out, maskY, bnE, pivot, part, M, K, N, p.RT, p.nrt, p.ncol);
+  return 0;
+}
+
+}  // namespace bc
+}  // namespace ttk
+
+using namespace ttk;
+using namespace ttk::bc;
+
+extern "C" {
+
+size_t ttk_bc_prepared_bytes(int Cin, int Cout) { return pw_shape_ok(Cin, Cout) ? (size_t)2 * Cin * Cout * 2 : 0; }
+
+int ttk_bc_prepare_weights(int n, const float* const* w, const int* cin, const int* cout, void* const* prepared, ttk_stream_t stream) {
+  TTK_REQUIRE(n >= 1 && n <= kMaxPrep && w && cin && cout && prepared, "bc_prepare_weights: 1..%d layers", kMaxPrep);
+  PrepTable t;
+  t.n = n;
+  long long total = 0;
+  for (int i = 0; i < n; ++i) {
+    TTK_REQUIRE(w[i] && prepared[i] && pw_shape_ok(cin[i], cout[i]), "bc_prepare_weights: layer %d: null pointer or unsupported shape %d -> %d", i, cin[i], cout[i]);
+    t.w[i] = w[i];
+    t.out[i] = reinterpret_cast<uint4*>(prepared[i]);
+    t.cin[i] = cin[i];
+    t.cout[i] = cout[i];
+    t.start[i] = total;
+    total += (long long)2 * cin[i] * cout[i] / 8;
+  }
+  t.start[n] = total;
+  int grid = (int)ceil_div(total, 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(bc_prepare_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, t);
+  TTK_LAUNCH_CHECK("bc_prepare_weights");
+}
+
+int ttk_bc_partial_rows_pw(int64_t M, int K, int Nout) {
+  if (M < 1 || !pw_shape_ok(K, Nout)) return -1;
+  if (is_e(K, Nout)) return e_grid(M);
+  if (is_l(K, Nout)) return l_plan(M, Nout).nrt;
+  return -1;
+}
+
+int ttk_bc_pw_fwd(const void* ydw, const float* bn_dw, const void* wprep, void* y, float* part, const float* pivot, int64_t M, int Cin, int Cout,
+                  ttk_stream_t stream) {
+  TTK_REQUIRE(ydw && bn_dw && wprep && y, "bc_pw_fwd: null pointer");
+  TTK_REQUIRE(M >= 1 && M < ((int64_t)1 << 31) && pw_shape_ok(Cin, Cout) && (is_e(Cin, Cout) || is_l(Cin, Cout)), "bc_pw_fwd: unsupported shape M=%lld %d -> %d",
+              (long long)M, Cin, Cout);
+  const int rc = launch_gemm<kFwd>((const bf16_t*)ydw, nullptr, bn_dw, (const uint4*)wprep, (bf16_t*)y, nullptr, nullptr, pivot, part, M, Cin, Cout, (hipStream_t)stream);
+  TTK_REQUIRE(rc == 0, "bc_pw_fwd: no kernel for %d -> %d", Cin, Cout);
+  TTK_LAUNCH_CHECK("bc_pw_fwd");
+}
+
+int ttk_bc_pw_bwd_data(const void* g, const void* y, const float* bn_pw, const void* wprep, const void* ydw, const float* bn_dw, void* g_dw,
+                       float* part, int64_t M, int Cin, int Cout, ttk_stream_t stream) {
+  TTK_REQUIRE(g && y && bn_pw && wprep && ydw && bn_dw && g_dw, "bc_pw_bwd_data: null pointer");
+  TTK_REQUIRE(M >= 1 && M < ((int64_t)1 << 31) && pw_shape_ok(Cin, Cout) && (is_e(Cout, Cin) || is_l(Cout, Cin)), "bc_pw_bwd_data: unsupported shape M=%lld %d -> %d",
+              (long long)M, Cin, Cout);
+  const uint4* img = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(wprep) + (size_t)Cin * Cout * 2);  // image 1: rows = Cin, k = Cout
+  const int rc = launch_gemm<kDgrad>((const bf16_t*)g, (const bf16_t*)y, bn_pw, img, (bf16_t*)g_dw, (const bf16_t*)ydw, bn_dw, nullptr, part, M, Cout, Cin,
+                                     (hipStream_t)stream);
+  TTK_REQUIRE(rc == 0, "bc_pw_bwd_data: no kernel for %d -> %d", Cin, Cout);
+  TTK_LAUNCH_CHECK("bc_pw_bwd_data");
+}
+
+}  // extern "C"

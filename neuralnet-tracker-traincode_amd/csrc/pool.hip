@@ -5,6 +5,14 @@
 
 namespace ttk {
 
+// element offset of (pixel m, channel c) by the layout argument: 0 = channel blocks of 32 (the fp32 MobileNet path), 1 = channels-last rows
+// (ResNet18), 2 = channel blocks of 64 (the bf16-compute path, csrc/bc_common.h; C >= 64)
+__device__ __forceinline__ size_t pool_off(int layout, int64_t m, int c, int64_t M, int C) {
+  if (layout == 1) return (size_t)m * C + c;
+  if (layout == 2) return ((size_t)(c >> 6) * (size_t)M + (size_t)m) * 64 + (c & 63);
+  return act_off(m, c, M);
+}
+
 // thread = (sample, channel quad)
 template <typename T>
 __global__ void __launch_bounds__(kBlock) avgpool_fwd_k(const T* __restrict__ y, const float* __restrict__ bnp,
@@ -20,7 +28,7 @@ __global__ void __launch_bounds__(kBlock) avgpool_fwd_k(const T* __restrict__ y,
     float4 s = f4(0.f);
     for (int p = 0; p < HW; ++p) {
       const int64_t m = (int64_t)n * HW + p;
-      const size_t off = rows_layout ? (size_t)m * C + 4 * c4 : act_off(m, 4 * c4, (int64_t)B * HW);  // channels-last rows (ResNet18) | channel blocks
+      const size_t off = pool_off(rows_layout, m, 4 * c4, (int64_t)B * HW, C);
       s = add4(s, skip ? bn.act(Act<T>::ld(y + off), Act<T>::ld(skip + off)) : bn.act(Act<T>::ld(y + off)));
     }
     st4(feat + (size_t)n * C + 4 * c4, make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv));
@@ -42,7 +50,7 @@ __global__ void __launch_bounds__(kBlock) avgpool_bwd_k(const float* __restrict_
   float gmx = 0.f;  // max |g| (ttk.h, TTK_AUX_GMAX)
   for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < items; idx += (int64_t)gridDim.x * kBlock) {
     const int n = (int)((unsigned)(idx >> qshift) / (unsigned)HW);  // 32-bit division (the host checks that B * HW fits)
-    const size_t off = rows_layout ? (size_t)idx << 2 : act_off(idx >> qshift, 4 * c4, (int64_t)B * HW);  // channels-last rows (ResNet18) | channel blocks
+    const size_t off = pool_off(rows_layout, idx >> qshift, 4 * c4, (int64_t)B * HW, C);
     const float4 yv = Act<T>::ld(y + off);
     const float4 a = skip ? bn.act(yv, Act<T>::ld(skip + off)) : bn.act(yv);
     float4 gv = ld4(gfeat + (size_t)n * C + 4 * c4);
@@ -79,7 +87,7 @@ int ttk_avgpool_fwd(const void* y, const float* bn, const void* skip, float* fea
   TTK_REQUIRE(B > 0 && HW > 0 && C >= 32 && C <= 1024 && (C & (C - 1)) == 0, "avgpool_fwd: unsupported shape B=%d HW=%d C=%d", B, HW, C);
   const int64_t items = (int64_t)B * (C / 4);
   TTK_ACT_DISPATCH(act_bf16, hipLaunchKernelGGL((avgpool_fwd_k<ActT>), dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream,
-                                                (const ActT*)y, bn, (const ActT*)skip, feat, B, HW, C, (act_bf16 & TTK_LAYOUT_ROWS) != 0));
+                                                (const ActT*)y, bn, (const ActT*)skip, feat, B, HW, C, (act_bf16 & TTK_LAYOUT_ROWS) ? 1 : ((act_bf16 & TTK_LAYOUT_CB64) ? 2 : 0)));
   TTK_LAUNCH_CHECK("avgpool_fwd");
 }
 
@@ -91,7 +99,7 @@ int ttk_avgpool_bwd(const float* gfeat, const void* y, float* bn, const void* sk
   const int qs = log2i_(C / 4);
   const int64_t items = ((int64_t)B * HW) << qs;
   TTK_ACT_DISPATCH(act_bf16, hipLaunchKernelGGL((avgpool_bwd_k<ActT, GradT>), dim3(elementwise_grid(items)), dim3(kBlock), 2 * (size_t)C * sizeof(float),
-                                                (hipStream_t)stream, gfeat, (const ActT*)y, bn, (const ActT*)skip, (GradT*)g, part, B, HW, C, qs, (act_bf16 & TTK_LAYOUT_ROWS) != 0));
+                                                (hipStream_t)stream, gfeat, (const ActT*)y, bn, (const ActT*)skip, (GradT*)g, part, B, HW, C, qs, (act_bf16 & TTK_LAYOUT_ROWS) ? 1 : ((act_bf16 & TTK_LAYOUT_CB64) ? 2 : 0)));
   TTK_LAUNCH_CHECK("avgpool_bwd");
 }
 

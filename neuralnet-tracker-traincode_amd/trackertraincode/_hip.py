@@ -95,15 +95,25 @@ _SIGNATURES = {
     "ttk_intensity_augment": [_P, _P, _P, _P, _I, _I, _I, _F],
     "ttk_clip_adam": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P],
     "ttk_stream_probe": [_P, _P, _P, _L, _I, _I, _I, _I, _L, _I, _I, _I],
+    # bf16-compute path (csrc/bc_*.hip)
+    "ttk_bc_prepare_weights": [_I, _P, _P, _P, _P],
+    "ttk_bc_pw_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I],
+    "ttk_bc_pw_bwd_data": [_P] * 8 + [_L, _I, _I],
+    "ttk_bc_pw_bwd_weight": [_P] * 7 + [_L, _I, _I],
+    "ttk_bc_dw_fwd": [_P] * 8 + [_I] * 5,
+    "ttk_bc_dw_bwd_data": [_P] * 12 + [_I, _P] + [_I] * 5,
 }
 
-ABI_VERSION = 21
+ABI_VERSION = 22
+
+
+# Whether the backbones hand the running mean to the forward producers as the statistics pivot (include/ttk.h).  Always on in the
+# product; tests/test_bn_pivot_gpu.py and tools flip this attribute for the A/B against plain sums of y and y^2.
+BN_PIVOT = True
 
 
 def bn_pivot() -> bool:
-    """Whether the backbones hand the running mean to the forward producers as the statistics pivot (include/ttk.h; TTK_BN_PIVOT=0:
-    plain sums of y and y^2, the A/B of tests/test_bn_pivot_gpu.py)."""
-    return os.environ.get("TTK_BN_PIVOT", "1") != "0"
+    return BN_PIVOT
 
 
 class LossOp(ctypes.Structure):
@@ -158,6 +168,10 @@ class _Library:
         self.cdll.ttk_pwconv1x1_bwd_fused_partial_bytes.argtypes, self.cdll.ttk_pwconv1x1_bwd_fused_partial_bytes.restype = [c_int64, c_int, c_int], ctypes.c_size_t
         self.cdll.ttk_stem7_wgrad_partial_bytes.argtypes, self.cdll.ttk_stem7_wgrad_partial_bytes.restype = [c_int] * 3, ctypes.c_size_t
         self.cdll.ttk_stem_wgrad_partial_bytes.argtypes, self.cdll.ttk_stem_wgrad_partial_bytes.restype = [], ctypes.c_size_t
+        self.cdll.ttk_bc_prepared_bytes.argtypes, self.cdll.ttk_bc_prepared_bytes.restype = [c_int, c_int], ctypes.c_size_t
+        self.cdll.ttk_bc_partial_rows_pw.argtypes, self.cdll.ttk_bc_partial_rows_pw.restype = [c_int64, c_int, c_int], c_int
+        self.cdll.ttk_bc_partial_rows_dw.argtypes, self.cdll.ttk_bc_partial_rows_dw.restype = [c_int] * 6, c_int
+        self.cdll.ttk_bc_pw_wgrad_scratch_bytes.argtypes, self.cdll.ttk_bc_pw_wgrad_scratch_bytes.restype = [c_int64, c_int, c_int], ctypes.c_size_t
         self._fns = {}
         self._stale_reported = False
         for name, sig in _SIGNATURES.items():
@@ -243,6 +257,15 @@ class _Library:
         co = (c_int * n)(*[int(w.shape[0]) for w in weights])
         self.call("ttk_pwconv_prepare_weights", n, wp, ci, co, pp)
 
+    def bc_prepare_weights(self, weights, prepared):
+        """ttk_bc_prepare_weights: the bf16 weight images (forward + data gradient) of every pointwise layer, one launch."""
+        n = len(weights)
+        wp = (c_void_p * n)(*[ptr(w) for w in weights])
+        pp = (c_void_p * n)(*[ptr(q) for q in prepared])
+        ci = (c_int * n)(*[int(w.shape[1]) for w in weights])
+        co = (c_int * n)(*[int(w.shape[0]) for w in weights])
+        self.call("ttk_bc_prepare_weights", n, wp, ci, co, pp)
+
     def multi_copy(self, srcs, dsts):
         """dsts[k].copy_(srcs[k]) (None: zero fill) for up to 32 contiguous float32 tensors per launch."""
         for i in range(0, len(dsts), 32):
@@ -312,8 +335,27 @@ def from_blocks(t: torch.Tensor) -> torch.Tensor:
     return t.reshape(C // CHANNEL_BLOCK, -1, CHANNEL_BLOCK).transpose(0, 1).reshape(t.shape)
 
 
+CHANNEL_BLOCK_BC = 64  # bf16-compute path (csrc/bc_common.h)
+
+
+def to_blocks64(t: torch.Tensor) -> torch.Tensor:
+    """Channels-last values [..., C] -> the bf16-compute path's storage order (channel blocks [C/64][pixels][64]); tests and tools only."""
+    C = t.shape[-1]
+    if C <= CHANNEL_BLOCK_BC:
+        return t.contiguous()
+    return t.reshape(-1, C // CHANNEL_BLOCK_BC, CHANNEL_BLOCK_BC).transpose(0, 1).contiguous().view(t.shape)
+
+
+def from_blocks64(t: torch.Tensor) -> torch.Tensor:
+    C = t.shape[-1]
+    if C <= CHANNEL_BLOCK_BC:
+        return t
+    return t.reshape(C // CHANNEL_BLOCK_BC, -1, CHANNEL_BLOCK_BC).transpose(0, 1).reshape(t.shape)
+
+
 def exported_symbols() -> list[str]:
     return ["ttk_abi_version", "ttk_last_error_string", "ttk_clear_error", "ttk_partial_rows_elementwise",
             "ttk_partial_rows_gemm", "ttk_partial_rows_pwconv", "ttk_pwconv_tile_rows", "ttk_partial_rows_dwconv", "ttk_heads_num_rows", "ttk_pwconv_prepared_bytes",
             "ttk_pwconv_wgrad_partial_bytes", "ttk_pwconv_wgrad_scratch_bytes", "ttk_stem_wgrad_partial_bytes", "ttk_conv_wgrad_partial_bytes", "ttk_stem7_wgrad_partial_bytes",
-            "ttk_pwconv1x1_bwd_fused_rows", "ttk_pwconv1x1_bwd_fused_partial_bytes"] + list(_SIGNATURES)
+            "ttk_pwconv1x1_bwd_fused_rows", "ttk_pwconv1x1_bwd_fused_partial_bytes", "ttk_bc_prepared_bytes", "ttk_bc_partial_rows_pw",
+            "ttk_bc_partial_rows_dw", "ttk_bc_pw_wgrad_scratch_bytes"] + list(_SIGNATURES)

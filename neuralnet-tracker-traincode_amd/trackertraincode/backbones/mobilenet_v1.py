@@ -27,8 +27,13 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import sys
+
 from .. import _hip
 from ..neuralnets.modelcomponents import BlurPool2D
+from . import _mobilenet_bc
+
+_THIS = sys.modules[__name__]
 
 __all__ = ["MobileNet", "DepthWiseBlock"]
 
@@ -90,19 +95,27 @@ class DepthWiseBlock(nn.Module):
 # rounded values), all arithmetic, weights and weight gradients stay fp32 (csrc/ttk_common.h: Act<T>).
 _ACT_DTYPE = torch.float32
 _GRAD_DTYPE = torch.float32
+# "bf16-compute" (BASELINE config 5's bf16 leg): a separate set of kernels - bf16 storage in 64-channel blocks AND bf16 operands of the
+# pointwise products (one MFMA product, fp32 accumulation); launch sequences in _mobilenet_bc.py, kernels csrc/bc_*.hip.
+_BF16_COMPUTE = False
 
 
 def set_activation_dtype(mode):
     """Storage of the backbone's activation-sized tensors in training: "fp32" (default), "bf16" (activations bfloat16,
-    their gradients float32) or "bf16-all" (both bfloat16; torch.float32 / torch.bfloat16 are accepted for the first and
-    the last).  BatchNorm's backward subtracts per-channel means of nearly constant gradients, which 8 mantissa bits do
+    their gradients float32), "bf16-all" (both bfloat16; torch.float32 / torch.bfloat16 are accepted for the first and
+    the last) or "bf16-compute" (both bfloat16 in 64-channel blocks AND bf16 operands of the pointwise products: its own kernels).  BatchNorm's backward subtracts per-channel means of nearly constant gradients, which 8 mantissa bits do
     not survive in the early layers: keep the gradients in fp32 unless you measure otherwise."""
-    global _ACT_DTYPE, _GRAD_DTYPE
+    global _ACT_DTYPE, _GRAD_DTYPE, _BF16_COMPUTE
     mode = {torch.float32: "fp32", torch.bfloat16: "bf16-all", "f32": "fp32"}.get(mode, mode)
-    if mode not in ("fp32", "bf16", "bf16-all"):
-        raise ValueError(f'activation storage must be "fp32", "bf16" or "bf16-all", got {mode}')
+    if mode not in ("fp32", "bf16", "bf16-all", "bf16-compute"):
+        raise ValueError(f'activation storage must be "fp32", "bf16", "bf16-all" or "bf16-compute", got {mode}')
+    _BF16_COMPUTE = mode == "bf16-compute"
     _ACT_DTYPE = torch.float32 if mode == "fp32" else torch.bfloat16
-    _GRAD_DTYPE = torch.bfloat16 if mode == "bf16-all" else torch.float32
+    _GRAD_DTYPE = torch.bfloat16 if mode in ("bf16-all", "bf16-compute") else torch.float32
+
+
+def bf16_compute() -> bool:
+    return _BF16_COMPUTE
 
 
 def get_activation_dtype():
@@ -277,14 +290,15 @@ def _forward_impl(x, params, buffers, momentum, eps, training, act_dtype=torch.f
 grad_ready_hook = None
 
 
-# TTK_WGRAD_STREAM=1 puts the weight-gradient GEMMs on a second stream beside the data-gradient chain.  It was worth
-# 0.3-0.4 ms/step while the kernels left the GPU half empty at their tails; with today's kernels the serial order is 0.3 %
-# faster (same box, alternating runs: 9.94 vs 9.98 ms), so it is off by default.
-_USE_WGRAD_STREAM = os.environ.get("TTK_WGRAD_STREAM", "0") != "0"
+# Experiment hooks (module attributes that tools/exp scripts flip; the product never reads the environment for them):
+# _USE_WGRAD_STREAM puts the weight-gradient GEMMs on a second stream beside the data-gradient chain.  It was worth 0.3-0.4 ms/step while
+# the kernels left the GPU half empty at their tails; with today's kernels the serial order is 0.3 % faster (same box, alternating runs:
+# 9.94 vs 9.98 ms).  _FUSED_PW_BWD = False selects the two-kernel backward of the first pointwise layers.
+_USE_WGRAD_STREAM = False
 # TTK_DETERMINISTIC=1: every weight-gradient reduction runs in a fixed order (slices of M stored to scratch and folded
 # by a second kernel instead of fp32 atomics): two runs of a step give bitwise equal gradients.
 _DETERMINISTIC = os.environ.get("TTK_DETERMINISTIC", "0") != "0"
-_FUSED_PW_BWD = os.environ.get("TTK_FUSED_PW_BWD", "1") != "0"  # 0: the two-kernel backward of the first pointwise layers (A/B timing)
+_FUSED_PW_BWD = True
 _SIDE_STREAMS: dict = {}
 
 
@@ -420,8 +434,11 @@ class _MobileNetFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, momentum, eps, buffers, frozen, blur, *params):
-        feat, c = _forward_impl(x, params, buffers, momentum, eps, training=not frozen, act_dtype=_ACT_DTYPE, grad_dtype=_GRAD_DTYPE, frozen=frozen,
-                                blur=blur)
+        if _BF16_COMPUTE:
+            feat, c = _mobilenet_bc.forward_impl(_THIS, x, params, buffers, momentum, eps, training=not frozen, frozen=frozen, blur=blur)
+        else:
+            feat, c = _forward_impl(x, params, buffers, momentum, eps, training=not frozen, act_dtype=_ACT_DTYPE, grad_dtype=_GRAD_DTYPE, frozen=frozen,
+                                    blur=blur)
         ctx.c = c
         ctx.nparams = len(params)
         ctx.save_for_backward(*params)
@@ -430,7 +447,10 @@ class _MobileNetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gfeat):
         params = ctx.saved_tensors
-        grads = _backward_impl(ctx.c, gfeat.contiguous(), params)
+        if ctx.c.bf == "bc":
+            grads = _mobilenet_bc.backward_impl(_THIS, ctx.c, gfeat.contiguous(), params)
+        else:
+            grads = _backward_impl(ctx.c, gfeat.contiguous(), params)
         ctx.c = None
         return (None, None, None, None, None, None, *grads)
 
@@ -521,7 +541,11 @@ class MobileNet(nn.Module):
                 raise NotImplementedError("eval-mode BatchNorm layers with trainable weight / bias are not built: freeze them "
                                           "(modelcomponents.freeze_norm_stats) or put the layers in training mode")
             return _MobileNetFn.apply(x, momentum, eps, self._flat_buffers(), True, self._blur_weights(), *self._flat_params())
-        feat, _ = _forward_impl(x, [q.detach() for q in self._flat_params()], self._flat_buffers(), momentum, eps, False, blur=self._blur_weights())
+        if _BF16_COMPUTE:
+            feat, _ = _mobilenet_bc.forward_impl(_THIS, x, [q.detach() for q in self._flat_params()], self._flat_buffers(), momentum, eps, False,
+                                                 blur=self._blur_weights())
+        else:
+            feat, _ = _forward_impl(x, [q.detach() for q in self._flat_params()], self._flat_buffers(), momentum, eps, False, blur=self._blur_weights())
         return feat
 
     def forward(self, x):

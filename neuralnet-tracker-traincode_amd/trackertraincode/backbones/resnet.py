@@ -59,7 +59,6 @@ class BasicBlock(nn.Module):
         return self.relu(out + identity)
 
 
-_MATERIALISE_DY = os.environ.get("TTK_GEMM") != "bf16x3"
 _DETERMINISTIC = os.environ.get("TTK_DETERMINISTIC", "0") != "0"  # bitwise reproducible steps (tests/test_determinism_gpu.py)
 _LAYOUT_ROWS = 4  # TTK_LAYOUT_ROWS (include/ttk.h): this backbone keeps its activations channels-last, [pixels][C]
 _BN_AUX = 7  # TTK_BN_AUX: [0] = TTK_AUX_ACT_BOUND of the activation this BatchNorm forms
@@ -242,10 +241,7 @@ def _backward_impl(c: _Ctx, gfeat, params):
 
     def through_bn(g, y, bn, rows, C):
         """-> (dy | g, None | y pointer): the 3x3 convolutions' two gradients read dy = ga*(g-gmean)+gb*(y-mean) materialised
-        once (fp16 kernels: half the operand bytes per pass - the data gradient gathers it nine times); TTK_GEMM=bf16x3
-        forms it on load as before."""
-        if not _MATERIALISE_DY:
-            return g, p(y)
+        once (fp16 kernels: half the operand bytes per pass - the data gradient gathers it nine times)."""
         dy = torch.empty_like(g)
         L.call("ttk_bn_bwd_apply", p(g), p(y), p(bn), p(dy), rows, C)
         return dy, None

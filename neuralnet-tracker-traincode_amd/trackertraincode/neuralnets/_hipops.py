@@ -31,7 +31,7 @@ class _Batch:
         self.keep = []  # the launch is on the stream: the caching allocator may recycle the temporaries behind it
 
 
-_BATCHING = os.environ.get("TTK_LOSS_BATCH", "1") != "0"  # 0: one launch per loss op (A/B timing)
+_BATCHING = True  # False (set by tools / tests): one launch per loss op, the A/B of the batched launch
 _TLS = threading.local()  # the open batch of this thread (backward runs on autograd's worker thread)
 
 

@@ -184,7 +184,7 @@ def default_compute_loss(preds: dict, batch: List[Batch], current_epoch: int, lo
         # Criterion accepts any callable) - that read memory the batch had not filled yet, and the term would get no gradient.
         # Nothing was launched so far: throw the deferred pass away and evaluate every term with one launch per loss op.
         _warn_once("a Criterion post-processes the value of a batched loss kernel; this step's losses run unbatched "
-                   "(wrap the arithmetic into the loss function's autograd, or set TTK_LOSS_BATCH=0, to silence this)")
+                   "(wrap the arithmetic into the loss function's autograd to silence this)")
         lb.ops.clear()
         lb.records.clear()
         lb.keep.clear()

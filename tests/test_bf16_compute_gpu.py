@@ -1,0 +1,156 @@
+"""The bf16-COMPUTE mode (`--precision bf16-compute`, BASELINE config 5's bf16 leg): bf16 storage in 64-channel blocks, ONE bf16 MFMA product
+per pointwise convolution with fp32 accumulation, bf16 depthwise tiles; fp32 master weights, statistics, reductions, optimiser
+(trackertraincode/backbones/_mobilenet_bc.py, csrc/bc_*.hip).  The reference trains in fp32 only (scripts/train_poseestimator.py:442-454
+sets no precision), so parity is stated against the fp32 oracle / the fp32 HIP step with the tolerances written here:
+
+  * first-step `loss_sum` within 1e-3 of the fp32 CPU oracle (north_star's per-step loss tolerance);
+  * AFLW2k-mini rotation MAE within 0.05 degrees of the fp32 path on identical weights and crops;
+  * the whole step against the fp32 HIP step: pooled features, running statistics, gradient norm, per-block gradient cosines - reported
+    and bounded (single-step backbone gradients are cancellation-dominated sums: tests/test_bf16_gpu.py explains the yardstick).
+The kernels themselves are held to float64 references in tests/test_bc_kernels_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import refmodel as R
+from oracle.synth import make_inputs, make_state
+from util import GOLDEN, build_net, load_golden, make_batches, script_args, train_script
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _mode(mode):
+    import trackertraincode.backbones.mobilenet_v1 as MB
+    MB.set_activation_dtype(mode)
+
+
+def _step(meta, epoch, mode):
+    import trackertraincode.train as train
+
+    S = train_script()
+    _mode(mode)
+    try:
+        net = build_net(meta, DEV).train()
+        crit, _ = S.setup_losses(script_args(meta["flags"]), net)
+        feats = []
+        orig = net.convnet.forward_features
+        net.convnet.forward_features = lambda x: feats.append(orig(x)) or feats[-1]
+        out = train.training_step(net, make_batches(meta, DEV), epoch, crit)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        return dict(loss=out["loss"].item(), feat=feats[0].detach().float().cpu(), mt={k: v.cpu() for k, v in out["mt_losses"].items()},
+                    grads={k: p.grad.detach().cpu() for k, p in net.named_parameters() if p.grad is not None},
+                    state={k: v.detach().cpu() for k, v in net.state_dict().items()})
+    finally:
+        _mode("fp32")
+
+
+@pytest.mark.parametrize("cfg,B", [("default", 64), ("full", 64)])
+def test_first_step_loss_within_1e3_of_the_fp32_oracle(cfg, B):
+    from test_oracle_golden import _batches, _criterions
+
+    _, meta = load_golden(f"model_{cfg}.npz")
+    meta = dict(meta, B=B, split=(B * 5) // 8)
+    got = _step(meta, 150, "bf16-compute")
+    st = R.state_from_numpy(make_state({k: tuple(v) for k, v in meta["shapes"].items()}, meta["state_seed"]))
+    image, ids = make_inputs(B, seed=meta["input_seed"])
+    ocrit, _ = _criterions(meta, GOLDEN)
+    o, _ = R.network_forward(st, torch.from_numpy(image), torch.from_numpy(ids), meta["config"], True)
+    ref_loss, by_name = R.compute_loss(o, _batches(meta), 150, ocrit)
+    print(f"bf16-compute loss {got['loss']:.6f}, fp32 oracle {ref_loss.item():.6f}")
+    assert abs(got["loss"] - ref_loss.item()) < 1e-3 * max(1.0, abs(ref_loss.item()))
+    worst = max(float((got["mt"][k] - v.detach()).abs().max() / v.detach().abs().max().clamp_min(1e-3)) for k, (v, _) in by_name.items())
+    print(f"   worst per-sample loss deviation relative to the term's scale: {worst:.3e}")
+    assert worst < 0.3
+
+
+@pytest.mark.parametrize("cfg,B", [("default", 96), ("full", 256)])
+def test_step_tracks_the_fp32_step(cfg, B):
+    _, meta = load_golden(f"model_{cfg}.npz")
+    meta = dict(meta, B=B, split=(B * 5) // 8)
+    a, b = _step(meta, 150, "fp32"), _step(meta, 150, "bf16-compute")
+    rel = lambda x, y: ((x.double() - y.double()).norm() / y.double().norm().clamp_min(1e-30)).item()
+    stats = dict(loss=abs(b["loss"] - a["loss"]) / abs(a["loss"]), feat=rel(b["feat"], a["feat"]), running=0.0)
+    for k, v in a["state"].items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            stats["running"] = max(stats["running"], rel(b["state"][k], v))
+    cos_by_block = {}
+    for k, g in a["grads"].items():
+        assert torch.isfinite(b["grads"][k]).all(), k
+        if g.numel() < 256 or float(g.norm()) == 0.0:
+            continue
+        cos = float((g.double().flatten() @ b["grads"][k].double().flatten()) / (g.double().norm() * b["grads"][k].double().norm()).clamp_min(1e-30))
+        blk = k.split(".")[1] if k.startswith("convnet.") else "heads"
+        cos_by_block[blk] = min(cos_by_block.get(blk, 1.0), cos)
+    gn = lambda d: float(torch.sqrt(sum((v.double() ** 2).sum() for v in d.values())))
+    stats["grad_norm"] = abs(gn(b["grads"]) - gn(a["grads"])) / gn(a["grads"])
+    print(f"bf16-compute vs fp32 (cfg={cfg}, B={B}): " + ", ".join(f"{k} {v:.2e}" for k, v in stats.items()))
+    print("   min gradient cosine per block: " + ", ".join(f"{k} {v:.3f}" for k, v in cos_by_block.items()))
+    assert stats["loss"] < 1e-2 and stats["feat"] < 0.1 and stats["running"] < 5e-2, stats
+    assert stats["grad_norm"] < 0.3, stats
+    assert cos_by_block["heads"] > 0.98 and min(cos_by_block.values()) > 0.4, cos_by_block
+
+
+def test_aflw2kmini_rotation_mae_within_005_degrees():
+    from test_eval_gpu import _load_mini
+    from trackertraincode import eval as E
+
+    images, d = _load_mini()
+    rois = d["rois"].astype(np.float32)
+    g, meta = load_golden("model_default.npz")
+    cal = {k[len("calib/"):]: g[k] for k in g.files if k.startswith("calib/")}
+    net = build_net(meta, "cuda", cal).eval()
+    targets = {"pose": torch.from_numpy(d["quats"].astype(np.float32)).cuda(), "roi": torch.from_numpy(rois).cuda(),
+               "coord": torch.from_numpy(d["coords"].astype(np.float32)).cuda()}
+    t_images = [torch.from_numpy(im) for im in images]
+    err = {}
+    try:
+        for mode in ("fp32", "bf16-compute"):
+            _mode(mode)
+            out = E.Predictor(net).predict_batch(t_images, torch.from_numpy(rois))
+            m = E.EulerAngleErrors()
+            m.update(out, targets)
+            err[mode] = np.abs(m.compute().cpu().numpy()) * 180.0 / np.pi
+    finally:
+        _mode("fp32")
+    print(f"rotation MAE fp32 {err['fp32'].mean():.4f} deg, bf16-compute {err['bf16-compute'].mean():.4f} deg; worst sample/angle differs by "
+          f"{np.abs(err['fp32'] - err['bf16-compute']).max():.4f} deg")
+    assert abs(err["fp32"].mean() - err["bf16-compute"].mean()) < 0.05
+    assert np.abs(err["fp32"].mean(0) - err["bf16-compute"].mean(0)).max() < 0.05  # pitch, yaw, roll separately
+
+
+def test_a_few_optimiser_steps_and_blurpool_run():
+    """Eight optimiser steps of the real loop (loss finite and falling on a fixed batch), and one step with `--blurpool`."""
+    import trackertraincode.train as train
+
+    S = train_script()
+    _, meta = load_golden("model_default.npz")
+    meta = dict(meta, B=64, split=40)
+    _mode("bf16-compute")
+    try:
+        net = build_net(meta, DEV).train()
+        crit, _ = S.setup_losses(script_args(meta["flags"]), net)
+        opt, _ = S.create_optimizer(net, script_args(meta["flags"]))
+        batches = make_batches(meta, DEV)
+        losses = []
+        for _ in range(8):
+            for q in net.parameters():
+                q.grad = None
+            out = train.training_step(net, batches, 0, crit)
+            out["loss"].backward()
+            opt.step()
+            losses.append(out["loss"].item())
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+        _, mb = load_golden("model_blurpool.npz")
+        mb = dict(mb, B=24, split=15)
+        netb = build_net(mb, DEV).train()
+        critb, _ = S.setup_losses(script_args(mb["flags"]), netb)
+        out = train.training_step(netb, make_batches(mb, DEV), 0, critb)
+        out["loss"].backward()
+        _mode("fp32")
+        netf = build_net(mb, DEV).train()
+        ref = train.training_step(netf, make_batches(mb, DEV), 0, critb)
+        assert abs(out["loss"].item() - ref["loss"].item()) < 5e-3 * max(1.0, abs(ref["loss"].item()))
+    finally:
+        _mode("fp32")
