@@ -7,6 +7,8 @@
 // ds_read_b128, widened and accumulated in fp32 (packed two-channel fmas).  Byte for byte the access pattern of the fp32 kernels'
 // 32-channel slabs, with twice the channels per byte.  C = 32 (the first block): a 32-channel block, 64-byte pixels.
 // BatchNorm maps in the one-fma forms (bc_common.h); partial sums in fp32 (the stored values carry 8 bits).
+#include <type_traits>
+
 #include "bc_common.h"
 
 namespace ttk {
@@ -14,9 +16,9 @@ namespace bc {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-constexpr int kPixBudgetFwd = 368;  // 128-byte pixels per LDS stage: 47 KB -> 3 workgroups per CU
-constexpr int kPixBudgetBwd = 560;  // 70 KB -> 2 workgroups per CU (72 weight-gradient accumulators per lane: <= 256 registers)
-constexpr int kWgsFwd = 3, kWgsBwd = 2;
+constexpr int kPixBudgetFwd = 560;  // 128-byte pixels per LDS stage: 70 KB -> 2 workgroups per CU (three, with 168 registers, spilled around the load ring)
+constexpr int kPixBudgetBwd = 512;  // 64 KB + 13 KB of taps / reduction scratch / constants: TWO workgroups per CU fit the 160 KB (560 did not: one per CU, one wave per SIMD); 72 weight-gradient accumulators per lane: <= 256 registers
+constexpr int kWgsFwd = 2, kWgsBwd = 2;
 constexpr int kCarryRegs = 5;       // 16-byte registers per thread that hand the shared rows from one band to the next
 constexpr int kColTileMinW = 48, kColTile = 17;
 
@@ -207,47 +209,61 @@ bc_dw_fwd_k(const bf16_t* __restrict__ yprev, const float* __restrict__ bn_prev,
     // ---- stage a_in = relu(scale*y + shift (+ skip)) as bf16, zero outside the image
     const int nstage = nimg * ((int)PI - ov * Wp) * KQ;
     const unsigned ovpix = (unsigned)(ov * Wp);
-    constexpr int kFwdU = (SKIP ? 3 : 4) - (CARRY ? 1 : 0);  // (carry mode holds five more 16-byte registers across the barrier)
-    for (int e = tid; e < nstage; e += kFwdU * kBlock) {
-      uint4 yv[kFwdU], sk[SKIP ? kFwdU : 1];
-      unsigned off[kFwdU];
-      bool in[kFwdU];
-      int pxs[kFwdU], own[kFwdU];
+    {
+      // a ring of register slots: a slot is transformed and stored, then refilled at once, so RING elements' loads are in flight per thread all
+      // the time (bytes in flight per CU are what this phase's rate follows); every load is issued unconditionally - clamped address - so
+      // that hipcc's counted vmcnt waits stay exact
+      constexpr int U = 1, RING = SKIP ? 4 : 8;  // eight 16-byte loads in flight per thread
+      struct Stg { u32x4 y[U], sk[SKIP ? U : 1]; unsigned off[U]; int px[U]; bool in[U], own[U]; };
+      auto issue = [&](int e, Stg& T) {
 #pragma unroll
-      for (int u = 0; u < kFwdU; ++u) {
-        const int ee = e + u * kBlock;
-        const unsigned pxa = ((unsigned)ee >> kQs) + ovpix;
-        const unsigned img = NI > 1 ? dPI.div(pxa) : 0u, px = NI > 1 ? pxa - __umul24(img, PI) : pxa;
-        const unsigned prow = dWp.div(px);
-        const int col = (int)(px - __umul24(prow, (unsigned)Wp)) - 1 + cx0, row = i0 + (int)prow;
-        pxs[u] = (int)pxa;
-        own[u] = (row >= o0 && row < own_hi && col >= cx0 && col < cx0 + tw) ? 1 : 0;
-        in[u] = ee < nstage && row >= 0 && row < H && col >= 0 && col < W;
-        off[u] = in[u] ? ((__umul24(__umul24(img, (unsigned)H) + (unsigned)row, (unsigned)W) + (unsigned)col) << cshift) + 8 * q : 0u;
-        yv[u] = in[u] ? ld16nt(ytile + off[u]) : make_uint4(0, 0, 0, 0);
-        if constexpr (SKIP) sk[u] = in[u] ? ld16nt(sktile + off[u]) : make_uint4(0, 0, 0, 0);
-      }
-#pragma unroll
-      for (int u = 0; u < kFwdU; ++u) {
-        const int ee = e + u * kBlock;
-        if (ee >= nstage) break;
-        uint4 a = make_uint4(0, 0, 0, 0);
-        if (in[u]) {
-          f2 v[4];
-          unpack_f2(yv[u], v);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = fma2(sc[k], v[k], sh[k]);
-          if constexpr (SKIP) {
-            f2 s[4];
-            unpack_f2(sk[u], s);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] += s[k];
-          }
-          a = pack_f2(v);
-          a.x = relu_pk(a.x); a.y = relu_pk(a.y); a.z = relu_pk(a.z); a.w = relu_pk(a.w);
-          if (S == 1 && a_out && own[u]) st16(aotile + off[u], a);
+        for (int u = 0; u < U; ++u) {
+          const int ee = e + u * kBlock;
+          const unsigned pxa = ((unsigned)ee >> kQs) + ovpix;
+          const unsigned img = NI > 1 ? dPI.div(pxa) : 0u, px = NI > 1 ? pxa - __umul24(img, PI) : pxa;
+          const unsigned prow = dWp.div(px);
+          const int col = (int)(px - __umul24(prow, (unsigned)Wp)) - 1 + cx0, row = i0 + (int)prow;
+          T.px[u] = (int)pxa;
+          T.own[u] = row >= o0 && row < own_hi && col >= cx0 && col < cx0 + tw;
+          T.in[u] = ee < nstage && row >= 0 && row < H && col >= 0 && col < W;
+          T.off[u] = T.in[u] ? ((__umul24(__umul24(img, (unsigned)H) + (unsigned)row, (unsigned)W) + (unsigned)col) << cshift) + 8 * q : 8u * q;
+          T.y[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ytile + T.off[u]));
+          if constexpr (SKIP) T.sk[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sktile + T.off[u]));
         }
-        lds[(size_t)pxs[u] * KQ + q] = a;
+      };
+      auto finish = [&](int e, const Stg& T) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int ee = e + u * kBlock;
+          if (ee >= nstage) break;
+          uint4 a = make_uint4(0, 0, 0, 0);
+          if (T.in[u]) {
+            f2 v[4];
+            unpack_f2(make_uint4(T.y[u].x, T.y[u].y, T.y[u].z, T.y[u].w), v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fma2(sc[k], v[k], sh[k]);
+            if constexpr (SKIP) {
+              f2 sv[4];
+              unpack_f2(make_uint4(T.sk[u].x, T.sk[u].y, T.sk[u].z, T.sk[u].w), sv);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] += sv[k];
+            }
+            a = pack_f2(v);
+            a.x = relu_pk(a.x); a.y = relu_pk(a.y); a.z = relu_pk(a.z); a.w = relu_pk(a.w);
+            if (S == 1 && a_out && T.own[u]) st16(aotile + T.off[u], a);
+          }
+          lds[(size_t)T.px[u] * KQ + q] = a;
+        }
+      };
+      Stg ring[RING];
+#pragma unroll
+      for (int j = 0; j < RING; ++j) issue(tid + j * kBlock, ring[j]);
+      for (int e = tid; e < nstage; e += RING * kBlock) {
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+          finish(e + j * kBlock, ring[j]);
+          issue(e + (j + RING) * kBlock, ring[j]);
+        }
       }
     }
     __syncthreads();
@@ -297,29 +313,27 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
             const bf16_t* __restrict__ skip_grad, const bf16_t* __restrict__ yprev, const float* __restrict__ bn_prev, const bf16_t* __restrict__ skip_prev,
             const bf16_t* __restrict__ a_in, bf16_t* __restrict__ g_prev, float* __restrict__ part, float* __restrict__ dwgrad, float* __restrict__ dw_partial,
             int B, int H, int W, int C, int Ho, int Wo, int R, int nbands, int nslabs, int stage_pix, int NI, int NCT, int TW) {
-  extern __shared__ uint4 lds[];  // dy[stage_pix][KQ] chunks | wt[9][SL] | red[4][9][SL]
+  extern __shared__ uint4 lds[];  // dy[stage_pix][KQ] chunks | wt[9][SL] | red[4][9][SL] | cst[6][SL]
   constexpr int KQ = SL / 8, kPixSlots = kBlock / KQ, kQs = ilog2(KQ), cshift = ilog2(SL);
   float* wt = reinterpret_cast<float*>(lds + (size_t)stage_pix * KQ);
   float* red = wt + 9 * SL;
+  float* cst = red + 4 * 9 * SL;
   const int tid = threadIdx.x, q = tid & (KQ - 1), slot = tid >> kQs;
   const int slab = blockIdx.x % nslabs, c0 = slab * SL + 8 * q;
   stage_taps<SL>(wt, w, slab * SL);
-  f2 psc[4], psh[4], pmu[4];      // the producer's forward map (mask / recomputed block input) and its mean (second partial sum)
-  f2 ga[4], gb[4], gc[4];         // BatchNorm-backward map of this block's depthwise output: dy = ga*g + gb*y + gc
-  {
-    f2 be[4], gm[4], mu[4];
-    ld8(bn_prev + TTK_BN_SCALE * C + c0, psc);
-    ld8(bn_prev + TTK_BN_MEAN * C + c0, pmu);
-    ld8(bn_prev + TTK_BN_BETA * C + c0, be);
-    ld8(bn_dw + TTK_BN_GA * C + c0, ga);
-    ld8(bn_dw + TTK_BN_GB * C + c0, gb);
-    ld8(bn_dw + TTK_BN_GMEAN * C + c0, gm);
-    ld8(bn_dw + TTK_BN_MEAN * C + c0, mu);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      psh[k] = fma2(-psc[k], pmu[k], be[k]);
-      gc[k] = -ga[k] * gm[k] - gb[k] * mu[k];
-    }
+  // Per-channel constants in LDS, read at the start of the phase that uses them (the two phases never hold both sets in registers):
+  //   [0] psc [1] psh [2] pmu  the producer's forward map a = psc*y + psh (mask / recomputed block input) and its mean (second partial sum)
+  //   [3] ga  [4] gb  [5] gc   BatchNorm-backward map of this block's depthwise output: dy = ga*g + gb*y + gc
+  if (tid < SL) {
+    const int c = slab * SL + tid;
+    const float sc_ = bn_prev[TTK_BN_SCALE * C + c], mu_ = bn_prev[TTK_BN_MEAN * C + c];
+    const float ga_ = bn_dw[TTK_BN_GA * C + c], gb_ = bn_dw[TTK_BN_GB * C + c];
+    cst[0 * SL + tid] = sc_;
+    cst[1 * SL + tid] = fmaf(-sc_, mu_, bn_prev[TTK_BN_BETA * C + c]);
+    cst[2 * SL + tid] = mu_;
+    cst[3 * SL + tid] = ga_;
+    cst[4 * SL + tid] = gb_;
+    cst[5 * SL + tid] = -ga_ * bn_dw[TTK_BN_GMEAN * C + c] - gb_ * bn_dw[TTK_BN_MEAN * C + c];
   }
   f2 s1[4], s2[4], wacc[9][4];
 #pragma unroll
@@ -336,8 +350,10 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
     const int cx0 = ct * TW, tw = NCT > 1 ? min(TW, W - cx0) : W;
     const int Wp = NCT > 1 ? tw + 2 : Wo + 2;
     const int r0 = band * R, r1 = min(r0 + R, H);
-    const int ho_lo = max(0, (r0 - 1 + S - 1) / S * (r0 > 0 ? 1 : 0));
-    const int ho_hi = min(Ho - 1, r1 / S);
+    // staged dy rows ho_lo .. ho_hi: every row a tap of this band can reach, INCLUDING the rows just outside the image (staged as zeros, like
+    // the two padding columns), so that the tap loop below has no bounds checks and its LDS reads can all be issued up front
+    const int ho_lo = S == 1 ? r0 - 1 : r0 / 2;
+    const int ho_hi = r1 / S;
     const int nrows = ho_hi - ho_lo + 1;
     const unsigned PI = (unsigned)(nrows * Wp);
     const TileDiv dPI(PI), dWp((unsigned)Wp), dtw((unsigned)tw);
@@ -350,124 +366,149 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
     const bf16_t* sgtile = skip_grad ? skip_grad + tin : nullptr;
     bf16_t* gptile = g_prev + tin;
     __syncthreads();
-    // ---- stage dy (bf16), zeros outside
+    // ---- stage dy (bf16), zeros outside.  A ring of register slots: a slot is transformed and stored, then refilled at once (every load is
+    // issued unconditionally - clamped address - so that the counted vmcnt waits stay exact).
     const int nstage = nimg * (int)PI * KQ;
-    constexpr int kBwdU = 4;
-    for (int e = tid; e < nstage; e += kBwdU * kBlock) {
-      uint4 gv[kBwdU], yv[kBwdU];
-      bool in[kBwdU];
+    {
+      constexpr int U = 1, RING = 4;  // eight 16-byte loads in flight per thread
+      f2 ga[4], gb[4], gc[4];
+      ld8(cst + 3 * SL + 8 * q, ga);
+      ld8(cst + 4 * SL + 8 * q, gb);
+      ld8(cst + 5 * SL + 8 * q, gc);
+      struct Stg { u32x4 g[U], y[U]; bool in[U]; };
+      auto issue = [&](int e, Stg& T) {
 #pragma unroll
-      for (int u = 0; u < kBwdU; ++u) {
-        const int ee = e + u * kBlock;
-        const unsigned pxa = (unsigned)ee >> kQs;
-        const unsigned img = NI > 1 ? dPI.div(pxa) : 0u, px = NI > 1 ? pxa - __umul24(img, PI) : pxa;
-        const unsigned prow = dWp.div(px);
-        const int col = (int)(px - __umul24(prow, (unsigned)Wp)) - 1 + cx0, row = ho_lo + (int)prow;
-        in[u] = ee < nstage && col >= 0 && col < Wo;
-        const unsigned off = in[u] ? ((__umul24(__umul24(img, (unsigned)Ho) + (unsigned)row, (unsigned)Wo) + (unsigned)col) << cshift) + 8 * q : 0u;
-        gv[u] = in[u] ? ld16nt(gtile + off) : make_uint4(0, 0, 0, 0);
-        yv[u] = in[u] ? ld16nt(ydtile + off) : make_uint4(0, 0, 0, 0);
-      }
-#pragma unroll
-      for (int u = 0; u < kBwdU; ++u) {
-        const int ee = e + u * kBlock;
-        if (ee >= nstage) break;
-        uint4 d = make_uint4(0, 0, 0, 0);
-        if (in[u]) {
-          f2 gg[4], yy[4];
-          unpack_f2(gv[u], gg);
-          unpack_f2(yv[u], yy);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) gg[k] = fma2(ga[k], gg[k], fma2(gb[k], yy[k], gc[k]));
-          d = pack_f2(gg);
+        for (int u = 0; u < U; ++u) {
+          const int ee = e + u * kBlock;
+          const unsigned pxa = (unsigned)ee >> kQs;
+          const unsigned img = NI > 1 ? dPI.div(pxa) : 0u, px = NI > 1 ? pxa - __umul24(img, PI) : pxa;
+          const unsigned prow = dWp.div(px);
+          const int col = (int)(px - __umul24(prow, (unsigned)Wp)) - 1 + cx0, row = ho_lo + (int)prow;
+          T.in[u] = ee < nstage && col >= 0 && col < Wo && row >= 0 && row < Ho;
+          const unsigned off = T.in[u] ? ((__umul24(__umul24(img, (unsigned)Ho) + (unsigned)row, (unsigned)Wo) + (unsigned)col) << cshift) + 8 * q : 8u * q;
+          T.g[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(gtile + off));
+          T.y[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ydtile + off));
         }
-        lds[(size_t)(ee >> kQs) * KQ + q] = d;
+      };
+      auto finish = [&](int e, const Stg& T) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int ee = e + u * kBlock;
+          if (ee >= nstage) break;
+          uint4 d = make_uint4(0, 0, 0, 0);
+          if (T.in[u]) {
+            f2 gg[4], yy[4];
+            unpack_f2(make_uint4(T.g[u].x, T.g[u].y, T.g[u].z, T.g[u].w), gg);
+            unpack_f2(make_uint4(T.y[u].x, T.y[u].y, T.y[u].z, T.y[u].w), yy);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gg[k] = fma2(ga[k], gg[k], fma2(gb[k], yy[k], gc[k]));
+            d = pack_f2(gg);
+          }
+          lds[(size_t)(ee >> kQs) * KQ + q] = d;
+        }
+      };
+      Stg ring[RING];
+#pragma unroll
+      for (int j = 0; j < RING; ++j) issue(tid + j * kBlock, ring[j]);
+      for (int e = tid; e < nstage; e += RING * kBlock) {
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+          finish(e + j * kBlock, ring[j]);
+          issue(e + (j + RING) * kBlock, ring[j]);
+        }
       }
     }
     __syncthreads();
-    const unsigned npix1 = (unsigned)((r1 - r0) * tw);
-    const int npix = nimg * (int)npix1;
-    const TileDiv dnp(npix1);
-    constexpr int NP = LEAN ? 3 : 2;
-    for (int p = slot; p < npix; p += NP * kPixSlots) {
-      bool has[NP];
-      unsigned imgs[NP], offs[NP];
-      int his[NP], wis[NP];
-      uint4 yps[NP], raws[NP], sgs[NP];
-#pragma unroll
-      for (int j = 0; j < NP; ++j) {
-        const int pj = p + j * kPixSlots;
-        has[j] = pj < npix;
-        const unsigned pq = has[j] ? (unsigned)pj : (unsigned)p;
-        imgs[j] = NI > 1 ? dnp.div(pq) : 0u;
-        const unsigned pp = NI > 1 ? pq - __umul24(imgs[j], npix1) : pq;
-        const unsigned pr = dtw.div(pp);
-        his[j] = r0 + (int)pr;
-        wis[j] = cx0 + (int)(pp - __umul24(pr, (unsigned)tw));
-        offs[j] = ((__umul24(__umul24(imgs[j], (unsigned)H) + (unsigned)his[j], (unsigned)W) + (unsigned)wis[j]) << cshift) + 8 * q;
-      }
-#pragma unroll
-      for (int j = 0; j < NP; ++j) yps[j] = ld16nt(yptile + offs[j]);
-#pragma unroll
-      for (int j = 0; j < NP; ++j) {
-        raws[j] = make_uint4(0, 0, 0, 0);
-        sgs[j] = make_uint4(0, 0, 0, 0);
+    // ---- the pixels of the band.  Stride 2: class by class of (row parity, column parity) - a pixel of a class is reached by a fixed set of
+    // 1, 2, 2 or 4 taps, so the lanes of a wave do the same work (enumerated in one loop over all pixels every wave ran all nine tap
+    // bodies under masks: 266 vector instructions per pixel where ~2.25 taps do work).
+    struct Item { u32x4 yp, raw, sg; int pj; };
+    f2 psc[4], psh[4], pmu[4];
+    ld8(cst + 0 * SL + 8 * q, psc);
+    ld8(cst + 1 * SL + 8 * q, psh);
+    ld8(cst + 2 * SL + 8 * q, pmu);
+    auto run = [&](auto phc, auto pwc) {
+      constexpr int PH = decltype(phc)::value, PW = decltype(pwc)::value;  // -1: every pixel (stride 1)
+      const int fr = S == 1 ? r0 : r0 + ((PH - r0) & 1), fc = S == 1 ? cx0 : cx0 + ((PW - cx0) & 1);
+      const int nr = S == 1 ? r1 - r0 : (r1 - fr + 1) / 2, nc = S == 1 ? tw : (cx0 + tw - fc + 1) / 2;
+      if (nr <= 0 || nc <= 0) return;
+      const unsigned npc = (unsigned)(nr * nc);
+      const int npix = nimg * (int)npc;
+      const TileDiv dnp(npc), dnc((unsigned)nc);
+      // item pj of the class -> image of the tile, pixel, element offset (absent items: the class's first pixel, a valid address)
+      auto decode = [&](int pj, unsigned& img, int& hi, int& wi, unsigned& off) {
+        const unsigned pq = pj < npix ? (unsigned)pj : 0u;
+        img = NI > 1 ? dnp.div(pq) : 0u;
+        const unsigned pp = NI > 1 ? pq - __umul24(img, npc) : pq;
+        const unsigned pr = dnc.div(pp);
+        hi = fr + (int)pr * (S == 1 ? 1 : 2);
+        wi = fc + (int)(pp - __umul24(pr, (unsigned)nc)) * (S == 1 ? 1 : 2);
+        off = ((__umul24(__umul24(img, (unsigned)H) + (unsigned)hi, (unsigned)W) + (unsigned)wi) << cshift) + 8 * q;
+      };
+      auto issue = [&](int it, Item& I) {
+        I.pj = slot + it * kPixSlots;
+        unsigned img, off;
+        int hi, wi;
+        decode(I.pj, img, hi, wi, off);
+        I.yp = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(yptile + off));
         if (!LEAN) {
-          if (a_in) raws[j] = ld16nt(aitile + offs[j]);
-          else if (skip_prev) raws[j] = ld16nt(sktile + offs[j]);
-          if (skip_grad) sgs[j] = ld16nt(sgtile + offs[j]);
+          if (a_in) I.raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(aitile + off));
+          else if (skip_prev) I.raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sktile + off));
+          if (skip_grad) I.sg = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sgtile + off));
         }
-      }
-#pragma unroll
-      for (int j = 0; j < NP; ++j) {
-        if (j > 0 && !has[j]) break;
-        const int hi = his[j], wi = wis[j];
-        const uint4* dyimg = lds + (__umul24(imgs[j], PI) << kQs) + q;
+      };
+      auto process = [&](const Item& I) {
+        if (I.pj >= npix) return;
+        unsigned img, off;
+        int hi, wi;
+        decode(I.pj, img, hi, wi, off);
+        const uint4* dyimg = lds + (__umul24(img, PI) << kQs) + q;
         f2 yp[4], a[4];
-        unpack_f2(yps[j], yp);
+        unpack_f2(make_uint4(I.yp.x, I.yp.y, I.yp.z, I.yp.w), yp);
         if (!LEAN && a_in) {
-          unpack_f2(raws[j], a);
+          unpack_f2(make_uint4(I.raw.x, I.raw.y, I.raw.z, I.raw.w), a);
         } else {
 #pragma unroll
           for (int k = 0; k < 4; ++k) a[k] = fma2(psc[k], yp[k], psh[k]);
           if (!LEAN && skip_prev) {
-            f2 s[4];
-            unpack_f2(raws[j], s);
+            f2 sk[4];
+            unpack_f2(make_uint4(I.raw.x, I.raw.y, I.raw.z, I.raw.w), sk);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a[k] += s[k];
+            for (int k = 0; k < 4; ++k) a[k] += sk[k];
           }
           // the block input as the forward kernel formed it: rounded to bf16, then relu
           uint4 ar = pack_f2(a);
           ar.x = relu_pk(ar.x); ar.y = relu_pk(ar.y); ar.z = relu_pk(ar.z); ar.w = relu_pk(ar.w);
           unpack_f2(ar, a);
         }
+        // the taps of this pixel (stride 2: those of its parity class - compile time): all their LDS reads first, then the arithmetic
+        uint4 dv[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            if (S == 2 && (((PH + 1 - kh) & 1) || ((PW + 1 - kw) & 1))) continue;
+            const int ho = (hi + 1 - kh) / S, wo = (wi + 1 - kw) / S;  // (stride 2: both even and >= 0; stride 1: -1 .. H / W: the zero border of the stage)
+            dv[kh * 3 + kw] = dyimg[(__mul24(ho - ho_lo, Wp) + wo - cx0 + 1) << kQs];
+          }
         f2 G[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) G[k] = f2{0.f, 0.f};
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const int th = hi + 1 - kh;
-          if (th < 0 || (S == 2 && (th & 1))) continue;
-          const int ho = th / S;
-          if (ho > Ho - 1) continue;
+        for (int t = 0; t < 9; ++t) {
+          if (S == 2 && (((PH + 1 - t / 3) & 1) || ((PW + 1 - t % 3) & 1))) continue;
+          f2 dy[4], wv[4];
+          unpack_f2(dv[t], dy);
+          ld8(wt + t * SL + 8 * q, wv);
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int twi = wi + 1 - kw;
-            if (S == 2 && (twi & 1)) continue;
-            const int wo = (S == 1) ? twi : (twi >> 1);
-            f2 dy[4], wv[4];
-            unpack_f2(dyimg[(__mul24(ho - ho_lo, Wp) + wo - cx0 + 1) << kQs], dy);
-            ld8(wt + (kh * 3 + kw) * SL + 8 * q, wv);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              G[k] = fma2(dy[k], wv[k], G[k]);
-              wacc[kh * 3 + kw][k] = fma2(dy[k], a[k], wacc[kh * 3 + kw][k]);
-            }
+          for (int k = 0; k < 4; ++k) {
+            G[k] = fma2(dy[k], wv[k], G[k]);
+            wacc[t][k] = fma2(dy[k], a[k], wacc[t][k]);
           }
         }
         if (!LEAN && skip_grad) {
           f2 sg[4];
-          unpack_f2(sgs[j], sg);
+          unpack_f2(make_uint4(I.sg.x, I.sg.y, I.sg.z, I.sg.w), sg);
 #pragma unroll
           for (int k = 0; k < 4; ++k) G[k] += sg[k];
         }
@@ -477,7 +518,7 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
           G[k].y = a[k].y > 0.f ? G[k].y : 0.f;
         }
         const uint4 o = pack_f2(G);
-        st16(gptile + offs[j], o);
+        st16(gptile + off, o);
         f2 gp[4];
         unpack_f2(o, gp);  // sums of what is stored
 #pragma unroll
@@ -485,7 +526,31 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
           s1[k] += gp[k];
           s2[k] = fma2(gp[k], yp[k] - pmu[k], s2[k]);
         }
+      };
+      // a ring of items: one is processed, its slot refilled at once - RING pixels' loads (1 or 3 tensors each) in flight per thread
+      constexpr int RING = LEAN ? 6 : 2;
+      const int nit = (npix + kPixSlots - 1) / kPixSlots;
+      Item ring[RING];
+#pragma unroll
+      for (int j = 0; j < RING; ++j) issue(j, ring[j]);
+      for (int it = 0; it < nit; it += RING) {
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+          process(ring[j]);
+          issue(it + j + RING, ring[j]);
+        }
       }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using IA = std::integral_constant<int, -1>;
+    if constexpr (S == 1) {
+      run(IA{}, IA{});
+    } else {
+      run(I1{}, I1{});
+      run(I1{}, I0{});
+      run(I0{}, I1{});
+      run(I0{}, I0{});
     }
   }
   if (part) slab_partials<SL>(s1, s2, q, C, slab * SL, part + (size_t)(blockIdx.x / nslabs) * 2 * C, red);
@@ -549,9 +614,10 @@ int ttk_bc_dw_fwd(const void* yprev, const float* bn_prev, const void* skip_prev
   const int stage_pix = t.NI * t.stage_rows * ((t.NCT > 1 ? t.TW : W) + 2);
   const size_t sm = (size_t)stage_pix * t.SL * 2 + (size_t)(9 + 8) * t.SL * sizeof(float);
 #define TTK_BC_FWD3(S_, SK_, SL_, CY_)                                                                                                            \
+  allow_big_lds<bc_dw_fwd_k<S_, SK_, SL_, CY_>>();                                                                                                \
   hipLaunchKernelGGL((bc_dw_fwd_k<S_, SK_, SL_, CY_>), dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, (const bf16_t*)yprev, bn_prev,          \
                      (const bf16_t*)skip_prev, (bf16_t*)a_out, w, (bf16_t*)y, part, pivot, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI, t.NCT, t.TW, stage_pix)
-#define TTK_BC_FWD2(S_, SK_, SL_) do { if (t.carry) TTK_BC_FWD3(S_, SK_, SL_, true); else TTK_BC_FWD3(S_, SK_, SL_, false); } while (0)
+#define TTK_BC_FWD2(S_, SK_, SL_) do { if (t.carry) { TTK_BC_FWD3(S_, SK_, SL_, true); } else { TTK_BC_FWD3(S_, SK_, SL_, false); } } while (0)
 #define TTK_BC_FWD1(S_, SK_) do { if (t.SL == 64) TTK_BC_FWD2(S_, SK_, 64); else TTK_BC_FWD2(S_, SK_, 32); } while (0)
   if (stride == 1) { if (skip_prev) TTK_BC_FWD1(1, true); else TTK_BC_FWD1(1, false); }
   else { if (skip_prev) TTK_BC_FWD1(2, true); else TTK_BC_FWD1(2, false); }
@@ -571,7 +637,7 @@ int ttk_bc_dw_bwd_data(const void* g_dw, const void* y_dw, const float* bn_dw, c
   const Tiling t = tiling(B, H, W, C, stride, true);
   TTK_REQUIRE((int64_t)((B + t.NI - 1) / t.NI) * t.nbands * t.NCT < ((int64_t)1 << 31) && (int64_t)B * H * W * t.SL < ((int64_t)1 << 32), "bc_dw_bwd_data: too large for 32-bit indexing");
   const int stage_pix = t.NI * t.stage_rows * ((t.NCT > 1 ? t.TW : Wo) + 2);
-  const size_t sm = (size_t)stage_pix * t.SL * 2 + (size_t)(9 + 4 * 9) * t.SL * sizeof(float);
+  const size_t sm = (size_t)stage_pix * t.SL * 2 + (size_t)(9 + 4 * 9 + 6) * t.SL * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (!dw) dw_partial = nullptr;
   if (dw && !dw_accumulate && !dw_partial) hipMemsetAsync(dw, 0, (size_t)9 * C * sizeof(float), st);

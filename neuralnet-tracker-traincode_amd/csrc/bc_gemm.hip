@@ -340,11 +340,11 @@ __global__ void __launch_bounds__(512) bc_gemm_l_k(const bf16_t* __restrict__ A0
   uint4 rc0[4], rc1[4], rn0[4], rn1[4];
   uint4 w0, w1, w2, w3;  // the next k64 slab of this column tile (256 rows x 128 B, contiguous in the image): 4 chunks per thread
   auto load_act = [&](int kb, uint4(&d0)[4], uint4(&d1)[4]) {
-    const size_t o = (size_t)kb * M * 64 + abase;
+    const size_t o = (size_t)kb * M * 64 + abase;  // (plain loads: the other column tiles of these pixels read the same lines from L2)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      d0[s] = ld16nt(A0 + o + 16 * s);
-      if constexpr (MODE == kDgrad) d1[s] = ld16nt(A1 + o + 16 * s);
+      d0[s] = ld16(A0 + o + 16 * s);
+      if constexpr (MODE == kDgrad) d1[s] = ld16(A1 + o + 16 * s);
     }
   };
 #define TTK_BC_LOAD_W(kb_)                                              \
@@ -357,34 +357,46 @@ __global__ void __launch_bounds__(512) bc_gemm_l_k(const bf16_t* __restrict__ A0
     uint4* dst_ = ring + (slot_) * 2048 + tid;                          \
     dst_[0] = w0; dst_[512] = w1; dst_[1024] = w2; dst_[1536] = w3;     \
   } while (0)
-  TTK_BC_LOAD_W(0);
-  load_act(0, rc0, rc1);
-  TTK_BC_STORE_W(0);
-  if (nkb > 1) TTK_BC_LOAD_W(1);
+  // Two k64 steps per loop iteration with the register sets swapping roles and NO conditional loads: every load is issued unconditionally
+  // (indices clamped to the last slab - the surplus ones are never consumed) so that hipcc's counted vmcnt waits stay exact; with a
+  // branch around the loads and a register copy at the loop end it waited for the loads it had just issued (67 us for the 512 x 512
+  // forward instead of ~35).  nkb is even (K a multiple of 128).
+  const int wrow = r * 8, wsw = (r >> 1) & 7;
   f32x16 acc[8];
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
-  const int wrow = r * 8, wsw = (r >> 1) & 7;
-  __syncthreads();
-  for (int kb = 0; kb < nkb; ++kb) {
-    if (kb + 1 < nkb) load_act(kb + 1, rn0, rn1);
-    const uint4* Ws = ring + (kb & 1) * 2048;
+  auto compute = [&](int slot, int kb, const uint4(&a0)[4], const uint4(&a1)[4]) {
+    const uint4* Ws = ring + slot * 2048;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const bf16x8 fr = make_frag<MODE>(rc0[s], rc1[s], cA, K, kb * 64 + 16 * s + 8 * h);
+      const bf16x8 fr = make_frag<MODE>(a0[s], a1[s], cA, K, kb * 64 + 16 * s + 8 * h);
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb) {
         const uint4 wv = Ws[nb * 256 + wrow + ((2 * s + h) ^ wsw)];
         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv), fr, acc[nb], 0, 0, 0);
       }
     }
-    if (kb + 1 < nkb) TTK_BC_STORE_W((kb + 1) & 1);  // (that slot was last read in step kb - 1: every wave has passed the barrier since)
-    if (kb + 2 < nkb) TTK_BC_LOAD_W(kb + 2);
+  };
+  const int klast = nkb - 1;
+  TTK_BC_LOAD_W(0);
+  TTK_BC_STORE_W(0);
+  load_act(0, rc0, rc1);
+  __builtin_amdgcn_sched_barrier(0);  // (the loop is entered with the loads pending in the order it leaves them: activations, then weights)
+  TTK_BC_LOAD_W(1);
+  __syncthreads();
+  for (int kb = 0; kb < nkb; kb += 2) {
+    load_act(kb + 1, rn0, rn1);
+    compute(0, kb, rc0, rc1);
+    TTK_BC_STORE_W(1);  // slab kb + 1 (that slot was last read a step ago: every wave has passed a barrier since)
+    TTK_BC_LOAD_W(min(kb + 2, klast));
     __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 4; ++s) { rc0[s] = rn0[s]; rc1[s] = rn1[s]; }
+    load_act(min(kb + 2, klast), rc0, rc1);
+    compute(1, kb + 1, rn0, rn1);
+    TTK_BC_STORE_W(0);  // slab kb + 2
+    TTK_BC_LOAD_W(min(kb + 3, klast));
+    __syncthreads();
   }
 #undef TTK_BC_LOAD_W
 #undef TTK_BC_STORE_W
@@ -448,7 +460,7 @@ static bool pw_shape_ok(int Cin, int Cout) {
 }
 // E: N <= 128 and K <= 256; else L needs N % 256 == 0 and K % 64 == 0
 static bool is_e(int K, int N) { return N <= 128 && K <= 256; }
-static bool is_l(int K, int N) { return N % 256 == 0 && K % 64 == 0; }
+static bool is_l(int K, int N) { return N % 256 == 0 && K % 128 == 0; }
 
 struct LPlan { int RT, nrt, ncol, grid; };
 static LPlan l_plan(int64_t M, int N) {

@@ -83,8 +83,8 @@ __global__ void __launch_bounds__(512) bc_wgrad_k(const bf16_t* __restrict__ G, 
       rx[i] = ld16nt(X + xbase + (size_t)m * wi);
     }
   };
-  auto store = [&](int c) {
-    unsigned char* buf = lds + (c & 1) * kBuf;
+  auto store_to = [&](int c, int slot) {
+    unsigned char* buf = lds + slot * kBuf;
     const int64_t mb = m_begin + (int64_t)c * CP;
 #pragma unroll
     for (int i = 0; i < IN; ++i) {
@@ -108,6 +108,7 @@ __global__ void __launch_bounds__(512) bc_wgrad_k(const bf16_t* __restrict__ G, 
       st16(buf + CP * PN + px * PK + ok * 16, pack8(v));
     }
   };
+  auto store = [&](int c) { store_to(c, c & 1); };
 
   // ---- multiply role
   const int wsub = wave / (WN * WK), wq = wave % (WN * WK), wn = wq / WK, wk = wq % WK;
@@ -127,9 +128,12 @@ __global__ void __launch_bounds__(512) bc_wgrad_k(const bf16_t* __restrict__ G, 
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   if (nchunks > 0) {
+    // every load / store of the pipeline is unconditional (chunk indices clamped to the last one; the surplus copies are never read): with
+    // branches around them hipcc's counted vmcnt waits degrade to waiting for the loads just issued
+    const int clast = nchunks - 1;
     load(0);
     store(0);
-    if (nchunks > 1) load(1);
+    load(min(1, clast));
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
       const unsigned char* buf = lds + (c & 1) * kBuf;
@@ -146,8 +150,8 @@ __global__ void __launch_bounds__(512) bc_wgrad_k(const bf16_t* __restrict__ G, 
 #pragma unroll
           for (int j = 0; j < BK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
-      if (c + 1 < nchunks) store(c + 1);  // (the other buffer: last read in step c - 1, every wave has passed the barrier since)
-      if (c + 2 < nchunks) load(c + 2);
+      store_to(min(c + 1, clast), (c + 1) & 1);  // (the other buffer: last read in step c - 1, every wave has passed the barrier since)
+      load(min(c + 2, clast));
       __syncthreads();
     }
   }
