@@ -68,6 +68,44 @@ inline void allow_big_lds() {
   }
 }
 
+// out[i] (+)= partial[0][i] + partial[1][i] + ...  for FEW outputs and MANY rows (the depthwise weight gradient's workgroup rows, the slice
+// partials of the small pointwise layers): 16 float4 columns x 64 row groups per 1024-thread block - a thread adds rows / 64 rows (loads in
+// flight together), the groups are folded by a fixed tree in LDS (bitwise reproducible).  The plain one-thread-per-output folds took
+// 9 - 13 us per launch on these shapes (latency of hundreds of dependent loads), 25 launches per step.
+template <int kDummy = 0>
+__global__ void __launch_bounds__(1024) fold_rows_fast_k(const float* __restrict__ partial, int rows, int64_t n, float* __restrict__ out, int accumulate) {
+  __shared__ float4 sm[64][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int64_t i = ((int64_t)blockIdx.x * 16 + tx) * 4;
+  float4 a = f4(0.f);
+  if (i < n) {
+    int r = ty;
+    for (; r + 3 * 64 < rows; r += 4 * 64) {
+      const float4 v0 = ld4nt(partial + (size_t)r * n + i), v1 = ld4nt(partial + (size_t)(r + 64) * n + i);
+      const float4 v2 = ld4nt(partial + (size_t)(r + 128) * n + i), v3 = ld4nt(partial + (size_t)(r + 192) * n + i);
+      a = add4(add4(add4(add4(a, v0), v1), v2), v3);
+    }
+    for (; r < rows; r += 64) a = add4(a, ld4nt(partial + (size_t)r * n + i));
+  }
+  sm[ty][tx] = a;
+  __syncthreads();
+#pragma unroll
+  for (int step = 32; step >= 1; step >>= 1) {
+    if (ty < step) sm[ty][tx] = add4(sm[ty][tx], sm[ty + step][tx]);
+    __syncthreads();
+  }
+  if (ty == 0 && i < n) {
+    float4 t = sm[0][tx];
+    if (accumulate) t = add4(t, ld4(out + i));
+    st4(out + i, t);
+  }
+}
+inline bool launch_fold_rows_fast(const float* partial, int rows, int64_t n, float* out, int accumulate, hipStream_t st) {
+  if (n % 4 != 0 || n > 65536 || rows < 16) return false;
+  hipLaunchKernelGGL(fold_rows_fast_k<0>, dim3((unsigned)((n / 4 + 15) / 16)), dim3(1024), 0, st, partial, rows, n, out, accumulate);
+  return true;
+}
+
 // Weight image of a pointwise layer for the GEMM kernels (ttk_bc_prepare_weights): for the product out[n] = sum_k in[k] * Wimg(n, k)
 // rows n of min(K, 64) bf16 (one k64 block, 128 B; K = 32: 64 B) in [K / 64][N][row]; the 16-byte chunks of a row are stored XOR-swizzled
 // so that the MFMA operand reads (32 rows x one chunk per ds_read_b128) are bank-conflict free in LDS:

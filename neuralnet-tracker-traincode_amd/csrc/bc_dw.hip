@@ -11,6 +11,14 @@
 
 #include "bc_common.h"
 
+// Timing-only bits of the backward kernel (experiment builds: tools/exp/build_variants.sh ... "-DTTK_BC_DBG=<bits>"; wrong results):
+//   1 no tap arithmetic (G and the weight-gradient accumulators)   2 no tap LDS reads   4 no store of g_prev
+//   8 no statistics                                                 16 no second-phase global loads
+//   32 no second phase at all                                       64 no staging phase (loads, BatchNorm-backward map, LDS stores)
+#ifndef TTK_BC_DBG
+#define TTK_BC_DBG 0
+#endif
+
 namespace ttk {
 namespace bc {
 
@@ -408,13 +416,15 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
         }
       };
       Stg ring[RING];
+      if (!(TTK_BC_DBG & 64)) {
 #pragma unroll
-      for (int j = 0; j < RING; ++j) issue(tid + j * kBlock, ring[j]);
-      for (int e = tid; e < nstage; e += RING * kBlock) {
+        for (int j = 0; j < RING; ++j) issue(tid + j * kBlock, ring[j]);
+        for (int e = tid; e < nstage; e += RING * kBlock) {
 #pragma unroll
-        for (int j = 0; j < RING; ++j) {
-          finish(e + j * kBlock, ring[j]);
-          issue(e + (j + RING) * kBlock, ring[j]);
+          for (int j = 0; j < RING; ++j) {
+            finish(e + j * kBlock, ring[j]);
+            issue(e + (j + RING) * kBlock, ring[j]);
+          }
         }
       }
     }
@@ -450,6 +460,7 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
         unsigned img, off;
         int hi, wi;
         decode(I.pj, img, hi, wi, off);
+        if (TTK_BC_DBG & 16) { I.yp = u32x4{(unsigned)off, 1u, 2u, 3u}; I.raw = I.yp; I.sg = I.yp; return; }
         I.yp = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(yptile + off));
         if (!LEAN) {
           if (a_in) I.raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(aitile + off));
@@ -489,7 +500,7 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
           for (int kw = 0; kw < 3; ++kw) {
             if (S == 2 && (((PH + 1 - kh) & 1) || ((PW + 1 - kw) & 1))) continue;
             const int ho = (hi + 1 - kh) / S, wo = (wi + 1 - kw) / S;  // (stride 2: both even and >= 0; stride 1: -1 .. H / W: the zero border of the stage)
-            dv[kh * 3 + kw] = dyimg[(__mul24(ho - ho_lo, Wp) + wo - cx0 + 1) << kQs];
+            dv[kh * 3 + kw] = (TTK_BC_DBG & 2) ? make_uint4(hi, wi, kh, kw) : dyimg[(__mul24(ho - ho_lo, Wp) + wo - cx0 + 1) << kQs];
           }
         f2 G[4];
 #pragma unroll
@@ -497,6 +508,7 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
           if (S == 2 && (((PH + 1 - t / 3) & 1) || ((PW + 1 - t % 3) & 1))) continue;
+          if (TTK_BC_DBG & 1) { G[0].x += __uint_as_float(dv[t].x ^ dv[t].y ^ dv[t].z ^ dv[t].w); continue; }
           f2 dy[4], wv[4];
           unpack_f2(dv[t], dy);
           ld8(wt + t * SL + 8 * q, wv);
@@ -518,9 +530,11 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
           G[k].y = a[k].y > 0.f ? G[k].y : 0.f;
         }
         const uint4 o = pack_f2(G);
-        st16(gptile + off, o);
+        if (!(TTK_BC_DBG & 4)) st16(gptile + off, o);
+        else if (o.x == 0x12345u) st16(gptile + off, o);
         f2 gp[4];
         unpack_f2(o, gp);  // sums of what is stored
+        if (TTK_BC_DBG & 8) { s1[0] += gp[0] + gp[1] + gp[2] + gp[3]; return; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           s1[k] += gp[k];
@@ -544,6 +558,7 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using IA = std::integral_constant<int, -1>;
+    if (TTK_BC_DBG & 32) continue;
     if constexpr (S == 1) {
       run(IA{}, IA{});
     } else {
@@ -640,7 +655,7 @@ int ttk_bc_dw_bwd_data(const void* g_dw, const void* y_dw, const float* bn_dw, c
   const size_t sm = (size_t)stage_pix * t.SL * 2 + (size_t)(9 + 4 * 9 + 6) * t.SL * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (!dw) dw_partial = nullptr;
-  if (dw && !dw_accumulate && !dw_partial) hipMemsetAsync(dw, 0, (size_t)9 * C * sizeof(float), st);
+  if (dw && !dw_accumulate && !dw_partial) (void)hipMemsetAsync(dw, 0, (size_t)9 * C * sizeof(float), st);
 #define TTK_BC_BWD3(S_, SL_, LEAN_)                                                                                                               \
   do {                                                                                                                                            \
     allow_big_lds<bc_dw_bwd_k<S_, SL_, LEAN_>>();                                                                                                \
@@ -655,7 +670,7 @@ int ttk_bc_dw_bwd_data(const void* g_dw, const void* y_dw, const float* bn_dw, c
 #undef TTK_BC_BWD1
 #undef TTK_BC_BWD2
 #undef TTK_BC_BWD3
-  if (dw_partial) launch_fold_partials(dw_partial, t.rows, (int64_t)9 * C, dw, dw_accumulate, st);
+  if (dw_partial && !launch_fold_rows_fast(dw_partial, t.rows, (int64_t)9 * C, dw, dw_accumulate, st)) launch_fold_partials(dw_partial, t.rows, (int64_t)9 * C, dw, dw_accumulate, st);
   TTK_LAUNCH_CHECK("bc_dw_bwd_data");
 }
 

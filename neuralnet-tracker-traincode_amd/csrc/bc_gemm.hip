@@ -18,6 +18,12 @@
 //                two-slot LDS ring (plain loads one step ahead + ds_write), one barrier per step.
 #include "bc_common.h"
 
+// Timing-only bits of bc_gemm_l_k's main loop (experiment builds: tools/exp/build_variants.sh ... "-DTTK_BC_GDBG=<bits>"; wrong results):
+//   1 no MFMAs   2 no global loads   4 no operand staging (BatchNorm map + LDS stores)   8 no fragment reads
+#ifndef TTK_BC_GDBG
+#define TTK_BC_GDBG 0
+#endif
+
 namespace ttk {
 namespace bc {
 
@@ -309,7 +315,16 @@ __global__ void __launch_bounds__(512) bc_gemm_e_k(const bf16_t* __restrict__ A0
 }
 
 // ---------------------------------------------------------------------------------------------
-// streamed-weight kernel: tiles of RT <= 256 pixels x 256 output channels; K, N multiples of 64 / 256
+// streamed-operand kernel: tiles of RT <= 256 pixels x 256 output channels; K a multiple of 128, N of 256.
+//
+// Both operands of a k64 step go through LDS: the weight slab of the column tile (256 rows x 128 B, copied as it lies in the image) and
+// the TRANSFORMED activation tile (256 pixels x 64 channels bf16).  Every thread stages four FIXED 16-byte chunk columns of the
+// activations (chunk = its 8 channels: the BatchNorm constants of a step are two or three LDS reads per thread, not per fragment) from
+// whole 128-byte lines, one step ahead in registers.  The eight waves form 2 (channel halves) x 4 (pixel quarters): a wave multiplies
+// 128 channels x 64 pixels = 4 x 2 blocks, so a k16 sub-step is 4 weight + 2 activation fragment reads for 8 MFMAs (the first form -
+// fragments loaded straight from global memory, 256 channels x 32 pixels per wave - read 8 + 4 constants' worth per 8 MFMAs and held the
+// LDS pipe at 75 %: 55 us for the 512 x 512 forward).  Two steps per loop iteration with the register sets swapping roles, every load
+// unconditional (clamped indices): hipcc's counted vmcnt waits stay exact.
 // ---------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ void __launch_bounds__(512) bc_gemm_l_k(const bf16_t* __restrict__ A0, const bf16_t* __restrict__ A1, const float* __restrict__ bnA,
@@ -317,11 +332,12 @@ __global__ void __launch_bounds__(512) bc_gemm_l_k(const bf16_t* __restrict__ A0
                                                     const float* __restrict__ bnE, const float* __restrict__ pivot, float* __restrict__ part, int64_t M,
                                                     int K, int N, int RT, int nrt, int ncol) {
   extern __shared__ uint4 lds[];
-  uint4* ring = lds;                                            // [2][256 rows x 8 chunks]
-  uint4* stg = lds + 2 * 2048;                                  // 8 waves x 256 chunks
-  float* cE = reinterpret_cast<float*>(stg + 8 * 256);          // [3][256]
+  uint4* wring = lds;                                           // [2][256 rows x 8 chunks]
+  uint4* aring = lds + 2 * 2048;                                // [2][256 pixels x 8 chunks]; after the loop: 8 waves x 256 chunks of store tiles
+  float* cE = reinterpret_cast<float*>(lds + 4 * 2048);         // [3][256]
   float* cA = cE + 3 * 256;                                     // [3][K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int wc = wave & 1, wp = wave >> 1;
   // blocks b and b + 8 share an XCD (round-robin dispatch): the column tiles of one row tile sit there together, the second one finds
   // the activation rows in that XCD's L2
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
@@ -331,122 +347,130 @@ __global__ void __launch_bounds__(512) bc_gemm_l_k(const bf16_t* __restrict__ A0
   const int64_t p0 = (int64_t)rt * RT, pend = (p0 + RT < M) ? p0 + RT : M;
   fill_cA<MODE>(cA, bnA, K, tid, 512);
   fill_cE<MODE>(cE, pivot, bnE, N, n0, 256, tid, 512);
-  const int nkb = K / 64;
-  // this wave's pixels p0 + 32 wave + r
-  int64_t pix = p0 + 32 * wave + r;
-  pix = pix < pend ? pix : pend - 1;
-  const bool wave_live = p0 + 32 * wave < pend;
-  const size_t abase = (size_t)pix * 64 + 8 * h;
-  uint4 rc0[4], rc1[4], rn0[4], rn1[4];
-  uint4 w0, w1, w2, w3;  // the next k64 slab of this column tile (256 rows x 128 B, contiguous in the image): 4 chunks per thread
-  auto load_act = [&](int kb, uint4(&d0)[4], uint4(&d1)[4]) {
-    const size_t o = (size_t)kb * M * 64 + abase;  // (plain loads: the other column tiles of these pixels read the same lines from L2)
+  const int nkb = K / 64, klast = nkb - 1;
+  // staging role: chunk column `oct` (channels 8 oct .. + 7 of the k64 block) of pixels (tid >> 3) + 64 i
+  const int oct = tid & 7;
+  size_t soff[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      d0[s] = ld16(A0 + o + 16 * s);
-      if constexpr (MODE == kDgrad) d1[s] = ld16(A1 + o + 16 * s);
-    }
+  for (int i = 0; i < 4; ++i) {
+    int64_t px = p0 + (tid >> 3) + 64 * i;
+    px = px < pend ? px : pend - 1;
+    soff[i] = (size_t)px * 64 + 8 * oct;
+  }
+  // Register chunks of the NEXT step's operands: chunk i (activation pixels (tid >> 3) + 64 i, weight chunk tid + 512 i) is transformed and
+  // stored behind the MFMAs of sub-step i of the current step, and reloaded at once for the step after next - a ring of four slots per
+  // operand, every load unconditional (clamped to the last slab: the surplus copies are never read).
+  u32x4 rx0[4], rx1[4], wr[4];  // (ext-vector registers: arrays of the HIP struct type captured by the lambdas went to scratch)
+  const u32x4* Wv = reinterpret_cast<const u32x4*>(Wimg);
+  auto load_chunk = [&](int kb, int i) {
+    const size_t o = (size_t)kb * M * 64 + soff[i];  // (plain loads: the other column tiles of these pixels read the same lines from L2)
+    rx0[i] = *reinterpret_cast<const u32x4*>(A0 + o);
+    if constexpr (MODE == kDgrad) rx1[i] = *reinterpret_cast<const u32x4*>(A1 + o);
+    wr[i] = Wv[((size_t)kb * N + n0) * 8 + tid + 512 * i];
   };
-#define TTK_BC_LOAD_W(kb_)                                              \
-  do {                                                                  \
-    const uint4* src_ = Wimg + ((size_t)(kb_) * N + n0) * 8 + tid;      \
-    w0 = src_[0]; w1 = src_[512]; w2 = src_[1024]; w3 = src_[1536];     \
-  } while (0)
-#define TTK_BC_STORE_W(slot_)                                           \
-  do {                                                                  \
-    uint4* dst_ = ring + (slot_) * 2048 + tid;                          \
-    dst_[0] = w0; dst_[512] = w1; dst_[1024] = w2; dst_[1536] = w3;     \
-  } while (0)
-  // Two k64 steps per loop iteration with the register sets swapping roles and NO conditional loads: every load is issued unconditionally
-  // (indices clamped to the last slab - the surplus ones are never consumed) so that hipcc's counted vmcnt waits stay exact; with a
-  // branch around the loads and a register copy at the loop end it waited for the loads it had just issued (67 us for the 512 x 512
-  // forward instead of ~35).  nkb is even (K a multiple of 128).
-  const int wrow = r * 8, wsw = (r >> 1) & 7;
-  f32x16 acc[8];
-#pragma unroll
-  for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
-  auto compute = [&](int slot, int kb, const uint4(&a0)[4], const uint4(&a1)[4]) {
-    const uint4* Ws = ring + slot * 2048;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bf16x8 fr = make_frag<MODE>(a0[s], a1[s], cA, K, kb * 64 + 16 * s + 8 * h);
-#pragma unroll
-      for (int nb = 0; nb < 8; ++nb) {
-        const uint4 wv = Ws[nb * 256 + wrow + ((2 * s + h) ^ wsw)];
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv), fr, acc[nb], 0, 0, 0);
-      }
-    }
+  auto store_chunk = [&](int slot, int kb, int i) {
+    const int px = (tid >> 3) + 64 * i;
+    const bf16x8 fr = make_frag<MODE>(make_uint4(rx0[i].x, rx0[i].y, rx0[i].z, rx0[i].w), make_uint4(rx1[i].x, rx1[i].y, rx1[i].z, rx1[i].w), cA, K, kb * 64 + 8 * oct);
+    aring[slot * 2048 + px * 8 + (oct ^ (px & 7))] = __builtin_bit_cast(uint4, fr);
+    reinterpret_cast<u32x4*>(wring)[slot * 2048 + tid + 512 * i] = wr[i];
   };
-  const int klast = nkb - 1;
-  TTK_BC_LOAD_W(0);
-  TTK_BC_STORE_W(0);
-  load_act(0, rc0, rc1);
-  __builtin_amdgcn_sched_barrier(0);  // (the loop is entered with the loads pending in the order it leaves them: activations, then weights)
-  TTK_BC_LOAD_W(1);
+  const int wrow = (128 * wc + r) * 8, wsw = (r >> 1) & 7;
+  const int arow = (64 * wp + r) * 8, asw = r & 7;
+  f32x16 acc[2][4];  // [pixel group][channel block]
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.f;
+  __syncthreads();  // constants are in LDS
+#pragma unroll
+  for (int i = 0; i < 4; ++i) load_chunk(0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) store_chunk(0, 0, i);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) load_chunk(1, i);  // (the loop is entered with the loads pending in the order it leaves them)
   __syncthreads();
-  for (int kb = 0; kb < nkb; kb += 2) {
-    load_act(kb + 1, rn0, rn1);
-    compute(0, kb, rc0, rc1);
-    TTK_BC_STORE_W(1);  // slab kb + 1 (that slot was last read a step ago: every wave has passed a barrier since)
-    TTK_BC_LOAD_W(min(kb + 2, klast));
-    __syncthreads();
-    load_act(min(kb + 2, klast), rc0, rc1);
-    compute(1, kb + 1, rn0, rn1);
-    TTK_BC_STORE_W(0);  // slab kb + 2
-    TTK_BC_LOAD_W(min(kb + 3, klast));
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int slot = kb & 1;
+    const uint4* Ws = wring + slot * 2048;
+    const uint4* As = aring + slot * 2048;
+    const int knext = min(kb + 1, klast), knn = min(kb + 2, klast);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      uint4 av[2], wv[4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) av[j] = (TTK_BC_GDBG & 8) ? make_uint4(kb, s4, j, lane) : As[arow + 256 * j + ((2 * s4 + h) ^ asw)];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) wv[nb] = (TTK_BC_GDBG & 8) ? make_uint4(kb, s4, nb, lane) : Ws[wrow + 256 * nb + ((2 * s4 + h) ^ wsw)];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (TTK_BC_GDBG & 1) { acc[j][nb][0] += __uint_as_float(wv[nb].x ^ av[j].y ^ wv[nb].z ^ av[j].w); continue; }
+          acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv[nb]), __builtin_bit_cast(bf16x8, av[j]), acc[j][nb], 0, 0, 0);
+        }
+      // behind them (the matrix pipe leaves three quarters of the issue slots to vector instructions): chunk s4 of the next step into the
+      // other slot (last read a step ago: every wave has passed a barrier since), and its registers refilled for the step after
+      if (!(TTK_BC_GDBG & 4)) store_chunk(slot ^ 1, knext, s4);
+      else acc[0][0][1] += __uint_as_float(rx0[s4].x ^ wr[s4].y);
+      if (!(TTK_BC_GDBG & 2)) load_chunk(knn, s4);
+    }
     __syncthreads();
   }
-#undef TTK_BC_LOAD_W
-#undef TTK_BC_STORE_W
-  // ---- epilogue: four 64-channel blocks through the wave's LDS tile
-  uint4* mystg = stg + wave * 256;
-  float* red = reinterpret_cast<float*>(ring);  // [8 waves][4 blocks][2][64] (the ring is free: barrier above)
-  const int64_t wp0 = p0 + 32 * wave;
-  const int oct = lane & 7;
+  // ---- epilogue: the wave's 2 channel blocks of 64 x 2 pixel groups of 32 through its LDS tile (the activation ring is free: barrier above)
+  uint4* mystg = aring + wave * 256;
+  float* red = reinterpret_cast<float*>(wring);  // [8 waves][2 blocks][2][64]
+  const int o8 = lane & 7;
   uint4 mk[2][4];
-  auto load_mask = [&](int cb, uint4(&d)[4]) {
+  auto load_mask = [&](int q4, uint4(&d)[4]) {  // q4 = 2 * (local channel block) + pixel group
     if constexpr (MODE == kDgrad) {
+      const int cb = n0 / 64 + 2 * wc + (q4 >> 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        int64_t p = wp0 + 8 * i + (lane >> 3);
+        int64_t p = p0 + 64 * wp + 32 * (q4 & 1) + 8 * i + (lane >> 3);
         p = p < pend ? p : pend - 1;
-        d[i] = ld16nt(maskY + ((size_t)(n0 / 64 + cb) * M + p) * 64 + 8 * oct);
+        d[i] = ld16nt(maskY + ((size_t)cb * M + p) * 64 + 8 * o8);
       }
     }
   };
-  if (wave_live) load_mask(0, mk[0]);
+  load_mask(0, mk[0]);
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb) {
+  for (int cbl = 0; cbl < 2; ++cbl) {
     float s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
-    if (wave_live) {
-      if (cb + 1 < 4) load_mask(cb + 1, mk[(cb + 1) & 1]);
-      store_block<MODE, 64>(acc + 2 * cb, mystg, out + ((size_t)(n0 / 64 + cb) * M + wp0) * 64, mk[cb & 1], cE + 64 * cb, 256, wp0, pend, s1, s2);
+    const int cb = n0 / 64 + 2 * wc + cbl;
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int off = 8; off < 64; off <<= 1) {
-          s1[j] += __shfl_xor(s1[j], off);
-          s2[j] += __shfl_xor(s2[j], off);
-        }
+    for (int j = 0; j < 2; ++j) {
+      const int q4 = 2 * cbl + j;
+      if (q4 + 1 < 4) load_mask(q4 + 1, mk[(q4 + 1) & 1]);
+      const int64_t g0 = p0 + 64 * wp + 32 * j;
+      if (g0 < pend)
+        store_block<MODE, 64>(acc[j] + 2 * cbl, mystg, out + ((size_t)cb * M + g0) * 64, mk[q4 & 1], cE + 64 * (2 * wc + cbl), 256, g0, pend, s1, s2);
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int off = 8; off < 64; off <<= 1) {
+        s1[j] += __shfl_xor(s1[j], off);
+        s2[j] += __shfl_xor(s2[j], off);
+      }
     if (lane < 8) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        red[((wave * 4 + cb) * 2 + 0) * 64 + 8 * lane + j] = s1[j];
-        red[((wave * 4 + cb) * 2 + 1) * 64 + 8 * lane + j] = s2[j];
+        red[((wave * 2 + cbl) * 2 + 0) * 64 + 8 * lane + j] = s1[j];
+        red[((wave * 2 + cbl) * 2 + 1) * 64 + 8 * lane + j] = s2[j];
       }
     }
   }
   __syncthreads();
-  if (part) {  // tid = which * 256 + column of the tile
-    const int which = tid >> 8, c = tid & 255, cb = c >> 6, cc = c & 63;
+  if (part) {  // tid = which * 256 + column of the tile; column c: channel half c >> 7, local block (c >> 6) & 1
+    const int which = tid >> 8, c = tid & 255, cwc = c >> 7, cbl = (c >> 6) & 1, cc = c & 63;
     float a = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) a += red[((w * 4 + cb) * 2 + which) * 64 + cc];
+    for (int q = 0; q < 4; ++q) a += red[(((2 * q + cwc) * 2 + cbl) * 2 + which) * 64 + cc];
     part[((size_t)rt * 2 + which) * N + n0 + c] = a;
   }
 }
@@ -489,7 +513,7 @@ static size_t e_lds_bytes(int K, int N) {
   const size_t stg = (size_t)8 * 4 * OC * 16, red = (size_t)8 * 2 * N * 4;
   return (size_t)N * K * 2 + (size_t)3 * K * 4 + (size_t)3 * N * 4 + (stg > red ? stg : red);
 }
-static size_t l_lds_bytes(int K) { return (size_t)2 * 2048 * 16 + (size_t)8 * 256 * 16 + (size_t)3 * 256 * 4 + (size_t)3 * K * 4; }
+static size_t l_lds_bytes(int K) { return (size_t)4 * 2048 * 16 + (size_t)3 * 256 * 4 + (size_t)3 * K * 4; }
 
 template <int MODE>
 static int launch_gemm(const bf16_t* A0, const bf16_t* A1, const float* bnA, const uint4* Wimg, bf16_t* out, const bf16_t* maskY, const float* bnE,

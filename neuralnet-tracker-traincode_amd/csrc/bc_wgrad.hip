@@ -271,7 +271,8 @@ int ttk_bc_pw_bwd_weight(const void* g, const void* y, const float* bn_pw, const
   else TTK_BC_WG(8, 8, 32, 4, 2, 1);
 #undef TTK_BC_WG
   const int64_t n = (int64_t)Cin * Cout;
-  hipLaunchKernelGGL(bc_wgrad_fold_k, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, st, scratch, dw, n, (int)p.slices);
+  if (!launch_fold_rows_fast(scratch, (int)p.slices, n, dw, 1, st))
+    hipLaunchKernelGGL(bc_wgrad_fold_k, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, st, scratch, dw, n, (int)p.slices);
   TTK_LAUNCH_CHECK("bc_pw_bwd_weight");
 }
 

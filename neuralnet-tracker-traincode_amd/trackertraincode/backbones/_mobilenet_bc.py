@@ -154,12 +154,15 @@ def backward_impl(MB, ctx, gfeat, params):
     # scratch of the pointwise weight gradients (slice partials, folded in a fixed order) and - deterministic mode - of the depthwise / stem ones
     need = max(L.cdll.ttk_bc_pw_wgrad_scratch_bytes(B * d[2] * d[3], d[4], d[5]) for d in ctx.dims)
     det = MB._DETERMINISTIC
+    # the fused depthwise weight gradient ALWAYS goes through workgroup rows + a fixed-order fold (float atomics of hundreds of workgroups on
+    # the same 9 x 64 addresses serialise at the memory side: 15 - 110 us per launch measured on an otherwise empty kernel)
+    need = max(need, max(rows_dw(B, d[0], d[1], d[4], d[6], 1) * 9 * d[4] * 4 for d in ctx.dims))
+    need = max([need] + [rows_dw(B, d[2], d[3], d[4], 1, 1) * 9 * d[4] * 4 for d, bl in zip(ctx.dims, ctx.blur) if bl is not None])
     if det:
         need = max(need, L.cdll.ttk_stem_wgrad_partial_bytes())
-        need = max(need, max(rows_dw(B, d[0], d[1], d[4], d[6], 1) * 9 * d[4] * 4 for d in ctx.dims))
-        need = max([need] + [rows_dw(B, d[2], d[3], d[4], 1, 1) * 9 * d[4] * 4 for d, bl in zip(ctx.dims, ctx.blur) if bl is not None])
     scratch = torch.empty(need // 4, dtype=torch.float32, device=gfeat.device)
-    dw_scratch = p(scratch) if det else None
+    dw_scratch = p(scratch)
+    stem_scratch = p(scratch) if det else None
 
     g = torch.empty(last.y.shape, dtype=_DT, device=last.y.device)
     L.call("ttk_avgpool_bwd", p(gfeat), p(last.y), p(last.bn), p(last.skip), p(g), p(part), B, ctx.HW, C, _BF_CB64)
@@ -197,7 +200,7 @@ def backward_impl(MB, ctx, gfeat, params):
             announce(pi, pi + 6)
     st0 = ctx.stages[0]
     _, _, H, W = ctx.x.shape
-    L.call("ttk_stem_bwd_weight", p(g), p(st0.y), p(st0.bn), p(ctx.x), p(grads[0]), 1, dw_scratch, B, H, W, _BF)
+    L.call("ttk_stem_bwd_weight", p(g), p(st0.y), p(st0.bn), p(ctx.x), p(grads[0]), 1, stem_scratch, B, H, W, _BF)
     if MB.grad_ready_hook is not None:
         announce(0, 3)
     return grads

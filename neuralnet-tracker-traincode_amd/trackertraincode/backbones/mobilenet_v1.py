@@ -299,6 +299,7 @@ _USE_WGRAD_STREAM = False
 # by a second kernel instead of fp32 atomics): two runs of a step give bitwise equal gradients.
 _DETERMINISTIC = os.environ.get("TTK_DETERMINISTIC", "0") != "0"
 _FUSED_PW_BWD = True
+_DW_WGRAD_ROWS = False  # True (tools; always in deterministic mode): rows + fold instead of float atomics - no gain measured on the fp32 kernels (round 5: 68.0k either way)
 _SIDE_STREAMS: dict = {}
 
 
@@ -353,6 +354,13 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
     pw_scratch = wg_scratch if (wg_scratch is not None and wg_scratch.numel() * 4 >= pw_need) else (
         torch.empty(pw_need // 4, dtype=torch.float32, device=gfeat.device) if pw_need else None)
     keep = []
+    # The fused depthwise weight gradient of the fp32 kernels adds float atomics (deterministic mode: workgroup rows + a fixed-order fold).
+    # Rows + fold in every mode were measured in round 5 (the bf16-compute kernels gain from them: _mobilenet_bc.py): no change here.
+    dw_rows = wg_scratch
+    if dw_rows is None and _DW_WGRAD_ROWS:
+        need = max(L.partial_rows_dwconv(B, d[0], d[1], d[4], d[6], True) * 9 * d[4] for d in ctx.dims)
+        need = max([need] + [L.partial_rows_dwconv(B, d[2], d[3], d[4], 1, True) * 9 * d[4] for d, bl in zip(ctx.dims, ctx.blur) if bl is not None])
+        dw_rows = torch.empty(need, dtype=torch.float32, device=gfeat.device)
 
     g = torch.empty(last.y.shape, dtype=ctx.gdt, device=last.y.device)
     L.call("ttk_avgpool_bwd", p(gfeat), p(last.y), p(last.bn), p(last.skip), p(g), p(part), B, ctx.HW, C, bf)
@@ -405,13 +413,13 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
             st_t, w_blur = ctx.blur[k]
             g_t = torch.empty(st_t.y.shape, dtype=ctx.gdt, device=st_t.y.device)
             L.call("ttk_dwconv3x3_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), None, p(st_t.y), p(st_t.bn), None, None, p(g_t),
-                   p(part), p(dWd), 1, p(wg_scratch), B, ho, wo, cin, 1, bf)
+                   p(part), p(dWd), 1, p(dw_rows), B, ho, wo, cin, 1, bf)
             L.call("ttk_bn_bwd_frozen", p(st_t.bn), cin)
             L.call("ttk_dwconv3x3_bwd_data", p(g_t), p(st_t.y), p(st_t.bn), p(w_blur), None, p(st_prev.y), p(st_prev.bn), p(st_prev.skip),
                    None, p(g_prev), p(part), None, 0, None, B, h, w_, cin, stride, bf)
         else:
             L.call("ttk_dwconv3x3_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), p(g) if has_skip else None, p(st_prev.y),
-                   p(st_prev.bn), p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 1, p(wg_scratch), B, h, w_, cin, stride, bf)
+                   p(st_prev.bn), p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 1, p(dw_rows), B, h, w_, cin, stride, bf)
         bwd_finalize(st_prev, L.partial_rows_dwconv(B, h, w_, cin, stride, True), B * h * w_, pi - 2 if k > 0 else 1)
         g = g_prev
         if grad_ready_hook is not None:  # this block's conv + bn_dw gradients and its own bn_sep gradients are final
