@@ -49,7 +49,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 22
+#define TTK_ABI_VERSION 23
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -287,6 +287,12 @@ int ttk_bc_pw_bwd_data(const void* g, const void* y, const float* bn_pw, const v
 size_t ttk_bc_pw_wgrad_scratch_bytes(int64_t M, int Cin, int Cout);
 int ttk_bc_pw_bwd_weight(const void* g, const void* y, const float* bn_pw, const void* ydw, const float* bn_dw, float* dw,
                          float* scratch, int64_t M, int Cin, int Cout, ttk_stream_t stream);
+/* AdaptiveAvgPool2d(1) over the last block's output and its backward (as ttk_avgpool_fwd / _bwd) on the 64-channel-block bf16 tensors;
+ * the backward writes ttk_bc_partial_rows_pool(B, HW, C) partial rows. */
+int ttk_bc_partial_rows_pool(int B, int HW, int C);
+int ttk_bc_avgpool_fwd(const void* y, const float* bn, const void* skip, float* feat, int B, int HW, int C, ttk_stream_t stream);
+int ttk_bc_avgpool_bwd(const float* gfeat, const void* y, const float* bn, const void* skip, void* g, float* part, int B, int HW, int C,
+                       ttk_stream_t stream);
 int ttk_bc_dw_fwd(const void* yprev, const float* bn_prev, const void* skip_prev, void* a_out, const float* w, void* y, float* part,
                   const float* pivot, int B, int H, int W, int C, int stride, ttk_stream_t stream);
 int ttk_bc_dw_bwd_data(const void* g_dw, const void* y_dw, const float* bn_dw, const float* w, const void* skip_grad,

@@ -19,7 +19,6 @@ import torch
 from .. import _hip
 
 _BF = 3          # TTK_STORE_ACT_BF16 | TTK_STORE_GRAD_BF16 (stem: C = 32, the same bytes in either block size)
-_BF_CB64 = 3 | 8  # ... | TTK_LAYOUT_CB64 (average pool over the last block's 1024 channels)
 _DT = torch.bfloat16
 
 
@@ -35,7 +34,7 @@ def part_buffer(B, H, W, device, blocks, blur=False):
         if blur and stride == 2:
             need = max(need, rows_dw(B, ho, ho, cin, 1, 0) * 2 * cin, rows_dw(B, ho, ho, cin, 1, 1) * 2 * cin)
         need = max(need, rows_pw(B * ho * ho, cin, cout) * 2 * cout, rows_pw(B * ho * ho, cout, cin) * 2 * cin)
-        need = max(need, L.partial_rows_elementwise(B * ho * ho * (cout // 4)) * 2 * cout)
+        need = max(need, L.cdll.ttk_bc_partial_rows_pool(B, ho * ho, cout) * 2 * cout)
         h = ho
     return torch.empty(need, dtype=torch.float32, device=device)
 
@@ -119,7 +118,7 @@ def forward_impl(MB, x, params, buffers, momentum, eps, training, frozen=False, 
         h, w_ = ho, wo
     C = prev.y.shape[-1]
     feat = torch.empty((B, C), dtype=torch.float32, device=dev)
-    L.call("ttk_avgpool_fwd", p(prev.y), p(prev.bn), p(prev.skip), p(feat), B, h * w_, C, _BF_CB64)
+    L.call("ttk_bc_avgpool_fwd", p(prev.y), p(prev.bn), p(prev.skip), p(feat), B, h * w_, C)
     ctx.HW = h * w_
     return feat, ctx
 
@@ -165,8 +164,8 @@ def backward_impl(MB, ctx, gfeat, params):
     stem_scratch = p(scratch) if det else None
 
     g = torch.empty(last.y.shape, dtype=_DT, device=last.y.device)
-    L.call("ttk_avgpool_bwd", p(gfeat), p(last.y), p(last.bn), p(last.skip), p(g), p(part), B, ctx.HW, C, _BF_CB64)
-    bwd_finalize(last, L.partial_rows_elementwise(B * ctx.HW * (C // 4)), B * ctx.HW, len(params) - 2)
+    L.call("ttk_bc_avgpool_bwd", p(gfeat), p(last.y), p(last.bn), p(last.skip), p(g), p(part), B, ctx.HW, C)
+    bwd_finalize(last, L.cdll.ttk_bc_partial_rows_pool(B, ctx.HW, C), B * ctx.HW, len(params) - 2)
 
     for k in range(len(blocks) - 1, -1, -1):
         h, w_, ho, wo, cin, cout, stride, has_skip = ctx.dims[k]
