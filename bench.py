@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (the measurement); gloo with --share-gpu: "
                     "a dry run of the multi-rank code path on a one-GPU box (tests/test_bench_dp_dryrun_gpu.py) - its rate is not a result")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses device 0")
+    ap.add_argument("--comm-only", action="store_true", help="N > 1: time ONLY the bucketed in-place gradient all-reduce of one step (the buckets a real "
+                    "backward announces, replayed on buffers of the same sizes): ms per step and bus bandwidth, no compute beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-copy-probe", action="store_true", help="skip the same-process streaming probe (copy_probe object)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-call HIP-event instrumentation (roofline = null)")
@@ -466,6 +468,49 @@ def main():
         sync()
         timer.enabled = False
         MB._USE_WGRAD_STREAM = use_side
+    # Communication diagnostics (N > 1; a separate pass: the extra events and stream waits are not free): per step the buckets and bytes the
+    # reducer exchanged, the device time of the collectives (they overlap backward), and the EXPOSED time - from the end of backward's last
+    # kernel to the completion of the last collective, i.e. how long the optimiser waited for the exchange; max over the ranks.
+    comm = None
+    if reducer is not None:
+        ranks = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(ranks, torch.tensor([rank], dtype=torch.int64, device=device))
+        world_seen = len({int(t.item()) for t in ranks})
+        comm_steps = max(1, min(args.steps, 5))
+        reducer.measure = True
+        for _ in range(comm_steps):
+            step()
+        sync()
+        reducer.measure = False
+        tm = reducer.collect_timing()
+        n = max(tm["steps"], 1)
+        stats = torch.tensor([tm["exposed_ms"] / n, tm["allreduce_ms_sum"] / n, tm["host_wait_ms_sum"] / n], dtype=torch.float64, device=device)
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        comm = {"world_seen": world_seen, "backend": args.dist_backend, "buckets": tm["buckets"] // n, "bytes_per_step": tm["bytes"] // n,
+                "bucket_bytes": reducer.bucket_bytes, "exposed_ms": float(stats[0]), "allreduce_ms_sum": float(stats[1]), "host_wait_ms_sum": float(stats[2]),
+                "steps": comm_steps,
+                "note": "exposed_ms = end of backward's last kernel -> last collective done (HIP events, main stream), allreduce_ms_sum = sum over the "
+                        "buckets of (range final -> collective done) on the side stream, both per step, max over ranks; host_wait_ms_sum: host time "
+                        "inside the collective calls (non-zero where the backend blocks the host: gloo)"}
+        if args.comm_only:
+            # the same buckets on their own: buffers of the sizes just seen, all-reduced in place back to back, nothing else on the GPU
+            sizes = reducer.last_bucket_bytes or [tm["bytes"] // n]
+            bufs = [torch.zeros(max(b // 4, 1), dtype=torch.float32, device=device) for b in sizes]
+            for _ in range(3):
+                for b in bufs:
+                    dist.all_reduce(b)
+            sync()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                for b in bufs:
+                    dist.all_reduce(b)
+            sync()
+            co = torch.tensor([(time.perf_counter() - t2) / args.steps * 1e3], dtype=torch.float64, device=device)
+            dist.all_reduce(co, op=dist.ReduceOp.MAX)
+            tot = sum(sizes)
+            comm["comm_only"] = {"ms_per_step": float(co[0]), "buckets": len(sizes), "bytes": tot,
+                                 "busbw_GBs": tot * 2 * (world - 1) / world / (float(co[0]) * 1e-3) / 1e9 if float(co[0]) > 0 else None,
+                                 "note": "bucketed all-reduce alone, back to back on the default stream; busbw = bytes * 2 (N-1)/N / time"}
     # optimiser step alone (already inside `value`; reported for reference)
     sync()
     t1 = time.perf_counter()
@@ -551,6 +596,8 @@ def main():
                                    max(sum(v["ms"] for k, v in ks.items() if k.startswith("pw")) * 1e-3, 1e-12) / 1e12) if ks else None,
             "dominant_kernel": dominant, "top_kernels": top5,
         }
+        if comm is not None:
+            line["comm"] = comm
         if world == 1 and not args.no_copy_probe:
             line["copy_probe"] = copy_probe(device)
         if world == 1 and not args.no_cpu_baseline:

@@ -32,6 +32,15 @@ class GradAllReduce:
         """`always_reduce`: issue the collectives even in a world of one (they are identities) - used to exercise the
         stream / event / bucket logic on a single GPU."""
         self.pg = process_group
+        # Diagnostics (bench.py's `comm` object): with `measure` set, every collective is bracketed by events on the side stream (the
+        # stream then waits for each collective itself, so the buckets of a step serialise there - as they do inside RCCL) and finish()
+        # brackets the wait of the main stream; collect_timing() returns the sums.
+        # Off in the timed region of a benchmark: the extra waits and events are not free.
+        self.measure = False
+        self._timing: list = []
+        self._finish_log: list = []
+        self.last_bucket_bytes: list = []             # sizes of the collectives of the last finished step (bench.py --comm-only)
+        self._bucket_bytes_now: list = []
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self._always = always_reduce
         self.bucket_bytes = bucket_bytes
@@ -79,11 +88,23 @@ class GradAllReduce:
                 self._stream = torch.cuda.Stream(device=flat.device)
             self._stream.wait_stream(torch.cuda.current_stream(flat.device))  # the producing kernels of this range are enqueued
             with torch.cuda.stream(self._stream):
-                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                if self.measure:
+                    import time
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    t0 = time.perf_counter()
+                    work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                    work.wait()  # RCCL: the side stream waits for the collective (the host does not); gloo: the host does
+                    host_ms = (time.perf_counter() - t0) * 1e3
+                    e1.record()
+                    self._timing.append((flat.numel() * flat.element_size(), e0, e1, host_ms))
+                else:
+                    work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         else:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self._works.append(work)
         self.collectives += 1
+        self._bucket_bytes_now.append(flat.numel() * flat.element_size())
 
     def _flush(self):
         if self._open is None:
@@ -106,8 +127,16 @@ class GradAllReduce:
         if rest:
             packed = torch.cat([p.grad.reshape(-1) for p in rest])  # a handful of tiny tensors: one launch
             self._all_reduce(packed)
+        ev_bwd = ev_done = None
+        if self.measure and self._stream is not None:
+            ev_bwd, ev_done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev_bwd.record()  # fires when the last kernel of backward is done
         for w in self._works:
             w.wait()  # CUDA: the current stream waits for the collective
+        if self.measure and self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+            ev_done.record()  # fires when the optimiser may start: backward done AND every collective done
+            self._finish_log.append((ev_bwd, ev_done))
         if packed is not None:
             off = 0
             for p in rest:
@@ -130,9 +159,28 @@ class GradAllReduce:
         self._works.clear()
         self._done.clear()
         self._entries.clear()
+        self.last_bucket_bytes, self._bucket_bytes_now = self._bucket_bytes_now, []
 
     def begin_step(self):
         self.collectives = 0
+
+    def collect_timing(self) -> dict:
+        """After a synchronize: the diagnostics of the steps run with `measure` set since the last call - per step averages over the
+        recorded finish() calls are left to the caller, this returns the raw sums: {buckets, bytes, allreduce_ms_sum, exposed_ms,
+        steps}.  `allreduce_ms_sum`: device time between the moment a bucket's range was final and its collective's completion, summed over
+        the buckets (they overlap backward: this is not time lost); `exposed_ms`: how long the optimiser had to wait for the exchange
+        after the LAST kernel of backward had finished (time lost to communication)."""
+        torch.cuda.synchronize()
+        out = dict(buckets=len(self._timing), bytes=sum(t[0] for t in self._timing), allreduce_ms_sum=0.0, host_wait_ms_sum=sum(t[3] for t in self._timing),
+                   exposed_ms=0.0)
+        for _, e0, e1, _ in self._timing:
+            out["allreduce_ms_sum"] += e0.elapsed_time(e1)
+        for a, b in self._finish_log:
+            out["exposed_ms"] += a.elapsed_time(b)
+        out["steps"] = len(self._finish_log)
+        self._timing.clear()
+        self._finish_log = []
+        return out
 
     def abort(self):
         """Backward raised: wait for the collectives already issued (they work in place on gradient arenas that are about to be
