@@ -64,7 +64,8 @@ def parse():
     ap.add_argument("--force-graph", action="store_true", help="always replay the captured hipGraph (default at N=1: whichever of graph replay "
                     "and eager enqueue the warm-up measures faster)")
     ap.add_argument("--serial-streams", action="store_true",
-                    help="keep every kernel on one stream (for rocprofv3 runs: per-kernel durations are then those of the kernel alone)")
+                    help="(kept for old command lines; every kernel of a step already runs on one stream - the weight-gradient side stream of earlier "
+                    "rounds is an experiment hook that is off)")
     ap.add_argument("--per-call", action="store_true", help="print the roofline pass call by call (kernel, shape, us, GB/s, TFLOP/s) on stderr")
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time budget of the CPU baseline sample")
@@ -298,41 +299,48 @@ def cpu_baseline(args):
     # host: use at most 32 threads and say so in `cores`.
     n = args.cpu_threads or min(os.cpu_count() or 1, 32)
     torch.set_num_threads(n)
-    B = args.cpu_batch
     if args.backbone == "resnet18":  # the heads on 512 features + the ResNet-18 backbone under "convnet."
         heads = {k: v for k, v in R.state_shapes(True, False, num_features=512).items() if not k.startswith("convnet.")}
         shapes = {**R.resnet18_state_shapes(prefix="convnet.", use_blurpool=args.blurpool), **heads}
     else:
         shapes = R.state_shapes(True, False, use_blurpool=args.blurpool)
     st = R.state_from_numpy(make_state(shapes, 0))
-    image, ids = make_inputs(B, seed=1, structured=False)
-    lab = make_labels(B, seed=1)
     gmm = R.ShapeGmm(os.path.join(REPO, "tests", "golden", "shapeparams_gmm.npz"))
     crit, _ = R.setup_losses(with_pointhead=True, with_nll_loss=False, gmm=gmm)
-    batch = [dict(tag="POSE_WITH_LANDMARKS", n=B, **{k: torch.from_numpy(v) for k, v in lab.items() if k != "dataset_weight"})]
-    x, idt = torch.from_numpy(image), torch.from_numpy(ids)
     cfg = dict(enable_point_head=True, enable_uncertainty=False, config=args.backbone)
 
-    def step():
-        for v in st.values():
-            v.grad = None
-        out, _ = R.network_forward(st, x, idt, cfg, True)
-        loss, _ = R.compute_loss(out, batch, 0, crit)
-        loss.backward()
+    def sample(B, seconds, max_steps):
+        image, ids = make_inputs(B, seed=1, structured=False)
+        lab = make_labels(B, seed=1)
+        batch = [dict(tag="POSE_WITH_LANDMARKS", n=B, **{k: torch.from_numpy(v) for k, v in lab.items() if k != "dataset_weight"})]
+        x, idt = torch.from_numpy(image), torch.from_numpy(ids)
 
-    tw = time.perf_counter()
-    step()  # warm-up (also tells how long one step takes)
-    tw = time.perf_counter() - tw
-    steps = 0
-    t0 = time.perf_counter()
-    while True:
-        step()
-        steps += 1
-        dt = time.perf_counter() - t0
-        if dt + tw > args.cpu_seconds or steps >= 50:
-            break
-    return {"value": B * steps / dt, "unit": "crops/s", "cores": n, "kind": "port",
-            "sample": f"{steps} fwd+bwd steps of the same network at batch {B} (fp32, torch CPU kernels, {n} threads), {dt:.1f} s"}
+        def step():
+            for v in st.values():
+                v.grad = None
+            out, _ = R.network_forward(st, x, idt, cfg, True)
+            loss, _ = R.compute_loss(out, batch, 0, crit)
+            loss.backward()
+
+        tw = time.perf_counter()
+        step()  # warm-up (also tells how long one step takes)
+        tw = time.perf_counter() - tw
+        steps = 0
+        t0 = time.perf_counter()
+        while True:
+            step()
+            steps += 1
+            dt = time.perf_counter() - t0
+            if dt + tw > seconds or steps >= max_steps:
+                break
+        return {"batch": B, "value": B * steps / dt, "steps": steps, "seconds": round(dt, 2)}
+
+    # the CPU path at B = 256 (BASELINE config 2's size) and at B = 64, inside one ~20 s budget
+    small = sample(args.cpu_batch, 0.4 * args.cpu_seconds, 50)
+    big = sample(256, 0.6 * args.cpu_seconds, 5) if args.cpu_batch != 256 else small
+    return {"value": big["value"], "unit": "crops/s", "cores": n, "host_cores": os.cpu_count(), "kind": "port", "samples": [small, big],
+            "sample": f"{big['steps']} fwd+bwd steps of the same network at batch 256 in {big['seconds']} s (value), and {small['steps']} at batch "
+                      f"{small['batch']} ({small['value']:.1f} crops/s); fp32, torch CPU kernels, {n} of the host's {os.cpu_count()} hardware threads"}
 
 
 def main():
@@ -451,11 +459,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # Per-kernel pass for the roofline object: the same step again with HIP events around every pointwise-GEMM
-    # call, all kernels on ONE stream.  It is a separate pass because (a) the events cost ~3 ms/step of host time
-    # and stream serialisation, which would distort `value`, and (b) in the timed region the weight-gradient GEMMs
-    # run on a second stream concurrently with the data-gradient chain, where a kernel's wall duration says
-    # nothing about the kernel alone.
+    # Per-kernel pass for the roofline object: the same step again with HIP events around every conv C-ABI call (one stream, as in the timed
+    # region).  It is a separate pass because the events cost ~3 ms/step of host time, which would distort `value`.
     roof_steps = 0 if args.no_kernel_timing else min(args.steps, 10)
     if roof_steps:
         use_side = MB._USE_WGRAD_STREAM

@@ -176,6 +176,10 @@ def run(args) -> TableBuilder:
     else:
         roi_configs = [RoiConfig(expansion_factor=args.roi_expansion) if args.roi_expansion is not None else RoiConfig()]
     if any(c.use_head_roi for c in roi_configs) and not _have_bfm_blob() and not all(d.endswith(".npz") for d in args.ds.split("+")):
+        if not getattr(args, "allow_landmark_roi_fallback", False):
+            raise FileNotFoundError("the (H_roi) box configurations need the BFM head mesh (trackertraincode/facemodel/bfm_noneck_v3.pkl, which the "
+                                    "reference's repository does not carry either); pass --allow-landmark-roi-fallback to evaluate them as (F_roi) - "
+                                    "the substitution shows in the row names, also of the JSON output")
         print("note: no BFM head mesh (trackertraincode/facemodel/bfm_noneck_v3.pkl): the (H_roi) configurations are evaluated as (F_roi)", file=sys.stderr)
         seen, repl = set(), []
         for c in roi_configs:
@@ -207,6 +211,8 @@ def make_parser():
     ap.add_argument("--alignment-scheme", choices=["perspective", "opal23", "none"], default="none")
     ap.add_argument("--roi-expansion", default=None, type=float)
     ap.add_argument("--json", type=str, default=None)
+    ap.add_argument("--allow-landmark-roi-fallback", action="store_true", default=False,
+                    help="without the BFM head-mesh blob: evaluate the (H_roi) configurations with the landmark extent (F_roi) instead of failing")
     ap.add_argument("--ds", type=str, default="aflw2k3d", help="validation sets joined by '+', or paths of .npz files")
     ap.add_argument("--datadir", type=str, default=None, help="directory of the converted shards (default $DATADIR)")
     return ap

@@ -294,6 +294,13 @@ class _Library:
         return self.cdll.ttk_partial_rows_pwconv(m, k, nout, int(dgrad))
 
 
+# hipGraph captures run in "global" error mode: a HIP call that another thread makes while a capture is open (an allocation, a copy on
+# another stream) invalidates it.  Whoever captures holds this lock (train.GraphedTrainStep); background threads that touch the GPU
+# (datasets.resident's host-frame prefetch) take it around their GPU work.
+import threading
+
+CAPTURE_LOCK = threading.RLock()
+
 _lib: _Library | None = None
 
 

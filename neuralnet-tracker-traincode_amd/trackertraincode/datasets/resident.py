@@ -27,6 +27,7 @@ from typing import Any, Iterator, Sequence
 import numpy as np
 import torch
 
+from .. import _hip
 from ..datatransformation.gpu import GpuFocusRoiAugment
 from ..datatransformation.tensors.affinetrafo import FieldCategory
 from .batch import Batch, Metadata
@@ -105,7 +106,12 @@ class _HostGather:
         out = {}
         ii = idx.numpy()
         with torch.cuda.stream(self.stream):
+            sel = None
             for k, v in fields.items():
+                if v.is_cuda:  # a field that already lives on the device beside host frames (e.g. a `dataset_weight` column): plain gather
+                    sel = idx.to(v.device) if sel is None else sel
+                    out[k] = v.index_select(0, sel)
+                    continue
                 stage = torch.empty((idx.numel(),) + tuple(v.shape[1:]), dtype=v.dtype, pin_memory=True)  # caching host allocator: recycled once the copy is done
                 self._take(v.numpy(), ii, stage.numpy())
                 out[k] = stage.to(self.device, non_blocking=True)
@@ -186,7 +192,8 @@ class ResidentLoader:
             try:
                 torch.cuda.set_device(self._device)
                 for _ in range(self.steps):
-                    item = self._gather_step()
+                    with _hip.CAPTURE_LOCK:  # never allocate / copy while the training thread captures a hipGraph (train.GraphedTrainStep)
+                        item = self._gather_step()
                     while not stop.is_set():
                         try:
                             q.put(item, timeout=0.1)

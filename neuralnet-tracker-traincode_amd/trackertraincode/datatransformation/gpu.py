@@ -71,6 +71,7 @@ class GpuFocusRoiAugment:
             raise RuntimeError("GpuFocusRoiAugment runs in HIP kernels: CUDA tensors required (no CPU fallback)")
         B, _, Hs, Ws = img.shape
         dev = img.device
+        _hip.lib().clear_stale_error("GpuFocusRoiAugment")  # once per loader batch: these launches run before training_step's own clear
         if params is None:
             params = self.make_params((B,), generator=generator, device=dev if generator is None or generator.device.type == "cuda" else "cpu")
         f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()

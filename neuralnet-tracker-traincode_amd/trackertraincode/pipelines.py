@@ -316,13 +316,19 @@ def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights
                                     f"{name}.h5 {path}` (h5py lives in the build container's conda interpreter only)")
         if path not in cache:
             frames = load_resident_frames(path, tag, "cpu")
+            if head_roi is not None and "pt3d_68" in frames.fields and str(device).startswith("cuda"):
+                # the forehead box is the extent of the posed head MESH (tens of thousands of vertices per frame): computed on the GPU from
+                # the labels alone, BEFORE the frames are placed - on host-placed sets it would otherwise run on the CPU for every frame
+                labels = {k: v.to(device) for k, v in frames.fields.items() if k != "image"}
+                head_roi(labels)
+                frames.fields["roi"] = labels["roi"].cpu()
+            elif head_roi is not None:
+                head_roi(frames.fields)  # frames with landmarks get the forehead box; the others keep their stored one
             if frames_on == "device" or (frames_on == "auto" and on_device_bytes[0] + frames.nbytes() <= budget):
                 on_device_bytes[0] += frames.nbytes()
                 cache[path] = frames.to(device)
             else:  # beyond the HBM budget (or asked for): pinned host memory, streamed per step
                 cache[path] = frames.to_host()
-            if head_roi is not None:
-                head_roi(cache[path].fields)  # frames with landmarks get the forehead box; the others keep their stored one
         return cache[path]
 
     dataset_weights = dataset_weights or {}
@@ -340,14 +346,16 @@ def make_pose_estimation_loaders(inputsize, batchsize, datasets, dataset_weights
     else:  # the weights scale the losses instead (`dataset_weight` field, reference :475-485); every dataset is drawn equally often
         wmax = max(weights)
         for t, w in zip(train_sets, weights):
-            t.fields["dataset_weight"] = torch.full((len(t),), w / wmax, dtype=torch.float32, device=device)
+            # beside the set's other fields: on the device, or - host-placed sets - in pinned host memory (the host gather reads numpy views)
+            col = torch.full((len(t),), w / wmax, dtype=torch.float32, device=t.fields["image"].device)
+            t.fields["dataset_weight"] = col.pin_memory() if (col.device.type == "cpu" and torch.cuda.is_available()) else col
         freqs = [1.0 / len(weights)] * len(weights)
     augs = make_image_augmentations(torch.Generator().manual_seed(99 + seed)) if enable_image_aug else None
     crop = GpuFocusRoiAugment(new_size=inputsize, rotation_aug_angle=rotation_aug_angle, extension_factor=extension_factor, whiten=not augs,
                               flip_rot_p=0.01, roi_from_landmarks=roi_override == "landmarks")
     steps = steps_per_epoch if steps_per_epoch is not None else (10 * 1024) // batchsize  # Trainer(limit_train_batches=...), train_poseestimator.py:447
-    train = ResidentLoader(train_sets, freqs, batchsize, steps, seed=seed, crop=crop, image_augmentations=augs)
+    train = ResidentLoader(train_sets, freqs, batchsize, steps, seed=seed, crop=crop, image_augmentations=augs, device=device)
     tname, ttag, (lo, hi) = _TEST_SHARD
     test = ResidentEvalLoader([_slice_frames(shard(tname, ttag), lo, hi)], batchsize * 2, new_size=inputsize, extension_factor=extension_factor,
-                              roi_from_landmarks=roi_override == "landmarks")
+                              roi_from_landmarks=roi_override == "landmarks", device=device)
     return train, test, total

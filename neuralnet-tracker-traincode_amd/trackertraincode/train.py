@@ -551,10 +551,11 @@ class GraphedTrainStep:
         self.optimizer.sync_hyper_to_device()
         self.graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)  # gradients are allocated from the graph's pool at fixed addresses
-        with torch.cuda.graph(self.graph):
-            out = training_step(self.model, self._static, epoch, self.criterions)
-            out["loss"].backward()
-            self.optimizer.step()
+        with _hip.CAPTURE_LOCK:  # (a loader's prefetch thread must not allocate or copy while the capture is open: _hip.CAPTURE_LOCK)
+            with torch.cuda.graph(self.graph):
+                out = training_step(self.model, self._static, epoch, self.criterions)
+                out["loss"].backward()
+                self.optimizer.step()
         self._out = out
         self.captures += 1
 
@@ -617,6 +618,7 @@ def validate(model: nn.Module, val_loader, val_criterions) -> float:
     epoch ramp with the batch index here)."""
     was_training = model.training
     model.eval()
+    _hip.lib().clear_stale_error("validate")  # (once per validation epoch: a pending error of an unrelated earlier call must not be blamed on these launches)
     total, count = None, 0
     try:
         for batch_idx, batch in enumerate(val_loader):

@@ -35,7 +35,7 @@ def test_script_tables(tmp_path, capsys):
     models.save_model(net, ck)
     shutil.copy(os.path.join(GOLDEN, "aflw2kmini.npz"), tmp_path / "aflw2k.npz")
     out_json = str(tmp_path / "t.json")
-    S.main([ck, "--ds", "aflw2k3d", "--datadir", str(tmp_path), "--comprehensive-roi", "--json", out_json])
+    S.main([ck, "--ds", "aflw2k3d", "--datadir", str(tmp_path), "--comprehensive-roi", "--json", out_json, "--allow-landmark-roi-fallback"])
     err = capsys.readouterr().err
     table = json.load(open(out_json))
     (model, cols), = table.items()

@@ -121,3 +121,35 @@ def test_mixed_placement_three_datasets_two_sizes():
             assert len(sa) == len(sb) == 2  # two Tags; the two landmark sets differ in frame size: cropped per set, collated
             for x, y in zip(sa, sb):
                 _equal(x, y)
+
+
+def test_host_frames_with_loss_weights_and_a_captured_step(tmp_path, monkeypatch):
+    """Round-4 advisor findings: (1) `use_weights_as_sampling_frequency=False` adds a `dataset_weight` column to every train set - on a
+    host-placed set it must sit beside the host fields (the host gather reads numpy views), and the loaders must use the requested device;
+    (2) the prefetch thread of host-placed sets allocates and copies while `fit(graphed=True)` captures the step as a hipGraph - both take
+    _hip.CAPTURE_LOCK."""
+    import trackertraincode.pipelines as P
+    import trackertraincode.train as train
+    from util import script_args, train_script
+
+    datadir = _datadir(tmp_path)
+    monkeypatch.setitem(P._POSE_SHARDS, P.Id.AFLW2k3d, ("aflw2k", P.Tag.POSE_WITH_LANDMARKS, 1000.0, (8, None)))
+    monkeypatch.setattr(P, "_TEST_SHARD", ("aflw2k", P.Tag.POSE_WITH_LANDMARKS, (0, 8)))
+    kw = dict(device="cuda", seed=5, datadir=datadir, steps_per_epoch=5, enable_image_aug=False, use_weights_as_sampling_frequency=False)
+    tr_d, _, _ = P.make_pose_estimation_loaders(129, 6, [P.Id.AFLW2k3d], frames_on="device", **kw)
+    tr_h, _, _ = P.make_pose_estimation_loaders(129, 6, [P.Id.AFLW2k3d], frames_on="host", **kw)
+    assert tr_h.datasets[0].on_host and tr_h.datasets[0].fields["dataset_weight"].device.type == "cpu" and tr_h._device.type == "cuda"
+    for step_d, step_h in zip(tr_d, tr_h):
+        for x, y in zip(step_d, step_h):
+            assert "dataset_weight" in x.keys() and x["dataset_weight"].is_cuda
+            _equal(x, y)
+    # a captured training step fed from host frames (the producer thread runs beside the capture)
+    S = train_script()
+    args = script_args(dict(with_pointhead=True, with_nll_loss=False, rampup_nll_losses=False), epochs=2)
+    torch.manual_seed(0)
+    net = S.create_net(args).cuda()
+    crit, _ = S.setup_losses(args, net)
+    opt, sch = S.create_optimizer(net, args)
+    tr2, _, _ = P.make_pose_estimation_loaders(129, 8, [P.Id.AFLW2k3d], frames_on="host", device="cuda", seed=1, datadir=datadir, steps_per_epoch=6)
+    train.fit(net, tr2, crit, opt, sch, epochs=2, graphed=True)
+    assert all(torch.isfinite(p).all() for p in net.parameters())
