@@ -49,7 +49,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 23
+#define TTK_ABI_VERSION 24
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -266,7 +266,7 @@ int ttk_bn_act(const float* y, const float* bn, const float* skip, float* a, int
  *  - every activation-sized tensor AND its gradient is bfloat16 in CHANNEL BLOCKS OF 64:  [C / 64][M][64], element (m, c) at
  *    ((c >> 6) * M + m) * 64 + (c & 63)  (C = 32: plain [M][32]) - a pixel of a block is one 128-byte line.  ttk_stem_fwd /
  *    ttk_stem_bwd_weight (C = 32: the same bytes in either layout) serve this path with act_bf16 = TTK_STORE_ACT_BF16 |
- *    TTK_STORE_GRAD_BF16, ttk_avgpool_* with TTK_LAYOUT_CB64 added, the ttk_bn_* finalisations unchanged;
+ *    TTK_STORE_GRAD_BF16; the ttk_bn_* finalisations are shared unchanged; the pool has its own pair (ttk_bc_avgpool_*);
  *  - the pointwise products run as ONE bf16 MFMA product with fp32 accumulation: operands rounded to bf16 after the BatchNorm (+ ReLU)
  *    / BatchNorm-backward map on load, weights rounded once per step by ttk_bc_prepare_weights (`wprep`: two images per layer,
  *    ttk_bc_prepared_bytes); no operand bounds (row TTK_BN_AUX is not read);
@@ -287,6 +287,14 @@ int ttk_bc_pw_bwd_data(const void* g, const void* y, const float* bn_pw, const v
 size_t ttk_bc_pw_wgrad_scratch_bytes(int64_t M, int Cin, int Cout);
 int ttk_bc_pw_bwd_weight(const void* g, const void* y, const float* bn_pw, const void* ydw, const float* bn_dw, float* dw,
                          float* scratch, int64_t M, int Cin, int Cout, ttk_stream_t stream);
+/* ttk_bc_pw_bwd_weight AND ttk_bc_pw_bwd_data of the early layers (32 -> 64, 64 -> 128, 128 -> 128: the largest pixel counts, HBM-bound)
+ * in one kernel that reads g, y and ydw once: same results as the pair (the weight gradient is reduced over a different slicing of the
+ * pixels).  ttk_bc_pw_bwd_fused_rows = the rows of `part` it writes, 0 = the shape has no fused form (use the pair);
+ * `scratch` of ttk_bc_pw_bwd_fused_scratch_bytes bytes; ADDS to dw. */
+int ttk_bc_pw_bwd_fused_rows(int64_t M, int Cin, int Cout);
+size_t ttk_bc_pw_bwd_fused_scratch_bytes(int64_t M, int Cin, int Cout);
+int ttk_bc_pw_bwd_fused(const void* g, const void* y, const float* bn_pw, const void* wprep, const void* ydw, const float* bn_dw,
+                        void* g_dw, float* dw, float* scratch, float* part, int64_t M, int Cin, int Cout, ttk_stream_t stream);
 /* AdaptiveAvgPool2d(1) over the last block's output and its backward (as ttk_avgpool_fwd / _bwd) on the 64-channel-block bf16 tensors;
  * the backward writes ttk_bc_partial_rows_pool(B, HW, C) partial rows. */
 int ttk_bc_partial_rows_pool(int B, int HW, int C);

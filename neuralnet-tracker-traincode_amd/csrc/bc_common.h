@@ -113,5 +113,108 @@ inline bool launch_fold_rows_fast(const float* partial, int rows, int64_t n, flo
 __host__ __device__ __forceinline__ int w_cpr(int K) { return K < 64 ? K / 8 : 8; }                  // chunks per row
 __host__ __device__ __forceinline__ int w_swz(int n, int cpr) { return cpr == 8 ? (n >> 1) & 7 : (n >> 2) & 3; }
 
+constexpr int kFwd = 0, kDgrad = 1;
+
+// constants of the output side, channels n0 .. n0 + cnt - 1: forward pivot; data gradient scale | shift | mean of the mask operand's BatchNorm
+template <int MODE>
+__device__ __forceinline__ void fill_cE(float* cE, const float* pivot, const float* bnE, int Ntot, int n0, int cnt, int tid, int nthreads) {
+  for (int c = tid; c < cnt; c += nthreads) {
+    if constexpr (MODE == kFwd) {
+      cE[c] = pivot ? pivot[n0 + c] : 0.f;
+    } else {
+      const float sc = bnE[TTK_BN_SCALE * Ntot + n0 + c], mu = bnE[TTK_BN_MEAN * Ntot + n0 + c];
+      cE[c] = sc;
+      cE[cnt + c] = fmaf(-sc, mu, bnE[TTK_BN_BETA * Ntot + n0 + c]);
+      cE[2 * cnt + c] = mu;
+    }
+  }
+}
+
+// One 32-pixel x OC-channel block of a wave's accumulators -> its LDS tile -> global memory (+ statistics).
+//   acc: BPC = OC / 32 accumulator blocks (channels x pixels); stg: wave-private tile [32 px][OC] bf16, chunks XOR-swizzled by pixel
+//   ce: output-side constants of THIS block's channels ([cnt] rows apart), pix0: first pixel, pend: end of the valid pixels
+//   s1, s2: the lane's running sums for its 8 channels (lane % LPP = its 16-byte chunk of the pixel)
+template <int MODE, int OC>
+__device__ __forceinline__ void store_block(const f32x16* acc, uint4* stg, bf16_t* __restrict__ outb, const uint4* mk, const float* ce, int cnt,
+                                            int64_t pix0, int64_t pend, float (&s1)[8], float (&s2)[8]) {
+  constexpr int LPP = OC / 8, PPI = 64 / LPP, NI = 32 / PPI, BPC = OC / 32;
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  unsigned char* sb = reinterpret_cast<unsigned char*>(stg);
+#pragma unroll
+  for (int blk = 0; blk < BPC; ++blk)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const f32x16& a = acc[blk];
+      const uint2 v = make_uint2(pack2(a[4 * gq], a[4 * gq + 1]), pack2(a[4 * gq + 2], a[4 * gq + 3]));
+      const int chunk = (4 * blk + gq) ^ (r & (LPP - 1));
+      *reinterpret_cast<uint2*>(sb + r * (OC * 2) + chunk * 16 + 8 * h) = v;
+    }
+  asm volatile("" ::: "memory");  // (LDS operations of one wave complete in order: the reads below see the stores above)
+  __builtin_amdgcn_wave_barrier();
+  const int oct = lane % LPP;
+  float e0[8], e1[8], e2[8];
+  *reinterpret_cast<float4*>(e0) = *reinterpret_cast<const float4*>(ce + 8 * oct);
+  *reinterpret_cast<float4*>(e0 + 4) = *reinterpret_cast<const float4*>(ce + 8 * oct + 4);
+  if constexpr (MODE == kDgrad) {
+    *reinterpret_cast<float4*>(e1) = *reinterpret_cast<const float4*>(ce + cnt + 8 * oct);
+    *reinterpret_cast<float4*>(e1 + 4) = *reinterpret_cast<const float4*>(ce + cnt + 8 * oct + 4);
+    *reinterpret_cast<float4*>(e2) = *reinterpret_cast<const float4*>(ce + 2 * cnt + 8 * oct);
+    *reinterpret_cast<float4*>(e2 + 4) = *reinterpret_cast<const float4*>(ce + 2 * cnt + 8 * oct + 4);
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int px = PPI * i + lane / LPP;
+    uint4 u = stg[px * LPP + (oct ^ (px & (LPP - 1)))];
+    const int64_t pix = pix0 + px;
+    const bool ok = pix < pend;
+    float f[8];
+    unpack8(u, f);
+    if constexpr (MODE == kFwd) {
+      if (ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = f[j] - e0[j];
+          s1[j] += d;
+          s2[j] = fmaf(d, d, s2[j]);
+        }
+      }
+    } else {
+      float y[8];
+      unpack8(mk[i], y);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float a = fmaf(e0[j], y[j], e1[j]);
+        f[j] = a > 0.f ? f[j] : 0.f;
+      }
+      u = pack8(f);  // (the kept values are bf16 already: exact)
+      if (ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          s1[j] += f[j];
+          s2[j] = fmaf(f[j], y[j] - e2[j], s2[j]);
+        }
+      }
+    }
+    if (ok) st16(outb + (size_t)(pix - pix0) * OC + 8 * oct, u);
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+
+// ---- transposed fragments (the contraction runs over PIXELS: weight gradient) ----------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__host__ __device__ constexpr int wg_pitch(int T) { return T == 32 ? 64 : 2 * T + 64; }  // bytes of one pixel row of a T-channel plane (= 64 mod 256)
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* plane, int off, int pitch) {
+  // pixels 8h .. 8h+3 and 8h+4 .. 8h+7 of the k16 step (the lane's address already holds 8h + q): element j = the lane's channel at pixel 8h + j
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + off));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + off + 4 * pitch));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 }  // namespace bc
 }  // namespace ttk

@@ -13,19 +13,6 @@
 namespace ttk {
 namespace bc {
 
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-
-__host__ __device__ constexpr int wg_pitch(int T) { return T == 32 ? 64 : 2 * T + 64; }  // bytes of one pixel row of a T-channel plane (= 64 mod 256)
-
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* plane, int off, int pitch) {
-  // pixels 8h .. 8h+3 and 8h+4 .. 8h+7 of the k16 step (the lane's address already holds 8h + q): element j = the lane's channel at pixel 8h + j
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + off));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + off + 4 * pitch));
-  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);
-}
-
 // TN32 x TK32 blocks of 32 x 32 per tile; CP pixels per chunk; the 8 waves form a WN x WK grid over the blocks, KS of them share a block
 // and split the k16 steps of a chunk between them (tiles of fewer than 8 blocks)
 template <int TN32, int TK32, int CP, int WN, int WK, int KS>

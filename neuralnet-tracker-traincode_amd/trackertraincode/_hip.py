@@ -100,13 +100,14 @@ _SIGNATURES = {
     "ttk_bc_pw_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I],
     "ttk_bc_pw_bwd_data": [_P] * 8 + [_L, _I, _I],
     "ttk_bc_pw_bwd_weight": [_P] * 7 + [_L, _I, _I],
+    "ttk_bc_pw_bwd_fused": [_P] * 10 + [_L, _I, _I],
     "ttk_bc_dw_fwd": [_P] * 8 + [_I] * 5,
     "ttk_bc_avgpool_fwd": [_P, _P, _P, _P, _I, _I, _I],
     "ttk_bc_avgpool_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
     "ttk_bc_dw_bwd_data": [_P] * 12 + [_I, _P] + [_I] * 5,
 }
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 
 # Whether the backbones hand the running mean to the forward producers as the statistics pivot (include/ttk.h).  Always on in the
@@ -175,6 +176,8 @@ class _Library:
         self.cdll.ttk_bc_partial_rows_dw.argtypes, self.cdll.ttk_bc_partial_rows_dw.restype = [c_int] * 6, c_int
         self.cdll.ttk_bc_partial_rows_pool.argtypes, self.cdll.ttk_bc_partial_rows_pool.restype = [c_int] * 3, c_int
         self.cdll.ttk_bc_pw_wgrad_scratch_bytes.argtypes, self.cdll.ttk_bc_pw_wgrad_scratch_bytes.restype = [c_int64, c_int, c_int], ctypes.c_size_t
+        self.cdll.ttk_bc_pw_bwd_fused_rows.argtypes, self.cdll.ttk_bc_pw_bwd_fused_rows.restype = [c_int64, c_int, c_int], c_int
+        self.cdll.ttk_bc_pw_bwd_fused_scratch_bytes.argtypes, self.cdll.ttk_bc_pw_bwd_fused_scratch_bytes.restype = [c_int64, c_int, c_int], ctypes.c_size_t
         self._fns = {}
         self._stale_reported = False
         for name, sig in _SIGNATURES.items():
@@ -368,4 +371,5 @@ def exported_symbols() -> list[str]:
             "ttk_partial_rows_gemm", "ttk_partial_rows_pwconv", "ttk_pwconv_tile_rows", "ttk_partial_rows_dwconv", "ttk_heads_num_rows", "ttk_pwconv_prepared_bytes",
             "ttk_pwconv_wgrad_partial_bytes", "ttk_pwconv_wgrad_scratch_bytes", "ttk_stem_wgrad_partial_bytes", "ttk_conv_wgrad_partial_bytes", "ttk_stem7_wgrad_partial_bytes",
             "ttk_pwconv1x1_bwd_fused_rows", "ttk_pwconv1x1_bwd_fused_partial_bytes", "ttk_bc_prepared_bytes", "ttk_bc_partial_rows_pw",
-            "ttk_bc_partial_rows_dw", "ttk_bc_partial_rows_pool", "ttk_bc_pw_wgrad_scratch_bytes"] + list(_SIGNATURES)
+            "ttk_bc_partial_rows_dw", "ttk_bc_partial_rows_pool", "ttk_bc_pw_wgrad_scratch_bytes", "ttk_bc_pw_bwd_fused_rows",
+            "ttk_bc_pw_bwd_fused_scratch_bytes"] + list(_SIGNATURES)

@@ -33,7 +33,8 @@ def part_buffer(B, H, W, device, blocks, blur=False):
         need = max(need, rows_dw(B, h, h, cin, stride, 1) * 2 * cin, rows_dw(B, h, h, cin, stride, 0) * 2 * cin)
         if blur and stride == 2:
             need = max(need, rows_dw(B, ho, ho, cin, 1, 0) * 2 * cin, rows_dw(B, ho, ho, cin, 1, 1) * 2 * cin)
-        need = max(need, rows_pw(B * ho * ho, cin, cout) * 2 * cout, rows_pw(B * ho * ho, cout, cin) * 2 * cin)
+        need = max(need, rows_pw(B * ho * ho, cin, cout) * 2 * cout, rows_pw(B * ho * ho, cout, cin) * 2 * cin,
+                   L.cdll.ttk_bc_pw_bwd_fused_rows(B * ho * ho, cin, cout) * 2 * cin)
         need = max(need, L.cdll.ttk_bc_partial_rows_pool(B, ho * ho, cout) * 2 * cout)
         h = ho
     return torch.empty(need, dtype=torch.float32, device=device)
@@ -151,7 +152,8 @@ def backward_impl(MB, ctx, gfeat, params):
 
     rows_pw, rows_dw = L.cdll.ttk_bc_partial_rows_pw, L.cdll.ttk_bc_partial_rows_dw
     # scratch of the pointwise weight gradients (slice partials, folded in a fixed order) and - deterministic mode - of the depthwise / stem ones
-    need = max(L.cdll.ttk_bc_pw_wgrad_scratch_bytes(B * d[2] * d[3], d[4], d[5]) for d in ctx.dims)
+    need = max(max(L.cdll.ttk_bc_pw_wgrad_scratch_bytes(B * d[2] * d[3], d[4], d[5]), L.cdll.ttk_bc_pw_bwd_fused_scratch_bytes(B * d[2] * d[3], d[4], d[5]))
+               for d in ctx.dims)
     det = MB._DETERMINISTIC
     # the fused depthwise weight gradient ALWAYS goes through workgroup rows + a fixed-order fold (float atomics of hundreds of workgroups on
     # the same 9 x 64 addresses serialise at the memory side: 15 - 110 us per launch measured on an otherwise empty kernel)
@@ -175,10 +177,16 @@ def backward_impl(MB, ctx, gfeat, params):
         a_in = ctx.a_in[k]
         M = B * ho * wo
         # -- pointwise: weight gradient, data gradient (+ bn_dw backward sums)
-        L.call("ttk_bc_pw_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(grads[pi + 3]), p(scratch), M, cin, cout)
         g_dw = torch.empty(st_dw.y.shape, dtype=_DT, device=st_dw.y.device)
-        L.call("ttk_bc_pw_bwd_data", p(g), p(st_pw.y), p(st_pw.bn), p(ctx.prep[k]), p(st_dw.y), p(st_dw.bn), p(g_dw), p(part), M, cin, cout)
-        bwd_finalize(st_dw, rows_pw(M, cout, cin), M, pi + 1)
+        fused_rows = L.cdll.ttk_bc_pw_bwd_fused_rows(M, cin, cout) if MB._FUSED_PW_BWD else 0
+        if fused_rows > 0:  # the early layers (HBM-bound): one kernel reads g, y, ydw once for both gradients
+            L.call("ttk_bc_pw_bwd_fused", p(g), p(st_pw.y), p(st_pw.bn), p(ctx.prep[k]), p(st_dw.y), p(st_dw.bn), p(g_dw), p(grads[pi + 3]), p(scratch),
+                   p(part), M, cin, cout)
+            bwd_finalize(st_dw, fused_rows, M, pi + 1)
+        else:
+            L.call("ttk_bc_pw_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(grads[pi + 3]), p(scratch), M, cin, cout)
+            L.call("ttk_bc_pw_bwd_data", p(g), p(st_pw.y), p(st_pw.bn), p(ctx.prep[k]), p(st_dw.y), p(st_dw.bn), p(g_dw), p(part), M, cin, cout)
+            bwd_finalize(st_dw, rows_pw(M, cout, cin), M, pi + 1)
         # -- depthwise: data gradient (+ residual gradient, + producer's bn sums) with the fused weight gradient
         dWd = grads[pi]
         g_prev = torch.empty(st_prev.y.shape, dtype=_DT, device=st_prev.y.device)

@@ -70,7 +70,10 @@ class ResidentFrames:
 
 def _device_of(datasets, device):
     if device is not None:
-        return torch.device(device)
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:  # torch.cuda.set_device / Stream(device=) want the index
+            device = torch.device("cuda", torch.cuda.current_device())
+        return device
     for d in datasets:
         if not d.on_host:
             return d.fields["image"].device

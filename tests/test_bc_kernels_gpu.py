@@ -61,7 +61,7 @@ def _dev(t, dtype):
 
 
 PW_SHAPES = [(1000, 32, 64), (777, 64, 128), (1500, 128, 128), (900, 128, 256), (1300, 256, 256), (700, 256, 512), (1111, 512, 512),
-             (300, 512, 1024), (520, 1024, 1024), (41, 512, 512), (20000, 32, 64)]
+             (300, 512, 1024), (520, 1024, 1024), (41, 512, 512), (20000, 32, 64), (70001, 64, 128), (40000, 128, 128), (33, 32, 64), (1, 128, 128)]
 
 
 @pytest.mark.parametrize("M,cin,cout", PW_SHAPES)
@@ -124,6 +124,21 @@ def test_pointwise_forward_datagrad_weightgrad(M, cin, cout):
     dw_ref = dy.T @ a
     err = (dw.cpu().double() - dw0.double() - dw_ref).abs().max().item()
     assert err <= 1e-4 * dw_ref.abs().max().item() + 1e-5, f"weight gradient off by {err:.3e} (scale {dw_ref.abs().max().item():.3e})"
+    # ---------------- both in one kernel (the early layers)
+    rows = L.cdll.ttk_bc_pw_bwd_fused_rows(M, cin, cout)
+    assert (rows > 0) == ((cin, cout) in ((32, 64), (64, 128), (128, 128)))
+    if rows > 0:
+        g_dw2 = torch.full((M, cin), float("nan"), dtype=torch.bfloat16, device="cuda")
+        part2 = torch.full((rows, 2, cin), float("nan"), device="cuda")
+        dw2 = dw0.clone().cuda()
+        scratch = torch.full((L.cdll.ttk_bc_pw_bwd_fused_scratch_bytes(M, cin, cout) // 4,), float("nan"), dtype=torch.float32, device="cuda")
+        L.call("ttk_bc_pw_bwd_fused", p(d_g), p(d_y), p(d_bn_pw), p(prep), p(d_ydw), p(d_bn_dw), p(g_dw2), p(dw2), p(scratch), p(part2), M, cin, cout)
+        torch.cuda.synchronize()
+        assert torch.equal(g_dw2.view(torch.int16), g_dw.view(torch.int16)), "fused data gradient differs from ttk_bc_pw_bwd_data's"
+        s2 = part2.double().sum(0).cpu()
+        assert torch.allclose(s2[0], gd_got.sum(0), rtol=1e-4, atol=1e-4) and torch.allclose(s2[1], (gd_got * (ydw - bn_dw[MEAN])).sum(0), rtol=1e-4, atol=1e-3)
+        err = (dw2.cpu().double() - dw0.double() - dw_ref).abs().max().item()
+        assert err <= 1e-4 * dw_ref.abs().max().item() + 1e-5, f"fused weight gradient off by {err:.3e}"
 
 
 def _nchw(t):
