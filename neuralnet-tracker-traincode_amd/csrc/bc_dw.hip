@@ -18,6 +18,19 @@
 #ifndef TTK_BC_DBG
 #define TTK_BC_DBG 0
 #endif
+#ifndef TTK_BC_STAGGER
+#define TTK_BC_STAGGER 0
+#endif
+// ring depths of the backward kernel (experiment builds may override them)
+#ifndef TTK_BC_RING_STAGE
+#define TTK_BC_RING_STAGE 4
+#endif
+#ifndef TTK_BC_RING_LEAN
+#define TTK_BC_RING_LEAN 6
+#endif
+#ifndef TTK_BC_RING_FULL
+#define TTK_BC_RING_FULL 2
+#endif
 
 namespace ttk {
 namespace bc {
@@ -181,6 +194,8 @@ bc_dw_fwd_k(const bf16_t* __restrict__ yprev, const float* __restrict__ bn_prev,
   int prev_img = -1, prev_band = -2, prev_nrows = 0;
   constexpr int OV = 3 - S;
   __syncthreads();  // taps staged
+  if (TTK_BC_STAGGER && blockIdx.x >= gridDim.x / 2 && tiles >= 4u * wgs)
+    for (int i = 0; i < TTK_BC_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
   for (unsigned t = t_begin; t < t_end; t += t_step) {
     const unsigned tb = t / (unsigned)NCT, ti = tb / (unsigned)nbands;
     const int ct = (int)(t - tb * NCT), band = (int)(tb - ti * nbands), n0 = (int)ti * NI;
@@ -351,6 +366,8 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
 #pragma unroll
     for (int k = 0; k < 4; ++k) wacc[t][k] = f2{0.f, 0.f};
   const unsigned tiles = (unsigned)((B + NI - 1) / NI) * nbands * NCT;
+  if (TTK_BC_STAGGER && blockIdx.x >= gridDim.x / 2 && tiles >= 4u * (gridDim.x / nslabs))
+    for (int i = 0; i < TTK_BC_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
   for (unsigned t = blockIdx.x / nslabs; t < tiles; t += gridDim.x / nslabs) {
     const unsigned tb = t / (unsigned)NCT, ti = tb / (unsigned)nbands;
     const int ct = (int)(t - tb * NCT), band = (int)(tb - ti * nbands), n0 = (int)ti * NI;
@@ -378,7 +395,7 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
     // issued unconditionally - clamped address - so that the counted vmcnt waits stay exact).
     const int nstage = nimg * (int)PI * KQ;
     {
-      constexpr int U = 1, RING = 4;  // eight 16-byte loads in flight per thread
+      constexpr int U = 1, RING = TTK_BC_RING_STAGE;  // 2 x RING 16-byte loads in flight per thread
       f2 ga[4], gb[4], gc[4];
       ld8(cst + 3 * SL + 8 * q, ga);
       ld8(cst + 4 * SL + 8 * q, gb);
@@ -542,7 +559,7 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
         }
       };
       // a ring of items: one is processed, its slot refilled at once - RING pixels' loads (1 or 3 tensors each) in flight per thread
-      constexpr int RING = LEAN ? 6 : 2;
+      constexpr int RING = LEAN ? TTK_BC_RING_LEAN : TTK_BC_RING_FULL;
       const int nit = (npix + kPixSlots - 1) / kPixSlots;
       Item ring[RING];
 #pragma unroll

@@ -54,7 +54,8 @@ for name, h, ci, co, s, res, mult in blocks:
         by = 2 * (n_in * (1 + (skp is not None) + res) + n_out)
         line += f"| dw fwd {us:6.1f} us {by / us / 1e3:5.0f} GB/s "
         tot["dw_fwd"] = tot.get("dw_fwd", 0.0) + us * mult
-        us = timed(lambda: L.call("ttk_bc_dw_bwd_data", p(gdw), p(ydw), p(bnd), p(w), p(sg), p(yprev), p(bnp), p(skp), p(a_out), p(gprev), p(part), p(dwg), 1, None,
+        rows_scr = torch.empty(L.cdll.ttk_bc_partial_rows_dw(B, h, h, ci, s, 1) * 9 * ci, device=dev)  # the product's form: workgroup rows + fold
+        us = timed(lambda: L.call("ttk_bc_dw_bwd_data", p(gdw), p(ydw), p(bnd), p(w), p(sg), p(yprev), p(bnp), p(skp), p(a_out), p(gprev), p(part), p(dwg), 1, p(rows_scr),
                                    B, h, h, ci, s))
         by = 2 * (2 * n_out + n_in * (2 + res + (res or skp is not None)))
         line += f"| dw bwd {us:6.1f} us {by / us / 1e3:5.0f} GB/s "
@@ -74,6 +75,12 @@ for name, h, ci, co, s, res, mult in blocks:
             us = timed(fn)
             line += f"| pw {k} {us:6.1f} us {by / us / 1e3:5.0f} GB/s {2 * M * ci * co / us / 1e6:5.0f} TF "
             tot["pw_" + k] = tot.get("pw_" + k, 0.0) + us * mult
+        fr = L.cdll.ttk_bc_pw_bwd_fused_rows(M, ci, co)
+        if fr > 0:  # what the step runs INSTEAD of dgrad + wgrad on the early layers
+            scr2, part2 = torch.empty(L.cdll.ttk_bc_pw_bwd_fused_scratch_bytes(M, ci, co) // 4, device=dev), torch.empty(fr * 2 * ci, device=dev)
+            us = timed(lambda: L.call("ttk_bc_pw_bwd_fused", p(g), p(y), p(bnq), p(prep), p(ydw2), p(bnd), p(gd), p(dW), p(scr2), p(part2), M, ci, co))
+            line += f"| fused bwd {us:6.1f} us {2 * M * 2 * (ci + co) / us / 1e3:5.0f} GB/s "
+            tot["pw_fused_bwd"] = tot.get("pw_fused_bwd", 0.0) + us * mult
     print(line, flush=True)
     prev_skip = res
 print("per-step totals (us):", {k: round(v) for k, v in tot.items()}, "sum", round(sum(tot.values())))
