@@ -101,14 +101,18 @@ class KernelTimer:
                 return (f"bc_gemm_e_k<0, {co // 32}, {ci // 32}>" if (co <= 128 and ci <= 256) else "bc_gemm_l_k<0>"), fl, 2 * (M * ci + M * co) + 2 * ci * co
             if name == "ttk_bc_pw_bwd_data":
                 return (f"bc_gemm_e_k<1, {ci // 32}, {co // 32}>" if (ci <= 128 and co <= 256) else "bc_gemm_l_k<1>"), fl, 2 * (2 * M * co + 2 * M * ci) + 2 * ci * co
+            if name == "ttk_bc_pw_bwd_fused":  # weight AND data gradient of the early layers, operands read once
+                return f"bc_bwd_fused_k<{co // 32}, {ci // 32}", 2 * fl, 2 * (2 * M * co + 2 * M * ci) + 6 * ci * co
             tn, tk = min(co, 256) // 32, min(ci, 256) // 32
             return f"bc_wgrad_k<{tn}, {tk}", fl, 2 * (2 * M * co + M * ci) + 4 * ci * co
         if name in ("ttk_bc_dw_fwd", "ttk_bc_dw_bwd_data"):
             B, H, W, C, s_ = a[-5:]
             n_in, n_out = B * H * W * C, B * ((H - 1) // s_ + 1) * ((W - 1) // s_ + 1) * C
-            if name == "ttk_bc_dw_fwd":
-                return f"bc_dw_fwd_k<{s_}", 2 * 9 * n_out, 2 * (n_in * (1 + bool(a[2]) + bool(a[3])) + n_out)
-            return f"bc_dw_bwd_k<{s_}", 2 * 2 * 9 * n_out, 2 * (2 * n_out + n_in * (2 + bool(a[4]) + bool(a[7] or a[8])))
+            tf = lambda v: "true" if v else "false"
+            if name == "ttk_bc_dw_fwd":  # bc_dw_fwd_k<stride, residual producer, channels per block, band carry> (the last from the tiling: not named)
+                return f"bc_dw_fwd_k<{s_}, {tf(a[2])}, {min(C, 64)}", 2 * 9 * n_out, 2 * (n_in * (1 + bool(a[2]) + bool(a[3])) + n_out)
+            lean = not (a[4] or a[7] or a[8])  # csrc/bc_dw.hip: no residual gradient, no residual producer, no materialised block input
+            return f"bc_dw_bwd_k<{s_}, {min(C, 64)}, {tf(lean)}>", 2 * 2 * 9 * n_out, 2 * (2 * n_out + n_in * (2 + bool(a[4]) + bool(a[7] or a[8])))
         if name.startswith("ttk_pwconv1x1"):
             # trailing arguments: ..., M, Cin, Cout, [scratch pointer of the split weights,] act_bf16
             M, ci, co = ints[-4:-1] if name == "ttk_pwconv1x1_bwd_weight" else ints[-5:-2]
@@ -579,7 +583,7 @@ def main():
                                  else "fp32-equivalent: 2500 TF dense 16-bit MFMA / piece products per fp32 product (3: fp16 x 2 split, 6: bf16 x 3 split)")
             roof["traffic_source"] = (traffic_src + f" (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; csrc_sha256 {tree[:16]} = this build)") if traffic_src else None
             roof["pass"] = f"{roof_steps} extra steps after the timed region, HIP events around each conv call, single stream"
-            top5 = [roofline_of(k) for k in order[:6]]
+            top5 = [roofline_of(k) for k in order[:(16 if args.precision == 'bf16-compute' else 6)]]  # (bf16-compute: every depthwise instantiation)
         dominant = roof["kernel"] if roof else None
         per_gpu = crops / world
         line = {
@@ -592,7 +596,8 @@ def main():
                        "parallelism": f"dp{world}"},
             "roofline": roof,
             "step_roofline": ({"hbm_frac_of_8TBs": per_gpu * ALGO_BYTES_PER_CROP * (0.5 if args.precision in ("bf16-all", "bf16-compute") else 1.0) / (PEAK_HBM_GBS * 1e9),
-                               "fp32_mfma_frac_of_157TF": per_gpu * ALGO_FLOP_PER_CROP / (PEAK_FP32_MFMA_TFLOPS * 1e12)} if args.backbone == "mobilenetv1"
+                               **({"bf16_mfma_frac_of_2500TF": per_gpu * ALGO_FLOP_PER_CROP / (PEAK_BF16_MFMA_TFLOPS * 1e12)} if args.precision == "bf16-compute"
+                                  else {"fp32_mfma_frac_of_157TF": per_gpu * ALGO_FLOP_PER_CROP / (PEAK_FP32_MFMA_TFLOPS * 1e12)})} if args.backbone == "mobilenetv1"
                               else {"fp32_mfma_frac_of_157TF": per_gpu * 4.203e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12)}),  # 4.203 GFLOP/crop
             "enqueue": ("hipGraph replay (1 capture)" if use_graph[0] else "eager Python launches") + enqueue_note,
             "optimizer_ms": opt_ms, "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3, "loss": float(loss.item()),

@@ -15,11 +15,20 @@
 //   1 no tap arithmetic (G and the weight-gradient accumulators)   2 no tap LDS reads   4 no store of g_prev
 //   8 no statistics                                                 16 no second-phase global loads
 //   32 no second phase at all                                       64 no staging phase (loads, BatchNorm-backward map, LDS stores)
+//   256 tap operands not widened (forward and backward)
+//   128 no weight-gradient accumulation (72 registers less: occupancy probes with TTK_BC_BLOCK / TTK_BC_WPE)
 #ifndef TTK_BC_DBG
 #define TTK_BC_DBG 0
 #endif
 #ifndef TTK_BC_STAGGER
 #define TTK_BC_STAGGER 0
+#endif
+// threads per workgroup / workgroups per CU of the backward kernel (experiment builds: occupancy probes; the product is 256 x 2)
+#ifndef TTK_BC_BLOCK
+#define TTK_BC_BLOCK 256
+#endif
+#ifndef TTK_BC_WPE
+#define TTK_BC_WPE 2
 #endif
 // ring depths of the backward kernel (experiment builds may override them)
 #ifndef TTK_BC_RING_STAGE
@@ -36,6 +45,8 @@ namespace ttk {
 namespace bc {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int kBlock = TTK_BC_BLOCK;  // (shadows ttk::kBlock inside this namespace)
+constexpr int kWvs = kBlock / kWave;
 
 constexpr int kPixBudgetFwd = 560;  // 128-byte pixels per LDS stage: 70 KB -> 2 workgroups per CU (three, with 168 registers, spilled around the load ring)
 constexpr int kPixBudgetBwd = 512;  // 64 KB + 13 KB of taps / reduction scratch / constants: TWO workgroups per CU fit the 160 KB (560 did not: one per CU, one wave per SIMD); 72 weight-gradient accumulators per lane: <= 256 registers
@@ -106,6 +117,15 @@ __device__ __forceinline__ void unpack_f2(uint4 u, f2 (&v)[4]) {
   v[2] = f2{__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u)};
   v[3] = f2{__uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
 }
+// timing-only (TTK_BC_DBG & 256): the tap operands are NOT widened (what an fp32 LDS tile would save in the tap loops; wrong results)
+__device__ __forceinline__ void unpack_tap(uint4 u, f2 (&v)[4]) {
+  if (TTK_BC_DBG & 256) {
+    v[0] = f2{__uint_as_float(u.x), __uint_as_float(u.y)}; v[1] = f2{__uint_as_float(u.z), __uint_as_float(u.w)};
+    v[2] = f2{__uint_as_float(u.x), __uint_as_float(u.z)}; v[3] = f2{__uint_as_float(u.y), __uint_as_float(u.w)};
+  } else {
+    unpack_f2(u, v);
+  }
+}
 __device__ __forceinline__ uint4 pack_f2(const f2 (&v)[4]) {
   return make_uint4(pack2(v[0].x, v[0].y), pack2(v[1].x, v[1].y), pack2(v[2].x, v[2].y), pack2(v[3].x, v[3].y));
 }
@@ -157,11 +177,11 @@ __device__ __forceinline__ void stage_taps(float* wt, const float* __restrict__ 
 // forward
 // ---------------------------------------------------------------------------------------------
 template <int S, bool SKIP, int SL, bool CARRY>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kWgsFwd, kWgsFwd)))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TTK_BC_WPE, TTK_BC_WPE)))
 bc_dw_fwd_k(const bf16_t* __restrict__ yprev, const float* __restrict__ bn_prev, const bf16_t* __restrict__ skip_prev, bf16_t* __restrict__ a_out,
             const float* __restrict__ w, bf16_t* __restrict__ y, float* __restrict__ part, const float* __restrict__ pivot, int B, int H, int W, int C,
             int Ho, int Wo, int R, int nbands, int nslabs, int NI_, int NCT_, int TW, int stage_pix) {
-  extern __shared__ uint4 lds[];  // [stage_pix][KQ] chunks | wt[9][SL] floats | red[4][2][SL] floats
+  extern __shared__ uint4 lds[];  // [stage_pix][KQ] chunks | wt[9][SL] floats | red[kWvs][2][SL] floats
   constexpr int KQ = SL / 8, kPixSlots = kBlock / KQ, kQs = ilog2(KQ), cshift = ilog2(SL);
   float* wt = reinterpret_cast<float*>(lds + (size_t)stage_pix * KQ);
   float* red = wt + 9 * SL;
@@ -307,7 +327,7 @@ bc_dw_fwd_k(const bf16_t* __restrict__ yprev, const float* __restrict__ bn_prev,
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           f2 a[4], wv[4];
-          unpack_f2(base[(kh * Wp + kw) * KQ], a);
+          unpack_tap(base[(kh * Wp + kw) * KQ], a);
           ld8(wt + (kh * 3 + kw) * SL + 8 * q, wv);
 #pragma unroll
           for (int k = 0; k < 4; ++k) acc[k] = fma2(a[k], wv[k], acc[k]);
@@ -331,7 +351,7 @@ bc_dw_fwd_k(const bf16_t* __restrict__ yprev, const float* __restrict__ bn_prev,
 // data gradient (+ fused weight gradient)
 // ---------------------------------------------------------------------------------------------
 template <int S, int SL, bool LEAN>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kWgsBwd, kWgsBwd)))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TTK_BC_WPE, TTK_BC_WPE)))
 bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, const float* __restrict__ bn_dw, const float* __restrict__ w,
             const bf16_t* __restrict__ skip_grad, const bf16_t* __restrict__ yprev, const float* __restrict__ bn_prev, const bf16_t* __restrict__ skip_prev,
             const bf16_t* __restrict__ a_in, bf16_t* __restrict__ g_prev, float* __restrict__ part, float* __restrict__ dwgrad, float* __restrict__ dw_partial,
@@ -340,7 +360,7 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
   constexpr int KQ = SL / 8, kPixSlots = kBlock / KQ, kQs = ilog2(KQ), cshift = ilog2(SL);
   float* wt = reinterpret_cast<float*>(lds + (size_t)stage_pix * KQ);
   float* red = wt + 9 * SL;
-  float* cst = red + 4 * 9 * SL;
+  float* cst = red + kWvs * 9 * SL;
   const int tid = threadIdx.x, q = tid & (KQ - 1), slot = tid >> kQs;
   const int slab = blockIdx.x % nslabs, c0 = slab * SL + 8 * q;
   stage_taps<SL>(wt, w, slab * SL);
@@ -527,12 +547,12 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
           if (S == 2 && (((PH + 1 - t / 3) & 1) || ((PW + 1 - t % 3) & 1))) continue;
           if (TTK_BC_DBG & 1) { G[0].x += __uint_as_float(dv[t].x ^ dv[t].y ^ dv[t].z ^ dv[t].w); continue; }
           f2 dy[4], wv[4];
-          unpack_f2(dv[t], dy);
+          unpack_tap(dv[t], dy);
           ld8(wt + t * SL + 8 * q, wv);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             G[k] = fma2(dy[k], wv[k], G[k]);
-            wacc[t][k] = fma2(dy[k], a[k], wacc[t][k]);
+            if (!(TTK_BC_DBG & 128)) wacc[t][k] = fma2(dy[k], a[k], wacc[t][k]);
           }
         }
         if (!LEAN && skip_grad) {
@@ -644,10 +664,10 @@ int ttk_bc_dw_fwd(const void* yprev, const float* bn_prev, const void* skip_prev
   const Tiling t = tiling(B, H, W, C, stride, false);
   TTK_REQUIRE((int64_t)((B + t.NI - 1) / t.NI) * t.nbands * t.NCT < ((int64_t)1 << 31) && (int64_t)B * H * W * t.SL < ((int64_t)1 << 32), "bc_dw_fwd: too large for 32-bit indexing");
   const int stage_pix = t.NI * t.stage_rows * ((t.NCT > 1 ? t.TW : W) + 2);
-  const size_t sm = (size_t)stage_pix * t.SL * 2 + (size_t)(9 + 8) * t.SL * sizeof(float);
+  const size_t sm = (size_t)stage_pix * t.SL * 2 + (size_t)(9 + 2 * kWvs) * t.SL * sizeof(float);
 #define TTK_BC_FWD3(S_, SK_, SL_, CY_)                                                                                                            \
   allow_big_lds<bc_dw_fwd_k<S_, SK_, SL_, CY_>>();                                                                                                \
-  hipLaunchKernelGGL((bc_dw_fwd_k<S_, SK_, SL_, CY_>), dim3(t.grid), dim3(kBlock), sm, (hipStream_t)stream, (const bf16_t*)yprev, bn_prev,          \
+  hipLaunchKernelGGL((bc_dw_fwd_k<S_, SK_, SL_, CY_>), dim3(t.grid), dim3(bc::kBlock), sm, (hipStream_t)stream, (const bf16_t*)yprev, bn_prev,          \
                      (const bf16_t*)skip_prev, (bf16_t*)a_out, w, (bf16_t*)y, part, pivot, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI, t.NCT, t.TW, stage_pix)
 #define TTK_BC_FWD2(S_, SK_, SL_) do { if (t.carry) { TTK_BC_FWD3(S_, SK_, SL_, true); } else { TTK_BC_FWD3(S_, SK_, SL_, false); } } while (0)
 #define TTK_BC_FWD1(S_, SK_) do { if (t.SL == 64) TTK_BC_FWD2(S_, SK_, 64); else TTK_BC_FWD2(S_, SK_, 32); } while (0)
@@ -669,14 +689,14 @@ int ttk_bc_dw_bwd_data(const void* g_dw, const void* y_dw, const float* bn_dw, c
   const Tiling t = tiling(B, H, W, C, stride, true);
   TTK_REQUIRE((int64_t)((B + t.NI - 1) / t.NI) * t.nbands * t.NCT < ((int64_t)1 << 31) && (int64_t)B * H * W * t.SL < ((int64_t)1 << 32), "bc_dw_bwd_data: too large for 32-bit indexing");
   const int stage_pix = t.NI * t.stage_rows * ((t.NCT > 1 ? t.TW : Wo) + 2);
-  const size_t sm = (size_t)stage_pix * t.SL * 2 + (size_t)(9 + 4 * 9 + 6) * t.SL * sizeof(float);
+  const size_t sm = (size_t)stage_pix * t.SL * 2 + (size_t)(9 + kWvs * 9 + 6) * t.SL * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (!dw) dw_partial = nullptr;
   if (dw && !dw_accumulate && !dw_partial) (void)hipMemsetAsync(dw, 0, (size_t)9 * C * sizeof(float), st);
 #define TTK_BC_BWD3(S_, SL_, LEAN_)                                                                                                               \
   do {                                                                                                                                            \
     allow_big_lds<bc_dw_bwd_k<S_, SL_, LEAN_>>();                                                                                                \
-    hipLaunchKernelGGL((bc_dw_bwd_k<S_, SL_, LEAN_>), dim3(t.grid), dim3(kBlock), sm, st, (const bf16_t*)g_dw, (const bf16_t*)y_dw, bn_dw, w,      \
+    hipLaunchKernelGGL((bc_dw_bwd_k<S_, SL_, LEAN_>), dim3(t.grid), dim3(bc::kBlock), sm, st, (const bf16_t*)g_dw, (const bf16_t*)y_dw, bn_dw, w,      \
                        (const bf16_t*)skip_grad, (const bf16_t*)yprev, bn_prev, (const bf16_t*)skip_prev, (const bf16_t*)a_in, (bf16_t*)g_prev, part, dw, \
                        dw_partial, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, stage_pix, t.NI, t.NCT, t.TW);                                     \
   } while (0)
