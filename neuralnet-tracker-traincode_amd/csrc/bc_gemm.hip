@@ -19,7 +19,7 @@
 #include "bc_common.h"
 
 // Timing-only bits of bc_gemm_l_k's main loop (experiment builds: tools/exp/build_variants.sh ... "-DTTK_BC_GDBG=<bits>"; wrong results):
-//   1 no MFMAs   2 no global loads   4 no operand staging (BatchNorm map + LDS stores)   8 no fragment reads
+//   1 no MFMAs   2 no global loads   4 no operand staging (BatchNorm map + LDS stores)   8 no fragment reads   16 no epilogue (mask loads, stores, sums)
 #ifndef TTK_BC_GDBG
 #define TTK_BC_GDBG 0
 #endif
@@ -258,8 +258,6 @@ __global__ void __launch_bounds__(512) bc_gemm_l_k(const bf16_t* __restrict__ A0
   if (rt >= nrt) return;
   const int n0 = ct * 256;
   const int64_t p0 = (int64_t)rt * RT, pend = (p0 + RT < M) ? p0 + RT : M;
-  fill_cA<MODE>(cA, bnA, K, tid, 512);
-  fill_cE<MODE>(cE, pivot, bnE, N, n0, 256, tid, 512);
   const int nkb = K / 64, klast = nkb - 1;
   // staging role: chunk column `oct` (channels 8 oct .. + 7 of the k64 block) of pixels (tid >> 3) + 64 i
   const int oct = tid & 7;
@@ -296,9 +294,12 @@ __global__ void __launch_bounds__(512) bc_gemm_l_k(const bf16_t* __restrict__ A0
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.f;
-  __syncthreads();  // constants are in LDS
+  // (the first step's operands are requested before the constants; measured: no difference to the other order, profiles/r05_bc_gemm_variants.txt)
 #pragma unroll
   for (int i = 0; i < 4; ++i) load_chunk(0, i);
+  fill_cA<MODE>(cA, bnA, K, tid, 512);
+  fill_cE<MODE>(cE, pivot, bnE, N, n0, 256, tid, 512);
+  __syncthreads();  // constants are in LDS
 #pragma unroll
   for (int i = 0; i < 4; ++i) store_chunk(0, 0, i);
   __builtin_amdgcn_sched_barrier(0);
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__(512) bc_gemm_l_k(const bf16_t* __restrict__ A0
   const int o8 = lane & 7;
   uint4 mk[2][4];
   auto load_mask = [&](int q4, uint4(&d)[4]) {  // q4 = 2 * (local channel block) + pixel group
-    if constexpr (MODE == kDgrad) {
+    if constexpr (MODE == kDgrad && !(TTK_BC_GDBG & 16)) {
       const int cb = n0 / 64 + 2 * wc + (q4 >> 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -360,6 +361,7 @@ __global__ void __launch_bounds__(512) bc_gemm_l_k(const bf16_t* __restrict__ A0
       const int q4 = 2 * cbl + j;
       if (q4 + 1 < 4) load_mask(q4 + 1, mk[(q4 + 1) & 1]);
       const int64_t g0 = p0 + 64 * wp + 32 * j;
+      if ((TTK_BC_GDBG & 16) && acc[j][2 * cbl][0] != 12345.f) continue;  // (timing only: no epilogue)
       if (g0 < pend)
         store_block<MODE, 64>(acc[j] + 2 * cbl, mystg, out + ((size_t)cb * M + g0) * 64, mk[q4 & 1], cE + 64 * (2 * wc + cbl), 256, g0, pend, s1, s2);
     }
