@@ -178,7 +178,11 @@ __global__ void __launch_bounds__(512) bc_wgrad_k(const bf16_t* __restrict__ G, 
         for (int e = 0; e < 16; ++e) {
           const int row = n0 + (wn * BN + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
           const int col = k0 + (wk * BK + j) * 32 + r;
+#if defined(TTK_BC_WGRAD_ATOMIC)  // (experiment builds: float atomics straight into dW instead of slice tiles + fold; `partial` = dW)
+          unsafeAtomicAdd(partial + (size_t)row * Cin + col, acc[i][j][e]);
+#else
           dst[(size_t)row * Cin + col] = acc[i][j][e];
+#endif
         }
   }
 }
@@ -227,6 +231,11 @@ static bool wgrad_plan(int64_t M, int Cin, int Cout, WPlan& p) {
 
 using namespace ttk;
 using namespace ttk::bc;
+#if defined(TTK_BC_WGRAD_ATOMIC)
+#define TTK_BC_WGRAD_DST dw
+#else
+#define TTK_BC_WGRAD_DST scratch
+#endif
 
 extern "C" {
 
@@ -249,7 +258,7 @@ int ttk_bc_pw_bwd_weight(const void* g, const void* y, const float* bn_pw, const
     constexpr size_t red = KS_ > 1 ? (size_t)8 * (TN32_ / WN_) * (TK32_ / WK_) * 16 * 64 * 4 : 0;                                               \
     allow_big_lds<bc_wgrad_k<TN32_, TK32_, CP_, WN_, WK_, KS_>>();                                                                              \
     hipLaunchKernelGGL((bc_wgrad_k<TN32_, TK32_, CP_, WN_, WK_, KS_>), dim3(grid), dim3(512), sm > red ? sm : red, st, (const bf16_t*)g, (const bf16_t*)y, bn_pw, \
-                       (const bf16_t*)ydw, bn_dw, scratch, M, Cin, Cout, p.rows, p.tiles);                                                      \
+                       (const bf16_t*)ydw, bn_dw, TTK_BC_WGRAD_DST, M, Cin, Cout, p.rows, p.tiles);                                                      \
   } while (0)
   if (p.TN == 64) TTK_BC_WG(2, 1, 128, 2, 1, 4);
   else if (p.TN == 128 && p.TK == 64) TTK_BC_WG(4, 2, 64, 4, 2, 1);
@@ -257,9 +266,11 @@ int ttk_bc_pw_bwd_weight(const void* g, const void* y, const float* bn_pw, const
   else if (p.TK == 128) TTK_BC_WG(8, 4, 32, 4, 2, 1);
   else TTK_BC_WG(8, 8, 32, 4, 2, 1);
 #undef TTK_BC_WG
+#if !defined(TTK_BC_WGRAD_ATOMIC)
   const int64_t n = (int64_t)Cin * Cout;
   if (!launch_fold_rows_fast(scratch, (int)p.slices, n, dw, 1, st))
     hipLaunchKernelGGL(bc_wgrad_fold_k, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, st, scratch, dw, n, (int)p.slices);
+#endif
   TTK_LAUNCH_CHECK("bc_pw_bwd_weight");
 }
 

@@ -30,3 +30,72 @@ def _fixed_cpu_threads():
 
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     yield
+
+
+class _WalkWorkers:
+    """The six CPU-oracle walks of tests/test_teacher_forced_gpu.py and tests/test_trajectory_gpu.py (each a worker process: 5 - 10 optimiser
+    steps of the fp32 AND the float64 oracle at B = 256, 50 - 70 s of host time, a few seconds of GPU time) run side by side instead of one
+    after the other: the first test that asks for its result starts the workers of EVERY such test selected in this session (<= 6 x 32 host
+    threads; the boxes have 256), then waits for its own.  Nothing about a worker changes - same script, arguments, environment, assertions."""
+
+    def __init__(self, session):
+        self._session, self._procs, self._tmp = session, {}, None
+
+    @staticmethod
+    def argv(kind, *args):
+        script = {"trajectory": "_trajectory_worker.py", "teacher": "_teacher_forced_worker.py"}[kind]
+        return [sys.executable, os.path.join(REPO, "tests", script), REPO, *[str(a) for a in args]]
+
+    def _selected(self):
+        jobs = []
+        for item in self._session.items:
+            fn = getattr(item, "function", None)
+            spec = getattr(fn, "walk_job", None)
+            if spec is not None and hasattr(item, "callspec"):
+                jobs.append(spec(**{k: v for k, v in item.callspec.params.items()}))
+        return jobs
+
+    def _start(self, job):
+        import subprocess
+        import tempfile
+
+        if job in self._procs:
+            return
+        if self._tmp is None:
+            self._tmp = tempfile.mkdtemp(prefix="ttk_walks_")
+        base = os.path.join(self._tmp, str(len(self._procs)))
+        out, err = open(base + ".out", "w+"), open(base + ".err", "w+")
+        env = dict(os.environ, TTK_DETERMINISTIC="1")
+        self._procs[job] = (subprocess.Popen(self.argv(*job), env=env, stdout=out, stderr=err, text=True), out, err)
+
+    def result(self, job, timeout=3000):
+        import json
+
+        for j in [job] + [j for j in self._selected() if j != job]:
+            self._start(j)
+        proc, out, err = self._procs[job]
+        rc = proc.wait(timeout=timeout)
+        err.seek(0)
+        assert rc == 0, err.read()[-3000:]
+        out.seek(0)
+        line = [l for l in out.read().splitlines() if l.startswith("RESULT ")][-1]
+        return json.loads(line[len("RESULT "):])
+
+    def close(self):
+        import shutil
+
+        for proc, out, err in self._procs.values():
+            if proc.poll() is None:
+                proc.kill()  # (the exact child this fixture started)
+                proc.wait()
+            out.close()
+            err.close()
+        if self._tmp is not None:
+            shutil.rmtree(self._tmp, ignore_errors=True)
+
+
+@pytest.fixture(scope="session")
+def walk_workers(request):
+    w = _WalkWorkers(request.session)
+    yield w
+    w.close()

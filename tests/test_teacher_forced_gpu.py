@@ -17,10 +17,7 @@ Tolerances (north_star: per-step losses within 1e-3):
   and exp_avg within 1e-4 absolute (measured 3e-5);
   parameters after the update: never further than 2 lr from the oracle's (an element whose gradient is rounding noise around zero moves
   +-lr in either implementation: Adam's update is lr * m / (sqrt(v) + eps)) - printed, and asserted as that bound."""
-import json
 import os
-import subprocess
-import sys
 
 import pytest
 
@@ -30,12 +27,8 @@ K = 10
 
 
 @pytest.mark.parametrize("cfg", ["default", "full"])
-def test_ten_teacher_forced_steps_at_the_full_learning_rate(cfg):
-    env = dict(os.environ, TTK_DETERMINISTIC="1")
-    out = subprocess.run([sys.executable, os.path.join(REPO, "tests", "_teacher_forced_worker.py"), REPO, cfg, "256", str(K), "150"], env=env, capture_output=True,
-                         text=True, timeout=3000)
-    assert out.returncode == 0, out.stderr[-3000:]
-    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
+def test_ten_teacher_forced_steps_at_the_full_learning_rate(cfg, walk_workers):
+    r = walk_workers.result(("teacher", cfg, 256, K, 150))  # (tests/conftest.py: the walks of this session run side by side)
     f = lambda xs: "[" + " ".join("%.1e" % x for x in xs) + "]"
     print(f"cfg={cfg} lr={r['lr']:.3g}: loss oracle {['%.5f' % x for x in r['loss_oracle']]}\n  |dloss| {f(r['dloss'])}\n  per-sample {f(r['dsample'])}\n"
           f"  running stats {f(r['running_rel'])}\n  grad norm rel {f(r['dgnorm_rel'])}\n  exp_avg rel {f(r['m_rel'])} abs {f(r['m_abs'])} ({r['worst_m'][-1]})\n"
@@ -53,3 +46,6 @@ def test_ten_teacher_forced_steps_at_the_full_learning_rate(cfg):
         assert r["m_l2_worst"][t] < 2e-2 and r["m_abs"][t] < 1e-4, (t, r["m_l2_worst"], r["m_abs"], r["worst_m"][t])
         assert r["v_l2_worst"][t] < 3e-2, (t, r["v_l2_worst"])
         assert r["param_over_lr"][t] <= 2.02, (t, r["param_over_lr"])
+
+
+test_ten_teacher_forced_steps_at_the_full_learning_rate.walk_job = lambda cfg: ("teacher", cfg, 256, K, 150)

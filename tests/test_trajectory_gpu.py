@@ -22,10 +22,7 @@ So the yardstick is measured in the same run - fp32 oracle walk vs float64 oracl
 Two schedule positions: the first steps of the training script's default run (ExponentialUpThenSteps over 200 epochs, epoch 0:
 lr 1.26e-5 - there loss_sum must ALSO stay within 1e-3 of the fp32 oracle at every step, measured 3e-5) and the full learning
 rate 1e-3 past the warm-up.  All distances are printed."""
-import json
 import os
-import subprocess
-import sys
 
 import pytest
 
@@ -40,13 +37,8 @@ K = 5
 YARD = 4
 
 
-def _walk(cfg, B, epoch, lr_epochs, lr_epoch, f64):
-    env = dict(os.environ, TTK_DETERMINISTIC="1")
-    out = subprocess.run([sys.executable, os.path.join(REPO, "tests", "_trajectory_worker.py"), REPO, cfg, str(B), str(K), str(epoch), str(lr_epochs), str(lr_epoch),
-                          "f64" if f64 else "nof64"], env=env, capture_output=True, text=True, timeout=2400)
-    assert out.returncode == 0, out.stderr[-3000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
-    return json.loads(line[len("RESULT "):])
+def _job(cfg, B, epoch, lr_epochs, lr_epoch, f64):
+    return ("trajectory", cfg, B, K, epoch, lr_epochs, lr_epoch, "f64" if f64 else "nof64")
 
 
 def _fmt(xs):
@@ -83,8 +75,8 @@ def _check_against_yardstick(r):
 
 
 @pytest.mark.parametrize("cfg", ["default", "full"])
-def test_first_five_steps_of_the_default_schedule(cfg):
-    r = _walk(cfg, 256, 150, 200, 0, True)
+def test_first_five_steps_of_the_default_schedule(cfg, walk_workers):
+    r = walk_workers.result(_job(cfg, 256, 150, 200, 0, True))  # (tests/conftest.py: the walks of this session run side by side)
     _report(r)
     assert abs(r["lr"] - 1.2589e-5) < 1e-8
     _check_against_yardstick(r)
@@ -92,9 +84,15 @@ def test_first_five_steps_of_the_default_schedule(cfg):
         assert r["dloss"][it] < 1e-3, (it, r["dloss"])
 
 
+test_first_five_steps_of_the_default_schedule.walk_job = lambda cfg: _job(cfg, 256, 150, 200, 0, True)
+
+
 @pytest.mark.parametrize("cfg", ["default", "full"])
-def test_five_steps_at_the_full_learning_rate(cfg):
-    r = _walk(cfg, 256, 150, 20, 5, True)
+def test_five_steps_at_the_full_learning_rate(cfg, walk_workers):
+    r = walk_workers.result(_job(cfg, 256, 150, 20, 5, True))
     _report(r)
     assert abs(r["lr"] - 1.0e-3) < 1e-12
     _check_against_yardstick(r)
+
+
+test_five_steps_at_the_full_learning_rate.walk_job = lambda cfg: _job(cfg, 256, 150, 20, 5, True)
