@@ -10,6 +10,8 @@
 //                                                     the second partial sum from the raw ydw tile in LDS
 // four passes (three reads, one write).  A workgroup owns one slice of the pixels (tile = the whole Cout x Cin matrix); it stores its dW
 // to partial[slice] (folded in a fixed order) and one row of BatchNorm-backward partial sums.
+#include <type_traits>
+
 #include "bc_common.h"
 
 namespace ttk {
@@ -56,32 +58,38 @@ __global__ void __launch_bounds__(512) bc_bwd_fused_k(const bf16_t* __restrict__
   }
   constexpr int wo = TN < 64 ? TN : 64, wi = TK < 64 ? TK : 64;
   const size_t gbase = (size_t)((8 * on) / wo) * M * wo + ((8 * on) % wo), xbase = (size_t)((8 * ok) / wi) * M * wi + ((8 * ok) % wi);
-  u32x4 rg[IN], ry[IN], rx[IK];
-  auto load = [&](int c) {
+  // two register sets: chunk k travels in set k & 1, so chunks c + 2 AND c + 3 are in flight while chunk c is multiplied (one set = 32 - 48 KB per
+  // CU in flight held the 128 -> 128 layer at 0.50 of 8 TB/s)
+  u32x4 rg[2][IN], ry[2][IN], rx[2][IK];
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  auto load = [&](int c, auto rset) {
+    constexpr int st = decltype(rset)::value;
     const int64_t mb = m_begin + (int64_t)c * CP;
 #pragma unroll
     for (int i = 0; i < IN; ++i) {
       int64_t m = mb + (tid + 512 * i) / ON;
       m = m < m_end ? m : m_end - 1;
-      rg[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(G + gbase + (size_t)m * wo));
-      ry[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Y + gbase + (size_t)m * wo));
+      rg[st][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(G + gbase + (size_t)m * wo));
+      ry[st][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Y + gbase + (size_t)m * wo));
     }
 #pragma unroll
     for (int i = 0; i < IK; ++i) {
       int64_t m = mb + (tid + 512 * i) / OK;
       m = m < m_end ? m : m_end - 1;
-      rx[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(X + xbase + (size_t)m * wi));
+      rx[st][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(X + xbase + (size_t)m * wi));
     }
   };
-  auto store_to = [&](int c, int slot) {
+  auto store_to = [&](int c, int slot, auto rset) {
+    constexpr int st = decltype(rset)::value;
     unsigned char* buf = lds + slot * kBuf;
     const int64_t mb = m_begin + (int64_t)c * CP;
 #pragma unroll
     for (int i = 0; i < IN; ++i) {
       const int px = (tid + 512 * i) / ON;
       float g[8], y[8], v[8];
-      unpack8(make_uint4(rg[i].x, rg[i].y, rg[i].z, rg[i].w), g);
-      unpack8(make_uint4(ry[i].x, ry[i].y, ry[i].z, ry[i].w), y);
+      unpack8(make_uint4(rg[st][i].x, rg[st][i].y, rg[st][i].z, rg[st][i].w), g);
+      unpack8(make_uint4(ry[st][i].x, ry[st][i].y, ry[st][i].z, ry[st][i].w), y);
       const bool live = mb + px < m_end;  // pixels past the slice contribute nothing
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = live ? fmaf(ga[j], g[j], fmaf(gb[j], y[j], c0[j])) : 0.f;
@@ -91,7 +99,7 @@ __global__ void __launch_bounds__(512) bc_bwd_fused_k(const bf16_t* __restrict__
     for (int i = 0; i < IK; ++i) {
       const int px = (tid + 512 * i) / OK;
       float x[8], v[8];
-      const uint4 xr = make_uint4(rx[i].x, rx[i].y, rx[i].z, rx[i].w);
+      const uint4 xr = make_uint4(rx[st][i].x, rx[st][i].y, rx[st][i].z, rx[st][i].w);
       unpack8(xr, x);
       const bool live = mb + px < m_end;
 #pragma unroll
@@ -131,11 +139,12 @@ __global__ void __launch_bounds__(512) bc_bwd_fused_k(const bf16_t* __restrict__
   __syncthreads();  // weight image and constants are in LDS
   if (nchunks > 0) {
     const int clast = nchunks - 1;
-    load(0);
-    store_to(0, 0);
-    load(min(1, clast));
+    load(0, S0{});
+    store_to(0, 0, S0{});
+    load(min(1, clast), S1{});
+    load(min(2, clast), S0{});
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
+    auto step = [&](int c, auto snext) {  // snext: the register set of chunk c + 1
       const unsigned char* buf = lds + (c & 1) * kBuf;
 #pragma unroll
       for (int ks = 0; ks < CP / 16; ++ks) {
@@ -176,9 +185,13 @@ __global__ void __launch_bounds__(512) bc_bwd_fused_k(const bf16_t* __restrict__
         const int64_t g0 = m_begin + (int64_t)c * CP + 32 * upg;
         if (g0 < m_end) store_block<kDgrad, OC>(gd, mystg, gdw + ((size_t)ucb * M + g0) * OC, mk, cE + ucb * OC, TK, g0, m_end, s1, s2);
       }
-      store_to(min(c + 1, clast), (c + 1) & 1);  // (the other buffer: last read in step c - 1, every wave has passed the barrier since)
-      load(min(c + 2, clast));
+      store_to(min(c + 1, clast), (c + 1) & 1, snext);  // (the other buffer: last read in step c - 1, every wave has passed the barrier since)
+      load(min(c + 3, clast), snext);
       __syncthreads();
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+      step(c, S1{});
+      if (c + 1 < nchunks) step(c + 1, S0{});
     }
   }
   // ---- partial sums of the data gradient: lanes of one chunk column, then the waves of a channel block (fixed order)
