@@ -482,44 +482,48 @@ def main():
     # kernel to the completion of the last collective, i.e. how long the optimiser waited for the exchange; max over the ranks.
     comm = None
     if reducer is not None:
-        ranks = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-        dist.all_gather(ranks, torch.tensor([rank], dtype=torch.int64, device=device))
-        world_seen = len({int(t.item()) for t in ranks})
-        comm_steps = max(1, min(args.steps, 5))
-        reducer.measure = True
-        for _ in range(comm_steps):
-            step()
-        sync()
-        reducer.measure = False
-        tm = reducer.collect_timing()
-        n = max(tm["steps"], 1)
-        stats = torch.tensor([tm["exposed_ms"] / n, tm["allreduce_ms_sum"] / n, tm["host_wait_ms_sum"] / n], dtype=torch.float64, device=device)
-        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-        comm = {"world_seen": world_seen, "backend": args.dist_backend, "buckets": tm["buckets"] // n, "bytes_per_step": tm["bytes"] // n,
-                "bucket_bytes": reducer.bucket_bytes, "exposed_ms": float(stats[0]), "allreduce_ms_sum": float(stats[1]), "host_wait_ms_sum": float(stats[2]),
-                "steps": comm_steps,
-                "note": "exposed_ms = end of backward's last kernel -> last collective done (HIP events, main stream), allreduce_ms_sum = sum over the "
-                        "buckets of (range final -> collective done) on the side stream, both per step, max over ranks; host_wait_ms_sum: host time "
-                        "inside the collective calls (non-zero where the backend blocks the host: gloo)"}
-        if args.comm_only:
-            # the same buckets on their own: buffers of the sizes just seen, all-reduced in place back to back, nothing else on the GPU
-            sizes = reducer.last_bucket_bytes or [tm["bytes"] // n]
-            bufs = [torch.zeros(max(b // 4, 1), dtype=torch.float32, device=device) for b in sizes]
-            for _ in range(3):
-                for b in bufs:
-                    dist.all_reduce(b)
+        try:  # (diagnostics only: `value` is already measured - a failure here must not cost the line)
+            ranks = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+            dist.all_gather(ranks, torch.tensor([rank], dtype=torch.int64, device=device))
+            world_seen = len({int(t.item()) for t in ranks})
+            comm_steps = max(1, min(args.steps, 5))
+            reducer.measure = True
+            for _ in range(comm_steps):
+                step()
             sync()
-            t2 = time.perf_counter()
-            for _ in range(args.steps):
-                for b in bufs:
-                    dist.all_reduce(b)
-            sync()
-            co = torch.tensor([(time.perf_counter() - t2) / args.steps * 1e3], dtype=torch.float64, device=device)
-            dist.all_reduce(co, op=dist.ReduceOp.MAX)
-            tot = sum(sizes)
-            comm["comm_only"] = {"ms_per_step": float(co[0]), "buckets": len(sizes), "bytes": tot,
-                                 "busbw_GBs": tot * 2 * (world - 1) / world / (float(co[0]) * 1e-3) / 1e9 if float(co[0]) > 0 else None,
-                                 "note": "bucketed all-reduce alone, back to back on the default stream; busbw = bytes * 2 (N-1)/N / time"}
+            reducer.measure = False
+            tm = reducer.collect_timing()
+            n = max(tm["steps"], 1)
+            stats = torch.tensor([tm["exposed_ms"] / n, tm["allreduce_ms_sum"] / n, tm["host_wait_ms_sum"] / n], dtype=torch.float64, device=device)
+            dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+            comm = {"world_seen": world_seen, "backend": args.dist_backend, "buckets": tm["buckets"] // n, "bytes_per_step": tm["bytes"] // n,
+                    "bucket_bytes": reducer.bucket_bytes, "exposed_ms": float(stats[0]), "allreduce_ms_sum": float(stats[1]), "host_wait_ms_sum": float(stats[2]),
+                    "steps": comm_steps,
+                    "note": "exposed_ms = end of backward's last kernel -> last collective done (HIP events, main stream), allreduce_ms_sum = sum over the "
+                            "buckets of (range final -> collective done) on the side stream, both per step, max over ranks; host_wait_ms_sum: host time "
+                            "inside the collective calls (non-zero where the backend blocks the host: gloo)"}
+            if args.comm_only:
+                # the same buckets on their own: buffers of the sizes just seen, all-reduced in place back to back, nothing else on the GPU
+                sizes = reducer.last_bucket_bytes or [tm["bytes"] // n]
+                bufs = [torch.zeros(max(b // 4, 1), dtype=torch.float32, device=device) for b in sizes]
+                for _ in range(3):
+                    for b in bufs:
+                        dist.all_reduce(b)
+                sync()
+                t2 = time.perf_counter()
+                for _ in range(args.steps):
+                    for b in bufs:
+                        dist.all_reduce(b)
+                sync()
+                co = torch.tensor([(time.perf_counter() - t2) / args.steps * 1e3], dtype=torch.float64, device=device)
+                dist.all_reduce(co, op=dist.ReduceOp.MAX)
+                tot = sum(sizes)
+                comm["comm_only"] = {"ms_per_step": float(co[0]), "buckets": len(sizes), "bytes": tot,
+                                     "busbw_GBs": tot * 2 * (world - 1) / world / (float(co[0]) * 1e-3) / 1e9 if float(co[0]) > 0 else None,
+                                     "note": "bucketed all-reduce alone, back to back on the default stream; busbw = bytes * 2 (N-1)/N / time"}
+        except Exception as e:  # noqa: BLE001
+            reducer.measure = False
+            comm = {"error": f"{type(e).__name__}: {e}"[:300]}
     # optimiser step alone (already inside `value`; reported for reference)
     sync()
     t1 = time.perf_counter()
