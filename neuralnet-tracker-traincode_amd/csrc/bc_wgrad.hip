@@ -10,6 +10,12 @@
 // of float atomics on one tile would cost more than the plain stores and the fold).
 #include "bc_common.h"
 
+// Timing-only bits (experiment builds: tools/exp/build_variants.sh ... "-DTTK_BC_WDBG=<bits>"; wrong results):
+//   1 no MFMAs   2 no global loads   4 no staging (BatchNorm maps + LDS stores)   8 no fragment reads   16 no tile stores
+#ifndef TTK_BC_WDBG
+#define TTK_BC_WDBG 0
+#endif
+
 namespace ttk {
 namespace bc {
 
@@ -55,6 +61,13 @@ __global__ void __launch_bounds__(512) bc_wgrad_k(const bf16_t* __restrict__ G, 
   const size_t gbase = (size_t)(cn / wo) * M * wo + (cn % wo), xbase = (size_t)(ck / wi) * M * wi + (ck % wi);
   uint4 rg[IN], ry[IN], rx[IK];
   auto load = [&](int c) {
+    if (TTK_BC_WDBG & 2) {
+#pragma unroll
+      for (int i = 0; i < IN; ++i) rg[i] = ry[i] = make_uint4(c, i, tid, 1);
+#pragma unroll
+      for (int i = 0; i < IK; ++i) rx[i] = make_uint4(c, i, tid, 2);
+      return;
+    }
     const int64_t mb = m_begin + (int64_t)c * CP;
 #pragma unroll
     for (int i = 0; i < IN; ++i) {
@@ -71,6 +84,10 @@ __global__ void __launch_bounds__(512) bc_wgrad_k(const bf16_t* __restrict__ G, 
     }
   };
   auto store_to = [&](int c, int slot) {
+    if (TTK_BC_WDBG & 4) {
+      asm volatile("" ::"v"(rg[0].x), "v"(ry[0].x), "v"(rx[0].x));
+      return;
+    }
     unsigned char* buf = lds + slot * kBuf;
     const int64_t mb = m_begin + (int64_t)c * CP;
 #pragma unroll
@@ -129,13 +146,16 @@ __global__ void __launch_bounds__(512) bc_wgrad_k(const bf16_t* __restrict__ G, 
         if (ks % KS != wsub) continue;
         bf16x8 a[BN], b[BK];
 #pragma unroll
-        for (int i = 0; i < BN; ++i) a[i] = tr_frag(buf, aoff[i] + ks * 16 * PN, PN);
+        for (int i = 0; i < BN; ++i) a[i] = (TTK_BC_WDBG & 8) ? __builtin_bit_cast(bf16x8, make_uint4(c, ks, i, lane)) : tr_frag(buf, aoff[i] + ks * 16 * PN, PN);
 #pragma unroll
-        for (int j = 0; j < BK; ++j) b[j] = tr_frag(buf, boff[j] + ks * 16 * PK, PK);
+        for (int j = 0; j < BK; ++j) b[j] = (TTK_BC_WDBG & 8) ? __builtin_bit_cast(bf16x8, make_uint4(c, ks, j, lane)) : tr_frag(buf, boff[j] + ks * 16 * PK, PK);
 #pragma unroll
         for (int i = 0; i < BN; ++i)
 #pragma unroll
-          for (int j = 0; j < BK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < BK; ++j) {
+            if (TTK_BC_WDBG & 1) { acc[i][j][0] += __uint_as_float(__builtin_bit_cast(uint4, a[i]).x ^ __builtin_bit_cast(uint4, b[j]).y); continue; }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          }
       }
       store_to(min(c + 1, clast), (c + 1) & 1);  // (the other buffer: last read in step c - 1, every wave has passed the barrier since)
       load(min(c + 2, clast));
@@ -169,7 +189,7 @@ __global__ void __launch_bounds__(512) bc_wgrad_k(const bf16_t* __restrict__ G, 
           }
     }
   }
-  if (wsub == 0) {
+  if (wsub == 0 && !((TTK_BC_WDBG & 16) && acc[0][0][0] != 12345.f)) {
 #pragma unroll
     for (int i = 0; i < BN; ++i)
 #pragma unroll
