@@ -58,6 +58,43 @@ __device__ __forceinline__ unsigned relu_pk(unsigned v) {
   return __builtin_bit_cast(unsigned, r);
 }
 
+// ---- channel pairs in packed fp32 (v_pk_fma_f32) -------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+// widen a 16-byte chunk into four channel pairs
+__device__ __forceinline__ void unpack_f2(uint4 u, f2 (&v)[4]) {
+  v[0] = f2{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)};
+  v[1] = f2{__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+  v[2] = f2{__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u)};
+  v[3] = f2{__uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+}
+__device__ __forceinline__ uint4 pack_f2(const f2 (&v)[4]) {
+  return make_uint4(pack2(v[0].x, v[0].y), pack2(v[1].x, v[1].y), pack2(v[2].x, v[2].y), pack2(v[3].x, v[3].y));
+}
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ void ld8(const float* p, f2 (&v)[4]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = f2{a.x, a.y}; v[1] = f2{a.z, a.w}; v[2] = f2{b.x, b.y}; v[3] = f2{b.z, b.w};
+}
+// operand chunks of the pixel-contraction kernels (weight gradient, fused backward): 8 channels of one pixel
+//   dy = bf16(ga*g + (gb*y + c0));   a = relu(bf16(scale*x + shift))  (= bf16(relu(.)): rounding keeps sign and zero)
+__device__ __forceinline__ uint4 dy_chunk(u32x4 g, u32x4 y, const f2 (&ga)[4], const f2 (&gb)[4], const f2 (&c0)[4]) {
+  f2 gg[4], yy[4];
+  unpack_f2(make_uint4(g.x, g.y, g.z, g.w), gg);
+  unpack_f2(make_uint4(y.x, y.y, y.z, y.w), yy);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) gg[k] = fma2(ga[k], gg[k], fma2(gb[k], yy[k], c0[k]));
+  return pack_f2(gg);
+}
+__device__ __forceinline__ uint4 act_chunk(u32x4 x, const f2 (&sc)[4], const f2 (&sh)[4]) {
+  f2 xx[4];
+  unpack_f2(make_uint4(x.x, x.y, x.z, x.w), xx);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) xx[k] = fma2(sc[k], xx[k], sh[k]);
+  uint4 p = pack_f2(xx);
+  p.x = relu_pk(p.x); p.y = relu_pk(p.y); p.z = relu_pk(p.z); p.w = relu_pk(p.w);
+  return p;
+}
+
 // kernels that declare more than 64 KB of dynamic LDS need the attribute once (per kernel instantiation)
 template <auto Kern>
 inline void allow_big_lds() {

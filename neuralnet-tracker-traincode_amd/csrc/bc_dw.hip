@@ -44,7 +44,6 @@
 namespace ttk {
 namespace bc {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kBlock = TTK_BC_BLOCK;  // (shadows ttk::kBlock inside this namespace)
 constexpr int kWvs = kBlock / kWave;
 
@@ -110,13 +109,6 @@ struct TileDiv {  // exact n / d for the tile-local indices (dwconv_tiled.hip)
   __device__ __forceinline__ unsigned div(unsigned n) const { return (unsigned)(((float)n + 0.5f) * inv); }
 };
 
-// widen a 16-byte chunk into four channel pairs
-__device__ __forceinline__ void unpack_f2(uint4 u, f2 (&v)[4]) {
-  v[0] = f2{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)};
-  v[1] = f2{__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
-  v[2] = f2{__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u)};
-  v[3] = f2{__uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
-}
 // timing-only (TTK_BC_DBG & 256): the tap operands are NOT widened (what an fp32 LDS tile would save in the tap loops; wrong results)
 __device__ __forceinline__ void unpack_tap(uint4 u, f2 (&v)[4]) {
   if (TTK_BC_DBG & 256) {
@@ -126,15 +118,6 @@ __device__ __forceinline__ void unpack_tap(uint4 u, f2 (&v)[4]) {
     unpack_f2(u, v);
   }
 }
-__device__ __forceinline__ uint4 pack_f2(const f2 (&v)[4]) {
-  return make_uint4(pack2(v[0].x, v[0].y), pack2(v[1].x, v[1].y), pack2(v[2].x, v[2].y), pack2(v[3].x, v[3].y));
-}
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ void ld8(const float* p, f2 (&v)[4]) {
-  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-  v[0] = f2{a.x, a.y}; v[1] = f2{a.z, a.w}; v[2] = f2{b.x, b.y}; v[3] = f2{b.z, b.w};
-}
-
 // per-channel sums of the workgroup -> part_row[0][c], part_row[1][c] (fixed wave order); lanes KQ apart own the same chunk
 template <int SL>
 __device__ __forceinline__ void slab_partials(f2 (&s1)[4], f2 (&s2)[4], int q, int C, int c_slab, float* part_row, float* red /* [4][2][SL] */) {

@@ -47,17 +47,29 @@ __global__ void __launch_bounds__(512) bc_bwd_fused_k(const bf16_t* __restrict__
 
   // ---- staging role (fixed chunk columns per thread: constants in registers)
   const int on = tid % ON, ok = tid % OK;
-  float ga[8], gb[8], c0[8], sc[8], sh[8];
+  f2 ga[4], gb[4], c0[4], sc[4], sh[4];
+  {
+    f2 gm[4], mu[4], be[4];
+    ld8(bn_pw + TTK_BN_GA * TN + 8 * on, ga);
+    ld8(bn_pw + TTK_BN_GB * TN + 8 * on, gb);
+    ld8(bn_pw + TTK_BN_GMEAN * TN + 8 * on, gm);
+    ld8(bn_pw + TTK_BN_MEAN * TN + 8 * on, mu);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    ga[j] = bn_pw[TTK_BN_GA * TN + 8 * on + j];
-    gb[j] = bn_pw[TTK_BN_GB * TN + 8 * on + j];
-    c0[j] = -ga[j] * bn_pw[TTK_BN_GMEAN * TN + 8 * on + j] - gb[j] * bn_pw[TTK_BN_MEAN * TN + 8 * on + j];
-    sc[j] = bn_x[TTK_BN_SCALE * TK + 8 * ok + j];
-    sh[j] = fmaf(-sc[j], bn_x[TTK_BN_MEAN * TK + 8 * ok + j], bn_x[TTK_BN_BETA * TK + 8 * ok + j]);
+    for (int k = 0; k < 4; ++k) c0[k] = -ga[k] * gm[k] - gb[k] * mu[k];
+    ld8(bn_x + TTK_BN_SCALE * TK + 8 * ok, sc);
+    ld8(bn_x + TTK_BN_MEAN * TK + 8 * ok, mu);
+    ld8(bn_x + TTK_BN_BETA * TK + 8 * ok, be);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sh[k] = fma2(-sc[k], mu[k], be[k]);
   }
   constexpr int wo = TN < 64 ? TN : 64, wi = TK < 64 ? TK : 64;
-  const size_t gbase = (size_t)((8 * on) / wo) * M * wo + ((8 * on) % wo), xbase = (size_t)((8 * ok) / wi) * M * wi + ((8 * ok) % wi);
+  // per-thread bases at the slice's first pixel; a chunk's pixels are (uniform chunk offset) + (fixed pixel of this thread): 32-bit arithmetic, one
+  // clamp against the slice's end (the loads of the last chunk stay inside the tensor; their values are zeroed by the `live` guard below)
+  constexpr int PXN = 512 / ON, PXK = 512 / OK;  // pixels between a thread's items
+  const int pn0 = tid / ON, pk0 = tid / OK, nrel = (int)(m_end - m_begin);
+  const bf16_t* Gb = G + (size_t)((8 * on) / wo) * M * wo + ((8 * on) % wo) + (size_t)m_begin * wo;
+  const bf16_t* Yb = Y + (size_t)((8 * on) / wo) * M * wo + ((8 * on) % wo) + (size_t)m_begin * wo;
+  const bf16_t* Xb = X + (size_t)((8 * ok) / wi) * M * wi + ((8 * ok) % wi) + (size_t)m_begin * wi;
   // two register sets: chunk k travels in set k & 1, so chunks c + 2 AND c + 3 are in flight while chunk c is multiplied (one set = 32 - 48 KB per
   // CU in flight held the 128 -> 128 layer at 0.50 of 8 TB/s)
   u32x4 rg[2][IN], ry[2][IN], rx[2][IK];
@@ -65,47 +77,36 @@ __global__ void __launch_bounds__(512) bc_bwd_fused_k(const bf16_t* __restrict__
   using S1 = std::integral_constant<int, 1>;
   auto load = [&](int c, auto rset) {
     constexpr int st = decltype(rset)::value;
-    const int64_t mb = m_begin + (int64_t)c * CP;
 #pragma unroll
     for (int i = 0; i < IN; ++i) {
-      int64_t m = mb + (tid + 512 * i) / ON;
-      m = m < m_end ? m : m_end - 1;
-      rg[st][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(G + gbase + (size_t)m * wo));
-      ry[st][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Y + gbase + (size_t)m * wo));
+      const unsigned rel = (unsigned)min(c * CP + i * PXN + pn0, nrel - 1);
+      rg[st][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Gb + rel * (unsigned)wo));
+      ry[st][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Yb + rel * (unsigned)wo));
     }
 #pragma unroll
     for (int i = 0; i < IK; ++i) {
-      int64_t m = mb + (tid + 512 * i) / OK;
-      m = m < m_end ? m : m_end - 1;
-      rx[st][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(X + xbase + (size_t)m * wi));
+      const unsigned rel = (unsigned)min(c * CP + i * PXK + pk0, nrel - 1);
+      rx[st][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Xb + rel * (unsigned)wi));
     }
   };
   auto store_to = [&](int c, int slot, auto rset) {
     constexpr int st = decltype(rset)::value;
     unsigned char* buf = lds + slot * kBuf;
-    const int64_t mb = m_begin + (int64_t)c * CP;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < IN; ++i) {
-      const int px = (tid + 512 * i) / ON;
-      float g[8], y[8], v[8];
-      unpack8(make_uint4(rg[st][i].x, rg[st][i].y, rg[st][i].z, rg[st][i].w), g);
-      unpack8(make_uint4(ry[st][i].x, ry[st][i].y, ry[st][i].z, ry[st][i].w), y);
-      const bool live = mb + px < m_end;  // pixels past the slice contribute nothing
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = live ? fmaf(ga[j], g[j], fmaf(gb[j], y[j], c0[j])) : 0.f;
-      st16(buf + px * PN + on * 16, pack8(v));
+      const int px = pn0 + i * PXN;
+      const bool live = c * CP + px < nrel;  // pixels past the slice contribute nothing
+      const uint4 d = dy_chunk(rg[st][i], ry[st][i], ga, gb, c0);
+      st16(buf + px * PN + on * 16, live ? d : zero);
     }
 #pragma unroll
     for (int i = 0; i < IK; ++i) {
-      const int px = (tid + 512 * i) / OK;
-      float x[8], v[8];
-      const uint4 xr = make_uint4(rx[st][i].x, rx[st][i].y, rx[st][i].z, rx[st][i].w);
-      unpack8(xr, x);
-      const bool live = mb + px < m_end;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = live ? fmaxf(fmaf(sc[j], x[j], sh[j]), 0.f) : 0.f;
-      st16(buf + CP * PN + px * PK + ok * 16, pack8(v));
-      st16(buf + CP * (PN + PK) + px * PK + ok * 16, xr);  // raw ydw: mask operand and second partial sum of the data gradient
+      const int px = pk0 + i * PXK;
+      const bool live = c * CP + px < nrel;
+      const uint4 a = act_chunk(rx[st][i], sc, sh);
+      st16(buf + CP * PN + px * PK + ok * 16, live ? a : zero);
+      st16(buf + CP * (PN + PK) + px * PK + ok * 16, make_uint4(rx[st][i].x, rx[st][i].y, rx[st][i].z, rx[st][i].w));  // raw ydw: mask operand and second partial sum of the data gradient
     }
   };
 

@@ -48,39 +48,49 @@ __global__ void __launch_bounds__(512) bc_wgrad_k(const bf16_t* __restrict__ G, 
   // ---- staging role: chunk `on` of the dy operand, chunk `ok` of the a operand (fixed per thread)
   const int on = tid % ON, ok = tid % OK;
   const int cn = n0 + 8 * on, ck = k0 + 8 * ok;
-  float ga[8], gb[8], c0[8], sc[8], sh[8];
+  f2 ga[4], gb[4], c0[4], sc[4], sh[4];
+  {
+    f2 gm[4], mu[4], be[4];
+    ld8(bn_pw + TTK_BN_GA * Cout + cn, ga);
+    ld8(bn_pw + TTK_BN_GB * Cout + cn, gb);
+    ld8(bn_pw + TTK_BN_GMEAN * Cout + cn, gm);
+    ld8(bn_pw + TTK_BN_MEAN * Cout + cn, mu);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    ga[j] = bn_pw[TTK_BN_GA * Cout + cn + j];
-    gb[j] = bn_pw[TTK_BN_GB * Cout + cn + j];
-    c0[j] = -ga[j] * bn_pw[TTK_BN_GMEAN * Cout + cn + j] - gb[j] * bn_pw[TTK_BN_MEAN * Cout + cn + j];
-    sc[j] = bn_x[TTK_BN_SCALE * Cin + ck + j];
-    sh[j] = fmaf(-sc[j], bn_x[TTK_BN_MEAN * Cin + ck + j], bn_x[TTK_BN_BETA * Cin + ck + j]);
+    for (int k = 0; k < 4; ++k) c0[k] = -ga[k] * gm[k] - gb[k] * mu[k];
+    ld8(bn_x + TTK_BN_SCALE * Cin + ck, sc);
+    ld8(bn_x + TTK_BN_MEAN * Cin + ck, mu);
+    ld8(bn_x + TTK_BN_BETA * Cin + ck, be);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sh[k] = fma2(-sc[k], mu[k], be[k]);
   }
-  const int wo = cbw(Cout), wi = cbw(Cin);
-  const size_t gbase = (size_t)(cn / wo) * M * wo + (cn % wo), xbase = (size_t)(ck / wi) * M * wi + (ck % wi);
-  uint4 rg[IN], ry[IN], rx[IK];
+  // per-thread bases at the slice's first pixel; a chunk's pixels are (uniform chunk offset) + (fixed pixel of this thread): 32-bit arithmetic, one
+  // clamp against the slice's end (the loads of the last chunk stay inside the tensor; their values are zeroed by the `live` guard below)
+  constexpr int wo = 64, wi = TK < 64 ? TK : 64;  // channels per block of the two tensors (TN >= 64)
+  constexpr int PXN = 512 / ON, PXK = 512 / OK;
+  const int pn0 = tid / ON, pk0 = tid / OK, nrel = (int)(m_end - m_begin);
+  const size_t goff = (size_t)(cn / wo) * M * wo + (cn % wo) + (size_t)m_begin * wo;
+  const bf16_t* Gb = G + goff;
+  const bf16_t* Yb = Y + goff;
+  const bf16_t* Xb = X + (size_t)(ck / wi) * M * wi + (ck % wi) + (size_t)m_begin * wi;
+  u32x4 rg[IN], ry[IN], rx[IK];
   auto load = [&](int c) {
     if (TTK_BC_WDBG & 2) {
 #pragma unroll
-      for (int i = 0; i < IN; ++i) rg[i] = ry[i] = make_uint4(c, i, tid, 1);
+      for (int i = 0; i < IN; ++i) rg[i] = ry[i] = u32x4{(unsigned)c, (unsigned)i, (unsigned)tid, 1u};
 #pragma unroll
-      for (int i = 0; i < IK; ++i) rx[i] = make_uint4(c, i, tid, 2);
+      for (int i = 0; i < IK; ++i) rx[i] = u32x4{(unsigned)c, (unsigned)i, (unsigned)tid, 2u};
       return;
     }
-    const int64_t mb = m_begin + (int64_t)c * CP;
 #pragma unroll
     for (int i = 0; i < IN; ++i) {
-      int64_t m = mb + (tid + 512 * i) / ON;
-      m = m < m_end ? m : m_end - 1;
-      rg[i] = ld16nt(G + gbase + (size_t)m * wo);
-      ry[i] = ld16nt(Y + gbase + (size_t)m * wo);
+      const unsigned rel = (unsigned)min(c * CP + i * PXN + pn0, nrel - 1);
+      rg[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Gb + rel * (unsigned)wo));
+      ry[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Yb + rel * (unsigned)wo));
     }
 #pragma unroll
     for (int i = 0; i < IK; ++i) {
-      int64_t m = mb + (tid + 512 * i) / OK;
-      m = m < m_end ? m : m_end - 1;
-      rx[i] = ld16nt(X + xbase + (size_t)m * wi);
+      const unsigned rel = (unsigned)min(c * CP + i * PXK + pk0, nrel - 1);
+      rx[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Xb + rel * (unsigned)wi));
     }
   };
   auto store_to = [&](int c, int slot) {
@@ -89,27 +99,20 @@ __global__ void __launch_bounds__(512) bc_wgrad_k(const bf16_t* __restrict__ G, 
       return;
     }
     unsigned char* buf = lds + slot * kBuf;
-    const int64_t mb = m_begin + (int64_t)c * CP;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < IN; ++i) {
-      const int px = (tid + 512 * i) / ON;
-      float g[8], y[8], v[8];
-      unpack8(rg[i], g);
-      unpack8(ry[i], y);
-      const bool live = mb + px < m_end;  // pixels past the slice contribute nothing
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = live ? fmaf(ga[j], g[j], fmaf(gb[j], y[j], c0[j])) : 0.f;
-      st16(buf + px * PN + on * 16, pack8(v));
+      const int px = pn0 + i * PXN;
+      const bool live = c * CP + px < nrel;  // pixels past the slice contribute nothing
+      const uint4 d = dy_chunk(rg[i], ry[i], ga, gb, c0);
+      st16(buf + px * PN + on * 16, live ? d : zero);
     }
 #pragma unroll
     for (int i = 0; i < IK; ++i) {
-      const int px = (tid + 512 * i) / OK;
-      float x[8], v[8];
-      unpack8(rx[i], x);
-      const bool live = mb + px < m_end;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = live ? fmaxf(fmaf(sc[j], x[j], sh[j]), 0.f) : 0.f;
-      st16(buf + CP * PN + px * PK + ok * 16, pack8(v));
+      const int px = pk0 + i * PXK;
+      const bool live = c * CP + px < nrel;
+      const uint4 a = act_chunk(rx[i], sc, sh);
+      st16(buf + CP * PN + px * PK + ok * 16, live ? a : zero);
     }
   };
   auto store = [&](int c) { store_to(c, c & 1); };
