@@ -452,7 +452,7 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
     // ---- the pixels of the band.  Stride 2: class by class of (row parity, column parity) - a pixel of a class is reached by a fixed set of
     // 1, 2, 2 or 4 taps, so the lanes of a wave do the same work (enumerated in one loop over all pixels every wave ran all nine tap
     // bodies under masks: 266 vector instructions per pixel where ~2.25 taps do work).
-    struct Item { u32x4 yp, raw, sg; int pj; };
+    struct Item { u32x4 yp, raw, sg; int pj; unsigned off; int lb; };  // off: element offset of the pixel; lb: LDS chunk index of its first tap (decoded once, at issue)
     f2 psc[4], psh[4], pmu[4];
     ld8(cst + 0 * SL + 8 * q, psc);
     ld8(cst + 1 * SL + 8 * q, psh);
@@ -480,6 +480,11 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
         unsigned img, off;
         int hi, wi;
         decode(I.pj, img, hi, wi, off);
+        I.off = off;
+        {  // tap (kh, kw) of this pixel reads chunk lb - ((kh - kh0) / S) * Wp - (kw - kw0) / S  (kh0, kw0: the class's first tap; stride 1: 0)
+          constexpr int kh0 = S == 1 ? 0 : (PH + 1) & 1, kw0 = S == 1 ? 0 : (PW + 1) & 1;
+          I.lb = (int)__umul24(img, PI) + __mul24((hi + 1 - kh0) / S - ho_lo, Wp) + (wi + 1 - kw0) / S - cx0 + 1;
+        }
         if (TTK_BC_DBG & 16) { I.yp = u32x4{(unsigned)off, 1u, 2u, 3u}; I.raw = I.yp; I.sg = I.yp; return; }
         I.yp = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(yptile + off));
         if (!LEAN) {
@@ -490,10 +495,18 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
       };
       auto process = [&](const Item& I) {
         if (I.pj >= npix) return;
-        unsigned img, off;
-        int hi, wi;
-        decode(I.pj, img, hi, wi, off);
-        const uint4* dyimg = lds + (__umul24(img, PI) << kQs) + q;
+        // kCache: the pixel's offsets come from the item (decoded at issue); the stride-1 kernel with residual operands is out of registers
+        // and decodes again (measured: caching there costs 2 us on the 9 x 9 layers, elsewhere it saves 2 - 8 %)
+        constexpr bool kCache = LEAN || S == 2;
+        unsigned off = I.off;
+        int lb = I.lb;
+        if constexpr (!kCache) {
+          unsigned img;
+          int hi, wi;
+          decode(I.pj, img, hi, wi, off);
+          lb = (int)__umul24(img, PI) + __mul24(hi + 1 - ho_lo, Wp) + wi + 1 - cx0 + 1;
+        }
+        const uint4* dyimg = lds + q;
         f2 yp[4], a[4];
         unpack_f2(make_uint4(I.yp.x, I.yp.y, I.yp.z, I.yp.w), yp);
         if (!LEAN && a_in) {
@@ -519,8 +532,10 @@ bc_dw_bwd_k(const bf16_t* __restrict__ g_dw, const bf16_t* __restrict__ y_dw, co
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
             if (S == 2 && (((PH + 1 - kh) & 1) || ((PW + 1 - kw) & 1))) continue;
-            const int ho = (hi + 1 - kh) / S, wo = (wi + 1 - kw) / S;  // (stride 2: both even and >= 0; stride 1: -1 .. H / W: the zero border of the stage)
-            dv[kh * 3 + kw] = (TTK_BC_DBG & 2) ? make_uint4(hi, wi, kh, kw) : dyimg[(__mul24(ho - ho_lo, Wp) + wo - cx0 + 1) << kQs];
+            // (stride 2: the taps of the class; stride 1: rows -1 .. H, columns -1 .. W - the zero border of the stage)
+            constexpr int kh0 = S == 1 ? 0 : (PH + 1) & 1, kw0 = S == 1 ? 0 : (PW + 1) & 1;
+            const int idx = lb - __mul24((kh - kh0) / S, Wp) - (kw - kw0) / S;
+            dv[kh * 3 + kw] = (TTK_BC_DBG & 2) ? make_uint4(idx, off, kh, kw) : dyimg[idx << kQs];
           }
         f2 G[4];
 #pragma unroll
