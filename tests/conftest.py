@@ -35,8 +35,8 @@ def _fixed_cpu_threads():
 class _WalkWorkers:
     """The six CPU-oracle walks of tests/test_teacher_forced_gpu.py and tests/test_trajectory_gpu.py (each a worker process: 5 - 10 optimiser
     steps of the fp32 AND the float64 oracle at B = 256, 50 - 70 s of host time, a few seconds of GPU time) run side by side instead of one
-    after the other: the first test that asks for its result starts the workers of EVERY such test selected in this session (<= 6 x 32 host
-    threads; the boxes have 256), then waits for its own.  Nothing about a worker changes - same script, arguments, environment, assertions."""
+    after the other: the workers of EVERY such test selected in the session start right after collection (<= 6 x 32 host threads; the boxes
+    have 256) and finish under the session's other tests; a test waits for its own worker only.  Nothing about a worker changes - same script, arguments, environment, assertions."""
 
     def __init__(self, session):
         self._session, self._procs, self._tmp = session, {}, None
@@ -94,8 +94,33 @@ class _WalkWorkers:
             shutil.rmtree(self._tmp, ignore_errors=True)
 
 
+_WALKS = {}
+
+
+def pytest_collection_finish(session):
+    """Start the walk workers of the selected walk tests right after collection: they are host-bound (CPU oracle) and finish under the other
+    tests of the session instead of holding the first walk test for two minutes."""
+    if getattr(session.config.option, "collectonly", False):
+        return
+    w = _WalkWorkers(session)
+    jobs = w._selected()
+    if jobs:
+        for j in jobs:
+            w._start(j)
+        _WALKS["w"] = w
+
+
+def pytest_sessionfinish(session, exitstatus):
+    w = _WALKS.pop("w", None)
+    if w is not None:
+        w.close()
+
+
 @pytest.fixture(scope="session")
 def walk_workers(request):
+    if "w" in _WALKS:
+        yield _WALKS["w"]
+        return
     w = _WalkWorkers(request.session)
     yield w
     w.close()
