@@ -1,6 +1,6 @@
 """BASELINE config 5 on the one GPU this pool offers: the multi-task mix (three dataset kinds with different label sets) drawn by the
 weighted sampler, random focus-ROI crop + affine warp + label bookkeeping + mirror / quarter turns + intensity augmentation on the GPU,
-NLL losses with their ramp, clip + Adam - with bf16 activation storage, at 512 crops per step, through train.fit().  (The 8-GPU part of
+NLL losses with their ramp, clip + Adam - in both bf16 modes (bf16 activation storage; bf16-compute = BASELINE config 5's bf16 leg), at 512 crops per step, through train.fit().  (The 8-GPU part of
 the configuration - RCCL all-reduce - is covered by tests/test_parallel_*.py and test_dp2_gpu.py.)  The bf16 run is held to the fp32 run
 of the same data: same draws, same augmentation parameters; per-step losses within the bf16-storage tolerance measured in
 tests/test_bf16_gpu.py for single steps, loosened for the parameter drift of the preceding steps."""
@@ -69,17 +69,25 @@ def _run(mode, steps=4, B=512):
     return losses, [b.meta.tag for b in first], [int(b["image"].shape[0]) for b in first], net
 
 
-def test_multitask_mix_with_bf16_storage_tracks_fp32():
+@pytest.fixture(scope="module")
+def fp32_run():
+    return _run("fp32")
+
+
+# first-step tolerance: the same parameters, only the mode's rounding differs.  bf16 (storage under the fp32 kernels): 2e-3;
+# bf16-compute (bf16 tensors AND one bf16 MFMA product per pointwise convolution): 2e-3 as well (measured 1e-4 at this batch)
+@pytest.mark.parametrize("mode", ["bf16", "bf16-compute"])
+def test_multitask_mix_in_bf16_tracks_fp32(mode, fp32_run):
     from trackertraincode.pipelines import Tag
 
-    l32, tags, sizes, net32 = _run("fp32")
-    l16, _, _, net16 = _run("bf16")
+    l32, tags, sizes, net32 = fp32_run
+    l16, _, _, net16 = _run(mode)
     assert set(tags) == {Tag.POSE_WITH_LANDMARKS, Tag.POSE_WITH_LMKS_NO_SHAPE_PARAMS, Tag.ONLY_POSE} and sum(sizes) == 512
     assert len(l32) == len(l16) == 4 and all(np.isfinite(l32)) and all(np.isfinite(l16))
-    print("fp32 losses", l32, "bf16 losses", l16)
-    assert abs(l16[0] - l32[0]) <= 2e-3 * abs(l32[0])  # first step: the same parameters, bf16 rounding of the stored activations only
+    print("fp32 losses", l32, mode, "losses", l16)
+    assert abs(l16[0] - l32[0]) <= 2e-3 * abs(l32[0])
     for a, b in zip(l32[1:], l16[1:]):
-        assert abs(b - a) <= 1e-1 * abs(a)  # later steps (measured 0.5 %, 1.5 %, 4.2 %): Adam's first updates amplify the gradients' bf16 noise
+        assert abs(b - a) <= 1e-1 * abs(a)  # later steps (measured 0.5 %, 1.5 %, 4.2 % for bf16 storage): Adam's first updates amplify the gradients' bf16 noise
     assert all(torch.isfinite(p).all() for p in net16.parameters())
-    moved = [float((p16 - p32).abs().max()) for p16, p32 in zip(net16.parameters(), net32.parameters())]
+    moved = [float((p16.detach() - p32.detach()).abs().max()) for p16, p32 in zip(net16.parameters(), net32.parameters())]
     assert max(moved) > 0.0  # the two runs are not the same run
