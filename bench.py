@@ -549,8 +549,10 @@ def main():
             # default workload) only to the default workload: per-launch bytes of B = 512 say nothing about another batch size or network
             traffic, traffic_src = {}, None
             default_workload = args.batch == 512 and args.backbone == "mobilenetv1" and args.precision == "fp32" and not args.blurpool
+            bc_workload = args.batch == 512 and args.backbone == "mobilenetv1" and args.precision == "bf16-compute" and not args.blurpool
             cands = [args.traffic_json] if args.traffic_json else (
-                sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True) if default_workload else [])
+                sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True) if default_workload else
+                sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic_bf16_compute.json")), reverse=True) if bc_workload else [])
             sys.path.insert(0, os.path.join(REPO, "tools"))
             from build_id import csrc_sha256
             tree = csrc_sha256()

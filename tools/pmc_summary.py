@@ -14,7 +14,7 @@ import collections, csv, json, re, sys
 
 
 def short(n):
-    return re.sub(r"\(.*", "", n).replace("void ", "").replace("ttk::", "").strip()
+    return re.sub(r"\(.*", "", n).replace("void ", "").replace("ttk::", "").replace("bc::", "").strip()
 
 
 def collect(path, counter):
@@ -32,7 +32,8 @@ l2 = {c: collect(sys.argv[4], c) for c in ("TCC_HIT_sum", "TCC_MISS_sum", "TCP_T
 out = {}
 for k in sorted(set(fetch) | set(write)):
     if not (k.startswith("pw") or k.startswith("dw_") or k.startswith("stem") or k.startswith("bn_") or k.startswith("heads")
-            or k.startswith("loss") or k.startswith("avgpool") or k.startswith("clip_adam") or k.startswith("affine")):
+            or k.startswith("loss") or k.startswith("avgpool") or k.startswith("clip_adam") or k.startswith("affine") or k.startswith("bc_")
+            or k.startswith("fold_")):
         continue
     nf, f = fetch.get(k, [0, 0.0])
     nw, w = write.get(k, [0, 0.0])
