@@ -98,9 +98,11 @@ class KernelTimer:
             M, ci, co = ints[-3:]
             fl = 2 * M * ci * co
             if name == "ttk_bc_pw_fwd":
-                return (f"bc_gemm_e_k<0, {co // 32}, {ci // 32}>" if (co <= 128 and ci <= 256) else "bc_gemm_l_k<0>"), fl, 2 * (M * ci + M * co) + 2 * ci * co
+                l128 = co == 128 and ci == 256  # csrc/bc_gemm.hip: is_l128 (N = 128, K = 256 runs the streamed kernel on 128-channel tiles)
+                return ("bc_gemm_l_k<0, 128>" if l128 else f"bc_gemm_e_k<0, {co // 32}, {ci // 32}>" if (co <= 128 and ci <= 256) else "bc_gemm_l_k<0, 256>"), fl, 2 * (M * ci + M * co) + 2 * ci * co
             if name == "ttk_bc_pw_bwd_data":
-                return (f"bc_gemm_e_k<1, {ci // 32}, {co // 32}>" if (ci <= 128 and co <= 256) else "bc_gemm_l_k<1>"), fl, 2 * (2 * M * co + 2 * M * ci) + 2 * ci * co
+                l128 = ci == 128 and co == 256
+                return ("bc_gemm_l_k<1, 128>" if l128 else f"bc_gemm_e_k<1, {ci // 32}, {co // 32}>" if (ci <= 128 and co <= 256) else "bc_gemm_l_k<1, 256>"), fl, 2 * (2 * M * co + 2 * M * ci) + 2 * ci * co
             if name == "ttk_bc_pw_bwd_fused":  # weight AND data gradient of the early layers, operands read once
                 return f"bc_bwd_fused_k<{co // 32}, {ci // 32}", 2 * fl, 2 * (2 * M * co + 2 * M * ci) + 6 * ci * co
             tn, tk = min(co, 256) // 32, min(ci, 256) // 32

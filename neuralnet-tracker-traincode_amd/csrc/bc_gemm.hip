@@ -239,16 +239,18 @@ __global__ void __launch_bounds__(512) bc_gemm_e_k(const bf16_t* __restrict__ A0
 // LDS pipe at 75 %: 55 us for the 512 x 512 forward).  Two steps per loop iteration with the register sets swapping roles, every load
 // unconditional (clamped indices): hipcc's counted vmcnt waits stay exact.
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
+// NCT: output channels per tile (256; 128 for the one layer with N = 128 and K = 256 - its data gradient ran at 0.29 of 8 TB/s in the resident-weight form)
+template <int MODE, int NCT>
 __global__ void __launch_bounds__(512) bc_gemm_l_k(const bf16_t* __restrict__ A0, const bf16_t* __restrict__ A1, const float* __restrict__ bnA,
                                                     const uint4* __restrict__ Wimg, bf16_t* __restrict__ out, const bf16_t* __restrict__ maskY,
                                                     const float* __restrict__ bnE, const float* __restrict__ pivot, float* __restrict__ part, int64_t M,
                                                     int K, int N, int RT, int nrt, int ncol) {
   extern __shared__ uint4 lds[];
-  uint4* wring = lds;                                           // [2][256 rows x 8 chunks]
-  uint4* aring = lds + 2 * 2048;                                // [2][256 pixels x 8 chunks]; after the loop: 8 waves x 256 chunks of store tiles
-  float* cE = reinterpret_cast<float*>(lds + 4 * 2048);         // [3][256]
-  float* cA = cE + 3 * 256;                                     // [3][K]
+  constexpr int WCH = NCT * 8, WPT = WCH / 512, NBW = NCT / 64, NCB = NCT / 128;  // weight chunks per stage / per thread; 32-channel blocks / 64-channel blocks per wave
+  uint4* wring = lds;                                           // [2][NCT rows x 8 chunks]
+  uint4* aring = lds + 2 * WCH;                                 // [2][256 pixels x 8 chunks]; after the loop: 8 waves x 256 chunks of store tiles
+  float* cE = reinterpret_cast<float*>(lds + 2 * WCH + 2 * 2048);  // [3][NCT]
+  float* cA = cE + 3 * NCT;                                     // [3][K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int wc = wave & 1, wp = wave >> 1;
   // blocks b and b + 8 share an XCD (round-robin dispatch): the column tiles of one row tile sit there together, the second one finds
@@ -256,7 +258,7 @@ __global__ void __launch_bounds__(512) bc_gemm_l_k(const bf16_t* __restrict__ A0
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
   const int ct = jj % ncol, rt = (jj / ncol) * 8 + xcd;
   if (rt >= nrt) return;
-  const int n0 = ct * 256;
+  const int n0 = ct * NCT;
   const int64_t p0 = (int64_t)rt * RT, pend = (p0 + RT < M) ? p0 + RT : M;
   const int nkb = K / 64, klast = nkb - 1;
   // staging role: chunk column `oct` (channels 8 oct .. + 7 of the k64 block) of pixels (tid >> 3) + 64 i
@@ -271,34 +273,34 @@ __global__ void __launch_bounds__(512) bc_gemm_l_k(const bf16_t* __restrict__ A0
   // Register chunks of the NEXT step's operands: chunk i (activation pixels (tid >> 3) + 64 i, weight chunk tid + 512 i) is transformed and
   // stored behind the MFMAs of sub-step i of the current step, and reloaded at once for the step after next - a ring of four slots per
   // operand, every load unconditional (clamped to the last slab: the surplus copies are never read).
-  u32x4 rx0[4], rx1[4], wr[4];  // (ext-vector registers: arrays of the HIP struct type captured by the lambdas went to scratch)
+  u32x4 rx0[4], rx1[4], wr[4];  // (wr: WPT of them are used)  // (ext-vector registers: arrays of the HIP struct type captured by the lambdas went to scratch)
   const u32x4* Wv = reinterpret_cast<const u32x4*>(Wimg);
   auto load_chunk = [&](int kb, int i) {
     const size_t o = (size_t)kb * M * 64 + soff[i];  // (plain loads: the other column tiles of these pixels read the same lines from L2)
     rx0[i] = *reinterpret_cast<const u32x4*>(A0 + o);
     if constexpr (MODE == kDgrad) rx1[i] = *reinterpret_cast<const u32x4*>(A1 + o);
-    wr[i] = Wv[((size_t)kb * N + n0) * 8 + tid + 512 * i];
+    if (i < WPT) wr[i] = Wv[((size_t)kb * N + n0) * 8 + tid + 512 * i];
   };
   auto store_chunk = [&](int slot, int kb, int i) {
     const int px = (tid >> 3) + 64 * i;
     const bf16x8 fr = make_frag<MODE>(make_uint4(rx0[i].x, rx0[i].y, rx0[i].z, rx0[i].w), make_uint4(rx1[i].x, rx1[i].y, rx1[i].z, rx1[i].w), cA, K, kb * 64 + 8 * oct);
     aring[slot * 2048 + px * 8 + (oct ^ (px & 7))] = __builtin_bit_cast(uint4, fr);
-    reinterpret_cast<u32x4*>(wring)[slot * 2048 + tid + 512 * i] = wr[i];
+    if (i < WPT) reinterpret_cast<u32x4*>(wring)[slot * WCH + tid + 512 * i] = wr[i];
   };
-  const int wrow = (128 * wc + r) * 8, wsw = (r >> 1) & 7;
+  const int wrow = ((NCT / 2) * wc + r) * 8, wsw = (r >> 1) & 7;
   const int arow = (64 * wp + r) * 8, asw = r & 7;
-  f32x16 acc[2][4];  // [pixel group][channel block]
+  f32x16 acc[2][NBW];  // [pixel group][channel block]
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+    for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.f;
   // (the first step's operands are requested before the constants; measured: no difference to the other order, profiles/r05_bc_gemm_variants.txt)
 #pragma unroll
   for (int i = 0; i < 4; ++i) load_chunk(0, i);
   fill_cA<MODE>(cA, bnA, K, tid, 512);
-  fill_cE<MODE>(cE, pivot, bnE, N, n0, 256, tid, 512);
+  fill_cE<MODE>(cE, pivot, bnE, N, n0, NCT, tid, 512);
   __syncthreads();  // constants are in LDS
 #pragma unroll
   for (int i = 0; i < 4; ++i) store_chunk(0, 0, i);
@@ -308,18 +310,18 @@ __global__ void __launch_bounds__(512) bc_gemm_l_k(const bf16_t* __restrict__ A0
   __syncthreads();
   for (int kb = 0; kb < nkb; ++kb) {
     const int slot = kb & 1;
-    const uint4* Ws = wring + slot * 2048;
+    const uint4* Ws = wring + slot * WCH;
     const uint4* As = aring + slot * 2048;
     const int knext = min(kb + 1, klast), knn = min(kb + 2, klast);
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
-      uint4 av[2], wv[4];
+      uint4 av[2], wv[NBW];
 #pragma unroll
       for (int j = 0; j < 2; ++j) av[j] = (TTK_BC_GDBG & 8) ? make_uint4(kb, s4, j, lane) : As[arow + 256 * j + ((2 * s4 + h) ^ asw)];
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) wv[nb] = (TTK_BC_GDBG & 8) ? make_uint4(kb, s4, nb, lane) : Ws[wrow + 256 * nb + ((2 * s4 + h) ^ wsw)];
+      for (int nb = 0; nb < NBW; ++nb) wv[nb] = (TTK_BC_GDBG & 8) ? make_uint4(kb, s4, nb, lane) : Ws[wrow + 256 * nb + ((2 * s4 + h) ^ wsw)];
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
+      for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if (TTK_BC_GDBG & 1) { acc[j][nb][0] += __uint_as_float(wv[nb].x ^ av[j].y ^ wv[nb].z ^ av[j].w); continue; }
@@ -335,12 +337,12 @@ __global__ void __launch_bounds__(512) bc_gemm_l_k(const bf16_t* __restrict__ A0
   }
   // ---- epilogue: the wave's 2 channel blocks of 64 x 2 pixel groups of 32 through its LDS tile (the activation ring is free: barrier above)
   uint4* mystg = aring + wave * 256;
-  float* red = reinterpret_cast<float*>(wring);  // [8 waves][2 blocks][2][64]
+  float* red = reinterpret_cast<float*>(wring);  // [8 waves][NCB blocks][2][64]
   const int o8 = lane & 7;
   uint4 mk[2][4];
   auto load_mask = [&](int q4, uint4(&d)[4]) {  // q4 = 2 * (local channel block) + pixel group
     if constexpr (MODE == kDgrad && !(TTK_BC_GDBG & 16)) {
-      const int cb = n0 / 64 + 2 * wc + (q4 >> 1);
+      const int cb = n0 / 64 + NCB * wc + (q4 >> 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         int64_t p = p0 + 64 * wp + 32 * (q4 & 1) + 8 * i + (lane >> 3);
@@ -351,19 +353,19 @@ __global__ void __launch_bounds__(512) bc_gemm_l_k(const bf16_t* __restrict__ A0
   };
   load_mask(0, mk[0]);
 #pragma unroll
-  for (int cbl = 0; cbl < 2; ++cbl) {
+  for (int cbl = 0; cbl < NCB; ++cbl) {
     float s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
-    const int cb = n0 / 64 + 2 * wc + cbl;
+    const int cb = n0 / 64 + NCB * wc + cbl;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int q4 = 2 * cbl + j;
-      if (q4 + 1 < 4) load_mask(q4 + 1, mk[(q4 + 1) & 1]);
+      if (q4 + 1 < 2 * NCB) load_mask(q4 + 1, mk[(q4 + 1) & 1]);
       const int64_t g0 = p0 + 64 * wp + 32 * j;
       if ((TTK_BC_GDBG & 16) && acc[j][2 * cbl][0] != 12345.f) continue;  // (timing only: no epilogue)
       if (g0 < pend)
-        store_block<MODE, 64>(acc[j] + 2 * cbl, mystg, out + ((size_t)cb * M + g0) * 64, mk[q4 & 1], cE + 64 * (2 * wc + cbl), 256, g0, pend, s1, s2);
+        store_block<MODE, 64>(acc[j] + 2 * cbl, mystg, out + ((size_t)cb * M + g0) * 64, mk[q4 & 1], cE + 64 * (NCB * wc + cbl), NCT, g0, pend, s1, s2);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -375,17 +377,17 @@ __global__ void __launch_bounds__(512) bc_gemm_l_k(const bf16_t* __restrict__ A0
     if (lane < 8) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        red[((wave * 2 + cbl) * 2 + 0) * 64 + 8 * lane + j] = s1[j];
-        red[((wave * 2 + cbl) * 2 + 1) * 64 + 8 * lane + j] = s2[j];
+        red[((wave * NCB + cbl) * 2 + 0) * 64 + 8 * lane + j] = s1[j];
+        red[((wave * NCB + cbl) * 2 + 1) * 64 + 8 * lane + j] = s2[j];
       }
     }
   }
   __syncthreads();
-  if (part) {  // tid = which * 256 + column of the tile; column c: channel half c >> 7, local block (c >> 6) & 1
-    const int which = tid >> 8, c = tid & 255, cwc = c >> 7, cbl = (c >> 6) & 1, cc = c & 63;
+  if (part && tid < 2 * NCT) {  // tid = which * NCT + column of the tile; column c: channel half c / (NCT / 2), local 64-channel block, channel in it
+    const int which = tid / NCT, c = tid % NCT, cwc = c / (NCT / 2), cbl = (c % (NCT / 2)) >> 6, cc = c & 63;
     float a = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a += red[(((2 * q + cwc) * 2 + cbl) * 2 + which) * 64 + cc];
+    for (int q = 0; q < 4; ++q) a += red[(((2 * q + cwc) * NCB + cbl) * 2 + which) * 64 + cc];
     part[((size_t)rt * 2 + which) * N + n0 + c] = a;
   }
 }
@@ -400,11 +402,12 @@ static bool pw_shape_ok(int Cin, int Cout) {
 // E: N <= 128 and K <= 256; else L needs N % 256 == 0 and K % 64 == 0
 static bool is_e(int K, int N) { return N <= 128 && K <= 256; }
 static bool is_l(int K, int N) { return N % 256 == 0 && K % 128 == 0; }
+static bool is_l128(int K, int N) { return N == 128 && K == 256; }  // (K = 128, N = 128 - the 128 -> 128 forward - is faster in the resident-weight form: 68 vs 90 us)  // (takes precedence over the resident-weight form for this shape, in both modes: the part rows depend on it)
 
 struct LPlan { int RT, nrt, ncol, grid; };
-static LPlan l_plan(int64_t M, int N) {
+static LPlan l_plan(int64_t M, int N, int nct = 256) {
   LPlan p;
-  p.ncol = N / 256;
+  p.ncol = N / nct;
   const int64_t t256 = ceil_div(M, 256);
   const int64_t rounds = ceil_div(t256 * p.ncol, 256);      // rounds of the 256 CUs with full 256-pixel tiles
   int64_t target = rounds * 256 / p.ncol;                   // row tiles that fill those rounds
@@ -428,11 +431,17 @@ static size_t e_lds_bytes(int K, int N) {
   const size_t stg = (size_t)8 * 4 * OC * 16, red = (size_t)8 * 2 * N * 4;
   return (size_t)N * K * 2 + (size_t)3 * K * 4 + (size_t)3 * N * 4 + (stg > red ? stg : red);
 }
-static size_t l_lds_bytes(int K) { return (size_t)4 * 2048 * 16 + (size_t)3 * 256 * 4 + (size_t)3 * K * 4; }
+static size_t l_lds_bytes(int K, int nct = 256) { return (size_t)(2 * nct * 8 + 2 * 2048) * 16 + (size_t)3 * nct * 4 + (size_t)3 * K * 4; }
 
 template <int MODE>
 static int launch_gemm(const bf16_t* A0, const bf16_t* A1, const float* bnA, const uint4* Wimg, bf16_t* out, const bf16_t* maskY, const float* bnE,
                        const float* pivot, float* part, int64_t M, int K, int N, hipStream_t st) {
+  if (is_l128(K, N)) {
+    const LPlan p = l_plan(M, N, 128);
+    allow_big_lds<bc_gemm_l_k<MODE, 128>>();
+    hipLaunchKernelGGL((bc_gemm_l_k<MODE, 128>), dim3(p.grid), dim3(512), l_lds_bytes(K, 128), st, A0, A1, bnA, Wimg, out, maskY, bnE, pivot, part, M, K, N, p.RT, p.nrt, p.ncol);
+    return 0;
+  }
   if (is_e(K, N)) {
     const int grid = e_grid(M);
     const size_t sm = e_lds_bytes(K, N);
@@ -449,8 +458,8 @@ static int launch_gemm(const bf16_t* A0, const bf16_t* A1, const float* bnA, con
   }
   if (!is_l(K, N)) return -2;
   const LPlan p = l_plan(M, N);
-  allow_big_lds<bc_gemm_l_k<MODE>>();
-  hipLaunchKernelGGL((bc_gemm_l_k<MODE>), dim3(p.grid), dim3(512), l_lds_bytes(K), st, A0, A1, bnA, Wimg, out, maskY, bnE, pivot, part, M, K, N, p.RT, p.nrt, p.ncol);
+  allow_big_lds<bc_gemm_l_k<MODE, 256>>();
+  hipLaunchKernelGGL((bc_gemm_l_k<MODE, 256>), dim3(p.grid), dim3(512), l_lds_bytes(K), st, A0, A1, bnA, Wimg, out, maskY, bnE, pivot, part, M, K, N, p.RT, p.nrt, p.ncol);
   return 0;
 }
 
@@ -487,6 +496,7 @@ int ttk_bc_prepare_weights(int n, const float* const* w, const int* cin, const i
 
 int ttk_bc_partial_rows_pw(int64_t M, int K, int Nout) {
   if (M < 1 || !pw_shape_ok(K, Nout)) return -1;
+  if (is_l128(K, Nout)) return l_plan(M, Nout, 128).nrt;
   if (is_e(K, Nout)) return e_grid(M);
   if (is_l(K, Nout)) return l_plan(M, Nout).nrt;
   return -1;
