@@ -49,7 +49,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 24
+#define TTK_ABI_VERSION 25
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -306,6 +306,13 @@ int ttk_bc_dw_fwd(const void* yprev, const float* bn_prev, const void* skip_prev
 int ttk_bc_dw_bwd_data(const void* g_dw, const void* y_dw, const float* bn_dw, const float* w, const void* skip_grad,
                        const void* yprev, const float* bn_prev, const void* skip_prev, const void* a_in, void* g_prev, float* part,
                        float* dw, int dw_accumulate, float* dw_partial, int B, int H, int W, int C, int stride, ttk_stream_t stream);
+/* dw_accumulate == 2 (with dw_partial): the kernel leaves its ttk_bc_partial_rows_dw(..., 1) rows of [C][9] weight-gradient sums in dw_partial
+ * UNFOLDED; the caller folds them in the same launch as the BatchNorm-backward finalisation that follows the kernel anyway:
+ * ttk_bn_bwd_finalize(part, ...) + "fold_out (+)= sum over fold_rows rows of fold_partial[row][fold_n]" as ONE launch (two dependent
+ * few-microsecond launches less per depthwise layer; same arithmetic, same results as the two separate calls). */
+int ttk_bc_bn_bwd_finalize_fold(float* part, int part_rows, int C, int64_t count, const float* gamma, float* bn, float* dgamma, float* dbeta,
+                                int accumulate, const float* fold_partial, int fold_rows, int64_t fold_n, float* fold_out, int fold_accumulate,
+                                ttk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense convolutions of the ResNet18 backbone variant (backbones/resnet.py:52-104; arithmetic =

@@ -109,11 +109,10 @@ inline void allow_big_lds() {
 // partials of the small pointwise layers): 16 float4 columns x 64 row groups per 1024-thread block - a thread adds rows / 64 rows (loads in
 // flight together), the groups are folded by a fixed tree in LDS (bitwise reproducible).  The plain one-thread-per-output folds took
 // 9 - 13 us per launch on these shapes (latency of hundreds of dependent loads), 25 launches per step.
-template <int kDummy = 0>
-__global__ void __launch_bounds__(1024) fold_rows_fast_k(const float* __restrict__ partial, int rows, int64_t n, float* __restrict__ out, int accumulate) {
+__device__ __forceinline__ void fold_rows_fast_body(const float* __restrict__ partial, int rows, int64_t n, float* __restrict__ out, int accumulate, unsigned block) {
   __shared__ float4 sm[64][16];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int64_t i = ((int64_t)blockIdx.x * 16 + tx) * 4;
+  const int64_t i = ((int64_t)block * 16 + tx) * 4;
   float4 a = f4(0.f);
   if (i < n) {
     int r = ty;
@@ -137,9 +136,15 @@ __global__ void __launch_bounds__(1024) fold_rows_fast_k(const float* __restrict
     st4(out + i, t);
   }
 }
+template <int kDummy = 0>
+__global__ void __launch_bounds__(1024) fold_rows_fast_k(const float* __restrict__ partial, int rows, int64_t n, float* __restrict__ out, int accumulate) {
+  fold_rows_fast_body(partial, rows, n, out, accumulate, blockIdx.x);
+}
+inline bool fold_rows_fast_ok(int rows, int64_t n) { return n % 4 == 0 && n <= 65536 && rows >= 16; }
+inline unsigned fold_rows_fast_blocks(int64_t n) { return (unsigned)((n / 4 + 15) / 16); }
 inline bool launch_fold_rows_fast(const float* partial, int rows, int64_t n, float* out, int accumulate, hipStream_t st) {
-  if (n % 4 != 0 || n > 65536 || rows < 16) return false;
-  hipLaunchKernelGGL(fold_rows_fast_k<0>, dim3((unsigned)((n / 4 + 15) / 16)), dim3(1024), 0, st, partial, rows, n, out, accumulate);
+  if (!fold_rows_fast_ok(rows, n)) return false;
+  hipLaunchKernelGGL(fold_rows_fast_k<0>, dim3(fold_rows_fast_blocks(n)), dim3(1024), 0, st, partial, rows, n, out, accumulate);
   return true;
 }
 

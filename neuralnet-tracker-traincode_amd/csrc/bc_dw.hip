@@ -690,6 +690,7 @@ int ttk_bc_dw_bwd_data(const void* g_dw, const void* y_dw, const float* bn_dw, c
   const size_t sm = (size_t)stage_pix * t.SL * 2 + (size_t)(9 + kWvs * 9 + 6) * t.SL * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (!dw) dw_partial = nullptr;
+  TTK_REQUIRE(dw_accumulate != 2 || dw_partial, "bc_dw_bwd_data: dw_accumulate = 2 needs dw_partial");
   if (dw && !dw_accumulate && !dw_partial) (void)hipMemsetAsync(dw, 0, (size_t)9 * C * sizeof(float), st);
 #define TTK_BC_BWD3(S_, SL_, LEAN_)                                                                                                               \
   do {                                                                                                                                            \
@@ -705,7 +706,9 @@ int ttk_bc_dw_bwd_data(const void* g_dw, const void* y_dw, const float* bn_dw, c
 #undef TTK_BC_BWD1
 #undef TTK_BC_BWD2
 #undef TTK_BC_BWD3
-  if (dw_partial && !launch_fold_rows_fast(dw_partial, t.rows, (int64_t)9 * C, dw, dw_accumulate, st)) launch_fold_partials(dw_partial, t.rows, (int64_t)9 * C, dw, dw_accumulate, st);
+  // dw_accumulate == 2: the rows stay unfolded - the caller folds them beside the BatchNorm-backward finalisation (ttk_bc_bn_bwd_finalize_fold)
+  if (dw_partial && dw_accumulate != 2 && !launch_fold_rows_fast(dw_partial, t.rows, (int64_t)9 * C, dw, dw_accumulate, st))
+    launch_fold_partials(dw_partial, t.rows, (int64_t)9 * C, dw, dw_accumulate, st);
   TTK_LAUNCH_CHECK("bc_dw_bwd_data");
 }
 

@@ -3,7 +3,7 @@
 #include <stdarg.h>
 #include <string.h>
 
-#include "ttk_common.h"
+#include "bc_common.h"  // (fold_rows_fast_body: the combined finalisation + fold launch of the bf16-compute path)
 
 namespace ttk {
 
@@ -83,13 +83,13 @@ __global__ void bn_eval_prepare_k(const float* gamma, const float* beta, const f
 // dy = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)),  xhat = (y - mean)*rstd
 //    = ga*(g - gmean) + gb*(y - mean)          ga = gamma*rstd, gb = -ga*rstd^2*mean(g*(y-mean))
 // partials: sum(g), sum(g*(y - mean));  dgamma = rstd*sum(g*(y-mean)), dbeta = sum(g)
-__global__ void __launch_bounds__(1024) bn_bwd_finalize_k(const float* __restrict__ part, int rows, int C, double inv_count,
-                                                          const float* __restrict__ gamma, float* __restrict__ bn,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                          int accumulate) {
+__device__ __forceinline__ void bn_bwd_finalize_body(const float* __restrict__ part, int rows, int C, double inv_count,
+                                                     const float* __restrict__ gamma, float* __restrict__ bn,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     int accumulate, unsigned block) {
   __shared__ double sm[2][32][32];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  const int c = block * 32 + cl;
   double a = 0.0, b = 0.0;
   if (c < C) {
 #pragma unroll 4
@@ -124,6 +124,23 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_k(const float* __restric
     for (int off = 16; off >= 1; off >>= 1) bound = fmaxf(bound, __shfl_xor(bound, off));
     if (cl == 0 && bound > 0.f) atomicMax(reinterpret_cast<unsigned*>(bn + (size_t)TTK_BN_AUX * C + TTK_AUX_DY_BOUND), __float_as_uint(bound));
   }
+}
+__global__ void __launch_bounds__(1024) bn_bwd_finalize_k(const float* __restrict__ part, int rows, int C, double inv_count,
+                                                          const float* __restrict__ gamma, float* __restrict__ bn,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          int accumulate) {
+  bn_bwd_finalize_body(part, rows, C, inv_count, gamma, bn, dgamma, dbeta, accumulate, blockIdx.x);
+}
+// The same finalisation AND a fold of workgroup rows (the fused depthwise weight gradient of the kernel that produced `part`) in ONE launch: the first
+// nfin blocks finalise, the others fold.  The two are independent and each is a few microseconds of dependent latency: as two launches they cost two
+// launch-to-launch round trips of the backward chain, 13 times per step (bf16-compute path).
+__global__ void __launch_bounds__(1024) bn_bwd_finalize_fold_k(const float* __restrict__ part, int rows, int C, double inv_count,
+                                                               const float* __restrict__ gamma, float* __restrict__ bn,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, unsigned nfin,
+                                                               const float* __restrict__ fold_partial, int fold_rows, int64_t fold_n,
+                                                               float* __restrict__ fold_out, int fold_accumulate) {
+  if (blockIdx.x < nfin) bn_bwd_finalize_body(part, rows, C, inv_count, gamma, bn, dgamma, dbeta, accumulate, blockIdx.x);
+  else bc::fold_rows_fast_body(fold_partial, fold_rows, fold_n, fold_out, fold_accumulate, blockIdx.x - nfin);
 }
 
 // Backward through a FROZEN BatchNorm (eval-mode statistics, reference modelcomponents.py:208-215 freeze_norm_stats: the layer
@@ -258,6 +275,25 @@ int ttk_bn_bwd_finalize(float* part, int part_rows, int C, int64_t count, const 
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, part_rows, C,
                      1.0 / (double)count, gamma, bn, dgamma, dbeta, accumulate);
   TTK_LAUNCH_CHECK("bn_bwd_finalize");
+}
+
+int ttk_bc_bn_bwd_finalize_fold(float* part, int part_rows, int C, int64_t count, const float* gamma, float* bn, float* dgamma, float* dbeta,
+                                int accumulate, const float* fold_partial, int fold_rows, int64_t fold_n, float* fold_out, int fold_accumulate,
+                                ttk_stream_t stream) {
+  TTK_REQUIRE(part && gamma && bn && fold_partial && fold_out, "bc_bn_bwd_finalize_fold: null pointer");
+  TTK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bc_bn_bwd_finalize_fold: dgamma/dbeta must both be given");
+  TTK_REQUIRE(C > 0 && part_rows > 0 && count > 0 && fold_rows > 0 && fold_n > 0, "bc_bn_bwd_finalize_fold: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  part_rows = fold_if_needed(part, part_rows, C, st);
+  if (!bc::fold_rows_fast_ok(fold_rows, fold_n)) {  // shapes the fast fold does not take: two launches, same results
+    launch_fold_partials(fold_partial, fold_rows, fold_n, fold_out, fold_accumulate, st);
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 31) / 32), dim3(1024), 0, st, part, part_rows, C, 1.0 / (double)count, gamma, bn, dgamma, dbeta, accumulate);
+  } else {
+    const unsigned nfin = (unsigned)((C + 31) / 32);
+    hipLaunchKernelGGL(bn_bwd_finalize_fold_k, dim3(nfin + bc::fold_rows_fast_blocks(fold_n)), dim3(1024), 0, st, part, part_rows, C, 1.0 / (double)count, gamma, bn,
+                       dgamma, dbeta, accumulate, nfin, fold_partial, fold_rows, fold_n, fold_out, fold_accumulate);
+  }
+  TTK_LAUNCH_CHECK("bc_bn_bwd_finalize_fold");
 }
 
 int ttk_bn_frozen_bound(float* part, const float* pivot, int part_rows, int C, int64_t count, float* bn, ttk_stream_t stream) {

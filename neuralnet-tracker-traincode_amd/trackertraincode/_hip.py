@@ -105,9 +105,10 @@ _SIGNATURES = {
     "ttk_bc_avgpool_fwd": [_P, _P, _P, _P, _I, _I, _I],
     "ttk_bc_avgpool_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
     "ttk_bc_dw_bwd_data": [_P] * 12 + [_I, _P] + [_I] * 5,
+    "ttk_bc_bn_bwd_finalize_fold": [_P, _I, _I, _L, _P, _P, _P, _P, _I, _P, _I, _L, _P, _I],
 }
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 
 # Whether the backbones hand the running mean to the forward producers as the statistics pivot (include/ttk.h).  Always on in the

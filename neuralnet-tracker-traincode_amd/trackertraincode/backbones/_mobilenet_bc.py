@@ -22,6 +22,10 @@ _BF = 3          # TTK_STORE_ACT_BF16 | TTK_STORE_GRAD_BF16 (stem: C = 32, the s
 _DT = torch.bfloat16
 
 
+# Experiment hook (tools/exp/ab_fold_finalize.py): False = the depthwise weight-gradient rows are folded by their own launch
+_FOLD_WITH_FINALIZE = True
+
+
 def part_buffer(B, H, W, device, blocks, blur=False):
     """One scratch buffer large enough for every layer's [rows][2][C] partial sums."""
     L = _hip.lib()
@@ -198,10 +202,21 @@ def backward_impl(MB, ctx, gfeat, params):
             L.call("ttk_bn_bwd_frozen", p(st_t.bn), cin)
             L.call("ttk_bc_dw_bwd_data", p(g_t), p(st_t.y), p(st_t.bn), p(w_blur), None, p(st_prev.y), p(st_prev.bn), p(st_prev.skip), None, p(g_prev),
                    p(part), None, 0, None, B, h, w_, cin, stride)
+            bwd_finalize(st_prev, rows_dw(B, h, w_, cin, stride, 1), B * h * w_, pi - 2 if k > 0 else 1)
         else:
-            L.call("ttk_bc_dw_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), p(g) if has_skip else None, p(st_prev.y), p(st_prev.bn),
-                   p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 1, dw_scratch, B, h, w_, cin, stride)
-        bwd_finalize(st_prev, rows_dw(B, h, w_, cin, stride, 1), B * h * w_, pi - 2 if k > 0 else 1)
+            rows = rows_dw(B, h, w_, cin, stride, 1)
+            gi = pi - 2 if k > 0 else 1
+            if ctx.frozen or not _FOLD_WITH_FINALIZE:
+                L.call("ttk_bc_dw_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), p(g) if has_skip else None, p(st_prev.y), p(st_prev.bn),
+                       p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 1, dw_scratch, B, h, w_, cin, stride)
+                bwd_finalize(st_prev, rows, B * h * w_, gi)
+            else:
+                # the kernel leaves its weight-gradient rows unfolded (dw_accumulate = 2); ONE launch finalises the producer's BatchNorm backward
+                # AND folds them (two dependent few-microsecond launches less per layer)
+                L.call("ttk_bc_dw_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), p(g) if has_skip else None, p(st_prev.y), p(st_prev.bn),
+                       p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 2, dw_scratch, B, h, w_, cin, stride)
+                L.call("ttk_bc_bn_bwd_finalize_fold", p(part), rows, cin, B * h * w_, p(params[gi]), p(st_prev.bn), p(grads[gi]), p(grads[gi + 1]), 0,
+                       dw_scratch, rows, 9 * cin, p(dWd), 1)
         g = g_prev
         if MB.grad_ready_hook is not None:
             announce(pi, pi + 6)

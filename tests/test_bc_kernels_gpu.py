@@ -214,3 +214,22 @@ def test_depthwise_forward_and_backward(B, H, W, C, stride, skip):
         s = part.double().sum(0).cpu()
         assert torch.allclose(s[0], gp_got.sum((0, 1, 2)), rtol=1e-4, atol=1e-3), "backward partial sums (1)"
         assert torch.allclose(s[1], (gp_got * (yprev - bn_prev[MEAN])).sum((0, 1, 2)), rtol=1e-4, atol=2e-3), "backward partial sums (2)"
+    # ---------------- workgroup rows + ONE launch for "fold the rows" and "finalise the producer's BatchNorm backward" = the two separate calls, bitwise
+    scr = torch.full((rows * 9 * C,), float("nan"), device="cuda")
+    gamma = (torch.rand(C, generator=g) + 0.5).float().cuda()
+    outs = []
+    for fused_launch in (False, True):
+        dwx, bnx = torch.full((C, 1, 3, 3), 0.25, device="cuda"), d_bnp.clone()
+        dgm, dbt = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        L.call("ttk_bc_dw_bwd_data", p(d_g), p(d_yd), p(d_bnd), p(d_w), p(d_sg), p(d_yprev), p(d_bnp), p(d_skip), p(a_out), p(g_prev), p(part), p(dwx),
+               2 if fused_launch else 1, p(scr), B, H, W, C, stride)
+        if fused_launch:
+            L.call("ttk_bc_bn_bwd_finalize_fold", p(part), rows, C, B * H * W, p(gamma), p(bnx), p(dgm), p(dbt), 0, p(scr), rows, 9 * C, p(dwx), 1)
+        else:
+            L.call("ttk_bn_bwd_finalize", p(part), rows, C, B * H * W, p(gamma), p(bnx), p(dgm), p(dbt), 0)
+        torch.cuda.synchronize()
+        outs.append((dwx.clone(), bnx.clone(), dgm.clone(), dbt.clone()))
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_), "combined finalisation + fold launch differs from the two separate launches"
+    err = (outs[1][0].cpu().double().view(C, 3, 3) - 0.25 - dw_ref).abs().max().item()
+    assert err <= 2e-4 * dw_ref.abs().max().item() + 1e-4, f"weight gradient through the row fold off by {err:.3e}"
