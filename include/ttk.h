@@ -49,7 +49,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 25
+#define TTK_ABI_VERSION 26
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -287,6 +287,10 @@ int ttk_bc_pw_bwd_data(const void* g, const void* y, const float* bn_pw, const v
 size_t ttk_bc_pw_wgrad_scratch_bytes(int64_t M, int Cin, int Cout);
 int ttk_bc_pw_bwd_weight(const void* g, const void* y, const float* bn_pw, const void* ydw, const float* bn_dw, float* dw,
                          float* scratch, int64_t M, int Cin, int Cout, ttk_stream_t stream);
+/* dw == NULL (ttk_bc_pw_bwd_weight, ttk_bc_pw_bwd_fused): the slice tiles stay in `scratch` as [slices][Cout * Cin] (slices =
+ * ttk_bc_pw_wgrad_slices / ttk_bc_pw_bwd_fused_rows) and the caller adds them to dw with ttk_bc_bn_bwd_finalize_fold, in the launch that
+ * finalises the BatchNorm backward of the layer's input (same fixed order, same results). */
+int ttk_bc_pw_wgrad_slices(int64_t M, int Cin, int Cout);
 /* ttk_bc_pw_bwd_weight AND ttk_bc_pw_bwd_data of the early layers (32 -> 64, 64 -> 128, 128 -> 128: the largest pixel counts, HBM-bound)
  * in one kernel that reads g, y and ydw once: same results as the pair (the weight gradient is reduced over a different slicing of the
  * pixels).  ttk_bc_pw_bwd_fused_rows = the rows of `part` it writes, 0 = the shape has no fused form (use the pair);

@@ -136,6 +136,23 @@ __device__ __forceinline__ void fold_rows_fast_body(const float* __restrict__ pa
     st4(out + i, t);
   }
 }
+// out[i] += partial[0][i] + partial[1][i] + ... for MANY outputs (the slice tiles of the wide pointwise weight gradients: up to 1 M outputs, <= 64 rows):
+// 16 B per thread, eight loads in flight, rows in order.  `block` of `nthreads` threads.
+__device__ __forceinline__ void fold_rows_wide_body(const float* __restrict__ partial, int rows, int64_t n, float* __restrict__ out, unsigned block, int nthreads) {
+  const int64_t i = ((int64_t)block * nthreads + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 a = ld4(out + i);
+  int s = 0;
+  for (; s + 8 <= rows; s += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ld4nt(partial + (size_t)(s + u) * n + i);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a = add4(a, v[u]);
+  }
+  for (; s < rows; ++s) a = add4(a, ld4nt(partial + (size_t)s * n + i));
+  st4(out + i, a);
+}
 template <int kDummy = 0>
 __global__ void __launch_bounds__(1024) fold_rows_fast_k(const float* __restrict__ partial, int rows, int64_t n, float* __restrict__ out, int accumulate) {
   fold_rows_fast_body(partial, rows, n, out, accumulate, blockIdx.x);

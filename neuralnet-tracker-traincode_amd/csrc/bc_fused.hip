@@ -314,7 +314,7 @@ size_t ttk_bc_pw_bwd_fused_scratch_bytes(int64_t M, int Cin, int Cout) {
 
 int ttk_bc_pw_bwd_fused(const void* g, const void* y, const float* bn_pw, const void* wprep, const void* ydw, const float* bn_dw, void* g_dw, float* dw,
                         float* scratch, float* part, int64_t M, int Cin, int Cout, ttk_stream_t stream) {
-  TTK_REQUIRE(g && y && bn_pw && wprep && ydw && bn_dw && g_dw && dw && scratch, "bc_pw_bwd_fused: null pointer");
+  TTK_REQUIRE(g && y && bn_pw && wprep && ydw && bn_dw && g_dw && scratch, "bc_pw_bwd_fused: null pointer");
   FPlan p;
   TTK_REQUIRE(fused_plan(M, Cin, Cout, p), "bc_pw_bwd_fused: no fused form for %d -> %d", Cin, Cout);
   hipStream_t st = (hipStream_t)stream;
@@ -323,7 +323,8 @@ int ttk_bc_pw_bwd_fused(const void* g, const void* y, const float* bn_pw, const 
   else if (Cin == 64) launch_fused<4, 2, 64>(p, st, g, y, bn_pw, ydw, bn_dw, img, g_dw, scratch, part, M);
   else launch_fused<4, 4, 32>(p, st, g, y, bn_pw, ydw, bn_dw, img, g_dw, scratch, part, M);
   const int64_t n = (int64_t)Cin * Cout;
-  if (!launch_fold_rows_fast(scratch, (int)p.slices, n, dw, 1, st)) launch_fold_partials(scratch, (int)p.slices, n, dw, 1, st);
+  // (dw == NULL: the caller folds the ttk_bc_pw_bwd_fused_rows tiles of scratch itself - ttk_bc_bn_bwd_finalize_fold)
+  if (dw && !launch_fold_rows_fast(scratch, (int)p.slices, n, dw, 1, st)) launch_fold_partials(scratch, (int)p.slices, n, dw, 1, st);
   TTK_LAUNCH_CHECK("bc_pw_bwd_fused");
 }
 

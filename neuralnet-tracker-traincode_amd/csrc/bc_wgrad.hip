@@ -212,19 +212,7 @@ __global__ void __launch_bounds__(512) bc_wgrad_k(const bf16_t* __restrict__ G, 
 
 // dW[i] += partial[0][i] + partial[1][i] + ... (fixed order); 16 B per lane, eight loads in flight
 __global__ void __launch_bounds__(256) bc_wgrad_fold_k(const float* __restrict__ partial, float* __restrict__ dW, int64_t n, int slices) {
-  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= n) return;
-  float4 a = ld4(dW + i);
-  int s = 0;
-  for (; s + 8 <= slices; s += 8) {
-    float4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = ld4nt(partial + (size_t)(s + u) * n + i);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) a = add4(a, v[u]);
-  }
-  for (; s < slices; ++s) a = add4(a, ld4nt(partial + (size_t)s * n + i));
-  st4(dW + i, a);
+  fold_rows_wide_body(partial, slices, n, dW, blockIdx.x, 256);
 }
 
 struct WPlan { int TN, TK, CP, tiles; int64_t slices, rows; };
@@ -268,9 +256,14 @@ size_t ttk_bc_pw_wgrad_scratch_bytes(int64_t M, int Cin, int Cout) {
   return (size_t)p.slices * Cin * Cout * sizeof(float);
 }
 
+int ttk_bc_pw_wgrad_slices(int64_t M, int Cin, int Cout) {
+  WPlan p;
+  return wgrad_plan(M, Cin, Cout, p) ? (int)p.slices : 0;
+}
+
 int ttk_bc_pw_bwd_weight(const void* g, const void* y, const float* bn_pw, const void* ydw, const float* bn_dw, float* dw, float* scratch, int64_t M,
                          int Cin, int Cout, ttk_stream_t stream) {
-  TTK_REQUIRE(g && y && bn_pw && ydw && bn_dw && dw && scratch, "bc_pw_bwd_weight: null pointer");
+  TTK_REQUIRE(g && y && bn_pw && ydw && bn_dw && scratch, "bc_pw_bwd_weight: null pointer");
   WPlan p;
   TTK_REQUIRE(wgrad_plan(M, Cin, Cout, p), "bc_pw_bwd_weight: unsupported shape M=%lld %d -> %d", (long long)M, Cin, Cout);
   hipStream_t st = (hipStream_t)stream;
@@ -290,6 +283,9 @@ int ttk_bc_pw_bwd_weight(const void* g, const void* y, const float* bn_pw, const
   else TTK_BC_WG(8, 8, 32, 4, 2, 1);
 #undef TTK_BC_WG
 #if !defined(TTK_BC_WGRAD_ATOMIC)
+  if (!dw) {  // the caller folds the ttk_bc_pw_wgrad_slices tiles of scratch itself (ttk_bc_bn_bwd_finalize_fold)
+    TTK_LAUNCH_CHECK("bc_pw_bwd_weight");
+  }
   const int64_t n = (int64_t)Cin * Cout;
   if (!launch_fold_rows_fast(scratch, (int)p.slices, n, dw, 1, st))
     hipLaunchKernelGGL(bc_wgrad_fold_k, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, st, scratch, dw, n, (int)p.slices);

@@ -140,7 +140,8 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_fold_k(const float* __re
                                                                const float* __restrict__ fold_partial, int fold_rows, int64_t fold_n,
                                                                float* __restrict__ fold_out, int fold_accumulate) {
   if (blockIdx.x < nfin) bn_bwd_finalize_body(part, rows, C, inv_count, gamma, bn, dgamma, dbeta, accumulate, blockIdx.x);
-  else bc::fold_rows_fast_body(fold_partial, fold_rows, fold_n, fold_out, fold_accumulate, blockIdx.x - nfin);
+  else if (fold_accumulate >= 0) bc::fold_rows_fast_body(fold_partial, fold_rows, fold_n, fold_out, fold_accumulate, blockIdx.x - nfin);
+  else bc::fold_rows_wide_body(fold_partial, fold_rows, fold_n, fold_out, blockIdx.x - nfin, 1024);  // (many outputs: always accumulates)
 }
 
 // Backward through a FROZEN BatchNorm (eval-mode statistics, reference modelcomponents.py:208-215 freeze_norm_stats: the layer
@@ -285,13 +286,16 @@ int ttk_bc_bn_bwd_finalize_fold(float* part, int part_rows, int C, int64_t count
   TTK_REQUIRE(C > 0 && part_rows > 0 && count > 0 && fold_rows > 0 && fold_n > 0, "bc_bn_bwd_finalize_fold: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   part_rows = fold_if_needed(part, part_rows, C, st);
-  if (!bc::fold_rows_fast_ok(fold_rows, fold_n)) {  // shapes the fast fold does not take: two launches, same results
-    launch_fold_partials(fold_partial, fold_rows, fold_n, fold_out, fold_accumulate, st);
-    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 31) / 32), dim3(1024), 0, st, part, part_rows, C, 1.0 / (double)count, gamma, bn, dgamma, dbeta, accumulate);
-  } else {
-    const unsigned nfin = (unsigned)((C + 31) / 32);
+  const unsigned nfin = (unsigned)((C + 31) / 32);
+  if (bc::fold_rows_fast_ok(fold_rows, fold_n)) {  // few outputs, many rows (depthwise workgroup rows, slice tiles of the early pointwise layers)
     hipLaunchKernelGGL(bn_bwd_finalize_fold_k, dim3(nfin + bc::fold_rows_fast_blocks(fold_n)), dim3(1024), 0, st, part, part_rows, C, 1.0 / (double)count, gamma, bn,
                        dgamma, dbeta, accumulate, nfin, fold_partial, fold_rows, fold_n, fold_out, fold_accumulate);
+  } else if (fold_n % 4 == 0 && fold_accumulate) {  // many outputs (slice tiles of the wide pointwise layers)
+    hipLaunchKernelGGL(bn_bwd_finalize_fold_k, dim3(nfin + (unsigned)ceil_div(fold_n, 4096)), dim3(1024), 0, st, part, part_rows, C, 1.0 / (double)count, gamma, bn,
+                       dgamma, dbeta, accumulate, nfin, fold_partial, fold_rows, fold_n, fold_out, -1);
+  } else {  // shapes neither form takes: two launches, same results
+    launch_fold_partials(fold_partial, fold_rows, fold_n, fold_out, fold_accumulate, st);
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(nfin), dim3(1024), 0, st, part, part_rows, C, 1.0 / (double)count, gamma, bn, dgamma, dbeta, accumulate);
   }
   TTK_LAUNCH_CHECK("bc_bn_bwd_finalize_fold");
 }

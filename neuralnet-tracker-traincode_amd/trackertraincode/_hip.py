@@ -108,7 +108,7 @@ _SIGNATURES = {
     "ttk_bc_bn_bwd_finalize_fold": [_P, _I, _I, _L, _P, _P, _P, _P, _I, _P, _I, _L, _P, _I],
 }
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 
 # Whether the backbones hand the running mean to the forward producers as the statistics pivot (include/ttk.h).  Always on in the
@@ -178,6 +178,7 @@ class _Library:
         self.cdll.ttk_bc_partial_rows_pool.argtypes, self.cdll.ttk_bc_partial_rows_pool.restype = [c_int] * 3, c_int
         self.cdll.ttk_bc_pw_wgrad_scratch_bytes.argtypes, self.cdll.ttk_bc_pw_wgrad_scratch_bytes.restype = [c_int64, c_int, c_int], ctypes.c_size_t
         self.cdll.ttk_bc_pw_bwd_fused_rows.argtypes, self.cdll.ttk_bc_pw_bwd_fused_rows.restype = [c_int64, c_int, c_int], c_int
+        self.cdll.ttk_bc_pw_wgrad_slices.argtypes, self.cdll.ttk_bc_pw_wgrad_slices.restype = [c_int64, c_int, c_int], c_int
         self.cdll.ttk_bc_pw_bwd_fused_scratch_bytes.argtypes, self.cdll.ttk_bc_pw_bwd_fused_scratch_bytes.restype = [c_int64, c_int, c_int], ctypes.c_size_t
         self._fns = {}
         self._stale_reported = False
@@ -373,4 +374,4 @@ def exported_symbols() -> list[str]:
             "ttk_pwconv_wgrad_partial_bytes", "ttk_pwconv_wgrad_scratch_bytes", "ttk_stem_wgrad_partial_bytes", "ttk_conv_wgrad_partial_bytes", "ttk_stem7_wgrad_partial_bytes",
             "ttk_pwconv1x1_bwd_fused_rows", "ttk_pwconv1x1_bwd_fused_partial_bytes", "ttk_bc_prepared_bytes", "ttk_bc_partial_rows_pw",
             "ttk_bc_partial_rows_dw", "ttk_bc_partial_rows_pool", "ttk_bc_pw_wgrad_scratch_bytes", "ttk_bc_pw_bwd_fused_rows",
-            "ttk_bc_pw_bwd_fused_scratch_bytes"] + list(_SIGNATURES)
+            "ttk_bc_pw_bwd_fused_scratch_bytes", "ttk_bc_pw_wgrad_slices"] + list(_SIGNATURES)

@@ -22,8 +22,9 @@ _BF = 3          # TTK_STORE_ACT_BF16 | TTK_STORE_GRAD_BF16 (stem: C = 32, the s
 _DT = torch.bfloat16
 
 
-# Experiment hook (tools/exp/ab_fold_finalize.py): False = the depthwise weight-gradient rows are folded by their own launch
-_FOLD_WITH_FINALIZE = True
+# Which weight-gradient folds ride in the launch that finalises a BatchNorm backward (ttk_bc_bn_bwd_finalize_fold) instead of their own launch:
+# 0 none, 1 the depthwise rows, 2 + the slice tiles of the fused early layers, 3 + those of the wide layers (tools/exp/ab_fold_finalize.py)
+_FOLD_WITH_FINALIZE = 2
 
 
 def part_buffer(B, H, W, device, blocks, blur=False):
@@ -183,14 +184,21 @@ def backward_impl(MB, ctx, gfeat, params):
         # -- pointwise: weight gradient, data gradient (+ bn_dw backward sums)
         g_dw = torch.empty(st_dw.y.shape, dtype=_DT, device=st_dw.y.device)
         fused_rows = L.cdll.ttk_bc_pw_bwd_fused_rows(M, cin, cout) if MB._FUSED_PW_BWD else 0
+        defer = (not ctx.frozen) and _FOLD_WITH_FINALIZE >= (2 if fused_rows > 0 else 3)  # the slice tiles are folded by the launch that finalises bn_dw's backward
+        dWp = None if defer else p(grads[pi + 3])
         if fused_rows > 0:  # the early layers (HBM-bound): one kernel reads g, y, ydw once for both gradients
-            L.call("ttk_bc_pw_bwd_fused", p(g), p(st_pw.y), p(st_pw.bn), p(ctx.prep[k]), p(st_dw.y), p(st_dw.bn), p(g_dw), p(grads[pi + 3]), p(scratch),
+            L.call("ttk_bc_pw_bwd_fused", p(g), p(st_pw.y), p(st_pw.bn), p(ctx.prep[k]), p(st_dw.y), p(st_dw.bn), p(g_dw), dWp, p(scratch),
                    p(part), M, cin, cout)
-            bwd_finalize(st_dw, fused_rows, M, pi + 1)
+            rows, slices = fused_rows, fused_rows
         else:
-            L.call("ttk_bc_pw_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), p(grads[pi + 3]), p(scratch), M, cin, cout)
+            L.call("ttk_bc_pw_bwd_weight", p(g), p(st_pw.y), p(st_pw.bn), p(st_dw.y), p(st_dw.bn), dWp, p(scratch), M, cin, cout)
             L.call("ttk_bc_pw_bwd_data", p(g), p(st_pw.y), p(st_pw.bn), p(ctx.prep[k]), p(st_dw.y), p(st_dw.bn), p(g_dw), p(part), M, cin, cout)
-            bwd_finalize(st_dw, rows_pw(M, cout, cin), M, pi + 1)
+            rows, slices = rows_pw(M, cout, cin), L.cdll.ttk_bc_pw_wgrad_slices(M, cin, cout)
+        if defer:
+            L.call("ttk_bc_bn_bwd_finalize_fold", p(part), rows, cin, M, p(params[pi + 1]), p(st_dw.bn), p(grads[pi + 1]), p(grads[pi + 2]), 0,
+                   p(scratch), slices, cin * cout, p(grads[pi + 3]), 1)
+        else:
+            bwd_finalize(st_dw, rows, M, pi + 1)
         # -- depthwise: data gradient (+ residual gradient, + producer's bn sums) with the fused weight gradient
         dWd = grads[pi]
         g_prev = torch.empty(st_prev.y.shape, dtype=_DT, device=st_prev.y.device)
@@ -206,7 +214,7 @@ def backward_impl(MB, ctx, gfeat, params):
         else:
             rows = rows_dw(B, h, w_, cin, stride, 1)
             gi = pi - 2 if k > 0 else 1
-            if ctx.frozen or not _FOLD_WITH_FINALIZE:
+            if ctx.frozen or _FOLD_WITH_FINALIZE < 1:
                 L.call("ttk_bc_dw_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), p(g) if has_skip else None, p(st_prev.y), p(st_prev.bn),
                        p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 1, dw_scratch, B, h, w_, cin, stride)
                 bwd_finalize(st_prev, rows, B * h * w_, gi)

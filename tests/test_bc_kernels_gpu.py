@@ -139,6 +139,37 @@ def test_pointwise_forward_datagrad_weightgrad(M, cin, cout):
         assert torch.allclose(s2[0], gd_got.sum(0), rtol=1e-4, atol=1e-4) and torch.allclose(s2[1], (gd_got * (ydw - bn_dw[MEAN])).sum(0), rtol=1e-4, atol=1e-3)
         err = (dw2.cpu().double() - dw0.double() - dw_ref).abs().max().item()
         assert err <= 1e-4 * dw_ref.abs().max().item() + 1e-5, f"fused weight gradient off by {err:.3e}"
+    # ---------------- deferred fold: dw = NULL leaves the slice tiles in scratch; ttk_bc_bn_bwd_finalize_fold adds them in the launch that finalises
+    # bn_dw's backward - bitwise what the separate launches give (weight gradient, BatchNorm-backward constants, dgamma / dbeta)
+    gamma = (torch.rand(cin, generator=g) + 0.5).float().cuda()
+    rows_d = L.cdll.ttk_bc_partial_rows_pw(M, cout, cin)
+    for fused in ((False, True) if rows > 0 else (False,)):
+        outs = []
+        for defer in (False, True):
+            dwx, bnx = dw0.clone().cuda(), d_bn_dw.clone()
+            dgm, dbt = torch.zeros(cin, device="cuda"), torch.zeros(cin, device="cuda")
+            if fused:
+                n_rows = slices = rows
+                scr = torch.full((L.cdll.ttk_bc_pw_bwd_fused_scratch_bytes(M, cin, cout) // 4,), float("nan"), dtype=torch.float32, device="cuda")
+                prt = torch.full((n_rows, 2, cin), float("nan"), device="cuda")
+                L.call("ttk_bc_pw_bwd_fused", p(d_g), p(d_y), p(d_bn_pw), p(prep), p(d_ydw), p(d_bn_dw), p(g_dw), None if defer else p(dwx), p(scr), p(prt), M, cin, cout)
+            else:
+                n_rows, slices = rows_d, L.cdll.ttk_bc_pw_wgrad_slices(M, cin, cout)
+                assert slices > 0
+                scr = torch.full((L.cdll.ttk_bc_pw_wgrad_scratch_bytes(M, cin, cout) // 4,), float("nan"), dtype=torch.float32, device="cuda")
+                prt = torch.full((n_rows, 2, cin), float("nan"), device="cuda")
+                L.call("ttk_bc_pw_bwd_weight", p(d_g), p(d_y), p(d_bn_pw), p(d_ydw), p(d_bn_dw), None if defer else p(dwx), p(scr), M, cin, cout)
+                L.call("ttk_bc_pw_bwd_data", p(d_g), p(d_y), p(d_bn_pw), p(prep), p(d_ydw), p(d_bn_dw), p(g_dw), p(prt), M, cin, cout)
+            if defer:
+                L.call("ttk_bc_bn_bwd_finalize_fold", p(prt), n_rows, cin, M, p(gamma), p(bnx), p(dgm), p(dbt), 0, p(scr), slices, cin * cout, p(dwx), 1)
+            else:
+                L.call("ttk_bn_bwd_finalize", p(prt), n_rows, cin, M, p(gamma), p(bnx), p(dgm), p(dbt), 0)
+            torch.cuda.synchronize()
+            outs.append((dwx.clone(), bnx.clone(), dgm.clone(), dbt.clone()))
+        for a_, b_ in zip(*outs):
+            assert torch.equal(a_, b_), f"deferred fold differs from the separate launches (fused={fused})"
+        err = (outs[1][0].cpu().double() - dw0.double() - dw_ref).abs().max().item()
+        assert err <= 1e-4 * dw_ref.abs().max().item() + 1e-5, f"deferred weight gradient off by {err:.3e}"
 
 
 def _nchw(t):
