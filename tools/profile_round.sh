@@ -33,7 +33,7 @@ rm -rf $OUT/prof_mn $OUT/prof_256 $OUT/prof_rn $OUT/prof_bf $OUT/prof_bc $OUT/pm
 python3 bench.py --steps 30 --warmup 5 --traffic-json $OUT/pmc_traffic.json > $OUT/bench_B512.json 2>/dev/null
 python3 bench.py --batch 256 --steps 30 --warmup 5 > $OUT/bench_B256.json 2>/dev/null
 python3 bench.py --backbone resnet18 --steps 20 --warmup 5 > $OUT/bench_resnet18_B512.json 2>/dev/null
-python3 bench.py --precision bf16-compute --steps 30 --warmup 5 > $OUT/bench_B512_bf16_compute.json 2>/dev/null
+python3 bench.py --precision bf16-compute --steps 30 --warmup 5 --traffic-json $OUT/pmc_traffic_bf16_compute.json > $OUT/bench_B512_bf16_compute.json 2>/dev/null
 python3 bench.py --precision bf16 --steps 30 --warmup 5 > $OUT/bench_B512_bf16.json 2>/dev/null
 for f in bench_B512 bench_B256 bench_resnet18_B512 bench_B512_bf16_compute bench_B512_bf16 bench_B512_profiled; do cut -c1-170 $OUT/$f.json; echo; done
 ls -la $OUT
