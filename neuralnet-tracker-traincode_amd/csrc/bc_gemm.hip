@@ -176,7 +176,8 @@ __global__ void __launch_bounds__(512) bc_gemm_e_k(const bf16_t* __restrict__ A0
 #pragma unroll(NKB <= 2 ? NKB : 1)
     for (int kb = 0; kb < NKB; ++kb) {
       if (kb + 1 < NKB) load(g, kb + 1, rn0, rn1);
-      else if (g + stride < groups) load(g + stride, 0, rn0, rn1);
+      else if constexpr (MODE == kFwd && NKB == 1) load(g + stride < groups ? g + stride : g, 0, rn0, rn1);  // unconditional (the last group requests itself again): 32 -> 64 forward 67.5 -> 63.5 us
+      else if (g + stride < groups) load(g + stride, 0, rn0, rn1);  // (the other shapes LOSE 8 - 17 % with the unconditional form: profiles/r05_bc_gemm_variants.txt)
 #pragma unroll
       for (int s = 0; s < SS; ++s) {
         const bf16x8 fr = make_frag<MODE>(rc0[s], rc1[s], cA, K, kb * 64 + 16 * s + 8 * h);
@@ -452,7 +453,7 @@ static int launch_gemm(const bf16_t* A0, const bf16_t* A1, const float* bnA, con
     return 0;                                                                                                                                     \
   }
     TTK_BC_E(2, 1) TTK_BC_E(4, 2) TTK_BC_E(4, 4)            // forward: 32 -> 64, 64 -> 128, 128 -> 128
-    TTK_BC_E(1, 2) TTK_BC_E(2, 4) TTK_BC_E(4, 8)            // data gradient of 32 -> 64, 64 -> 128, 128 -> 256 (and 4, 4: 128 -> 128)
+    TTK_BC_E(1, 2) TTK_BC_E(2, 4)                           // data gradient of 32 -> 64, 64 -> 128 (and 4, 4: 128 -> 128); K = 256 runs the streamed kernel
 #undef TTK_BC_E
     return -2;
   }
