@@ -49,7 +49,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 26
+#define TTK_ABI_VERSION 27
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {
@@ -183,7 +183,8 @@ int ttk_dwconv3x3_fwd(const void* yprev, const float* bn_prev, const void* skip_
  * needs is already in registers here.
  * Raises bn_prev[TTK_BN_AUX][TTK_AUX_GMAX] to max |g_prev| (the bound the previous block's GEMMs scale by).
  * dw_partial (nullable): scratch of ttk_partial_rows_dwconv(.., 1) * 9 * C floats - the fused weight gradient is then
- * folded from per-workgroup rows in a fixed order (bitwise reproducible) instead of fp32 atomics. */
+ * folded from per-workgroup rows in a fixed order (bitwise reproducible) instead of fp32 atomics.  * dw_accumulate == 2 (with dw_partial): the rows stay UNFOLDED in dw_partial and the caller folds them with ttk_bc_bn_bwd_finalize_fold, in the
+ * launch that finalises the producer's BatchNorm backward (the product's default since round 5: one launch instead of float atomics). */
 int ttk_dwconv3x3_bwd_data(const void* g_dw, const void* y_dw, const float* bn_dw, const float* w,
                            const void* skip_grad, const void* yprev, float* bn_prev,
                            const void* skip_prev, const void* a_in, void* g_prev, float* part,

@@ -602,7 +602,8 @@ int ttk_dwconv3x3_bwd_data(const void* g_dw, const void* y_dw, const float* bn_d
 #undef TTK_DW_BWD_L
 #undef TTK_DW_BWD
 #undef TTK_DW_BWD_SL
-  if (dw_partial) launch_fold_partials(dw_partial, t.rows, (int64_t)9 * C, dw, dw_accumulate, st);
+  // dw_accumulate == 2: the rows stay unfolded - the caller folds them beside the BatchNorm-backward finalisation (ttk_bc_bn_bwd_finalize_fold)
+  if (dw_partial && dw_accumulate != 2) launch_fold_partials(dw_partial, t.rows, (int64_t)9 * C, dw, dw_accumulate, st);
   TTK_LAUNCH_CHECK("dwconv3x3_bwd_data");
 }
 

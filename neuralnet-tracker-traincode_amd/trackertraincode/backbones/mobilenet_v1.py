@@ -299,7 +299,10 @@ _USE_WGRAD_STREAM = False
 # by a second kernel instead of fp32 atomics): two runs of a step give bitwise equal gradients.
 _DETERMINISTIC = os.environ.get("TTK_DETERMINISTIC", "0") != "0"
 _FUSED_PW_BWD = True
-_DW_WGRAD_ROWS = False  # True (tools; always in deterministic mode): rows + fold instead of float atomics - no gain measured on the fp32 kernels (round 5: 68.0k either way)
+# The fused depthwise weight gradient: 0 = float atomics (the product until round 5), 1 = workgroup rows + their own fold launch (slower: 67.3 k against
+# 68.4 k crops/s), 2 = rows folded inside the launch that finalises the producer's BatchNorm backward (ttk_bc_bn_bwd_finalize_fold: 68.9 k, same box,
+# tools/exp/ab_dw_rows_fp32.py) - the product.  Deterministic mode keeps its own scratch and fold order.
+_DW_WGRAD_ROWS = 2
 _SIDE_STREAMS: dict = {}
 
 
@@ -354,8 +357,7 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
     pw_scratch = wg_scratch if (wg_scratch is not None and wg_scratch.numel() * 4 >= pw_need) else (
         torch.empty(pw_need // 4, dtype=torch.float32, device=gfeat.device) if pw_need else None)
     keep = []
-    # The fused depthwise weight gradient of the fp32 kernels adds float atomics (deterministic mode: workgroup rows + a fixed-order fold).
-    # Rows + fold in every mode were measured in round 5 (the bf16-compute kernels gain from them: _mobilenet_bc.py): no change here.
+    # The fused depthwise weight gradient of the fp32 kernels: workgroup rows (see _DW_WGRAD_ROWS above; deterministic mode: rows + a fixed-order fold of its own).
     dw_rows = wg_scratch
     if dw_rows is None and _DW_WGRAD_ROWS:
         need = max(L.partial_rows_dwconv(B, d[0], d[1], d[4], d[6], True) * 9 * d[4] for d in ctx.dims)
@@ -417,10 +419,18 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
             L.call("ttk_bn_bwd_frozen", p(st_t.bn), cin)
             L.call("ttk_dwconv3x3_bwd_data", p(g_t), p(st_t.y), p(st_t.bn), p(w_blur), None, p(st_prev.y), p(st_prev.bn), p(st_prev.skip),
                    None, p(g_prev), p(part), None, 0, None, B, h, w_, cin, stride, bf)
+            bwd_finalize(st_prev, L.partial_rows_dwconv(B, h, w_, cin, stride, True), B * h * w_, pi - 2 if k > 0 else 1)
+        elif _DW_WGRAD_ROWS == 2 and not _DETERMINISTIC and not ctx.frozen:
+            # workgroup rows, folded by the launch that finalises the producer's BatchNorm backward (one launch instead of atomics + nothing / rows + fold)
+            rows, gi = L.partial_rows_dwconv(B, h, w_, cin, stride, True), (pi - 2 if k > 0 else 1)
+            L.call("ttk_dwconv3x3_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), p(g) if has_skip else None, p(st_prev.y),
+                   p(st_prev.bn), p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 2, p(dw_rows), B, h, w_, cin, stride, bf)
+            L.call("ttk_bc_bn_bwd_finalize_fold", p(part), rows, cin, B * h * w_, p(params[gi]), p(st_prev.bn), p(grads[gi]), p(grads[gi + 1]), 0,
+                   p(dw_rows), rows, 9 * cin, p(dWd), 1)
         else:
             L.call("ttk_dwconv3x3_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), p(g) if has_skip else None, p(st_prev.y),
                    p(st_prev.bn), p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 1, p(dw_rows), B, h, w_, cin, stride, bf)
-        bwd_finalize(st_prev, L.partial_rows_dwconv(B, h, w_, cin, stride, True), B * h * w_, pi - 2 if k > 0 else 1)
+            bwd_finalize(st_prev, L.partial_rows_dwconv(B, h, w_, cin, stride, True), B * h * w_, pi - 2 if k > 0 else 1)
         g = g_prev
         if grad_ready_hook is not None:  # this block's conv + bn_dw gradients and its own bn_sep gradients are final
             if side is not None:
