@@ -46,10 +46,12 @@ def parse():
     ap.add_argument("--backbone", default="mobilenetv1", choices=["mobilenetv1", "resnet18"])
     ap.add_argument("--blurpool", action="store_true", help="the training script's --blurpool: BlurPool2D + stride-1 depthwise conv in the strided MobileNet blocks (ResNet18: in front of every "
                     "block's first convolution and in the max-pool's place)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16-all", "bf16-compute"],
-                    help="BASELINE config 5's bf16 leg (separate line, dtype bf16; mobilenetv1 only): bf16-compute = activations and gradients bf16 in "
-                    "64-channel blocks, pointwise convolutions as ONE bf16 MFMA product with fp32 accumulation (csrc/bc_*.hip); bf16 / bf16-all = the "
-                    "storage-only variants of earlier rounds (activations | activations and gradients bf16 under the fp32 kernels)")
+    ap.add_argument("--precision", default="fp32",
+                    help="fp32 (default, the headline) | bf16-compute = BASELINE config 5's bf16 leg (separate line, dtype bf16; mobilenetv1 only): activations "
+                    "and gradients bf16 in 64-channel blocks, pointwise convolutions as ONE bf16 MFMA product with fp32 accumulation (csrc/bc_*.hip).  The "
+                    "storage-only variants bf16 / bf16-all of earlier rounds are retired and raise")
+    ap.add_argument("--no-legs", action="store_true", help="skip the two short extra legs the default N = 1 run appends to its line (`legs`: batch 256 fp32 = "
+                    "BASELINE config 2, batch 512 bf16-compute = config 5's bf16 leg; 10 steps each after the headline is measured)")
     ap.add_argument("--traffic-json", default=None, help="rocprofv3 PMC summary (tools/pmc_summary.py) taken with THIS build; "
                     "fills roofline.traffic (null without it)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (the measurement); gloo with --share-gpu: "
@@ -239,6 +241,8 @@ def build_step(args, device):
     g = torch.Generator().manual_seed(7)  # synthetic 3DMM keypoint basis (the real blob is not in the reference)
     net.landmarks.deformablekeypoints.set_basis(torch.randn(68, 3, generator=g) * 0.5, torch.randn(50, 68, 3, generator=g) * 0.05)
     net = net.to(device).train()
+    if args.backbone == "mobilenetv1":
+        net.convnet.set_precision(args.precision)  # an attribute of THIS backbone: the extra legs build their own networks beside it
     flags = dict(with_pointhead=True, with_nll_loss=False, rampup_nll_losses=False)
     crit, _ = S.setup_losses(script_args(flags), net)
     opt, _ = S.create_optimizer(net, script_args(flags))
@@ -293,6 +297,50 @@ def copy_probe(device):
     out["note"] = ("ttk_stream_probe on this device: bytes read + written per second; linear = contiguous sweep, slab128 = 128-byte pieces 2048 B apart "
                    "(the depthwise kernels' 32-channel slab at C = 512); 1 GiB per measurement")
     return out
+
+
+def run_leg(args, device, batch, precision, steps=10, warmup=3):
+    """One short extra leg in the same process, after the headline is measured: its own network, optimiser and batch (precision is an
+    attribute of the backbone instance), the whole step replayed as one hipGraph (eager enqueue in-process if the capture fails), `steps`
+    timed steps between synchronisations.  Returns {"value", "ms_per_step", ...}."""
+    import argparse as _ap
+    import gc
+
+    a = _ap.Namespace(**vars(args))
+    a.batch, a.precision = batch, precision
+    net, crit, opt, batches, train = build_step(a, device)
+    params = list(net.parameters())
+
+    def eager():
+        for p in params:
+            p.grad = None
+        out = train.training_step(net, batches, 0, crit)
+        out["loss"].backward()
+        opt.step()
+        return out["loss"]
+
+    mode = "hipGraph replay"
+    try:
+        graphed = train.GraphedTrainStep(net, crit, opt)
+        step = lambda: graphed.run(batches, 0)["loss"]
+        step()
+    except Exception as exc:  # noqa: BLE001  (a failed capture must not cost the leg: eager enqueue always works, in this process)
+        print(f"bench.py: leg B={batch} {precision}: hipGraph capture failed ({type(exc).__name__}: {exc}); eager enqueue", file=sys.stderr)
+        graphed, step, mode = None, eager, "eager Python launches"
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"value": batch * steps / dt, "unit": "crops/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "per_gpu_batch": batch,
+           "dtype": "f32" if precision == "fp32" else "bf16", "precision": precision, "enqueue": mode, "loss": float(loss.item())}
+    del graphed, net, opt, batches, params
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
 
 
 def cpu_baseline(args):
@@ -374,7 +422,7 @@ def main():
     from trackertraincode import parallel
     from trackertraincode.parallel import GradAllReduce, broadcast_module_state
 
-    MB.set_activation_dtype(args.precision)
+    MB._check_precision(args.precision)  # (raises for the retired storage-only modes, naming bf16-compute)
     KernelTimer.act_bytes = 4 if args.precision == "fp32" else 2
     net, crit, opt, batches, train = build_step(args, device)
     broadcast_module_state(net)
@@ -593,6 +641,7 @@ def main():
             roof["pass"] = f"{roof_steps} extra steps after the timed region, HIP events around each conv call, single stream"
             top5 = [roofline_of(k) for k in order[:(16 if args.precision == 'bf16-compute' else 6)]]  # (bf16-compute: every depthwise instantiation)
         dominant = roof["kernel"] if roof else None
+        default_run = args.batch == 512 and args.backbone == "mobilenetv1" and args.precision == "fp32" and not args.blurpool
         per_gpu = crops / world
         line = {
             "metric": f"face-crops/sec fwd+bwd @ batch {args.batch}", "value": crops, "unit": "crops/s", "n_gpus": world, "steps": args.steps,
@@ -603,7 +652,7 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "input": "129x129x1 f32",
                        "parallelism": f"dp{world}"},
             "roofline": roof,
-            "step_roofline": ({"hbm_frac_of_8TBs": per_gpu * ALGO_BYTES_PER_CROP * (0.5 if args.precision in ("bf16-all", "bf16-compute") else 1.0) / (PEAK_HBM_GBS * 1e9),
+            "step_roofline": ({"hbm_frac_of_8TBs": per_gpu * ALGO_BYTES_PER_CROP * (0.5 if args.precision == "bf16-compute" else 1.0) / (PEAK_HBM_GBS * 1e9),
                                **({"bf16_mfma_frac_of_2500TF": per_gpu * ALGO_FLOP_PER_CROP / (PEAK_BF16_MFMA_TFLOPS * 1e12)} if args.precision == "bf16-compute"
                                   else {"fp32_mfma_frac_of_157TF": per_gpu * ALGO_FLOP_PER_CROP / (PEAK_FP32_MFMA_TFLOPS * 1e12)})} if args.backbone == "mobilenetv1"
                               else {"fp32_mfma_frac_of_157TF": per_gpu * 4.203e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12)}),  # 4.203 GFLOP/crop
@@ -616,6 +665,18 @@ def main():
         }
         if comm is not None:
             line["comm"] = comm
+        if world == 1 and default_run and not args.no_legs:
+            # BASELINE configs 2 and 5 on the same clock as the headline: two short legs in this process, AFTER the headline
+            # fields above are final; they never change `value`
+            legs = {}
+            for name, (lb, lp) in (("B256", (256, "fp32")), ("bf16_compute", (512, "bf16-compute"))):
+                try:
+                    legs[name] = run_leg(args, device, lb, lp)
+                except Exception as exc:  # noqa: BLE001
+                    legs[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            legs["note"] = ("same process, after the timed region: B256 = BASELINE config 2 (fp32, batch 256), bf16_compute = config 5's bf16 leg (batch 512); "
+                            "10 timed steps each after 3 warm-up steps, the whole step (optimiser inside) replayed as one hipGraph")
+            line["legs"] = legs
         if world == 1 and not args.no_copy_probe:
             line["copy_probe"] = copy_probe(device)
         if world == 1 and not args.no_cpu_baseline:

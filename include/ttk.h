@@ -75,14 +75,13 @@ enum {
 enum { TTK_AUX_ACT_BOUND = 0, TTK_AUX_DY_BOUND = 1, TTK_AUX_GMAX = 2 };
 /* Storage of the activation-sized tensors of the MobileNet path.  Entry points with an `act_bf16` argument take them as
  * `void*`; the argument is a set of TTK_STORE_* bits:
- *   0                                      everything float32 - the reference's precision, the default
- *   TTK_STORE_ACT_BF16                     ACTIVATIONS (raw conv outputs y, materialised block inputs) bfloat16, their
- *                                          GRADIENTS (g, g_dw, g_prev) float32 - `--precision bf16`
- *   TTK_STORE_ACT_BF16|TTK_STORE_GRAD_BF16 both bfloat16 - `--precision bf16-all` (BatchNorm's backward subtracts the
- *                                          per-channel mean of a nearly constant gradient: 8 mantissa bits are too few
- *                                          for the early layers, see tests/test_bf16_gpu.py)
- * bf16 values are rounded to nearest even on store; BatchNorm statistics are always taken from the values as stored;
- * arithmetic, statistics, weights and weight gradients are fp32 in every mode. */
+ *   0                                      everything float32 - the reference's precision: what the depthwise (ttk_dwconv3x3_*),
+ *                                          pointwise (ttk_pwconv1x1_*) and pooling (ttk_avgpool_*) entry points accept.  The storage-only
+ *                                          bf16 variants of rounds 2-5 (`--precision bf16 | bf16-all`) are RETIRED: those entry points
+ *                                          return -1 for either bit and name the bf16-compute path (ttk_bc_*, below)
+ *   TTK_STORE_ACT_BF16|TTK_STORE_GRAD_BF16 activations AND gradients bfloat16: accepted by the stem pair only (ttk_stem_fwd,
+ *                                          ttk_stem_bwd_weight), which also serves the bf16-compute path (C = 32: same bytes in either
+ *                                          block layout).  Rounded to nearest even on store; BatchNorm statistics from the values as stored. */
 #define TTK_STORE_ACT_BF16 1
 #define TTK_STORE_GRAD_BF16 2
 /* The two entry points both backbones share (ttk_avgpool_fwd / ttk_avgpool_bwd) take this bit in the same argument: their

@@ -15,6 +15,7 @@
 // fp32 path protect.
 #pragma once
 #include "ttk_common.h"
+#include <atomic>
 
 namespace ttk {
 namespace bc {
@@ -95,14 +96,19 @@ __device__ __forceinline__ uint4 act_chunk(u32x4 x, const f2 (&sc)[4], const f2 
   return p;
 }
 
-// kernels that declare more than 64 KB of dynamic LDS need the attribute once (per kernel instantiation)
+// kernels that declare more than 64 KB of dynamic LDS need the attribute - per kernel instantiation AND per device: one bit per device ordinal,
+// set with a relaxed atomic (forward runs on the main thread, backward on autograd's: both may come here first; setting the attribute twice is
+// harmless).  The call's result is returned so that a launch function can report it instead of failing later with an opaque launch error.
 template <auto Kern>
-inline void allow_big_lds() {
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    done = true;
-  }
+inline hipError_t allow_big_lds() {
+  static std::atomic<unsigned long long> done{0ull};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;  // (ordinals beyond the mask: set it every time)
+  const unsigned long long bit = 1ull << dev;
+  if (dev != 63 && (done.load(std::memory_order_relaxed) & bit)) return hipSuccess;
+  const hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (rc == hipSuccess) done.fetch_or(bit, std::memory_order_relaxed);
+  return rc;
 }
 
 // out[i] (+)= partial[0][i] + partial[1][i] + ...  for FEW outputs and MANY rows (the depthwise weight gradient's workgroup rows, the slice

@@ -664,7 +664,7 @@ int ttk_bc_dw_fwd(const void* yprev, const float* bn_prev, const void* skip_prev
   const int stage_pix = t.NI * t.stage_rows * ((t.NCT > 1 ? t.TW : W) + 2);
   const size_t sm = (size_t)stage_pix * t.SL * 2 + (size_t)(9 + 2 * kWvs) * t.SL * sizeof(float);
 #define TTK_BC_FWD3(S_, SK_, SL_, CY_)                                                                                                            \
-  allow_big_lds<bc_dw_fwd_k<S_, SK_, SL_, CY_>>();                                                                                                \
+  (void)allow_big_lds<bc_dw_fwd_k<S_, SK_, SL_, CY_>>();                                                                                                \
   hipLaunchKernelGGL((bc_dw_fwd_k<S_, SK_, SL_, CY_>), dim3(t.grid), dim3(bc::kBlock), sm, (hipStream_t)stream, (const bf16_t*)yprev, bn_prev,          \
                      (const bf16_t*)skip_prev, (bf16_t*)a_out, w, (bf16_t*)y, part, pivot, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, t.NI, t.NCT, t.TW, stage_pix)
 #define TTK_BC_FWD2(S_, SK_, SL_) do { if (t.carry) { TTK_BC_FWD3(S_, SK_, SL_, true); } else { TTK_BC_FWD3(S_, SK_, SL_, false); } } while (0)
@@ -694,7 +694,7 @@ int ttk_bc_dw_bwd_data(const void* g_dw, const void* y_dw, const float* bn_dw, c
   if (dw && !dw_accumulate && !dw_partial) (void)hipMemsetAsync(dw, 0, (size_t)9 * C * sizeof(float), st);
 #define TTK_BC_BWD3(S_, SL_, LEAN_)                                                                                                               \
   do {                                                                                                                                            \
-    allow_big_lds<bc_dw_bwd_k<S_, SL_, LEAN_>>();                                                                                                \
+    (void)allow_big_lds<bc_dw_bwd_k<S_, SL_, LEAN_>>();                                                                                                \
     hipLaunchKernelGGL((bc_dw_bwd_k<S_, SL_, LEAN_>), dim3(t.grid), dim3(bc::kBlock), sm, st, (const bf16_t*)g_dw, (const bf16_t*)y_dw, bn_dw, w,      \
                        (const bf16_t*)skip_grad, (const bf16_t*)yprev, bn_prev, (const bf16_t*)skip_prev, (const bf16_t*)a_in, (bf16_t*)g_prev, part, dw, \
                        dw_partial, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, stage_pix, t.NI, t.NCT, t.TW);                                     \

@@ -288,7 +288,7 @@ template <int TN32, int TK32, int CP>
 static void launch_fused(const FPlan& p, hipStream_t st, const void* g, const void* y, const float* bn_pw, const void* ydw, const float* bn_dw, const uint4* img,
                          void* g_dw, float* scratch, float* part, int64_t M) {
   constexpr auto kern = bc_bwd_fused_k<TN32, TK32, CP>;
-  allow_big_lds<kern>();
+  (void)allow_big_lds<kern>();
   const size_t lds_bytes = fused_lds<TN32, TK32, CP>();
   hipLaunchKernelGGL(kern, dim3((unsigned)p.slices), dim3(512), lds_bytes, st, (const bf16_t*)g, (const bf16_t*)y, bn_pw, (const bf16_t*)ydw,
                      bn_dw, img, (bf16_t*)g_dw, scratch, part, M, p.rows);
@@ -314,7 +314,7 @@ size_t ttk_bc_pw_bwd_fused_scratch_bytes(int64_t M, int Cin, int Cout) {
 
 int ttk_bc_pw_bwd_fused(const void* g, const void* y, const float* bn_pw, const void* wprep, const void* ydw, const float* bn_dw, void* g_dw, float* dw,
                         float* scratch, float* part, int64_t M, int Cin, int Cout, ttk_stream_t stream) {
-  TTK_REQUIRE(g && y && bn_pw && wprep && ydw && bn_dw && g_dw && scratch, "bc_pw_bwd_fused: null pointer");
+  TTK_REQUIRE(g && y && bn_pw && wprep && ydw && bn_dw && g_dw && scratch && part, "bc_pw_bwd_fused: null pointer");
   FPlan p;
   TTK_REQUIRE(fused_plan(M, Cin, Cout, p), "bc_pw_bwd_fused: no fused form for %d -> %d", Cin, Cout);
   hipStream_t st = (hipStream_t)stream;

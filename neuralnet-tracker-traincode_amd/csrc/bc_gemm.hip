@@ -439,7 +439,7 @@ static int launch_gemm(const bf16_t* A0, const bf16_t* A1, const float* bnA, con
                        const float* pivot, float* part, int64_t M, int K, int N, hipStream_t st) {
   if (is_l128(K, N)) {
     const LPlan p = l_plan(M, N, 128);
-    allow_big_lds<bc_gemm_l_k<MODE, 128>>();
+    (void)allow_big_lds<bc_gemm_l_k<MODE, 128>>();
     hipLaunchKernelGGL((bc_gemm_l_k<MODE, 128>), dim3(p.grid), dim3(512), l_lds_bytes(K, 128), st, A0, A1, bnA, Wimg, out, maskY, bnE, pivot, part, M, K, N, p.RT, p.nrt, p.ncol);
     return 0;
   }
@@ -448,7 +448,7 @@ static int launch_gemm(const bf16_t* A0, const bf16_t* A1, const float* bnA, con
     const size_t sm = e_lds_bytes(K, N);
 #define TTK_BC_E(NB_, KH_)                                                                                                                        \
   if (N == 32 * NB_ && K == 32 * KH_) {                                                                                                           \
-    allow_big_lds<bc_gemm_e_k<MODE, NB_, KH_>>();                                                                                                 \
+    (void)allow_big_lds<bc_gemm_e_k<MODE, NB_, KH_>>();                                                                                                 \
     hipLaunchKernelGGL((bc_gemm_e_k<MODE, NB_, KH_>), dim3(grid), dim3(512), sm, st, A0, A1, bnA, Wimg, out, maskY, bnE, pivot, part, M);             \
     return 0;                                                                                                                                     \
   }
@@ -459,7 +459,7 @@ static int launch_gemm(const bf16_t* A0, const bf16_t* A1, const float* bnA, con
   }
   if (!is_l(K, N)) return -2;
   const LPlan p = l_plan(M, N);
-  allow_big_lds<bc_gemm_l_k<MODE, 256>>();
+  (void)allow_big_lds<bc_gemm_l_k<MODE, 256>>();
   hipLaunchKernelGGL((bc_gemm_l_k<MODE, 256>), dim3(p.grid), dim3(512), l_lds_bytes(K), st, A0, A1, bnA, Wimg, out, maskY, bnE, pivot, part, M, K, N, p.RT, p.nrt, p.ncol);
   return 0;
 }

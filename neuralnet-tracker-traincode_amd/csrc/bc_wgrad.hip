@@ -272,7 +272,7 @@ int ttk_bc_pw_bwd_weight(const void* g, const void* y, const float* bn_pw, const
   do {                                                                                                                                          \
     constexpr size_t sm = (size_t)2 * CP_ * (wg_pitch(32 * TN32_) + wg_pitch(32 * TK32_));                                                      \
     constexpr size_t red = KS_ > 1 ? (size_t)8 * (TN32_ / WN_) * (TK32_ / WK_) * 16 * 64 * 4 : 0;                                               \
-    allow_big_lds<bc_wgrad_k<TN32_, TK32_, CP_, WN_, WK_, KS_>>();                                                                              \
+    (void)allow_big_lds<bc_wgrad_k<TN32_, TK32_, CP_, WN_, WK_, KS_>>();                                                                              \
     hipLaunchKernelGGL((bc_wgrad_k<TN32_, TK32_, CP_, WN_, WK_, KS_>), dim3(grid), dim3(512), sm > red ? sm : red, st, (const bf16_t*)g, (const bf16_t*)y, bn_pw, \
                        (const bf16_t*)ydw, bn_dw, TTK_BC_WGRAD_DST, M, Cin, Cout, p.rows, p.tiles);                                                      \
   } while (0)

@@ -589,6 +589,7 @@ int ttk_dwconv3x3_bwd_data(const void* g_dw, const void* y_dw, const float* bn_d
   const size_t sm = (stage + 4 * 9 * t.SL + 9 * t.SL) * sizeof(float);  // stage + reduction scratch + filter taps
   hipStream_t st = (hipStream_t)stream;
   if (!dw) dw_partial = nullptr;
+  TTK_REQUIRE(dw_accumulate != 2 || dw_partial, "dwconv3x3_bwd_data: dw_accumulate = 2 (rows folded by the caller) needs dw and dw_partial");
   if (dw && !dw_accumulate && !dw_partial) hipLaunchKernelGGL(zero_fill_k, dim3((9 * C + 255) / 256), dim3(256), 0, st, dw, (int64_t)9 * C);
 #define TTK_DW_BWD(S_) TTK_DW_BWD_SL(S_, kCB)
 #define TTK_DW_BWD_SL(S_, SL_) \

@@ -1084,11 +1084,6 @@ bool launch_conv_gemm16(int amode, int emode, const float* A0, const float* A1, 
   template bool launch_f16_wgrad<T_, TG_>(const TG_*, const T_*, const float*, const T_*, const float*, float*, float*, int64_t, int, int, \
                                           hipStream_t);
 TTK_INST(float, float)
-TTK_INST(bf16_t, bf16_t)
-template bool launch_f16_gemm<SMODE_DGRAD, bf16_t, float>(const float*, const bf16_t*, const float*, const float*, float*, const bf16_t*, const float*,
-                                                          float*, int64_t, int, int, void*, float*, hipStream_t);
-template bool launch_f16_wgrad<bf16_t, float>(const float*, const bf16_t*, const float*, const bf16_t*, const float*, float*, float*, int64_t, int, int,
-                                              hipStream_t);
 #undef TTK_INST
 
 }  // namespace ttk

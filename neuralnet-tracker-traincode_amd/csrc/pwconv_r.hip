@@ -1428,10 +1428,6 @@ bool launch_f16t_wgrad(const TG* g, const T* y, const float* bn_pw, const T* ydw
   return true;
 }
 template bool launch_f16t_wgrad<float, float>(const float*, const float*, const float*, const float*, const float*, float*, float*, int64_t, int, int, hipStream_t);
-template bool launch_f16t_wgrad<bf16_t, bf16_t>(const bf16_t*, const bf16_t*, const float*, const bf16_t*, const float*, float*, float*, int64_t, int, int,
-                                                hipStream_t);
-template bool launch_f16t_wgrad<bf16_t, float>(const float*, const bf16_t*, const float*, const bf16_t*, const float*, float*, float*, int64_t, int, int,
-                                               hipStream_t);
 
 // ---- tiling: row blocks of RT rows such that the tiles fill whole rounds of the CUs ------------------------------------------
 bool f16r_enabled() {
@@ -1546,9 +1542,6 @@ bool launch_f16r_gemm(const TO* A0, const T* A1, const float* bnA, const float* 
   template bool launch_f16r_gemm<RMODE_DGRAD, T_, TG_>(const TG_*, const T_*, const float*, const float*, TG_*, const T_*, const float*,    \
                                                        float*, int64_t, int, int, void*, float*, hipStream_t);
 TTK_RINST(float, float)
-TTK_RINST(bf16_t, bf16_t)
-template bool launch_f16r_gemm<RMODE_DGRAD, bf16_t, float>(const float*, const bf16_t*, const float*, const float*, float*, const bf16_t*, const float*,
-                                                           float*, int64_t, int, int, void*, float*, hipStream_t);
 #undef TTK_RINST
 
 }  // namespace ttk

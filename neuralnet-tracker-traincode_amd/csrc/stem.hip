@@ -521,10 +521,10 @@ int ttk_stem_fwd(const float* x, const float* w, void* y, float* part, const flo
     const int band_rows = kFwBand < Ho ? kFwBand : Ho;  // (balanced 11-row bands measured no better here: 74.9 vs 71.1 us - more halo rows per output row)
     const int nbands = (Ho + band_rows - 1) / band_rows;
     if (!gather && sm <= 64 * 1024)
-      TTK_ACT_DISPATCH(act_bf16, hipLaunchKernelGGL((stem_fwd_band_k<ActT>), dim3(elementwise_grid(items)), dim3(kBlock), sm, (hipStream_t)stream, x, w,
+      TTK_ACT_DISPATCH_STEM(act_bf16, hipLaunchKernelGGL((stem_fwd_band_k<ActT>), dim3(elementwise_grid(items)), dim3(kBlock), sm, (hipStream_t)stream, x, w,
                                                     (ActT*)y, part, pivot, B, H, W, Ho, Wo, nbands, band_rows));
     else
-      TTK_ACT_DISPATCH(act_bf16, hipLaunchKernelGGL((stem_fwd_mfma_k<ActT>), dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, x, w,
+      TTK_ACT_DISPATCH_STEM(act_bf16, hipLaunchKernelGGL((stem_fwd_mfma_k<ActT>), dim3(elementwise_grid(items)), dim3(kBlock), 0, (hipStream_t)stream, x, w,
                                                     (ActT*)y, part, pivot, B, H, W, Ho, Wo));
   }
   TTK_LAUNCH_CHECK("stem_fwd");
@@ -558,7 +558,7 @@ int ttk_stem_bwd_weight(const void* g, const void* y, const float* bn, const flo
     grid = B * nbands < resident ? B * nbands : resident;
     const size_t sm = ((size_t)(2 * kWgBand + 3) * W + (kBlock / kWave) * (kWgChunk * kStemC + kStemC * 25)) * sizeof(float);
     TTK_REQUIRE(sm <= 64 * 1024, "stem_bwd_weight: image too wide for the LDS band (W=%d)", W);
-    TTK_ACT_DISPATCH(act_bf16, hipLaunchKernelGGL((stem_wgrad_mfma_k<ActT, GradT>), dim3(grid), dim3(kBlock), sm, (hipStream_t)stream, (const GradT*)g,
+    TTK_ACT_DISPATCH_STEM(act_bf16, hipLaunchKernelGGL((stem_wgrad_mfma_k<ActT, GradT>), dim3(grid), dim3(kBlock), sm, (hipStream_t)stream, (const GradT*)g,
                                                   (const ActT*)y, bn, x, dw, partial, B, H, W, Ho, Wo, nbands, band_rows));
     if (partial) launch_fold_partials(partial, grid, 25 * kStemC, dw, accumulate, (hipStream_t)stream);
   }

@@ -200,13 +200,20 @@ template <> struct Act<bf16_t> {
     return __uint_as_float((unsigned)u << 16);
   }
 };
-// dispatch of a launch on the storage flag of the C-ABI: bit 0 = activations (ActT) bf16, bit 1 = activation GRADIENTS
-// (GradT) bf16 (TTK_STORE_* in ttk.h; gradients in bf16 only together with activations)
-#define TTK_ACT_DISPATCH(flag, ...)                                                               \
-  do {                                                                                            \
-    if (((flag) & 3) == 3) { using ActT = ::ttk::bf16_t; using GradT = ::ttk::bf16_t; __VA_ARGS__; } \
-    else if ((flag) & 1) { using ActT = ::ttk::bf16_t; using GradT = float; __VA_ARGS__; }        \
-    else { using ActT = float; using GradT = float; __VA_ARGS__; }                                \
+// The storage flag of the C-ABI (TTK_STORE_* in ttk.h).  Round 6 retired the bf16 STORAGE variants of the fp32 kernels (`--precision bf16 | bf16-all`:
+// slower than fp32, superseded by the bf16-compute path's own kernels, csrc/bc_*.hip): the depthwise / pointwise / pooling entry points take fp32
+// tensors only and refuse the bits; the stem pair, which also serves the bf16-compute path (C = 32: the same bytes in either layout), takes fp32 or
+// BOTH bits (activations and gradients bfloat16).
+#define TTK_ACT_DISPATCH(flag, ...)                                                                                                             \
+  do {                                                                                                                                          \
+    TTK_REQUIRE(((flag) & 3) == 0, "bf16 activation storage under the fp32 kernels was retired (round 6): use the bf16-compute path (ttk_bc_*)"); \
+    using ActT [[maybe_unused]] = float; using GradT [[maybe_unused]] = float; __VA_ARGS__;                                         \
+  } while (0)
+#define TTK_ACT_DISPATCH_STEM(flag, ...)                                                                                                        \
+  do {                                                                                                                                          \
+    TTK_REQUIRE(((flag) & 3) == 0 || ((flag) & 3) == 3, "the stem takes fp32 tensors or activations AND gradients bfloat16 (bf16-compute path)"); \
+    if (((flag) & 3) == 3) { using ActT = ::ttk::bf16_t; using GradT = ::ttk::bf16_t; __VA_ARGS__; }                                            \
+    else { using ActT = float; using GradT = float; __VA_ARGS__; }                                                                              \
   } while (0)
 
 // The "apply on load" forms of BatchNorm (see ttk.h).  Every layer owns one block

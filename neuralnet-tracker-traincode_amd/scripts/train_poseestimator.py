@@ -163,10 +163,10 @@ def make_parser():
     p.add_argument("--rampup-nll-losses", default=False, action="store_true")
     p.add_argument("--enable-6drot", default=False, action="store_true")
     # not a flag of the reference (it trains in fp32 only): storage of the backbone's activations in HBM
-    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16-all", "bf16-compute"],
-                   help="bf16: activations cross HBM as bfloat16, their gradients stay fp32; bf16-all: both bfloat16 (statistics / accumulation / weights fp32); "
-                   "bf16-compute (mobilenetv1): both bfloat16 in 64-channel blocks AND bf16 operands of the pointwise convolutions (one MFMA product, fp32 "
-                   "accumulation; master weights, statistics and Adam fp32)")
+    p.add_argument("--precision", default="fp32",
+                   help="fp32 (the reference's precision) | bf16-compute (mobilenetv1): activations and their gradients bfloat16 in 64-channel blocks AND bf16 "
+                   "operands of the pointwise convolutions (one MFMA product, fp32 accumulation; master weights, statistics and Adam fp32).  The "
+                   "storage-only variants bf16 / bf16-all of earlier rounds are retired (they were slower than fp32): they raise, naming bf16-compute")
     p.add_argument("--graph-steps", default=False, action="store_true",
                    help="single GPU: replay one captured hipGraph per training step instead of ~150 eager launches (train.GraphedTrainStep)")
     return p

@@ -89,37 +89,42 @@ class DepthWiseBlock(nn.Module):
         return self.relu(out)
 
 
-# Storage type of the activation tensors that cross HBM during TRAINING (raw conv outputs, materialised block inputs and
-# their gradients): torch.float32 - the reference's precision, the default and the only mode `bench.py`'s headline uses - or
-# torch.bfloat16 (`--precision bf16`, BASELINE config 5): half the activation bytes; BatchNorm statistics (taken from the
-# rounded values), all arithmetic, weights and weight gradients stay fp32 (csrc/ttk_common.h: Act<T>).
-_ACT_DTYPE = torch.float32
-_GRAD_DTYPE = torch.float32
-# "bf16-compute" (BASELINE config 5's bf16 leg): a separate set of kernels - bf16 storage in 64-channel blocks AND bf16 operands of the
-# pointwise products (one MFMA product, fp32 accumulation); launch sequences in _mobilenet_bc.py, kernels csrc/bc_*.hip.
-_BF16_COMPUTE = False
+# Precision of the TRAINING kernels, an attribute of every MobileNet INSTANCE (`MobileNet.precision`, `MobileNet.set_precision`; not part of
+# `get_config()` / the state dict, so checkpoints load in the reference unchanged):
+#   "fp32"          the reference's precision - activations, gradients and arithmetic fp32 (the default, `bench.py`'s headline);
+#   "bf16-compute"  BASELINE config 5's bf16 leg: activation-sized tensors and their gradients bf16 in 64-channel blocks AND bf16 operands of
+#                   the pointwise products (one MFMA product, fp32 accumulation); launch sequences in _mobilenet_bc.py, kernels csrc/bc_*.hip.
+# The storage-only variants of rounds 2-4 ("bf16" / "bf16-all": bf16 tensors under the fp32 kernels, slower than fp32) are retired.
+_PRECISIONS = ("fp32", "bf16-compute")
+_RETIRED = ("bf16", "bf16-all")
+_DEFAULT_PRECISION = "fp32"
+
+
+def _check_precision(mode):
+    mode = {torch.float32: "fp32", "f32": "fp32"}.get(mode, mode)
+    if mode in _RETIRED or mode is torch.bfloat16:
+        raise ValueError(f'precision "{mode}" (bf16 storage under the fp32 kernels) was retired: it ran slower than fp32; use "bf16-compute"')
+    if mode not in _PRECISIONS:
+        raise ValueError(f'precision must be "fp32" or "bf16-compute", got {mode}')
+    return mode
 
 
 def set_activation_dtype(mode):
-    """Storage of the backbone's activation-sized tensors in training: "fp32" (default), "bf16" (activations bfloat16,
-    their gradients float32), "bf16-all" (both bfloat16; torch.float32 / torch.bfloat16 are accepted for the first and
-    the last) or "bf16-compute" (both bfloat16 in 64-channel blocks AND bf16 operands of the pointwise products: its own kernels).  BatchNorm's backward subtracts per-channel means of nearly constant gradients, which 8 mantissa bits do
-    not survive in the early layers: keep the gradients in fp32 unless you measure otherwise."""
-    global _ACT_DTYPE, _GRAD_DTYPE, _BF16_COMPUTE
-    mode = {torch.float32: "fp32", torch.bfloat16: "bf16-all", "f32": "fp32"}.get(mode, mode)
-    if mode not in ("fp32", "bf16", "bf16-all", "bf16-compute"):
-        raise ValueError(f'activation storage must be "fp32", "bf16", "bf16-all" or "bf16-compute", got {mode}')
-    _BF16_COMPUTE = mode == "bf16-compute"
-    _ACT_DTYPE = torch.float32 if mode == "fp32" else torch.bfloat16
-    _GRAD_DTYPE = torch.bfloat16 if mode in ("bf16-all", "bf16-compute") else torch.float32
+    """Default precision of MobileNet instances that have not been given one of their own (`MobileNet.set_precision`): "fp32" or
+    "bf16-compute".  Kept for the scripts' `--precision` flag; two networks of different precision in one process use `set_precision`."""
+    global _DEFAULT_PRECISION
+    _DEFAULT_PRECISION = _check_precision(mode)
 
 
 def bf16_compute() -> bool:
-    return _BF16_COMPUTE
+    """Is the module-wide DEFAULT precision bf16-compute (instances may override it)."""
+    return _DEFAULT_PRECISION == "bf16-compute"
 
 
 def get_activation_dtype():
-    return _ACT_DTYPE, _GRAD_DTYPE
+    """(activation, gradient) storage types of the module-wide default precision."""
+    t = torch.bfloat16 if bf16_compute() else torch.float32
+    return t, t
 
 
 _BN_ROWS = 8  # TTK_BN_ROWS: scale, beta, mean, rstd, ga, gb, gmean, (pad) - see include/ttk.h
@@ -186,7 +191,7 @@ def _identity_bn(C, device):
     return _IDENTITY_BN[key].clone()
 
 
-def _forward_impl(x, params, buffers, momentum, eps, training, act_dtype=torch.float32, grad_dtype=torch.float32, frozen=False, blur=None):
+def _forward_impl(x, params, buffers, momentum, eps, training, frozen=False, blur=None):
     """Launches the forward kernels.  `params`: flat list [conv1.w, bn1.w, bn1.b, (dw.w, bn_dw.w,
     bn_dw.b, pw.w, bn_sep.w, bn_sep.b) x 13]; `buffers`: flat list of (running_mean, running_var,
     num_batches_tracked) per BN in the same order; `blur`: per block, the BlurPool2D kernel as a depthwise weight
@@ -203,8 +208,9 @@ def _forward_impl(x, params, buffers, momentum, eps, training, act_dtype=torch.f
     ctx.blur = []
     ctx.frozen = frozen  # backward through eval-mode BatchNorm: the fixed affine map (ttk_bn_bwd_frozen)
     ctx.stages, ctx.a_in, ctx.dims = [], [], []
-    bf = int(act_dtype == torch.bfloat16) | (2 if grad_dtype == torch.bfloat16 else 0)  # TTK_STORE_* bits
-    ctx.bf, ctx.gdt = bf, grad_dtype
+    act_dtype = torch.float32
+    bf = 0  # TTK_STORE_* bits of the C-ABI: fp32 tensors (the bf16 storage variants under these kernels are retired)
+    ctx.bf, ctx.gdt = bf, torch.float32
     bns = _BnArena([32] + [c for _, cin, cout, _ in _BLOCKS for c in (cin, cout)], dev)
 
     def pivot(bi):
@@ -358,10 +364,11 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         torch.empty(pw_need // 4, dtype=torch.float32, device=gfeat.device) if pw_need else None)
     keep = []
     # The fused depthwise weight gradient of the fp32 kernels: workgroup rows (see _DW_WGRAD_ROWS above; deterministic mode: rows + a fixed-order fold of its own).
+    # (the BlurPool blocks and frozen fine-tuning keep float atomics unless deterministic: they pass `wg_scratch`, not these rows)
     dw_rows = wg_scratch
-    if dw_rows is None and _DW_WGRAD_ROWS:
-        need = max(L.partial_rows_dwconv(B, d[0], d[1], d[4], d[6], True) * 9 * d[4] for d in ctx.dims)
-        need = max([need] + [L.partial_rows_dwconv(B, d[2], d[3], d[4], 1, True) * 9 * d[4] for d, bl in zip(ctx.dims, ctx.blur) if bl is not None])
+    rows_layers = [d for d, bl in zip(ctx.dims, ctx.blur) if bl is None]
+    if dw_rows is None and _DW_WGRAD_ROWS and not ctx.frozen and rows_layers:
+        need = max(L.partial_rows_dwconv(B, d[0], d[1], d[4], d[6], True) * 9 * d[4] for d in rows_layers)
         dw_rows = torch.empty(need, dtype=torch.float32, device=gfeat.device)
 
     g = torch.empty(last.y.shape, dtype=ctx.gdt, device=last.y.device)
@@ -415,7 +422,7 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
             st_t, w_blur = ctx.blur[k]
             g_t = torch.empty(st_t.y.shape, dtype=ctx.gdt, device=st_t.y.device)
             L.call("ttk_dwconv3x3_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), None, p(st_t.y), p(st_t.bn), None, None, p(g_t),
-                   p(part), p(dWd), 1, p(dw_rows), B, ho, wo, cin, 1, bf)
+                   p(part), p(dWd), 1, p(wg_scratch), B, ho, wo, cin, 1, bf)  # (float atomics unless deterministic: rows + an own fold launch measured slower)
             L.call("ttk_bn_bwd_frozen", p(st_t.bn), cin)
             L.call("ttk_dwconv3x3_bwd_data", p(g_t), p(st_t.y), p(st_t.bn), p(w_blur), None, p(st_prev.y), p(st_prev.bn), p(st_prev.skip),
                    None, p(g_prev), p(part), None, 0, None, B, h, w_, cin, stride, bf)
@@ -429,7 +436,8 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
                    p(dw_rows), rows, 9 * cin, p(dWd), 1)
         else:
             L.call("ttk_dwconv3x3_bwd_data", p(g_dw), p(st_dw.y), p(st_dw.bn), p(w_dw), p(g) if has_skip else None, p(st_prev.y),
-                   p(st_prev.bn), p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 1, p(dw_rows), B, h, w_, cin, stride, bf)
+                   p(st_prev.bn), p(st_prev.skip), p(a_in), p(g_prev), p(part), p(dWd), 1,
+                   p(dw_rows if (_DW_WGRAD_ROWS == 1 and not ctx.frozen) else wg_scratch), B, h, w_, cin, stride, bf)  # (_DW_WGRAD_ROWS = 1: the A/B form, rows + own fold)
             bwd_finalize(st_prev, L.partial_rows_dwconv(B, h, w_, cin, stride, True), B * h * w_, pi - 2 if k > 0 else 1)
         g = g_prev
         if grad_ready_hook is not None:  # this block's conv + bn_dw gradients and its own bn_sep gradients are final
@@ -451,12 +459,11 @@ class _MobileNetFn(torch.autograd.Function):
     """One autograd node for the whole backbone: saves raw conv outputs + BN constants."""
 
     @staticmethod
-    def forward(ctx, x, momentum, eps, buffers, frozen, blur, *params):
-        if _BF16_COMPUTE:
+    def forward(ctx, x, momentum, eps, buffers, frozen, blur, precision, *params):
+        if precision == "bf16-compute":
             feat, c = _mobilenet_bc.forward_impl(_THIS, x, params, buffers, momentum, eps, training=not frozen, frozen=frozen, blur=blur)
         else:
-            feat, c = _forward_impl(x, params, buffers, momentum, eps, training=not frozen, act_dtype=_ACT_DTYPE, grad_dtype=_GRAD_DTYPE, frozen=frozen,
-                                    blur=blur)
+            feat, c = _forward_impl(x, params, buffers, momentum, eps, training=not frozen, frozen=frozen, blur=blur)
         ctx.c = c
         ctx.nparams = len(params)
         ctx.save_for_backward(*params)
@@ -470,7 +477,7 @@ class _MobileNetFn(torch.autograd.Function):
         else:
             grads = _backward_impl(ctx.c, gfeat.contiguous(), params)
         ctx.c = None
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
 class MobileNet(nn.Module):
@@ -488,6 +495,7 @@ class MobileNet(nn.Module):
             return DepthWiseBlock(inplanes, planes, stride=stride, momentum=momentum, use_blurpool=use_blurpool)
 
         self.use_blurpool = bool(use_blurpool)
+        self.precision = None  # None = the module-wide default (set_activation_dtype); "fp32" | "bf16-compute" through set_precision
         self.conv1 = nn.Conv2d(input_channel, 32, kernel_size=5, stride=2, padding=2, bias=False)
         self.bn1 = NormalizationLayer(32, momentum=momentum)
         self.relu = ActivationFunc(inplace=True)
@@ -504,6 +512,15 @@ class MobileNet(nn.Module):
             if isinstance(m, nn.Conv2d):
                 n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
                 m.weight.data.normal_(0, math.sqrt(2.0 / n))
+
+    # ---- precision of the training kernels (an attribute of the instance; not in the checkpoint) ------------------
+    def set_precision(self, mode):
+        """"fp32" | "bf16-compute" for THIS backbone (None: follow the module-wide default again).  Returns self."""
+        self.precision = None if mode is None else _check_precision(mode)
+        return self
+
+    def effective_precision(self) -> str:
+        return self.precision if getattr(self, "precision", None) is not None else _DEFAULT_PRECISION
 
     # ---- parameter plumbing -----------------------------------------------------------------
     def _bns(self):
@@ -549,7 +566,7 @@ class MobileNet(nn.Module):
         x = x.contiguous()
         bn_training = [bn.training for bn in self._bns()]
         if self.training and all(bn_training):
-            return _MobileNetFn.apply(x, momentum, eps, self._flat_buffers(), False, self._blur_weights(), *self._flat_params())
+            return _MobileNetFn.apply(x, momentum, eps, self._flat_buffers(), False, self._blur_weights(), self.effective_precision(), *self._flat_params())
         if any(bn_training):
             raise NotImplementedError("mixed train/eval BatchNorm layers are not supported by the fused backbone")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._flat_params()):
@@ -558,8 +575,8 @@ class MobileNet(nn.Module):
             if any(p.requires_grad for bn in self._bns() for p in bn.parameters()):
                 raise NotImplementedError("eval-mode BatchNorm layers with trainable weight / bias are not built: freeze them "
                                           "(modelcomponents.freeze_norm_stats) or put the layers in training mode")
-            return _MobileNetFn.apply(x, momentum, eps, self._flat_buffers(), True, self._blur_weights(), *self._flat_params())
-        if _BF16_COMPUTE:
+            return _MobileNetFn.apply(x, momentum, eps, self._flat_buffers(), True, self._blur_weights(), self.effective_precision(), *self._flat_params())
+        if self.effective_precision() == "bf16-compute":
             feat, _ = _mobilenet_bc.forward_impl(_THIS, x, [q.detach() for q in self._flat_params()], self._flat_buffers(), momentum, eps, False,
                                                  blur=self._blur_weights())
         else:

@@ -23,6 +23,8 @@ from __future__ import annotations
 
 from typing import Iterable, Sequence
 
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -41,6 +43,7 @@ class GradAllReduce:
         self._finish_log: list = []
         self.last_bucket_bytes: list = []             # sizes of the collectives of the last finished step (bench.py --comm-only)
         self._bucket_bytes_now: list = []
+        self._timing_mark = 0  # len(_timing) at the end of the last completed step
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self._always = always_reduce
         self.bucket_bytes = bucket_bytes
@@ -88,8 +91,7 @@ class GradAllReduce:
                 self._stream = torch.cuda.Stream(device=flat.device)
             self._stream.wait_stream(torch.cuda.current_stream(flat.device))  # the producing kernels of this range are enqueued
             with torch.cuda.stream(self._stream):
-                if self.measure:
-                    import time
+                if self.measure:  # (diagnostic pass only: the host-side wait below serialises backward under gloo - bench.py's `comm.note` says so)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     t0 = time.perf_counter()
@@ -160,6 +162,7 @@ class GradAllReduce:
         self._done.clear()
         self._entries.clear()
         self.last_bucket_bytes, self._bucket_bytes_now = self._bucket_bytes_now, []
+        self._timing_mark = len(self._timing)  # timing records up to here belong to completed steps (abort() drops the rest)
 
     def begin_step(self):
         self.collectives = 0
@@ -180,6 +183,7 @@ class GradAllReduce:
         out["steps"] = len(self._finish_log)
         self._timing.clear()
         self._finish_log = []
+        self._timing_mark = 0
         return out
 
     def abort(self):
@@ -194,6 +198,13 @@ class GradAllReduce:
         self._done.clear()
         self._entries.clear()
         self._open = None
+        # the diagnostics of the aborted step too: a later finish() must not publish its buckets as `last_bucket_bytes`, and collect_timing()
+        # must not count collectives whose step never finished (events recorded for them are dropped with the lists)
+        if self._bucket_bytes_now:
+            self._bucket_bytes_now = []
+        # keep the records of COMPLETED steps (collect_timing() divides by len(_finish_log)); the aborted step's buckets were appended after the
+        # last completed step's finish(), i.e. beyond _timing_mark
+        del self._timing[self._timing_mark:]
 
 
 def install(reducer: GradAllReduce | None):

@@ -6,7 +6,7 @@ sets no precision), so parity is stated against the fp32 oracle / the fp32 HIP s
   * first-step `loss_sum` within 1e-3 of the fp32 CPU oracle (north_star's per-step loss tolerance);
   * AFLW2k-mini rotation MAE within 0.05 degrees of the fp32 path on identical weights and crops;
   * the whole step against the fp32 HIP step: pooled features, running statistics, gradient norm, per-block gradient cosines - reported
-    and bounded (single-step backbone gradients are cancellation-dominated sums: tests/test_bf16_gpu.py explains the yardstick).
+    and bounded (single-step backbone gradients are cancellation-dominated sums: fp32 vs fp64 already moves the worst tensor by 7e-3).
 The kernels themselves are held to float64 references in tests/test_bc_kernels_gpu.py."""
 import numpy as np
 import pytest
@@ -159,3 +159,42 @@ def test_a_few_optimiser_steps_and_blurpool_run():
         assert abs(out["loss"].item() - ref["loss"].item()) < 5e-3 * max(1.0, abs(ref["loss"].item()))
     finally:
         _mode("fp32")
+
+
+def test_two_networks_of_different_precision_in_one_process():
+    """Precision is an attribute of the backbone INSTANCE (`MobileNet.set_precision`), not a module global: an fp32 and a bf16-compute network
+    alive side by side each run their own kernels, step after step, whatever the other did last; neither changes the module-wide default."""
+    import trackertraincode.backbones.mobilenet_v1 as MB
+    import trackertraincode.train as train
+
+    S = train_script()
+    _, meta = load_golden("model_default.npz")
+    meta = dict(meta, B=64, split=40)
+    assert MB._DEFAULT_PRECISION == "fp32"
+    nets = {m: build_net(meta, DEV).train() for m in ("fp32", "bf16-compute")}
+    for m, net in nets.items():
+        net.convnet.set_precision(m)
+        assert "precision" not in net.get_config() and not any("precision" in k for k in net.state_dict())
+    crit, _ = S.setup_losses(script_args(meta["flags"]), nets["fp32"])
+    batches = make_batches(meta, DEV)
+    lib = __import__("trackertraincode._hip", fromlist=["lib"]).lib()
+    seen, orig = [], lib.call
+    lib.call = lambda name, *a: (seen.append(name), orig(name, *a))[1]
+    try:
+        losses = {}
+        for m in ("fp32", "bf16-compute", "fp32", "bf16-compute"):  # interleaved
+            seen.clear()
+            out = train.training_step(nets[m], batches, 150, crit)
+            out["loss"].backward()
+            torch.cuda.synchronize()
+            used_bc = any(n.startswith("ttk_bc_pw") for n in seen)
+            assert used_bc == (m == "bf16-compute"), (m, sorted(set(seen))[:8])
+            losses.setdefault(m, []).append(out["loss"].item())
+            for p in nets[m].parameters():
+                p.grad = None
+    finally:
+        lib.call = orig
+    # no optimiser step in between: fp32 repeats its loss exactly up to the running statistics' effect on nothing (training-mode BatchNorm uses batch statistics)
+    assert abs(losses["fp32"][0] - losses["fp32"][1]) < 1e-6 and abs(losses["bf16-compute"][0] - losses["bf16-compute"][1]) < 1e-6
+    assert abs(losses["fp32"][0] - losses["bf16-compute"][0]) < 1e-2 * abs(losses["fp32"][0])
+    assert MB._DEFAULT_PRECISION == "fp32"

@@ -37,8 +37,8 @@ CASES = {
     "resnet18_posonly": (["--ds", "synthetic", "--batchsize", "16", "--epochs", "1", "--backbone", "resnet18", "--no-pointhead", "--no-imgaug"],
                          "NetworkWithPointHead_resnet18"),
     "resnet18_blurpool": (["--ds", "synthetic", "--batchsize", "16", "--epochs", "1", "--backbone", "resnet18", "--blurpool"], "NetworkWithPointHead_resnet18"),
-    "blurpool_graph_bf16": (["--ds", "synthetic", "--batchsize", "32", "--epochs", "2", "--blurpool", "--graph-steps", "--precision", "bf16"],
-                            "NetworkWithPointHead_mobilenetv1"),
+    "blurpool_graph": (["--ds", "synthetic", "--batchsize", "32", "--epochs", "2", "--blurpool", "--graph-steps"],
+                       "NetworkWithPointHead_mobilenetv1"),
     "graph_nll_bf16_compute": (["--ds", "synthetic", "--batchsize", "32", "--epochs", "2", "--graph-steps", "--with-nll-loss", "--rampup-nll-losses", "--precision", "bf16-compute"],
                                "NetworkWithPointHead_mobilenetv1"),
     "shards_landmark_roi": (["--ds", "aflw2k:500", "--batchsize", "8", "--epochs", "2", "--roi-override", "landmarks", "--ds-weighting", "--raug", "20"],

@@ -18,7 +18,7 @@ ap.add_argument("--backbone", default="mobilenetv1")
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--steps", type=int, default=600)
 ap.add_argument("--blurpool", action="store_true")
-ap.add_argument("--precision", default="fp32", help="fp32 | bf16 | bf16-all | bf16-compute (mobilenetv1)")
+ap.add_argument("--precision", default="fp32", help="fp32 | bf16-compute (mobilenetv1)")
 a = ap.parse_args()
 sys.argv = ["bench.py", "--backbone", a.backbone, "--batch", str(a.batch), "--precision", a.precision] + (["--blurpool"] if a.blurpool else [])
 args = bench.parse()
