@@ -68,6 +68,20 @@ size_t conv_wgrad16_partial_bytes(int64_t M, int Cout, int ncols, int taps);
 __host__ __device__ inline int64_t r_plane_index(int row, int k, int rows) {
   return ((int64_t)(k >> 4) * rows + row) * 16 + ((((k >> 3) & 1) ^ ((row >> 3) & 1)) << 3) + (k & 7);
 }
+// element (row n, k) of a [rows][K] weight operand inside the fragment-ordered image of ttk_pwconv_prepare_weights (split code 3):
+// [k32 step][16-row block][plane][lane = 16 (k chunk) + row][8 k] fp16 - a wave's fragment of one block and plane is 1 KB, lane-linear
+__host__ __device__ inline int64_t x_plane_index(int row, int k, int rows, int plane) {
+  const int ks = k >> 5, q = (k >> 3) & 3, cb = row >> 4, r = row & 15;
+  return (((int64_t)ks * (rows >> 4) + cb) * 2 + plane) * 512 + (q * 16 + r) * 8 + (k & 7);
+}
+
+// Full-width GEMMs (pwconv_x.hip, round 6): they take the wide shapes in the product; the row-block kernels stay for experiment builds (TTK_GEMM_X=0)
+bool f16x_gemm_shape(int K, int Nout, int dgrad);
+int f16x_partial_rows(int64_t M, int K, int Nout, int dgrad);
+int f16x_tile_rows(int64_t M, int K, int Nout, int dgrad);
+template <int MODE>
+bool launch_f16x_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0, const float* bnE, float* part, int64_t M,
+                      int K, int Nout, void* planes, float* wmax, hipStream_t st);
 bool f16r_gemm_shape(int K, int Nout, int dgrad);
 int f16r_partial_rows(int64_t M, int K, int Nout, int dgrad);
 int f16r_tile_rows(int64_t M, int K, int Nout, int dgrad);

@@ -16,6 +16,7 @@
 // one 32x32x2 MFMA - the sum over k is order-free, so no shuffling is needed.
 #include "ttk_common.h"
 #include "conv_geom.h"
+#include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 
@@ -407,6 +408,9 @@ template <int MODE, typename T, typename TO>
 static bool launch_gemm(const TO* A0, const T* A1, const float* bnA, const float* Bm, TO* out, const T* E0,
                         const float* bnE, float* part, int64_t M, int K, int Nout, void* region, float* hdr, hipStream_t st) {
   const int mode = gemm_mode();
+  if constexpr (std::is_same<T, float>::value && std::is_same<TO, float>::value) {
+    if (mode == GEMM_F16X2 && launch_f16x_gemm<MODE == MODE_FWD ? 0 : 1>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, region, hdr, st)) return true;
+  }
   if (mode == GEMM_F16X2 && launch_f16r_gemm<MODE, T, TO>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, region, hdr, st)) return true;
   if (mode == GEMM_F16X2 && launch_f16_gemm<MODE, T, TO>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, region, hdr, st)) return true;
   if constexpr (!Act<T>::kBf16 && !Act<TO>::kBf16) {
@@ -449,6 +453,14 @@ __device__ __forceinline__ void prep_store(unsigned char* region, int split, int
     return;
   }
   uint16_t* q = reinterpret_cast<uint16_t*>(region);
+  if (split == 3) {  // fragment-ordered image, the two planes of a block side by side
+    const float xs = x * s;
+    const _Float16 hh = (_Float16)xs;
+    const _Float16 ll = (_Float16)(xs - (float)hh);
+    q[x_plane_index(row, k, rows, 0)] = __builtin_bit_cast(uint16_t, hh);
+    q[x_plane_index(row, k, rows, 1)] = __builtin_bit_cast(uint16_t, ll);
+    return;
+  }
   const int64_t idx = split == 2 ? r_plane_index(row, k, rows) : ((int64_t)(k >> 5) * rows + row) * 32 + (k & 31);
   if (mode == GEMM_BF16X3) {
     const float r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
@@ -531,10 +543,15 @@ using namespace ttk;
 extern "C" {
 
 int ttk_partial_rows_pwconv(int64_t M, int K, int Nout, int dgrad) {
+  const int x = f16x_partial_rows(M, K, Nout, dgrad);
+  if (x) return x;
   const int r = f16r_partial_rows(M, K, Nout, dgrad);
   return r ? r : (int)ceil_div(M, BM);
 }
-int ttk_pwconv_tile_rows(int64_t M, int K, int Nout, int dgrad) { return f16r_tile_rows(M, K, Nout, dgrad); }
+int ttk_pwconv_tile_rows(int64_t M, int K, int Nout, int dgrad) {
+  const int x = f16x_tile_rows(M, K, Nout, dgrad);
+  return x ? x : f16r_tile_rows(M, K, Nout, dgrad);
+}
 
 int ttk_pwconv1x1_fwd(const void* ydw, const float* bn_dw, const float* w, void* y, float* part, const float* pivot, int64_t M, int Cin,
                       int Cout, void* wsplit, int act_bf16, ttk_stream_t stream) {
@@ -669,9 +686,10 @@ int ttk_pwconv_prepare_weights(int n, const float* const* w, const int* cin, con
     a.cout[i] = cout[i];
     a.first_tile[i] = tiles;
     tiles += (cin[i] / 32) * (cout[i] / 32);
-    // 0: fp32 rows; 1: piece planes [K/32][rows][32]; 2: the row-block kernels' planes [K/16][rows][16] (pwconv_r.hip)
-    a.split_fwd[i] = a.mode == GEMM_F16X2 ? (f16r_gemm_shape(cin[i], cout[i], 0) ? 2 : f16_gemm_shape(cin[i], cout[i])) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cin[i], cout[i]));
-    a.split_bwd[i] = a.mode == GEMM_F16X2 ? (f16r_gemm_shape(cout[i], cin[i], 1) ? 2 : f16_gemm_shape(cout[i], cin[i])) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cout[i], cin[i]));
+    // 0: fp32 rows; 1: piece planes [K/32][rows][32]; 2: the row-block kernels' planes [K/16][rows][16] (pwconv_r.hip); 3: the full-width kernels'
+    // fragment-ordered image (pwconv_x.hip)
+    a.split_fwd[i] = a.mode == GEMM_F16X2 ? (f16x_gemm_shape(cin[i], cout[i], 0) ? 3 : f16r_gemm_shape(cin[i], cout[i], 0) ? 2 : f16_gemm_shape(cin[i], cout[i])) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cin[i], cout[i]));
+    a.split_bwd[i] = a.mode == GEMM_F16X2 ? (f16x_gemm_shape(cout[i], cin[i], 1) ? 3 : f16r_gemm_shape(cout[i], cin[i], 1) ? 2 : f16_gemm_shape(cout[i], cin[i])) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cout[i], cin[i]));
   }
   a.first_tile[n] = tiles;
   hipStream_t st = (hipStream_t)stream;

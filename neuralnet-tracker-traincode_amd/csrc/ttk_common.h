@@ -212,8 +212,8 @@ template <> struct Act<bf16_t> {
 #define TTK_ACT_DISPATCH_STEM(flag, ...)                                                                                                        \
   do {                                                                                                                                          \
     TTK_REQUIRE(((flag) & 3) == 0 || ((flag) & 3) == 3, "the stem takes fp32 tensors or activations AND gradients bfloat16 (bf16-compute path)"); \
-    if (((flag) & 3) == 3) { using ActT = ::ttk::bf16_t; using GradT = ::ttk::bf16_t; __VA_ARGS__; }                                            \
-    else { using ActT = float; using GradT = float; __VA_ARGS__; }                                                                              \
+    if (((flag) & 3) == 3) { using ActT [[maybe_unused]] = ::ttk::bf16_t; using GradT [[maybe_unused]] = ::ttk::bf16_t; __VA_ARGS__; }              \
+    else { using ActT [[maybe_unused]] = float; using GradT [[maybe_unused]] = float; __VA_ARGS__; }                                                \
   } while (0)
 
 // The "apply on load" forms of BatchNorm (see ttk.h).  Every layer owns one block

@@ -194,7 +194,9 @@ def test_two_networks_of_different_precision_in_one_process():
                 p.grad = None
     finally:
         lib.call = orig
-    # no optimiser step in between: fp32 repeats its loss exactly up to the running statistics' effect on nothing (training-mode BatchNorm uses batch statistics)
-    assert abs(losses["fp32"][0] - losses["fp32"][1]) < 1e-6 and abs(losses["bf16-compute"][0] - losses["bf16-compute"][1]) < 1e-6
+    # no optimiser step in between: the fp32 net repeats its loss (training-mode BatchNorm normalises with batch statistics); the bf16-compute net
+    # repeats it to bf16 rounding only - the running means it uses as statistics pivots moved with the first pass, so the stored bf16 values
+    # round differently (measured 1.7e-3 of 3.15)
+    assert abs(losses["fp32"][0] - losses["fp32"][1]) < 1e-6 and abs(losses["bf16-compute"][0] - losses["bf16-compute"][1]) < 1e-2 * abs(losses["fp32"][0])
     assert abs(losses["fp32"][0] - losses["bf16-compute"][0]) < 1e-2 * abs(losses["fp32"][0])
     assert MB._DEFAULT_PRECISION == "fp32"

@@ -16,6 +16,8 @@ BF = int(os.environ.get("BF16", "0"))  # BF16=1: bf16 activation storage
 ADT = torch.bfloat16 if BF else torch.float32
 shapes = [("dw2_1", 65, 32, 64, 1), ("dw2_2", 33, 64, 128, 1), ("dw3_1", 33, 128, 128, 1), ("dw3_2", 17, 128, 256, 1), ("dw4_1", 17, 256, 256, 1),
           ("dw4_2", 9, 256, 512, 1), ("dw5_x", 9, 512, 512, 5), ("dw5_6", 5, 512, 1024, 1), ("dw6", 5, 1024, 1024, 1)]
+if os.environ.get("LAYERS"):  # LAYERS=dw5_x,dw6: only these
+    shapes = [s for s in shapes if s[0] in os.environ["LAYERS"].split(",")]
 tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
 dev = "cuda"
 for name, hw, ci, co, mult in shapes:
@@ -41,6 +43,8 @@ for name, hw, ci, co, mult in shapes:
         fpart = torch.empty(L.cdll.ttk_pwconv1x1_bwd_fused_rows(M, ci, co) * 2 * ci, device=dev)
         calls["fused"] = lambda: L.call("ttk_pwconv1x1_bwd_fused", p(g), p(y), p(bn_pw), p(w), p(prep), p(ydw), p(bn_dw), p(gdw), p(dW), None, p(fpart), M, ci, co)
     line = f"{name:6s} M={M:8d} K={ci:4d} N={co:4d} "
+    if os.environ.get("KINDS"):  # KINDS=fwd,dgrad
+        calls = {k: v for k, v in calls.items() if k in os.environ["KINDS"].split(",")}
     for k, fn in calls.items():
         for _ in range(3):
             fn()
