@@ -51,10 +51,13 @@ struct DwTiling {
   int NI;                             // images per tile (> 1 only when one band covers the image: the 9x9 and 5x5 layers)
   int stage_rows;                     // LDS rows of one image's stage
   int NCT, TW;                        // column tiles per band and their width (stride 1, wide images); else 1, full width
-  int carry;                          // forward only: a workgroup walks CONSECUTIVE bands of an image and keeps their shared rows in LDS
+  int carry;                          // a workgroup walks CONSECUTIVE bands of an image and hands their shared staged rows from band to band
 };
 #ifndef TTK_DW_CARRY
 #define TTK_DW_CARRY 1
+#endif
+#ifndef TTK_DW_CARRY_BWD
+#define TTK_DW_CARRY_BWD 1
 #endif
 constexpr int kCarryRegs = 5;  // float4 registers per thread that hand the shared rows from one band to the next
 
@@ -83,7 +86,14 @@ inline DwTiling dw_tiling_sl(int B, int H, int W, int C, int stride, bool backwa
   // ONCE - a workgroup takes a contiguous run of bands and carries those rows over in LDS - so the tensor is read exactly once
   // (column tiles of 17 x 17 results staged 19 x 19 = 1.25 x; full-width bands without the carry 5 rows for 3 = 1.67 x; PMC of
   // round 3: 480 MB for 404 on the stride-1 kernel, 833 for 696 on the stride-2 65 x 65 x 64 layer).
-  t.carry = TTK_DW_CARRY && !backward && (3 - stride) * (W + 2) * (SL / 4) <= kCarryRegs * kBlock;
+  // Backward (round 6): the same for the staged dy rows - neighbouring bands of input rows share 2 (stride 1) or 1 (stride 2) rows of dy - with
+  // full-width bands instead of the 19 x 19 column tiles of the 65-pixel layers (halo 1.25 x on g and y) and the 10-for-8-row bands of the
+  // 33-pixel ones.
+  static const int carry_bwd = [] { const char* e = exp_env("TTK_DW_CARRY_BWD"); return e ? atoi(e) : TTK_DW_CARRY_BWD; }();  // (experiments)
+  // (stride 2, where the bands share ONE dy row of a tensor a quarter of the input's size, measured slower with the ring: 65 x 65 x 64 259 -> 268 us;
+  // stride 1: 33 x 33 x 128 319 -> 284 us, 65 x 65 x 32 217 -> 190 us, profiles/r06_depthwise_backward_carry.txt)
+  t.carry = backward ? (carry_bwd && stride == 1 && (Wo + 2) <= 80)
+                     : (TTK_DW_CARRY && (3 - stride) * (W + 2) * (SL / 4) <= kCarryRegs * kBlock);
   if (!t.carry && stride == 1 && W >= kColTileMinW && col_tile < W) {
     t.NCT = (W + col_tile - 1) / col_tile;
     t.TW = (W + t.NCT - 1) / t.NCT;
@@ -355,7 +365,7 @@ dw_fwd_tiled_k(const T* __restrict__ yprev, const float* __restrict__ bn_prev,
 #ifndef TTK_DW_BWD_LEAN_PIX2
 #define TTK_DW_BWD_LEAN_PIX2 4  // stride 2 (6 measured slower: 276 vs 263 us on the 65 x 65 x 64 layer)
 #endif
-template <int S, typename T, typename TG, int SL, bool LEAN>
+template <int S, typename T, typename TG, int SL, bool LEAN, bool CARRY>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TTK_DW_WGS_PER_CU, TTK_DW_WGS_PER_CU)))  // <= 168 VGPRs: 3 workgroups per CU, as the LDS tile allows
 dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
                                                           const float* __restrict__ bn_dw, const float* __restrict__ w,
@@ -364,8 +374,9 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
                                                           const T* __restrict__ skip_prev, const T* __restrict__ a_in,
                                                           TG* __restrict__ g_prev, float* __restrict__ part,
                                                           float* __restrict__ dwgrad, float* __restrict__ dw_partial, int B, int H, int W, int C, int Ho, int Wo,
-                                                          int R, int nbands, int nslabs, int stage_floats, int NI, int NCT, int TW) {
+                                                          int R, int nbands, int nslabs, int stage_floats, int NI_, int NCT_, int TW, int ring) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // dy[NI][stage_rows][Wo+2][SL] + reduction scratch
+  const int NI = CARRY ? 1 : NI_, NCT = CARRY ? 1 : NCT_;  // (carry mode: one image per tile, full-width bands)
   constexpr int kSlab = SL, kSlabQuads = SL / 4, kPixSlots = kBlock / kSlabQuads, kQs = ilog2(kSlabQuads), kPs = ilog2(SL);
   const int tid = threadIdx.x, q = tid & (kSlabQuads - 1), slot = tid >> kQs;
   const int slab = blockIdx.x % nslabs, c0 = slab * kSlab + 4 * q;
@@ -387,7 +398,13 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
 #pragma unroll
   for (int t = 0; t < 9; ++t) wacc[t] = f4(0.f);
   const unsigned tiles = (unsigned)((B + NI - 1) / NI) * nbands * NCT;  // (< 2^31: checked by the host)
-  for (unsigned t = blockIdx.x / nslabs; t < tiles; t += gridDim.x / nslabs) {
+  // Tile order as in the forward kernel: round-robin, or - carry mode - a CONTIGUOUS run of tiles per workgroup (consecutive bands of an image), the
+  // dy rows two neighbouring bands share going from one band's stage to the next through registers instead of being read (g AND y) and formed again.
+  const unsigned wgs = gridDim.x / nslabs, wg = blockIdx.x / nslabs;
+  const unsigned t_begin = CARRY ? (unsigned)((uint64_t)tiles * wg / wgs) : wg, t_end = CARRY ? (unsigned)((uint64_t)tiles * (wg + 1) / wgs) : tiles;
+  const unsigned t_step = CARRY ? 1u : wgs;
+  int prev_img = -1, prev_band = -2, prev_hi = -1;
+  for (unsigned t = t_begin; t < t_end; t += t_step) {
     const unsigned tb = t / (unsigned)NCT, ti = tb / (unsigned)nbands;
     const int ct = (int)(t - tb * NCT), band = (int)(tb - ti * nbands), n0 = (int)ti * NI;  // NI > 1 implies one tile per image
     const int nimg = min(NI, B - n0);
@@ -410,21 +427,37 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
     const T* sktile = skip_prev ? skip_prev + tin : nullptr;
     const TG* sgtile = skip_grad ? skip_grad + tin : nullptr;
     TG* gptile = g_prev + tin;
-    __syncthreads();
-    // ---- stage dy rows ho_lo..ho_hi, columns -1..Wo (zeros outside) of nimg images; two elements per thread and
-    // iteration (four loads in flight)
-    const int nstage = nimg * (int)PI * kSlabQuads;
+    // carry mode: dy rows ho_lo .. ho_lo + ov - 1 of this band are the last ov staged rows of the previous one.  They STAY where they are: the
+    // stage is a ring of `ring` rows (dy row ho of an image lives in ring row ho mod ring), a band stages only its new rows behind them.  (The
+    // forward kernel hands its shared rows over through five float4 registers; here that broke the 168-register cap of three workgroups per
+    // CU - 40 spilled registers - so the ring addressing pays three compare-and-subtracts per pixel instead.)
+    const int ov = (CARRY && (int)ti == prev_img && band == prev_band + 1 && prev_hi >= ho_lo) ? prev_hi - ho_lo + 1 : 0;
+    const int rbase = CARRY ? ho_lo % ring : 0;  // ring row of dy row ho_lo
+    prev_img = (int)ti; prev_band = band; prev_hi = ho_hi;
+    __syncthreads();  // the previous tile's readers are done
+    // ---- stage dy rows ho_lo + ov..ho_hi, columns -1..Wo (zeros outside) of nimg images; kBwdU elements per thread and
+    // iteration (2 kBwdU loads in flight)
+    const unsigned ovpix = (unsigned)(ov * Wp);
+    const int nstage = nimg * ((int)PI - (int)ovpix) * kSlabQuads;
     constexpr int kBwdU = TTK_DW_BWD_U;  // staged elements per thread and iteration: 2 * kBwdU loads in flight
     for (int e = tid; e < nstage; e += kBwdU * kBlock) {
       float4 gv[kBwdU], yv[kBwdU];
       bool in[kBwdU];
+      unsigned pxs[kBwdU];
 #pragma unroll
       for (int u = 0; u < kBwdU; ++u) {
         const int ee = e + u * kBlock;
-        const unsigned pxa = (unsigned)ee >> kQs;
+        const unsigned pxa = ((unsigned)ee >> kQs) + ovpix;
         const unsigned img = NI > 1 ? dPI.div(pxa) : 0u, px = NI > 1 ? pxa - __umul24(img, PI) : pxa;
         const unsigned prow = dWp.div(px);
         const int col = (int)(px - __umul24(prow, (unsigned)Wp)) - 1 + cx0, row = ho_lo + (int)prow;
+        if constexpr (CARRY) {
+          unsigned rr = (unsigned)rbase + prow;
+          rr -= rr >= (unsigned)ring ? (unsigned)ring : 0u;
+          pxs[u] = __umul24(rr, (unsigned)Wp) + (px - __umul24(prow, (unsigned)Wp));
+        } else {
+          pxs[u] = pxa;
+        }
         in[u] = ee < nstage && col >= 0 && col < Wo;
         const unsigned off = in[u] ? ((__umul24(__umul24(img, (unsigned)Ho) + (unsigned)row, (unsigned)Wo) + (unsigned)col) << cshift) + 4 * q : 0u;  // qq == q (see forward)
         gv[u] = in[u] ? Act<TG>::ldnt(gtile + off) : f4(0.f);
@@ -434,7 +467,7 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
       for (int u = 0; u < kBwdU; ++u) {
         const int ee = e + u * kBlock;
         if (ee >= nstage) break;
-        st4(lds + (size_t)(ee >> kQs) * kSlab + 4 * q, in[u] ? bg.dy(gv[u], yv[u]) : f4(0.f));
+        st4(lds + (size_t)pxs[u] * kSlab + 4 * q, in[u] ? bg.dy(gv[u], yv[u]) : f4(0.f));
       }
     }
     __syncthreads();
@@ -493,7 +526,9 @@ dw_bwd_tiled_k(const TG* __restrict__ g_dw, const T* __restrict__ y_dw,
             const int tw = wi + 1 - kw;  // -1 .. W
             if (S == 2 && (tw & 1)) continue;
             const int wo = (S == 1) ? tw : (tw >> 1);  // -1 or Wo hit the zero padding columns (S=1); always inside for S=2
-            const float4 dy = ld4(dyimg + ((__mul24(ho - ho_lo, Wp) + wo - cx0 + 1) << kPs) + 4 * q);
+            int lr = ho - ho_lo;  // staged row of this tap (carry mode: through the ring)
+            if constexpr (CARRY) { lr += rbase; lr -= lr >= ring ? ring : 0; }
+            const float4 dy = ld4(dyimg + ((__mul24(lr, Wp) + wo - cx0 + 1) << kPs) + 4 * q);
             G = fma4(dy, ld4(wt + (kh * 3 + kw) * kSlab + 4 * q), G);
             wacc[kh * 3 + kw] = fma4(dy, a, wacc[kh * 3 + kw]);
           }
@@ -593,14 +628,16 @@ int ttk_dwconv3x3_bwd_data(const void* g_dw, const void* y_dw, const float* bn_d
   if (dw && !dw_accumulate && !dw_partial) hipLaunchKernelGGL(zero_fill_k, dim3((9 * C + 255) / 256), dim3(256), 0, st, dw, (int64_t)9 * C);
 #define TTK_DW_BWD(S_) TTK_DW_BWD_SL(S_, kCB)
 #define TTK_DW_BWD_SL(S_, SL_) \
-  TTK_DW_BWD_L(S_, SL_, true); else TTK_DW_BWD_L(S_, SL_, false)
-#define TTK_DW_BWD_L(S_, SL_, LEAN_)                                                                                                      \
-  hipLaunchKernelGGL((dw_bwd_tiled_k<S_, ActT, GradT, SL_, LEAN_>), dim3(t.grid), dim3(kBlock), sm, st, (const GradT*)g_dw, (const ActT*)y_dw, bn_dw, w, \
+  TTK_DW_BWD_C(S_, SL_, true); else TTK_DW_BWD_C(S_, SL_, false)
+#define TTK_DW_BWD_C(S_, SL_, LEAN_) do { if (t.carry) TTK_DW_BWD_L(S_, SL_, LEAN_, true); else TTK_DW_BWD_L(S_, SL_, LEAN_, false); } while (0)
+#define TTK_DW_BWD_L(S_, SL_, LEAN_, CY_)                                                                                                 \
+  hipLaunchKernelGGL((dw_bwd_tiled_k<S_, ActT, GradT, SL_, LEAN_, CY_>), dim3(t.grid), dim3(kBlock), sm, st, (const GradT*)g_dw, (const ActT*)y_dw, bn_dw, w, \
                      (const GradT*)skip_grad, (const ActT*)yprev, bn_prev, (const ActT*)skip_prev, (const ActT*)a_in, (GradT*)g_prev, part,  \
-                     dw, dw_partial, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage, t.NI, t.NCT, t.TW)
+                     dw, dw_partial, B, H, W, C, Ho, Wo, t.R, t.nbands, t.nslabs, (int)stage, t.NI, t.NCT, t.TW, t.stage_rows)
   const bool lean = !a_in && !skip_prev && !skip_grad;
   TTK_ACT_DISPATCH(act_bf16, if (stride == 1) { if (lean) TTK_DW_BWD(1); } else { if (lean) TTK_DW_BWD(2); });
 #undef TTK_DW_BWD_L
+#undef TTK_DW_BWD_C
 #undef TTK_DW_BWD
 #undef TTK_DW_BWD_SL
   // dw_accumulate == 2: the rows stay unfolded - the caller folds them beside the BatchNorm-backward finalisation (ttk_bc_bn_bwd_finalize_fold)
