@@ -82,6 +82,12 @@ int f16x_tile_rows(int64_t M, int K, int Nout, int dgrad);
 template <int MODE>
 bool launch_f16x_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0, const float* bnE, float* part, int64_t M,
                       int K, int Nout, void* planes, float* wmax, hipStream_t st);
+// Streaming GEMMs of the narrow HBM-bound layers (pwconv_y.hip, round 6)
+bool f16y_gemm_shape(int K, int Nout, int dgrad);
+int f16y_partial_rows(int64_t M, int K, int Nout, int dgrad);
+template <int MODE>
+bool launch_f16y_gemm(const float* A0, const float* A1, const float* bnA, const float* Bm, float* out, const float* E0, const float* bnE, float* part, int64_t M,
+                      int K, int Nout, void* planes, float* wmax, hipStream_t st);
 bool f16r_gemm_shape(int K, int Nout, int dgrad);
 int f16r_partial_rows(int64_t M, int K, int Nout, int dgrad);
 int f16r_tile_rows(int64_t M, int K, int Nout, int dgrad);

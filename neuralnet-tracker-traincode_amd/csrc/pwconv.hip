@@ -409,6 +409,7 @@ static bool launch_gemm(const TO* A0, const T* A1, const float* bnA, const float
                         const float* bnE, float* part, int64_t M, int K, int Nout, void* region, float* hdr, hipStream_t st) {
   const int mode = gemm_mode();
   if constexpr (std::is_same<T, float>::value && std::is_same<TO, float>::value) {
+    if (mode == GEMM_F16X2 && launch_f16y_gemm<MODE == MODE_FWD ? 0 : 1>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, region, hdr, st)) return true;
     if (mode == GEMM_F16X2 && launch_f16x_gemm<MODE == MODE_FWD ? 0 : 1>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, region, hdr, st)) return true;
   }
   if (mode == GEMM_F16X2 && launch_f16r_gemm<MODE, T, TO>(A0, A1, bnA, Bm, out, E0, bnE, part, M, K, Nout, region, hdr, st)) return true;
@@ -543,6 +544,8 @@ using namespace ttk;
 extern "C" {
 
 int ttk_partial_rows_pwconv(int64_t M, int K, int Nout, int dgrad) {
+  const int yrows = f16y_partial_rows(M, K, Nout, dgrad);
+  if (yrows) return yrows;
   const int x = f16x_partial_rows(M, K, Nout, dgrad);
   if (x) return x;
   const int r = f16r_partial_rows(M, K, Nout, dgrad);
@@ -688,8 +691,8 @@ int ttk_pwconv_prepare_weights(int n, const float* const* w, const int* cin, con
     tiles += (cin[i] / 32) * (cout[i] / 32);
     // 0: fp32 rows; 1: piece planes [K/32][rows][32]; 2: the row-block kernels' planes [K/16][rows][16] (pwconv_r.hip); 3: the full-width kernels'
     // fragment-ordered image (pwconv_x.hip)
-    a.split_fwd[i] = a.mode == GEMM_F16X2 ? (f16x_gemm_shape(cin[i], cout[i], 0) ? 3 : f16r_gemm_shape(cin[i], cout[i], 0) ? 2 : f16_gemm_shape(cin[i], cout[i])) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cin[i], cout[i]));
-    a.split_bwd[i] = a.mode == GEMM_F16X2 ? (f16x_gemm_shape(cout[i], cin[i], 1) ? 3 : f16r_gemm_shape(cout[i], cin[i], 1) ? 2 : f16_gemm_shape(cout[i], cin[i])) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cout[i], cin[i]));
+    a.split_fwd[i] = a.mode == GEMM_F16X2 ? ((f16y_gemm_shape(cin[i], cout[i], 0) || f16x_gemm_shape(cin[i], cout[i], 0)) ? 3 : f16r_gemm_shape(cin[i], cout[i], 0) ? 2 : f16_gemm_shape(cin[i], cout[i])) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cin[i], cout[i]));
+    a.split_bwd[i] = a.mode == GEMM_F16X2 ? ((f16y_gemm_shape(cout[i], cin[i], 1) || f16x_gemm_shape(cout[i], cin[i], 1)) ? 3 : f16r_gemm_shape(cout[i], cin[i], 1) ? 2 : f16_gemm_shape(cout[i], cin[i])) : (a.mode == GEMM_BF16X3 && split_gemm_shape(cout[i], cin[i]));
   }
   a.first_tile[n] = tiles;
   hipStream_t st = (hipStream_t)stream;

@@ -45,7 +45,10 @@ SHAPES = [(648, 512, 512), (1000, 128, 256), (4100, 256, 256), (300, 1024, 1024)
           (648, 64, 128), (1234, 32, 64), (5000, 128, 128), (128, 512, 1024),
           # row-block kernels (csrc/pwconv_r.hip) at tile heights their cost model picks by itself: 162 of 192 rows (two column tiles:
           # one full round of 256 CUs), 200 of 256 rows, 193-row blocks with a ragged last one
-          (20736, 512, 512), (12800, 256, 1024), (49601, 128, 256)]
+          (20736, 512, 512), (12800, 256, 1024), (49601, 128, 256),
+          # the streaming kernel of the narrow layers (csrc/pwconv_y.hip: 32 -> 64, 64 -> 128, 128 -> 128 forward; data gradient of 128 -> 256): more pixel
+          # groups than resident waves, a ragged last group, fewer groups than waves
+          (140001, 32, 64), (99990, 64, 128), (70001, 128, 128), (33, 64, 128), (41111, 128, 256)]
 
 
 # LOOSE: how far the operand bounds of row TTK_BN_AUX lie above the true maxima (the step's own bounds are 1-100x loose)
