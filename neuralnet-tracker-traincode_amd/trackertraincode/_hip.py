@@ -202,7 +202,9 @@ class _Library:
         return stale
 
     def call(self, name: str, *args):
-        rc = self._fns[name](*args, torch.cuda.current_stream().cuda_stream)
+        # (the raw handle of torch's current stream on the current device: two C calls.  `torch.cuda.current_stream().cuda_stream` builds a Stream
+        # object and resolves the device index in Python - 10 us per launch, 1.5 ms of the ~160 launches of a step until round 5)
+        rc = self._fns[name](*args, _raw_stream(_cur_device()))
         if rc != 0:
             msg = self.cdll.ttk_last_error_string().decode(errors="replace")
             hint = "" if rc < 0 else " (a positive code is a hipError_t read from the sticky hipGetLastError(): an earlier launch of this step may have left it)"
@@ -307,6 +309,10 @@ import threading
 CAPTURE_LOCK = threading.RLock()
 
 _lib: _Library | None = None
+
+
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_cur_device = torch._C._cuda_getDevice
 
 
 def lib() -> _Library:
