@@ -235,7 +235,7 @@ def build_step(args, device):
             setattr(ns, k, v)
         return ns
 
-    torch.manual_seed(0)
+    torch.manual_seed(getattr(args, "seed", 0))  # (tools/soak.py --seed: the weight initialisation of its legs)
     net = NetworkWithPointHead(enable_point_head=True, enable_uncertainty=False, config=args.backbone,
                                backbone_args={"use_blurpool": args.blurpool})
     g = torch.Generator().manual_seed(7)  # synthetic 3DMM keypoint basis (the real blob is not in the reference)

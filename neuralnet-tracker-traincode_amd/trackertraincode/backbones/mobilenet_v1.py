@@ -269,11 +269,15 @@ def _forward_impl(x, params, buffers, momentum, eps, training, frozen=False, blu
                    stride, bf)
             dw_rows = L.partial_rows_dwconv(B, h, w_, cin, stride, False)
             ctx.blur.append(None)
+        if _EXP_TENSOR_HOOK is not None:
+            _EXP_TENSOR_HOOK("y", k, ydw)
         bn_dw = bns.take(cin)
         finalize(bn_dw, dw_rows, cin, B * ho * wo, g_dw, b_dw, bi)
         ypw = torch.empty((B, ho, wo, cout), dtype=act_dtype, device=dev)
         M = B * ho * wo
         L.call("ttk_pwconv1x1_fwd", p(ydw), p(bn_dw), None, p(ypw), part_arg, pivot(bi + 1), M, cin, cout, p(ctx.prep[len(ctx.dims)]), bf)
+        if _EXP_TENSOR_HOOK is not None:
+            _EXP_TENSOR_HOOK("y", k, ypw)
         bn_pw = bns.take(cout)
         finalize(bn_pw, L.partial_rows_gemm(M, cin, cout), cout, M, g_pw, b_pw, bi + 1)
         bi += 2
@@ -317,6 +321,12 @@ def _side_stream(device):
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]
+
+
+# Experiment hook of tools/soak.py (None in the product): called as _EXP_TENSOR_HOOK(kind, block, tensor) right after a kernel has produced
+# a gradient ("g": with respect to a conv output before its BatchNorm) or an activation ("y": a raw conv output) of the fp32 path, e.g. to round it
+# to the bf16 grid in place - how much of the bf16-compute path's soak gap each tensor class explains (profiles/r06_soak_rounding_ab.txt).
+_EXP_TENSOR_HOOK = None
 
 
 def _backward_impl(ctx: _Ctx, gfeat, params):
@@ -374,6 +384,8 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
     g = torch.empty(last.y.shape, dtype=ctx.gdt, device=last.y.device)
     L.call("ttk_avgpool_bwd", p(gfeat), p(last.y), p(last.bn), p(last.skip), p(g), p(part), B, ctx.HW, C, bf)
     bwd_finalize(last, L.partial_rows_elementwise(B * ctx.HW * (C // 4)), B * ctx.HW, len(params) - 2)
+    if _EXP_TENSOR_HOOK is not None:
+        _EXP_TENSOR_HOOK("g", len(_BLOCKS), g)
 
     for k in range(len(_BLOCKS) - 1, -1, -1):
         h, w_, ho, wo, cin, cout, stride, has_skip = ctx.dims[k]
@@ -394,6 +406,8 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
             L.call("ttk_pwconv1x1_bwd_fused", p(g), p(st_pw.y), p(st_pw.bn), p(w_pw), p(ctx.prep[k]), p(st_dw.y), p(st_dw.bn), p(g_dw), p(dW),
                    p(wg_scratch), p(part), M, cin, cout)
             bwd_finalize(st_dw, fused_rows, M, pi + 1)
+            if _EXP_TENSOR_HOOK is not None:
+                _EXP_TENSOR_HOOK("g", k, g_dw)
         elif side is not None:
             ev = torch.cuda.Event()
             ev.record(main)  # g, bn_pw backward constants and the zeroed dW are ready
@@ -412,6 +426,8 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
             L.call("ttk_pwconv1x1_bwd_data", p(g), p(st_pw.y), p(st_pw.bn), None, p(st_dw.y), p(st_dw.bn), p(g_dw), p(part), M,
                    cin, cout, p(ctx.prep[k]), bf)
             bwd_finalize(st_dw, L.partial_rows_gemm(M, cout, cin, True), M, pi + 1)
+            if _EXP_TENSOR_HOOK is not None:
+                _EXP_TENSOR_HOOK("g", k, g_dw)
         # -- depthwise: weight gradient, then data gradient (+ residual gradient, + producer's bn sums)
         dWd = grads[pi]  # accumulated by the fused weight-gradient path of bwd_data
         g_prev = torch.empty(st_prev.y.shape, dtype=ctx.gdt, device=st_prev.y.device)
@@ -440,6 +456,8 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
                    p(dw_rows if (_DW_WGRAD_ROWS == 1 and not ctx.frozen) else wg_scratch), B, h, w_, cin, stride, bf)  # (_DW_WGRAD_ROWS = 1: the A/B form, rows + own fold)
             bwd_finalize(st_prev, L.partial_rows_dwconv(B, h, w_, cin, stride, True), B * h * w_, pi - 2 if k > 0 else 1)
         g = g_prev
+        if _EXP_TENSOR_HOOK is not None:
+            _EXP_TENSOR_HOOK("g", k, g)
         if grad_ready_hook is not None:  # this block's conv + bn_dw gradients and its own bn_sep gradients are final
             if side is not None:
                 main.wait_event(done)

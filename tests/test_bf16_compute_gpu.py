@@ -89,8 +89,13 @@ def test_step_tracks_the_fp32_step(cfg, B):
     print(f"bf16-compute vs fp32 (cfg={cfg}, B={B}): " + ", ".join(f"{k} {v:.2e}" for k, v in stats.items()))
     print("   min gradient cosine per block: " + ", ".join(f"{k} {v:.3f}" for k, v in cos_by_block.items()))
     assert stats["loss"] < 1e-2 and stats["feat"] < 0.1 and stats["running"] < 5e-2, stats
-    assert stats["grad_norm"] < 0.3, stats
-    assert cos_by_block["heads"] > 0.98 and min(cos_by_block.values()) > 0.4, cos_by_block
+    # observed (round 6, gpurun_out cos run): grad_norm 1.1e-2 / 1.1e-3; min cosine per block 0.68 (dw2_1) .. 0.96 (dw6), heads 1.000.  The noise is that of
+    # 8-bit-mantissa storage of the raw conv outputs of the first blocks (profiles/r06_soak_rounding_ab.txt: rounding the GRADIENTS of the fp32 path to the
+    # bf16 grid changes nothing, rounding its early ACTIVATIONS reproduces the whole soak gap); floors = observed minus a margin
+    assert stats["grad_norm"] < 0.05, stats
+    assert cos_by_block["heads"] > 0.999 and min(cos_by_block.values()) > 0.6, cos_by_block
+    late = [v for k, v in cos_by_block.items() if k in ("dw5_6", "dw6")]
+    assert min(late) > 0.85, cos_by_block
 
 
 def test_aflw2kmini_rotation_mae_within_005_degrees():
