@@ -49,7 +49,7 @@ extern "C" {
 
 typedef void* ttk_stream_t; /* hipStream_t */
 
-#define TTK_ABI_VERSION 27
+#define TTK_ABI_VERSION 28
 
 /* rows of a layer's BatchNorm constant block  float bn[TTK_BN_ROWS][C] */
 enum {

@@ -108,7 +108,7 @@ _SIGNATURES = {
     "ttk_bc_bn_bwd_finalize_fold": [_P, _I, _I, _L, _P, _P, _P, _P, _I, _P, _I, _L, _P, _I],
 }
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 
 # Whether the backbones hand the running mean to the forward producers as the statistics pivot (include/ttk.h).  Always on in the
