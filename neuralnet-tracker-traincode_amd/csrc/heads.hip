@@ -39,57 +39,37 @@ __global__ void __launch_bounds__(kBlock) heads_fwd_k(HeadsArgs a, float* __rest
                                                        float* __restrict__ qu, float* __restrict__ Lc,
                                                        float* __restrict__ Lr, float* __restrict__ pts,
                                                        float* __restrict__ shp) {
-  // FOUR samples per workgroup (round 6; one until round 5: 512 workgroups each pulled the whole stacked weight matrix - 330 KB - through its
-  // CU, 169 MB of L2 reads for a 28.8 us launch): the samples' feature rows sit in LDS, the four waves share the rows of the stacked linear
-  // layer and form every row's dot product with all four samples from ONE pass over the weights (the per-sample arithmetic and its order are
-  // unchanged: same bits); then wave w finishes sample w.
-  constexpr int SPW = 4;
-  extern __shared__ __attribute__((aligned(16))) float hsm[];  // [SPW][F] features + [SPW][kMaxZ] z
-  float* fs = hsm;
-  float* zall = hsm + SPW * a.F;
+  // One workgroup per sample: its four waves share the rows of the stacked linear layer (the kernel is a chain of
+  // load latencies - a wave per sample left half the CUs idle and took 56 us at B = 512), then wave 0 finishes the sample.
+  __shared__ float zs1[kMaxZ];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int s0 = blockIdx.x * SPW, ns = min(SPW, a.B - s0);
-  for (int i = threadIdx.x * 4; i < SPW * a.F; i += kBlock * 4) {
-    const int u = i / a.F;
-    st4(fs + i, u < ns ? ld4(a.feat + (size_t)s0 * a.F + i) : f4(0.f));
-  }
-  __syncthreads();
+  const int s = blockIdx.x;
+  const float* f = a.feat + (size_t)s * a.F;
   // four rows at a time: their weight loads are independent, so a wave has 4x the loads in flight of a row-by-row loop
   for (int j0 = 4 * wv; j0 < a.NZ; j0 += 4 * (kBlock / kWave)) {
-    float acc[4][SPW];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int x = 0; x < SPW; ++x) acc[u][x] = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int k = lane * 4; k < a.F; k += 256) {
-      float4 wv4[4];
+      const float4 fv = ld4(f + k);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) wv4[u] = ld4(a.wcat + (size_t)min(j0 + u, a.NZ - 1) * a.F + k);
-#pragma unroll
-      for (int x = 0; x < SPW; ++x) {
-        const float4 fv = ld4(fs + x * a.F + k);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u][x] = fmaf(fv.x, wv4[u].x, fmaf(fv.y, wv4[u].y, fmaf(fv.z, wv4[u].z, fmaf(fv.w, wv4[u].w, acc[u][x]))));
+      for (int u = 0; u < 4; ++u) {
+        const int j = min(j0 + u, a.NZ - 1);
+        const float4 wv4 = ld4(a.wcat + (size_t)j * a.F + k);
+        acc[u] = fmaf(fv.x, wv4.x, fmaf(fv.y, wv4.y, fmaf(fv.z, wv4.z, fmaf(fv.w, wv4.w, acc[u]))));
       }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+      const float v = wave_sum(acc[u]);
       const int j = j0 + u;
-#pragma unroll
-      for (int x = 0; x < SPW; ++x) {
-        const float v = wave_sum(acc[u][x]);
-        if (lane == 0 && j < a.NZ && x < ns) {
-          const float zz = v + a.bcat[j];
-          zall[x * kMaxZ + j] = zz;
-          z[(size_t)(s0 + x) * a.NZ + j] = zz;
-        }
+      if (lane == 0 && j < a.NZ) {
+        const float zz = v + a.bcat[j];
+        zs1[j] = zz;
+        z[(size_t)s * a.NZ + j] = zz;
       }
     }
   }
   __syncthreads();
-  if (wv >= ns) return;
-  const int s = s0 + wv;
-  const float* zs1 = zall + wv * kMaxZ;
+  if (wv != 0) return;
   const float* zz = zs1;
   const int id = a.ids ? a.ids[s] : 0;
   const float* prow = a.P ? a.P + 4 * id : nullptr;
@@ -252,38 +232,26 @@ __global__ void __launch_bounds__(kBlock) heads_bwd_feat_k(const float* __restri
   st4(dfeat + (size_t)b * F + f, acc);
 }
 
-// dW[j][f] += sum_{b in chunk} dz[b][j]*feat[b][f];  db[j] += sum_b dz[b][j]   (chunks of 64 samples, atomics).  A thread owns FOUR rows j of one
-// feature quad (round 6; one row until round 5: every feature load fed one fma4 and the launch took 24.9 us): a feature load feeds four.
+// dW[j][f] += sum_{b in chunk} dz[b][j]*feat[b][f];  db[j] += sum_b dz[b][j]   (chunks of 64 samples, atomics)
 __global__ void __launch_bounds__(kBlock) heads_bwd_weight_k(const float* __restrict__ dz, const float* __restrict__ feat,
                                                               float* __restrict__ dw, float* __restrict__ db, int B, int F,
                                                               int NZ) {
   const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int fq = F >> 2, nj4 = (NZ + 3) >> 2;
-  if (idx >= (int64_t)nj4 * fq) return;
-  const int j0 = (int)(idx / fq) * 4, f = (int)(idx % fq) * 4;
+  const int fq = F >> 2;
+  if (idx >= (int64_t)NZ * fq) return;
+  const int j = (int)(idx / fq), f = (int)(idx % fq) * 4;
   const int chunk = gridDim.y == 1 ? B : 64;  // one chunk (deterministic mode): plain stores of the complete sums
   const int b0 = blockIdx.y * chunk, b1 = min(B, b0 + chunk);
-  float4 acc[4] = {f4(0.f), f4(0.f), f4(0.f), f4(0.f)};
-  float sb[4] = {0.f, 0.f, 0.f, 0.f};
-  int jr[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) jr[r] = min(j0 + r, NZ - 1);
+  float4 acc = f4(0.f);
+  float sb = 0.f;
   for (int b = b0; b < b1; ++b) {
-    const float4 fv = ld4(feat + (size_t)b * F + f);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float d = dz[(size_t)b * NZ + jr[r]];
-      acc[r] = fma4(f4(d), fv, acc[r]);
-      sb[r] += d;
-    }
+    const float d = dz[(size_t)b * NZ + j];
+    acc = fma4(f4(d), ld4(feat + (size_t)b * F + f), acc);
+    sb += d;
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    if (j0 + r >= NZ) break;
-    float* o = dw + (size_t)(j0 + r) * F + f;
-    atomicAdd(o, acc[r].x); atomicAdd(o + 1, acc[r].y); atomicAdd(o + 2, acc[r].z); atomicAdd(o + 3, acc[r].w);
-    if (f == 0) atomicAdd(db + j0 + r, sb[r]);
-  }
+  float* o = dw + (size_t)j * F + f;
+  atomicAdd(o, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
+  if (f == 0) atomicAdd(db + j, sb);
 }
 
 // dP[r][c] = sum_{b: id_b == r} dprow[b][c] (c<4), dPk likewise (c>=4).  One workgroup per output element
@@ -356,8 +324,7 @@ int ttk_heads_fwd(const float* feat, const float* wcat, const float* bcat, const
   TTK_REQUIRE(!enable_point_head || (pts && shp && keypts && keyeig), "heads_fwd: point-head buffers missing");
   TTK_REQUIRE(!use_offset || (P && (!enable_point_head || Pk)), "heads_fwd: local pose offset parameters missing");
   HeadsArgs a{feat, wcat, bcat, P, Pk, keypts, keyeig, ids, B, F, NZ, enable_uncertainty, enable_point_head, use_offset, enable_6drot};
-  TTK_REQUIRE(F <= 2048, "heads_fwd: at most 2048 features (four samples' rows are staged in LDS)");
-  hipLaunchKernelGGL(heads_fwd_k, dim3((B + 3) / 4), dim3(kBlock), (size_t)4 * (F + kMaxZ) * sizeof(float), (hipStream_t)stream, a, z, roi, coord, rot, qu, Lc, Lr,
+  hipLaunchKernelGGL(heads_fwd_k, dim3(B), dim3(kBlock), 0, (hipStream_t)stream, a, z, roi, coord, rot, qu, Lc, Lr,
                      pts, shp);
   TTK_LAUNCH_CHECK("heads_fwd");
 }
@@ -380,7 +347,7 @@ int ttk_heads_bwd(const float* feat, const float* wcat, const float* z, const in
                      NZ);
   // TTK_DETERMINISTIC=1: one chunk of samples per weight instead of B/64 chunks that add atomically (fixed summation order)
   const bool det = deterministic_mode();
-  hipLaunchKernelGGL(heads_bwd_weight_k, dim3((unsigned)ceil_div((int64_t)((NZ + 3) / 4) * (F / 4), kBlock), det ? 1u : (unsigned)ceil_div(B, 64)), dim3(kBlock), 0, st, dz,
+  hipLaunchKernelGGL(heads_bwd_weight_k, dim3((unsigned)ceil_div(nw, kBlock), det ? 1u : (unsigned)ceil_div(B, 64)), dim3(kBlock), 0, st, dz,
                      feat, dwcat, dbcat, B, F, NZ);
   if (use_offset && (dP || dPk)) hipLaunchKernelGGL(heads_bwd_offset_k, dim3(64), dim3(kBlock), 0, st, dprow, ids, dP, dPk, B);
   TTK_LAUNCH_CHECK("heads_bwd");

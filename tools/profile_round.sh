@@ -12,9 +12,9 @@ rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_mn -- python3 $R/bench.py --gpu
 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_256 -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --batch 256 > $R/$OUT/bench_B256_profiled.json 2>/dev/null
 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_rn -- python3 $R/bench.py --gpus 1 --steps 10 --warmup 3 --backbone resnet18 > $R/$OUT/bench_resnet18_B512_profiled.json 2>/dev/null
 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_bc -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --precision bf16-compute > $R/$OUT/bench_B512_bf16_compute_profiled.json 2>/dev/null
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_f -- python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_w -- python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d $R/$OUT/pmc_l2 -- python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_f -- python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timing --no-legs > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_w -- python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timing --no-legs > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d $R/$OUT/pmc_l2 -- python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timing --no-legs > /dev/null 2>&1
 BCARGS="--precision bf16-compute --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timing"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_bf -- python3 $R/bench.py $BCARGS > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_bw -- python3 $R/bench.py $BCARGS > /dev/null 2>&1
