@@ -44,7 +44,13 @@ SHAPES = [(4, 9, 9, 64, 1, True),     # 3 images per tile, ragged last tile
           (40, 65, 65, 32, 1, True),
           (40, 65, 65, 32, 2, False),
           (100, 33, 33, 64, 1, True),
-          (90, 33, 33, 64, 2, False)]
+          (90, 33, 33, 64, 2, False),
+          # round 6: the BACKWARD walks consecutive full-width bands too (stride 1, staged width <= 80: a ring of LDS rows keeps the dy rows
+          # two bands share) - the lean form (no residual operands) across image boundaries, and images too wide for it (column tiles stay)
+          (40, 65, 65, 32, 1, False),
+          (3, 30, 90, 32, 1, True),
+          (2, 20, 100, 64, 1, False),
+          (7, 78, 78, 32, 1, True)]    # staged width exactly 80
 
 
 @pytest.mark.parametrize("B,H,W,C,stride,skip", SHAPES)
