@@ -10,6 +10,15 @@ from util import build_net, load_golden, make_batches, script_args, train_script
 import trackertraincode.train as train
 import trackertraincode.backbones.mobilenet_v1 as MB
 
+if os.environ.get("POISON"):  # every torch.empty / empty_like of a floating dtype comes back filled with NaN: a kernel that leaves elements of its output
+    _e, _el = torch.empty, torch.empty_like  # unwritten shows up as NaN downstream (single process, deterministic)
+    def _pe(*a, **k):
+        t = _e(*a, **k)
+        return t.fill_(float("nan")) if t.is_floating_point() and t.is_cuda else t
+    def _pel(*a, **k):
+        t = _el(*a, **k)
+        return t.fill_(float("nan")) if t.is_floating_point() and t.is_cuda else t
+    torch.empty, torch.empty_like = _pe, _pel
 cfg = sys.argv[1] if len(sys.argv) > 1 else "default"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 300
@@ -59,6 +68,9 @@ for it in range(N):
     for k, p in net.named_parameters():
         if p.grad is not None: cs("grad:" + k, p.grad)
     cur = (list(names), torch.stack(sums).cpu())
+    if os.environ.get("POISON"):
+        nanl = [n for n, v in zip(cur[0], cur[1][:, 0].tolist()) if v != v]
+        print(f"iteration {it}: non-finite checksums: {nanl[:20]}", flush=True)
     if ref is None:
         ref = cur
         keep["ref"] = keep["pts"]
@@ -79,5 +91,7 @@ for it in range(N):
             print(f"   dump: {len(wd)} entries differ; lanes {sorted(set(wd[:, 1].tolist()))}; columns {cols} (0-2 local, 3-6 qk, 7-9 ck, 10-11 sh, 12 kp, 13 eig, 14-15 out)")
             for (ss, ll, cc) in wd[:6].tolist():
                 print(f"      sample {ss} lane {ll} col {cc}: {keep['dump'][ss, ll, cc].item():.7g} vs {keep['dref'][ss, ll, cc].item():.7g}")
+        other = [cur[0][i] for i in idx if not (cur[0][i].startswith("grad:convnet") or (cur[0][i][0] == "g" and cur[0][i][1:].isdigit()))]
+        print(f"   outside the backbone: {other[:12]}")
         print(f"iteration {it}: {len(idx)} checksums differ; first: " + "; ".join(f"{cur[0][i]} ({d[i]:.2e})" for i in idx[:6]), flush=True)
 print(f"{cfg} B={B}: {N} iterations, {bad} deviating (deterministic={os.environ.get('TTK_DETERMINISTIC', '0')})")
