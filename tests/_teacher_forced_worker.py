@@ -26,7 +26,7 @@ torch.set_num_threads(min(os.cpu_count() or 1, 32))
 from oracle import refmodel as R  # noqa: E402
 from oracle.synth import make_inputs, make_state  # noqa: E402
 from test_oracle_golden import _batches, _criterions  # noqa: E402
-from util import GOLDEN, build_net, load_golden, make_batches, script_args, train_script  # noqa: E402
+from util import GOLDEN, build_net, gpu_section, load_golden, make_batches, script_args, train_script  # noqa: E402
 import trackertraincode.train as train  # noqa: E402
 
 LR_EPOCHS, LR_EPOCH = 20, 5  # past the warm-up of ExponentialUpThenSteps: the full learning rate 1e-3
@@ -82,7 +82,9 @@ def f64_moments(snap):
 YARD_T = K - 1
 m64, v64 = f64_moments(snaps[YARD_T])
 
-# ---- HIP: one step from every snapshot
+# ---- HIP: one step from every snapshot (the workers' GPU parts take turns: util.gpu_section; released when the process ends)
+_turn = gpu_section()
+_turn.__enter__()
 net = build_net(meta, "cuda").train()
 crit, _ = S.setup_losses(script_args(meta["flags"]), net)
 opt, sch = S.create_optimizer(net, script_args(meta["flags"], epochs=LR_EPOCHS))

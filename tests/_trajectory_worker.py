@@ -26,7 +26,7 @@ torch.set_num_threads(min(os.cpu_count() or 1, 32))
 from oracle import refmodel as R  # noqa: E402
 from oracle.synth import make_inputs, make_state  # noqa: E402
 from test_oracle_golden import _batches, _criterions  # noqa: E402
-from util import GOLDEN, build_net, load_golden, make_batches, script_args, train_script  # noqa: E402
+from util import GOLDEN, build_net, gpu_section, load_golden, make_batches, script_args, train_script  # noqa: E402
 import trackertraincode.train as train  # noqa: E402
 
 # schedule position of both optimisers (ExponentialUpThenSteps over LR_EPOCHS epochs, at epoch LR_EPOCH): (200, 0) = the first epoch
@@ -37,30 +37,31 @@ meta = dict(meta, B=B, split=(B * 5) // 8)
 S = train_script()
 
 # ---- HIP trajectory
-net = build_net(meta, "cuda").train()
-crit, _ = S.setup_losses(script_args(meta["flags"]), net)
-opt, sch = S.create_optimizer(net, script_args(meta["flags"], epochs=LR_EPOCHS))
-import warnings  # noqa: E402
+with gpu_section():
+    net = build_net(meta, "cuda").train()
+    crit, _ = S.setup_losses(script_args(meta["flags"]), net)
+    opt, sch = S.create_optimizer(net, script_args(meta["flags"], epochs=LR_EPOCHS))
+    import warnings  # noqa: E402
 
-with warnings.catch_warnings():
-    warnings.simplefilter("ignore")
-    for _ in range(LR_EPOCH):
-        sch.step()
-assert abs(opt.param_groups[0]["lr"] - LR0) < 1e-12 * max(1.0, LR0), (opt.param_groups[0]["lr"], LR0)
-batches = make_batches(meta, "cuda")
-hip_loss, hip_vals, hip_norm = [], [], []
-for it in range(K):
-    opt.zero_grad(set_to_none=True)
-    out = train.training_step(net, batches, epoch, crit)
-    out["loss"].backward()
-    opt.step()
-    hip_loss.append(out["loss"].item())
-    hip_vals.append({k: v.detach().cpu().double() for k, v in out["mt_losses"].items()})
-    hip_norm.append(float(opt.last_grad_norm.item()))
-torch.cuda.synchronize()
-hip_state = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
-del net, opt, out
-torch.cuda.empty_cache()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(LR_EPOCH):
+            sch.step()
+    assert abs(opt.param_groups[0]["lr"] - LR0) < 1e-12 * max(1.0, LR0), (opt.param_groups[0]["lr"], LR0)
+    batches = make_batches(meta, "cuda")
+    hip_loss, hip_vals, hip_norm = [], [], []
+    for it in range(K):
+        opt.zero_grad(set_to_none=True)
+        out = train.training_step(net, batches, epoch, crit)
+        out["loss"].backward()
+        opt.step()
+        hip_loss.append(out["loss"].item())
+        hip_vals.append({k: v.detach().cpu().double() for k, v in out["mt_losses"].items()})
+        hip_norm.append(float(opt.last_grad_norm.item()))
+    torch.cuda.synchronize()
+    hip_state = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
+    del net, opt, out
+    torch.cuda.empty_cache()
 
 # ---- oracle trajectories (CPU): fp32 = the reference's arithmetic; fp64 (optional) = the yardstick for how far two fp32 walks may part
 shapes = {k: tuple(v) for k, v in meta["shapes"].items()}

@@ -12,6 +12,28 @@ PKG = os.path.join(REPO, "neuralnet-tracker-traincode_amd")
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
 
+class gpu_section:
+    """with gpu_section(): the GPU part of a WORKER process (tests/_trajectory_worker.py, _teacher_forced_worker.py).  The workers of a session run side by
+    side for their long CPU-oracle parts; their short HIP parts take turns (an advisory file lock), so that at most one worker shares the GPU with the
+    session's own tests.  (Several processes time-slicing the GPU is where round 6 found sporadic wrong results in two tiny kernels -
+    profiles/r06_packed_fma_under_time_slicing.txt - and it slows every one of them 20-60 x.)"""
+
+    def __enter__(self):
+        import fcntl
+        import tempfile
+        self._f = open(os.path.join(tempfile.gettempdir(), "ttk_gpu_worker.lock"), "w")
+        fcntl.flock(self._f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        fcntl.flock(self._f, fcntl.LOCK_UN)
+        self._f.close()
+        return False
+
+
 def load_golden(name):
     d = np.load(os.path.join(GOLDEN, name))
     return d, json.loads(str(d["meta"]))
