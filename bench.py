@@ -79,7 +79,7 @@ class KernelTimer:
     """HIP-event timing of the C-ABI calls on the stream they are launched on (torch's current stream),
     with the algorithmic flops/bytes of each call."""
 
-    act_bytes = 4  # bytes per activation element in HBM (2 with --precision bf16)
+    act_bytes = 4  # bytes per activation element in HBM (2 on the bf16-compute path)
 
     def __init__(self):
         self.records = []  # (name, start, end, flops, bytes)

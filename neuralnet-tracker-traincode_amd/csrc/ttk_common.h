@@ -158,10 +158,9 @@ __device__ __forceinline__ float4 sub4(float4 a, float4 b) {
 }
 
 // ---- storage type of the activation tensors that cross HBM ------------------------------------------------------
-// float (the reference's precision, the default) or bf16 (`--precision bf16`, BASELINE config 5): raw conv outputs and
-// their gradients are then rounded to nearest-even bf16 on their way out and widened on load; BatchNorm statistics are
-// taken from the ROUNDED values (the consumer normalises exactly what is stored), all arithmetic, LDS tiles, weights,
-// statistics and weight gradients stay fp32.  Offsets are in elements either way.
+// float (the reference's precision) for the fp32 kernel family; Act<bf16_t> (values rounded to nearest-even bf16 on their way out,
+// widened on load) is what remains of rounds 2-5's bf16 STORAGE variant: only the stem of the bf16-compute path instantiates it
+// (TTK_ACT_DISPATCH_STEM below).  Offsets are in elements either way.
 typedef uint16_t bf16_t;  // storage only
 typedef __bf16 ttk_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float ttk_f32x2 __attribute__((ext_vector_type(2)));
