@@ -303,7 +303,9 @@ grad_ready_hook = None
 # Experiment hooks (module attributes that tools/exp scripts flip; the product never reads the environment for them):
 # _USE_WGRAD_STREAM puts the weight-gradient GEMMs on a second stream beside the data-gradient chain.  It was worth 0.3-0.4 ms/step while
 # the kernels left the GPU half empty at their tails; with today's kernels the serial order is 0.3 % faster (same box, alternating runs:
-# 9.94 vs 9.98 ms).  _FUSED_PW_BWD = False selects the two-kernel backward of the first pointwise layers.
+# 9.94 vs 9.98 ms; round 6, the wide layers only, the fused early layers kept: 69.1-69.6 k against 69.7-70.3 k crops/s, tools/exp/ab_wgrad_stream.py -
+# the finalisation gaps it could fill are smaller than what two kernels that each want every CU cost one another).  _FUSED_PW_BWD = False selects the
+# two-kernel backward of the first pointwise layers.
 _USE_WGRAD_STREAM = False
 # TTK_DETERMINISTIC=1: every weight-gradient reduction runs in a fixed order (slices of M stored to scratch and folded
 # by a second kernel instead of fp32 atomics): two runs of a step give bitwise equal gradients.
@@ -399,7 +401,7 @@ def _backward_impl(ctx: _Ctx, gfeat, params):
         # tail (too few tiles left for 256 CUs) and the HBM-bound depthwise kernels fill each other's gaps.
         dW = grads[pi + 3]
         g_dw = torch.empty(st_dw.y.shape, dtype=ctx.gdt, device=st_dw.y.device)
-        fused_rows = L.cdll.ttk_pwconv1x1_bwd_fused_rows(M, cin, cout) if (_FUSED_PW_BWD and bf == 0 and side is None) else 0
+        fused_rows = L.cdll.ttk_pwconv1x1_bwd_fused_rows(M, cin, cout) if (_FUSED_PW_BWD and bf == 0) else 0  # (one kernel for both gradients: main stream, with or without the side stream)
         if fused_rows:
             # the first three pointwise layers (HBM-bound, the largest activations): weight and data gradient in ONE kernel - g,
             # the conv output and the depthwise output are read once instead of twice (csrc/pw_bwd_fused.hip)
