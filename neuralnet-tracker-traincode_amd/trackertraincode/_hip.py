@@ -5,6 +5,8 @@ raises; an entry point that returns non-zero raises RuntimeError(ttk_last_error_
 """
 from __future__ import annotations
 
+import functools
+
 import ctypes
 import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
@@ -245,6 +247,7 @@ class _Library:
         """Scratch bytes of the deterministic (fixed-order) weight-gradient reduction; 0 = this shape has none."""
         return self.cdll.ttk_pwconv_wgrad_partial_bytes(m, cin, cout)
 
+    @functools.lru_cache(maxsize=None)
     def pwconv_wgrad_scratch_bytes(self, m: int, cin: int, cout: int) -> int:
         """Scratch bytes ttk_pwconv1x1_bwd_weight wants as `partial` in the DEFAULT mode (0: the shape runs its atomic form)."""
         return self.cdll.ttk_pwconv_wgrad_scratch_bytes(m, cin, cout)
@@ -287,12 +290,16 @@ class _Library:
             self.call("ttk_multi_copy", n, (c_void_p * n)(*[ptr(a) for a in s]), (c_void_p * n)(*[ptr(b) for b in d]),
                       (c_int64 * n)(*[b.numel() for b in d]))
 
+    # (pure functions of their integer arguments, asked ~80 times per step: cached)
+    @functools.lru_cache(maxsize=None)
     def partial_rows_elementwise(self, items: int) -> int:
         return self.cdll.ttk_partial_rows_elementwise(items)
 
+    @functools.lru_cache(maxsize=None)
     def partial_rows_dwconv(self, B, H, W, C, stride, backward) -> int:
         return self.cdll.ttk_partial_rows_dwconv(B, H, W, C, stride, int(backward))
 
+    @functools.lru_cache(maxsize=None)
     def partial_rows_gemm(self, m: int, k: int | None = None, nout: int | None = None, dgrad: bool = False) -> int:
         """Rows of BatchNorm partial sums a GEMM epilogue writes for m rows.  With (k, nout): of ttk_pwconv1x1_fwd (k = Cin, nout = Cout) /
         ttk_pwconv1x1_bwd_data (k = Cout, nout = Cin, dgrad=True), whose tiling depends on the shape; without: the 128-row form (convolutions)."""
@@ -333,6 +340,19 @@ def ptr(t: torch.Tensor | None):
     if not t.is_contiguous():
         raise RuntimeError("HIP entry point received a non-contiguous tensor")
     return t.data_ptr()
+
+
+def check_tensors(ts, what="tensor"):
+    """The checks of ptr() for a list of tensors at once (the backbones validate their parameters and inputs ONCE per call and then
+    take the addresses of those and of the tensors they allocate themselves with fast_ptr)."""
+    for t in ts:
+        if t is not None and not (t.is_cuda and t.is_contiguous()):
+            raise RuntimeError(f"HIP entry point received a non-CUDA or non-contiguous {what}")
+
+
+def fast_ptr(t: torch.Tensor | None):
+    """Device pointer without ptr()'s checks: for tensors the caller allocated itself or has run through check_tensors."""
+    return None if t is None else t.data_ptr()
 
 
 CHANNEL_BLOCK = 32  # kCB of csrc/ttk_common.h

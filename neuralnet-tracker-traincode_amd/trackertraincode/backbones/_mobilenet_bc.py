@@ -48,12 +48,16 @@ def part_buffer(B, H, W, device, blocks, blur=False):
 def forward_impl(MB, x, params, buffers, momentum, eps, training, frozen=False, blur=None):
     """`MB`: the mobilenet_v1 module (block table, `_Stage`, `_Ctx`, `_BnArena`, `_identity_bn`)."""
     L = _hip.lib()
-    p = _hip.ptr
+    blocks = MB._BLOCKS
+    blur = list(blur) if blur is not None else [None] * len(blocks)
+    _hip.check_tensors([x], "input")  # (what came from outside is checked once; everything else below is allocated here)
+    _hip.check_tensors(params, "parameter")
+    _hip.check_tensors(buffers, "BatchNorm buffer")
+    _hip.check_tensors(blur, "blur kernel")
+    p = _hip.fast_ptr
     dev = x.device
     B, _, H, W = x.shape
     Ho, Wo = (H + 1) // 2, (W + 1) // 2
-    blocks = MB._BLOCKS
-    blur = list(blur) if blur is not None else [None] * len(blocks)
     part = part_buffer(B, H, W, dev, blocks, any(b is not None for b in blur))
     ctx = MB._Ctx()
     ctx.x, ctx.part, ctx.B = x, part, B
@@ -131,7 +135,9 @@ def forward_impl(MB, x, params, buffers, momentum, eps, training, frozen=False, 
 
 def backward_impl(MB, ctx, gfeat, params):
     L = _hip.lib()
-    p = _hip.ptr
+    _hip.check_tensors([gfeat], "gradient")
+    _hip.check_tensors(params, "parameter")
+    p = _hip.fast_ptr
     B, part = ctx.B, ctx.part
     blocks = MB._BLOCKS
     offs, total = [], 0

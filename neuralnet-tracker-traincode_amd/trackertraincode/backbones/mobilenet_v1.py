@@ -197,11 +197,15 @@ def _forward_impl(x, params, buffers, momentum, eps, training, frozen=False, blu
     num_batches_tracked) per BN in the same order; `blur`: per block, the BlurPool2D kernel as a depthwise weight
     [Cin,1,3,3] (use_blurpool, strided blocks) or None."""
     L = _hip.lib()
-    p = _hip.ptr
+    blur = list(blur) if blur is not None else [None] * len(_BLOCKS)
+    _hip.check_tensors([x], "input")  # what came from outside is checked once; everything else below is allocated here
+    _hip.check_tensors(params, "parameter")
+    _hip.check_tensors(buffers, "BatchNorm buffer")
+    _hip.check_tensors(blur, "blur kernel")
+    p = _hip.fast_ptr
     dev = x.device
     B, _, H, W = x.shape
     Ho, Wo = (H + 1) // 2, (W + 1) // 2
-    blur = list(blur) if blur is not None else [None] * len(_BLOCKS)
     part = _part_buffer(B, H, W, dev, any(b is not None for b in blur))
     ctx = _Ctx()
     ctx.x, ctx.part, ctx.B = x, part, B
@@ -333,7 +337,9 @@ _EXP_TENSOR_HOOK = None
 
 def _backward_impl(ctx: _Ctx, gfeat, params):
     L = _hip.lib()
-    p = _hip.ptr
+    _hip.check_tensors([gfeat], "gradient")
+    _hip.check_tensors(params, "parameter")
+    p = _hip.fast_ptr
     B, part, bf = ctx.B, ctx.part, ctx.bf
     # one zeroed arena for every parameter gradient (the weight-gradient kernels accumulate atomically): one fill launch
     offs, total = [], 0

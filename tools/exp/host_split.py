@@ -9,6 +9,8 @@ args = bench.parse()
 dev = torch.device("cuda", 0)
 net, crit, opt, batches, train = bench.build_step(args, dev)
 import trackertraincode.backbones.mobilenet_v1 as MB
+if os.environ.get("CHECKED_PTR"):  # A/B: every pointer through the checked _hip.ptr again (the path until round 6)
+    MB._hip.fast_ptr = MB._hip.ptr
 T = {}
 def wrap(obj, name, key):
     f = getattr(obj, name)
