@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocm-smi samples beside tools/exp/mfma_power.hip's loops -> gpurun_out/power/mfma_*.txt
-O=gpurun_out/power; mkdir -p $O
+O=gpurun_out/power; mkdir -p $O tools/exp/_build
+[ -x tools/exp/_build/mfma_power ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/exp/mfma_power.hip -o tools/exp/_build/mfma_power 2>/dev/null
 for cfg in "0 1" "1 1" "0 2" "1 2"; do
   set -- $cfg
   n=mfma_s$1_w$2
